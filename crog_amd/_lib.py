@@ -1,0 +1,154 @@
+"""Build and bind libcrog_hip.so (the gfx950 kernel library) through its C ABI.
+
+The prototypes are read from include/crog_hip.h itself, so the header is the single source of
+truth for the boundary: every declared symbol must exist in the .so (checked at load) and the
+ctypes argtypes are derived from the C declarations.
+
+There is deliberately no CPU fallback: if the library cannot be loaded, importing the compute
+path raises (tests that need no GPU only use `parse_header` / `load`).
+"""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(ROOT)
+CSRC = os.path.join(ROOT, "csrc")
+HEADER = os.path.join(REPO, "include", "crog_hip.h")
+LIB_PATH = os.path.join(ROOT, "libcrog_hip.so")
+BUILD_DIR = os.path.join(ROOT, "csrc", "build")
+SOURCES = ["api.hip", "gemm.hip", "norm.hip", "eltwise.hip", "head.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
+
+
+class GemmDesc(ctypes.Structure):
+    """Mirror of `crog_gemm_desc` (include/crog_hip.h)."""
+
+    _fields_ = [
+        ("dtype", ctypes.c_int), ("a_layout", ctypes.c_int), ("b_layout", ctypes.c_int),
+        ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p),
+        ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
+        ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("ldc", ctypes.c_int64),
+        ("batch", ctypes.c_int), ("batch_inner", ctypes.c_int),
+        ("sAo", ctypes.c_int64), ("sAi", ctypes.c_int64), ("sBo", ctypes.c_int64),
+        ("sBi", ctypes.c_int64), ("sCo", ctypes.c_int64), ("sCi", ctypes.c_int64),
+        ("splitk", ctypes.c_int),
+        ("convH", ctypes.c_int), ("convW", ctypes.c_int), ("convC", ctypes.c_int),
+        ("alpha", ctypes.c_float), ("bias", ctypes.c_void_p), ("act", ctypes.c_int),
+        ("R", ctypes.c_void_p), ("ldr", ctypes.c_int64), ("out_mode", ctypes.c_int),
+        ("col_stats", ctypes.c_void_p),
+    ]
+
+
+_CTYPE = {
+    "int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64,
+    "uint64_t": ctypes.c_uint64, "crog_stream_t": ctypes.c_void_p, "size_t": ctypes.c_size_t,
+}
+
+
+def parse_header(path: str = HEADER):
+    """Return {name: (restype, [argtypes], [argnames])} for every function declared in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"typedef struct crog_gemm_desc \{.*?\} crog_gemm_desc;", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(?:^|[;}\n])\s*(const char\s*\*|int)\s+(crog_\w+)\s*\(([^)]*)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+        argtypes, argnames = [], []
+        args = " ".join(args.split())
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                argnames.append(a.split()[-1].lstrip("*"))
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    ty = a.replace("const ", "").split()[0]
+                    argtypes.append(_CTYPE[ty])
+        protos[name] = (restype, argtypes, argnames)
+    return protos
+
+
+def _needs_rebuild(obj: str, deps):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(verbose: bool = False, force: bool = False) -> str:
+    """Compile every HIP source for gfx950 and link crog_amd/libcrog_hip.so (in-tree)."""
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    common = [os.path.join(CSRC, "common.h"), HEADER]
+    hipcc = os.environ.get("HIPCC", "hipcc")
+
+    def compile_one(src):
+        s = os.path.join(CSRC, src)
+        o = os.path.join(BUILD_DIR, src.replace(".hip", ".o"))
+        if force or _needs_rebuild(o, [s] + common):
+            cmd = [hipcc] + HIPCC_FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        return o
+
+    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _needs_rebuild(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen the library and bind every prototype of the header. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(crog_amd has no CPU fallback)")
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes, _) in parse_header().items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"libcrog_hip.so does not export {name} declared in crog_hip.h") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def source_digest() -> str:
+    h = hashlib.sha1()
+    for f in SOURCES + ["common.h"]:
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(HEADER, "rb").read())
+    return h.hexdigest()[:12]
+
+
+class CrogError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().crog_last_error().decode()
+        raise CrogError(f"{what}: rc={rc}: {msg}")

@@ -1,0 +1,96 @@
+// Shared device/host helpers for the crog_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/crog_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define CROG_WAVE 64
+
+// ---- error plumbing (host) ---------------------------------------------------------------
+void crog_set_error(const char* fmt, ...);
+#define CROG_CHECK_ARG(cond, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      crog_set_error(__VA_ARGS__);                \
+      return CROG_ERR_ARG;                        \
+    }                                             \
+  } while (0)
+#define CROG_LAUNCH_CHECK()                                             \
+  do {                                                                  \
+    hipError_t e__ = hipGetLastError();                                 \
+    if (e__ != hipSuccess) {                                            \
+      crog_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,     \
+                     hipGetErrorString(e__));                           \
+      return CROG_ERR_LAUNCH;                                           \
+    }                                                                   \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- element traits ----------------------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte vector
+  __device__ static inline float to_f(float v) { return v; }
+  __device__ static inline float from_f(float v) { return v; }
+};
+template <> struct Elem<bf16> {
+  static constexpr int VEC = 8;
+  __device__ static inline float to_f(bf16 v) { return (float)v; }
+  __device__ static inline bf16 from_f(float v) { return (bf16)v; }
+};
+
+// 16-byte vector of T
+template <typename T> struct alignas(16) Vec16 {
+  T v[16 / sizeof(T)];
+};
+
+template <typename T>
+__device__ inline Vec16<T> ldg16(const T* p) {
+  return *reinterpret_cast<const Vec16<T>*>(p);
+}
+template <typename T>
+__device__ inline void stg16(T* p, const Vec16<T>& v) {
+  *reinterpret_cast<Vec16<T>*>(p) = v;
+}
+template <typename T>
+__device__ inline Vec16<T> zero16() {
+  Vec16<T> z;
+#pragma unroll
+  for (int i = 0; i < (int)(16 / sizeof(T)); i++) z.v[i] = (T)0.f;
+  return z;
+}
+
+// ---- wave / block reductions ---------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Counter-based RNG for dropout: one 32-bit hash per (seed, offset); keep-mask reproducible
+// between forward and backward because both recompute it from the same (seed, index).
+__device__ inline uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+// returns true when the element is KEPT with probability (1-p); thr = p * 2^32
+__device__ inline bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thr) {
+  return hash_u32(seed, idx) >= thr;
+}

@@ -1,0 +1,634 @@
+// Streaming (HBM-bound) kernels: pooling, bilinear x2, embedding, broadcasts, dropout/activation
+// backward, layout staging for the stem, casts and the fused Adam step.  16-byte vectors everywhere.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+inline int stream_grid(long work_items) {
+  long g = (work_items + NT - 1) / NT;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#define GRID_STRIDE(i, total) for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (total); i += (long)gridDim.x * NT)
+
+// ---- AvgPool2d(2)  (clip.py:23,35,184; layers.py:386) -------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT) avgpool2_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int B, int H,
+                                                          int W, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int OH = H / 2, OW = W / 2, cvec = C / VEC;
+  const long total = (long)B * OH * OW * cvec;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % cvec) * VEC;
+    long p = i / cvec;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const long b = p / OH;
+    const long base = ((b * H + 2 * oy) * W + 2 * ox);
+    Vec16<T> a = ldg16(x + base * ldx + c), bb = ldg16(x + (base + 1) * ldx + c);
+    Vec16<T> cc = ldg16(x + (base + W) * ldx + c), d = ldg16(x + (base + W + 1) * ldx + c);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; e++)
+      o.v[e] = Elem<T>::from_f(0.25f * (Elem<T>::to_f(a.v[e]) + Elem<T>::to_f(bb.v[e]) + Elem<T>::to_f(cc.v[e]) + Elem<T>::to_f(d.v[e])));
+    stg16(y + ((b * OH + oy) * OW + ox) * ldy + c, o);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(NT) avgpool2_bwd_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx, int B, int H,
+                                                          int W, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int OH = H / 2, OW = W / 2, cvec = C / VEC;
+  const long total = (long)B * OH * OW * cvec;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % cvec) * VEC;
+    long p = i / cvec;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const long b = p / OH;
+    Vec16<T> g = ldg16(dy + ((b * OH + oy) * OW + ox) * lddy + c);
+#pragma unroll
+    for (int e = 0; e < VEC; e++) g.v[e] = Elem<T>::from_f(0.25f * Elem<T>::to_f(g.v[e]));
+    const long base = ((b * H + 2 * oy) * W + 2 * ox);
+    stg16(dx + base * lddx + c, g);
+    stg16(dx + (base + 1) * lddx + c, g);
+    stg16(dx + (base + W) * lddx + c, g);
+    stg16(dx + (base + W + 1) * lddx + c, g);
+  }
+}
+
+// ---- bilinear x2, align_corners=False (nn.Upsample / F.interpolate: layers.py:54,56,382,393) -----
+struct Lin2 { int i0, i1; float w0, w1; };
+__device__ inline Lin2 src_index_x2(int d, int n_in) {
+  float s = (d + 0.5f) * 0.5f - 0.5f;
+  if (s < 0.f) s = 0.f;
+  Lin2 r;
+  r.i0 = (int)s;
+  r.i1 = r.i0 + (r.i0 < n_in - 1 ? 1 : 0);
+  r.w1 = s - r.i0;
+  r.w0 = 1.f - r.w1;
+  return r;
+}
+template <typename T>
+__global__ void __launch_bounds__(NT) upsample2_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int B, int H,
+                                                           int W, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int OH = 2 * H, OW = 2 * W, cvec = C / VEC;
+  const long total = (long)B * OH * OW * cvec;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % cvec) * VEC;
+    long p = i / cvec;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const long b = p / OH;
+    const Lin2 ly = src_index_x2(oy, H), lx = src_index_x2(ox, W);
+    const T* xb = x + (b * H * W) * ldx + c;
+    Vec16<T> v00 = ldg16(xb + ((long)ly.i0 * W + lx.i0) * ldx), v01 = ldg16(xb + ((long)ly.i0 * W + lx.i1) * ldx);
+    Vec16<T> v10 = ldg16(xb + ((long)ly.i1 * W + lx.i0) * ldx), v11 = ldg16(xb + ((long)ly.i1 * W + lx.i1) * ldx);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      const float top = lx.w0 * Elem<T>::to_f(v00.v[e]) + lx.w1 * Elem<T>::to_f(v01.v[e]);
+      const float bot = lx.w0 * Elem<T>::to_f(v10.v[e]) + lx.w1 * Elem<T>::to_f(v11.v[e]);
+      o.v[e] = Elem<T>::from_f(ly.w0 * top + ly.w1 * bot);
+    }
+    stg16(y + ((b * OH + oy) * OW + ox) * ldy + c, o);
+  }
+}
+// gather form of the transpose: input pixel i receives from outputs d in [2i-2, 2i+3]
+template <typename T>
+__global__ void __launch_bounds__(NT) upsample2_bwd_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx, int B, int H,
+                                                           int W, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int OH = 2 * H, OW = 2 * W, cvec = C / VEC;
+  const long total = (long)B * H * W * cvec;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % cvec) * VEC;
+    long p = i / cvec;
+    const int ix = (int)(p % W);
+    p /= W;
+    const int iy = (int)(p % H);
+    const long b = p / H;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) acc[e] = 0.f;
+    for (int oy = max(0, 2 * iy - 2); oy <= min(OH - 1, 2 * iy + 3); oy++) {
+      const Lin2 ly = src_index_x2(oy, H);
+      const float wy = (ly.i0 == iy ? ly.w0 : 0.f) + (ly.i1 == iy ? ly.w1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = max(0, 2 * ix - 2); ox <= min(OW - 1, 2 * ix + 3); ox++) {
+        const Lin2 lx = src_index_x2(ox, W);
+        const float wx = (lx.i0 == ix ? lx.w0 : 0.f) + (lx.i1 == ix ? lx.w1 : 0.f);
+        if (wx == 0.f) continue;
+        Vec16<T> g = ldg16(dy + ((b * OH + oy) * OW + ox) * lddy + c);
+        const float w = wy * wx;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) acc[e] += w * Elem<T>::to_f(g.v[e]);
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(acc[e]);
+    stg16(dx + ((b * H + iy) * W + ix) * lddx + c, o);
+  }
+}
+
+// ---- token embedding + learned positions (clip.py:440-443) ----------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT) embedding_fwd_kernel(const int64_t* __restrict__ word, const T* __restrict__ tok, const T* __restrict__ pos,
+                                                           T* __restrict__ out, long rows, int L, int C, int vocab) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  GRID_STRIDE(i, rows * cvec) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    long id = word[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    Vec16<T> a = ldg16(tok + id * C + c), p = ldg16(pos + (r % L) * C + c), o;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(Elem<T>::to_f(a.v[e]) + Elem<T>::to_f(p.v[e]));
+    stg16(out + r * C + c, o);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(NT) embedding_bwd_kernel(const int64_t* __restrict__ word, const T* __restrict__ dout, float* __restrict__ dtok,
+                                                           float* __restrict__ dpos, long rows, int L, int C, int vocab) {
+  GRID_STRIDE(i, rows * C) {
+    const long r = i / C;
+    const int c = (int)(i % C);
+    long id = word[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float g = Elem<T>::to_f(dout[r * C + c]);
+    atomicAdd(dtok + id * C + c, g);
+    atomicAdd(dpos + (r % L) * C + c, g);
+  }
+}
+
+// ---- row gather / scatter (EOT token select, clip.py:451-452) ---------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT) gather_rows_kernel(const T* __restrict__ x, long ldx, const int64_t* __restrict__ idx, T* __restrict__ out,
+                                                         long ldo, long n, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  GRID_STRIDE(i, n * cvec) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    stg16(out + r * ldo + c, ldg16(x + idx[r] * ldx + c));
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(NT) scatter_rows_kernel(const T* __restrict__ dout, long lddo, const int64_t* __restrict__ idx, T* __restrict__ dx,
+                                                          long lddx, long n, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  GRID_STRIDE(i, n * cvec) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    stg16(dx + idx[r] * lddx + c, ldg16(dout + r * lddo + c));
+  }
+}
+
+// ---- z[b,p,:] = x[b,p,:] * s[b,:]   (f5 * state, layers.py:379) -------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT) mul_bcast_fwd_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ s, long lds_, T* __restrict__ z,
+                                                           long ldz, int B, int P, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  GRID_STRIDE(i, (long)B * P * cvec) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    const long b = r / P;
+    Vec16<T> a = ldg16(x + r * ldx + c), sv = ldg16(s + b * lds_ + c), o;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(Elem<T>::to_f(a.v[e]) * Elem<T>::to_f(sv.v[e]));
+    stg16(z + r * ldz + c, o);
+  }
+}
+// dx = dz * s ; ds[b,:] = sum_p dz * x    (one thread per (b, channel chunk))
+template <typename T>
+__global__ void __launch_bounds__(NT) mul_bcast_bwd_kernel(const T* __restrict__ dz, long lddz, const T* __restrict__ x, long ldx,
+                                                           const T* __restrict__ s, long lds_, T* __restrict__ dx, long lddx, T* __restrict__ ds,
+                                                           long ldds, int B, int P, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  GRID_STRIDE(i, (long)B * cvec) {
+    const long b = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    Vec16<T> sv = ldg16(s + b * lds_ + c);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) acc[e] = 0.f;
+    for (int p = 0; p < P; p++) {
+      const long r = b * P + p;
+      Vec16<T> g = ldg16(dz + r * lddz + c), xv = ldg16(x + r * ldx + c), o;
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        const float gf = Elem<T>::to_f(g.v[e]);
+        acc[e] += gf * Elem<T>::to_f(xv.v[e]);
+        o.v[e] = Elem<T>::from_f(gf * Elem<T>::to_f(sv.v[e]));
+      }
+      stg16(dx + r * lddx + c, o);
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(acc[e]);
+    stg16(ds + b * ldds + c, o);
+  }
+}
+
+// ---- out = a + b[row % brows]  (residual adds, positional broadcasts) ---------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT) add_rows_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, long brows,
+                                                      T* __restrict__ out, long ldo, long M, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  GRID_STRIDE(i, M * cvec) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    Vec16<T> x = ldg16(a + r * lda + c), y = ldg16(b + (r % brows) * ldb + c), o;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(Elem<T>::to_f(x.v[e]) + Elem<T>::to_f(y.v[e]));
+    stg16(out + r * ldo + c, o);
+  }
+}
+// out[r,:] (fp32) = sum_b x[b*R + r,:]
+template <typename T>
+__global__ void __launch_bounds__(NT) sum_over_batch_kernel(const T* __restrict__ x, long ldx, float* __restrict__ out, long ldo, int B, long R,
+                                                            int C, int accumulate) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  GRID_STRIDE(i, R * cvec) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) acc[e] = accumulate ? out[r * ldo + c + e] : 0.f;
+    for (int b = 0; b < B; b++) {
+      Vec16<T> v = ldg16(x + ((long)b * R + r) * ldx + c);
+#pragma unroll
+      for (int e = 0; e < VEC; e++) acc[e] += Elem<T>::to_f(v.v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; e++) out[r * ldo + c + e] = acc[e];
+  }
+}
+
+// ---- out = a + dropout(b)  /  db = dropout_bwd(dout)   (layers.py:326,334,338) ------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT) add_dropout_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, T* __restrict__ out,
+                                                         long ldo, long M, int C, float p, uint64_t seed) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  const uint32_t thr = (uint32_t)(p * 4294967296.0);
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  GRID_STRIDE(i, M * cvec) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    Vec16<T> y = ldg16(b + r * ldb + c), x, o;
+    if (a) x = ldg16(a + r * lda + c);
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      float f = Elem<T>::to_f(y.v[e]);
+      if (p > 0.f) f = dropout_keep(seed, (uint64_t)r * C + c + e, thr) ? f * sc : 0.f;
+      if (a) f += Elem<T>::to_f(x.v[e]);
+      o.v[e] = Elem<T>::from_f(f);
+    }
+    stg16(out + r * ldo + c, o);
+  }
+}
+
+// ---- activation backward ------------------------------------------------------------------------------
+// mode 0: dx = dy * (y > 0)            (ReLU, y = saved output)
+// mode 1: dx = dy * d/du quickgelu(u)  (QuickGELU, y = saved pre-activation u; clip.py:234-236)
+template <typename T>
+__global__ void __launch_bounds__(NT) act_bwd_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy, T* __restrict__ dx,
+                                                     long lddx, long M, int C, int mode) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  GRID_STRIDE(i, M * cvec) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    Vec16<T> g = ldg16(dy + r * lddy + c), yv = ldg16(y + r * ldy + c), o;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      const float gf = Elem<T>::to_f(g.v[e]), u = Elem<T>::to_f(yv.v[e]);
+      float d;
+      if (mode == 0) d = u > 0.f ? gf : 0.f;
+      else {
+        const float sg = 1.f / (1.f + __expf(-1.702f * u));
+        d = gf * sg * (1.f + 1.702f * u * (1.f - sg));
+      }
+      o.v[e] = Elem<T>::from_f(d);
+    }
+    stg16(dx + r * lddx + c, o);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(NT) quickgelu_fwd_kernel(const T* __restrict__ u, long ldu, T* __restrict__ out, long ldo, long M, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  GRID_STRIDE(i, M * cvec) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    Vec16<T> v = ldg16(u + r * ldu + c), o;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      const float f = Elem<T>::to_f(v.v[e]);
+      o.v[e] = Elem<T>::from_f(f / (1.f + __expf(-1.702f * f)));
+    }
+    stg16(out + r * ldo + c, o);
+  }
+}
+
+// ---- stem: 3x3 stride-2 pad-1 patches of an NCHW fp32 image -> [B*OH*OW][32] (27 used; clip.py:165-170) ----
+// column k = (ky*3 + kx)*3 + ci matches the channels-last (KRSC) weight row.
+template <typename T>
+__global__ void __launch_bounds__(NT) stem_im2col_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W) {
+  const int OH = H / 2, OW = W / 2;
+  const long total = (long)B * OH * OW;
+  GRID_STRIDE(i, total) {
+    const int ox = (int)(i % OW);
+    const int oy = (int)((i / OW) % OH);
+    const long b = i / ((long)OW * OH);
+    T row[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) row[k] = Elem<T>::from_f(0.f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+#pragma unroll
+          for (int ci = 0; ci < 3; ci++)
+            row[(ky * 3 + kx) * 3 + ci] = Elem<T>::from_f(img[((b * 3 + ci) * H + iy) * W + ix]);
+      }
+    T* dst = out + i * 32;
+#pragma unroll
+    for (int v = 0; v < 32 / Elem<T>::VEC; v++) {
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < Elem<T>::VEC; e++) o.v[e] = row[v * Elem<T>::VEC + e];
+      stg16(dst + v * Elem<T>::VEC, o);
+    }
+  }
+}
+
+// ---- dst[r][c] = c < cols_src ? src[r][c] : 0, c < cols_dst   (fp32 source; T or fp32 destination) ------
+template <typename TD>
+__global__ void __launch_bounds__(NT) cast_pad2d_kernel(const float* __restrict__ src, long lds_, int cols_src, TD* __restrict__ dst, long ldd,
+                                                        int cols_dst, long rows) {
+  GRID_STRIDE(i, rows * cols_dst) {
+    const long r = i / cols_dst;
+    const int c = (int)(i % cols_dst);
+    const float v = c < cols_src ? src[r * lds_ + c] : 0.f;
+    dst[r * ldd + c] = Elem<TD>::from_f(v);
+  }
+}
+
+// ---- flat casts ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT) cast_f32_to_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long n) {
+  const long nv = n / 8;
+  GRID_STRIDE(i, nv) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + i * 8), b = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+    Vec16<bf16> o;
+    o.v[0] = (bf16)a[0]; o.v[1] = (bf16)a[1]; o.v[2] = (bf16)a[2]; o.v[3] = (bf16)a[3];
+    o.v[4] = (bf16)b[0]; o.v[5] = (bf16)b[1]; o.v[6] = (bf16)b[2]; o.v[7] = (bf16)b[3];
+    stg16(dst + i * 8, o);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[nv * 8 + threadIdx.x] = (bf16)src[nv * 8 + threadIdx.x];
+}
+template <typename T>
+__global__ void __launch_bounds__(NT) cast_to_f32_kernel(const T* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, long M, int C) {
+  GRID_STRIDE(i, M * C) {
+    const long r = i / C;
+    const int c = (int)(i % C);
+    dst[r * ldd + c] = Elem<T>::to_f(src[r * lds_ + c]);
+  }
+}
+
+// ---- CoordConv coordinate channels (layers.py:30-39): buf[b,y,x,c0] = x in [-1,1], [c0+1] = y, rest 0 ------
+template <typename T>
+__global__ void __launch_bounds__(NT) coord_fill_kernel(T* __restrict__ buf, long ld, int B, int H, int W, int c0, int cend) {
+  GRID_STRIDE(i, (long)B * H * W) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const float fx = W > 1 ? -1.f + 2.f * x / (W - 1) : -1.f;
+    const float fy = H > 1 ? -1.f + 2.f * y / (H - 1) : -1.f;
+    T* p = buf + i * ld;
+    p[c0] = Elem<T>::from_f(fx);
+    p[c0 + 1] = Elem<T>::from_f(fy);
+    for (int c = c0 + 2; c < cend; c++) p[c] = Elem<T>::from_f(0.f);
+  }
+}
+
+// ---- fused Adam (torch.optim.Adam semantics, train_crog.py:119-121) + optional bf16 shadow copy ---------------
+__global__ void __launch_bounds__(NT) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                  long n, float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
+                                                  float bc2_sqrt, bf16* __restrict__ shadow) {
+  const float step_size = lr / bc1;
+  GRID_STRIDE(i, (n + 3) / 4) {
+    const long o = i * 4;
+    if (o + 4 <= n) {
+      f32x4 pv = *reinterpret_cast<f32x4*>(p + o), gv = *reinterpret_cast<const f32x4*>(g + o);
+      f32x4 mv = *reinterpret_cast<f32x4*>(m + o), vv = *reinterpret_cast<f32x4*>(v + o);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float gg = gv[e] + weight_decay * pv[e];
+        mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
+        vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
+        const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+        pv[e] -= step_size * mv[e] / denom;
+      }
+      *reinterpret_cast<f32x4*>(p + o) = pv;
+      *reinterpret_cast<f32x4*>(m + o) = mv;
+      *reinterpret_cast<f32x4*>(v + o) = vv;
+      if (shadow) {
+        bf16x4 s;
+#pragma unroll
+        for (int e = 0; e < 4; e++) s[e] = (bf16)pv[e];
+        *reinterpret_cast<bf16x4*>(shadow + o) = s;
+      }
+    } else {
+      for (long j = o; j < n; j++) {
+        float gg = g[j] + weight_decay * p[j];
+        m[j] = beta1 * m[j] + (1.f - beta1) * gg;
+        v[j] = beta2 * v[j] + (1.f - beta2) * gg * gg;
+        p[j] -= step_size * m[j] / (sqrtf(v[j]) / bc2_sqrt + eps);
+        if (shadow) shadow[j] = (bf16)p[j];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                                   \
+  do {                                                           \
+    if ((dtype) == CROG_BF16) { using T = bf16; __VA_ARGS__; }   \
+    else if ((dtype) == CROG_F32) { using T = float; __VA_ARGS__; } \
+    else { crog_set_error("bad dtype %d", (int)(dtype)); return CROG_ERR_ARG; } \
+  } while (0)
+#define VECOF(dtype) ((dtype) == CROG_BF16 ? 8 : 4)
+#define LAUNCH(kern, work, stream, ...)                                                            \
+  hipLaunchKernelGGL(kern, dim3(stream_grid(work)), dim3(NT), 0, (hipStream_t)(stream), __VA_ARGS__)
+
+extern "C" int crog_avgpool2_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C, crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % vec == 0 && ldx % vec == 0 && ldy % vec == 0, "avgpool2: H,W even and C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((avgpool2_fwd_kernel<T>), (long)B * (H / 2) * (W / 2) * (C / vec), s, (const T*)x, (long)ldx, (T*)y, (long)ldy, B, H, W, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_avgpool2_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int H, int W, int C, crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % vec == 0 && lddy % vec == 0 && lddx % vec == 0, "avgpool2_bwd: bad shape");
+  DISPATCH_T(dtype, LAUNCH((avgpool2_bwd_kernel<T>), (long)B * (H / 2) * (W / 2) * (C / vec), s, (const T*)dy, (long)lddy, (T*)dx, (long)lddx, B, H, W, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_upsample2_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C, crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && ldx % vec == 0 && ldy % vec == 0, "upsample2: C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((upsample2_fwd_kernel<T>), (long)B * 4 * H * W * (C / vec), s, (const T*)x, (long)ldx, (T*)y, (long)ldy, B, H, W, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_upsample2_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int H, int W, int C, crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && lddy % vec == 0 && lddx % vec == 0, "upsample2_bwd: C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((upsample2_bwd_kernel<T>), (long)B * H * W * (C / vec), s, (const T*)dy, (long)lddy, (T*)dx, (long)lddx, B, H, W, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_embedding_fwd(int dtype, const int64_t* word, const void* tok, const void* pos, void* out, int64_t rows, int L, int C, int vocab,
+                                  crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && L > 0, "embedding: C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((embedding_fwd_kernel<T>), rows * (C / vec), s, word, (const T*)tok, (const T*)pos, (T*)out, (long)rows, L, C, vocab));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_embedding_bwd(int dtype, const int64_t* word, const void* dout, float* dtok, float* dpos, int64_t rows, int L, int C, int vocab,
+                                  crog_stream_t s) {
+  DISPATCH_T(dtype, LAUNCH((embedding_bwd_kernel<T>), rows * C, s, word, (const T*)dout, dtok, dpos, (long)rows, L, C, vocab));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_gather_rows(int dtype, const void* x, int64_t ldx, const int64_t* idx, void* out, int64_t ldo, int64_t n, int C, crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && ldx % vec == 0 && ldo % vec == 0, "gather_rows: C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((gather_rows_kernel<T>), n * (C / vec), s, (const T*)x, (long)ldx, idx, (T*)out, (long)ldo, (long)n, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_scatter_rows(int dtype, const void* dout, int64_t lddo, const int64_t* idx, void* dx, int64_t lddx, int64_t n, int C, crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && lddo % vec == 0 && lddx % vec == 0, "scatter_rows: C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((scatter_rows_kernel<T>), n * (C / vec), s, (const T*)dout, (long)lddo, idx, (T*)dx, (long)lddx, (long)n, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_mul_bcast_fwd(int dtype, const void* x, int64_t ldx, const void* sv, int64_t lds_, void* z, int64_t ldz, int B, int P, int C,
+                                  crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && ldx % vec == 0 && lds_ % vec == 0 && ldz % vec == 0, "mul_bcast: C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((mul_bcast_fwd_kernel<T>), (long)B * P * (C / vec), s, (const T*)x, (long)ldx, (const T*)sv, (long)lds_, (T*)z, (long)ldz, B, P, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_mul_bcast_bwd(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, const void* sv, int64_t lds_, void* dx,
+                                  int64_t lddx, void* ds, int64_t ldds, int B, int P, int C, crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0, "mul_bcast_bwd: C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((mul_bcast_bwd_kernel<T>), (long)B * (C / vec), s, (const T*)dz, (long)lddz, (const T*)x, (long)ldx, (const T*)sv, (long)lds_,
+                           (T*)dx, (long)lddx, (T*)ds, (long)ldds, B, P, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_add_rows(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, int64_t brows, void* out, int64_t ldo, int64_t M,
+                             int C, crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && lda % vec == 0 && ldb % vec == 0 && ldo % vec == 0 && brows > 0, "add_rows: C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((add_rows_kernel<T>), M * (C / vec), s, (const T*)a, (long)lda, (const T*)b, (long)ldb, (long)brows, (T*)out, (long)ldo, (long)M, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_sum_over_batch(int dtype, const void* x, int64_t ldx, float* out, int64_t ldo, int B, int64_t R, int C, int accumulate,
+                                   crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && ldx % vec == 0, "sum_over_batch: C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((sum_over_batch_kernel<T>), R * (C / vec), s, (const T*)x, (long)ldx, out, (long)ldo, B, (long)R, C, accumulate));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_add_dropout(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t M, int C, float p,
+                                uint64_t seed, crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && ldb % vec == 0 && ldo % vec == 0 && p >= 0.f && p < 1.f, "add_dropout: bad args");
+  DISPATCH_T(dtype, LAUNCH((add_dropout_kernel<T>), M * (C / vec), s, (const T*)a, (long)lda, (const T*)b, (long)ldb, (T*)out, (long)ldo, (long)M, C, p, seed));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_act_bwd(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, void* dx, int64_t lddx, int64_t M, int C, int mode,
+                            crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && lddy % vec == 0 && ldy % vec == 0 && lddx % vec == 0, "act_bwd: C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((act_bwd_kernel<T>), M * (C / vec), s, (const T*)dy, (long)lddy, (const T*)y, (long)ldy, (T*)dx, (long)lddx, (long)M, C, mode));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_quickgelu_fwd(int dtype, const void* u, int64_t ldu, void* out, int64_t ldo, int64_t M, int C, crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && ldu % vec == 0 && ldo % vec == 0, "quickgelu: C %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((quickgelu_fwd_kernel<T>), M * (C / vec), s, (const T*)u, (long)ldu, (T*)out, (long)ldo, (long)M, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_stem_im2col(int dtype, const float* img, void* out, int B, int H, int W, crog_stream_t s) {
+  CROG_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "stem_im2col: H, W must be even");
+  DISPATCH_T(dtype, LAUNCH((stem_im2col_kernel<T>), (long)B * (H / 2) * (W / 2), s, img, (T*)out, B, H, W));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_cast_pad2d(int dtype_dst, const float* src, int64_t lds_, int cols_src, void* dst, int64_t ldd, int cols_dst, int64_t rows,
+                               crog_stream_t s) {
+  DISPATCH_T(dtype_dst, LAUNCH((cast_pad2d_kernel<T>), rows * cols_dst, s, src, (long)lds_, cols_src, (T*)dst, (long)ldd, cols_dst, (long)rows));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_cast_f32_to_bf16(const float* src, void* dst, int64_t n, crog_stream_t s) {
+  CROG_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "cast: pointers must be 16-byte aligned");
+  LAUNCH(cast_f32_to_bf16_kernel, n / 8 + 1, s, src, (bf16*)dst, (long)n);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_cast_to_f32(int dtype, const void* src, int64_t lds_, float* dst, int64_t ldd, int64_t M, int C, crog_stream_t s) {
+  DISPATCH_T(dtype, LAUNCH((cast_to_f32_kernel<T>), M * C, s, (const T*)src, (long)lds_, dst, (long)ldd, (long)M, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_coord_fill(int dtype, void* buf, int64_t ld, int B, int H, int W, int c0, int cend, crog_stream_t s) {
+  CROG_CHECK_ARG(c0 + 2 <= cend && cend <= ld, "coord_fill: bad channel range");
+  DISPATCH_T(dtype, LAUNCH((coord_fill_kernel<T>), (long)B * H * W, s, (T*)buf, (long)ld, B, H, W, c0, cend));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, void* bf16_shadow, crog_stream_t s) {
+  CROG_CHECK_ARG(step >= 1 && n >= 0, "adam: step must be >= 1");
+  CROG_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+                 "adam: buffers must be 16-byte aligned");
+  if (n == 0) return CROG_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  LAUNCH(adam_kernel, (n + 3) / 4, s, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, (bf16*)bf16_shadow);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}

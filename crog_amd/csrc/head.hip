@@ -1,0 +1,233 @@
+// Text-conditioned dynamic-conv head, losses and the training metric
+// (layers.py:64-132 MultiTaskProjector / :152-173 Projector; crog.py:76-111; utils/misc.py:115-131).
+//
+// The per-sample grouped 3x3 conv  out[b,h] = conv3x3(x5[b, h*C:(h+1)*C], w[b]) + bias[b]  is evaluated as
+//   t[b,p,h,tap] = sum_c x5[b,p,h*C+c] * w[b,c,tap]        (batched MFMA GEMM, reads x5 exactly once)
+//   out[b,h,y,x] = bias[b] + sum_tap t[b,(y+dy,x+dx),h,tap] (9-point stencil on a 16-wide fp32 map)
+// which is the same sum re-associated; the stencil, the nearest-neighbour target resize, the five
+// losses and d(loss)/d(pred) are one pass each over the small maps.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+inline int stream_grid(long work_items) {
+  long g = (work_items + NT - 1) / NT;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+#define GRID_STRIDE(i, total) for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (total); i += (long)gridDim.x * NT)
+
+// word (fp32 [B][ldw], txt Linear output: C*9 weights then 1 bias) -> wpad[b][c][16] (taps 9..15 zero)
+template <typename T>
+__global__ void __launch_bounds__(NT) head_pack_weights_kernel(const float* __restrict__ word, long ldw, T* __restrict__ wpad, int B, int C) {
+  GRID_STRIDE(i, (long)B * C * 16) {
+    const int tap = (int)(i & 15);
+    const long bc = i >> 4;
+    const int c = (int)(bc % C);
+    const long b = bc / C;
+    wpad[i] = Elem<T>::from_f(tap < 9 ? word[b * ldw + c * 9 + tap] : 0.f);
+  }
+}
+// dwpad (fp32 [B][C][16]) + dbias[b] -> dword (T [B][ldd]): cols [0,C*9) weights, col C*9 bias, rest 0
+template <typename T>
+__global__ void __launch_bounds__(NT) head_unpack_wgrad_kernel(const float* __restrict__ dwpad, const float* __restrict__ dbias, T* __restrict__ dword,
+                                                               long ldd, int B, int C) {
+  GRID_STRIDE(i, (long)B * ldd) {
+    const int col = (int)(i % ldd);
+    const long b = i / ldd;
+    float v = 0.f;
+    if (col < C * 9) v = dwpad[(b * C + col / 9) * 16 + col % 9];
+    else if (col == C * 9) v = dbias[b];
+    dword[i] = Elem<T>::from_f(v);
+  }
+}
+
+// out[b,h,y,x] = bias[b] + sum_tap t[((b*P + p')*heads + h)*16 + tap]
+__global__ void __launch_bounds__(NT) head_stencil_fwd_kernel(const float* __restrict__ t, const float* __restrict__ word, long ldw, int bias_col,
+                                                              float* __restrict__ out, int B, int heads, int H, int W) {
+  const long P = (long)H * W;
+  GRID_STRIDE(i, (long)B * heads * P) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const int h = (int)((i / P) % heads);
+    const long b = i / (P * heads);
+    float acc = word[b * ldw + bias_col];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+      const int sy = y + tap / 3 - 1, sx = x + tap % 3 - 1;
+      if (sy >= 0 && sy < H && sx >= 0 && sx < W) acc += t[((b * P + (long)sy * W + sx) * heads + h) * 16 + tap];
+    }
+    out[i] = acc;
+  }
+}
+// dt[((b*P + p)*heads + h)*16 + tap] = dout[b,h,p - off(tap)]
+template <typename T>
+__global__ void __launch_bounds__(NT) head_stencil_bwd_kernel(const float* __restrict__ dout, T* __restrict__ dt, int B, int heads, int H, int W) {
+  const long P = (long)H * W;
+  GRID_STRIDE(i, (long)B * P * heads) {
+    const int h = (int)(i % heads);
+    const long bp = i / heads;
+    const int x = (int)(bp % W), y = (int)((bp / W) % H);
+    const long b = bp / P;
+    Vec16<T> o[16 / Elem<T>::VEC];
+#pragma unroll
+    for (int tap = 0; tap < 16; tap++) {
+      float v = 0.f;
+      if (tap < 9) {
+        const int oy = y - (tap / 3 - 1), ox = x - (tap % 3 - 1);
+        if (oy >= 0 && oy < H && ox >= 0 && ox < W) v = dout[((b * heads + h) * H + oy) * W + ox];
+      }
+      o[tap / Elem<T>::VEC].v[tap % Elem<T>::VEC] = Elem<T>::from_f(v);
+    }
+#pragma unroll
+    for (int v = 0; v < 16 / Elem<T>::VEC; v++) stg16(dt + i * 16 + v * Elem<T>::VEC, o[v]);
+  }
+}
+// dbias[b] = sum over heads, pixels of dout[b]
+__global__ void __launch_bounds__(NT) head_bias_grad_kernel(const float* __restrict__ dout, float* __restrict__ dbias, long per_b) {
+  __shared__ float red[NT / 64];
+  const long b = blockIdx.x;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < per_b; i += NT) s += dout[b * per_b + i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dbias[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- losses (crog.py:76-99) -----------------------------------------------------------------------------
+// pred fp32 [B][heads][H][W];  tgt[h] fp32 [B][1][Hin][Win] -> nearest resize to HxW (crog.py:78-83)
+// head 0: BCE-with-logits, weight = mask*0.5+1 when weighted (crog.py:90-92) else plain (crog.py:124)
+// heads 1..4: smooth-L1, beta = 1 (crog.py:93-96).  All means over N = B*H*W; total = sum of means.
+struct LossTargets { const float* t[5]; };
+__global__ void __launch_bounds__(NT) head_loss_kernel(const float* __restrict__ pred, LossTargets tg, int B, int heads, int H, int W, int Hin, int Win,
+                                                       int weighted, float* __restrict__ tgt_small, float* __restrict__ loss_sums,
+                                                       float* __restrict__ dpred) {
+  __shared__ float red[NT / 64][5];
+  const long P = (long)H * W, N = (long)B * P;
+  const float invN = 1.f / (float)N;
+  const float sy = (float)Hin / H, sx = (float)Win / W;
+  float ls[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  GRID_STRIDE(i, N) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long b = i / P;
+    const int iy = min((int)floorf(y * sy), Hin - 1), ix = min((int)floorf(x * sx), Win - 1);
+    for (int h = 0; h < heads; h++) {
+      const float t = tg.t[h][(b * Hin + iy) * Win + ix];
+      const float p = pred[((b * heads + h) * H + y) * W + x];
+      tgt_small[(long)h * N + i] = t;
+      float l, g;
+      if (h == 0) {
+        const float w = weighted ? t * 0.5f + 1.f : 1.f;
+        l = w * (fmaxf(p, 0.f) - p * t + log1pf(__expf(-fabsf(p))));
+        g = w * (1.f / (1.f + __expf(-p)) - t);
+      } else {
+        const float d = p - t, ad = fabsf(d);
+        l = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+        g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+      }
+      ls[h] += l;
+      dpred[((b * heads + h) * H + y) * W + x] = g * invN;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 5; h++) {
+    const float s = wave_sum(ls[h]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][h] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < heads) {
+    float s = 0.f;
+    for (int w = 0; w < NT / 64; w++) s += red[w][threadIdx.x];
+    atomicAdd(loss_sums + threadIdx.x, s * invN);
+  }
+}
+
+// ---- trainMetricGPU (utils/misc.py:115-131): sigmoid, threshold, per-sample IoU, Prec@pr_iou ---------------
+__global__ void __launch_bounds__(NT) metric_counts_kernel(const float* __restrict__ pred, long pred_bstride, const float* __restrict__ tgt, long P,
+                                                           float thr, float* __restrict__ counts) {
+  __shared__ float red[NT / 64][2];
+  const long b = blockIdx.x;
+  float inter = 0.f, uni = 0.f;
+  for (long i = threadIdx.x; i < P; i += NT) {
+    const float s = 1.f / (1.f + expf(-pred[b * pred_bstride + i]));
+    const bool o = s >= thr, t = tgt[b * P + i] != 0.f;
+    inter += (o && t) ? 1.f : 0.f;
+    uni += (o || t) ? 1.f : 0.f;
+  }
+  inter = wave_sum(inter);
+  uni = wave_sum(uni);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = inter; red[threadIdx.x >> 6][1] = uni; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    counts[2 * b] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    counts[2 * b + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+  }
+}
+__global__ void metric_finalize_kernel(const float* __restrict__ counts, int B, float pr_iou, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float iou = 0.f, prec = 0.f;
+  for (int b = 0; b < B; b++) {
+    const float v = counts[2 * b] / (counts[2 * b + 1] + 1e-6f);
+    iou += v;
+    prec += v > pr_iou ? 1.f : 0.f;
+  }
+  out[0] = 100.f * iou / B;
+  out[1] = 100.f * prec / B;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                                   \
+  do {                                                           \
+    if ((dtype) == CROG_BF16) { using T = bf16; __VA_ARGS__; }   \
+    else if ((dtype) == CROG_F32) { using T = float; __VA_ARGS__; } \
+    else { crog_set_error("bad dtype %d", (int)(dtype)); return CROG_ERR_ARG; } \
+  } while (0)
+#define LAUNCH(kern, work, stream, ...)                                                            \
+  hipLaunchKernelGGL(kern, dim3(stream_grid(work)), dim3(NT), 0, (hipStream_t)(stream), __VA_ARGS__)
+
+extern "C" int crog_head_pack_weights(int dtype, const float* word, int64_t ldw, void* wpad, int B, int C, crog_stream_t s) {
+  DISPATCH_T(dtype, LAUNCH((head_pack_weights_kernel<T>), (long)B * C * 16, s, word, (long)ldw, (T*)wpad, B, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_head_unpack_wgrad(int dtype, const float* dwpad, const float* dbias, void* dword, int64_t ldd, int B, int C, crog_stream_t s) {
+  CROG_CHECK_ARG(ldd >= C * 9 + 1, "head_unpack_wgrad: ldd too small");
+  DISPATCH_T(dtype, LAUNCH((head_unpack_wgrad_kernel<T>), (long)B * ldd, s, dwpad, dbias, (T*)dword, (long)ldd, B, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_head_stencil_fwd(const float* t, const float* word, int64_t ldw, int bias_col, float* out, int B, int heads, int H, int W,
+                                     crog_stream_t s) {
+  LAUNCH(head_stencil_fwd_kernel, (long)B * heads * H * W, s, t, word, (long)ldw, bias_col, out, B, heads, H, W);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_head_stencil_bwd(int dtype, const float* dout, void* dt, float* dbias, int B, int heads, int H, int W, crog_stream_t s) {
+  DISPATCH_T(dtype, LAUNCH((head_stencil_bwd_kernel<T>), (long)B * heads * H * W, s, dout, (T*)dt, B, heads, H, W));
+  CROG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(head_bias_grad_kernel, dim3(B), dim3(NT), 0, (hipStream_t)s, dout, dbias, (long)heads * H * W);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_head_loss(const float* pred, const float* const* targets, int B, int heads, int H, int W, int Hin, int Win, int weighted,
+                              float* tgt_small, float* loss_sums, float* dpred, crog_stream_t s) {
+  CROG_CHECK_ARG(heads >= 1 && heads <= 5, "head_loss: heads must be in [1,5]");
+  LossTargets tg;
+  for (int h = 0; h < 5; h++) tg.t[h] = h < heads ? targets[h] : nullptr;
+  hipError_t e = hipMemsetAsync(loss_sums, 0, 5 * sizeof(float), (hipStream_t)s);
+  if (e != hipSuccess) { crog_set_error("head_loss: memset failed"); return CROG_ERR_LAUNCH; }
+  LAUNCH(head_loss_kernel, (long)B * H * W, s, pred, tg, B, heads, H, W, Hin, Win, weighted, tgt_small, loss_sums, dpred);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_train_metric(const float* pred, int64_t pred_bstride, const float* tgt, int B, int64_t P, float threshold, float pr_iou,
+                                 float* counts, float* out2, crog_stream_t s) {
+  hipLaunchKernelGGL(metric_counts_kernel, dim3(B), dim3(NT), 0, (hipStream_t)s, pred, (long)pred_bstride, tgt, (long)P, threshold, counts);
+  CROG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(metric_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, counts, B, pr_iou, out2);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}

@@ -1,0 +1,644 @@
+// BatchNorm (training, cross-replica capable), LayerNorm and masked softmax kernels.
+// All are HBM-bound streaming kernels: 16-byte vector loads, fp32 math, wave-shuffle reductions.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// =============================================================================================
+// BatchNorm statistics.  x is [M][C] (row stride ld).  Each block reduces ROWS rows for all
+// channels and writes one partial slab row: partial[block][C][2] = (sum, sum of squares).
+// =============================================================================================
+template <typename T>
+__global__ void __launch_bounds__(NT) bn_partial_stats_kernel(const T* __restrict__ x, long M, int C, long ld,
+                                                               int rows_per_block, float* __restrict__ partial) {
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float red[NT][2 * VEC + 1];
+  const int cvec = C / VEC;
+  const int cw = cvec < NT ? cvec : NT;  // threads across channel chunks
+  const int tx = threadIdx.x % cw, ty = threadIdx.x / cw, nty = NT / cw;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(r0 + rows_per_block, M);
+  for (int cg = 0; cg < cvec; cg += cw) {
+    const int c = (cg + tx) * VEC;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) s1[e] = s2[e] = 0.f;
+    for (long r = r0 + ty; r < r1; r += nty) {
+      Vec16<T> v = ldg16(x + r * ld + c);
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        float f = Elem<T>::to_f(v.v[e]);
+        s1[e] += f;
+        s2[e] += f * f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      red[threadIdx.x][e] = s1[e];
+      red[threadIdx.x][VEC + e] = s2[e];
+    }
+    __syncthreads();
+    if (ty == 0) {
+      for (int j = 1; j < nty; j++)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          s1[e] += red[j * cw + tx][e];
+          s2[e] += red[j * cw + tx][VEC + e];
+        }
+      float* dst = partial + ((long)blockIdx.x * C + c) * 2;
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        dst[2 * e] = s1[e];
+        dst[2 * e + 1] = s2[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// sums[c][2] = sum over parts of partial[part][c][2]  (any pair of per-channel quantities)
+__global__ void reduce_pairs_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int p = 0; p < nparts; p++) {
+    const float2 v = *reinterpret_cast<const float2*>(partial + ((long)p * C + c) * 2);
+    a += v.x;
+    b += v.y;
+  }
+  sums[2 * c] = a;
+  sums[2 * c + 1] = b;
+}
+
+// Finalize training-mode BN from (global) sums: scale/shift for the apply pass, mean/invstd for
+// backward, running-stat update with momentum (torch semantics: unbiased var in running_var).
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps, int C,
+                                   float* __restrict__ scale_shift, float* __restrict__ mean_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = sums[2 * c] / count;
+  float var = sums[2 * c + 1] / count - mean * mean;
+  var = fmaxf(var, 0.f);
+  const float invstd = rsqrtf(var + eps);
+  const float sc = gamma[c] * invstd;
+  scale_shift[2 * c] = sc;
+  scale_shift[2 * c + 1] = beta[c] - mean * sc;
+  mean_invstd[2 * c] = mean;
+  mean_invstd[2 * c + 1] = invstd;
+  if (running_mean) {
+    const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+// Eval-mode BN: scale/shift straight from running statistics.
+__global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                     float eps, int C, float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] * rsqrtf(running_var[c] + eps);
+  scale_shift[2 * c] = sc;
+  scale_shift[2 * c + 1] = beta[c] - running_mean[c] * sc;
+}
+
+// y = [relu]( z*scale + shift [+ res] )
+template <typename T>
+__global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ z, long ldz, const float* __restrict__ scale_shift,
+                                                      const T* __restrict__ res, long ldr, int relu, T* __restrict__ y,
+                                                      long ldy, long M, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  const long total = M * cvec;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    Vec16<T> v = ldg16(z + r * ldz + c);
+    Vec16<T> rv;
+    if (res) rv = ldg16(res + r * ldr + c);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      float f = Elem<T>::to_f(v.v[e]) * scale_shift[2 * (c + e)] + scale_shift[2 * (c + e) + 1];
+      if (res) f += Elem<T>::to_f(rv.v[e]);
+      if (relu) f = fmaxf(f, 0.f);
+      o.v[e] = Elem<T>::from_f(f);
+    }
+    stg16(y + r * ldy + c, o);
+  }
+}
+
+// Backward pass 1: g = dy * (y > 0 if relu);  partial[block][C][2] = (sum g, sum g*zhat)
+template <typename T>
+__global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
+                                                            const T* __restrict__ z, long ldz, const float* __restrict__ mean_invstd,
+                                                            long M, int C, int rows_per_block, float* __restrict__ partial) {
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float red[NT][2 * VEC + 1];
+  const int cvec = C / VEC;
+  const int cw = cvec < NT ? cvec : NT;
+  const int tx = threadIdx.x % cw, ty = threadIdx.x / cw, nty = NT / cw;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(r0 + rows_per_block, M);
+  for (int cg = 0; cg < cvec; cg += cw) {
+    const int c = (cg + tx) * VEC;
+    float s1[VEC], s2[VEC], mu[VEC], is[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      s1[e] = s2[e] = 0.f;
+      mu[e] = mean_invstd[2 * (c + e)];
+      is[e] = mean_invstd[2 * (c + e) + 1];
+    }
+    for (long r = r0 + ty; r < r1; r += nty) {
+      Vec16<T> g = ldg16(dy + r * lddy + c);
+      Vec16<T> zz = ldg16(z + r * ldz + c);
+      Vec16<T> yy;
+      if (y) yy = ldg16(y + r * ldy + c);
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        float gf = Elem<T>::to_f(g.v[e]);
+        if (y && !(Elem<T>::to_f(yy.v[e]) > 0.f)) gf = 0.f;
+        const float zh = (Elem<T>::to_f(zz.v[e]) - mu[e]) * is[e];
+        s1[e] += gf;
+        s2[e] += gf * zh;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      red[threadIdx.x][e] = s1[e];
+      red[threadIdx.x][VEC + e] = s2[e];
+    }
+    __syncthreads();
+    if (ty == 0) {
+      for (int j = 1; j < nty; j++)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          s1[e] += red[j * cw + tx][e];
+          s2[e] += red[j * cw + tx][VEC + e];
+        }
+      float* dst = partial + ((long)blockIdx.x * C + c) * 2;
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        dst[2 * e] = s1[e];
+        dst[2 * e + 1] = s2[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// dgamma/dbeta from the (local) sums: dbeta = sum g, dgamma = sum g*zhat.  accumulate flag adds.
+__global__ void bn_param_grads_kernel(const float* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = sums[2 * c];
+  dgamma[c] = sums[2 * c + 1];
+}
+
+// Backward pass 2: dz = gamma*invstd * (g - sum_g/count - zhat * sum_gz/count);  dres = g (optional)
+template <typename T>
+__global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
+                                                          const T* __restrict__ z, long ldz, const float* __restrict__ mean_invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ sums, float count,
+                                                          T* __restrict__ dz, long lddz, T* __restrict__ dres, long lddres, long M, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC;
+  const long total = M * cvec;
+  const float inv_count = 1.f / count;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    Vec16<T> g = ldg16(dy + r * lddy + c);
+    Vec16<T> zz = ldg16(z + r * ldz + c);
+    Vec16<T> yy;
+    if (y) yy = ldg16(y + r * ldy + c);
+    Vec16<T> o, gr;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      float gf = Elem<T>::to_f(g.v[e]);
+      if (y && !(Elem<T>::to_f(yy.v[e]) > 0.f)) gf = 0.f;
+      const float mu = mean_invstd[2 * (c + e)], is = mean_invstd[2 * (c + e) + 1];
+      const float zh = (Elem<T>::to_f(zz.v[e]) - mu) * is;
+      const float d = gamma[c + e] * is * (gf - sums[2 * (c + e)] * inv_count - zh * sums[2 * (c + e) + 1] * inv_count);
+      o.v[e] = Elem<T>::from_f(d);
+      gr.v[e] = Elem<T>::from_f(gf);
+    }
+    stg16(dz + r * lddz + c, o);
+    if (dres) stg16(dres + r * lddres + c, gr);
+  }
+}
+
+// =============================================================================================
+// LayerNorm: one wave per row.  Optional fused pieces (all follow layers.py:313-339 ordering):
+//   xin  = dropout_in(x)                                   (ffn Dropout before LayerNorm, layers.py:299-300)
+//   y    = LN(xin) * gamma + beta
+//   out  = res + dropout_out(y)                            (vis + dropout(norm(attn)), layers.py:325-326)
+//   out2 = out + pos[row % pos_rows]                       (with_pos_embed, layers.py:310-311,323)
+// stats[row] = (mean, rstd) for backward.
+// =============================================================================================
+template <typename T>
+__global__ void __launch_bounds__(NT) ln_fwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float eps, long M, int C, T* __restrict__ out,
+                                                    long ldo, float* __restrict__ stats, const T* __restrict__ res, long ldr,
+                                                    T* __restrict__ out2, long ldo2, const T* __restrict__ pos, int pos_rows, long ldp,
+                                                    float p_in, uint64_t seed_in, float p_out, uint64_t seed_out) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int MAXV = 2048 / (64 * 4);  // up to C = 2048 (f32: 8 vectors of 4 per lane)
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int cvec = C / VEC;
+  const uint32_t thr_in = (uint32_t)(p_in * 4294967296.0), thr_out = (uint32_t)(p_out * 4294967296.0);
+  const float sc_in = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, sc_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
+  float vals[MAXV][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXV; j++) {
+    const int cv = lane + j * 64;
+    if (cv < cvec) {
+      Vec16<T> v = ldg16(x + row * ldx + cv * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        float f = Elem<T>::to_f(v.v[e]);
+        if (p_in > 0.f) f = dropout_keep(seed_in, (uint64_t)row * C + cv * VEC + e, thr_in) ? f * sc_in : 0.f;
+        vals[j][e] = f;
+        s += f;
+      }
+    }
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXV; j++) {
+    const int cv = lane + j * 64;
+    if (cv < cvec)
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        const float d = vals[j][e] - mean;
+        q += d * d;
+      }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  if (lane == 0 && stats) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+#pragma unroll
+  for (int j = 0; j < MAXV; j++) {
+    const int cv = lane + j * 64;
+    if (cv < cvec) {
+      const int c = cv * VEC;
+      Vec16<T> o, o2, rv, pv;
+      if (res) rv = ldg16(res + row * ldr + c);
+      if (out2 && pos) pv = ldg16(pos + (row % pos_rows) * ldp + c);
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        float f = (vals[j][e] - mean) * rstd * gamma[c + e] + beta[c + e];
+        if (p_out > 0.f) f = dropout_keep(seed_out, (uint64_t)row * C + c + e, thr_out) ? f * sc_out : 0.f;
+        if (res) f += Elem<T>::to_f(rv.v[e]);
+        o.v[e] = Elem<T>::from_f(f);
+        if (out2) o2.v[e] = Elem<T>::from_f(Elem<T>::to_f(o.v[e]) + (pos ? Elem<T>::to_f(pv.v[e]) : 0.f));
+      }
+      stg16(out + row * ldo + c, o);
+      if (out2) stg16(out2 + row * ldo2 + c, o2);
+    }
+  }
+}
+
+// LayerNorm backward.  g = dout (+ dout2);  dy = dropout_out_bwd(g);  dxin via LN backward;
+// dx = dropout_in_bwd(dxin).  Per-block partial (dgamma, dbeta) rows go to partial[block][C][2].
+template <typename T>
+__global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, long lddo, const T* __restrict__ dout2, long lddo2,
+                                                    const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                    const float* __restrict__ stats, long M, int C, T* __restrict__ dx, long lddx,
+                                                    float* __restrict__ partial, int rows_per_block, float p_in, uint64_t seed_in,
+                                                    float p_out, uint64_t seed_out) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int MAXV = 2048 / (64 * 4);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cvec = C / VEC;
+  const uint32_t thr_in = (uint32_t)(p_in * 4294967296.0), thr_out = (uint32_t)(p_out * 4294967296.0);
+  const float sc_in = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, sc_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
+  float dg[MAXV][VEC], db[MAXV][VEC];
+#pragma unroll
+  for (int j = 0; j < MAXV; j++)
+#pragma unroll
+    for (int e = 0; e < VEC; e++) dg[j][e] = db[j][e] = 0.f;
+
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(r0 + rows_per_block, M);
+  for (long row = r0 + wv; row < r1; row += NT / 64) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[MAXV][VEC], gy[MAXV][VEC];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; j++) {
+      const int cv = lane + j * 64;
+      if (cv < cvec) {
+        const int c = cv * VEC;
+        Vec16<T> g = ldg16(dout + row * lddo + c);
+        Vec16<T> g2;
+        if (dout2) g2 = ldg16(dout2 + row * lddo2 + c);
+        Vec16<T> xv = ldg16(x + row * ldx + c);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          float gf = Elem<T>::to_f(g.v[e]);
+          if (dout2) gf += Elem<T>::to_f(g2.v[e]);
+          if (p_out > 0.f) gf = dropout_keep(seed_out, (uint64_t)row * C + c + e, thr_out) ? gf * sc_out : 0.f;
+          float xf = Elem<T>::to_f(xv.v[e]);
+          if (p_in > 0.f) xf = dropout_keep(seed_in, (uint64_t)row * C + c + e, thr_in) ? xf * sc_in : 0.f;
+          const float h = (xf - mean) * rstd;
+          xh[j][e] = h;
+          dg[j][e] += gf * h;
+          db[j][e] += gf;
+          const float gyv = gf * gamma[c + e];
+          gy[j][e] = gyv;
+          a += gyv;
+          b += gyv * h;
+        }
+      }
+    }
+    a = wave_sum(a) / C;
+    b = wave_sum(b) / C;
+#pragma unroll
+    for (int j = 0; j < MAXV; j++) {
+      const int cv = lane + j * 64;
+      if (cv < cvec) {
+        const int c = cv * VEC;
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          float d = rstd * (gy[j][e] - a - xh[j][e] * b);
+          if (p_in > 0.f) d = dropout_keep(seed_in, (uint64_t)row * C + c + e, thr_in) ? d * sc_in : 0.f;
+          o.v[e] = Elem<T>::from_f(d);
+        }
+        stg16(dx + row * lddx + c, o);
+      }
+    }
+  }
+  // combine the block's 4 waves through global atomics into this block's partial row (zeroed by host)
+  float* dst = partial + (long)blockIdx.x * C * 2;
+#pragma unroll
+  for (int j = 0; j < MAXV; j++) {
+    const int cv = lane + j * 64;
+    if (cv < cvec)
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        atomicAdd(dst + 2 * (cv * VEC + e), dg[j][e]);
+        atomicAdd(dst + 2 * (cv * VEC + e) + 1, db[j][e]);
+      }
+  }
+}
+
+// pairs [C][2] -> two separate fp32 vectors (dgamma, dbeta)
+__global__ void split_pairs_kernel(const float* __restrict__ sums, int C, float* __restrict__ a, float* __restrict__ b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  a[c] = sums[2 * c];
+  b[c] = sums[2 * c + 1];
+}
+
+// =============================================================================================
+// Masked row softmax over scores S[rows][ldp] (already scaled), one wave per row.
+//   rows = batch*heads*Lq, row -> (b = row / (heads*Lq), q = row % Lq)
+//   causal: key j > q masked (clip.py:424-430);  kpm[b][j] != 0 masked (layers.py:332, crog.py:55)
+//   columns >= Lk (row padding up to ldp) are written as 0 so they can feed the P.V GEMM.
+//   P  = softmax probabilities;  Pd (optional) = dropout(P)  (nn.MultiheadAttention dropout, layers.py:291)
+// =============================================================================================
+template <typename T>
+__global__ void __launch_bounds__(NT) softmax_fwd_kernel(T* __restrict__ S, long rows, int Lq, int Lk, int ldp, int heads,
+                                                         int causal, const uint8_t* __restrict__ kpm, T* __restrict__ Pd,
+                                                         float p_drop, uint64_t seed) {
+  constexpr int MAXE = 12;  // Lk up to 768
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int q = (int)(row % Lq);
+  const long b = row / ((long)heads * Lq);
+  T* s = S + row * ldp;
+  float v[MAXE];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < MAXE; j++) {
+    const int k = lane + j * 64;
+    float f = -INFINITY;
+    if (k < Lk) {
+      f = Elem<T>::to_f(s[k]);
+      if (causal && k > q) f = -INFINITY;
+      if (kpm && kpm[b * Lk + k]) f = -INFINITY;
+    }
+    v[j] = f;
+    mx = fmaxf(mx, f);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXE; j++) {
+    const float e = (v[j] == -INFINITY) ? 0.f : __expf(v[j] - mx);
+    v[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;  // a fully masked row gives NaN exactly as torch does
+  const uint32_t thr = (uint32_t)(p_drop * 4294967296.0);
+  const float sc = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+#pragma unroll
+  for (int j = 0; j < MAXE; j++) {
+    const int k = lane + j * 64;
+    if (k < ldp) {
+      const float pv = (k < Lk) ? v[j] * inv : 0.f;
+      s[k] = Elem<T>::from_f(pv);
+      if (Pd) {
+        float pd = pv;
+        if (p_drop > 0.f) pd = dropout_keep(seed, (uint64_t)row * ldp + k, thr) ? pv * sc : 0.f;
+        Pd[row * ldp + k] = Elem<T>::from_f(pd);
+      }
+    }
+  }
+}
+
+// dS = P * (dP - sum_k dP*P) with dP = dropout_bwd(dPd); written in place over dPd.
+template <typename T>
+__global__ void __launch_bounds__(NT) softmax_bwd_kernel(const T* __restrict__ P, T* __restrict__ dPd, long rows, int Lk, int ldp,
+                                                         float p_drop, uint64_t seed) {
+  constexpr int MAXE = 12;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint32_t thr = (uint32_t)(p_drop * 4294967296.0);
+  const float sc = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  float pv[MAXE], dp[MAXE];
+  float dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXE; j++) {
+    const int k = lane + j * 64;
+    pv[j] = dp[j] = 0.f;
+    if (k < Lk) {
+      pv[j] = Elem<T>::to_f(P[row * ldp + k]);
+      float d = Elem<T>::to_f(dPd[row * ldp + k]);
+      if (p_drop > 0.f) d = dropout_keep(seed, (uint64_t)row * ldp + k, thr) ? d * sc : 0.f;
+      dp[j] = d;
+      dot += d * pv[j];
+    }
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int j = 0; j < MAXE; j++) {
+    const int k = lane + j * 64;
+    if (k < ldp) dPd[row * ldp + k] = Elem<T>::from_f(k < Lk ? pv[j] * (dp[j] - dot) : 0.f);
+  }
+}
+
+inline int stream_grid(long work_items) {
+  long g = (work_items + NT - 1) / NT;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                                   \
+  do {                                                           \
+    if ((dtype) == CROG_BF16) { using T = bf16; __VA_ARGS__; }   \
+    else if ((dtype) == CROG_F32) { using T = float; __VA_ARGS__; } \
+    else { crog_set_error("bad dtype %d", (int)(dtype)); return CROG_ERR_ARG; } \
+  } while (0)
+
+static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" int crog_bn_stat_blocks(int64_t M, int rows_per_block) { return cdiv(M, rows_per_block); }
+
+extern "C" int crog_bn_partial_stats(int dtype, const void* x, int64_t M, int C, int64_t ld, int rows_per_block,
+                                     float* partial, crog_stream_t stream) {
+  const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(C % vec == 0 && pow2(C / vec) && ld % vec == 0, "bn_partial_stats: C/vec must be a power of two (C=%d)", C);
+  CROG_CHECK_ARG(rows_per_block > 0 && M > 0, "bn_partial_stats: bad sizes");
+  const int blocks = cdiv(M, rows_per_block);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_partial_stats_kernel<T>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream,
+                                       (const T*)x, (long)M, C, (long)ld, rows_per_block, partial));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, crog_stream_t stream) {
+  CROG_CHECK_ARG(nparts > 0 && C > 0, "reduce_pairs: bad sizes");
+  hipLaunchKernelGGL(reduce_pairs_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, partial, nparts, C, sums);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_split_pairs(const float* sums, int C, float* a, float* b, crog_stream_t stream) {
+  hipLaunchKernelGGL(split_pairs_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sums, C, a, b);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_bn_finalize(const float* sums, float count, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float momentum, float eps, int C, float* scale_shift, float* mean_invstd,
+                                crog_stream_t stream) {
+  CROG_CHECK_ARG(count > 0 && C > 0, "bn_finalize: bad sizes");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sums, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, C, scale_shift, mean_invstd);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_bn_eval_scale(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                  float eps, int C, float* scale_shift, crog_stream_t stream) {
+  hipLaunchKernelGGL(bn_eval_scale_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                     running_var, eps, C, scale_shift);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_bn_apply(int dtype, const void* z, int64_t ldz, const float* scale_shift, const void* res, int64_t ldr,
+                             int relu, void* y, int64_t ldy, int64_t M, int C, crog_stream_t stream) {
+  const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(C % vec == 0 && ldz % vec == 0 && ldy % vec == 0 && (!res || ldr % vec == 0), "bn_apply: C/ld must be multiples of %d", vec);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(stream_grid(M * (C / vec))), dim3(NT), 0, (hipStream_t)stream,
+                                       (const T*)z, (long)ldz, scale_shift, (const T*)res, (long)ldr, relu, (T*)y, (long)ldy,
+                                       (long)M, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
+                                   const float* mean_invstd, int64_t M, int C, int rows_per_block, float* partial,
+                                   crog_stream_t stream) {
+  const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(C % vec == 0 && pow2(C / vec), "bn_bwd_partial: C/vec must be a power of two (C=%d)", C);
+  const int blocks = cdiv(M, rows_per_block);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dy,
+                                       (long)lddy, (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, (long)M, C,
+                                       rows_per_block, partial));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
+                                 const float* mean_invstd, const float* gamma, const float* sums, float count, void* dz,
+                                 int64_t lddz, void* dres, int64_t lddres, int64_t M, int C, crog_stream_t stream) {
+  const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(C % vec == 0, "bn_bwd_apply: C %% %d != 0", vec);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(stream_grid(M * (C / vec))), dim3(NT), 0,
+                                       (hipStream_t)stream, (const T*)dy, (long)lddy, (const T*)y, (long)ldy, (const T*)z,
+                                       (long)ldz, mean_invstd, gamma, sums, count, (T*)dz, (long)lddz, (T*)dres, (long)lddres,
+                                       (long)M, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_ln_fwd(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, int64_t M, int C,
+                           void* out, int64_t ldo, float* stats, const void* res, int64_t ldr, void* out2, int64_t ldo2,
+                           const void* pos, int pos_rows, int64_t ldp, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out,
+                           crog_stream_t stream) {
+  const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(C % vec == 0 && C <= 2048, "ln_fwd: C=%d must be a multiple of %d and <= 2048", C, vec);
+  CROG_CHECK_ARG(!pos || pos_rows > 0, "ln_fwd: pos_rows");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3(cdiv(M, NT / 64)), dim3(NT), 0, (hipStream_t)stream, (const T*)x,
+                                       (long)ldx, gamma, beta, eps, (long)M, C, (T*)out, (long)ldo, stats, (const T*)res, (long)ldr,
+                                       (T*)out2, (long)ldo2, (const T*)pos, pos_rows, (long)ldp, p_in, seed_in, p_out, seed_out));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_ln_bwd_blocks(int64_t M, int rows_per_block) { return cdiv(M, rows_per_block); }
+
+extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void* dout2, int64_t lddo2, const void* x, int64_t ldx,
+                           const float* gamma, const float* stats, int64_t M, int C, void* dx, int64_t lddx, float* partial,
+                           int rows_per_block, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, crog_stream_t stream) {
+  const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(C % vec == 0 && C <= 2048, "ln_bwd: C=%d must be a multiple of %d and <= 2048", C, vec);
+  const int blocks = cdiv(M, rows_per_block);
+  hipError_t e = hipMemsetAsync(partial, 0, (size_t)blocks * C * 2 * sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) { crog_set_error("ln_bwd: memset failed"); return CROG_ERR_LAUNCH; }
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dout, (long)lddo,
+                                       (const T*)dout2, (long)lddo2, (const T*)x, (long)ldx, gamma, stats, (long)M, C, (T*)dx,
+                                       (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_softmax_fwd(int dtype, void* S, int64_t rows, int Lq, int Lk, int ldp, int heads, int causal,
+                                const uint8_t* key_padding_mask, void* Pd, float p_drop, uint64_t seed, crog_stream_t stream) {
+  CROG_CHECK_ARG(Lk > 0 && Lk <= ldp && ldp <= 768, "softmax_fwd: need Lk <= ldp <= 768 (Lk=%d ldp=%d)", Lk, ldp);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_fwd_kernel<T>), dim3(cdiv(rows, NT / 64)), dim3(NT), 0, (hipStream_t)stream, (T*)S,
+                                       (long)rows, Lq, Lk, ldp, heads, causal, key_padding_mask, (T*)Pd, p_drop, seed));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_softmax_bwd(int dtype, const void* P, void* dPd, int64_t rows, int Lk, int ldp, float p_drop, uint64_t seed,
+                                crog_stream_t stream) {
+  CROG_CHECK_ARG(Lk > 0 && Lk <= ldp && ldp <= 768, "softmax_bwd: need Lk <= ldp <= 768");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_bwd_kernel<T>), dim3(cdiv(rows, NT / 64)), dim3(NT), 0, (hipStream_t)stream,
+                                       (const T*)P, (T*)dPd, (long)rows, Lk, ldp, p_drop, seed));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}

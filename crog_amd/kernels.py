@@ -1,0 +1,369 @@
+"""Tensor-level wrappers over the C ABI (include/crog_hip.h).
+
+Each function takes torch tensors that live on the GPU, checks layout, and enqueues the HIP
+kernel on torch's current stream.  PyTorch is only the allocator / stream owner here; no torch
+operator computes anything on this path.  Nothing in this file falls back to CPU or to ATen.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+F32, BF16 = 0, 1
+A_KC, A_IM2COL, A_MC = 0, 1, 2
+B_KC, B_NC, B_NC_DGRAD, B_NC_IM2COL = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
+OUT_T, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
+
+
+def lib():
+    return _lib.load()
+
+
+def dcode(t_or_dtype) -> int:
+    dt = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise TypeError(f"crog_amd kernels support float32 / bfloat16 activations, got {dt}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("crog_amd kernels need GPU tensors (there is no CPU path)")
+    return t.data_ptr()
+
+
+def mat(t: torch.Tensor):
+    """View a tensor as a row matrix: returns (rows, cols, ld). Last dim must be unit-stride and
+    the leading dims must collapse to a single row index with constant stride ld."""
+    if t.dim() == 1:
+        if t.stride(0) != 1 and t.numel() > 1:
+            raise ValueError("1-D tensor must be contiguous")
+        return 1, t.shape[0], t.shape[0]
+    if t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise ValueError(f"last dim must be contiguous, strides={t.stride()}")
+    ld = t.stride(-2)
+    rows = 1
+    for i in range(t.dim() - 1):
+        rows *= t.shape[i]
+    for i in range(t.dim() - 2):
+        if t.shape[i] != 1 and t.stride(i) != t.stride(i + 1) * t.shape[i + 1]:
+            raise ValueError(f"leading dims do not collapse: shape={tuple(t.shape)} strides={t.stride()}")
+    if ld < t.shape[-1]:
+        raise ValueError("row stride smaller than row length")
+    return rows, t.shape[-1], ld
+
+
+def is_mat(t: torch.Tensor) -> bool:
+    try:
+        mat(t)
+        return True
+    except ValueError:
+        return False
+
+
+def as_mat(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` if it is a valid row matrix view, else a contiguous copy (incoming autograd grads)."""
+    return t if is_mat(t) else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# GEMM
+# --------------------------------------------------------------------------------------------
+def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, ldc, *, batch=1, batch_inner=1,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, conv=(0, 0, 0), alpha=1.0, bias=None, act=ACT_NONE, R=None,
+         ldr=0, out_mode=OUT_T, col_stats=None, a_off=0, b_off=0, c_off=0):
+    """Raw descriptor launch. A/B/C are tensors (or ints = device addresses); *_off are element offsets."""
+    esz = 2 if dtype == BF16 else 4
+    csz = esz if out_mode == OUT_T else 4
+
+    def addr(x, off, sz):
+        base = x if isinstance(x, int) else ptr(x)
+        return base + off * sz
+
+    d = GemmDesc()
+    d.dtype, d.a_layout, d.b_layout = dtype, a_layout, b_layout
+    d.A, d.B, d.C = addr(A, a_off, esz), addr(B, b_off, esz), addr(C, c_off, csz)
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.lda, d.ldb, d.ldc = int(lda), int(ldb), int(ldc)
+    d.batch, d.batch_inner = int(batch), int(batch_inner)
+    d.sAo, d.sAi = int(sA[0]), int(sA[1])
+    d.sBo, d.sBi = int(sB[0]), int(sB[1])
+    d.sCo, d.sCi = int(sC[0]), int(sC[1])
+    d.splitk = int(splitk)
+    d.convH, d.convW, d.convC = int(conv[0]), int(conv[1]), int(conv[2])
+    d.alpha = float(alpha)
+    d.bias = ptr(bias)
+    d.act = int(act)
+    d.R = ptr(R)
+    d.ldr = int(ldr)
+    d.out_mode = int(out_mode)
+    d.col_stats = ptr(col_stats)
+    check(lib().crog_gemm(ctypes.byref(d), stream()), "crog_gemm")
+
+
+def stat_tiles(M: int) -> int:
+    return (M + 127) // 128
+
+
+def pick_splitk(M: int, N: int, K: int, bk: int) -> int:
+    """Split the reduction so that a weight-gradient GEMM (small MxN, huge K) still fills 256 CUs."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    ktiles = (K + bk - 1) // bk
+    target = 1024
+    s = max(1, min(target // max(tiles, 1), ktiles // 8 if ktiles >= 16 else 1))
+    return max(1, min(s, 1024))
+
+
+# --------------------------------------------------------------------------------------------
+# BatchNorm pieces
+# --------------------------------------------------------------------------------------------
+def bn_rows_per_block(M: int) -> int:
+    return max(32, (M + 1023) // 1024)
+
+
+def bn_partial_stats(x: torch.Tensor, partial: torch.Tensor, rows_per_block: int):
+    M, C, ld = mat(x)
+    check(lib().crog_bn_partial_stats(dcode(x), ptr(x), M, C, ld, rows_per_block, ptr(partial), stream()), "bn_partial_stats")
+
+
+def reduce_pairs(partial: torch.Tensor, nparts: int, C: int, sums: torch.Tensor):
+    check(lib().crog_reduce_pairs(ptr(partial), nparts, C, ptr(sums), stream()), "reduce_pairs")
+
+
+def split_pairs(sums: torch.Tensor, C: int, a: torch.Tensor, b: torch.Tensor):
+    check(lib().crog_split_pairs(ptr(sums), C, ptr(a), ptr(b), stream()), "split_pairs")
+
+
+def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale_shift, mean_invstd):
+    check(lib().crog_bn_finalize(ptr(sums), float(count), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                 float(momentum), float(eps), C, ptr(scale_shift), ptr(mean_invstd), stream()), "bn_finalize")
+
+
+def bn_eval_scale(gamma, beta, running_mean, running_var, eps, C, scale_shift):
+    check(lib().crog_bn_eval_scale(ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), C,
+                                   ptr(scale_shift), stream()), "bn_eval_scale")
+
+
+def bn_apply(z, scale_shift, res, relu: bool, y):
+    M, C, ldz = mat(z)
+    _, _, ldy = mat(y)
+    ldr = mat(res)[2] if res is not None else 0
+    check(lib().crog_bn_apply(dcode(z), ptr(z), ldz, ptr(scale_shift), ptr(res), ldr, int(relu), ptr(y), ldy, M, C, stream()),
+          "bn_apply")
+
+
+def bn_bwd_partial(dy, y, z, mean_invstd, rows_per_block, partial):
+    M, C, lddy = mat(dy)
+    ldy = mat(y)[2] if y is not None else 0
+    check(lib().crog_bn_bwd_partial(dcode(dy), ptr(dy), lddy, ptr(y), ldy, ptr(z), mat(z)[2], ptr(mean_invstd), M, C,
+                                    rows_per_block, ptr(partial), stream()), "bn_bwd_partial")
+
+
+def bn_bwd_apply(dy, y, z, mean_invstd, gamma, sums, count, dz, dres):
+    M, C, lddy = mat(dy)
+    ldy = mat(y)[2] if y is not None else 0
+    lddres = mat(dres)[2] if dres is not None else 0
+    check(lib().crog_bn_bwd_apply(dcode(dy), ptr(dy), lddy, ptr(y), ldy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(gamma),
+                                  ptr(sums), float(count), ptr(dz), mat(dz)[2], ptr(dres), lddres, M, C, stream()),
+          "bn_bwd_apply")
+
+
+# --------------------------------------------------------------------------------------------
+# LayerNorm / softmax
+# --------------------------------------------------------------------------------------------
+def ln_fwd(x, gamma, beta, eps, out, stats, res=None, out2=None, pos=None, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0):
+    M, C, ldx = mat(x)
+    pos_rows, ldp = (0, 0)
+    if pos is not None:
+        pos_rows, _, ldp = mat(pos)
+    check(lib().crog_ln_fwd(dcode(x), ptr(x), ldx, ptr(gamma), ptr(beta), float(eps), M, C, ptr(out), mat(out)[2], ptr(stats),
+                            ptr(res), mat(res)[2] if res is not None else 0, ptr(out2), mat(out2)[2] if out2 is not None else 0,
+                            ptr(pos), pos_rows, ldp, float(p_in), int(seed_in), float(p_out), int(seed_out), stream()), "ln_fwd")
+
+
+def ln_bwd_rows_per_block(M: int) -> int:
+    return max(4, (M + 511) // 512)
+
+
+def ln_bwd(dout, dout2, x, gamma, stats, dx, partial, rows_per_block, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0):
+    M, C, ldx = mat(x)
+    check(lib().crog_ln_bwd(dcode(x), ptr(dout), mat(dout)[2], ptr(dout2), mat(dout2)[2] if dout2 is not None else 0, ptr(x), ldx,
+                            ptr(gamma), ptr(stats), M, C, ptr(dx), mat(dx)[2], ptr(partial), rows_per_block, float(p_in),
+                            int(seed_in), float(p_out), int(seed_out), stream()), "ln_bwd")
+
+
+def softmax_fwd(S, rows, Lq, Lk, ldp, heads, causal, kpm, Pd, p_drop, seed):
+    check(lib().crog_softmax_fwd(dcode(S), ptr(S), rows, Lq, Lk, ldp, heads, int(causal), ptr(kpm), ptr(Pd), float(p_drop),
+                                 int(seed), stream()), "softmax_fwd")
+
+
+def softmax_bwd(P, dPd, rows, Lk, ldp, p_drop, seed):
+    check(lib().crog_softmax_bwd(dcode(P), ptr(P), ptr(dPd), rows, Lk, ldp, float(p_drop), int(seed), stream()), "softmax_bwd")
+
+
+# --------------------------------------------------------------------------------------------
+# streaming ops
+# --------------------------------------------------------------------------------------------
+def _nhwc(x):
+    B, H, W, C = x.shape
+    _, _, ld = mat(x)
+    return B, H, W, C, ld
+
+
+def avgpool2_fwd(x, y):
+    B, H, W, C, ld = _nhwc(x)
+    check(lib().crog_avgpool2_fwd(dcode(x), ptr(x), ld, ptr(y), mat(y)[2], B, H, W, C, stream()), "avgpool2_fwd")
+
+
+def avgpool2_bwd(dy, dx):
+    B, H, W, C, ld = _nhwc(dx)
+    check(lib().crog_avgpool2_bwd(dcode(dy), ptr(dy), mat(dy)[2], ptr(dx), ld, B, H, W, C, stream()), "avgpool2_bwd")
+
+
+def upsample2_fwd(x, y):
+    B, H, W, C, ld = _nhwc(x)
+    check(lib().crog_upsample2_fwd(dcode(x), ptr(x), ld, ptr(y), mat(y)[2], B, H, W, C, stream()), "upsample2_fwd")
+
+
+def upsample2_bwd(dy, dx):
+    B, H, W, C, ld = _nhwc(dx)
+    check(lib().crog_upsample2_bwd(dcode(dy), ptr(dy), mat(dy)[2], ptr(dx), ld, B, H, W, C, stream()), "upsample2_bwd")
+
+
+def embedding_fwd(word, tok, pos, out, L, vocab):
+    rows, C, _ = mat(out)
+    check(lib().crog_embedding_fwd(dcode(out), ptr(word), ptr(tok), ptr(pos), ptr(out), rows, L, C, vocab, stream()), "embedding_fwd")
+
+
+def embedding_bwd(word, dout, dtok, dpos, L, vocab):
+    rows, C, _ = mat(dout)
+    check(lib().crog_embedding_bwd(dcode(dout), ptr(word), ptr(dout), ptr(dtok), ptr(dpos), rows, L, C, vocab, stream()),
+          "embedding_bwd")
+
+
+def gather_rows(x, idx, out):
+    _, C, ldx = mat(x)
+    n, _, ldo = mat(out)
+    check(lib().crog_gather_rows(dcode(x), ptr(x), ldx, ptr(idx), ptr(out), ldo, n, C, stream()), "gather_rows")
+
+
+def scatter_rows(dout, idx, dx):
+    n, C, lddo = mat(dout)
+    check(lib().crog_scatter_rows(dcode(dout), ptr(dout), lddo, ptr(idx), ptr(dx), mat(dx)[2], n, C, stream()), "scatter_rows")
+
+
+def mul_bcast_fwd(x, s, z, B, P):
+    _, C, ldx = mat(x)
+    check(lib().crog_mul_bcast_fwd(dcode(x), ptr(x), ldx, ptr(s), mat(s)[2], ptr(z), mat(z)[2], B, P, C, stream()), "mul_bcast_fwd")
+
+
+def mul_bcast_bwd(dz, x, s, dx, ds, B, P):
+    _, C, ldx = mat(x)
+    check(lib().crog_mul_bcast_bwd(dcode(x), ptr(dz), mat(dz)[2], ptr(x), ldx, ptr(s), mat(s)[2], ptr(dx), mat(dx)[2], ptr(ds),
+                                   mat(ds)[2], B, P, C, stream()), "mul_bcast_bwd")
+
+
+def add_rows(a, b, out):
+    M, C, lda = mat(a)
+    brows, _, ldb = mat(b)
+    check(lib().crog_add_rows(dcode(a), ptr(a), lda, ptr(b), ldb, brows, ptr(out), mat(out)[2], M, C, stream()), "add_rows")
+
+
+def sum_over_batch(x, out, B, accumulate=False):
+    M, C, ldx = mat(x)
+    R = M // B
+    check(lib().crog_sum_over_batch(dcode(x), ptr(x), ldx, ptr(out), mat(out)[2], B, R, C, int(accumulate), stream()), "sum_over_batch")
+
+
+def add_dropout(a, b, out, p, seed):
+    M, C, ldb = mat(b)
+    check(lib().crog_add_dropout(dcode(b), ptr(a), mat(a)[2] if a is not None else 0, ptr(b), ldb, ptr(out), mat(out)[2], M, C,
+                                 float(p), int(seed), stream()), "add_dropout")
+
+
+def act_bwd(dy, y, dx, mode):
+    M, C, lddy = mat(dy)
+    check(lib().crog_act_bwd(dcode(dy), ptr(dy), lddy, ptr(y), mat(y)[2], ptr(dx), mat(dx)[2], M, C, mode, stream()), "act_bwd")
+
+
+def quickgelu_fwd(u, out):
+    M, C, ldu = mat(u)
+    check(lib().crog_quickgelu_fwd(dcode(u), ptr(u), ldu, ptr(out), mat(out)[2], M, C, stream()), "quickgelu_fwd")
+
+
+def stem_im2col(img, out):
+    B, _, H, W = img.shape
+    check(lib().crog_stem_im2col(dcode(out), ptr(img), ptr(out), B, H, W, stream()), "stem_im2col")
+
+
+def cast_pad2d(src, lds, cols_src, dst, ldd, cols_dst, rows, src_off=0, dst_off=0):
+    dt = dcode(dst)
+    sz = 2 if dt == BF16 else 4
+    check(lib().crog_cast_pad2d(dt, ptr(src) + 4 * src_off, lds, cols_src, ptr(dst) + sz * dst_off, ldd, cols_dst, rows, stream()),
+          "cast_pad2d")
+
+
+def cast_f32_to_bf16(src, dst, n):
+    check(lib().crog_cast_f32_to_bf16(ptr(src), ptr(dst), n, stream()), "cast_f32_to_bf16")
+
+
+def cast_to_f32(src, dst):
+    M, C, lds = mat(src)
+    check(lib().crog_cast_to_f32(dcode(src), ptr(src), lds, ptr(dst), mat(dst)[2], M, C, stream()), "cast_to_f32")
+
+
+def coord_fill(buf, c0, cend):
+    B, H, W, _, ld = _nhwc(buf)
+    check(lib().crog_coord_fill(dcode(buf), ptr(buf), ld, B, H, W, c0, cend, stream()), "coord_fill")
+
+
+def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, shadow=None, off=0):
+    sh = None if shadow is None else ptr(shadow) + 2 * off
+    check(lib().crog_adam_step(ptr(p) + 4 * off, ptr(g) + 4 * off, ptr(m) + 4 * off, ptr(v) + 4 * off, n, float(lr), float(beta1),
+                               float(beta2), float(eps), float(wd), int(step), sh, stream()), "adam_step")
+
+
+# --------------------------------------------------------------------------------------------
+# head
+# --------------------------------------------------------------------------------------------
+def head_pack_weights(word, wpad, B, C):
+    check(lib().crog_head_pack_weights(dcode(wpad), ptr(word), mat(word)[2], ptr(wpad), B, C, stream()), "head_pack_weights")
+
+
+def head_unpack_wgrad(dwpad, dbias, dword, B, C):
+    check(lib().crog_head_unpack_wgrad(dcode(dword), ptr(dwpad), ptr(dbias), ptr(dword), mat(dword)[2], B, C, stream()),
+          "head_unpack_wgrad")
+
+
+def head_stencil_fwd(t, word, bias_col, out, B, heads, H, W):
+    check(lib().crog_head_stencil_fwd(ptr(t), ptr(word), mat(word)[2], bias_col, ptr(out), B, heads, H, W, stream()), "head_stencil_fwd")
+
+
+def head_stencil_bwd(dout, dt, dbias, B, heads, H, W):
+    check(lib().crog_head_stencil_bwd(dcode(dt), ptr(dout), ptr(dt), ptr(dbias), B, heads, H, W, stream()), "head_stencil_bwd")
+
+
+def head_loss(pred, targets, Hin, Win, weighted, tgt_small, loss_sums, dpred):
+    B, heads, H, W = pred.shape
+    arr = (ctypes.c_void_p * 5)(*[ptr(t) for t in targets] + [None] * (5 - len(targets)))
+    check(lib().crog_head_loss(ptr(pred), ctypes.cast(arr, ctypes.c_void_p), B, heads, H, W, Hin, Win, int(weighted), ptr(tgt_small),
+                               ptr(loss_sums), ptr(dpred), stream()), "head_loss")
+
+
+def train_metric(pred, pred_bstride, tgt, B, P, threshold, pr_iou, counts, out2):
+    check(lib().crog_train_metric(ptr(pred), pred_bstride, ptr(tgt), B, P, float(threshold), float(pr_iou), ptr(counts), ptr(out2),
+                                  stream()), "train_metric")

@@ -1,0 +1,241 @@
+/*
+ * crog_hip.h — C ABI of libcrog_hip.so, the MI355X (gfx950) kernel library behind
+ * crog_amd's drop-in CROG module.
+ *
+ * The reference (HilbertXu/CROG) has no FFI layer: its hot path calls torch.nn / ATen ops
+ * from Python.  Each entry point below therefore names the reference
+ * call site(s) (file:line under the reference tree) whose ATen op it replaces.  A reference
+ * maintainer binds these with ctypes exactly as crog_amd/_lib.py does.
+ *
+ * Conventions
+ *  - every function returns 0 (CROG_OK) or a negative crog_status; crog_last_error() gives text
+ *  - nothing here allocates, frees or synchronises: all buffers are caller-owned device
+ *    memory, work is enqueued on the hipStream_t passed as `stream`, and every launch is
+ *    legal inside hipGraph stream capture
+ *  - `dtype` selects the activation/compute storage type: CROG_F32 or CROG_BF16
+ *    (accumulation, statistics and reductions are always fp32)
+ *  - activations are channels-last: a feature map is [B*H*W, C] row-major with an explicit
+ *    row stride `ld` (elements), so channel concatenation is a pointer offset
+ */
+#ifndef CROG_HIP_H
+#define CROG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* crog_stream_t; /* hipStream_t */
+
+enum crog_dtype { CROG_F32 = 0, CROG_BF16 = 1 };
+enum crog_status { CROG_OK = 0, CROG_ERR_ARG = -1, CROG_ERR_LAUNCH = -2 };
+
+int crog_hip_version(void);
+const char* crog_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM convolution family (MFMA 32x32x16 bf16, 32x32x2 f32).
+ *   C[z][m][n] = epilogue( alpha * sum_k Aop(z,m,k) * Bop(z,n,k) )
+ * Replaces: F.conv2d 1x1 / 3x3 (clip.py:17-25,47-50; layers.py:8-11,55-58), nn.Linear
+ * (clip.py:70-73,249-251; layers.py:14-16,62,298-301), the packed in_proj / out_proj GEMMs and
+ * the QK^T / PV batched products inside F.multi_head_attention_forward (clip.py:119-139,
+ * clip.py:259; layers.py:324,329), and their autograd backward (dgrad / wgrad).
+ * ---------------------------------------------------------------------------------------- */
+enum crog_a_layout {
+  CROG_A_KC = 0,     /* A[m][k], k contiguous, row stride lda                                   */
+  CROG_A_IM2COL = 1, /* A = 3x3/pad1/stride1 patches of an NHWC map [B,H,W,convC] (row stride
+                        lda); k = tap*convC + c, tap = ky*3+kx; M = B*H*W                        */
+  CROG_A_MC = 2      /* A stored transposed: A_mem[k][m], m contiguous, row stride lda           */
+};
+enum crog_b_layout {
+  CROG_B_KC = 0,        /* B[n][k], k contiguous, row stride ldb (torch Linear / KRSC conv weight) */
+  CROG_B_NC = 1,        /* B_mem[k][n], n contiguous, row stride ldb                              */
+  CROG_B_NC_DGRAD = 2,  /* conv3x3 data-gradient weights read in place from KRSC storage
+                           W[co][tap][ci] (row stride ldb = Cin): k = tap'*convC + co reads
+                           W[co][8-tap'][n]                                                      */
+  CROG_B_NC_IM2COL = 3  /* wgrad of conv3x3: B_mem[k = pixel][n = tap*convC + c] gathered from an
+                           NHWC map [B,H,W,convC] (row stride ldb); K = B*H*W                    */
+};
+enum crog_act { CROG_ACT_NONE = 0, CROG_ACT_RELU = 1, CROG_ACT_QUICKGELU = 2 };
+enum crog_out_mode {
+  CROG_OUT_T = 0,         /* store as dtype                                                      */
+  CROG_OUT_F32 = 1,       /* store fp32                                                          */
+  CROG_OUT_F32_ATOMIC = 2 /* atomicAdd fp32 (required when splitk > 1; C must be pre-zeroed or
+                             hold the value to accumulate onto)                                  */
+};
+
+typedef struct crog_gemm_desc {
+  int dtype;     /* crog_dtype of A, B, R and (for CROG_OUT_T) C */
+  int a_layout;  /* crog_a_layout */
+  int b_layout;  /* crog_b_layout */
+  const void* A;
+  const void* B;
+  void* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc; /* row strides in elements */
+  /* batching: z in [0,batch); zo = z / batch_inner, zi = z % batch_inner;
+     X += zo*sXo + zi*sXi (elements).  batch_inner >= 1. */
+  int batch, batch_inner;
+  int64_t sAo, sAi, sBo, sBi, sCo, sCi;
+  int splitk; /* >= 1; K range split across blocks (needs CROG_OUT_F32_ATOMIC if > 1) */
+  /* 3x3 geometry for the IM2COL / DGRAD layouts */
+  int convH, convW, convC;
+  /* epilogue */
+  float alpha;
+  const float* bias; /* [N] fp32 or NULL, added before act */
+  int act;           /* crog_act */
+  const void* R;     /* residual [M][N] (dtype), added after act, or NULL (unbatched only) */
+  int64_t ldr;
+  int out_mode;      /* crog_out_mode */
+  float* col_stats;  /* NULL, or [ceil(M/128)][N][2] fp32 partial (sum, sum of squares) over the
+                        rows of each 128-row tile of v = alpha*acc + bias (BatchNorm statistics,
+                        clip.py:18,21,26; layers.py:11).  batch must be 1, splitk 1. */
+} crog_gemm_desc;
+
+int crog_gemm(const crog_gemm_desc* d, crog_stream_t stream);
+/* number of 128-row tiles (= rows of the col_stats slab) for a given M */
+int crog_gemm_stat_tiles(int M);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm, training mode with optional cross-replica statistics (nn.BatchNorm2d/1d under
+ * SyncBatchNorm: clip.py:18,21,26,42,78,171-183; layers.py:11,16,351; train_crog.py:113-114).
+ * Statistics travel as per-channel pairs [C][2]:
+ *   forward  pairs = (sum x, sum x^2)       backward pairs = (sum g, sum g*xhat)
+ * so that the caller can all-reduce `sums` across ranks between reduce and finalize/apply.
+ * ---------------------------------------------------------------------------------------- */
+int crog_bn_stat_blocks(int64_t M, int rows_per_block);
+int crog_bn_partial_stats(int dtype, const void* x, int64_t M, int C, int64_t ld, int rows_per_block,
+                          float* partial, crog_stream_t stream);
+int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, crog_stream_t stream);
+int crog_split_pairs(const float* sums, int C, float* a, float* b, crog_stream_t stream);
+int crog_bn_finalize(const float* sums, float count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, int C,
+                     float* scale_shift, float* mean_invstd, crog_stream_t stream);
+int crog_bn_eval_scale(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int C, float* scale_shift,
+                       crog_stream_t stream);
+/* y = [relu](z*scale + shift [+ res])  — bn + residual add + ReLU of Bottleneck (clip.py:47-56) */
+int crog_bn_apply(int dtype, const void* z, int64_t ldz, const float* scale_shift, const void* res,
+                  int64_t ldr, int relu, void* y, int64_t ldy, int64_t M, int C, crog_stream_t stream);
+/* g = dy * (y > 0) when y != NULL;  partial[block][C][2] = (sum g, sum g*xhat) */
+int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
+                        int64_t ldz, const float* mean_invstd, int64_t M, int C, int rows_per_block,
+                        float* partial, crog_stream_t stream);
+/* dz = gamma*invstd*(g - sums.g/count - xhat*sums.gx/count);  dres = g when dres != NULL */
+int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
+                      int64_t ldz, const float* mean_invstd, const float* gamma, const float* sums,
+                      float count, void* dz, int64_t lddz, void* dres, int64_t lddres, int64_t M, int C,
+                      crog_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm (fp32 math; clip.py:226-231, layers.py:192,288-305) with the decoder's surrounding
+ * dropout / residual / positional adds fused (layers.py:310-338):
+ *   y = LN(dropout_in(x));  out = res + dropout_out(y);  out2 = out + pos[row % pos_rows]
+ * res / out2 / pos may be NULL; stats[row] = (mean, rstd) is kept for backward.
+ * ---------------------------------------------------------------------------------------- */
+int crog_ln_fwd(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                int64_t M, int C, void* out, int64_t ldo, float* stats, const void* res, int64_t ldr,
+                void* out2, int64_t ldo2, const void* pos, int pos_rows, int64_t ldp, float p_in,
+                uint64_t seed_in, float p_out, uint64_t seed_out, crog_stream_t stream);
+int crog_ln_bwd_blocks(int64_t M, int rows_per_block);
+/* dx from g = dout (+ dout2); partial[block][C][2] = (dgamma, dbeta) partial sums (zeroed inside) */
+int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void* dout2, int64_t lddo2, const void* x,
+                int64_t ldx, const float* gamma, const float* stats, int64_t M, int C, void* dx,
+                int64_t lddx, float* partial, int rows_per_block, float p_in, uint64_t seed_in,
+                float p_out, uint64_t seed_out, crog_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Masked softmax over attention scores S[batch*heads*Lq][ldp] in place (the softmax inside
+ * F.multi_head_attention_forward: causal text mask clip.py:424-430, key_padding_mask
+ * layers.py:332 / crog.py:55, attention dropout layers.py:291-296).  Pd = dropout(P) or NULL.
+ * ---------------------------------------------------------------------------------------- */
+int crog_softmax_fwd(int dtype, void* S, int64_t rows, int Lq, int Lk, int ldp, int heads, int causal,
+                     const uint8_t* key_padding_mask, void* Pd, float p_drop, uint64_t seed,
+                     crog_stream_t stream);
+int crog_softmax_bwd(int dtype, const void* P, void* dPd, int64_t rows, int Lk, int ldp, float p_drop,
+                     uint64_t seed, crog_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Streaming ops on channels-last maps [B,H,W,C] / row matrices [M,C]
+ * ---------------------------------------------------------------------------------------- */
+/* nn.AvgPool2d(2): clip.py:23,35,184; F.avg_pool2d layers.py:386 */
+int crog_avgpool2_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C,
+                      crog_stream_t stream);
+int crog_avgpool2_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int H, int W,
+                      int C, crog_stream_t stream);
+/* bilinear x2, align_corners=False: layers.py:54,56,382,393.  (H, W) is the INPUT size. */
+int crog_upsample2_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C,
+                       crog_stream_t stream);
+int crog_upsample2_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int H, int W,
+                       int C, crog_stream_t stream);
+/* token_embedding(text) + positional_embedding[:L]: clip.py:440-443 */
+int crog_embedding_fwd(int dtype, const int64_t* word, const void* tok, const void* pos, void* out,
+                       int64_t rows, int L, int C, int vocab, crog_stream_t stream);
+int crog_embedding_bwd(int dtype, const int64_t* word, const void* dout, float* dtok, float* dpos,
+                       int64_t rows, int L, int C, int vocab, crog_stream_t stream);
+/* x[arange(B), text.argmax(-1)]: clip.py:451-452 */
+int crog_gather_rows(int dtype, const void* x, int64_t ldx, const int64_t* idx, void* out, int64_t ldo,
+                     int64_t n, int C, crog_stream_t stream);
+int crog_scatter_rows(int dtype, const void* dout, int64_t lddo, const int64_t* idx, void* dx, int64_t lddx,
+                      int64_t n, int C, crog_stream_t stream);
+/* f5 * state broadcast over pixels: layers.py:379 */
+int crog_mul_bcast_fwd(int dtype, const void* x, int64_t ldx, const void* s, int64_t lds, void* z, int64_t ldz,
+                       int B, int P, int C, crog_stream_t stream);
+int crog_mul_bcast_bwd(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, const void* s,
+                       int64_t lds, void* dx, int64_t lddx, void* ds, int64_t ldds, int B, int P, int C,
+                       crog_stream_t stream);
+/* out = a + b[row % brows]: residual adds and positional broadcasts (clip.py:117,443; layers.py:311) */
+int crog_add_rows(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, int64_t brows, void* out,
+                  int64_t ldo, int64_t M, int C, crog_stream_t stream);
+/* out[r] (fp32) (+)= sum_b x[b*R + r]: gradient of a batch-broadcast positional table */
+int crog_sum_over_batch(int dtype, const void* x, int64_t ldx, float* out, int64_t ldo, int B, int64_t R, int C,
+                        int accumulate, crog_stream_t stream);
+/* out = a + dropout(b) (a may be NULL: out = dropout(b)): layers.py:326,334,338 and their backward */
+int crog_add_dropout(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo,
+                     int64_t M, int C, float p, uint64_t seed, crog_stream_t stream);
+/* mode 0: dx = dy*(y>0) (ReLU, y = output);  mode 1: QuickGELU backward, y = pre-activation */
+int crog_act_bwd(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, void* dx, int64_t lddx,
+                 int64_t M, int C, int mode, crog_stream_t stream);
+/* QuickGELU x*sigmoid(1.702x): clip.py:234-236 */
+int crog_quickgelu_fwd(int dtype, const void* u, int64_t ldu, void* out, int64_t ldo, int64_t M, int C,
+                       crog_stream_t stream);
+/* stem conv1 (3->32, 3x3, stride 2, pad 1; clip.py:165-170): NCHW fp32 image -> patch rows
+ * [B*(H/2)*(W/2)][32], column (ky*3+kx)*3+ci, columns 27..31 zero; the conv is then crog_gemm */
+int crog_stem_im2col(int dtype, const float* img, void* out, int B, int H, int W, crog_stream_t stream);
+/* dst[r][c] = c < cols_src ? src[r][c] : 0 for c < cols_dst (fp32 source) */
+int crog_cast_pad2d(int dtype_dst, const float* src, int64_t lds, int cols_src, void* dst, int64_t ldd,
+                    int cols_dst, int64_t rows, crog_stream_t stream);
+int crog_cast_f32_to_bf16(const float* src, void* dst, int64_t n, crog_stream_t stream);
+int crog_cast_to_f32(int dtype, const void* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C,
+                     crog_stream_t stream);
+/* CoordConv coordinate channels: layers.py:30-39 */
+int crog_coord_fill(int dtype, void* buf, int64_t ld, int B, int H, int W, int c0, int cend,
+                    crog_stream_t stream);
+/* torch.optim.Adam step over one flat fp32 segment (train_crog.py:119-121, crog_engine.py:83) */
+int crog_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, void* bf16_shadow, crog_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Text-conditioned dynamic conv head, losses, metric
+ * (layers.py:64-132,152-173; crog.py:76-111,119-131; utils/misc.py:115-131)
+ * ---------------------------------------------------------------------------------------- */
+int crog_head_pack_weights(int dtype, const float* word, int64_t ldw, void* wpad, int B, int C,
+                           crog_stream_t stream);
+int crog_head_unpack_wgrad(int dtype, const float* dwpad, const float* dbias, void* dword, int64_t ldd, int B,
+                           int C, crog_stream_t stream);
+int crog_head_stencil_fwd(const float* t, const float* word, int64_t ldw, int bias_col, float* out, int B,
+                          int heads, int H, int W, crog_stream_t stream);
+int crog_head_stencil_bwd(int dtype, const float* dout, void* dt, float* dbias, int B, int heads, int H, int W,
+                          crog_stream_t stream);
+/* targets: host array of `heads` device pointers, each fp32 [B][1][Hin][Win] */
+int crog_head_loss(const float* pred, const float* const* targets, int B, int heads, int H, int W, int Hin,
+                   int Win, int weighted, float* tgt_small, float* loss_sums, float* dpred,
+                   crog_stream_t stream);
+int crog_train_metric(const float* pred, int64_t pred_bstride, const float* tgt, int B, int64_t P,
+                      float threshold, float pr_iou, float* counts, float* out2, crog_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CROG_HIP_H */

@@ -1,0 +1,497 @@
+"""Kernel-level parity: every HIP kernel against a plain torch fp32 computation of the same op.
+
+These run on the GPU box (`-m gpu`) and call through the C ABI (crog_amd.kernels -> libcrog_hip.so).
+torch ops are used here only as the checker.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dt, k=1):
+    # fp32 path: exact-f32 MFMA, differences are summation order only. bf16: inputs rounded to 8 bits.
+    return (2e-5, 2e-5) if dt == torch.float32 else (2e-2, 2e-2)
+
+
+def close(a, b, dt, scale=1.0):
+    rt, at = tol(dt)
+    a = a.float()
+    b = b.float()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-6
+    assert err <= at * scale * max(ref, 1.0) + rt * ref, f"max err {err} vs ref max {ref}"
+
+
+@pytest.fixture(scope="module")
+def K():
+    from crog_amd import kernels
+    kernels.lib()
+    return kernels
+
+
+def rnd(*shape, dt=torch.float32, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g).to("cuda").to(dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (200, 72, 40), (1000, 320, 256), (37, 9, 16), (676, 676, 64)])
+def test_gemm_nt(K, dt, M, N, K_):
+    a, b = rnd(M, K_, dt=dt), rnd(N, K_, dt=dt, seed=1)
+    c = torch.empty(M, N, device="cuda", dtype=dt) if N % 8 == 0 else torch.empty(M, ((N + 7) // 8) * 8, device="cuda", dtype=dt)
+    ldc = c.stride(0)
+    K.gemm(K.dcode(dt), K.A_KC, K.B_KC, a, b, c, M, N, K_, K_, K_, ldc)
+    ref = a.float() @ b.float().t()
+    close(c[:, :N], ref, dt, scale=math.sqrt(K_) / 4)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_epilogue(K, dt):
+    M, N, K_ = 300, 136, 96
+    a, b = rnd(M, K_, dt=dt), rnd(N, K_, dt=dt, seed=1)
+    bias = rnd(N, seed=2)
+    r = rnd(M, N, dt=dt, seed=3)
+    for act in (K.ACT_NONE, K.ACT_RELU, K.ACT_QUICKGELU):
+        c = torch.empty(M, N, device="cuda", dtype=dt)
+        K.gemm(K.dcode(dt), K.A_KC, K.B_KC, a, b, c, M, N, K_, K_, K_, N, alpha=0.5, bias=bias, act=act, R=r, ldr=N)
+        v = 0.5 * (a.float() @ b.float().t()) + bias
+        if act == K.ACT_RELU:
+            v = v.relu()
+        elif act == K.ACT_QUICKGELU:
+            v = v * torch.sigmoid(1.702 * v)
+        close(c, v + r.float(), dt, scale=3)
+    # fp32 output + column statistics
+    c32 = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    stats = torch.zeros(K.stat_tiles(M), N, 2, device="cuda")
+    K.gemm(K.dcode(dt), K.A_KC, K.B_KC, a, b, c32, M, N, K_, K_, K_, N, out_mode=K.OUT_F32, col_stats=stats)
+    ref = a.float() @ b.float().t()
+    close(c32, ref, dt, scale=3)
+    s = stats.sum(0)
+    close(s[:, 0], ref.sum(0), dt, scale=30)
+    close(s[:, 1], (ref * ref).sum(0), dt, scale=300)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (250, 72, 44), (676, 64, 676), (64, 2048, 49)])
+def test_gemm_nn(K, dt, M, N, K_):
+    # A[m][k] k-contig (K padded to a multiple of 8 with zeros), B_mem[k][n] n-contig
+    Kp = ((K_ + 7) // 8) * 8
+    a = torch.zeros(M, Kp, device="cuda", dtype=dt)
+    a[:, :K_] = rnd(M, K_, dt=dt)
+    b = rnd(K_, N, dt=dt, seed=1)
+    c = torch.empty(M, N, device="cuda", dtype=dt)
+    # K = Kp for the K-contiguous operand; rows >= K_ of B do not exist -> pass K_ and rely on A's zero pad
+    bp = torch.zeros(Kp, N, device="cuda", dtype=dt)
+    bp[:K_] = b
+    K.gemm(K.dcode(dt), K.A_KC, K.B_NC, a, bp, c, M, N, Kp, Kp, N, N)
+    close(c, a[:, :K_].float() @ b.float(), dt, scale=math.sqrt(K_) / 4)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K_,split", [(64, 64, 5000, 8), (200, 136, 333, 1), (256, 512, 2048, 4), (49, 2048, 169, 1)])
+def test_gemm_tn(K, dt, M, N, K_, split):
+    # wgrad shape: C[m][n] = sum_k A_mem[k][m] * B_mem[k][n]
+    a, b = rnd(K_, M, dt=dt), rnd(K_, N, dt=dt, seed=1)
+    c = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+    K.gemm(K.dcode(dt), K.A_MC, K.B_NC, a, b, c, M, N, K_, M, N, N, splitk=split,
+           out_mode=K.OUT_F32_ATOMIC if split > 1 else K.OUT_F32)
+    close(c, a.float().t() @ b.float(), dt, scale=math.sqrt(K_) / 4)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_tn_kc(K, dt):
+    M, N, K_ = 72, 200, 512
+    a, b = rnd(K_, M, dt=dt), rnd(N, K_, dt=dt, seed=1)
+    c = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+    K.gemm(K.dcode(dt), K.A_MC, K.B_KC, a, b, c, M, N, K_, M, K_, N, out_mode=K.OUT_F32)
+    close(c, a.float().t() @ b.float().t(), dt, scale=math.sqrt(K_) / 4)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_batched_heads(K, dt):
+    # attention-style: q,k from a packed [B*L, 3E] buffer; scores S[b,h] = q k^T; out = P v
+    B, H, L, dh = 3, 4, 50, 64
+    E = H * dh
+    qkv = rnd(B * L, 3 * E, dt=dt)
+    Lp = ((L + 7) // 8) * 8
+    S = torch.zeros(B * H, L, Lp, device="cuda", dtype=dt)
+    K.gemm(K.dcode(dt), K.A_KC, K.B_KC, qkv, qkv, S, L, L, dh, 3 * E, 3 * E, Lp, batch=B * H, batch_inner=H,
+           sA=(L * 3 * E, dh), sB=(L * 3 * E, dh), sC=(H * L * Lp, L * Lp), b_off=E, alpha=0.125)
+    q = qkv[:, :E].float().view(B, L, H, dh).permute(0, 2, 1, 3)
+    k = qkv[:, E:2 * E].float().view(B, L, H, dh).permute(0, 2, 1, 3)
+    v = qkv[:, 2 * E:].float().view(B, L, H, dh).permute(0, 2, 1, 3)
+    ref = 0.125 * q @ k.transpose(-1, -2)
+    close(S.view(B, H, L, Lp)[..., :L], ref, dt, scale=2)
+    # O = P V with P = S (pad cols are zero), V n-contiguous
+    O = torch.empty(B * L, E, device="cuda", dtype=dt)
+    K.gemm(K.dcode(dt), K.A_KC, K.B_NC, S, qkv, O, L, dh, Lp, Lp, 3 * E, E, batch=B * H, batch_inner=H,
+           sA=(H * L * Lp, L * Lp), sB=(L * 3 * E, dh), sC=(L * E, dh), b_off=2 * E)
+    refo = (S.view(B, H, L, Lp)[..., :L].float() @ v).permute(0, 2, 1, 3).reshape(B * L, E)
+    close(O, refo, dt, scale=8)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 13, 13, 64, 96), (1, 26, 20, 32, 32), (3, 8, 8, 128, 256)])
+def test_conv3x3_fwd_dgrad_wgrad(K, dt, B, H, W, Cin, Cout):
+    x = rnd(B, H, W, Cin, dt=dt)
+    w = (rnd(Cout, 3, 3, Cin, dt=dt, seed=1) * 0.1).to(dt)  # KRSC
+    M = B * H * W
+    y = torch.empty(B, H, W, Cout, device="cuda", dtype=dt)
+    stats = torch.zeros(K.stat_tiles(M), Cout, 2, device="cuda")
+    K.gemm(K.dcode(dt), K.A_IM2COL, K.B_KC, x, w, y, M, Cout, 9 * Cin, Cin, 9 * Cin, Cout, conv=(H, W, Cin), col_stats=stats)
+    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wt = w.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.conv2d(xt, wt, padding=1)
+    close(y, ref.permute(0, 2, 3, 1), dt, scale=math.sqrt(9 * Cin) / 4)
+    close(stats.sum(0)[:, 0], ref.sum((0, 2, 3)), dt, scale=40)
+    dy = rnd(B, H, W, Cout, dt=dt, seed=5)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    dx = torch.empty(B, H, W, Cin, device="cuda", dtype=dt)
+    K.gemm(K.dcode(dt), K.A_IM2COL, K.B_NC_DGRAD, dy, w, dx, M, Cin, 9 * Cout, Cout, Cin, Cin, conv=(H, W, Cout))
+    close(dx, xt.grad.permute(0, 2, 3, 1), dt, scale=math.sqrt(9 * Cout) / 4)
+    dw = torch.zeros(Cout, 9 * Cin, device="cuda", dtype=torch.float32)
+    K.gemm(K.dcode(dt), K.A_MC, K.B_NC_IM2COL, dy, x, dw, Cout, 9 * Cin, M, Cout, Cin, 9 * Cin, conv=(H, W, Cin), splitk=3,
+           out_mode=K.OUT_F32_ATOMIC)
+    close(dw.view(Cout, 3, 3, Cin), wt.grad.permute(0, 2, 3, 1), dt, scale=math.sqrt(M) / 2)
+
+
+def test_gemm_hwtr_matches_fallback(K):
+    """ds_read_b64_tr_b16 fragment path == scalar LDS read path (run in a subprocess with the env switch)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch, sys; sys.path.insert(0, %r); from crog_amd import kernels as K;"
+        "g=torch.Generator().manual_seed(1); a=torch.randn(300,72,generator=g).cuda().bfloat16(); b=torch.randn(300,200,generator=g).cuda().bfloat16();"
+        "c=torch.zeros(72,200,device='cuda'); K.gemm(1,K.A_MC,K.B_NC,a,b,c,72,200,300,72,200,200,out_mode=K.OUT_F32);"
+        "torch.cuda.synchronize(); ref=a.float().t()@b.float(); print(float((c-ref).abs().max()))"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, CROG_GEMM_NO_HWTR=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs.append(float(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] < 0.5 and outs[1] < 0.5, outs
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DT)
+def test_batchnorm_train_fwd_bwd(K, dt):
+    M, C = 1000, 64
+    z = (rnd(M, C, dt=dt) * 2 + 0.5).to(dt)
+    res = rnd(M, C, dt=dt, seed=3)
+    gamma, beta = rnd(C, seed=1).abs() + 0.5, rnd(C, seed=2)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    rpb = 64
+    nb = (M + rpb - 1) // rpb
+    partial = torch.empty(nb, C, 2, device="cuda")
+    K.bn_partial_stats(z, partial, rpb)
+    sums = torch.empty(C, 2, device="cuda")
+    K.reduce_pairs(partial, nb, C, sums)
+    ss, mi = torch.empty(C, 2, device="cuda"), torch.empty(C, 2, device="cuda")
+    K.bn_finalize(sums, M, gamma, beta, rm, rv, 0.1, 1e-5, C, ss, mi)
+    y = torch.empty_like(z)
+    K.bn_apply(z, ss, res, True, y)
+    zt = z.float().requires_grad_(True)
+    rt = res.float().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm2, rv2 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    ref = F.relu(F.batch_norm(zt, rm2, rv2, g_, b_, True, 0.1, 1e-5) + rt)
+    close(y, ref, dt, scale=2)
+    assert torch.allclose(rm, rm2, atol=1e-4) and torch.allclose(rv, rv2, atol=1e-3)
+    dy = rnd(M, C, dt=dt, seed=9)
+    # use the kernel's own y for the relu mask so that rounding of y near 0 cannot flip the comparison
+    ref2 = F.relu(F.batch_norm(zt, None, None, g_, b_, True, 0.1, 1e-5) + rt)
+    mask = (y.float() > 0).float()
+    (ref2 * 0 + (F.batch_norm(zt, None, None, g_, b_, True, 0.1, 1e-5) + rt) * mask).backward(dy.float())
+    K.bn_bwd_partial(dy, y, z, mi, rpb, partial)
+    K.reduce_pairs(partial, nb, C, sums)
+    dz, dres = torch.empty_like(z), torch.empty_like(z)
+    K.bn_bwd_apply(dy, y, z, mi, gamma, sums, M, dz, dres)
+    close(dz, zt.grad, dt, scale=4)
+    close(dres, rt.grad, dt)
+    close(sums[:, 0], b_.grad, dt, scale=30)
+    close(sums[:, 1], g_.grad, dt, scale=30)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("C", [512, 2048, 768])
+def test_layernorm(K, dt, C):
+    M, R = 300, 100
+    x, res, pos = rnd(M, C, dt=dt), rnd(M, C, dt=dt, seed=1), rnd(R, C, dt=dt, seed=2)
+    g, b = rnd(C, seed=3), rnd(C, seed=4)
+    out, out2 = torch.empty_like(x), torch.empty_like(x)
+    stats = torch.empty(M, 2, device="cuda")
+    K.ln_fwd(x, g, b, 1e-5, out, stats, res=res, out2=out2, pos=pos)
+    xt = x.float().requires_grad_(True)
+    gt, bt = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xt, (C,), gt, bt, 1e-5) + res.float()
+    close(out, ref, dt, scale=2)
+    close(out2, ref + pos.float().repeat(M // R, 1), dt, scale=2)
+    d1, d2 = rnd(M, C, dt=dt, seed=5), rnd(M, C, dt=dt, seed=6)
+    ref.backward(d1.float() + d2.float())
+    rpb = K.ln_bwd_rows_per_block(M)
+    nb = (M + rpb - 1) // rpb
+    partial = torch.empty(nb, C, 2, device="cuda")
+    dx = torch.empty_like(x)
+    K.ln_bwd(d1, d2, x, g, stats, dx, partial, rpb)
+    close(dx, xt.grad, dt, scale=4)
+    sums = torch.empty(C, 2, device="cuda")
+    K.reduce_pairs(partial, nb, C, sums)
+    close(sums[:, 0], gt.grad, dt, scale=40)
+    close(sums[:, 1], bt.grad, dt, scale=40)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_layernorm_dropout_consistency(K, dt):
+    # dropout masks are recomputed in backward from (seed, index): d(out)/d(x) must use the same mask
+    M, C = 64, 512
+    x = rnd(M, C, dt=dt)
+    g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    out = torch.empty_like(x)
+    stats = torch.empty(M, 2, device="cuda")
+    K.ln_fwd(x, g, b, 1e-5, out, stats, p_out=0.5, seed_out=123)
+    frac = (out.float() == 0).float().mean().item()
+    assert 0.4 < frac < 0.6
+    dx = torch.empty_like(x)
+    partial = torch.empty(16, C, 2, device="cuda")
+    K.ln_bwd(torch.ones_like(x), None, x, g, stats, dx, partial, 4, p_out=0.5, seed_out=123)
+    sums = torch.empty(C, 2, device="cuda")
+    K.reduce_pairs(partial, 16, C, sums)
+    kept = (out.float() != 0).float()
+    close(sums[:, 1], 2.0 * kept.sum(0), dt, scale=2)  # dbeta = sum of kept * 1/(1-p)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_softmax(K, dt):
+    B, H, Lq, Lk = 2, 3, 40, 20
+    ldp = 24
+    S = torch.zeros(B * H * Lq, ldp, device="cuda", dtype=dt)
+    S[:, :Lk] = rnd(B * H * Lq, Lk, dt=dt)
+    kpm = torch.zeros(B, Lk, dtype=torch.bool, device="cuda")
+    kpm[0, 15:] = True
+    kpm[1, 7:] = True
+    s0 = S.clone()
+    K.softmax_fwd(S, B * H * Lq, Lq, Lk, ldp, H, False, kpm, None, 0.0, 0)
+    st = s0[:, :Lk].float().view(B, H, Lq, Lk).requires_grad_(True)
+    ref = torch.softmax(st.masked_fill(kpm[:, None, None, :], float("-inf")), -1)
+    close(S[:, :Lk].view(B, H, Lq, Lk), ref, dt)
+    assert (S[:, Lk:] == 0).all()
+    dP = torch.zeros_like(S)
+    dP[:, :Lk] = rnd(B * H * Lq, Lk, dt=dt, seed=4)
+    ref.backward(dP[:, :Lk].float().view(B, H, Lq, Lk))
+    K.softmax_bwd(S, dP, B * H * Lq, Lk, ldp, 0.0, 0)
+    close(dP[:, :Lk].view(B, H, Lq, Lk), st.grad, dt)
+    # causal
+    L = 20
+    S2 = torch.zeros(H * L, ldp, device="cuda", dtype=dt)
+    S2[:, :L] = rnd(H * L, L, dt=dt, seed=8)
+    ref2 = torch.softmax(S2[:, :L].float().view(H, L, L) + torch.full((L, L), float("-inf"), device="cuda").triu(1), -1)
+    K.softmax_fwd(S2, H * L, L, L, ldp, H, True, None, None, 0.0, 0)
+    close(S2[:, :L].view(H, L, L), ref2, dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_pool_upsample(K, dt):
+    B, H, W, C = 2, 6, 10, 32
+    x = rnd(B, H, W, C, dt=dt)
+    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    y = torch.empty(B, H // 2, W // 2, C, device="cuda", dtype=dt)
+    K.avgpool2_fwd(x, y)
+    ref = F.avg_pool2d(xt, 2)
+    close(y, ref.permute(0, 2, 3, 1), dt)
+    dy = rnd(B, H // 2, W // 2, C, dt=dt, seed=2)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    dx = torch.empty_like(x)
+    K.avgpool2_bwd(dy, dx)
+    close(dx, xt.grad.permute(0, 2, 3, 1), dt)
+    xt.grad = None
+    up = torch.empty(B, 2 * H, 2 * W, C, device="cuda", dtype=dt)
+    K.upsample2_fwd(x, up)
+    ref = F.interpolate(xt, scale_factor=2, mode="bilinear")
+    close(up, ref.permute(0, 2, 3, 1), dt)
+    dup = rnd(B, 2 * H, 2 * W, C, dt=dt, seed=3)
+    ref.backward(dup.float().permute(0, 3, 1, 2))
+    K.upsample2_bwd(dup, dx)
+    close(dx, xt.grad.permute(0, 2, 3, 1), dt, scale=2)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_embedding_gather(K, dt):
+    B, L, C, V = 4, 20, 512, 1000
+    tok, pos = rnd(V, C, dt=dt), rnd(77, C, dt=dt, seed=1)
+    word = torch.randint(0, V, (B, L), device="cuda")
+    out = torch.empty(B * L, C, device="cuda", dtype=dt)
+    K.embedding_fwd(word, tok, pos, out, L, V)
+    close(out.view(B, L, C), tok.float()[word] + pos.float()[:L], dt)
+    dout = rnd(B * L, C, dt=dt, seed=2)
+    dtok, dpos = torch.zeros(V, C, device="cuda"), torch.zeros(77, C, device="cuda")
+    K.embedding_bwd(word, dout, dtok, dpos, L, V)
+    ref = torch.zeros(V, C, device="cuda").index_add_(0, word.view(-1), dout.float())
+    close(dtok, ref, dt)
+    close(dpos[:L], dout.float().view(B, L, C).sum(0), dt)
+    idx = torch.tensor([3, 25, 47, 79], device="cuda")
+    g = torch.empty(4, C, device="cuda", dtype=dt)
+    K.gather_rows(out, idx, g)
+    assert torch.equal(g, out[idx])
+    dx = torch.zeros_like(out)
+    K.scatter_rows(g, idx, dx)
+    assert torch.equal(dx[idx], g) and dx.float().abs().sum() == g.float().abs().sum()
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_bcast_ops(K, dt):
+    B, P, C = 3, 20, 64
+    x, s = rnd(B * P, C, dt=dt), rnd(B, C, dt=dt, seed=1)
+    z = torch.empty_like(x)
+    K.mul_bcast_fwd(x, s, z, B, P)
+    close(z.view(B, P, C), x.float().view(B, P, C) * s.float()[:, None], dt)
+    dz = rnd(B * P, C, dt=dt, seed=2)
+    dx, ds = torch.empty_like(x), torch.empty_like(s)
+    K.mul_bcast_bwd(dz, x, s, dx, ds, B, P)
+    close(dx.view(B, P, C), dz.float().view(B, P, C) * s.float()[:, None], dt)
+    close(ds, (dz.float() * x.float()).view(B, P, C).sum(1), dt, scale=5)
+    pos = rnd(P, C, dt=dt, seed=3)
+    o = torch.empty_like(x)
+    K.add_rows(x, pos, o)
+    close(o.view(B, P, C), x.float().view(B, P, C) + pos.float(), dt)
+    acc = torch.zeros(P, C, device="cuda")
+    K.sum_over_batch(x, acc, B)
+    close(acc, x.float().view(B, P, C).sum(0), dt)
+    o2 = torch.empty_like(x)
+    K.add_dropout(x, dz, o2, 0.0, 0)
+    close(o2, x.float() + dz.float(), dt)
+    K.add_dropout(None, torch.ones_like(x), o2, 0.25, 77)
+    v = o2.float()
+    assert set(torch.unique(v).tolist()) <= {0.0, float(torch.tensor(1 / 0.75).to(dt))}
+    assert 0.15 < (v == 0).float().mean().item() < 0.35
+    u = rnd(B * P, C, dt=dt, seed=7)
+    a = torch.empty_like(u)
+    K.quickgelu_fwd(u, a)
+    ut = u.float().requires_grad_(True)
+    ref = ut * torch.sigmoid(1.702 * ut)
+    close(a, ref, dt)
+    ref.backward(dz.float())
+    du = torch.empty_like(u)
+    K.act_bwd(dz, u, du, 1)
+    close(du, ut.grad, dt)
+    K.act_bwd(dz, u, du, 0)
+    close(du, dz.float() * (u.float() > 0), dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_stem_im2col_and_casts(K, dt):
+    B, H, W = 2, 16, 12
+    img = rnd(B, 3, H, W)
+    w = rnd(32, 3, 3, 3, seed=1)
+    out = torch.empty(B * (H // 2) * (W // 2), 32, device="cuda", dtype=dt)
+    K.stem_im2col(img, out)
+    wk = torch.zeros(32, 32, device="cuda", dtype=dt)
+    wkrsc = w.permute(0, 2, 3, 1).contiguous().view(32, 27)
+    K.cast_pad2d(wkrsc, 27, 27, wk, 32, 32, 32)
+    y = out.float() @ wk.float().t()
+    ref = F.conv2d(img.to(dt).float(), w.to(dt).float(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, 32)
+    close(y, ref, torch.float32, scale=10)
+    n = 1000 * 8 + 5
+    src = rnd(n)
+    dst = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    K.cast_f32_to_bf16(src, dst, n)
+    assert torch.equal(dst, src.bfloat16())
+    buf = torch.full((2, 5, 7, 48), 9.0, device="cuda", dtype=dt)
+    K.coord_fill(buf, 32, 48)
+    xs = torch.linspace(-1, 1, 7, device="cuda")
+    ys = torch.linspace(-1, 1, 5, device="cuda")
+    close(buf[0, :, :, 32], xs[None, :].expand(5, 7), dt)
+    close(buf[1, :, :, 33], ys[:, None].expand(5, 7), dt)
+    assert (buf[..., 34:] == 0).all() and (buf[..., :32] == 9).all()
+
+
+def test_adam_matches_torch(K):
+    n = 10007
+    p = rnd(n)
+    p2 = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p2], lr=1e-3, weight_decay=0.0)
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    shadow = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    for step in range(1, 4):
+        g = rnd(n, seed=step)
+        p2.grad = g.clone()
+        opt.step()
+        K.adam_step(p, g, m, v, n, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, shadow)
+    assert torch.allclose(p, p2.detach(), atol=1e-6, rtol=1e-5)
+    assert torch.equal(shadow, p.bfloat16())
+
+
+def test_head_and_loss(K):
+    B, heads, H, W, C = 2, 5, 12, 10, 32
+    dt = torch.float32
+    x5 = rnd(B, H, W, heads * C)
+    word = rnd(B, C * 9 + 1 + 7, seed=1)  # ld padded
+    wpad = torch.empty(B, C, 16, device="cuda", dtype=dt)
+    K.head_pack_weights(word, wpad, B, C)
+    P = H * W
+    t = torch.empty(B * P * heads, 16, device="cuda")
+    K.gemm(K.F32, K.A_KC, K.B_NC, x5, wpad, t, P * heads, 16, C, C, 16, 16, batch=B, sA=(P * heads * C, 0), sB=(C * 16, 0),
+           sC=(P * heads * 16, 0), out_mode=K.OUT_F32)
+    out = torch.empty(B, heads, H, W, device="cuda")
+    K.head_stencil_fwd(t, word, C * 9, out, B, heads, H, W)
+    wt = word[:, :C * 9].reshape(B, C, 3, 3)
+    xs = x5.permute(0, 3, 1, 2)
+    refs = []
+    for h in range(heads):
+        xi = xs[:, h * C:(h + 1) * C].reshape(1, B * C, H, W)
+        refs.append(F.conv2d(xi, wt, padding=1, groups=B, bias=word[:, C * 9]).transpose(0, 1))
+    ref = torch.cat(refs, 1)
+    close(out, ref, dt, scale=4)
+    # loss
+    Hin, Win = 4 * H, 4 * W
+    tg = [(rnd(B, 1, Hin, Win, seed=10 + i) > 0.5).float() if i == 0 else rnd(B, 1, Hin, Win, seed=10 + i) for i in range(5)]
+    pred = out.clone().requires_grad_(True)
+    small = [F.interpolate(t_, (H, W), mode="nearest") for t_ in tg]
+    l0 = F.binary_cross_entropy_with_logits(pred[:, 0:1], small[0], weight=small[0] * 0.5 + 1)
+    ls = [l0] + [F.smooth_l1_loss(pred[:, i:i + 1], small[i]) for i in range(1, 5)]
+    total = sum(ls)
+    total.backward()
+    tgt_small = torch.empty(5, B, H, W, device="cuda")
+    sums = torch.empty(5, device="cuda")
+    dpred = torch.empty_like(out)
+    K.head_loss(out, tg, Hin, Win, True, tgt_small, sums, dpred)
+    for i in range(5):
+        assert torch.allclose(sums[i], ls[i].detach(), rtol=1e-4, atol=1e-6), (i, sums[i].item(), ls[i].item())
+        assert torch.equal(tgt_small[i], small[i][:, 0])
+    assert torch.allclose(dpred, pred.grad, rtol=1e-4, atol=1e-7)
+    # stencil backward
+    dtb = torch.empty(B * P * heads, 16, device="cuda")
+    dbias = torch.empty(B, device="cuda")
+    K.head_stencil_bwd(dpred, dtb, dbias, B, heads, H, W)
+    assert torch.allclose(dbias, dpred.sum((1, 2, 3)), rtol=1e-4, atol=1e-7)
+    tt = t.clone().requires_grad_(True)
+    # reference stencil via autograd on a torch restatement
+    tv = tt.view(B, H, W, heads, 16)
+    acc = torch.zeros(B, heads, H, W, device="cuda")
+    for tap in range(9):
+        dy_, dx_ = tap // 3 - 1, tap % 3 - 1
+        sh = torch.zeros(B, H, W, heads, device="cuda")
+        ys = slice(max(0, -dy_), H - max(0, dy_))
+        xs_ = slice(max(0, -dx_), W - max(0, dx_))
+        yd = slice(max(0, dy_), H - max(0, -dy_))
+        xd = slice(max(0, dx_), W - max(0, -dx_))
+        sh[:, ys, xs_] = tv[:, yd, xd, :, tap]
+        acc = acc + sh.permute(0, 3, 1, 2)
+    close(acc + word[:, C * 9][:, None, None, None], out, dt, scale=4)
+    acc.backward(dpred)
+    assert torch.allclose(dtb, tt.grad, rtol=1e-4, atol=1e-7)
+    # metric
+    counts, m2 = torch.empty(B, 2, device="cuda"), torch.empty(2, device="cuda")
+    K.train_metric(out, heads * P, tgt_small[0], B, P, 0.35, 0.5, counts, m2)
+    o = (torch.sigmoid(out[:, 0]).flatten(1) >= 0.35)
+    tb = tgt_small[0].flatten(1).bool()
+    ious = (o & tb).sum(1) / ((o | tb).sum(1) + 1e-6)
+    assert torch.allclose(m2[0], 100 * ious.mean(), atol=1e-3) and torch.allclose(m2[1], 100 * (ious > 0.5).float().mean(), atol=1e-3)
