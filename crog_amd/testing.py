@@ -1,0 +1,102 @@
+"""Deterministic synthetic inputs and weights shared by tests, bench.py and the golden generator.
+
+Nothing here is model code: it only produces tensors.  Weights are generated per parameter name
+(seeded by the name), so the reference model, the CPU oracle and the HIP module can all be loaded
+with bit-identical values without committing 588 MB of weights.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from types import SimpleNamespace
+from typing import Dict, Iterable, Tuple
+
+import torch
+
+
+def make_cfg(**over):
+    """Hot-path keys of config/OCID-VLG/crog_multiple_r50.yaml, word_len = 20 per BASELINE.json."""
+    cfg = dict(clip_pretrain="synthetic-RN50", word_len=20, word_dim=1024, vis_dim=512, fpn_in=[512, 1024, 1024],
+               fpn_out=[256, 512, 1024], num_layers=3, num_head=8, dim_ffn=2048, dropout=0.1, intermediate=False,
+               use_contrastive=True, use_pretrained_clip=False, use_grasp_masks=True, base_lr=1e-4, lr_multi=0.1,
+               sync_bn=True, batch_size=32, weight_decay=0.0, milestones=[35], lr_decay=0.1, max_norm=0.0, print_freq=100,
+               input_size=416,
+               # architecture of the CLIP backbone when no checkpoint is given (RN50 values, clip.py:503-546)
+               clip_arch=dict(embed_dim=1024, image_resolution=224, vision_layers=(3, 4, 6, 3), vision_width=64,
+                              vision_patch_size=None, context_length=77, vocab_size=49408, transformer_width=512,
+                              transformer_heads=8, transformer_layers=12))
+    cfg.update(over)
+    return SimpleNamespace(**cfg)
+
+
+def tiny_cfg(**over):
+    """Same channel widths as CROG-R50 (kernels see real K/N sizes) but one block per stage, a 2-layer text
+    transformer and a small vocabulary, for fast CPU-oracle parity."""
+    arch = dict(embed_dim=1024, image_resolution=224, vision_layers=(1, 1, 1, 1), vision_width=64, vision_patch_size=None,
+                context_length=77, vocab_size=512, transformer_width=512, transformer_heads=8, transformer_layers=2)
+    base = dict(clip_arch=arch, num_layers=1, dropout=0.0, word_len=12, input_size=96)
+    base.update(over)
+    return make_cfg(**base)
+
+
+def _gen(name: str, seed: int) -> torch.Generator:
+    return torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+
+
+def seeded_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Tensor:
+    """Value recipe keyed on the parameter name; scales chosen so activations stay O(1) through the net."""
+    g = _gen(name, seed)
+    leaf = name.split(".")[-1]
+    if leaf == "num_batches_tracked":
+        return torch.zeros((), dtype=torch.long)
+    if leaf == "running_mean":
+        return 0.1 * torch.randn(shape, generator=g)
+    if leaf == "running_var":
+        return 1.0 + 0.2 * torch.rand(shape, generator=g)
+    if name.endswith("logit_scale"):
+        return torch.tensor(math.log(1 / 0.07))
+    is_norm = any(t in name for t in (".bn", "ln_", ".norm", "_norm", "downsample.1", "connect.1", ".ffn.3")) or \
+        (len(shape) == 1 and leaf == "weight")
+    if len(shape) == 1:
+        if leaf == "weight" and is_norm:
+            return 1.0 + 0.1 * torch.randn(shape, generator=g)
+        return 0.05 * torch.randn(shape, generator=g)
+    if "positional_embedding" in name or leaf == "class_embedding":
+        return 0.02 * torch.randn(shape, generator=g)
+    if "token_embedding" in name:
+        return 0.05 * torch.randn(shape, generator=g)
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    if leaf in ("text_projection", "proj"):
+        fan_in = shape[0]
+    gain = math.sqrt(2.0) if len(shape) == 4 else 1.0
+    return (gain / math.sqrt(fan_in)) * torch.randn(shape, generator=g)
+
+
+def seeded_state(shapes: Dict[str, Iterable[int]], seed: int = 0) -> Dict[str, torch.Tensor]:
+    return {k: seeded_tensor(k, tuple(v), seed) for k, v in shapes.items()}
+
+
+def synthetic_batch(B: int, size: int = 416, L: int = 20, vocab: int = 49408, seed: int = 1234, device="cpu"):
+    """img ~ N(0,1); word = [SOT, t1..tk, EOT, 0...]; mask in {0,1}; qua, wid ~ U(0,1);
+    sin/cos of 2*theta masked by `mask` (mirrors utils/dataset.py:892-897).  Returns dict of CPU/`device` tensors."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 3, size, size, generator=g)
+    sot, eot = vocab - 2, vocab - 1
+    word = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        k = int(torch.randint(3, max(4, L - 2), (1,), generator=g))
+        word[b, 0] = sot
+        word[b, 1:1 + k] = torch.randint(1, sot, (k,), generator=g)
+        word[b, 1 + k] = eot
+    # blobby mask: low-res Bernoulli upsampled
+    low = (torch.rand(B, 1, size // 16, size // 16, generator=g) > 0.8).float()
+    mask = torch.nn.functional.interpolate(low, size=(size, size), mode="nearest")
+    theta = (torch.rand(B, 1, size, size, generator=g) - 0.5) * math.pi
+    qua = torch.rand(B, 1, size, size, generator=g) * mask
+    wid = torch.rand(B, 1, size, size, generator=g) * mask
+    sin = torch.sin(2 * theta) * mask
+    cos = torch.cos(2 * theta) * mask
+    out = dict(img=img, word=word, mask=mask, qua=qua, sin=sin, cos=cos, wid=wid)
+    return {k: v.to(device) for k, v in out.items()}

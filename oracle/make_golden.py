@@ -1,0 +1,195 @@
+"""Generate tests/golden/* by importing the REFERENCE (HilbertXu/CROG) in the build container.
+
+Run here only (needs /root/reference; the GPU box never sees it):   python oracle/make_golden.py
+The reference is imported read-only (no bytecode written), with stubs for the packages the image
+lacks (loguru, cv2) and torch.jit.load replaced by an object that yields a CLIP state dict of the
+wanted architecture (there is no RN50.pt and no network) — recipe from SURVEY.md §8(c).
+Only data leaves this script: inputs are re-derivable from seeds, outputs are stored as .npz/.json.
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = os.environ.get("CROG_REFERENCE", "/root/reference")
+
+import numpy as np
+import torch
+
+from crog_amd.testing import make_cfg, seeded_state, synthetic_batch, tiny_cfg
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def import_reference():
+    class _Logger:
+        def __getattr__(self, k):
+            return lambda *a, **kw: None
+    sys.modules["loguru"] = types.SimpleNamespace(logger=_Logger())
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    sys.path.insert(0, REF)
+    import model as ref_model  # noqa
+    import model.clip as ref_clip
+    import model.crog as ref_crog
+    import model.layers as ref_layers
+    return ref_model, ref_clip, ref_crog, ref_layers
+
+
+def build_reference(cfg, ref_model, ref_clip):
+    a = cfg.clip_arch
+    proto = ref_clip.CLIP(a["embed_dim"], a["image_resolution"], a["vision_layers"], a["vision_width"], a["vision_patch_size"],
+                          a["context_length"], cfg.word_len, a["vocab_size"], a["transformer_width"], a["transformer_heads"],
+                          a["transformer_layers"])
+    sd = proto.state_dict()
+
+    class _Jit:
+        def eval(self):
+            return self
+
+        def state_dict(self):
+            return dict(sd)
+    orig = torch.jit.load
+    torch.jit.load = lambda *a_, **k_: _Jit()
+    try:
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            model, groups = ref_model.build_crog(cfg)
+    finally:
+        torch.jit.load = orig
+    return model, groups
+
+
+def run_case(name, cfg, B, seed, ref_model, ref_clip, store_intermediates):
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    model, groups = build_reference(cfg, ref_model, ref_clip)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(seeded_state(shapes, seed=seed))
+    batch = synthetic_batch(B, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + seed)
+    out = {}
+    inter = {}
+    if store_intermediates:
+        def hook(key):
+            def f(_m, _i, o):
+                inter[key] = o
+            return f
+        model.neck.register_forward_hook(hook("fq"))
+        model.decoder.register_forward_hook(hook("fq_dec"))
+    model.train()
+    vis = model.backbone.encode_image(batch["img"])
+    wfeat, state = model.backbone.encode_text(batch["word"])
+    if store_intermediates:
+        out.update(x2=vis[0], x3=vis[1], x4=vis[2], word_feat=wfeat, state=state)
+    # the encode_* calls above updated BN running stats once; reload so that the recorded step is step 1
+    model.load_state_dict(seeded_state(shapes, seed=seed))
+    model.zero_grad()
+    preds, tgts, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
+    loss.backward()
+    for i, nm in enumerate(["ins", "qua", "sin", "cos", "wid"]):
+        out["pred_" + nm] = preds[i]
+        out["tgt_" + nm] = tgts[i]
+    out["loss_total"] = loss.detach()
+    out["loss_items"] = torch.tensor([loss_dict[k] for k in ("m_ins", "m_qua", "m_sin", "m_cos", "m_wid")])
+    if store_intermediates:
+        out["fq"] = inter["fq"]
+        out["fq_dec"] = inter["fq_dec"]
+    names = [n for n, _ in model.named_parameters()]
+    gn = torch.tensor([float(p.grad.norm()) if p.grad is not None else -1.0 for _, p in model.named_parameters()])
+    out["grad_norms"] = gn
+    # a few full gradients (small tensors) to pin direction, not just norm
+    sd_grads = {}
+    for n, p in model.named_parameters():
+        if p.grad is not None and p.numel() <= 4096 and any(t in n for t in ("bn1.weight", "ln_final", "norm.weight", "txt.bias", "vis.4.bias",
+                                                                              "attnpool.c_proj.bias", "norm_layer.0.bias")):
+            sd_grads["grad::" + n] = p.grad
+    out.update(sd_grads)
+    # BN running statistics after this one training step
+    bn_sum = {k: float(v.double().sum()) for k, v in model.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    out["bn_running_checksum"] = torch.tensor([bn_sum[k] for k in sorted(bn_sum)])
+    # metric (utils/misc.py:115-131) restated inline to avoid importing cv2-dependent utils
+    model.eval()
+    with torch.no_grad():
+        ev = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
+    for i, nm in enumerate(["ins", "qua", "sin", "cos", "wid"]):
+        out["eval_pred_" + nm] = ev[0][i]
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **{k: v.detach().numpy() for k, v in out.items()})
+    meta = dict(param_names=names, shapes={k: list(v) for k, v in shapes.items()},
+                group_backbone=len(groups[0]["params"]), group_head=len(groups[1]["params"]),
+                group_lrs=[groups[0]["initial_lr"], groups[1]["initial_lr"]], seed=seed, B=B,
+                bn_keys=sorted(bn_sum))
+    json.dump(meta, open(os.path.join(GOLD, name + ".json"), "w"))
+    print(name, "loss", float(loss), "items", out["loss_items"].tolist(), flush=True)
+    return model
+
+
+def op_fixtures(ref_clip, ref_layers):
+    """Per-op pins from the reference classes at small shapes (weights + input + output + input grad)."""
+    torch.manual_seed(7)
+    fx = {}
+
+    def rec(tag, mod, *inputs, post=lambda o: o):
+        mod.train()
+        for p in mod.parameters():
+            p.data.normal_(0, 0.2)
+        for n, b in mod.named_buffers():
+            if n.endswith("running_var"):
+                b.data.uniform_(0.8, 1.2)
+        sd0 = {k: v.clone() for k, v in mod.state_dict().items()}
+        ins = [i.clone().requires_grad_(True) if i.is_floating_point() else i for i in inputs]
+        o = post(mod(*ins))
+        o.sum().backward() if o.dim() == 0 else (o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum().backward()
+        fx[tag + "::out"] = o.detach()
+        for j, i in enumerate(ins):
+            fx[f"{tag}::in{j}"] = i.detach()
+            if i.is_floating_point() and i.grad is not None:
+                fx[f"{tag}::din{j}"] = i.grad
+        for k, v in sd0.items():
+            fx[f"{tag}::w::{k}"] = v
+
+    rec("bottleneck_s2", ref_clip.Bottleneck(64, 32, 2), torch.randn(2, 64, 8, 8))
+    rec("bottleneck_s1", ref_clip.Bottleneck(128, 32, 1), torch.randn(2, 128, 6, 6))
+    rec("attnpool", ref_clip.AttentionPool2d(7, 128, 2, 64), torch.randn(2, 128, 3, 3))
+    mask = torch.full((6, 6), float("-inf")).triu_(1)
+    rec("resblock", ref_clip.ResidualAttentionBlock(128, 2, mask), torch.randn(6, 3, 128))
+    rec("declayer", ref_layers.TransformerDecoderLayer(128, 2, 256, 0.0),
+        torch.randn(16, 2, 128), torch.randn(5, 2, 128), ref_layers.TransformerDecoder.pos2d(128, 4, 4),
+        ref_layers.TransformerDecoder.pos1d(128, 5), torch.tensor([[False, False, False, True, True], [False] * 5]))
+    rec("coordconv", ref_layers.CoordConv(32, 32, 3, 1), torch.randn(2, 32, 5, 7))
+    rec("mtproj", ref_layers.MultiTaskProjector(64, 32, 3), torch.randn(2, 64, 4, 4), torch.randn(2, 64),
+        post=lambda o: torch.cat(o, 1))
+    rec("proj", ref_layers.Projector(64, 32, 3), torch.randn(2, 64, 4, 4), torch.randn(2, 64))
+    fx["pos1d_128_9"] = ref_layers.TransformerDecoder.pos1d(128, 9).squeeze(1)
+    fx["pos2d_128_5_7"] = ref_layers.TransformerDecoder.pos2d(128, 5, 7).squeeze(1)
+    np.savez_compressed(os.path.join(GOLD, "ops.npz"), **{k: v.detach().numpy() for k, v in fx.items()})
+    print("ops fixtures:", len(fx), flush=True)
+
+
+def shapes_only(ref_clip):
+    """Parameter names/shapes of the real CLIP RN50 and ViT-B/16 towers + CROG heads (names are the checkpoint contract)."""
+    vit = ref_clip.CLIP(512, 224, 12, 768, 16, 77, 20, 49408, 512, 8, 12)
+    json.dump({k: list(v.shape) for k, v in vit.state_dict().items()}, open(os.path.join(GOLD, "shapes_clip_vitb16.json"), "w"))
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    ref_model, ref_clip, ref_crog, ref_layers = import_reference()
+    which = sys.argv[1:] or ["tiny", "ops", "shapes", "full"]
+    if "tiny" in which:
+        run_case("tiny_crog", tiny_cfg(), B=2, seed=3, ref_model=ref_model, ref_clip=ref_clip, store_intermediates=True)
+        run_case("tiny_crog_nomask", tiny_cfg(use_grasp_masks=False), B=2, seed=4, ref_model=ref_model, ref_clip=ref_clip,
+                 store_intermediates=False)
+    if "ops" in which:
+        op_fixtures(ref_clip, ref_layers)
+    if "shapes" in which:
+        shapes_only(ref_clip)
+    if "full" in which:
+        # BASELINE config 1: CROG-R50, 2 x 416x416 + 20 tokens, dropout 0 for determinism
+        run_case("crog_r50_b2", make_cfg(dropout=0.0), B=2, seed=5, ref_model=ref_model, ref_clip=ref_clip, store_intermediates=False)
+
+
+if __name__ == "__main__":
+    main()
