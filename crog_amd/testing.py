@@ -71,6 +71,8 @@ def seeded_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Ten
     if leaf in ("text_projection", "proj"):
         fan_in = shape[0]
     gain = math.sqrt(2.0) if len(shape) == 4 else 1.0
+    if name.endswith("proj.txt.weight"):
+        gain = 0.02  # the generated 3x3 kernel is summed over C*9 taps: keep logits O(1)
     return (gain / math.sqrt(fan_in)) * torch.randn(shape, generator=g)
 
 

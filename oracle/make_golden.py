@@ -90,8 +90,9 @@ def run_case(name, cfg, B, seed, ref_model, ref_clip, store_intermediates):
     preds, tgts, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
     loss.backward()
     for i, nm in enumerate(["ins", "qua", "sin", "cos", "wid"]):
-        out["pred_" + nm] = preds[i]
-        out["tgt_" + nm] = tgts[i]
+        if preds[i] is not None:
+            out["pred_" + nm] = preds[i]
+            out["tgt_" + nm] = tgts[i]
     out["loss_total"] = loss.detach()
     out["loss_items"] = torch.tensor([loss_dict[k] for k in ("m_ins", "m_qua", "m_sin", "m_cos", "m_wid")])
     if store_intermediates:
@@ -114,15 +115,17 @@ def run_case(name, cfg, B, seed, ref_model, ref_clip, store_intermediates):
     model.eval()
     with torch.no_grad():
         ev = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
+    ev_preds = ev[0] if isinstance(ev[0], (tuple, list)) else [ev[0]]
     for i, nm in enumerate(["ins", "qua", "sin", "cos", "wid"]):
-        out["eval_pred_" + nm] = ev[0][i]
+        if i < len(ev_preds) and ev_preds[i] is not None:
+            out["eval_pred_" + nm] = ev_preds[i]
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **{k: v.detach().numpy() for k, v in out.items()})
     meta = dict(param_names=names, shapes={k: list(v) for k, v in shapes.items()},
                 group_backbone=len(groups[0]["params"]), group_head=len(groups[1]["params"]),
                 group_lrs=[groups[0]["initial_lr"], groups[1]["initial_lr"]], seed=seed, B=B,
                 bn_keys=sorted(bn_sum))
     json.dump(meta, open(os.path.join(GOLD, name + ".json"), "w"))
-    print(name, "loss", float(loss), "items", out["loss_items"].tolist(), flush=True)
+    print(name, "loss", float(loss.detach()), "items", out["loss_items"].tolist(), flush=True)
     return model
 
 
@@ -179,8 +182,8 @@ def main():
     ref_model, ref_clip, ref_crog, ref_layers = import_reference()
     which = sys.argv[1:] or ["tiny", "ops", "shapes", "full"]
     if "tiny" in which:
-        run_case("tiny_crog", tiny_cfg(), B=2, seed=3, ref_model=ref_model, ref_clip=ref_clip, store_intermediates=True)
-        run_case("tiny_crog_nomask", tiny_cfg(use_grasp_masks=False), B=2, seed=4, ref_model=ref_model, ref_clip=ref_clip,
+        run_case("tiny_crog", tiny_cfg(), B=4, seed=3, ref_model=ref_model, ref_clip=ref_clip, store_intermediates=True)
+        run_case("tiny_crog_nomask", tiny_cfg(use_grasp_masks=False), B=4, seed=4, ref_model=ref_model, ref_clip=ref_clip,
                  store_intermediates=False)
     if "ops" in which:
         op_fixtures(ref_clip, ref_layers)
