@@ -467,6 +467,35 @@ __global__ void __launch_bounds__(NT) adam_kernel(float* __restrict__ p, const f
   }
 }
 
+// ---- out[c] += sum_r x[r][c]  (bias gradients): one thread per (row block, 16-byte column chunk) ----------
+template <typename T>
+__global__ void __launch_bounds__(NT) colsum_kernel(const T* __restrict__ x, long ldx, long M, int C, int rows_per_block, float* __restrict__ out) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = (C + VEC - 1) / VEC;
+  const long nblk = (M + rows_per_block - 1) / rows_per_block;
+  GRID_STRIDE(i, nblk * cvec) {
+    const long rb = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    const long r0 = rb * rows_per_block, r1 = min(r0 + rows_per_block, M);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) acc[e] = 0.f;
+    if (c + VEC <= C) {
+      for (long r = r0; r < r1; r++) {
+        Vec16<T> v = ldg16(x + r * ldx + c);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) acc[e] += Elem<T>::to_f(v.v[e]);
+      }
+    } else {
+      for (long r = r0; r < r1; r++)
+        for (int e = 0; e < VEC && c + e < C; e++) acc[e] += Elem<T>::to_f(x[r * ldx + c + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; e++)
+      if (c + e < C) atomicAdd(out + c + e, acc[e]);
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, ...)                                   \
@@ -629,6 +658,14 @@ extern "C" int crog_adam_step(float* p, const float* g, float* m, float* v, int6
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   LAUNCH(adam_kernel, (n + 3) / 4, s, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, (bf16*)bf16_shadow);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, int rows_per_block, float* out, crog_stream_t s) {
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(ldx % vec == 0 && rows_per_block > 0, "colsum: ldx %% %d == 0 required", vec);
+  DISPATCH_T(dtype, LAUNCH((colsum_kernel<T>), (long)cdiv(M, rows_per_block) * cdiv(C, vec), s, (const T*)x, (long)ldx, (long)M, C, rows_per_block, out));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -142,7 +142,15 @@ struct KcLoader {
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const bool ok = grow[i] >= 0 && k < K;
-        reg[i] = ok ? ldg16(base + grow[i] * ld + k) : zero16<T>();
+        if (ok && k + VEC > K) {  // ragged K tail (K % VEC != 0): element-wise, zero filled
+          reg[i] = zero16<T>();
+          const T* src = base + grow[i] * ld + k;
+#pragma unroll
+          for (int e = 0; e < VEC; e++)
+            if (k + e < K) reg[i].v[e] = src[e];
+        } else {
+          reg[i] = ok ? ldg16(base + grow[i] * ld + k) : zero16<T>();
+        }
       }
     }
   }
@@ -486,8 +494,6 @@ extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
   CROG_CHECK_ARG(((uintptr_t)d.A % 16) == 0 && ((uintptr_t)d.B % 16) == 0, "crog_gemm: A/B must be 16-byte aligned");
   CROG_CHECK_ARG((d.sAo * esz) % 16 == 0 && (d.sAi * esz) % 16 == 0 && (d.sBo * esz) % 16 == 0 && (d.sBi * esz) % 16 == 0,
                  "crog_gemm: batch strides of A/B must keep 16-byte alignment");
-  if (d.a_layout == CROG_A_KC || d.b_layout == CROG_B_KC)
-    CROG_CHECK_ARG(d.K % vec == 0, "crog_gemm: K=%d must be a multiple of %d for K-contiguous operands", d.K, vec);
   if (d.a_layout == CROG_A_IM2COL || d.b_layout == CROG_B_NC_DGRAD || d.b_layout == CROG_B_NC_IM2COL) {
     CROG_CHECK_ARG(d.convH > 0 && d.convW > 0 && d.convC > 0 && d.convC % 32 == 0,
                    "crog_gemm: conv geometry needs convC %% 32 == 0 (H=%d W=%d C=%d)", d.convH, d.convW, d.convC);

@@ -1,0 +1,925 @@
+"""Autograd-visible operators of the HIP path.
+
+Every operator is a torch.autograd.Function whose forward and backward enqueue HIP kernels from
+libcrog_hip.so through crog_amd.kernels.  Autograd is used only to order the backward launches;
+no ATen kernel computes anything here.
+
+Conventions
+  * activations are channels-last row matrices [..., C] in the compute dtype (bf16 or fp32)
+  * weights are read from the flat store in the compute dtype (`WRef.w()`), weight gradients are
+    accumulated with fp32 atomics straight into the flat gradient buffer (`WRef.g()`); backward
+    therefore returns None for parameter inputs (p.grad already aliases that buffer)
+  * token tensors are batch-first: row = b * L + l
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+from .runtime import RT, ParamStore
+
+
+def _cdt(t: torch.Tensor) -> int:
+    return K.dcode(t)
+
+
+def _bk(dt: int) -> int:
+    return 32 if dt == K.BF16 else 16
+
+
+def _vec(dt: int) -> int:
+    return 8 if dt == K.BF16 else 4
+
+
+def _pad(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+class OutRef:
+    """Hides a preallocated destination view (a channel slice of a concat buffer) from autograd's argument scan."""
+
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+
+def _dest(out: Optional["OutRef"]):
+    return None if out is None else out.t.view(out.t.shape)
+
+
+class WRef:
+    """A block of `rows` consecutive rows (each `cols` long) of a parameter in the flat store."""
+
+    __slots__ = ("store", "param", "off", "rows", "cols")
+
+    def __init__(self, store: ParamStore, param, row0: int = 0, rows: Optional[int] = None, cols: Optional[int] = None):
+        self.store = store
+        self.param = param
+        total_rows = param.shape[0]
+        self.cols = cols if cols is not None else param.numel() // total_rows
+        self.rows = rows if rows is not None else total_rows - row0
+        self.off = store.off(param) + row0 * self.cols
+
+    def w(self, dtype: torch.dtype) -> torch.Tensor:
+        return self.store.weights(dtype)
+
+    @property
+    def G(self) -> torch.Tensor:
+        return self.store.G
+
+    @property
+    def P(self) -> torch.Tensor:
+        return self.store.P
+
+    def master(self) -> torch.Tensor:
+        """fp32 view of the block (biases, norm scales)."""
+        return self.store.P[self.off:self.off + self.rows * self.cols]
+
+    def grad(self) -> torch.Tensor:
+        return self.store.G[self.off:self.off + self.rows * self.cols]
+
+    def done(self):
+        if RT.reducer is not None:
+            RT.reducer.mark_ready(self.param)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM helpers on row matrices
+# ------------------------------------------------------------------------------------------------
+def lin_fwd(x, w: WRef, out, *, bias: Optional[WRef] = None, act=K.ACT_NONE, res=None, stats=None, out_mode=K.OUT_T, alpha=1.0,
+            c_off=0, ldc=None, N=None):
+    """out[M, N] = act(alpha * x[M, K] @ W[N, K]^T + bias) + res"""
+    M, Kd, lda = K.mat(x)
+    dt = _cdt(x)
+    n = w.rows if N is None else N
+    K.gemm(dt, K.A_KC, K.B_KC, x, w.w(x.dtype), out, M, n, Kd, lda, w.cols, ldc if ldc is not None else K.mat(out)[2],
+           b_off=w.off, bias=bias.master() if bias is not None else None, act=act, R=res, ldr=K.mat(res)[2] if res is not None else 0,
+           col_stats=stats, out_mode=out_mode, alpha=alpha, c_off=c_off)
+
+
+def lin_dgrad(dy, w: WRef, dx, *, accumulate_into: Optional[torch.Tensor] = None, a_off=0, lda=None, N=None):
+    """dx[M, K] = dy[M, N] @ W[N, K]  (+ accumulate_into)"""
+    M, n, ld = K.mat(dy)
+    if N is not None:
+        n = N
+    dt = _cdt(dx)
+    K.gemm(dt, K.A_KC, K.B_NC, dy, w.w(dx.dtype), dx, M, w.cols, n, lda if lda is not None else ld, w.cols, K.mat(dx)[2],
+           a_off=a_off, b_off=w.off, R=accumulate_into, ldr=K.mat(accumulate_into)[2] if accumulate_into is not None else 0)
+
+
+def lin_wgrad(dy, x, w: WRef, *, a_off=0, lda=None, N=None):
+    """G[w] += dy[M, N]^T @ x[M, K]"""
+    M, n, ld = K.mat(dy)
+    if N is not None:
+        n = N
+    _, Kd, ldx = K.mat(x)
+    dt = _cdt(x)
+    sk = K.pick_splitk(n, Kd, M, _bk(dt))
+    K.gemm(dt, K.A_MC, K.B_NC, dy, x, w.G, n, Kd, M, lda if lda is not None else ld, ldx, w.cols, a_off=a_off, c_off=w.off,
+           splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+
+
+def bias_grad(dy, b: WRef, col0=0, n=None):
+    M, C, ld = K.mat(dy)
+    view = dy if (col0 == 0 and (n is None or n == C)) else dy[..., col0:col0 + n]
+    K.colsum(view, b.G, b.off)
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv (1x1 / 3x3 / stem / none) + BatchNorm(train|eval, cross-replica) + residual + ReLU
+# ------------------------------------------------------------------------------------------------
+class BnBuffers:
+    """What conv_bn_act needs from a BatchNorm module."""
+
+    def __init__(self, gamma: WRef, beta: WRef, running_mean, running_var, momentum, eps):
+        self.gamma, self.beta = gamma, beta
+        self.running_mean, self.running_var = running_mean, running_var
+        self.momentum, self.eps = momentum, eps
+
+
+class ConvBnAct(Function):
+    """y = [relu]( BN( conv_k(x) ) [+ res] ).   ksize: 0 (no conv), 1, 3, or 's' (stem 3x3/s2 on an NCHW fp32 image).
+    Reference: Bottleneck clip.py:44-57, stem clip.py:208-213, conv_layer layers.py:8-11, linear_layer layers.py:14-16,
+    attnpool.connect clip.py:76-78, norm_layer layers.py:351,379.  Training-mode statistics are per-channel
+    (sum, sum^2) pairs produced by the GEMM epilogue, optionally all-reduced across replicas (SyncBatchNorm,
+    train_crog.py:113-114)."""
+
+    @staticmethod
+    def forward(ctx, x, res, _wp, _gp, _bp, w: Optional[WRef], bn: BnBuffers, ksize, relu: bool, training: bool, out, wpad, dtype):
+        dev = x.device
+        if ksize == "s":
+            B, _, Hi, Wi = x.shape
+            H, W = Hi // 2, Wi // 2
+            lead = (B, H, W)
+            M = B * H * W
+            cin = 27
+        else:
+            lead = tuple(x.shape[:-1])
+            M, cin, _ = K.mat(x)
+            if ksize == 3:
+                B, H, W = x.shape[0], x.shape[1], x.shape[2]
+        dt = K.dcode(dtype)
+        C = bn.gamma.rows * bn.gamma.cols
+        wt = wbuf_off = None
+        if ksize != 0:
+            wt, wbuf_off, wcols = w.w(dtype), w.off, w.cols
+            if wpad is not None:  # ragged Cin (stem 27 -> 32, CoordConv 514 -> 544): zero-padded compute copy of the weight
+                src_cols, dst_cols, rows = wpad
+                wt = torch.empty(rows * dst_cols, device=dev, dtype=dtype)
+                K.cast_pad2d(w.P, src_cols, src_cols, wt, dst_cols, dst_cols, rows, src_off=w.off)
+                wbuf_off = 0
+                wcols = dst_cols * (9 if ksize == 3 else 1)
+        stats = None
+        if ksize == 0:
+            z = x
+        else:
+            z = torch.empty(lead + (C,), device=dev, dtype=dtype)
+            if training:
+                stats = torch.empty(K.stat_tiles(M), C, 2, device=dev, dtype=torch.float32)
+            if ksize == "s":
+                patches = torch.empty(M, 32, device=dev, dtype=dtype)
+                K.stem_im2col(x, patches)
+                K.gemm(dt, K.A_KC, K.B_KC, patches, wt, z, M, C, 32, 32, 32, C, b_off=wbuf_off, col_stats=stats)
+            elif ksize == 1:
+                K.gemm(dt, K.A_KC, K.B_KC, x, wt, z, M, C, cin, K.mat(x)[2], wcols, C, b_off=wbuf_off, col_stats=stats)
+            else:
+                K.gemm(dt, K.A_IM2COL, K.B_KC, x, wt, z, M, C, 9 * cin, K.mat(x)[2], wcols, C, b_off=wbuf_off, conv=(H, W, cin),
+                       col_stats=stats)
+        ss = torch.empty(C, 2, device=dev, dtype=torch.float32)
+        mi = None
+        count = float(M)
+        if training:
+            if stats is None:
+                rpb = K.bn_rows_per_block(M)
+                nparts = (M + rpb - 1) // rpb
+                stats = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
+                K.bn_partial_stats(z, stats, rpb)
+            sums = torch.empty(C, 2, device=dev, dtype=torch.float32)
+            K.reduce_pairs(stats, stats.shape[0], C, sums)
+            if RT.comm is not None and RT.comm.world_size > 1:
+                RT.comm.all_reduce_sum(sums)
+                count = float(M * RT.comm.world_size)
+            mi = torch.empty(C, 2, device=dev, dtype=torch.float32)
+            K.bn_finalize(sums, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum, bn.eps, C, ss, mi)
+        else:
+            K.bn_eval_scale(bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.eps, C, ss)
+        y = _dest(out) if out is not None else torch.empty(lead + (C,), device=dev, dtype=dtype)
+        K.bn_apply(z, ss, res, relu, y)
+        ctx.cfg = (ksize, relu, training, w, bn, wpad, count, cin, C, lead, dtype)
+        ctx.has_res = res is not None
+        ctx.x_needs = ksize != "s" and x.requires_grad
+        ctx.wt = (wt, wbuf_off) if wpad is not None else None
+        if ksize == "s":
+            ctx.save_for_backward(patches, z, y, mi)
+        else:
+            ctx.save_for_backward(x, z, y, mi)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ksize, relu, training, w, bn, wpad, count, cin, C, lead, dtype = ctx.cfg
+        if not training:
+            raise NotImplementedError("crog_amd: backward through eval-mode BatchNorm is not supported (reference trains with model.train())")
+        x, z, y, mi = ctx.saved_tensors
+        dev = dy.device
+        dt = K.dcode(dtype)
+        dy = K.as_mat(dy)
+        M = z.numel() // C
+        rpb = K.bn_rows_per_block(M)
+        nparts = (M + rpb - 1) // rpb
+        partial = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
+        ymask = y if relu else None
+        K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial)
+        sums = torch.empty(C, 2, device=dev, dtype=torch.float32)
+        K.reduce_pairs(partial, nparts, C, sums)
+        K.split_pairs(sums, C, bn.beta.grad(), bn.gamma.grad())  # local sums: (sum g -> dbeta, sum g*xhat -> dgamma)
+        bn.beta.done()
+        bn.gamma.done()
+        if RT.comm is not None and RT.comm.world_size > 1:
+            RT.comm.all_reduce_sum(sums)
+        dz = torch.empty(lead + (C,), device=dev, dtype=dtype)
+        dres = torch.empty(lead + (C,), device=dev, dtype=dtype) if ctx.has_res else None
+        K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres)
+        dx = None
+        if ksize == 0:
+            dx = dz
+        else:
+            if wpad is not None:
+                wt, woff = ctx.wt
+                src_cols, dst_cols, rows = wpad
+                wcols = dst_cols * (9 if ksize == 3 else 1)
+                gscratch = torch.zeros(rows * dst_cols, device=dev, dtype=torch.float32)
+                gt, goff = gscratch, 0
+            else:
+                wt, woff, wcols = w.w(dtype), w.off, w.cols
+                gt, goff = w.G, w.off
+            if ksize == "s":
+                sk = K.pick_splitk(C, 32, M, _bk(dt))
+                K.gemm(dt, K.A_MC, K.B_NC, dz, x, gt, C, 32, M, C, 32, 32, c_off=goff, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+            elif ksize == 1:
+                sk = K.pick_splitk(C, cin, M, _bk(dt))
+                K.gemm(dt, K.A_MC, K.B_NC, dz, x, gt, C, cin, M, C, K.mat(x)[2], wcols, c_off=goff, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+                if ctx.x_needs:
+                    dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
+                    K.gemm(dt, K.A_KC, K.B_NC, dz, wt, dx, M, cin, C, C, wcols, cin, b_off=woff)
+            else:
+                B, H, W = lead
+                sk = K.pick_splitk(C, 9 * cin, M, _bk(dt))
+                K.gemm(dt, K.A_MC, K.B_NC_IM2COL, dz, x, gt, C, 9 * cin, M, C, K.mat(x)[2], wcols, c_off=goff, conv=(H, W, cin), splitk=sk,
+                       out_mode=K.OUT_F32_ATOMIC)
+                if ctx.x_needs:
+                    dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
+                    K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, dz, wt, dx, M, cin, 9 * C, C, cin, cin, b_off=woff, conv=(H, W, C))
+            if wpad is not None:  # strip the zero padding back out into the real gradient
+                K.cast_pad2d(gscratch, dst_cols, dst_cols, w.G, src_cols, src_cols, rows, dst_off=w.off)
+            w.done()
+        return (dx, dres) + (None,) * 11
+
+
+def conv_bn_act(x, w: Optional[WRef], bn: BnBuffers, *, ksize, relu=True, res=None, training=True, out=None, wpad=None, dtype=None):
+    dtype = dtype if dtype is not None else x.dtype
+    wp = w.param if w is not None else None
+    return ConvBnAct.apply(x, res, wp, bn.gamma.param, bn.beta.param, w, bn, ksize, relu, training, out, wpad, dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear with fused bias / activation / residual epilogue
+# ------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = act(x W^T + b) + res.  act in {none, relu}.  nn.Linear call sites: clip.py:249-251 (c_fc/c_proj),
+    layers.py:298-301 (ffn), proj.vis.4 1x1 conv with bias (layers.py:58)."""
+
+    @staticmethod
+    def forward(ctx, x, res, _wp, _bp, w: WRef, b: Optional[WRef], act, out):
+        M, Kd, _ = K.mat(x)
+        y = _dest(out) if out is not None else torch.empty(tuple(x.shape[:-1]) + (w.rows,), device=x.device, dtype=x.dtype)
+        lin_fwd(x, w, y, bias=b, act=act, res=res)
+        ctx.cfg = (w, b, act, res is not None)
+        ctx.save_for_backward(x, y if act == K.ACT_RELU else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, b, act, has_res = ctx.cfg
+        x, y = ctx.saved_tensors
+        dy = K.as_mat(dy)
+        dres = dy if has_res else None
+        g = dy
+        if act == K.ACT_RELU:
+            if has_res:
+                raise NotImplementedError("relu + residual epilogue backward")
+            g = torch.empty(dy.shape, device=dy.device, dtype=dy.dtype)
+            K.act_bwd(dy, y, g, 0)
+        lin_wgrad(g, x, w)
+        w.done()
+        if b is not None:
+            bias_grad(g, b)
+            b.done()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+            lin_dgrad(g, w, dx)
+        return dx, dres, None, None, None, None, None, None
+
+
+def linear(x, w: WRef, b: Optional[WRef] = None, *, act=K.ACT_NONE, res=None, out=None):
+    return LinearFn.apply(x, res, w.param, b.param if b is not None else None, w, b, act, out)
+
+
+class QuickGeluFn(Function):
+    """x * sigmoid(1.702 x)  (clip.py:234-236)."""
+
+    @staticmethod
+    def forward(ctx, u):
+        a = torch.empty_like(u)
+        K.quickgelu_fwd(u, a)
+        ctx.save_for_backward(u)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        (u,) = ctx.saved_tensors
+        du = torch.empty_like(u)
+        K.act_bwd(K.as_mat(da), u, du, 1)
+        return du
+
+
+def quickgelu(u):
+    return QuickGeluFn.apply(u)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm with fused dropout / residual / positional add
+# ------------------------------------------------------------------------------------------------
+class LayerNormFn(Function):
+    """out = res + dropout_out(LN(dropout_in(x)));  out2 = out + pos (optional second output).
+    clip.py:226-231; layers.py:288-305,313-339."""
+
+    @staticmethod
+    def forward(ctx, x, res, _gp, _bp, gamma: WRef, beta: WRef, eps, pos, p_in, p_out, want_out2):
+        ctx.set_materialize_grads(False)
+        M, C, _ = K.mat(x)
+        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+        out2 = torch.empty(x.shape, device=x.device, dtype=x.dtype) if want_out2 else None
+        stats = torch.empty(M, 2, device=x.device, dtype=torch.float32)
+        seed_in = RT.next_seed() if p_in > 0 else 0
+        seed_out = RT.next_seed() if p_out > 0 else 0
+        K.ln_fwd(x, gamma.master(), beta.master(), eps, out, stats, res=res, out2=out2, pos=pos, p_in=p_in, seed_in=seed_in, p_out=p_out,
+                 seed_out=seed_out)
+        ctx.cfg = (gamma, beta, p_in, seed_in, p_out, seed_out, res is not None, want_out2)
+        ctx.save_for_backward(x, stats)
+        if want_out2:
+            return out, out2
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, dout2=None):
+        gamma, beta, p_in, seed_in, p_out, seed_out, has_res, want_out2 = ctx.cfg
+        x, stats = ctx.saved_tensors
+        M, C, _ = K.mat(x)
+        if dout is None and dout2 is None:
+            return (None,) * 11
+        if dout is None:
+            dout, dout2 = dout2, None
+        dout = K.as_mat(dout)
+        dout2 = K.as_mat(dout2) if dout2 is not None else None
+        dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+        rpb = K.ln_bwd_rows_per_block(M)
+        nb = (M + rpb - 1) // rpb
+        partial = torch.empty(nb, C, 2, device=x.device, dtype=torch.float32)
+        K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, partial, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out)
+        sums = torch.empty(C, 2, device=x.device, dtype=torch.float32)
+        K.reduce_pairs(partial, nb, C, sums)
+        K.split_pairs(sums, C, gamma.grad(), beta.grad())
+        gamma.done()
+        beta.done()
+        dres = None
+        if has_res:
+            if dout2 is None:
+                dres = dout
+            else:
+                dres = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+                K.add_rows(dout, dout2, dres)
+        return dx, dres, None, None, None, None, None, None, None, None, None
+
+
+def layernorm(x, gamma: WRef, beta: WRef, *, eps=1e-5, res=None, pos=None, p_in=0.0, p_out=0.0, want_out2=False):
+    return LayerNormFn.apply(x, res, gamma.param, beta.param, gamma, beta, eps, pos, float(p_in), float(p_out), want_out2)
+
+
+# ------------------------------------------------------------------------------------------------
+# Multi-head attention (projections + scores + masked softmax + PV + out-proj [+ residual])
+# ------------------------------------------------------------------------------------------------
+class MhaFn(Function):
+    """F.multi_head_attention_forward restated on row matrices (clip.py:119-139,246-260; layers.py:291-296,324,329-332).
+    xq: [B*Lq, E]; xk, xv: [B*Lk, E].  Weight rows come as WRefs so packed in_proj slices and separate q/k/v
+    projections share one code path.  Scores are materialised per (batch, head) in the compute dtype with the row
+    padded to a multiple of 8 so that P feeds the P.V MFMA GEMM directly."""
+
+    @staticmethod
+    def forward(ctx, xq, xk, xv, res, *args):
+        (wq, wk, wv, bq, bk, bv, wo, bo, B, heads, causal, kpm, p_drop) = args[-13:]
+        dev, dtype = xq.device, xq.dtype
+        dt = K.dcode(dtype)
+        E = wq.rows
+        dh = E // heads
+        Lq, Lk = xq.shape[0] // B, xk.shape[0] // B
+        same_qk, same_kv = xq is xk, xk is xv
+        # ---- projections ----
+        self_attn = Lq == Lk and (same_qk or same_kv)
+        if Lq == Lk:
+            qkv = torch.empty(B * Lq, 3 * E, device=dev, dtype=dtype)
+            qb, kb, vb = (qkv, 0, 3 * E), (qkv, E, 3 * E), (qkv, 2 * E, 3 * E)
+        else:
+            qbuf = torch.empty(B * Lq, E, device=dev, dtype=dtype)
+            kvbuf = torch.empty(B * Lk, 2 * E, device=dev, dtype=dtype)
+            qb, kb, vb = (qbuf, 0, E), (kvbuf, 0, 2 * E), (kvbuf, E, 2 * E)
+        jobs = [[xq, wq, bq, qb], [xk, wk, bk, kb], [xv, wv, bv, vb]]
+        merged = []
+        for j in jobs:
+            if merged:
+                p = merged[-1]
+                contiguous_w = p[1].param is j[1].param and p[1].off + p[1].rows * p[1].cols == j[1].off
+                contiguous_b = (p[2] is None and j[2] is None) or (p[2] is not None and j[2] is not None and p[2].param is j[2].param
+                                                                    and p[2].off + p[2].rows == j[2].off)
+                contiguous_o = p[3][0] is j[3][0] and p[3][1] + p[1].rows == j[3][1]
+                if p[0] is j[0] and contiguous_w and contiguous_b and contiguous_o:
+                    p[1] = _merge_w(p[1], j[1])
+                    p[2] = _merge_w(p[2], j[2]) if p[2] is not None else None
+                    continue
+            merged.append(list(j))
+        for x_, w_, b_, (buf, col, ld) in merged:
+            lin_fwd(x_, w_, buf, bias=b_, c_off=col, ldc=ld)
+        # ---- scores, softmax ----
+        Lkp = _pad(Lk, 8)
+        S = torch.empty(B * heads, Lq, Lkp, device=dev, dtype=dtype)
+        scale = dh ** -0.5
+        K.gemm(dt, K.A_KC, K.B_KC, qb[0], kb[0], S, Lq, Lk, dh, qb[2], kb[2], Lkp, batch=B * heads, batch_inner=heads,
+               sA=(Lq * qb[2], dh), sB=(Lk * kb[2], dh), sC=(heads * Lq * Lkp, Lq * Lkp), a_off=qb[1], b_off=kb[1], alpha=scale)
+        Pd = None
+        seed = 0
+        if p_drop > 0:
+            Pd = torch.empty_like(S)
+            seed = RT.next_seed()
+        K.softmax_fwd(S, B * heads * Lq, Lq, Lk, Lkp, heads, causal, kpm, Pd, p_drop, seed)
+        Pm = Pd if Pd is not None else S
+        # ---- O = P V, out projection ----
+        O = torch.empty(B * Lq, E, device=dev, dtype=dtype)
+        K.gemm(dt, K.A_KC, K.B_NC, Pm, vb[0], O, Lq, dh, Lk, Lkp, vb[2], E, batch=B * heads, batch_inner=heads,
+               sA=(heads * Lq * Lkp, Lq * Lkp), sB=(Lk * vb[2], dh), sC=(Lq * E, dh), b_off=vb[1])
+        out = torch.empty(B * Lq, wo.rows, device=dev, dtype=dtype)
+        lin_fwd(O, wo, out, bias=bo, res=res)
+        ctx.cfg = (merged, qb, kb, vb, wo, bo, B, heads, Lq, Lk, Lkp, E, dh, scale, p_drop, seed, res is not None, same_qk, same_kv)
+        ctx.save_for_backward(xq, xk, xv, S, Pd, O)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        merged, qb, kb, vb, wo, bo, B, heads, Lq, Lk, Lkp, E, dh, scale, p_drop, seed, has_res, same_qk, same_kv = ctx.cfg
+        xq, xk, xv, S, Pd, O = ctx.saved_tensors
+        dev, dtype = dout.device, xq.dtype
+        dt = K.dcode(dtype)
+        dout = K.as_mat(dout)
+        # out projection
+        lin_wgrad(dout, O, wo)
+        wo.done()
+        if bo is not None:
+            bias_grad(dout, bo)
+            bo.done()
+        dO = torch.empty(B * Lq, E, device=dev, dtype=dtype)
+        lin_dgrad(dout, wo, dO)
+        # gradient buffers mirror the projection buffers
+        if qb[0] is kb[0]:
+            dqkv = torch.empty_like(qb[0])
+            dqb, dkb, dvb = (dqkv, 0, 3 * E), (dqkv, E, 3 * E), (dqkv, 2 * E, 3 * E)
+        else:
+            dq_ = torch.empty_like(qb[0])
+            dkv_ = torch.empty_like(kb[0])
+            dqb, dkb, dvb = (dq_, 0, E), (dkv_, 0, 2 * E), (dkv_, E, 2 * E)
+        Pm = Pd if Pd is not None else S
+        bh = B * heads
+        # dV[b,h] = Pm^T dO
+        K.gemm(dt, K.A_MC, K.B_NC, Pm, dO, dvb[0], Lk, dh, Lq, Lkp, E, dvb[2], batch=bh, batch_inner=heads,
+               sA=(heads * Lq * Lkp, Lq * Lkp), sB=(Lq * E, dh), sC=(Lk * dvb[2], dh), c_off=dvb[1])
+        # dPd = dO V^T
+        dP = torch.empty(bh, Lq, Lkp, device=dev, dtype=dtype)
+        K.gemm(dt, K.A_KC, K.B_KC, dO, vb[0], dP, Lq, Lk, dh, E, vb[2], Lkp, batch=bh, batch_inner=heads,
+               sA=(Lq * E, dh), sB=(Lk * vb[2], dh), sC=(heads * Lq * Lkp, Lq * Lkp), b_off=vb[1])
+        K.softmax_bwd(S, dP, bh * Lq, Lk, Lkp, p_drop, seed)
+        # dQ = scale * dS K ;  dK = scale * dS^T Q
+        K.gemm(dt, K.A_KC, K.B_NC, dP, kb[0], dqb[0], Lq, dh, Lk, Lkp, kb[2], dqb[2], batch=bh, batch_inner=heads,
+               sA=(heads * Lq * Lkp, Lq * Lkp), sB=(Lk * kb[2], dh), sC=(Lq * dqb[2], dh), b_off=kb[1], c_off=dqb[1], alpha=scale)
+        K.gemm(dt, K.A_MC, K.B_NC, dP, qb[0], dkb[0], Lk, dh, Lq, Lkp, qb[2], dkb[2], batch=bh, batch_inner=heads,
+               sA=(heads * Lq * Lkp, Lq * Lkp), sB=(Lq * qb[2], dh), sC=(Lk * dkb[2], dh), b_off=qb[1], c_off=dkb[1], alpha=scale)
+        # projections backward
+        dbufs = {id(qb[0]): None}
+        grads = {}
+        for x_, w_, b_, (buf, col, ld) in merged:
+            dbuf = dqb[0] if buf is qb[0] else dkb[0]
+            M = x_.shape[0]
+            lin_wgrad(dbuf, x_, w_, a_off=col, lda=ld, N=w_.rows)
+            w_.done()
+            if b_ is not None:
+                bias_grad(dbuf[:, col:col + w_.rows], b_)
+                b_.done()
+            prev = grads.get(id(x_))
+            dx = prev if prev is not None else torch.empty(x_.shape, device=dev, dtype=dtype)
+            lin_dgrad(dbuf, w_, dx, accumulate_into=prev, a_off=col, lda=ld, N=w_.rows)
+            grads[id(x_)] = dx
+        dxq = grads.get(id(xq))
+        dxk = None if same_qk else grads.get(id(xk))
+        dxv = None if (same_kv or xv is xq) else grads.get(id(xv))
+        dres = dout if has_res else None
+        n_extra = 13 + 8
+        return (dxq, dxk, dxv, dres) + (None,) * n_extra
+
+
+def _merge_w(a: WRef, b: WRef) -> WRef:
+    m = WRef.__new__(WRef)
+    m.store, m.param, m.off, m.cols = a.store, a.param, a.off, a.cols
+    m.rows = a.rows + b.rows
+    return m
+
+
+def mha(xq, xk, xv, wq: WRef, wk: WRef, wv: WRef, bq, bk, bv, wo: WRef, bo, *, B, heads, causal=False, kpm=None, p_drop=0.0, res=None):
+    params = [r.param for r in (wq, wk, wv, bq, bk, bv, wo, bo) if r is not None]
+    params = params + [None] * (8 - len(params))
+    return MhaFn.apply(xq, xk, xv, res, *params, wq, wk, wv, bq, bk, bv, wo, bo, B, heads, causal, kpm, float(p_drop))
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / upsampling / joins / broadcasts
+# ------------------------------------------------------------------------------------------------
+class AvgPool2Fn(Function):
+    @staticmethod
+    def forward(ctx, x, out):
+        B, H, W, C = x.shape
+        y = _dest(out) if out is not None else torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=x.dtype)
+        K.avgpool2_fwd(x, y)
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=dy.dtype)
+        K.avgpool2_bwd(K.as_mat(dy), dx)
+        return dx, None
+
+
+def avgpool2(x, out=None):
+    return AvgPool2Fn.apply(x, out)
+
+
+class Upsample2Fn(Function):
+    @staticmethod
+    def forward(ctx, x, out):
+        B, H, W, C = x.shape
+        y = _dest(out) if out is not None else torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=x.dtype)
+        K.upsample2_fwd(x, y)
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=dy.dtype)
+        K.upsample2_bwd(K.as_mat(dy), dx)
+        return dx, None
+
+
+def upsample2(x, out=None):
+    return Upsample2Fn.apply(x, out)
+
+
+class JoinFn(Function):
+    """Channel concatenation without a copy: the producers already wrote into channel slices of `buf`
+    (torch.cat call sites layers.py:38,383,387,394).  Backward hands each producer its slice of the gradient."""
+
+    @staticmethod
+    def forward(ctx, buf: "OutRef", widths, *parts):
+        ctx.widths = widths
+        return buf.t.view(buf.t.shape)
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        outs, c = [], 0
+        for w in ctx.widths:
+            outs.append(dbuf[..., c:c + w])
+            c += w
+        return (None, None) + tuple(outs)
+
+
+def join(buf: torch.Tensor, parts):
+    return JoinFn.apply(OutRef(buf), tuple(p.shape[-1] for p in parts), *parts)
+
+
+class AddReluFn(Function):
+    """relu(a + b)   (attnpool tail clip.py:141-142)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        C = a.shape[-1]
+        ident = torch.zeros(C, 2, device=a.device, dtype=torch.float32)
+        ident[:, 0] = 1.0
+        y = torch.empty_like(a)
+        K.bn_apply(a, ident, b, True, y)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        g = torch.empty_like(y)
+        K.act_bwd(K.as_mat(dy), y, g, 0)
+        return g, g
+
+
+def add_relu(a, b):
+    return AddReluFn.apply(a, b)
+
+
+class MulBcastFn(Function):
+    """z[b,p,:] = x[b,p,:] * s[b,:]   (layers.py:379)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        B = s.shape[0]
+        P = x.numel() // (B * x.shape[-1])
+        z = torch.empty_like(x)
+        K.mul_bcast_fwd(x, s, z, B, P)
+        ctx.save_for_backward(x, s)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, s = ctx.saved_tensors
+        B = s.shape[0]
+        P = x.numel() // (B * x.shape[-1])
+        dx, ds = torch.empty_like(x), torch.empty_like(s)
+        K.mul_bcast_bwd(K.as_mat(dz), x, s, dx, ds, B, P)
+        return dx, ds
+
+
+def mul_bcast(x, s):
+    return MulBcastFn.apply(x, s)
+
+
+class AddRowsFn(Function):
+    """out = a + table[row % rows(table)]; the table is a constant (sin/cos encodings) or carries its own grad path."""
+
+    @staticmethod
+    def forward(ctx, a, table):
+        out = torch.empty_like(a)
+        K.add_rows(a, table, out)
+        ctx.tshape = table.shape
+        ctx.tgrad = table.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dt_ = None
+        if ctx.tgrad:
+            dout_m = K.as_mat(dout)
+            rows = 1
+            for s in ctx.tshape[:-1]:
+                rows *= s
+            acc = torch.empty(rows, ctx.tshape[-1], device=dout.device, dtype=torch.float32)
+            K.sum_over_batch(dout_m.reshape(-1, ctx.tshape[-1]), acc, dout_m.numel() // (rows * ctx.tshape[-1]))
+            dt_ = acc.to(dout.dtype).view(ctx.tshape) if dout.dtype != torch.float32 else acc.view(ctx.tshape)
+        return dout, dt_
+
+
+def add_rows(a, table):
+    return AddRowsFn.apply(a, table)
+
+
+class AddDropoutFn(Function):
+    """out = a + dropout(b)   (layers.py:338 with p > 0)."""
+
+    @staticmethod
+    def forward(ctx, a, b, p):
+        out = torch.empty_like(b)
+        seed = RT.next_seed() if p > 0 else 0
+        K.add_dropout(a, b, out, p, seed)
+        ctx.cfg = (p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, seed = ctx.cfg
+        dout = K.as_mat(dout)
+        db = torch.empty_like(dout)
+        K.add_dropout(None, dout, db, p, seed)
+        return dout, db, None
+
+
+def add_dropout(a, b, p):
+    return AddDropoutFn.apply(a, b, float(p))
+
+
+# ------------------------------------------------------------------------------------------------
+# text front end
+# ------------------------------------------------------------------------------------------------
+class EmbeddingFn(Function):
+    """token_embedding(text) + positional_embedding[:L]   (clip.py:440-443)."""
+
+    @staticmethod
+    def forward(ctx, word, _tp, _pp, tok: WRef, pos: WRef, dtype):
+        B, L = word.shape
+        C = tok.cols
+        out = torch.empty(B * L, C, device=word.device, dtype=dtype)
+        wbuf = tok.w(dtype)
+        esz = 2 if dtype == torch.bfloat16 else 4
+        K.check(K.lib().crog_embedding_fwd(K.dcode(dtype), K.ptr(word), K.ptr(wbuf) + esz * tok.off, K.ptr(wbuf) + esz * pos.off, K.ptr(out),
+                                           B * L, L, C, tok.rows, K.stream()), "embedding_fwd")
+        ctx.cfg = (tok, pos, L)
+        ctx.save_for_backward(word)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tok, pos, L = ctx.cfg
+        (word,) = ctx.saved_tensors
+        dout = K.as_mat(dout)
+        C = tok.cols
+        K.check(K.lib().crog_embedding_bwd(K.dcode(dout), K.ptr(word), K.ptr(dout), K.ptr(tok.G) + 4 * tok.off, K.ptr(pos.G) + 4 * pos.off,
+                                           dout.shape[0], L, C, tok.rows, K.stream()), "embedding_bwd")
+        tok.done()
+        pos.done()
+        return (None,) * 6
+
+
+def embedding(word, tok: WRef, pos: WRef, dtype):
+    return EmbeddingFn.apply(word, tok.param, pos.param, tok, pos, dtype)
+
+
+class GatherRowsFn(Function):
+    """x[idx] over rows (EOT token select, clip.py:451-452)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        out = torch.empty(idx.shape[0], x.shape[-1], device=x.device, dtype=x.dtype)
+        K.gather_rows(x, idx, out)
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dx = torch.zeros(ctx.shape, device=dout.device, dtype=dout.dtype)
+        K.scatter_rows(K.as_mat(dout), idx, dx)
+        return dx, None
+
+
+def gather_rows(x, idx):
+    return GatherRowsFn.apply(x, idx)
+
+
+class TableMatmulFn(Function):
+    """out[R, C] = A[R, Kp] @ table[K, C] for a constant A and a parameter table: the bicubic 7x7 -> HxW resize of
+    attnpool.positional_embedding[1:] written as its (fixed) interpolation matrix (clip.py:95-108), and
+    `x @ text_projection` / `x @ proj` style right-multiplications by a [K, N] parameter (clip.py:452,330)."""
+
+    @staticmethod
+    def forward(ctx, A, _tp, table: WRef, dtype):
+        R, Kp = A.shape
+        C = table.cols
+        out = torch.empty(R, C, device=A.device, dtype=dtype)
+        K.gemm(K.dcode(dtype), K.A_KC, K.B_NC, A, table.w(dtype), out, R, C, table.rows, Kp, C, C, b_off=table.off)
+        ctx.cfg = (table, A.requires_grad)
+        ctx.save_for_backward(A)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        table, a_grad = ctx.cfg
+        (A,) = ctx.saved_tensors
+        dout = K.as_mat(dout)
+        R, Kp = A.shape
+        C = table.cols
+        dt = K.dcode(dout)
+        sk = K.pick_splitk(table.rows, C, R, _bk(dt))
+        K.gemm(dt, K.A_MC, K.B_NC, A, dout, table.G, table.rows, C, R, Kp, K.mat(dout)[2], C, c_off=table.off, splitk=sk,
+               out_mode=K.OUT_F32_ATOMIC)
+        table.done()
+        dA = None
+        if a_grad:
+            dA = torch.empty_like(A)
+            # dA[R, K] = dout[R, C] @ table[K, C]^T : table rows are K-contiguous over C
+            K.gemm(dt, K.A_KC, K.B_KC, dout, table.w(dout.dtype), dA, R, table.rows, C, K.mat(dout)[2], C, Kp, b_off=table.off)
+            if Kp > table.rows:
+                dA[:, table.rows:].zero_()
+        return dA, None, None, None
+
+
+def table_matmul(A, table: WRef, dtype):
+    return TableMatmulFn.apply(A, table.param, table, dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# dynamic-conv head + losses
+# ------------------------------------------------------------------------------------------------
+class DynHeadFn(Function):
+    """Projector / MultiTaskProjector tail (layers.py:90-132,161-173): txt Linear(state) -> per-sample 3x3 kernel + bias,
+    applied to each C-channel group of x5.  Output: fp32 logits [B, groups, H, W]."""
+
+    @staticmethod
+    def forward(ctx, x5, state, _wp, _bp, tw: WRef, tb: WRef, C):
+        B, H, W, CT = x5.shape
+        groups = CT // C
+        dev, dtype = x5.device, x5.dtype
+        dt = K.dcode(dtype)
+        nout = C * 9 + 1
+        ldw = _pad(nout, 8)
+        word = torch.empty(B, ldw, device=dev, dtype=torch.float32)
+        lin_fwd(state, tw, word, bias=tb, out_mode=K.OUT_F32, ldc=ldw)
+        wpad = torch.empty(B, C, 16, device=dev, dtype=dtype)
+        K.head_pack_weights(word, wpad, B, C)
+        P = H * W
+        t = torch.empty(B * P * groups, 16, device=dev, dtype=torch.float32)
+        K.gemm(dt, K.A_KC, K.B_NC, x5, wpad, t, P * groups, 16, C, C, 16, 16, batch=B, sA=(P * groups * C, 0), sB=(C * 16, 0),
+               sC=(P * groups * 16, 0), out_mode=K.OUT_F32)
+        out = torch.empty(B, groups, H, W, device=dev, dtype=torch.float32)
+        K.head_stencil_fwd(t, word, C * 9, out, B, groups, H, W)
+        ctx.cfg = (tw, tb, C, groups, ldw)
+        ctx.save_for_backward(x5, state, wpad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tw, tb, C, groups, ldw = ctx.cfg
+        x5, state, wpad = ctx.saved_tensors
+        B, H, W, CT = x5.shape
+        dev, dtype = x5.device, x5.dtype
+        dt = K.dcode(dtype)
+        P = H * W
+        dout = dout.contiguous()
+        dtb = torch.empty(B * P * groups, 16, device=dev, dtype=dtype)
+        dbias = torch.empty(B, device=dev, dtype=torch.float32)
+        K.head_stencil_bwd(dout, dtb, dbias, B, groups, H, W)
+        # dx5[b,(p,g),c] = sum_tap dt[b,(p,g),tap] * w[b,c,tap]
+        dx5 = torch.empty_like(x5)
+        K.gemm(dt, K.A_KC, K.B_KC, dtb, wpad, dx5, P * groups, C, 16, 16, 16, C, batch=B, sA=(P * groups * 16, 0), sB=(C * 16, 0),
+               sC=(P * groups * C, 0))
+        # dw[b,c,tap] = sum_(p,g) x5[b,(p,g),c] * dt[b,(p,g),tap]
+        dwpad = torch.zeros(B, C, 16, device=dev, dtype=torch.float32)
+        sk = max(1, min(16, (P * groups) // 2048))
+        K.gemm(dt, K.A_MC, K.B_NC, x5, dtb, dwpad, C, 16, P * groups, C, 16, 16, batch=B, sA=(P * groups * C, 0), sB=(P * groups * 16, 0),
+               sC=(C * 16, 0), splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+        dword = torch.empty(B, ldw, device=dev, dtype=dtype)
+        K.head_unpack_wgrad(dwpad, dbias, dword, B, C)
+        nout = C * 9 + 1
+        lin_wgrad(dword, state, tw, N=nout)
+        tw.done()
+        bias_grad(dword[:, :nout], tb)
+        tb.done()
+        dstate = torch.empty_like(state)
+        lin_dgrad(dword, tw, dstate, N=nout)
+        return dx5, dstate, None, None, None, None, None
+
+
+def dyn_head(x5, state, tw: WRef, tb: WRef, C):
+    return DynHeadFn.apply(x5, state, tw.param, tb.param, tw, tb, C)
+
+
+class LossFn(Function):
+    """crog.py:76-99 / 119-124 in one pass: nearest target resize, weighted BCE + 4 smooth-L1, d(loss)/d(pred)."""
+
+    @staticmethod
+    def forward(ctx, pred, targets, weighted):
+        B, heads, H, W = pred.shape
+        Hin, Win = targets[0].shape[-2:]
+        tgt_small = torch.empty(heads, B, 1, H, W, device=pred.device, dtype=torch.float32)
+        sums = torch.empty(5, device=pred.device, dtype=torch.float32)
+        dpred = torch.empty_like(pred)
+        K.head_loss(pred, [t.contiguous() for t in targets], Hin, Win, weighted, tgt_small, sums, dpred)
+        ctx.save_for_backward(dpred)
+        ctx.mark_non_differentiable(tgt_small, sums)
+        total = sums[:heads].sum()
+        return total, sums, tgt_small
+
+    @staticmethod
+    def backward(ctx, dtotal, _a, _b):
+        (dpred,) = ctx.saved_tensors
+        return dpred * dtotal, None, None
+
+
+def head_loss(pred, targets, weighted):
+    return LossFn.apply(pred, targets, weighted)
+
+
+def train_metric(pred_ins, target, threshold=0.35, pr_iou=0.5):
+    """utils/misc.py:115-131 on device: returns (100*IoU, 100*Prec@pr_iou) as a 2-element fp32 tensor."""
+    B = pred_ins.shape[0]
+    P = pred_ins[0].numel()
+    if pred_ins.dtype != torch.float32:
+        raise TypeError("train_metric expects fp32 logits")
+    counts = torch.empty(B, 2, device=pred_ins.device, dtype=torch.float32)
+    out2 = torch.empty(2, device=pred_ins.device, dtype=torch.float32)
+    K.train_metric(pred_ins, pred_ins.stride(0), target.contiguous(), B, P, threshold, pr_iou, counts, out2)
+    return out2

@@ -331,6 +331,12 @@ def coord_fill(buf, c0, cend):
     check(lib().crog_coord_fill(dcode(buf), ptr(buf), ld, B, H, W, c0, cend, stream()), "coord_fill")
 
 
+def colsum(x, out, out_off=0):
+    M, C, ldx = mat(x)
+    rpb = max(16, (M + 255) // 256)
+    check(lib().crog_colsum(dcode(x), ptr(x), ldx, M, C, rpb, ptr(out) + 4 * out_off, stream()), "colsum")
+
+
 def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, shadow=None, off=0):
     sh = None if shadow is None else ptr(shadow) + 2 * off
     check(lib().crog_adam_step(ptr(p) + 4 * off, ptr(g) + 4 * off, ptr(m) + 4 * off, ptr(v) + 4 * off, n, float(lr), float(beta1),

@@ -1,0 +1,176 @@
+"""CROG module on the HIP path — drop-in for the reference's model/crog.py (same constructor keys, same
+forward signature and return contract).
+
+Compute dtype: bf16 when called under torch autocast (the reference's training step runs under
+`amp.autocast()`, engine/crog_engine.py:72), fp32 otherwise (its eval path, crog_engine.py:166);
+`model.compute_dtype = torch.float32 | torch.bfloat16` pins it explicitly.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from ..runtime import RT, ParamStore
+from .blocks import BatchNorm, bind_all
+from .clip import arch_from_state_dict, build_model
+from .layers import FPN, MultiTaskProjector, Projector, TransformerDecoder
+
+RN50_ARCH = dict(embed_dim=1024, image_resolution=224, vision_layers=(3, 4, 6, 3), vision_width=64, vision_patch_size=None,
+                 context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12)
+
+
+class LossDict(dict):
+    """loss_dict of crog.py:101-106 with ONE device->host sync on first access instead of five `.item()` calls."""
+
+    KEYS = ("m_ins", "m_qua", "m_sin", "m_cos", "m_wid")
+
+    def __init__(self, sums: torch.Tensor, heads: int):
+        super().__init__()
+        self._sums, self._heads = sums, heads
+        self._done = False
+
+    def _fill(self):
+        if not self._done:
+            vals = self._sums.tolist()
+            for i, k in enumerate(self.KEYS):
+                dict.__setitem__(self, k, vals[i] if i < self._heads else 0)
+            self._done = True
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return 5
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+
+class CROG(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.use_contrastive = cfg.use_contrastive
+        self.use_pretrained_clip = cfg.use_pretrained_clip
+        self.use_grasp_masks = cfg.use_grasp_masks
+        arch, sd = self._clip_arch(cfg)
+        self.backbone = build_model(arch, cfg.word_len)
+        if sd is not None and self.use_pretrained_clip:
+            # clip.py:552-554: fp16 round trip of the checkpoint weights, strict=False (attnpool.connect.* stay random)
+            sd = {k: (v.half().float() if v.is_floating_point() else v) for k, v in sd.items()
+                  if k not in ("input_resolution", "context_length", "vocab_size")}
+            self.backbone.load_state_dict(sd, strict=False)
+        self.neck = FPN(in_channels=cfg.fpn_in, out_channels=cfg.fpn_out)
+        if self.use_contrastive:
+            self.decoder = TransformerDecoder(num_layers=cfg.num_layers, d_model=cfg.vis_dim, nhead=cfg.num_head, dim_ffn=cfg.dim_ffn,
+                                              dropout=cfg.dropout, return_intermediate=cfg.intermediate)
+        if self.use_grasp_masks:
+            self.proj = MultiTaskProjector(cfg.word_dim, cfg.vis_dim // 2, 3)
+        else:
+            self.proj = Projector(cfg.word_dim, cfg.vis_dim // 2, 3)
+        self.compute_dtype = None
+        self._store = None
+        self._bns = None
+
+    @staticmethod
+    def _clip_arch(cfg):
+        """cfg.clip_pretrain names a TorchScript CLIP archive (crog.py:20-23).  When it exists, the architecture is
+        inferred from its tensor shapes; otherwise `cfg.clip_arch` (or RN50) describes it and weights are random-init."""
+        import os
+        path = getattr(cfg, "clip_pretrain", None)
+        if path and os.path.exists(str(path)):
+            sd = torch.jit.load(path, map_location="cpu").eval().state_dict()
+            return arch_from_state_dict(sd), sd
+        return dict(getattr(cfg, "clip_arch", None) or RN50_ARCH), None
+
+    # ---- storage ---------------------------------------------------------------------------------
+    def prepare(self, device=None):
+        """Move parameters into the flat store on `device` and bind the kernels' weight references."""
+        if device is None:
+            device = next(self.parameters()).device
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("crog_amd.CROG runs on an MI355X only: there is no CPU path (move the module with .cuda())")
+        for b_name, buf in list(self.named_buffers()):
+            if buf.device != device:
+                mod = self
+                *path, leaf = b_name.split(".")
+                for p in path:
+                    mod = getattr(mod, p)
+                mod._buffers[leaf] = buf.to(device)
+        self._store = ParamStore(self, device)
+        bind_all(self, self._store)
+        self._bns = [m for m in self.modules() if isinstance(m, BatchNorm)]
+        return self
+
+    def _ensure(self, device):
+        if self._store is None or not self._store.valid() or self._store.device != device:
+            self.prepare(device)
+
+    @property
+    def store(self) -> ParamStore:
+        return self._store
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._store = None  # .cuda()/.float()/.to() re-materialise parameters: rebuild the flat store lazily
+        return out
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        if self._store is not None:
+            self._store.invalidate_shadow()
+        return out
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, img, word, mask=None, grasp_qua_mask=None, grasp_sin_mask=None, grasp_cos_mask=None, grasp_wid_mask=None):
+        """img: [b,3,h,w] fp32; word: [b,L] int64; masks: [b,1,h,w] fp32 (crog.py:47)."""
+        dev = img.device
+        self._ensure(dev)
+        dtype = self.compute_dtype or (torch.bfloat16 if torch.is_autocast_enabled() else torch.float32)
+        store = self._store
+        store.invalidate_shadow()          # parameters may have been stepped since the last forward
+        if self.training and torch.is_grad_enabled():
+            store.relink_grads()
+            store.zero_grad()
+        with torch.autocast("cuda", enabled=False):
+            pad_mask = (word == 0).contiguous()
+            vis = self.backbone.image_features(img, dtype)
+            wfeat, state = self.backbone.text_features(word, dtype)
+            fq = self.neck(vis, state)
+            if self.use_contrastive:
+                fq = self.decoder(fq, wfeat, pad_mask)
+            pred = self.proj(fq, state)                      # fp32 logits [b, groups, H, W]
+            if self.training and self._bns:
+                torch._foreach_add_([m.num_batches_tracked for m in self._bns], 1)
+            n = 5 if self.use_grasp_masks else 1
+            preds = tuple(pred[:, i:i + 1].detach() for i in range(n))
+            targets = (mask, grasp_qua_mask, grasp_sin_mask, grasp_cos_mask, grasp_wid_mask)[:n]
+            if self.training:
+                total, sums, small = Fn.head_loss(pred, [t.float() for t in targets], weighted=self.use_grasp_masks)
+                loss_dict = LossDict(sums, n)
+                tgt = tuple(small[i] for i in range(n))
+                if self.use_grasp_masks:
+                    return preds, tgt, total, loss_dict
+                return (preds[0], None, None, None, None), (tgt[0], None, None, None, None), total, loss_dict
+            if self.use_grasp_masks:
+                return preds, tuple(targets)
+            return preds[0], mask
