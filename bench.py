@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of CROG-R50, 416x416, 20 tokens, batch 32 per GPU (BASELINE.json).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = forward (bf16 autocast) + losses + backward + gradient all-reduce (N > 1) + fused Adam + train metric on one
+synthetic batch that is already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+FLOP_PER_IMG = 413.6e9          # fwd+bwd, 2*MAC (probe of the reference)
+BYTES_PER_IMG = 1.58e9          # algorithmic HBM bytes per image, bf16 activations, contraction-level fusion
+BYTES_PER_STEP_WEIGHTS = 5.6e9  # per-step weight-side traffic (bf16 weight reads x3, fp32 grad write, Adam 7 streams)
+PEAK_HBM_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_MFMA_TF = 2500.0           # dense bf16 MFMA
+
+
+def cpu_baseline(steps=2, warmup=1):
+    """The CPU oracle (oracle/crog_oracle.py, a restatement of the reference's PyTorch-CPU path) doing the same training step
+    (fwd + losses + bwd + Adam) on BASELINE config 1: CROG-R50, B=2, 416x416, fp32, on this box's host cores."""
+    from crog_amd.testing import make_cfg, seeded_state, synthetic_batch
+    from crog_amd.model import build_crog
+    from oracle import crog_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    cfg = make_cfg(dropout=0.0)
+    model, _ = build_crog(cfg)  # only for names/shapes (CPU tensors; never run)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    names = [n for n, _ in model.named_parameters()]
+    del model
+    P = seeded_state(shapes, seed=5, residual_gain=0.25)
+    params = [P[n].requires_grad_(True) for n in names]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    b = synthetic_batch(2, 416, 20, 49408, seed=1)
+    times = []
+    for i in range(warmup + steps):
+        t0 = time.time()
+        out = O.crog_forward(P, b["img"], b["word"], [b[k] for k in ("mask", "qua", "sin", "cos", "wid")], num_head=cfg.num_head)
+        opt.zero_grad()
+        out["total"].backward()
+        opt.step()
+        times.append(time.time() - t0)
+    t = sum(times[warmup:]) / steps
+    return dict(value=round(2.0 / t, 4), unit="images/sec", cores=ncores, kind="port",
+                sample=f"oracle training step (fwd+loss+bwd+Adam), CROG-R50 fp32, B=2, 416x416, 20 tokens: {steps} timed steps after "
+                       f"{warmup} warm-up, {t:.2f} s/step, torch CPU threads={ncores}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-kernel", default="conv3x3_wgrad", choices=["conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "lin_fwd", "none"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from crog_amd import kernels as K
+    from crog_amd.engine import train_step
+    from crog_amd.model import build_crog
+    from crog_amd.optim import FusedAdam
+    from crog_amd.parallel import DistributedDataParallel, convert_sync_batchnorm
+    from crog_amd.runtime import RT
+    from crog_amd.testing import make_cfg, synthetic_batch
+
+    cfg = make_cfg(batch_size=args.batch * world, input_size=args.size)  # crog_multiple_r50.yaml keys, dropout 0.1, sync_bn True
+    torch.manual_seed(0)
+    model, groups = build_crog(cfg)            # random init of the RN50 architecture (no checkpoint / network here)
+    model = model.to(dev)
+    model.prepare(dev)
+    net = model
+    if world > 1:
+        convert_sync_batchnorm(model)
+        net = DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True)
+    opt = FusedAdam(groups, lr=cfg.base_lr, weight_decay=cfg.weight_decay, store=model.store)
+    RT.manual_seed(1234 + rank)
+    batch = synthetic_batch(args.batch, args.size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + rank, device=dev)
+    net.train()
+    adt = torch.bfloat16 if args.dtype == "bf16" else None
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stats, _ = train_step(net, opt, None, batch, cfg, autocast_dtype=adt)
+    sync()
+    key = {"conv3x3_fwd": (K.A_IM2COL, K.B_KC), "conv3x3_dgrad": (K.A_IM2COL, K.B_NC_DGRAD), "conv3x3_wgrad": (K.A_MC, K.B_NC_IM2COL),
+           "lin_fwd": (K.A_KC, K.B_KC), "none": None}[args.roofline_kernel]
+    if key is not None and rank == 0:
+        K.PROF = dict(key=key, records=[])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats, _ = train_step(net, opt, None, batch, cfg, autocast_dtype=adt)
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    last = stats.tolist()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        ips = args.batch * world * args.steps / dt
+        roof = None
+        if K.PROF is not None and K.PROF["records"]:
+            recs = K.PROF["records"]
+            K.PROF = None
+            durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _, _ in recs]
+            flops = [f for _, _, f, _ in recs]
+            avg_d, avg_f = sum(durs) / len(durs), sum(flops) / len(flops)
+            roof = dict(bound="mfma", achieved=round(avg_f / avg_d / 1e12, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
+                        frac=round(avg_f / avg_d / 1e12 / PEAK_MFMA_TF, 4), traffic=None,
+                        kernel=K.GEMM_SYMBOL[key], launches_per_step=len(recs) // args.steps,
+                        avg_launch_us=round(avg_d * 1e6, 1), avg_gflop_per_launch=round(avg_f / 1e9, 2),
+                        share_of_step=round(sum(durs) / dt, 4))
+        out = {
+            "metric": "training images/sec CROG-R50 416x416 bs32/GPU", "value": round(ips, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"CROG-R50 {args.dtype} training step (fwd+loss+bwd+allreduce+Adam+metric), {args.size}x{args.size} RGB + "
+                                   f"20 tokens, batch {args.batch}/GPU, dropout 0.1, SyncBN, random-init RN50 architecture",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "step_roofline": {"hbm_frac": round((BYTES_PER_IMG * args.batch + BYTES_PER_STEP_WEIGHTS) / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                              "mfma_frac": round(FLOP_PER_IMG * args.batch / (ms * 1e-3) / 1e12 / PEAK_MFMA_TF, 4),
+                              "note": "per-GPU algorithmic bytes (1.58 GB/img + 5.6 GB/step) and FLOPs (413.6 GFLOP/img) / step time vs 8 TB/s, 2.5 PFLOP/s"},
+            "roofline": roof,
+            "last_step": {"loss": round(last[0], 4), "iou": round(last[1], 3), "prec50": round(last[2], 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

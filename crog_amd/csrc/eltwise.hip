@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(NT) act_bwd_kernel(const T* __restrict__ dy, l
       float d;
       if (mode == 0) d = u > 0.f ? gf : 0.f;
       else {
-        const float sg = 1.f / (1.f + __expf(-1.702f * u));
+        const float sg = 1.f / (1.f + expf(-1.702f * u));
         d = gf * sg * (1.f + 1.702f * u * (1.f - sg));
       }
       o.v[e] = Elem<T>::from_f(d);
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(NT) quickgelu_fwd_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < VEC; e++) {
       const float f = Elem<T>::to_f(v.v[e]);
-      o.v[e] = Elem<T>::from_f(f / (1.f + __expf(-1.702f * f)));
+      o.v[e] = Elem<T>::from_f(f / (1.f + expf(-1.702f * f)));
     }
     stg16(out + r * ldo + c, o);
   }

@@ -120,8 +120,8 @@ __global__ void __launch_bounds__(NT) head_loss_kernel(const float* __restrict__
       float l, g;
       if (h == 0) {
         const float w = weighted ? t * 0.5f + 1.f : 1.f;
-        l = w * (fmaxf(p, 0.f) - p * t + log1pf(__expf(-fabsf(p))));
-        g = w * (1.f / (1.f + __expf(-p)) - t);
+        l = w * (fmaxf(p, 0.f) - p * t + log1pf(expf(-fabsf(p))));
+        g = w * (1.f / (1.f + expf(-p)) - t);
       } else {
         const float d = p - t, ad = fabsf(d);
         l = ad < 1.f ? 0.5f * d * d : ad - 0.5f;

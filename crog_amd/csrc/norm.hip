@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(NT) softmax_fwd_kernel(T* __restrict__ S, long
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < MAXE; j++) {
-    const float e = (v[j] == -INFINITY) ? 0.f : __expf(v[j] - mx);
+    const float e = (v[j] == -INFINITY) ? 0.f : expf(v[j] - mx);
     v[j] = e;
     sum += e;
   }

@@ -1,0 +1,89 @@
+"""Training step / epoch loop of the HIP path — mirror of engine/crog_engine.py::train_with_grasp (:17-122).
+
+Same call signature and per-step semantics (autocast forward, zero_grad, scaled backward, optional clipping,
+optimizer step, scaler update, train IoU / Prec@50 metric, rank-averaged scalars), with two changes that do not
+alter results: the three scalar all-reduces of crog_engine.py:88-90 are packed into one 3-float all-reduce, and
+host reads of device scalars happen once per `print_freq` steps instead of ~8 times per step.
+"""
+from __future__ import annotations
+
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+
+
+class AverageMeter:
+    def __init__(self, name, fmt=":f"):
+        self.name, self.fmt = name, fmt
+        self.val = self.avg = self.sum = self.count = 0.0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / max(self.count, 1)
+
+    def __str__(self):
+        return ("{name} {val" + self.fmt + "} ({avg" + self.fmt + "})").format(**self.__dict__)
+
+
+def train_step(model, optimizer, scaler, batch, args=None, autocast_dtype=torch.bfloat16):
+    """One optimisation step (crog_engine.py:60-90). `batch` holds device tensors img, word, mask, qua, sin, cos, wid with the
+    masks already [B,1,H,W].  Returns a 3-element device tensor (loss, 100*IoU, 100*Prec@50), rank-averaged."""
+    with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
+        pred, target, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
+    optimizer.zero_grad()
+    if scaler is not None and scaler.is_enabled():
+        scaler.scale(loss).backward()
+    else:
+        loss.backward()
+    max_norm = getattr(args, "max_norm", 0.0) if args is not None else 0.0
+    if max_norm:
+        if scaler is not None and scaler.is_enabled():
+            scaler.unscale_(optimizer)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+    if scaler is not None and scaler.is_enabled():
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        optimizer.step()
+    m = Fn.train_metric(pred[0], target[0], 0.35, 0.5)
+    stats = torch.stack([loss.detach().float(), m[0], m[1]])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(stats)
+        stats = stats / dist.get_world_size()
+    return stats, loss_dict
+
+
+def train_with_grasp(train_loader, model, optimizer, scheduler, scaler, epoch, args, log=print):
+    """Epoch loop with the reference's meters (crog_engine.py:17-122)."""
+    batch_time, data_time = AverageMeter("Batch", ":2.2f"), AverageMeter("Data", ":2.2f")
+    lr, loss_meter = AverageMeter("Lr", ":1.6f"), AverageMeter("Loss", ":2.4f")
+    iou_meter, pr_meter = AverageMeter("IoU", ":2.2f"), AverageMeter("Prec@50", ":2.2f")
+    model.train()
+    end = time.time()
+    pending = []
+    for i, data in enumerate(train_loader):
+        data_time.update(time.time() - end)
+        gm = data["grasp_masks"]
+        batch = dict(img=data["img"].cuda(non_blocking=True), word=data["word_vec"].cuda(non_blocking=True),
+                     mask=data["mask"].cuda(non_blocking=True).unsqueeze(1), qua=gm["qua"].cuda(non_blocking=True).unsqueeze(1),
+                     sin=gm["sin"].cuda(non_blocking=True).unsqueeze(1), cos=gm["cos"].cuda(non_blocking=True).unsqueeze(1),
+                     wid=gm["wid"].cuda(non_blocking=True).unsqueeze(1))
+        stats, _ = train_step(model, optimizer, scaler, batch, args)
+        pending.append((stats, batch["img"].size(0)))
+        lr.update(scheduler.get_last_lr()[-1])
+        if (i + 1) % args.print_freq == 0 or i + 1 == len(train_loader):
+            for st, n in pending:           # one host sync per print window
+                v = st.tolist()
+                loss_meter.update(v[0], n)
+                iou_meter.update(v[1], n)
+                pr_meter.update(v[2], n)
+            pending.clear()
+            batch_time.update((time.time() - end) / args.print_freq)
+            end = time.time()
+            log("Training: Epoch=[{}/{}] [{}/{}]  ".format(epoch, args.epochs, i + 1, len(train_loader)) +
+                "  ".join(str(m) for m in (batch_time, data_time, lr, loss_meter, iou_meter, pr_meter)))

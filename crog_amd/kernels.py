@@ -21,6 +21,19 @@ ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
 OUT_T, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 
 
+# Optional per-launch timing of ONE GEMM variant (bench.py's roofline leg): {"key": (a_layout, b_layout), "records": []}
+PROF = None
+GEMM_SYMBOL = {
+    (A_KC, B_KC): "gemm_kernel<T, A_KC, B_KC>  (1x1 conv / linear forward, Q.K^T)",
+    (A_IM2COL, B_KC): "gemm_kernel<T, A_IM2COL, B_KC>  (3x3 conv forward, implicit GEMM)",
+    (A_KC, B_NC): "gemm_kernel<T, A_KC, B_NC>  (1x1 / linear dgrad, P.V)",
+    (A_IM2COL, B_NC_DGRAD): "gemm_kernel<T, A_IM2COL, B_NC_DGRAD>  (3x3 conv dgrad)",
+    (A_MC, B_NC): "gemm_kernel<T, A_MC, B_NC>  (1x1 / linear wgrad)",
+    (A_MC, B_NC_IM2COL): "gemm_kernel<T, A_MC, B_NC_IM2COL>  (3x3 conv wgrad)",
+    (A_MC, B_KC): "gemm_kernel<T, A_MC, B_KC>",
+}
+
+
 def lib():
     return _lib.load()
 
@@ -112,6 +125,13 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
     d.ldr = int(ldr)
     d.out_mode = int(out_mode)
     d.col_stats = ptr(col_stats)
+    if PROF is not None and PROF["key"] == (a_layout, b_layout):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().crog_gemm(ctypes.byref(d), stream()), "crog_gemm")
+        e1.record()
+        PROF["records"].append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, batch)))
+        return
     check(lib().crog_gemm(ctypes.byref(d), stream()), "crog_gemm")
 
 

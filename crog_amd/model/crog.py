@@ -89,6 +89,7 @@ class CROG(nn.Module):
         self.compute_dtype = None
         self._store = None
         self._bns = None
+        self.explicit_grad_ready = True  # kernels write gradients in place and call RT.reducer.mark_ready themselves
 
     @staticmethod
     def _clip_arch(cfg):

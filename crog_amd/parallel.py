@@ -1,0 +1,171 @@
+"""Data parallelism for the HIP path: one process per MI355X, RCCL (torch.distributed backend "nccl") over xGMI.
+
+Re-expresses the reference's DistributedDataParallel + SyncBatchNorm (train_crog.py:113-114,154-156):
+  * gradients: the flat gradient buffer is cut into contiguous buckets in reverse parameter order (the order
+    in which backward finishes them); a bucket's all-reduce is issued asynchronously the moment its last
+    parameter gradient has been written, so communication overlaps the rest of backward.  Buckets are slices
+    of the flat buffer — no packing copies.  xGMI is point-to-point (7 links x ~153 GB/s per GPU), so buckets
+    are large (64 MiB default) to keep each collective bandwidth-bound rather than latency-bound.
+  * BatchNorm statistics: per-layer (sum, sum^2) / (sum g, sum g*xhat) pairs all-reduced on the compute stream
+    (crog_amd.functional.ConvBnAct), i.e. SyncBatchNorm semantics with equal per-rank batch sizes.
+  * the reference's find_unused_parameters round trip (only `logit_scale` is unused) is not needed: unused
+    parameters keep a zero gradient in the flat buffer and their bucket is flushed at the end of backward.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .runtime import ALIGN, RT
+
+
+class SyncBNComm:
+    def __init__(self, group=None):
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def convert_sync_batchnorm(model, process_group=None):
+    """nn.SyncBatchNorm.convert_sync_batchnorm equivalent: BatchNorm statistics of the HIP path become cross-replica."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        RT.comm = SyncBNComm(process_group)
+    return model
+
+
+class Reducer:
+    """Bucketed, overlapped mean all-reduce of a flat gradient buffer."""
+
+    def __init__(self, flat_grad: torch.Tensor, entries, group=None, bucket_cap_mb: float = 64.0):
+        """entries: iterable of (param, offset, numel) in registration order."""
+        self.G = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group)
+        cap = int(bucket_cap_mb * (1 << 20) / 4)
+        ents = sorted(((o, (n + ALIGN - 1) // ALIGN * ALIGN, p) for p, o, n in entries), key=lambda e: e[0])
+        self.buckets: List[dict] = []
+        cur = None
+        for o, n, p in reversed(ents):  # backward produces gradients from the end of the buffer
+            if cur is None or cur["numel"] + n > cap or o + n != cur["start"]:
+                cur = dict(start=o + n, end=o + n, numel=0, params=[], pending=0, work=None, launched=False)
+                self.buckets.append(cur)
+            cur["start"] = o
+            cur["numel"] += n
+            cur["params"].append(p)
+        self.bucket_of = {}
+        for i, b in enumerate(self.buckets):
+            for p in b["params"]:
+                self.bucket_of[id(p)] = i
+        self._armed = False
+        self._use_avg = dist.get_backend(group) == "nccl"
+        self.reset()
+
+    def reset(self):
+        for b in self.buckets:
+            b["pending"] = len(b["params"])
+            b["work"] = None
+            b["launched"] = False
+            b["seen"] = set()
+        self._armed = False
+        self._done = True
+
+    def _launch(self, b):
+        if b["launched"]:
+            return
+        b["launched"] = True
+        view = self.G[b["start"]:b["start"] + b["numel"]]
+        op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+        b["work"] = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+
+    def mark_ready(self, param):
+        i = self.bucket_of.get(id(param))
+        if i is None:
+            return
+        if not self._armed:
+            self._armed = True
+            self._done = False
+            torch.autograd.Variable._execution_engine.queue_callback(self.wait)
+        b = self.buckets[i]
+        if id(param) in b["seen"]:
+            return
+        b["seen"].add(id(param))
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def wait(self):
+        """Flush buckets holding unused parameters, wait for all collectives, finish the mean."""
+        if self._done:
+            return
+        for b in self.buckets:
+            self._launch(b)
+        for b in self.buckets:
+            b["work"].wait()
+            if not self._use_avg:
+                self.G[b["start"]:b["start"] + b["numel"]].div_(self.world)
+        self.reset()
+
+
+class DistributedDataParallel(torch.nn.Module):
+    """Drop-in for torch.nn.parallel.DistributedDataParallel(model.cuda(), device_ids=[gpu], find_unused_parameters=True)
+    as used at train_crog.py:154-156, for crog_amd models (or any module whose parameters live in a ParamStore)."""
+
+    def __init__(self, module, device_ids=None, find_unused_parameters=False, process_group=None, bucket_cap_mb: float = 64.0,
+                 broadcast_buffers: bool = True):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.bucket_cap_mb = bucket_cap_mb
+        self.reducer: Optional[Reducer] = None
+        self._hooks = []
+        if hasattr(module, "prepare"):
+            dev = torch.device("cuda", device_ids[0]) if device_ids else next(module.parameters()).device
+            module.prepare(dev)
+        self._sync_initial_state()
+
+    def _sync_initial_state(self):
+        """DDP broadcasts rank 0's parameters and buffers at construction."""
+        if dist.get_world_size(self.process_group) == 1:
+            return
+        store = getattr(self.module, "store", None)
+        if store is not None:
+            dist.broadcast(store.P, 0, group=self.process_group)
+        else:
+            for p in self.module.parameters():
+                dist.broadcast(p.data, 0, group=self.process_group)
+        for b in self.module.buffers():
+            dist.broadcast(b, 0, group=self.process_group)
+
+    def _ensure_reducer(self):
+        store = self.module.store
+        if self.reducer is None or self.reducer.G is not store.G:
+            self.reducer = Reducer(store.G, [(p, o, n) for _, p, o, n, _ in store.entries], self.process_group, self.bucket_cap_mb)
+            for h in self._hooks:
+                h.remove()
+            self._hooks = []
+            if not getattr(self.module, "explicit_grad_ready", False):
+                for _, p, _, _, _ in store.entries:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(lambda p_, r=self.reducer: r.mark_ready(p_)))
+
+    def forward(self, *args, **kwargs):
+        out_is_training = self.module.training and torch.is_grad_enabled()
+        if hasattr(self.module, "_ensure") and args:
+            self.module._ensure(args[0].device)
+        if out_is_training and dist.get_world_size(self.process_group) > 1:
+            self._ensure_reducer()
+            self.reducer.reset()
+            RT.reducer = self.reducer
+        else:
+            RT.reducer = None
+        return self.module(*args, **kwargs)
+
+    def state_dict(self, *a, **kw):
+        sd = self.module.state_dict(*a, **kw)
+        return type(sd)(("module." + k, v) for k, v in sd.items())
+
+    def load_state_dict(self, sd, strict=True):
+        return self.module.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}, strict)

@@ -76,8 +76,17 @@ def seeded_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Ten
     return (gain / math.sqrt(fan_in)) * torch.randn(shape, generator=g)
 
 
-def seeded_state(shapes: Dict[str, Iterable[int]], seed: int = 0) -> Dict[str, torch.Tensor]:
-    return {k: seeded_tensor(k, tuple(v), seed) for k, v in shapes.items()}
+def seeded_state(shapes: Dict[str, Iterable[int]], seed: int = 0, residual_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """`residual_gain` < 1 scales the last norm of every residual branch (bn3 of each Bottleneck), which is how
+    trained / zero-init-residual networks look (clip.py:402-408 zero-inits bn3).  With gain 1 the random R50 trunk
+    amplifies any perturbation ~5000x end to end (measured: fp32 rounding 1e-7 -> 5e-4 at the logits), which is fine
+    for fp32 parity but makes bf16-vs-fp32 comparisons meaningless; bf16 checks use a damped trunk."""
+    out = {k: seeded_tensor(k, tuple(v), seed) for k, v in shapes.items()}
+    if residual_gain != 1.0:
+        for k in out:
+            if k.endswith("bn3.weight") and ".layer" in k:
+                out[k] = out[k] * residual_gain
+    return out
 
 
 def synthetic_batch(B: int, size: int = 416, L: int = 20, vocab: int = 49408, seed: int = 1234, device="cpu"):

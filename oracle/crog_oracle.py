@@ -40,7 +40,8 @@ def batchnorm(P: State, pre: str, x: Tensor, training: bool) -> Tensor:
 def layernorm(P: State, pre: str, x: Tensor) -> Tensor:
     """clip.py:226-231 (fp32 LayerNorm) and nn.LayerNorm in layers.py; eps 1e-5."""
     w = P[pre + ".weight"]
-    return F.layer_norm(x.float(), (w.shape[0],), w, P[pre + ".bias"], LN_EPS)
+    xin = x if x.dtype == torch.float64 else x.float()  # float64 only in precision studies (scripts/debug_grads.py)
+    return F.layer_norm(xin, (w.shape[0],), w, P[pre + ".bias"], LN_EPS)
 
 
 def mha(q_in: Tensor, k_in: Tensor, v_in: Tensor, wq, wk, wv, bq, bk, bv, wo, bo, heads: int,
