@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(ROOT)
 CSRC = os.path.join(ROOT, "csrc")
 HEADER = os.path.join(REPO, "include", "crog_hip.h")
-LIB_PATH = os.path.join(ROOT, "libcrog_hip.so")
+LIB_PATH = os.environ.get("CROG_LIB") or os.path.join(ROOT, "libcrog_hip.so")
 BUILD_DIR = os.path.join(ROOT, "csrc", "build")
 SOURCES = ["api.hip", "gemm.hip", "norm.hip", "eltwise.hip", "head.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
@@ -120,6 +120,7 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    import torch  # noqa: F401  (torch's bundled HIP runtime must be the one already resident when the library is dlopened)
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

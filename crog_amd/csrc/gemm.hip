@@ -1,37 +1,42 @@
 // MFMA GEMM / implicit-GEMM conv family for gfx950 (see include/crog_hip.h, crog_gemm).
 //
-// One 256-thread workgroup (4 waves, 2x2) computes a 128x128 tile of C; each wave owns a
-// 64x64 sub-tile as 2x2 MFMA 32x32 accumulators (64 fp32 registers).  Operands are staged
-// global -> registers -> LDS with a two-deep LDS ring (loads for k-tile t+1 are issued before
+// A workgroup of WVM x WVN waves computes a (32*WM*WVM) x (32*WN*WVN) tile of C; each wave owns WM x WN MFMA
+// 32x32 accumulators.  Three tile shapes are instantiated and chosen per problem on the host:
+//     BIG   256x128, 4 waves (2x2), 128 acc regs/lane  — large convolutions: 85 FLOP per byte staged into the CU
+//     MID   128x128, 4 waves (2x2)                      — default
+//     SMALL  64x64,  4 waves (2x2)                      — latency-bound small GEMMs (text transformer, attention)
+// Operands are staged global -> registers -> LDS with a two-deep LDS ring (loads for k-tile t+1 are issued before
 // the MFMAs of tile t and written to LDS after them), one barrier per k-tile.
 //
 //   bf16: v_mfma_f32_32x32x16_bf16, BK = 32        f32: v_mfma_f32_32x32x2_f32 (exact f32), BK = 16
 //
 // Operand layouts (crog_a_layout / crog_b_layout):
-//   K-contiguous operands land in LDS as [128][BK+pad] and fragments are single ds_read_b128.
+//   K-contiguous operands land in LDS as [rows][BK+pad] and fragments are single ds_read_b128.
 //   Transposed operands (reduction index is the slow memory index: dgrad weights, wgrad, P.V)
-//   are copied row-major into LDS as [BK][128+pad] with full 16-byte coalesced loads and are
+//   are copied row-major into LDS as [BK][cols+pad] with full 16-byte coalesced loads and are
 //   transposed on the READ side: ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32.
 #include "common.h"
 #include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-constexpr int OP_BYTES = 10240;  // LDS bytes per operand per ring slot
-constexpr int NTHREADS = 256;
-
 template <typename T> struct TileCfg;
 template <> struct TileCfg<bf16> {
   static constexpr int VEC = 8, BK = 32;
-  static constexpr int KC_ROW = 40;   // elements; 80-byte rows  -> conflict-free ds_read_b128
-  static constexpr int TR_ROW = 160;  // elements; 320-byte rows -> conflict-free ds_read_b64_tr_b16
+  static constexpr int KC_ROW = 40;   // elements; 80-byte rows -> conflict-free ds_read_b128
+  static constexpr int TR_PAD = 32;   // elements; row bytes = 2*cols + 64 -> (bytes/4) % 64 == 16: conflict-free ds_read_b64_tr_b16
 };
 template <> struct TileCfg<float> {
   static constexpr int VEC = 4, BK = 16;
   static constexpr int KC_ROW = 20;   // 80-byte rows
-  static constexpr int TR_ROW = 132;  // 528-byte rows
+  static constexpr int TR_PAD = 4;
 };
+
+template <typename T, int ROWS> constexpr int op_bytes() {
+  constexpr int kc = ROWS * TileCfg<T>::KC_ROW * (int)sizeof(T);
+  constexpr int tr = TileCfg<T>::BK * (ROWS + TileCfg<T>::TR_PAD) * (int)sizeof(T);
+  return (kc > tr ? kc : tr + 15) / 16 * 16;
+}
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16> { bf16x8 v; };
@@ -62,10 +67,9 @@ __device__ inline Frag<float> frag_kc(const float* tile, int row, int ks, int h)
   f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
   return f;
 }
-// Row-major-copy LDS tile [BK][TR_ROW]; wave's 32 columns start at `cbase`.
-template <bool HWTR>
+// Row-major-copy LDS tile [BK][ROW]; wave's 32 columns start at `cbase`.
+template <bool HWTR, int ROW>
 __device__ inline Frag<bf16> frag_tr(const bf16* tile, int cbase, int ks, int lane) {
-  constexpr int ROW = TileCfg<bf16>::TR_ROW;
   const int h = lane >> 5;
   Frag<bf16> f;
   if constexpr (HWTR) {
@@ -85,9 +89,8 @@ __device__ inline Frag<bf16> frag_tr(const bf16* tile, int cbase, int ks, int la
   }
   return f;
 }
-template <bool HWTR>
+template <bool HWTR, int ROW>
 __device__ inline Frag<float> frag_tr(const float* tile, int cbase, int ks, int lane) {
-  constexpr int ROW = TileCfg<float>::TR_ROW;
   const int h = lane >> 5, col = cbase + (lane & 31);
   Frag<float> f;
 #pragma unroll
@@ -97,26 +100,28 @@ __device__ inline Frag<float> frag_tr(const float* tile, int cbase, int ks, int 
 
 struct ConvGeom { int H, W, C; };
 
-// ---- K-contiguous loader: 128 rows x BK, thread -> rows {tid/4, tid/4+64}, 16-byte chunk tid%4 ----
-template <typename T, bool IM2COL>
+// ---- K-contiguous loader: ROWS rows x BK, 4 16-byte chunks per row, thread -> rows {tid/4 + i*NT/4} ----
+template <typename T, bool IM2COL, int ROWS, int NT>
 struct KcLoader {
   static constexpr int VEC = TileCfg<T>::VEC, BK = TileCfg<T>::BK, ROW = TileCfg<T>::KC_ROW;
+  static constexpr int NV = ROWS * 4 / NT;
+  static_assert(NV >= 1 && ROWS * 4 % NT == 0, "tile/threads mismatch");
   const T* base;
   int64_t ld;
   int K;
-  int kv;            // element offset of this thread's chunk inside the k-tile
-  int lrow[2];       // tile-local rows
-  long grow[2];      // global row (pixel) index, -1 when out of range
-  int py[2], px[2];  // im2col: pixel coordinates
+  int kv;             // element offset of this thread's chunk inside the k-tile
+  int lrow[NV];       // tile-local rows
+  long grow[NV];      // global row (pixel) index, -1 when out of range
+  int py[NV], px[NV]; // im2col: pixel coordinates
   ConvGeom g;
-  Vec16<T> reg[2];
+  Vec16<T> reg[NV];
 
   __device__ void init(const T* b, int64_t ld_, int rows_total, int K_, int row0, ConvGeom g_, int tid) {
     base = b; ld = ld_; K = K_; g = g_;
     kv = (tid & 3) * VEC;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      lrow[i] = (tid >> 2) + i * 64;
+    for (int i = 0; i < NV; i++) {
+      lrow[i] = (tid >> 2) + i * (NT / 4);
       long m = (long)row0 + lrow[i];
       grow[i] = (m < rows_total) ? m : -1;
       if constexpr (IM2COL) {
@@ -133,14 +138,14 @@ struct KcLoader {
       const int c = k - tap * g.C;
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
+      for (int i = 0; i < NV; i++) {
         const int sy = py[i] + dy, sx = px[i] + dx;
         const bool ok = grow[i] >= 0 && k < K && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
         reg[i] = ok ? ldg16(base + (grow[i] + dy * g.W + dx) * ld + c) : zero16<T>();
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
+      for (int i = 0; i < NV; i++) {
         const bool ok = grow[i] >= 0 && k < K;
         if (ok && k + VEC > K) {  // ragged K tail (K % VEC != 0): element-wise, zero filled
           reg[i] = zero16<T>();
@@ -156,19 +161,21 @@ struct KcLoader {
   }
   __device__ void store(T* tile) const {
 #pragma unroll
-    for (int i = 0; i < 2; i++) stg16(tile + lrow[i] * ROW + kv, reg[i]);
+    for (int i = 0; i < NV; i++) stg16(tile + lrow[i] * ROW + kv, reg[i]);
   }
 };
 
-// ---- transposed-operand loader: row-major copy of [BK] reduction rows x 128 columns ------------
+// ---- transposed-operand loader: row-major copy of [BK] reduction rows x COLS columns --------------
 // MODE 0: dense  mem[k][col]            (row stride ld)
 // MODE 1: conv3x3 dgrad weights: k = tap'*C + co -> W[co][8-tap'][col]   (row stride ld)
 // MODE 2: wgrad im2col: k = pixel, col = tap*C + c -> X[pixel shifted by tap][c] (row stride ld)
-template <typename T, int MODE>
+template <typename T, int MODE, int COLS, int NT>
 struct TrLoader {
-  static constexpr int VEC = TileCfg<T>::VEC, BK = TileCfg<T>::BK, ROW = TileCfg<T>::TR_ROW;
-  static constexpr int CPR = 128 / VEC;        // chunks per row
-  static constexpr int RSTEP = NTHREADS / CPR;  // row step between the thread's two chunks
+  static constexpr int VEC = TileCfg<T>::VEC, BK = TileCfg<T>::BK, ROW = COLS + TileCfg<T>::TR_PAD;
+  static constexpr int CPR = COLS / VEC;   // chunks per row
+  static constexpr int RSTEP = NT / CPR;   // row step between the thread's chunks
+  static constexpr int NV = BK / RSTEP;
+  static_assert(NV >= 1 && NT % CPR == 0 && BK % RSTEP == 0, "tile/threads mismatch");
   const T* base;
   int64_t ld;
   int K, ncols;  // reduction length, number of valid columns
@@ -176,7 +183,7 @@ struct TrLoader {
   int lcol, lrow0;
   ConvGeom g;
   int tdy, tdx, tc;  // MODE 2: tap offset and channel of this thread's chunk
-  Vec16<T> reg[2];
+  Vec16<T> reg[NV];
 
   __device__ void init(const T* b, int64_t ld_, int ncols_, int K_, int col0, ConvGeom g_, int tid) {
     base = b; ld = ld_; K = K_; ncols = ncols_; g = g_;
@@ -200,7 +207,7 @@ struct TrLoader {
   }
   __device__ void load(int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NV; i++) {
       const long k = (long)k0 + lrow0 + i * RSTEP;
       if (k >= K || col >= ncols) { reg[i] = zero16<T>(); continue; }
       if constexpr (MODE == 0) {
@@ -219,19 +226,19 @@ struct TrLoader {
   }
   __device__ void store(T* tile) const {
 #pragma unroll
-    for (int i = 0; i < 2; i++) stg16(tile + (lrow0 + i * RSTEP) * ROW + lcol, reg[i]);
+    for (int i = 0; i < NV; i++) stg16(tile + (lrow0 + i * RSTEP) * ROW + lcol, reg[i]);
   }
 };
 
-template <typename T, int AL> struct ALoaderSel;
-template <typename T> struct ALoaderSel<T, CROG_A_KC> { using type = KcLoader<T, false>; static constexpr bool TR = false; };
-template <typename T> struct ALoaderSel<T, CROG_A_IM2COL> { using type = KcLoader<T, true>; static constexpr bool TR = false; };
-template <typename T> struct ALoaderSel<T, CROG_A_MC> { using type = TrLoader<T, 0>; static constexpr bool TR = true; };
-template <typename T, int BL> struct BLoaderSel;
-template <typename T> struct BLoaderSel<T, CROG_B_KC> { using type = KcLoader<T, false>; static constexpr bool TR = false; };
-template <typename T> struct BLoaderSel<T, CROG_B_NC> { using type = TrLoader<T, 0>; static constexpr bool TR = true; };
-template <typename T> struct BLoaderSel<T, CROG_B_NC_DGRAD> { using type = TrLoader<T, 1>; static constexpr bool TR = true; };
-template <typename T> struct BLoaderSel<T, CROG_B_NC_IM2COL> { using type = TrLoader<T, 2>; static constexpr bool TR = true; };
+template <typename T, int AL, int ROWS, int NT> struct ALoaderSel;
+template <typename T, int R, int NT> struct ALoaderSel<T, CROG_A_KC, R, NT> { using type = KcLoader<T, false, R, NT>; static constexpr bool TR = false; };
+template <typename T, int R, int NT> struct ALoaderSel<T, CROG_A_IM2COL, R, NT> { using type = KcLoader<T, true, R, NT>; static constexpr bool TR = false; };
+template <typename T, int R, int NT> struct ALoaderSel<T, CROG_A_MC, R, NT> { using type = TrLoader<T, 0, R, NT>; static constexpr bool TR = true; };
+template <typename T, int BL, int ROWS, int NT> struct BLoaderSel;
+template <typename T, int R, int NT> struct BLoaderSel<T, CROG_B_KC, R, NT> { using type = KcLoader<T, false, R, NT>; static constexpr bool TR = false; };
+template <typename T, int R, int NT> struct BLoaderSel<T, CROG_B_NC, R, NT> { using type = TrLoader<T, 0, R, NT>; static constexpr bool TR = true; };
+template <typename T, int R, int NT> struct BLoaderSel<T, CROG_B_NC_DGRAD, R, NT> { using type = TrLoader<T, 1, R, NT>; static constexpr bool TR = true; };
+template <typename T, int R, int NT> struct BLoaderSel<T, CROG_B_NC_IM2COL, R, NT> { using type = TrLoader<T, 2, R, NT>; static constexpr bool TR = true; };
 
 __device__ inline float apply_act(float v, int act) {
   if (act == CROG_ACT_RELU) return fmaxf(v, 0.f);
@@ -239,18 +246,167 @@ __device__ inline float apply_act(float v, int act) {
   return v;
 }
 
-template <typename T, int AL, int BL, bool HWTR>
-__global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const crog_gemm_desc p) {
-  using Cfg = TileCfg<T>;
-  constexpr int BK = Cfg::BK;
-  using ALd = typename ALoaderSel<T, AL>::type;
-  using BLd = typename BLoaderSel<T, BL>::type;
-  constexpr bool ATR = ALoaderSel<T, AL>::TR, BTR = BLoaderSel<T, BL>::TR;
+template <int WM_, int WN_, int WVM_, int WVN_>
+struct Shape {
+  static constexpr int WM = WM_, WN = WN_, WVM = WVM_, WVN = WVN_;
+  static constexpr int NT = 64 * WVM * WVN, BM = 32 * WM * WVM, BN = 32 * WN * WVN;
+};
+using ShapeBig = Shape<4, 2, 2, 2>;    // 256 x 128, 256 threads, 128 accumulator registers per lane
+using ShapeMid = Shape<2, 2, 2, 2>;    // 128 x 128, 256 threads
+using ShapeSmall = Shape<1, 1, 2, 2>;  //  64 x  64, 256 threads
 
-  __shared__ __attribute__((aligned(16))) char smem[4 * OP_BYTES];
+template <typename T, typename S> constexpr int lds_bytes() {
+  constexpr int ring = 2 * (op_bytes<T, S::BM>() + op_bytes<T, S::BN>());
+  constexpr int stage = (S::NT / 64) * 32 * (32 * S::WN + 8) * 2;           // bf16 epilogue staging, wave-private
+  constexpr int red = S::WVM * S::BN * 2 * 4;                              // column-statistics exchange
+  constexpr int m1 = ring > stage ? ring : stage;
+  return m1 > red ? m1 : red;
+}
+
+// ------------------------------------------ epilogue ------------------------------------------
+// Shared by the register-staged and the LDS-DMA kernels.  `smem` may be reused: the caller has passed its last barrier.
+template <typename T, typename S>
+__device__ inline void gemm_epilogue(f32x16 (&acc)[S::WM][S::WN], const crog_gemm_desc& p, char* smem, int m0, int n0, int zs, int64_t coff) {
+  constexpr int NT = S::NT, BM = S::BM, BN = S::BN, WM = S::WM, WN = S::WN, WVN = S::WVN, WVM = S::WVM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WVN, wc = wave % WVN;
+  const int r = lane & 31, h = lane >> 5;
+  const float alpha = p.alpha;
+  const float* bias = (zs == 0) ? p.bias : nullptr;
+  float bcol[WN];
+  int ncol[WN];
+#pragma unroll
+  for (int j = 0; j < WN; j++) {
+    ncol[j] = n0 + (wc * WN + j) * 32 + r;
+    bcol[j] = (bias && ncol[j] < p.N) ? bias[ncol[j]] : 0.f;
+  }
+  float s1[WN], s2[WN];
+#pragma unroll
+  for (int j = 0; j < WN; j++) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < WM; i++)
+#pragma unroll
+    for (int j = 0; j < WN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        float v = alpha * acc[i][j][e] + bcol[j];
+        if (p.col_stats) {
+          const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (m < p.M) { s1[j] += v; s2[j] += v * v; }
+        }
+        acc[i][j][e] = apply_act(v, p.act);
+      }
+
+  if (p.col_stats) {  // block-uniform branch; slab rows are 128 matrix rows each
+    constexpr int RG = 32 * WM;          // rows per wave-row
+    constexpr int GPS = 128 / RG;        // wave-rows per slab row (MID: 2, BIG: 1)
+    static_assert(RG <= 128 && 128 % RG == 0 && BM % 128 == 0 || BM < 128, "stats slab granularity");
+    float* red = reinterpret_cast<float*>(smem);  // [WVM][BN][2]; the k-loop's last barrier has passed
+#pragma unroll
+    for (int j = 0; j < WN; j++) {
+      s1[j] += __shfl_xor(s1[j], 32, 64);
+      s2[j] += __shfl_xor(s2[j], 32, 64);
+      if (h == 0) {
+        const int c = (wc * WN + j) * 32 + r;
+        red[(wr * BN + c) * 2 + 0] = s1[j];
+        red[(wr * BN + c) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    constexpr int SLABS = (BM >= 128) ? BM / 128 : 1;
+    for (int idx = tid; idx < SLABS * BN; idx += NT) {
+      const int sl = idx / BN, c = idx % BN;
+      if (n0 + c < p.N && m0 + sl * 128 < p.M) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int q = 0; q < GPS; q++) {
+          a += red[((sl * GPS + q) * BN + c) * 2];
+          b += red[((sl * GPS + q) * BN + c) * 2 + 1];
+        }
+        float* dst = p.col_stats + ((int64_t)(m0 / 128 + sl) * p.N + n0 + c) * 2;
+        dst[0] = a;
+        dst[1] = b;
+      }
+    }
+    __syncthreads();
+  }
+
+  const T* R = reinterpret_cast<const T*>(p.R);
+  if (p.out_mode != CROG_OUT_T || sizeof(T) == 4) {
+    // direct stores from the accumulator layout: a register covers 2 rows x 32 consecutive columns
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+      for (int j = 0; j < WN; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int n = ncol[j];
+          if (m < p.M && n < p.N) {
+            float v = acc[i][j][e];
+            if (R) v += Elem<T>::to_f(R[(int64_t)m * p.ldr + n]);
+            const int64_t o = coff + (int64_t)m * p.ldc + n;
+            if (p.out_mode == CROG_OUT_F32_ATOMIC) atomicAdd(reinterpret_cast<float*>(p.C) + o, v);
+            else if (p.out_mode == CROG_OUT_F32) reinterpret_cast<float*>(p.C)[o] = v;
+            else reinterpret_cast<T*>(p.C)[o] = Elem<T>::from_f(v);
+          }
+        }
+  } else {
+    // 2-byte output: each wave stages 32 x (32*WN) of its tile in a private LDS region, then adds the residual
+    // and stores 16 bytes per lane (full 64/128-byte row segments)
+    if constexpr (sizeof(T) == 2) {
+      constexpr int CW = 32 * WN, CROW = CW + 8, VPR = CW / 8, RPP = 64 / VPR;  // vectors per row, rows per pass
+      T* Cs = reinterpret_cast<T*>(smem) + wave * 32 * CROW;
+      T* C = reinterpret_cast<T*>(p.C) + coff;
+#pragma unroll
+      for (int i = 0; i < WM; i++) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+          for (int e = 0; e < 16; e++) Cs[((e & 3) + 8 * (e >> 2) + 4 * h) * CROW + j * 32 + r] = (T)acc[i][j][e];
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ps++) {
+          const int lr = ps * RPP + lane / VPR, cv = (lane % VPR) * 8;
+          const int m = m0 + (wr * WM + i) * 32 + lr, n = n0 + wc * CW + cv;
+          if (m < p.M && n < p.N) {
+            Vec16<T> o = *reinterpret_cast<const Vec16<T>*>(Cs + lr * CROW + cv);
+            if (n + 8 <= p.N) {
+              if (R) {
+                Vec16<T> rv = ldg16(R + (int64_t)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; e++) o.v[e] = (T)((float)o.v[e] + (float)rv.v[e]);
+              }
+              stg16(C + (int64_t)m * p.ldc + n, o);
+            } else {
+              for (int e = 0; e < 8 && n + e < p.N; e++) {
+                float f = (float)o.v[e];
+                if (R) f += (float)R[(int64_t)m * p.ldr + n + e];
+                C[(int64_t)m * p.ldc + n + e] = (T)f;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int AL, int BL, bool HWTR, typename S>
+__global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))) gemm_kernel(const crog_gemm_desc p) {
+  using Cfg = TileCfg<T>;
+  constexpr int BK = Cfg::BK, NT = S::NT, BM = S::BM, BN = S::BN, WM = S::WM, WN = S::WN, WVN = S::WVN, WVM = S::WVM;
+  using ALd = typename ALoaderSel<T, AL, BM, NT>::type;
+  using BLd = typename BLoaderSel<T, BL, BN, NT>::type;
+  constexpr bool ATR = ALoaderSel<T, AL, BM, NT>::TR, BTR = BLoaderSel<T, BL, BN, NT>::TR;
+  constexpr int OPA = op_bytes<T, BM>(), OPB = op_bytes<T, BN>();
+  constexpr int AROW = BM + Cfg::TR_PAD, BROW = BN + Cfg::TR_PAD;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WVN, wc = wave % WVN;
   const int r = lane & 31, h = lane >> 5;
 
   // XCD-aware tile order: blocks that share an XCD (id % 8) get a contiguous run of tiles.
@@ -283,6 +439,298 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const crog_gemm_desc 
   la.init(A, p.lda, p.M, p.K, m0, g, tid);
   lb.init(B, p.ldb, p.N, p.K, n0, g, tid);
 
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; i++)
+#pragma unroll
+    for (int j = 0; j < WN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  // Reduction order.  For the 3x3 forward / data-gradient kernels the k-tiles are visited channel-chunk-major, tap-minor
+  // (the 9 taps of one 32-channel chunk back to back): the 9 shifted reads of the same pixels then hit L1/L2 instead of
+  // being 9 separate sweeps of the map 16 k-tiles apart.  A and B use the same memory offset, so the sum is unchanged.
+  auto kmem = [&](int kt) -> int {
+    if constexpr (AL == CROG_A_IM2COL) return (kt % 9) * p.convC + (kt / 9) * BK;
+    else return kt * BK;
+  };
+  // LDS ring: A slots at [0, 2*OPA), B slots at [2*OPA, 2*OPA + 2*OPB)
+  la.load(kmem(kt0));
+  lb.load(kmem(kt0));
+  la.store(reinterpret_cast<T*>(smem));
+  lb.store(reinterpret_cast<T*>(smem + 2 * OPA));
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; kt++) {
+    const bool more = kt + 1 < kt1;
+    if (more) {
+      const int kn = kmem(kt + 1);
+      la.load(kn);
+      lb.load(kn);
+    }
+    const T* at = reinterpret_cast<const T*>(smem + cur * OPA);
+    const T* bt = reinterpret_cast<const T*>(smem + 2 * OPA + cur * OPB);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ks++) {
+      Frag<T> fa[WM], fb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; i++) {
+        if constexpr (ATR) fa[i] = frag_tr<HWTR, AROW>(at, (wr * WM + i) * 32, ks, lane);
+        else fa[i] = frag_kc(at, (wr * WM + i) * 32 + r, ks, h);
+      }
+#pragma unroll
+      for (int j = 0; j < WN; j++) {
+        if constexpr (BTR) fb[j] = frag_tr<HWTR, BROW>(bt, (wc * WN + j) * 32, ks, lane);
+        else fb[j] = frag_kc(bt, (wc * WN + j) * 32 + r, ks, h);
+      }
+#pragma unroll
+      for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++) mma16(fa[i], fb[j], acc[i][j]);
+    }
+    if (more) {
+      la.store(reinterpret_cast<T*>(smem + (cur ^ 1) * OPA));
+      lb.store(reinterpret_cast<T*>(smem + 2 * OPA + (cur ^ 1) * OPB));
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  gemm_epilogue<T, S>(acc, p, smem, m0, n0, zs, coff);
+}
+
+
+// =================================================================================================
+// LDS-DMA variant of the 128x128 tile (all operand layouts).
+// Tiles go global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR staging, no ds_write), three LDS stages,
+// two k-tiles always in flight behind a counted vmcnt, one raw s_barrier per k-tile.  The LDS image of a tile is
+// exactly what the DMA writes (wave-uniform base + lane*16, 1 KiB per wave-instruction), so bank conflicts are
+// avoided by XOR-swizzling the 16-byte chunk index on the SOURCE address and again on the fragment read:
+//   K-contiguous tile  [128 rows][64 B]:   chunk ^= (row >> 2) & 3            -> ds_read_b128 conflict-free
+//   transposed tile    [BK rows][128 cols]: chunk ^= ((row&3)<<2)|((row>>2)&3) (bf16) -> ds_read_b64_tr_b16 conflict-free
+// Out-of-range rows/columns, conv padding and ragged K are an out-of-bounds buffer offset: the hardware writes zeros.
+// =================================================================================================
+constexpr unsigned DMA_OOB = 0x80000000u;
+constexpr int DMA_TILE_B = 128 * 64, DMA_STAGE_B = 2 * DMA_TILE_B, DMA_NSTAGE = 3;
+
+// K-contiguous operand (MODE 0 dense rows, MODE 1 im2col patches of an NHWC map)
+template <typename T, int MODE>
+struct DmaKc {
+  static constexpr int VEC = TileCfg<T>::VEC, BK = TileCfg<T>::BK;
+  static constexpr bool TR = false;
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned base[2];   // byte offset of (row, swizzled chunk) at k = 0; DMA_OOB when the row is out of range
+  unsigned cb[2];     // byte position of the lane's logical chunk inside the k-tile
+  int py[2], px[2];
+  int ldb_;           // row stride in bytes
+  unsigned kbytes;
+
+  __device__ void init(const T* ptr, int64_t ld, int rows_total, int K, int row0, int wave, int lane, const ConvGeom& g) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr), 0, 0x7fffffff, 0x00020000);
+    ldb_ = (int)(ld * sizeof(T));
+    kbytes = (unsigned)(K * sizeof(T));
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int row = (wave * 2 + i) * 16 + (lane >> 2);
+      cb[i] = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
+      const long m = (long)row0 + row;
+      base[i] = (m < rows_total) ? (unsigned)(m * ld * sizeof(T)) + cb[i] : DMA_OOB;
+      if constexpr (MODE == 1) {
+        const long rem = m % ((long)g.H * g.W);
+        py[i] = (int)(rem / g.W);
+        px[i] = (int)(rem % g.W);
+      }
+    }
+  }
+  // kt: k-tile index; kmem: element offset of the k-tile inside the reduction (see kmem in the kernels)
+  __device__ unsigned off(int i, int kt, int kmem, const ConvGeom& g) const {
+    if constexpr (MODE == 1) {
+      const int tap = kt % 9, chunk = kt / 9;
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const int sy = py[i] + dy, sx = px[i] + dx;
+      const bool ok = base[i] != DMA_OOB && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
+      return ok ? base[i] + (unsigned)((dy * g.W + dx) * ldb_) + (unsigned)(chunk * BK * sizeof(T)) : DMA_OOB;  // wrap-around = negative shift
+    } else {
+      const unsigned kb = (unsigned)(kmem * sizeof(T));
+      return (base[i] != DMA_OOB && kb + cb[i] < kbytes) ? base[i] + kb : DMA_OOB;
+    }
+  }
+  __device__ static Frag<T> frag(const char* tile, int rbase, int ks, int lane);
+};
+template <> __device__ inline Frag<bf16> DmaKc<bf16, 0>::frag(const char* tile, int rbase, int ks, int lane) {
+  const int row = rbase + (lane & 31), c = (ks * 2 + (lane >> 5)) ^ ((row >> 2) & 3);
+  Frag<bf16> f;
+  f.v = *reinterpret_cast<const bf16x8*>(tile + row * 64 + c * 16);
+  return f;
+}
+template <> __device__ inline Frag<bf16> DmaKc<bf16, 1>::frag(const char* tile, int rbase, int ks, int lane) {
+  return DmaKc<bf16, 0>::frag(tile, rbase, ks, lane);
+}
+template <> __device__ inline Frag<float> DmaKc<float, 0>::frag(const char* tile, int rbase, int ks, int lane) {
+  const int row = rbase + (lane & 31), h = lane >> 5, sw = (row >> 2) & 3;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(tile + row * 64 + ((2 * h) ^ sw) * 16);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(tile + row * 64 + ((2 * h + 1) ^ sw) * 16);
+  Frag<float> f;
+  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+  return f;
+}
+template <> __device__ inline Frag<float> DmaKc<float, 1>::frag(const char* tile, int rbase, int ks, int lane) {
+  return DmaKc<float, 0>::frag(tile, rbase, ks, lane);
+}
+
+// Transposed operand: the tile is [BK reduction rows][128 columns] of memory (MODE as TrLoader: 0 dense, 1 dgrad weights, 2 wgrad im2col)
+template <typename T, int MODE>
+struct DmaTr {
+  static constexpr int VEC = TileCfg<T>::VEC, BK = TileCfg<T>::BK;
+  static constexpr bool TR = true;
+  static constexpr int CPR = 128 / VEC;          // chunks per tile row: 16 (bf16) / 32 (f32)
+  static constexpr int RPI = 64 / CPR;           // tile rows per wave-instruction: 4 / 2
+  static constexpr int ROWB = 128 * (int)sizeof(T);
+  __amdgpu_buffer_rsrc_t rsrc;
+  int rowin[2];       // reduction row of this lane inside the k-tile
+  unsigned colb[2];   // byte offset of the lane's logical column chunk (DMA_OOB when the columns are out of range)
+  int tdy[2], tdx[2]; // MODE 2
+  int ldb_, K;
+
+  __device__ static int swz(int row) { return sizeof(T) == 2 ? (((row & 3) << 2) | ((row >> 2) & 3)) : 0; }
+
+  __device__ void init(const T* ptr, int64_t ld, int ncols, int K_, int col0, int wave, int lane, const ConvGeom& g) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr), 0, 0x7fffffff, 0x00020000);
+    ldb_ = (int)(ld * sizeof(T));
+    K = K_;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int row = (wave * 2 + i) * RPI + lane / CPR;
+      const int c = (lane % CPR) ^ swz(row);
+      rowin[i] = row;
+      const int col = col0 + c * VEC;
+      if (col >= ncols) { colb[i] = DMA_OOB; tdy[i] = tdx[i] = 0; continue; }
+      if constexpr (MODE == 2) {
+        const int tap = col / g.C;
+        colb[i] = (unsigned)((col - tap * g.C) * sizeof(T));
+        tdy[i] = tap / 3 - 1;
+        tdx[i] = tap % 3 - 1;
+      } else {
+        colb[i] = (unsigned)(col * sizeof(T));
+      }
+    }
+  }
+  __device__ unsigned off(int i, int kt, int kmem, const ConvGeom& g) const {
+    const int k = kmem + rowin[i];
+    if (colb[i] == DMA_OOB || k >= K) return DMA_OOB;
+    if constexpr (MODE == 0) {
+      return (unsigned)k * (unsigned)ldb_ + colb[i];
+    } else if constexpr (MODE == 1) {
+      const int tap = k / g.C, co = k - tap * g.C;
+      return (unsigned)(co * 9 + (8 - tap)) * (unsigned)ldb_ + colb[i];
+    } else {
+      const int x = k % g.W, y = (k / g.W) % g.H;
+      const int sy = y + tdy[i], sx = x + tdx[i];
+      if (sy < 0 || sy >= g.H || sx < 0 || sx >= g.W) return DMA_OOB;
+      return (unsigned)(k + tdy[i] * g.W + tdx[i]) * (unsigned)ldb_ + colb[i];
+    }
+  }
+  __device__ static Frag<T> frag(const char* tile, int cbase, int ks, int lane);
+};
+template <int MODE> struct DmaTrFrag {
+  __device__ static Frag<bf16> get(const char* tile, int cbase, int ks, int lane) {
+    // ds_read_b64_tr_b16 on the swizzled image: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3
+    const int h = lane >> 5, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int col = cbase + 16 * ((lane >> 4) & 1) + 4 * pp;
+    const int chunk = col >> 3, inb = (col & 7) * 2;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int r0 = ks * 16 + 8 * h + q, r1 = r0 + 4;
+    const int x0 = ((r0 & 3) << 2) | ((r0 >> 2) & 3), x1 = ((r1 & 3) << 2) | ((r1 >> 2) & 3);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * 256 + ((chunk ^ x0) << 4) + inb));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * 256 + ((chunk ^ x1) << 4) + inb));
+    Frag<bf16> f;
+    f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return f;
+  }
+  __device__ static Frag<float> getf(const char* tile, int cbase, int ks, int lane) {
+    const int h = lane >> 5, col = cbase + (lane & 31);
+    const float* t = reinterpret_cast<const float*>(tile);
+    Frag<float> f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) f.v[j] = t[(8 * h + j) * 128 + col];
+    return f;
+  }
+};
+template <> __device__ inline Frag<bf16> DmaTr<bf16, 0>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::get(t, c, ks, l); }
+template <> __device__ inline Frag<bf16> DmaTr<bf16, 1>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::get(t, c, ks, l); }
+template <> __device__ inline Frag<bf16> DmaTr<bf16, 2>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::get(t, c, ks, l); }
+template <> __device__ inline Frag<float> DmaTr<float, 0>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::getf(t, c, ks, l); }
+template <> __device__ inline Frag<float> DmaTr<float, 1>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::getf(t, c, ks, l); }
+template <> __device__ inline Frag<float> DmaTr<float, 2>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::getf(t, c, ks, l); }
+
+template <typename T, int AL> struct DmaASel;
+template <typename T> struct DmaASel<T, CROG_A_KC> { using type = DmaKc<T, 0>; };
+template <typename T> struct DmaASel<T, CROG_A_IM2COL> { using type = DmaKc<T, 1>; };
+template <typename T> struct DmaASel<T, CROG_A_MC> { using type = DmaTr<T, 0>; };
+template <typename T, int BL> struct DmaBSel;
+template <typename T> struct DmaBSel<T, CROG_B_KC> { using type = DmaKc<T, 0>; };
+template <typename T> struct DmaBSel<T, CROG_B_NC> { using type = DmaTr<T, 0>; };
+template <typename T> struct DmaBSel<T, CROG_B_NC_DGRAD> { using type = DmaTr<T, 1>; };
+template <typename T> struct DmaBSel<T, CROG_B_NC_IM2COL> { using type = DmaTr<T, 2>; };
+
+// Issue the LDS-DMA loads of one k-tile into ring stage `stage` (2 A + 2 B wave-instructions of 1 KiB per wave).
+// A plain __device__ function on purpose: a lambda here makes hipcc's HOST pass drop the kernel stub silently.
+template <typename OA, typename OB>
+__device__ inline void dma_issue(const OA& da, const OB& db, const ConvGeom& g, char* smem, int wave, int kt, int kmem, int stage) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  char* sa = smem + stage * DMA_STAGE_B + wave * 2 * 1024;
+  char* sb = sa + DMA_TILE_B;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const unsigned oa = da.off(i, kt, kmem, g), ob = db.off(i, kt, kmem, g);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(da.rsrc, (lds_void*)(sa + i * 1024), 16, oa, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(db.rsrc, (lds_void*)(sb + i * 1024), 16, ob, 0, 0, 0);
+  }
+}
+
+template <typename T, int AL, int BL>
+__global__ void __launch_bounds__(256, 3) gemm_dma_kernel(const crog_gemm_desc p) {
+  using S = ShapeMid;
+  using OA = typename DmaASel<T, AL>::type;
+  using OB = typename DmaBSel<T, BL>::type;
+  constexpr int BK = TileCfg<T>::BK, BM = S::BM, BN = S::BN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
+  const int nwg = tilesM * tilesN;
+  int id = blockIdx.x;
+  {
+    const int q = nwg >> 3, rr = nwg & 7, xcd = id & 7, loc = id >> 3;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  }
+  const int tm = id / tilesN, tn = id % tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int zb = z / p.splitk, zs = z % p.splitk;
+  const int zo = zb / p.batch_inner, zi = zb % p.batch_inner;
+  const T* A = reinterpret_cast<const T*>(p.A) + zo * p.sAo + zi * p.sAi;
+  const T* B = reinterpret_cast<const T*>(p.B) + zo * p.sBo + zi * p.sBi;
+  const int64_t coff = zo * p.sCo + zi * p.sCi;
+
+  const int ktiles = (p.K + BK - 1) / BK;
+  const int per = (ktiles + p.splitk - 1) / p.splitk;
+  const int kt0 = zs * per;
+  const int kt1 = min(kt0 + per, ktiles);
+  if (kt0 >= kt1) return;
+  const int nt = kt1 - kt0;
+
+  const ConvGeom g{p.convH, p.convW, p.convC};
+  OA da;
+  OB db;
+  da.init(A, p.lda, p.M, p.K, m0, wave, lane, g);
+  db.init(B, p.ldb, p.N, p.K, n0, wave, lane, g);
+
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -291,176 +739,129 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const crog_gemm_desc 
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  // LDS ring: A slots at [0, 2*OP_BYTES), B slots at [2*OP_BYTES, 4*OP_BYTES)
-  la.load(kt0 * BK);
-  lb.load(kt0 * BK);
-  la.store(reinterpret_cast<T*>(smem));
-  lb.store(reinterpret_cast<T*>(smem + 2 * OP_BYTES));
-  __syncthreads();
-
-  int cur = 0;
-  for (int kt = kt0; kt < kt1; kt++) {
-    const bool more = kt + 1 < kt1;
-    if (more) {
-      la.load((kt + 1) * BK);
-      lb.load((kt + 1) * BK);
-    }
-    const T* at = reinterpret_cast<const T*>(smem + cur * OP_BYTES);
-    const T* bt = reinterpret_cast<const T*>(smem + (2 + cur) * OP_BYTES);
+  // channel-chunk-major, tap-minor reduction order for the 3x3 forward / data-gradient forms (see gemm_kernel)
+#define CROG_KMEM(kt) ((AL == CROG_A_IM2COL) ? (((kt) % 9) * p.convC + ((kt) / 9) * BK) : (kt) * BK)
+  dma_issue(da, db, g, smem, wave, kt0, CROG_KMEM(kt0), 0);
+  if (nt > 1) dma_issue(da, db, g, smem, wave, kt0 + 1, CROG_KMEM(kt0 + 1), 1);
+  int stage = 0;
+  for (int t = 0; t < nt; t++) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) dma_issue(da, db, g, smem, wave, kt0 + t + 2, CROG_KMEM(kt0 + t + 2), stage >= 1 ? stage - 1 : 2);
+    const char* at = smem + stage * DMA_STAGE_B;
+    const char* bt = at + DMA_TILE_B;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
       Frag<T> fa[2], fb[2];
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        if constexpr (ATR) fa[i] = frag_tr<HWTR>(at, wr * 64 + i * 32, ks, lane);
-        else fa[i] = frag_kc(at, wr * 64 + i * 32 + r, ks, h);
-      }
+      for (int i = 0; i < 2; i++) fa[i] = OA::frag(at, wr * 64 + i * 32, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        if constexpr (BTR) fb[j] = frag_tr<HWTR>(bt, wc * 64 + j * 32, ks, lane);
-        else fb[j] = frag_kc(bt, wc * 64 + j * 32 + r, ks, h);
-      }
+      for (int j = 0; j < 2; j++) fb[j] = OB::frag(bt, wc * 64 + j * 32, ks, lane);
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) mma16(fa[i], fb[j], acc[i][j]);
     }
-    if (more) {
-      la.store(reinterpret_cast<T*>(smem + (cur ^ 1) * OP_BYTES));
-      lb.store(reinterpret_cast<T*>(smem + (2 + (cur ^ 1)) * OP_BYTES));
-    }
-    __syncthreads();
-    cur ^= 1;
+    stage = stage == 2 ? 0 : stage + 1;
   }
-
-  // ------------------------------------------ epilogue ------------------------------------------
-  const float alpha = p.alpha;
-  const float* bias = (zs == 0) ? p.bias : nullptr;
-  float bcol[2];
-  int ncol[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    ncol[j] = n0 + wc * 64 + j * 32 + r;
-    bcol[j] = (bias && ncol[j] < p.N) ? bias[ncol[j]] : 0.f;
-  }
-  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) {
-        float v = alpha * acc[i][j][e] + bcol[j];
-        if (p.col_stats) {
-          const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (m < p.M) { s1[j] += v; s2[j] += v * v; }
-        }
-        acc[i][j][e] = apply_act(v, p.act);
-      }
-
-  if (p.col_stats) {  // block-uniform branch
-    float* red = reinterpret_cast<float*>(smem);  // [2 wr][128][2]; the k-loop's last barrier has passed
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      s1[j] += __shfl_xor(s1[j], 32, 64);
-      s2[j] += __shfl_xor(s2[j], 32, 64);
-      if (h == 0) {
-        const int c = wc * 64 + j * 32 + r;
-        red[(wr * 128 + c) * 2 + 0] = s1[j];
-        red[(wr * 128 + c) * 2 + 1] = s2[j];
-      }
-    }
-    __syncthreads();
-    if (tid < 128 && n0 + tid < p.N) {
-      float* dst = p.col_stats + ((int64_t)tm * p.N + n0 + tid) * 2;
-      dst[0] = red[tid * 2] + red[(128 + tid) * 2];
-      dst[1] = red[tid * 2 + 1] + red[(128 + tid) * 2 + 1];
-    }
-    __syncthreads();
-  }
-
-  const T* R = reinterpret_cast<const T*>(p.R);
-  if (p.out_mode != CROG_OUT_T || sizeof(T) == 4) {
-    // direct stores from the accumulator layout: a register covers 2 rows x 32 consecutive columns
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const int n = ncol[j];
-          if (m < p.M && n < p.N) {
-            float v = acc[i][j][e];
-            if (R) v += Elem<T>::to_f(R[(int64_t)m * p.ldr + n]);
-            const int64_t o = coff + (int64_t)m * p.ldc + n;
-            if (p.out_mode == CROG_OUT_F32_ATOMIC) atomicAdd(reinterpret_cast<float*>(p.C) + o, v);
-            else if (p.out_mode == CROG_OUT_F32) reinterpret_cast<float*>(p.C)[o] = v;
-            else reinterpret_cast<T*>(p.C)[o] = Elem<T>::from_f(v);
-          }
-        }
-  } else {
-    // 2-byte output: stage the tile in LDS, then residual-add and store 16 bytes per lane
-    if constexpr (sizeof(T) == 2) {
-      constexpr int CROW = 136;
-      T* Cs = reinterpret_cast<T*>(smem);
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-          for (int e = 0; e < 16; e++) {
-            const int lr = wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            Cs[lr * CROW + wc * 64 + j * 32 + r] = (T)acc[i][j][e];
-          }
-      __syncthreads();
-      T* C = reinterpret_cast<T*>(p.C) + coff;
-#pragma unroll
-      for (int it = 0; it < 8; it++) {
-        const int v = tid + it * NTHREADS;
-        const int lr = v >> 4, cv = (v & 15) * 8;
-        const int m = m0 + lr, n = n0 + cv;
-        if (m < p.M && n < p.N) {
-          Vec16<T> o = *reinterpret_cast<const Vec16<T>*>(Cs + lr * CROW + cv);
-          if (n + 8 <= p.N) {
-            if (R) {
-              Vec16<T> rv = ldg16(R + (int64_t)m * p.ldr + n);
-#pragma unroll
-              for (int e = 0; e < 8; e++) o.v[e] = (T)((float)o.v[e] + (float)rv.v[e]);
-            }
-            stg16(C + (int64_t)m * p.ldc + n, o);
-          } else {
-            for (int e = 0; e < 8 && n + e < p.N; e++) {
-              float f = (float)o.v[e];
-              if (R) f += (float)R[(int64_t)m * p.ldr + n + e];
-              C[(int64_t)m * p.ldc + n + e] = (T)f;
-            }
-          }
-        }
-      }
-    }
-  }
+#undef CROG_KMEM
+  __syncthreads();
+  gemm_epilogue<T, S>(acc, p, smem, m0, n0, zs, coff);
 }
 
-template <typename T, int AL, int BL, bool HWTR>
-int launch(const crog_gemm_desc& d, hipStream_t s) {
-  const int tilesM = cdiv(d.M, BM), tilesN = cdiv(d.N, BN);
-  dim3 grid(tilesM * tilesN, d.batch * d.splitk, 1);
-  hipLaunchKernelGGL((gemm_kernel<T, AL, BL, HWTR>), grid, dim3(NTHREADS), 0, s, d);
+template <typename T, int AL, int BL>
+int launch_dma(const crog_gemm_desc& d, hipStream_t s) {
+  constexpr int LDS = DMA_NSTAGE * DMA_STAGE_B;
+  static bool attr_set = false;
+  auto kern = gemm_dma_kernel<T, AL, BL>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      crog_set_error("crog_gemm: hipFuncSetAttribute(%d bytes) failed: %s", LDS, hipGetErrorString(e));
+      return CROG_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(d.M, 128) * cdiv(d.N, 128), d.batch * d.splitk, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, d);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
 
-template <typename T, bool HWTR>
+template <typename T>
+int dispatch_dma(const crog_gemm_desc& d, hipStream_t s) {
+  const int a = d.a_layout, b = d.b_layout;
+  if (a == CROG_A_KC && b == CROG_B_KC) return launch_dma<T, CROG_A_KC, CROG_B_KC>(d, s);
+  if (a == CROG_A_IM2COL && b == CROG_B_KC) return launch_dma<T, CROG_A_IM2COL, CROG_B_KC>(d, s);
+  if (a == CROG_A_KC && b == CROG_B_NC) return launch_dma<T, CROG_A_KC, CROG_B_NC>(d, s);
+  if (a == CROG_A_IM2COL && b == CROG_B_NC_DGRAD) return launch_dma<T, CROG_A_IM2COL, CROG_B_NC_DGRAD>(d, s);
+  if (a == CROG_A_MC && b == CROG_B_NC) return launch_dma<T, CROG_A_MC, CROG_B_NC>(d, s);
+  if (a == CROG_A_MC && b == CROG_B_NC_IM2COL) return launch_dma<T, CROG_A_MC, CROG_B_NC_IM2COL>(d, s);
+  if (a == CROG_A_MC && b == CROG_B_KC) return launch_dma<T, CROG_A_MC, CROG_B_KC>(d, s);
+  crog_set_error("crog_gemm: unsupported layout combination a=%d b=%d", a, b);
+  return CROG_ERR_ARG;
+}
+
+bool dma_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CROG_GEMM_NO_DMA");
+    v = (e && e[0] == '1') ? 0 : 1;
+  }
+  return v == 1;
+}
+
+// The DMA kernel addresses each operand through a 32-bit byte offset from its (batch-adjusted) base pointer and moves whole
+// 16-byte chunks: K-contiguous operands need K %% vec == 0, transposed operands need their column count %% vec == 0.
+bool dma_eligible(const crog_gemm_desc& d) {
+  if (!dma_enabled()) return false;
+  const long esz = d.dtype == CROG_BF16 ? 2 : 4, vec = 16 / esz;
+  const bool a_tr = d.a_layout == CROG_A_MC, b_tr = d.b_layout != CROG_B_KC;
+  if ((!a_tr || !b_tr) && d.K % vec != 0) return false;
+  if (a_tr && d.M % vec != 0) return false;
+  if (b_tr && d.N % vec != 0) return false;
+  const long rows_a = a_tr ? d.K : (d.a_layout == CROG_A_IM2COL ? (long)d.M + d.convW + 1 : d.M);
+  long rows_b = d.N;
+  if (d.b_layout == CROG_B_NC) rows_b = d.K;
+  else if (d.b_layout == CROG_B_NC_DGRAD) rows_b = 9L * d.convC;
+  else if (d.b_layout == CROG_B_NC_IM2COL) rows_b = (long)d.K + d.convW + 1;
+  if (rows_a * d.lda * esz >= 0x7fffffffL || rows_b * d.ldb * esz >= 0x7fffffffL) return false;
+  return true;
+}
+
+template <typename T, int AL, int BL, bool HWTR, typename S>
+int launch(const crog_gemm_desc& d, hipStream_t s) {
+  constexpr int LDS = lds_bytes<T, S>();
+  static bool attr_set = false;
+  auto kern = gemm_kernel<T, AL, BL, HWTR, S>;
+  if (!attr_set) {
+    if (LDS > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) {
+        crog_set_error("crog_gemm: hipFuncSetAttribute(%d bytes) failed: %s", LDS, hipGetErrorString(e));
+        return CROG_ERR_LAUNCH;
+      }
+    }
+    attr_set = true;
+  }
+  const int tilesM = cdiv(d.M, S::BM), tilesN = cdiv(d.N, S::BN);
+  dim3 grid(tilesM * tilesN, d.batch * d.splitk, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(S::NT), LDS, s, d);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+template <typename T, bool HWTR, typename S>
 int dispatch_layout(const crog_gemm_desc& d, hipStream_t s) {
   const int a = d.a_layout, b = d.b_layout;
-  if (a == CROG_A_KC && b == CROG_B_KC) return launch<T, CROG_A_KC, CROG_B_KC, true>(d, s);
-  if (a == CROG_A_IM2COL && b == CROG_B_KC) return launch<T, CROG_A_IM2COL, CROG_B_KC, true>(d, s);
-  if (a == CROG_A_KC && b == CROG_B_NC) return launch<T, CROG_A_KC, CROG_B_NC, HWTR>(d, s);
-  if (a == CROG_A_IM2COL && b == CROG_B_NC_DGRAD) return launch<T, CROG_A_IM2COL, CROG_B_NC_DGRAD, HWTR>(d, s);
-  if (a == CROG_A_MC && b == CROG_B_NC) return launch<T, CROG_A_MC, CROG_B_NC, HWTR>(d, s);
-  if (a == CROG_A_MC && b == CROG_B_NC_IM2COL) return launch<T, CROG_A_MC, CROG_B_NC_IM2COL, HWTR>(d, s);
-  if (a == CROG_A_MC && b == CROG_B_KC) return launch<T, CROG_A_MC, CROG_B_KC, HWTR>(d, s);
+  if (a == CROG_A_KC && b == CROG_B_KC) return launch<T, CROG_A_KC, CROG_B_KC, true, S>(d, s);
+  if (a == CROG_A_IM2COL && b == CROG_B_KC) return launch<T, CROG_A_IM2COL, CROG_B_KC, true, S>(d, s);
+  if (a == CROG_A_KC && b == CROG_B_NC) return launch<T, CROG_A_KC, CROG_B_NC, HWTR, S>(d, s);
+  if (a == CROG_A_IM2COL && b == CROG_B_NC_DGRAD) return launch<T, CROG_A_IM2COL, CROG_B_NC_DGRAD, HWTR, S>(d, s);
+  if (a == CROG_A_MC && b == CROG_B_NC) return launch<T, CROG_A_MC, CROG_B_NC, HWTR, S>(d, s);
+  if (a == CROG_A_MC && b == CROG_B_NC_IM2COL) return launch<T, CROG_A_MC, CROG_B_NC_IM2COL, HWTR, S>(d, s);
+  if (a == CROG_A_MC && b == CROG_B_KC) return launch<T, CROG_A_MC, CROG_B_KC, HWTR, S>(d, s);
   crog_set_error("crog_gemm: unsupported layout combination a=%d b=%d", a, b);
   return CROG_ERR_ARG;
 }
@@ -474,9 +875,50 @@ bool hwtr_enabled() {
   return v == 1;
 }
 
+// 0 = auto, 1 = small, 2 = mid, 3 = big (CROG_GEMM_SHAPE, for tests and A/B runs)
+int forced_shape() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CROG_GEMM_SHAPE");
+    v = 0;
+    if (e) {
+      if (e[0] == 's') v = 1;
+      else if (e[0] == 'm') v = 2;
+      else if (e[0] == 'b') v = 3;
+    }
+  }
+  return v;
+}
+
+int pick_shape(const crog_gemm_desc& d) {
+  const int f = forced_shape();
+  const long zb = (long)d.batch * d.splitk;
+  if (f == 3 || f == 2) return f;
+  if (f == 1) return d.col_stats ? 2 : 1;
+  const long mid = (long)cdiv(d.M, 128) * cdiv(d.N, 128) * zb;
+  const long big = (long)cdiv(d.M, 256) * cdiv(d.N, 128) * zb;
+  // BIG when it still fills the chip and does not waste more of the tile on padding than MID does
+  const double eff_big = (double)d.M * d.N / ((double)cdiv(d.M, 256) * 256 * cdiv(d.N, 128) * 128);
+  const double eff_mid = (double)d.M * d.N / ((double)cdiv(d.M, 128) * 128 * cdiv(d.N, 128) * 128);
+  (void)big; (void)eff_big; (void)eff_mid;  // BIG is kept for A/B runs only: measured slower than MID/SMALL (occupancy-bound staging)
+  if (mid < 192 && !d.col_stats) return 1;
+  return 2;
+}
+
+template <typename T, bool HWTR>
+int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
+  const int shape = pick_shape(d);
+  if (shape == 2 && dma_eligible(d)) return dispatch_dma<T>(d, s);
+  switch (shape) {
+    case 3: return dispatch_layout<T, HWTR, ShapeBig>(d, s);
+    case 1: return dispatch_layout<T, HWTR, ShapeSmall>(d, s);
+    default: return dispatch_layout<T, HWTR, ShapeMid>(d, s);
+  }
+}
+
 }  // namespace
 
-extern "C" int crog_gemm_stat_tiles(int M) { return cdiv(M, BM); }
+extern "C" int crog_gemm_stat_tiles(int M) { return cdiv(M, 128); }
 
 extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
   CROG_CHECK_ARG(dp != nullptr, "crog_gemm: null descriptor");
@@ -514,6 +956,6 @@ extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
   CROG_CHECK_ARG((long)d.batch * d.splitk <= 65535, "crog_gemm: batch*splitk too large");
   hipStream_t s = (hipStream_t)stream;
   const bool hw = hwtr_enabled();
-  if (d.dtype == CROG_BF16) return hw ? dispatch_layout<bf16, true>(d, s) : dispatch_layout<bf16, false>(d, s);
-  return dispatch_layout<float, true>(d, s);
+  if (d.dtype == CROG_BF16) return hw ? dispatch_shape<bf16, true>(d, s) : dispatch_shape<bf16, false>(d, s);
+  return dispatch_shape<float, true>(d, s);
 }

@@ -58,18 +58,21 @@ __global__ void __launch_bounds__(NT) bn_partial_stats_kernel(const T* __restric
   }
 }
 
-// sums[c][2] = sum over parts of partial[part][c][2]  (any pair of per-channel quantities)
-__global__ void reduce_pairs_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ sums) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float a = 0.f, b = 0.f;
-  for (int p = 0; p < nparts; p++) {
-    const float2 v = *reinterpret_cast<const float2*>(partial + ((long)p * C + c) * 2);
-    a += v.x;
-    b += v.y;
-  }
-  sums[2 * c] = a;
-  sums[2 * c + 1] = b;
+// sums[c][2] = sum over parts of partial[part][c][2]  (any pair of per-channel quantities).
+// Block = 32 channels (64 consecutive floats of a slab row) x 4 part-lanes; grid.y splits the part range;
+// partial results meet in `sums` through fp32 atomics (sums is zeroed by the launcher).
+__global__ void __launch_bounds__(NT) reduce_pairs_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ sums) {
+  __shared__ float red[4][64];
+  const int f = threadIdx.x & 63, lane_p = threadIdx.x >> 6;   // float index inside the 32-channel group, part lane
+  const int col = blockIdx.x * 64 + f;                           // float column in a slab row of 2*C floats
+  const int per = (nparts + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = min(p0 + per, nparts);
+  float acc = 0.f;
+  if (col < 2 * C)
+    for (int p = p0 + lane_p; p < p1; p += 4) acc += partial[(long)p * 2 * C + col];
+  red[lane_p][f] = acc;
+  __syncthreads();
+  if (lane_p == 0 && col < 2 * C) atomicAdd(sums + col, red[0][f] + red[1][f] + red[2][f] + red[3][f]);
 }
 
 // Finalize training-mode BN from (global) sums: scale/shift for the apply pass, mean/invstd for
@@ -248,7 +251,7 @@ __global__ void __launch_bounds__(NT) ln_fwd_kernel(const T* __restrict__ x, lon
                                                     T* __restrict__ out2, long ldo2, const T* __restrict__ pos, int pos_rows, long ldp,
                                                     float p_in, uint64_t seed_in, float p_out, uint64_t seed_out) {
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int MAXV = 2048 / (64 * 4);  // up to C = 2048 (f32: 8 vectors of 4 per lane)
+  constexpr int MAXV = 2048 / (64 * VEC);  // up to C = 2048: 4 (bf16) or 8 (f32) 16-byte vectors per lane
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -319,7 +322,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
                                                     float* __restrict__ partial, int rows_per_block, float p_in, uint64_t seed_in,
                                                     float p_out, uint64_t seed_out) {
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int MAXV = 2048 / (64 * 4);
+  constexpr int MAXV = 2048 / (64 * VEC);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int cvec = C / VEC;
   const uint32_t thr_in = (uint32_t)(p_in * 4294967296.0), thr_out = (uint32_t)(p_out * 4294967296.0);
@@ -528,7 +531,12 @@ extern "C" int crog_bn_partial_stats(int dtype, const void* x, int64_t M, int C,
 
 extern "C" int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, crog_stream_t stream) {
   CROG_CHECK_ARG(nparts > 0 && C > 0, "reduce_pairs: bad sizes");
-  hipLaunchKernelGGL(reduce_pairs_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, partial, nparts, C, sums);
+  hipError_t e = hipMemsetAsync(sums, 0, (size_t)C * 2 * sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) { crog_set_error("reduce_pairs: memset failed"); return CROG_ERR_LAUNCH; }
+  int splits = nparts / 16;
+  if (splits < 1) splits = 1;
+  if (splits > 128) splits = 128;
+  hipLaunchKernelGGL(reduce_pairs_kernel, dim3(cdiv(2 * C, 64), splits), dim3(NT), 0, (hipStream_t)stream, partial, nparts, C, sums);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
