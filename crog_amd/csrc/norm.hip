@@ -384,17 +384,24 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
       }
     }
   }
-  // combine the block's 4 waves through global atomics into this block's partial row (zeroed by host)
+  // combine the block's 4 waves through LDS, then one plain store per value into this block's partial row
+  __shared__ float red[NT / 64][2 * 2048 / 8 + 1];
   float* dst = partial + (long)blockIdx.x * C * 2;
+  for (int cg = 0; cg < 2 * C; cg += 2 * 2048 / 8) {  // 512 floats (256 channels) per round keeps LDS at 8 KB
 #pragma unroll
-  for (int j = 0; j < MAXV; j++) {
-    const int cv = lane + j * 64;
-    if (cv < cvec)
+    for (int j = 0; j < MAXV; j++) {
+      const int cv = lane + j * 64;
+      if (cv < cvec)
 #pragma unroll
-      for (int e = 0; e < VEC; e++) {
-        atomicAdd(dst + 2 * (cv * VEC + e), dg[j][e]);
-        atomicAdd(dst + 2 * (cv * VEC + e) + 1, db[j][e]);
-      }
+        for (int e = 0; e < VEC; e++) {
+          const int f = 2 * (cv * VEC + e) - cg;
+          if (f >= 0 && f < 2 * 2048 / 8) { red[wv][f] = dg[j][e]; red[wv][f + 1] = db[j][e]; }
+        }
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < 2 * 2048 / 8 && cg + f < 2 * C; f += NT)
+      dst[cg + f] = red[0][f] + red[1][f] + red[2][f] + red[3][f];
+    __syncthreads();
   }
 }
 
@@ -624,8 +631,6 @@ extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0 && C <= 2048, "ln_bwd: C=%d must be a multiple of %d and <= 2048", C, vec);
   const int blocks = cdiv(M, rows_per_block);
-  hipError_t e = hipMemsetAsync(partial, 0, (size_t)blocks * C * 2 * sizeof(float), (hipStream_t)stream);
-  if (e != hipSuccess) { crog_set_error("ln_bwd: memset failed"); return CROG_ERR_LAUNCH; }
   DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dout, (long)lddo,
                                        (const T*)dout2, (long)lddo2, (const T*)x, (long)ldx, gamma, stats, (long)M, C, (T*)dx,
                                        (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out));

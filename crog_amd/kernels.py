@@ -140,11 +140,12 @@ def stat_tiles(M: int) -> int:
 
 
 def pick_splitk(M: int, N: int, K: int, bk: int) -> int:
-    """Split the reduction so that a weight-gradient GEMM (small MxN, huge K) still fills 256 CUs."""
+    """Split the reduction of a weight-gradient GEMM (small MxN, huge K) so that it fills 256 CUs, but keep at
+    least ~24 k-tiles per block: every split pays one 128x128 fp32 atomic epilogue (64 KiB), and fp32 atomics run at
+    ~1.3 TB/s chip-wide, so many thin splits turn the GEMM into an atomic-add benchmark."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     ktiles = (K + bk - 1) // bk
-    target = 1024
-    s = max(1, min(target // max(tiles, 1), ktiles // 8 if ktiles >= 16 else 1))
+    s = min(max(1, 768 // max(tiles, 1)), max(1, ktiles // 24))
     return max(1, min(s, 1024))
 
 
@@ -216,7 +217,7 @@ def ln_fwd(x, gamma, beta, eps, out, stats, res=None, out2=None, pos=None, p_in=
 
 
 def ln_bwd_rows_per_block(M: int) -> int:
-    return max(4, (M + 255) // 256)
+    return max(8, (M + 1023) // 1024)
 
 
 def ln_bwd(dout, dout2, x, gamma, stats, dx, partial, rows_per_block, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0):
@@ -353,7 +354,7 @@ def coord_fill(buf, c0, cend):
 
 def colsum(x, out, out_off=0):
     M, C, ldx = mat(x)
-    rpb = max(16, (M + 255) // 256)
+    rpb = max(8, min(64, (M + 2047) // 2048))
     check(lib().crog_colsum(dcode(x), ptr(x), ldx, M, C, rpb, ptr(out) + 4 * out_off, stream()), "colsum")
 
 

@@ -1,0 +1,112 @@
+"""Host-side checks that need no GPU: the C-ABI library exports every symbol the header declares, the ctypes mirror of
+crog_gemm_desc matches the C struct, argument validation works without touching a device, and the module tree reproduces
+the reference's parameter names / shapes / optimizer groups (fixtures captured from the reference, tests/golden/*.json)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from crog_amd import _lib  # noqa: E402
+from crog_amd.testing import make_cfg, tiny_cfg  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    protos = _lib.parse_header()
+    assert len(protos) >= 45
+    for name in protos:
+        assert hasattr(lib, name), name
+    # and the header is the only place prototypes live: every extern "C" crog_* definition is declared there
+    defined = set()
+    for f in _lib.SOURCES:
+        defined |= set(re.findall(r'extern "C" (?:const char\*|int) (crog_\w+)\(', open(os.path.join(_lib.CSRC, f)).read()))
+    assert defined == set(protos), (defined ^ set(protos))
+    assert lib.crog_hip_version() >= 100
+
+
+def test_gemm_desc_layout_matches_c_struct(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "crog_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(crog_gemm_desc),'
+                   ' offsetof(crog_gemm_desc, lda), offsetof(crog_gemm_desc, splitk), offsetof(crog_gemm_desc, bias), offsetof(crog_gemm_desc, col_stats));return 0;}')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).split()
+    D = _lib.GemmDesc
+    assert [int(x) for x in out] == [ctypes.sizeof(D), D.lda.offset, D.splitk.offset, D.bias.offset, D.col_stats.offset]
+
+
+def test_argument_validation_needs_no_device(lib):
+    d = _lib.GemmDesc()
+    assert lib.crog_gemm(ctypes.byref(d), None) == 0           # empty problem: nothing to do
+    d.M, d.N, d.K, d.batch = 4, 4, 4, 1
+    assert lib.crog_gemm(ctypes.byref(d), None) == -1          # null operands are rejected before any launch
+    assert b"crog_gemm" in lib.crog_last_error()
+    d.dtype = 7
+    assert lib.crog_gemm(ctypes.byref(d), None) == -1 and b"dtype" in lib.crog_last_error()
+    assert lib.crog_gemm_stat_tiles(129) == 2
+    assert lib.crog_adam_step(None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 0.0, 0, None, None) == -1  # step must be >= 1
+
+
+def test_product_path_has_no_cpu_fallback():
+    from crog_amd import kernels as K
+    with pytest.raises(RuntimeError):
+        K.ptr(torch.zeros(4))                                    # CPU tensors are refused, not silently computed
+    from crog_amd.model import build_crog
+    model, _ = build_crog(tiny_cfg())
+    with pytest.raises(RuntimeError):
+        model.prepare(torch.device("cpu"))
+    # nothing under crog_amd/ imports the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "crog_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+@pytest.mark.parametrize("case,cfgf", [("tiny_crog", tiny_cfg), ("crog_r50_b2", make_cfg)])
+def test_state_dict_and_groups_match_reference(case, cfgf):
+    from crog_amd.model import build_crog
+    meta = json.load(open(os.path.join(GOLD, case + ".json")))
+    model, groups = build_crog(cfgf())
+    sd = model.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == meta["shapes"]
+    assert len(groups[0]["params"]) == meta["group_backbone"] and len(groups[1]["params"]) == meta["group_head"]
+    assert [groups[0]["initial_lr"], groups[1]["initial_lr"]] == pytest.approx(meta["group_lrs"])
+    names = [n for n, _ in model.named_parameters()]
+    assert sorted(names) == sorted(meta["param_names"])
+    if case == "crog_r50_b2":
+        assert sum(p.numel() for p in model.parameters()) == 147112290
+
+
+def test_flat_store_layout_on_cpu_tensors():
+    """ParamStore is plain tensor bookkeeping (no kernels): check offsets, alignment, KRSC views and grad aliasing on CPU."""
+    from crog_amd.runtime import ALIGN, ParamStore
+    m = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, bias=False), torch.nn.Conv2d(16, 4, 1), torch.nn.Linear(5, 3))
+    ref = {k: v.clone() for k, v in m.state_dict().items()}
+    st = ParamStore(m, torch.device("cpu"))
+    for name, p, o, n, g in st.entries:
+        assert o % ALIGN == 0 and torch.equal(p.detach(), ref[name]) and p.grad is g
+        assert p.data_ptr() == st.P.data_ptr() + 4 * o
+    w = m[0].weight
+    assert w.shape == (16, 8, 3, 3) and w.stride() == (72, 1, 24, 8)          # physically [Cout][ky][kx][Cin]
+    assert torch.equal(st.P[:16 * 72].view(16, 3, 3, 8), ref["0.weight"].permute(0, 2, 3, 1))
+    out = m[2](m[1](m[0](torch.randn(2, 8, 6, 6))).flatten(1)[:, :5])
+    out.sum().backward()
+    assert st.G.abs().sum() > 0 and m[0].weight.grad.data_ptr() == st.G.data_ptr()   # autograd accumulated in place into G
+    st.zero_grad()
+    assert m[2].weight.grad.abs().sum() == 0

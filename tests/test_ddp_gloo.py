@@ -1,0 +1,83 @@
+"""Multi-process data parallelism on CPU (gloo, world_size 2): the bucketed overlapped reducer over the flat gradient
+buffer gives every rank the mean gradient == the single-process gradient on the concatenated batch, parameters are
+broadcast from rank 0, unused parameters do not hang the step, and the cross-replica BatchNorm statistics exchange
+(pairs of per-channel sums) reproduces whole-batch statistics."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(12, 40)
+        self.c = torch.nn.Conv2d(2, 3, 3, bias=False)
+        self.b = torch.nn.Linear(40, 5)
+        self.unused = torch.nn.Parameter(torch.ones(7))    # like CLIP.logit_scale: never receives a gradient
+        self.explicit_grad_ready = False
+        self._store = None
+
+    def prepare(self, device):
+        from crog_amd.runtime import ParamStore
+        self._store = ParamStore(self, torch.device(device))
+        return self
+
+    @property
+    def store(self):
+        return self._store
+
+    def forward(self, x, img):
+        return self.b(torch.tanh(self.a(x))).sum() + self.c(img).pow(2).mean()
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from crog_amd.parallel import DistributedDataParallel, SyncBNComm
+    torch.manual_seed(100 + rank)                      # different init per rank: DDP must broadcast rank 0's weights
+    net = Net().prepare("cpu")
+    ddp = DistributedDataParallel(net, bucket_cap_mb=0.001)   # tiny buckets -> several collectives in flight
+    g = torch.Generator().manual_seed(7)
+    X, I = torch.randn(8, 12, generator=g), torch.randn(8, 2, 6, 6, generator=g)
+    xs, im = X[rank * 4:(rank + 1) * 4], I[rank * 4:(rank + 1) * 4]
+    for step in range(2):
+        net.store.zero_grad()
+        loss = ddp(xs, im)
+        loss.backward()
+        ddp.reducer.wait()
+    assert len(ddp.reducer.buckets) > 2
+    # cross-replica BatchNorm statistics: all-reduce of (sum, sum^2) pairs
+    comm = SyncBNComm()
+    z = I[rank * 4:(rank + 1) * 4]
+    pairs = torch.stack([z.sum((0, 2, 3)), (z * z).sum((0, 2, 3))], 1).contiguous()
+    comm.all_reduce_sum(pairs)
+    torch.save(dict(G=net.store.G.clone(), P=net.store.P.clone(), pairs=pairs), os.path.join(tmp, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_reducer_matches_single_process(tmp_path):
+    world, port = 2, 29000 + os.getpid() % 2000
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["P"], r1["P"]) and torch.allclose(r0["G"], r1["G"], atol=1e-7)
+    # single-process reference with rank 0's weights on the whole batch
+    from crog_amd.runtime import ParamStore
+    torch.manual_seed(100)
+    net = Net()
+    st = ParamStore(net, torch.device("cpu"))
+    assert torch.equal(st.P, r0["P"])
+    g = torch.Generator().manual_seed(7)
+    X, I = torch.randn(8, 12, generator=g), torch.randn(8, 2, 6, 6, generator=g)
+    # mean over ranks of per-rank losses == what DDP's averaged gradient corresponds to
+    (0.5 * (net(X[:4], I[:4]) + net(X[4:], I[4:]))).backward()
+    assert torch.allclose(st.G, r0["G"], atol=1e-6, rtol=1e-5)
+    assert st.G[st.off(net.unused):st.off(net.unused) + 7].abs().sum() == 0
+    ref = torch.stack([I.sum((0, 2, 3)), (I * I).sum((0, 2, 3))], 1)
+    assert torch.allclose(r0["pairs"], ref, atol=1e-4)
