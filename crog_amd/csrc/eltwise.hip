@@ -467,33 +467,45 @@ __global__ void __launch_bounds__(NT) adam_kernel(float* __restrict__ p, const f
   }
 }
 
-// ---- out[c] += sum_r x[r][c]  (bias gradients): one thread per (row block, 16-byte column chunk) ----------
+// ---- out[c] += sum_r x[r][c]  (bias gradients), two passes without contended atomics -----------------------------
+// pass 1: block (4 row lanes x 64 chunk lanes) reduces `rows_per_block` rows of a 64-chunk column group -> partial[rb][c]
 template <typename T>
-__global__ void __launch_bounds__(NT) colsum_kernel(const T* __restrict__ x, long ldx, long M, int C, int rows_per_block, float* __restrict__ out) {
+__global__ void __launch_bounds__(NT) colsum_partial_kernel(const T* __restrict__ x, long ldx, long M, int C, int rows_per_block,
+                                                           float* __restrict__ partial) {
   constexpr int VEC = Elem<T>::VEC;
-  const int cvec = (C + VEC - 1) / VEC;
-  const long nblk = (M + rows_per_block - 1) / rows_per_block;
-  GRID_STRIDE(i, nblk * cvec) {
-    const long rb = i / cvec;
-    const int c = (int)(i % cvec) * VEC;
-    const long r0 = rb * rows_per_block, r1 = min(r0 + rows_per_block, M);
-    float acc[VEC];
+  __shared__ float red[4][64][VEC + 1];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = (blockIdx.y * 64 + tx) * VEC;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+  float acc[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; e++) acc[e] = 0.f;
-    if (c + VEC <= C) {
-      for (long r = r0; r < r1; r++) {
-        Vec16<T> v = ldg16(x + r * ldx + c);
+  for (int e = 0; e < VEC; e++) acc[e] = 0.f;
+  if (c + VEC <= C) {
+    for (long r = r0 + ty; r < r1; r += 4) {
+      Vec16<T> v = ldg16(x + r * ldx + c);
 #pragma unroll
-        for (int e = 0; e < VEC; e++) acc[e] += Elem<T>::to_f(v.v[e]);
-      }
-    } else {
-      for (long r = r0; r < r1; r++)
-        for (int e = 0; e < VEC && c + e < C; e++) acc[e] += Elem<T>::to_f(x[r * ldx + c + e]);
+      for (int e = 0; e < VEC; e++) acc[e] += Elem<T>::to_f(v.v[e]);
     }
+  } else if (c < C) {
+    for (long r = r0 + ty; r < r1; r += 4)
+      for (int e = 0; e < VEC && c + e < C; e++) acc[e] += Elem<T>::to_f(x[r * ldx + c + e]);
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; e++) red[ty][tx][e] = acc[e];
+  __syncthreads();
+  if (ty == 0 && c < C) {
 #pragma unroll
     for (int e = 0; e < VEC; e++)
-      if (c + e < C) atomicAdd(out + c + e, acc[e]);
+      if (c + e < C) partial[(long)blockIdx.x * C + c + e] = red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e];
   }
+}
+// pass 2: out[c] += sum_rb partial[rb][c]
+__global__ void __launch_bounds__(NT) colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * NT + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int b = 0; b < nblk; b++) a += partial[(long)b * C + c];
+  out[c] += a;
 }
 
 }  // namespace
@@ -662,10 +674,15 @@ extern "C" int crog_adam_step(float* p, const float* g, float* m, float* v, int6
   return CROG_OK;
 }
 
-extern "C" int crog_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, int rows_per_block, float* out, crog_stream_t s) {
+extern "C" int crog_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, int rows_per_block, float* partial, float* out,
+                           crog_stream_t s) {
   const int vec = VECOF(dtype);
-  CROG_CHECK_ARG(ldx % vec == 0 && rows_per_block > 0, "colsum: ldx %% %d == 0 required", vec);
-  DISPATCH_T(dtype, LAUNCH((colsum_kernel<T>), (long)cdiv(M, rows_per_block) * cdiv(C, vec), s, (const T*)x, (long)ldx, (long)M, C, rows_per_block, out));
+  CROG_CHECK_ARG(ldx % vec == 0 && rows_per_block > 0 && partial != nullptr, "colsum: ldx %% %d == 0 and a partial workspace are required", vec);
+  const int nblk = cdiv(M, rows_per_block);
+  dim3 grid(nblk, cdiv(cdiv(C, vec), 64));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(NT), 0, (hipStream_t)s, (const T*)x, (long)ldx, (long)M, C, rows_per_block, partial));
+  CROG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, NT)), dim3(NT), 0, (hipStream_t)s, partial, nblk, C, out);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

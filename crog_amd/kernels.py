@@ -354,8 +354,9 @@ def coord_fill(buf, c0, cend):
 
 def colsum(x, out, out_off=0):
     M, C, ldx = mat(x)
-    rpb = max(8, min(64, (M + 2047) // 2048))
-    check(lib().crog_colsum(dcode(x), ptr(x), ldx, M, C, rpb, ptr(out) + 4 * out_off, stream()), "colsum")
+    rpb = max(8, (M + 255) // 256)
+    ws = torch.empty(((M + rpb - 1) // rpb) * C, device=x.device, dtype=torch.float32)
+    check(lib().crog_colsum(dcode(x), ptr(x), ldx, M, C, rpb, ptr(ws), ptr(out) + 4 * out_off, stream()), "colsum")
 
 
 def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, shadow=None, off=0):

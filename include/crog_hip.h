@@ -212,9 +212,10 @@ int crog_cast_to_f32(int dtype, const void* src, int64_t lds, float* dst, int64_
 /* CoordConv coordinate channels: layers.py:30-39 */
 int crog_coord_fill(int dtype, void* buf, int64_t ld, int B, int H, int W, int c0, int cend,
                     crog_stream_t stream);
-/* out[c] += sum_r x[r][c] (fp32 atomics): bias gradients of nn.Linear / nn.Conv2d(bias=True) */
-int crog_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, int rows_per_block, float* out,
-                crog_stream_t stream);
+/* out[c] += sum_r x[r][c]: bias gradients of nn.Linear / nn.Conv2d(bias=True).  partial: fp32 workspace of
+ * ceil(M / rows_per_block) * C floats (two-pass reduction, no contended atomics) */
+int crog_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, int rows_per_block, float* partial,
+                float* out, crog_stream_t stream);
 /* torch.optim.Adam step over one flat fp32 segment (train_crog.py:119-121, crog_engine.py:83) */
 int crog_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, void* bf16_shadow, crog_stream_t stream);

@@ -495,3 +495,15 @@ def test_head_and_loss(K):
     tb = tgt_small[0].flatten(1).bool()
     ious = (o & tb).sum(1) / ((o | tb).sum(1) + 1e-6)
     assert torch.allclose(m2[0], 100 * ious.mean(), atol=1e-3) and torch.allclose(m2[1], 100 * (ious > 0.5).float().mean(), atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,C", [(1000, 512), (37, 1536), (4, 2305), (21632, 64)])
+def test_colsum(K, dt, M, C):
+    ld = ((C + 7) // 8) * 8
+    buf = rnd(M, ld, dt=dt)
+    x = buf[:, :C]
+    out = torch.ones(C + 3, device="cuda")
+    K.colsum(x, out, out_off=0)
+    close(out[:C], 1.0 + x.float().sum(0), dt, scale=math.sqrt(M))
+    assert (out[C:] == 1).all()
