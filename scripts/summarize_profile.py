@@ -4,7 +4,7 @@ tag, stats_dir, fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], sys.argv
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
-sf = glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))[0]
+sf = max(glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 shutil.copy(sf, os.path.join(out, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(sf)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -12,7 +12,7 @@ def agg(d, counter):
     acc = collections.defaultdict(lambda: [0, 0.0])
     fs = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
     if not fs: return acc
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         if r["Counter_Name"] == counter:
             acc[r["Kernel_Name"]][0] += 1; acc[r["Kernel_Name"]][1] += float(r["Counter_Value"])
     return acc
