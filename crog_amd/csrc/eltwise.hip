@@ -499,13 +499,17 @@ __global__ void __launch_bounds__(NT) colsum_partial_kernel(const T* __restrict_
       if (c + e < C) partial[(long)blockIdx.x * C + c + e] = red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e];
   }
 }
-// pass 2: out[c] += sum_rb partial[rb][c]
+// pass 2: out[c] += sum_rb partial[rb][c]   (block = 64 channels x 4 row-block lanes)
 __global__ void __launch_bounds__(NT) colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * NT + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   float a = 0.f;
-  for (int b = 0; b < nblk; b++) a += partial[(long)b * C + c];
-  out[c] += a;
+  if (c < C)
+    for (int b = ty; b < nblk; b += 4) a += partial[(long)b * C + c];
+  red[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && c < C) out[c] += red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
 }  // namespace
@@ -682,7 +686,7 @@ extern "C" int crog_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int
   dim3 grid(nblk, cdiv(cdiv(C, vec), 64));
   DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(NT), 0, (hipStream_t)s, (const T*)x, (long)ldx, (long)M, C, rows_per_block, partial));
   CROG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, NT)), dim3(NT), 0, (hipStream_t)s, partial, nblk, C, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(NT), 0, (hipStream_t)s, partial, nblk, C, out);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -527,7 +527,10 @@ struct DmaKc {
   unsigned kbytes;
 
   __device__ void init(const T* ptr, int64_t ld, int rows_total, int K, int row0, int wave, int lane, const ConvGeom& g) {
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr), 0, 0x7fffffff, 0x00020000);
+    // num_records = the operand's true extent (rows_total rows of ld elements; the last row ends at K rounded up to a
+    // chunk): anything past it reads as zero instead of touching a neighbouring allocation
+    const long extent = ((long)(rows_total - 1) * ld + ((K + VEC - 1) / VEC) * VEC) * (long)sizeof(T);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr), 0, (int)extent, 0x00020000);
     ldb_ = (int)(ld * sizeof(T));
     kbytes = (unsigned)(K * sizeof(T));
 #pragma unroll
@@ -597,7 +600,11 @@ struct DmaTr {
   __device__ static int swz(int row) { return sizeof(T) == 2 ? (((row & 3) << 2) | ((row >> 2) & 3)) : 0; }
 
   __device__ void init(const T* ptr, int64_t ld, int ncols, int K_, int col0, int wave, int lane, const ConvGeom& g) {
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr), 0, 0x7fffffff, 0x00020000);
+    long rows = K_;                                    // rows of memory the tile can touch
+    if (MODE == 1) rows = 9L * g.C;                    // KRSC weight rows (co*9 + tap)
+    const long width = (MODE == 2) ? g.C : ((ncols + VEC - 1) / VEC) * VEC;   // im2col rows are one pixel's channels
+    const long extent = ((rows - 1) * ld + width) * (long)sizeof(T);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr), 0, (int)extent, 0x00020000);
     ldb_ = (int)(ld * sizeof(T));
     K = K_;
 #pragma unroll
@@ -813,19 +820,26 @@ bool dma_enabled() {
 }
 
 // The DMA kernel addresses each operand through a 32-bit byte offset from its (batch-adjusted) base pointer and moves whole
-// 16-byte chunks: K-contiguous operands need K %% vec == 0, transposed operands need their column count %% vec == 0.
+// 16-byte chunks.  A ragged last chunk (K or a transposed operand's column count not a multiple of the chunk) is read in full:
+// that is memory-safe when the row stride covers the rounded-up length, and value-safe because the partner operand's rows
+// beyond K are zero-filled (transposed partner, exact row guard) or the extra columns only feed outputs that are never stored.
 bool dma_eligible(const crog_gemm_desc& d) {
   if (!dma_enabled()) return false;
   const long esz = d.dtype == CROG_BF16 ? 2 : 4, vec = 16 / esz;
   const bool a_tr = d.a_layout == CROG_A_MC, b_tr = d.b_layout != CROG_B_KC;
-  if ((!a_tr || !b_tr) && d.K % vec != 0) return false;
-  if (a_tr && d.M % vec != 0) return false;
-  if (b_tr && d.N % vec != 0) return false;
-  const long rows_a = a_tr ? d.K : (d.a_layout == CROG_A_IM2COL ? (long)d.M + d.convW + 1 : d.M);
+  auto up = [&](long v) { return (v + vec - 1) / vec * vec; };
+  if (d.K % vec != 0) {
+    if (!a_tr && !b_tr) return false;                  // both K-contiguous: nobody zero-fills the tail
+    if (!a_tr && (d.a_layout != CROG_A_KC || up(d.K) > d.lda)) return false;
+    if (!b_tr && up(d.K) > d.ldb) return false;
+  }
+  if (a_tr && up(d.M) > d.lda) return false;
+  if (b_tr && d.b_layout == CROG_B_NC && up(d.N) > d.ldb) return false;
+  if (b_tr && d.b_layout != CROG_B_NC && d.N % vec != 0) return false;
+  const long rows_a = a_tr ? d.K : d.M;
   long rows_b = d.N;
-  if (d.b_layout == CROG_B_NC) rows_b = d.K;
+  if (d.b_layout == CROG_B_NC || d.b_layout == CROG_B_NC_IM2COL) rows_b = d.K;
   else if (d.b_layout == CROG_B_NC_DGRAD) rows_b = 9L * d.convC;
-  else if (d.b_layout == CROG_B_NC_IM2COL) rows_b = (long)d.K + d.convW + 1;
   if (rows_a * d.lda * esz >= 0x7fffffffL || rows_b * d.ldb * esz >= 0x7fffffffL) return false;
   return true;
 }

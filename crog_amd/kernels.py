@@ -354,7 +354,7 @@ def coord_fill(buf, c0, cend):
 
 def colsum(x, out, out_off=0):
     M, C, ldx = mat(x)
-    rpb = max(8, (M + 255) // 256)
+    rpb = max(8, (M + 127) // 128)
     ws = torch.empty(((M + rpb - 1) // rpb) * C, device=x.device, dtype=torch.float32)
     check(lib().crog_colsum(dcode(x), ptr(x), ldx, M, C, rpb, ptr(ws), ptr(out) + 4 * out_off, stream()), "colsum")
 
