@@ -99,10 +99,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_ddp = os.environ.get("CROG_FORCE_DDP") == "1"   # exercise the RCCL path on a single GPU (smoke test of the N > 1 code)
+    if world > 1 or force_ddp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -120,9 +123,9 @@ def main():
     model = model.to(dev)
     model.prepare(dev)
     net = model
-    if world > 1:
-        convert_sync_batchnorm(model)
-        net = DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True)
+    if world > 1 or force_ddp:
+        convert_sync_batchnorm(model, force=force_ddp)
+        net = DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True, force=force_ddp)
     opt = FusedAdam(groups, lr=cfg.base_lr, weight_decay=cfg.weight_decay, store=model.store)
     RT.manual_seed(1234 + rank)
     batch = synthetic_batch(args.batch, args.size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + rank, device=dev)
@@ -130,7 +133,7 @@ def main():
     adt = torch.bfloat16 if args.dtype == "bf16" else None
 
     def sync():
-        if world > 1:
+        if world > 1 or force_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -183,7 +186,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -100,6 +100,21 @@ __device__ inline Frag<float> frag_tr(const float* tile, int cbase, int ks, int 
 
 struct ConvGeom { int H, W, C; };
 
+// Reduction order of the 3x3 forward / data-gradient forms: k-tile index -> (tap, 32-channel chunk).
+// Chunk-PAIR major, tap, then the two chunks of the pair: consecutive k-tiles read the two 64-byte halves of the same
+// 128-byte lines of a pixel (full-line use of L2), and the 9 taps of a chunk pair are 18 consecutive k-tiles (L2/L1 reuse
+// of the shifted pixels).  Falls back to chunk-major / tap-minor when the number of chunks is odd (Cin = 32).
+__device__ inline void conv_ktile(int kt, int nchunks, int& tap, int& chunk) {
+  if ((nchunks & 1) == 0) {
+    const int pair = kt / 18, r = kt - pair * 18;
+    tap = r >> 1;
+    chunk = pair * 2 + (r & 1);
+  } else {
+    tap = kt % 9;
+    chunk = kt / 9;
+  }
+}
+
 // ---- K-contiguous loader: ROWS rows x BK, 4 16-byte chunks per row, thread -> rows {tid/4 + i*NT/4} ----
 template <typename T, bool IM2COL, int ROWS, int NT>
 struct KcLoader {
@@ -451,8 +466,13 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))
   // (the 9 taps of one 32-channel chunk back to back): the 9 shifted reads of the same pixels then hit L1/L2 instead of
   // being 9 separate sweeps of the map 16 k-tiles apart.  A and B use the same memory offset, so the sum is unchanged.
   auto kmem = [&](int kt) -> int {
-    if constexpr (AL == CROG_A_IM2COL) return (kt % 9) * p.convC + (kt / 9) * BK;
-    else return kt * BK;
+    if constexpr (AL == CROG_A_IM2COL) {
+      int tap, chunk;
+      conv_ktile(kt, p.convC / BK, tap, chunk);
+      return tap * p.convC + chunk * BK;
+    } else {
+      return kt * BK;
+    }
   };
   // LDS ring: A slots at [0, 2*OPA), B slots at [2*OPA, 2*OPA + 2*OPB)
   la.load(kmem(kt0));
@@ -512,7 +532,7 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))
 // Out-of-range rows/columns, conv padding and ragged K are an out-of-bounds buffer offset: the hardware writes zeros.
 // =================================================================================================
 constexpr unsigned DMA_OOB = 0x80000000u;
-constexpr int DMA_TILE_B = 128 * 64, DMA_STAGE_B = 2 * DMA_TILE_B, DMA_NSTAGE = 3;
+constexpr int DMA_NSTAGE = 3;   // tile edge = 32 * (waves per block): 128 (4 waves) or 256 (8 waves); one operand tile = edge * 64 bytes
 
 // K-contiguous operand (MODE 0 dense rows, MODE 1 im2col patches of an NHWC map)
 template <typename T, int MODE>
@@ -549,7 +569,8 @@ struct DmaKc {
   // kt: k-tile index; kmem: element offset of the k-tile inside the reduction (see kmem in the kernels)
   __device__ unsigned off(int i, int kt, int kmem, const ConvGeom& g) const {
     if constexpr (MODE == 1) {
-      const int tap = kt % 9, chunk = kt / 9;
+      int tap, chunk;
+      conv_ktile(kt, g.C / BK, tap, chunk);
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
       const int sy = py[i] + dy, sx = px[i] + dx;
       const bool ok = base[i] != DMA_OOB && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
@@ -584,13 +605,13 @@ template <> __device__ inline Frag<float> DmaKc<float, 1>::frag(const char* tile
 }
 
 // Transposed operand: the tile is [BK reduction rows][128 columns] of memory (MODE as TrLoader: 0 dense, 1 dgrad weights, 2 wgrad im2col)
-template <typename T, int MODE>
+template <typename T, int MODE, int COLS>
 struct DmaTr {
   static constexpr int VEC = TileCfg<T>::VEC, BK = TileCfg<T>::BK;
   static constexpr bool TR = true;
-  static constexpr int CPR = 128 / VEC;          // chunks per tile row: 16 (bf16) / 32 (f32)
-  static constexpr int RPI = 64 / CPR;           // tile rows per wave-instruction: 4 / 2
-  static constexpr int ROWB = 128 * (int)sizeof(T);
+  static constexpr int CPR = COLS / VEC;         // chunks per tile row
+  static constexpr int ROWB = COLS * (int)sizeof(T);
+  static constexpr int RPI1024 = 1024 / ROWB;    // whole tile rows per 1 KiB wave-instruction (>= 1 for all shapes used)
   __amdgpu_buffer_rsrc_t rsrc;
   int rowin[2];       // reduction row of this lane inside the k-tile
   unsigned colb[2];   // byte offset of the lane's logical column chunk (DMA_OOB when the columns are out of range)
@@ -609,7 +630,7 @@ struct DmaTr {
     K = K_;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const int row = (wave * 2 + i) * RPI + lane / CPR;
+      const int row = (wave * 2 + i) * RPI1024 + lane / CPR;
       const int c = (lane % CPR) ^ swz(row);
       rowin[i] = row;
       const int col = col0 + c * VEC;
@@ -641,17 +662,18 @@ struct DmaTr {
   }
   __device__ static Frag<T> frag(const char* tile, int cbase, int ks, int lane);
 };
-template <int MODE> struct DmaTrFrag {
+template <int COLS> struct DmaTrFrag {
   __device__ static Frag<bf16> get(const char* tile, int cbase, int ks, int lane) {
     // ds_read_b64_tr_b16 on the swizzled image: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3
+    constexpr int ROWB = COLS * 2;
     const int h = lane >> 5, i = lane & 15, q = i >> 2, pp = i & 3;
     const int col = cbase + 16 * ((lane >> 4) & 1) + 4 * pp;
     const int chunk = col >> 3, inb = (col & 7) * 2;
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     const int r0 = ks * 16 + 8 * h + q, r1 = r0 + 4;
     const int x0 = ((r0 & 3) << 2) | ((r0 >> 2) & 3), x1 = ((r1 & 3) << 2) | ((r1 >> 2) & 3);
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * 256 + ((chunk ^ x0) << 4) + inb));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * 256 + ((chunk ^ x1) << 4) + inb));
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * ROWB + ((chunk ^ x0) << 4) + inb));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * ROWB + ((chunk ^ x1) << 4) + inb));
     Frag<bf16> f;
     f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return f;
@@ -661,34 +683,37 @@ template <int MODE> struct DmaTrFrag {
     const float* t = reinterpret_cast<const float*>(tile);
     Frag<float> f;
 #pragma unroll
-    for (int j = 0; j < 8; j++) f.v[j] = t[(8 * h + j) * 128 + col];
+    for (int j = 0; j < 8; j++) f.v[j] = t[(8 * h + j) * COLS + col];
     return f;
   }
 };
-template <> __device__ inline Frag<bf16> DmaTr<bf16, 0>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::get(t, c, ks, l); }
-template <> __device__ inline Frag<bf16> DmaTr<bf16, 1>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::get(t, c, ks, l); }
-template <> __device__ inline Frag<bf16> DmaTr<bf16, 2>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::get(t, c, ks, l); }
-template <> __device__ inline Frag<float> DmaTr<float, 0>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::getf(t, c, ks, l); }
-template <> __device__ inline Frag<float> DmaTr<float, 1>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::getf(t, c, ks, l); }
-template <> __device__ inline Frag<float> DmaTr<float, 2>::frag(const char* t, int c, int ks, int l) { return DmaTrFrag<0>::getf(t, c, ks, l); }
+template <typename T, int MODE, int COLS> struct DmaTrFragSel;
+template <int MODE, int COLS> struct DmaTrFragSel<bf16, MODE, COLS> {
+  __device__ static Frag<bf16> get(const char* t, int c, int ks, int l) { return DmaTrFrag<COLS>::get(t, c, ks, l); }
+};
+template <int MODE, int COLS> struct DmaTrFragSel<float, MODE, COLS> {
+  __device__ static Frag<float> get(const char* t, int c, int ks, int l) { return DmaTrFrag<COLS>::getf(t, c, ks, l); }
+};
+template <typename T, int MODE, int COLS>
+__device__ inline Frag<T> DmaTr<T, MODE, COLS>::frag(const char* t, int c, int ks, int l) { return DmaTrFragSel<T, MODE, COLS>::get(t, c, ks, l); }
 
-template <typename T, int AL> struct DmaASel;
-template <typename T> struct DmaASel<T, CROG_A_KC> { using type = DmaKc<T, 0>; };
-template <typename T> struct DmaASel<T, CROG_A_IM2COL> { using type = DmaKc<T, 1>; };
-template <typename T> struct DmaASel<T, CROG_A_MC> { using type = DmaTr<T, 0>; };
-template <typename T, int BL> struct DmaBSel;
-template <typename T> struct DmaBSel<T, CROG_B_KC> { using type = DmaKc<T, 0>; };
-template <typename T> struct DmaBSel<T, CROG_B_NC> { using type = DmaTr<T, 0>; };
-template <typename T> struct DmaBSel<T, CROG_B_NC_DGRAD> { using type = DmaTr<T, 1>; };
-template <typename T> struct DmaBSel<T, CROG_B_NC_IM2COL> { using type = DmaTr<T, 2>; };
+template <typename T, int AL, int EDGE> struct DmaASel;
+template <typename T, int E> struct DmaASel<T, CROG_A_KC, E> { using type = DmaKc<T, 0>; };
+template <typename T, int E> struct DmaASel<T, CROG_A_IM2COL, E> { using type = DmaKc<T, 1>; };
+template <typename T, int E> struct DmaASel<T, CROG_A_MC, E> { using type = DmaTr<T, 0, E>; };
+template <typename T, int BL, int EDGE> struct DmaBSel;
+template <typename T, int E> struct DmaBSel<T, CROG_B_KC, E> { using type = DmaKc<T, 0>; };
+template <typename T, int E> struct DmaBSel<T, CROG_B_NC, E> { using type = DmaTr<T, 0, E>; };
+template <typename T, int E> struct DmaBSel<T, CROG_B_NC_DGRAD, E> { using type = DmaTr<T, 1, E>; };
+template <typename T, int E> struct DmaBSel<T, CROG_B_NC_IM2COL, E> { using type = DmaTr<T, 2, E>; };
 
 // Issue the LDS-DMA loads of one k-tile into ring stage `stage` (2 A + 2 B wave-instructions of 1 KiB per wave).
 // A plain __device__ function on purpose: a lambda here makes hipcc's HOST pass drop the kernel stub silently.
-template <typename OA, typename OB>
+template <int TILE_B, typename OA, typename OB>
 __device__ inline void dma_issue(const OA& da, const OB& db, const ConvGeom& g, char* smem, int wave, int kt, int kmem, int stage) {
   typedef __attribute__((address_space(3))) void lds_void;
-  char* sa = smem + stage * DMA_STAGE_B + wave * 2 * 1024;
-  char* sb = sa + DMA_TILE_B;
+  char* sa = smem + stage * 2 * TILE_B + wave * 2 * 1024;
+  char* sb = sa + TILE_B;
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     const unsigned oa = da.off(i, kt, kmem, g), ob = db.off(i, kt, kmem, g);
@@ -697,17 +722,20 @@ __device__ inline void dma_issue(const OA& da, const OB& db, const ConvGeom& g, 
   }
 }
 
-template <typename T, int AL, int BL>
-__global__ void __launch_bounds__(256, 3) gemm_dma_kernel(const crog_gemm_desc p) {
-  using S = ShapeMid;
-  using OA = typename DmaASel<T, AL>::type;
-  using OB = typename DmaBSel<T, BL>::type;
-  constexpr int BK = TileCfg<T>::BK, BM = S::BM, BN = S::BN;
+using ShapeDma8 = Shape<4, 2, 2, 4>;   // 256 x 256, 8 waves, 128 accumulator registers per lane
+
+template <typename T, int AL, int BL, typename S>
+__global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 2 : 3)) gemm_dma_kernel(const crog_gemm_desc p) {
+  static_assert(S::BM == S::BN && S::BM == 32 * (S::NT / 64), "DMA tiles are (32 * waves)^2: every wave issues 2+2 KiB per k-tile");
+  using OA = typename DmaASel<T, AL, S::BM>::type;
+  using OB = typename DmaBSel<T, BL, S::BN>::type;
+  constexpr int BK = TileCfg<T>::BK, BM = S::BM, BN = S::BN, WM = S::WM, WN = S::WN;
+  constexpr int DMA_TILE_B = BM * 64, DMA_STAGE_B = 2 * DMA_TILE_B;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / S::WVN, wc = wave % S::WVN;
 
   const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
   const int nwg = tilesM * tilesN;
@@ -738,37 +766,47 @@ __global__ void __launch_bounds__(256, 3) gemm_dma_kernel(const crog_gemm_desc p
   da.init(A, p.lda, p.M, p.K, m0, wave, lane, g);
   db.init(B, p.ldb, p.N, p.K, n0, wave, lane, g);
 
-  f32x16 acc[2][2];
+  f32x16 acc[WM][WN];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < WM; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < WN; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
   // channel-chunk-major, tap-minor reduction order for the 3x3 forward / data-gradient forms (see gemm_kernel)
-#define CROG_KMEM(kt) ((AL == CROG_A_IM2COL) ? (((kt) % 9) * p.convC + ((kt) / 9) * BK) : (kt) * BK)
-  dma_issue(da, db, g, smem, wave, kt0, CROG_KMEM(kt0), 0);
-  if (nt > 1) dma_issue(da, db, g, smem, wave, kt0 + 1, CROG_KMEM(kt0 + 1), 1);
+  auto kmem_of = [&](int kt) -> int {   // no builtins inside: safe for the host pass (see dma_issue)
+    if constexpr (AL == CROG_A_IM2COL) {
+      int tap, chunk;
+      conv_ktile(kt, p.convC / BK, tap, chunk);
+      return tap * p.convC + chunk * BK;
+    } else {
+      return kt * BK;
+    }
+  };
+#define CROG_KMEM(kt) kmem_of(kt)
+  dma_issue<DMA_TILE_B>(da, db, g, smem, wave, kt0, CROG_KMEM(kt0), 0);
+  if (nt > 1) dma_issue<DMA_TILE_B>(da, db, g, smem, wave, kt0 + 1, CROG_KMEM(kt0 + 1), 1);
   int stage = 0;
   for (int t = 0; t < nt; t++) {
     if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < nt) dma_issue(da, db, g, smem, wave, kt0 + t + 2, CROG_KMEM(kt0 + t + 2), stage >= 1 ? stage - 1 : 2);
+    if (t + 2 < nt && !(p.debug & 1)) dma_issue<DMA_TILE_B>(da, db, g, smem, wave, kt0 + t + 2, CROG_KMEM(kt0 + t + 2), stage >= 1 ? stage - 1 : 2);
     const char* at = smem + stage * DMA_STAGE_B;
     const char* bt = at + DMA_TILE_B;
+    if (!(p.debug & 2))
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
-      Frag<T> fa[2], fb[2];
+      Frag<T> fa[WM], fb[WN];
 #pragma unroll
-      for (int i = 0; i < 2; i++) fa[i] = OA::frag(at, wr * 64 + i * 32, ks, lane);
+      for (int i = 0; i < WM; i++) fa[i] = OA::frag(at, (wr * WM + i) * 32, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 2; j++) fb[j] = OB::frag(bt, wc * 64 + j * 32, ks, lane);
+      for (int j = 0; j < WN; j++) fb[j] = OB::frag(bt, (wc * WN + j) * 32, ks, lane);
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int i = 0; i < WM; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) mma16(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < WN; j++) mma16(fa[i], fb[j], acc[i][j]);
     }
     stage = stage == 2 ? 0 : stage + 1;
   }
@@ -777,11 +815,11 @@ __global__ void __launch_bounds__(256, 3) gemm_dma_kernel(const crog_gemm_desc p
   gemm_epilogue<T, S>(acc, p, smem, m0, n0, zs, coff);
 }
 
-template <typename T, int AL, int BL>
+template <typename T, int AL, int BL, typename S>
 int launch_dma(const crog_gemm_desc& d, hipStream_t s) {
-  constexpr int LDS = DMA_NSTAGE * DMA_STAGE_B;
+  constexpr int LDS = DMA_NSTAGE * 2 * S::BM * 64;
   static bool attr_set = false;
-  auto kern = gemm_dma_kernel<T, AL, BL>;
+  auto kern = gemm_dma_kernel<T, AL, BL, S>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
@@ -790,24 +828,39 @@ int launch_dma(const crog_gemm_desc& d, hipStream_t s) {
     }
     attr_set = true;
   }
-  dim3 grid(cdiv(d.M, 128) * cdiv(d.N, 128), d.batch * d.splitk, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, d);
+  dim3 grid(cdiv(d.M, S::BM) * cdiv(d.N, S::BN), d.batch * d.splitk, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(S::NT), LDS, s, d);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
 
-template <typename T>
+template <typename T, typename S>
 int dispatch_dma(const crog_gemm_desc& d, hipStream_t s) {
   const int a = d.a_layout, b = d.b_layout;
-  if (a == CROG_A_KC && b == CROG_B_KC) return launch_dma<T, CROG_A_KC, CROG_B_KC>(d, s);
-  if (a == CROG_A_IM2COL && b == CROG_B_KC) return launch_dma<T, CROG_A_IM2COL, CROG_B_KC>(d, s);
-  if (a == CROG_A_KC && b == CROG_B_NC) return launch_dma<T, CROG_A_KC, CROG_B_NC>(d, s);
-  if (a == CROG_A_IM2COL && b == CROG_B_NC_DGRAD) return launch_dma<T, CROG_A_IM2COL, CROG_B_NC_DGRAD>(d, s);
-  if (a == CROG_A_MC && b == CROG_B_NC) return launch_dma<T, CROG_A_MC, CROG_B_NC>(d, s);
-  if (a == CROG_A_MC && b == CROG_B_NC_IM2COL) return launch_dma<T, CROG_A_MC, CROG_B_NC_IM2COL>(d, s);
-  if (a == CROG_A_MC && b == CROG_B_KC) return launch_dma<T, CROG_A_MC, CROG_B_KC>(d, s);
+  if (a == CROG_A_KC && b == CROG_B_KC) return launch_dma<T, CROG_A_KC, CROG_B_KC, S>(d, s);
+  if (a == CROG_A_IM2COL && b == CROG_B_KC) return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, S>(d, s);
+  if (a == CROG_A_KC && b == CROG_B_NC) return launch_dma<T, CROG_A_KC, CROG_B_NC, S>(d, s);
+  if (a == CROG_A_IM2COL && b == CROG_B_NC_DGRAD) return launch_dma<T, CROG_A_IM2COL, CROG_B_NC_DGRAD, S>(d, s);
+  if (a == CROG_A_MC && b == CROG_B_NC) return launch_dma<T, CROG_A_MC, CROG_B_NC, S>(d, s);
+  if (a == CROG_A_MC && b == CROG_B_NC_IM2COL) return launch_dma<T, CROG_A_MC, CROG_B_NC_IM2COL, S>(d, s);
+  if (a == CROG_A_MC && b == CROG_B_KC) return launch_dma<T, CROG_A_MC, CROG_B_KC, S>(d, s);
   crog_set_error("crog_gemm: unsupported layout combination a=%d b=%d", a, b);
   return CROG_ERR_ARG;
+}
+
+// 256x256 DMA tile when the problem still fills the chip and wastes no more of the tile on padding than 128x128 does
+bool dma_prefers_256(const crog_gemm_desc& d) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("CROG_GEMM_DMA256");
+    forced = e ? (e[0] == '1' ? 1 : (e[0] == 'a' ? 2 : 0)) : 0;   // default off: measured no gain on CROG's conv shapes (N = 256/512)
+  }
+  if (forced != 2) return forced == 1;
+  const long zb = (long)d.batch * d.splitk;
+  const long big = (long)cdiv(d.M, 256) * cdiv(d.N, 256) * zb;
+  const double eff_big = (double)d.M * d.N / ((double)cdiv(d.M, 256) * 256 * cdiv(d.N, 256) * 256);
+  const double eff_mid = (double)d.M * d.N / ((double)cdiv(d.M, 128) * 128 * cdiv(d.N, 128) * 128);
+  return big >= 224 && eff_big >= 0.9 * eff_mid;
 }
 
 bool dma_enabled() {
@@ -922,7 +975,7 @@ int pick_shape(const crog_gemm_desc& d) {
 template <typename T, bool HWTR>
 int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
   const int shape = pick_shape(d);
-  if (shape == 2 && dma_eligible(d)) return dispatch_dma<T>(d, s);
+  if (shape == 2 && dma_eligible(d)) return dma_prefers_256(d) ? dispatch_dma<T, ShapeDma8>(d, s) : dispatch_dma<T, ShapeMid>(d, s);
   switch (shape) {
     case 3: return dispatch_layout<T, HWTR, ShapeBig>(d, s);
     case 1: return dispatch_layout<T, HWTR, ShapeSmall>(d, s);

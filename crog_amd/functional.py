@@ -201,7 +201,7 @@ class ConvBnAct(Function):
                 K.bn_partial_stats(z, stats, rpb)
             sums = torch.empty(C, 2, device=dev, dtype=torch.float32)
             K.reduce_pairs(stats, stats.shape[0], C, sums)
-            if RT.comm is not None and RT.comm.world_size > 1:
+            if RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force):
                 RT.comm.all_reduce_sum(sums)
                 count = float(M * RT.comm.world_size)
             mi = torch.empty(C, 2, device=dev, dtype=torch.float32)
@@ -240,7 +240,7 @@ class ConvBnAct(Function):
         K.split_pairs(sums, C, bn.beta.grad(), bn.gamma.grad())  # local sums: (sum g -> dbeta, sum g*xhat -> dgamma)
         bn.beta.done()
         bn.gamma.done()
-        if RT.comm is not None and RT.comm.world_size > 1:
+        if RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force):
             RT.comm.all_reduce_sum(sums)
         dz = torch.empty(lead + (C,), device=dev, dtype=dtype)
         dres = torch.empty(lead + (C,), device=dev, dtype=dtype) if ctx.has_res else None

@@ -23,6 +23,7 @@ OUT_T, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 
 # Optional per-launch timing of ONE GEMM variant (bench.py's roofline leg): {"key": (a_layout, b_layout), "records": []}
 PROF = None
+DEBUG_FLAGS = 0  # timing-only ablation bits of crog_gemm_desc.debug (scripts/ablate_gemm.py); 0 in production
 GEMM_SYMBOL = {
     (A_KC, B_KC): "gemm_kernel<T, A_KC, B_KC>  (1x1 conv / linear forward, Q.K^T)",
     (A_IM2COL, B_KC): "gemm_kernel<T, A_IM2COL, B_KC>  (3x3 conv forward, implicit GEMM)",
@@ -125,6 +126,7 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
     d.ldr = int(ldr)
     d.out_mode = int(out_mode)
     d.col_stats = ptr(col_stats)
+    d.debug = DEBUG_FLAGS
     if PROF is not None and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

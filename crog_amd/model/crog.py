@@ -89,6 +89,8 @@ class CROG(nn.Module):
         self.compute_dtype = None
         self._store = None
         self._bns = None
+        self.overlap_text = True
+        self._side = None
         self.explicit_grad_ready = True  # kernels write gradients in place and call RT.reducer.mark_ready themselves
 
     @staticmethod
@@ -154,8 +156,25 @@ class CROG(nn.Module):
             store.zero_grad()
         with torch.autocast("cuda", enabled=False):
             pad_mask = (word == 0).contiguous()
-            vis = self.backbone.image_features(img, dtype)
-            wfeat, state = self.backbone.text_features(word, dtype)
+            # The text tower (640 token rows: ~100 latency-bound launches) is independent of the image tower until the
+            # neck, so it runs on a second HIP stream and overlaps the 208x208 / 104x104 convolutions; autograd replays each
+            # node on its forward stream, which overlaps the two backward passes the same way.
+            main = torch.cuda.current_stream()
+            store.weights(dtype)               # refresh the bf16 shadow on the main stream BEFORE the streams fork
+            if self.overlap_text:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                RT.streams = [main, self._side]
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    wfeat, state = self.backbone.text_features(word, dtype)
+                vis = self.backbone.image_features(img, dtype)
+                main.wait_stream(self._side)
+                wfeat.record_stream(main)
+                state.record_stream(main)
+            else:
+                vis = self.backbone.image_features(img, dtype)
+                wfeat, state = self.backbone.text_features(word, dtype)
             fq = self.neck(vis, state)
             if self.use_contrastive:
                 fq = self.decoder(fq, wfeat, pad_mask)

@@ -25,15 +25,18 @@ class SyncBNComm:
     def __init__(self, group=None):
         self.group = group
         self.world_size = dist.get_world_size(group)
+        self.force = False
 
     def all_reduce_sum(self, t: torch.Tensor):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
 
-def convert_sync_batchnorm(model, process_group=None):
-    """nn.SyncBatchNorm.convert_sync_batchnorm equivalent: BatchNorm statistics of the HIP path become cross-replica."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+def convert_sync_batchnorm(model, process_group=None, force=False):
+    """nn.SyncBatchNorm.convert_sync_batchnorm equivalent: BatchNorm statistics of the HIP path become cross-replica.
+    `force` installs the communicator even at world_size 1 (single-GPU smoke test of the collective path)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force):
         RT.comm = SyncBNComm(process_group)
+        RT.comm.force = force
     return model
 
 
@@ -77,6 +80,13 @@ class Reducer:
         if b["launched"]:
             return
         b["launched"] = True
+        # a bucket can hold gradients written on different streams (image tower: main, text tower: side stream):
+        # make the launching stream wait for the others before RCCL's stream takes its dependency on it
+        if self.G.is_cuda:
+            cur = torch.cuda.current_stream()
+            for s in RT.streams:
+                if s != cur:
+                    cur.wait_stream(s)
         view = self.G[b["start"]:b["start"] + b["numel"]]
         op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
         b["work"] = dist.all_reduce(view, op=op, group=self.group, async_op=True)
@@ -115,9 +125,10 @@ class DistributedDataParallel(torch.nn.Module):
     as used at train_crog.py:154-156, for crog_amd models (or any module whose parameters live in a ParamStore)."""
 
     def __init__(self, module, device_ids=None, find_unused_parameters=False, process_group=None, bucket_cap_mb: float = 64.0,
-                 broadcast_buffers: bool = True):
+                 broadcast_buffers: bool = True, force: bool = False):
         super().__init__()
         self.module = module
+        self.force = force
         self.process_group = process_group
         self.bucket_cap_mb = bucket_cap_mb
         self.reducer: Optional[Reducer] = None
@@ -129,7 +140,7 @@ class DistributedDataParallel(torch.nn.Module):
 
     def _sync_initial_state(self):
         """DDP broadcasts rank 0's parameters and buffers at construction."""
-        if dist.get_world_size(self.process_group) == 1:
+        if dist.get_world_size(self.process_group) == 1 and not self.force:
             return
         store = getattr(self.module, "store", None)
         if store is not None:
@@ -155,7 +166,7 @@ class DistributedDataParallel(torch.nn.Module):
         out_is_training = self.module.training and torch.is_grad_enabled()
         if hasattr(self.module, "_ensure") and args:
             self.module._ensure(args[0].device)
-        if out_is_training and dist.get_world_size(self.process_group) > 1:
+        if out_is_training and (dist.get_world_size(self.process_group) > 1 or self.force):
             self._ensure_reducer()
             self.reducer.reset()
             RT.reducer = self.reducer

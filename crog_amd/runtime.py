@@ -23,6 +23,7 @@ class Runtime:
     def __init__(self):
         self.comm = None       # object with .world_size and .all_reduce_sum(tensor) for SyncBatchNorm
         self.reducer = None    # gradient reducer (crog_amd.parallel); .mark_ready(param)
+        self.streams = []      # HIP streams the model's kernels run on (main + text-tower side stream)
         self.seed_base = 0x5EED
         self._seed_ctr = 0
 
