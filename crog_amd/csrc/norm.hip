@@ -75,6 +75,67 @@ __global__ void __launch_bounds__(NT) reduce_pairs_kernel(const float* __restric
   if (lane_p == 0 && col < 2 * C) atomicAdd(sums + col, red[0][f] + red[1][f] + red[2][f] + red[3][f]);
 }
 
+// Single-launch reductions of a partial slab [nparts][C][2] (no atomics, no memset): block = 8 channels (16 floats,
+// one 64-byte segment per slab row) x 16 part lanes, LDS tree over the lanes, then the per-channel tail runs in-block.
+__device__ inline void reduce_slab_16(const float* __restrict__ partial, int nparts, int C, float (&red)[16][17], float& out) {
+  const int f = threadIdx.x & 15, lane_p = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + f;
+  float acc = 0.f;
+  if (col < 2 * C)
+    for (int p = lane_p; p < nparts; p += 16) acc += partial[(long)p * 2 * C + col];
+  red[lane_p][f] = acc;
+  __syncthreads();
+  out = 0.f;
+  if (lane_p == 0) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) out += red[q][f];
+    red[0][f] = out;
+  }
+  __syncthreads();
+}
+// BN forward (single replica): slab -> sums -> scale/shift, mean/invstd, running statistics
+__global__ void __launch_bounds__(NT) bn_reduce_finalize_kernel(const float* __restrict__ partial, int nparts, float count,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                                                float eps, int C, float* __restrict__ scale_shift, float* __restrict__ mean_invstd) {
+  __shared__ float red[16][17];
+  float dummy;
+  reduce_slab_16(partial, nparts, C, red, dummy);
+  const int t = threadIdx.x;
+  const int c = blockIdx.x * 8 + t;
+  if (t < 8 && c < C) {
+    const float mean = red[0][2 * t] / count;
+    float var = red[0][2 * t + 1] / count - mean * mean;
+    var = fmaxf(var, 0.f);
+    const float invstd = rsqrtf(var + eps);
+    const float sc = gamma[c] * invstd;
+    scale_shift[2 * c] = sc;
+    scale_shift[2 * c + 1] = beta[c] - mean * sc;
+    mean_invstd[2 * c] = mean;
+    mean_invstd[2 * c + 1] = invstd;
+    if (running_mean) {
+      const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+  }
+}
+// backward-side: slab -> sums[C][2] (optional) and the two per-channel vectors a[c] = sum of .x, b[c] = sum of .y
+__global__ void __launch_bounds__(NT) reduce_split_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ sums,
+                                                          float* __restrict__ a, float* __restrict__ b) {
+  __shared__ float red[16][17];
+  float dummy;
+  reduce_slab_16(partial, nparts, C, red, dummy);
+  const int t = threadIdx.x;
+  const int col = blockIdx.x * 16 + t;
+  if (t < 16 && col < 2 * C) {
+    const float v = red[0][t];
+    if (sums) sums[col] = v;
+    if (col & 1) { if (b) b[col >> 1] = v; }
+    else { if (a) a[col >> 1] = v; }
+  }
+}
+
 // Finalize training-mode BN from (global) sums: scale/shift for the apply pass, mean/invstd for
 // backward, running-stat update with momentum (torch semantics: unbiased var in running_var).
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, const float* __restrict__ gamma,
@@ -140,7 +201,8 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ z, l
 template <typename T>
 __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
                                                             const T* __restrict__ z, long ldz, const float* __restrict__ mean_invstd,
-                                                            long M, int C, int rows_per_block, float* __restrict__ partial) {
+                                                            const float* __restrict__ relu_ss, long M, int C, int rows_per_block,
+                                                            float* __restrict__ partial) {
   constexpr int VEC = Elem<T>::VEC;
   __shared__ float red[NT][2 * VEC + 1];
   const int cvec = C / VEC;
@@ -150,12 +212,14 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
   const long r1 = min(r0 + rows_per_block, M);
   for (int cg = 0; cg < cvec; cg += cw) {
     const int c = (cg + tx) * VEC;
-    float s1[VEC], s2[VEC], mu[VEC], is[VEC];
+    float s1[VEC], s2[VEC], mu[VEC], is[VEC], rsc[VEC], rsh[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; e++) {
       s1[e] = s2[e] = 0.f;
       mu[e] = mean_invstd[2 * (c + e)];
       is[e] = mean_invstd[2 * (c + e) + 1];
+      rsc[e] = relu_ss ? relu_ss[2 * (c + e)] : 0.f;
+      rsh[e] = relu_ss ? relu_ss[2 * (c + e) + 1] : 0.f;
     }
     for (long r = r0 + ty; r < r1; r += nty) {
       Vec16<T> g = ldg16(dy + r * lddy + c);
@@ -165,8 +229,10 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
 #pragma unroll
       for (int e = 0; e < VEC; e++) {
         float gf = Elem<T>::to_f(g.v[e]);
+        const float zf = Elem<T>::to_f(zz.v[e]);
         if (y && !(Elem<T>::to_f(yy.v[e]) > 0.f)) gf = 0.f;
-        const float zh = (Elem<T>::to_f(zz.v[e]) - mu[e]) * is[e];
+        if (relu_ss && !(zf * rsc[e] + rsh[e] > 0.f)) gf = 0.f;   // ReLU mask recomputed from z (no residual): y is not read
+        const float zh = (zf - mu[e]) * is[e];
         s1[e] += gf;
         s2[e] += gf * zh;
       }
@@ -208,7 +274,8 @@ template <typename T>
 __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
                                                           const T* __restrict__ z, long ldz, const float* __restrict__ mean_invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ sums, float count,
-                                                          T* __restrict__ dz, long lddz, T* __restrict__ dres, long lddres, long M, int C) {
+                                                          const float* __restrict__ relu_ss, T* __restrict__ dz, long lddz, T* __restrict__ dres,
+                                                          long lddres, long M, int C) {
   constexpr int VEC = Elem<T>::VEC;
   const int cvec = C / VEC;
   const long total = M * cvec;
@@ -224,9 +291,11 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
 #pragma unroll
     for (int e = 0; e < VEC; e++) {
       float gf = Elem<T>::to_f(g.v[e]);
+      const float zf = Elem<T>::to_f(zz.v[e]);
       if (y && !(Elem<T>::to_f(yy.v[e]) > 0.f)) gf = 0.f;
+      if (relu_ss && !(zf * relu_ss[2 * (c + e)] + relu_ss[2 * (c + e) + 1] > 0.f)) gf = 0.f;
       const float mu = mean_invstd[2 * (c + e)], is = mean_invstd[2 * (c + e) + 1];
-      const float zh = (Elem<T>::to_f(zz.v[e]) - mu) * is;
+      const float zh = (zf - mu) * is;
       const float d = gamma[c + e] * is * (gf - sums[2 * (c + e)] * inv_count - zh * sums[2 * (c + e) + 1] * inv_count);
       o.v[e] = Elem<T>::from_f(d);
       gr.v[e] = Elem<T>::from_f(gf);
@@ -584,26 +653,27 @@ extern "C" int crog_bn_apply(int dtype, const void* z, int64_t ldz, const float*
 }
 
 extern "C" int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
-                                   const float* mean_invstd, int64_t M, int C, int rows_per_block, float* partial,
-                                   crog_stream_t stream) {
+                                   const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C, int rows_per_block,
+                                   float* partial, crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0 && pow2(C / vec), "bn_bwd_partial: C/vec must be a power of two (C=%d)", C);
   const int blocks = cdiv(M, rows_per_block);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dy,
-                                       (long)lddy, (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, (long)M, C,
+                                       (long)lddy, (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, relu_scale_shift, (long)M, C,
                                        rows_per_block, partial));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
 
 extern "C" int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
-                                 const float* mean_invstd, const float* gamma, const float* sums, float count, void* dz,
-                                 int64_t lddz, void* dres, int64_t lddres, int64_t M, int C, crog_stream_t stream) {
+                                 const float* mean_invstd, const float* gamma, const float* sums, float count,
+                                 const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres, int64_t M, int C,
+                                 crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0, "bn_bwd_apply: C %% %d != 0", vec);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(stream_grid(M * (C / vec))), dim3(NT), 0,
                                        (hipStream_t)stream, (const T*)dy, (long)lddy, (const T*)y, (long)ldy, (const T*)z,
-                                       (long)ldz, mean_invstd, gamma, sums, count, (T*)dz, (long)lddz, (T*)dres, (long)lddres,
+                                       (long)ldz, mean_invstd, gamma, sums, count, relu_scale_shift, (T*)dz, (long)lddz, (T*)dres, (long)lddres,
                                        (long)M, C));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
@@ -652,6 +722,23 @@ extern "C" int crog_softmax_bwd(int dtype, const void* P, void* dPd, int64_t row
   CROG_CHECK_ARG(Lk > 0 && Lk <= ldp && ldp <= 768, "softmax_bwd: need Lk <= ldp <= 768");
   DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_bwd_kernel<T>), dim3(cdiv(rows, NT / 64)), dim3(NT), 0, (hipStream_t)stream,
                                        (const T*)P, (T*)dPd, (long)rows, Lk, ldp, p_drop, seed));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_bn_reduce_finalize(const float* partial, int nparts, float count, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, float momentum, float eps, int C, float* scale_shift,
+                                       float* mean_invstd, crog_stream_t stream) {
+  CROG_CHECK_ARG(nparts > 0 && C > 0 && count > 0, "bn_reduce_finalize: bad sizes");
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(C, 8)), dim3(NT), 0, (hipStream_t)stream, partial, nparts, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, C, scale_shift, mean_invstd);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_reduce_split(const float* partial, int nparts, int C, float* sums, float* a, float* b, crog_stream_t stream) {
+  CROG_CHECK_ARG(nparts > 0 && C > 0, "reduce_split: bad sizes");
+  hipLaunchKernelGGL(reduce_split_kernel, dim3(cdiv(C, 8)), dim3(NT), 0, (hipStream_t)stream, partial, nparts, C, sums, a, b);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -39,6 +39,10 @@ def _pad(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
+import os as _os
+FUSED_REDUCE_MAX_PARTS = int(_os.environ.get("CROG_FUSED_REDUCE_MAX_PARTS", "256"))
+
+
 class OutRef:
     """Hides a preallocated destination view (a channel slice of a concat buffer) from autograd's argument scan."""
 
@@ -199,19 +203,27 @@ class ConvBnAct(Function):
                 nparts = (M + rpb - 1) // rpb
                 stats = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
                 K.bn_partial_stats(z, stats, rpb)
-            sums = torch.empty(C, 2, device=dev, dtype=torch.float32)
-            K.reduce_pairs(stats, stats.shape[0], C, sums)
+            mi = torch.empty(C, 2, device=dev, dtype=torch.float32)
             if RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force):
+                sums = torch.empty(C, 2, device=dev, dtype=torch.float32)
+                K.reduce_pairs(stats, stats.shape[0], C, sums)
                 RT.comm.all_reduce_sum(sums)
                 count = float(M * RT.comm.world_size)
-            mi = torch.empty(C, 2, device=dev, dtype=torch.float32)
-            K.bn_finalize(sums, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum, bn.eps, C, ss, mi)
+                K.bn_finalize(sums, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum, bn.eps, C, ss, mi)
+            elif stats.shape[0] <= FUSED_REDUCE_MAX_PARTS:   # single replica, short slab: statistics -> scale/shift in one launch
+                K.bn_reduce_finalize(stats, stats.shape[0], count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var,
+                                     bn.momentum, bn.eps, C, ss, mi)
+            else:                                            # long slab (>= 100k rows): split reduction across blocks first
+                sums = torch.empty(C, 2, device=dev, dtype=torch.float32)
+                K.reduce_pairs(stats, stats.shape[0], C, sums)
+                K.bn_finalize(sums, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum, bn.eps, C, ss, mi)
         else:
             K.bn_eval_scale(bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.eps, C, ss)
         y = _dest(out) if out is not None else torch.empty(lead + (C,), device=dev, dtype=dtype)
         K.bn_apply(z, ss, res, relu, y)
         ctx.cfg = (ksize, relu, training, w, bn, wpad, count, cin, C, lead, dtype)
         ctx.has_res = res is not None
+        ctx.relu_ss = ss if (relu and res is None and training) else None   # ReLU mask can be recomputed from z: y is not re-read in backward
         ctx.x_needs = ksize != "s" and x.requires_grad
         ctx.wt = (wt, wbuf_off) if wpad is not None else None
         if ksize == "s":
@@ -233,18 +245,23 @@ class ConvBnAct(Function):
         rpb = K.bn_rows_per_block(M)
         nparts = (M + rpb - 1) // rpb
         partial = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
-        ymask = y if relu else None
-        K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial)
+        relu_ss = ctx.relu_ss
+        ymask = y if (relu and relu_ss is None) else None
+        K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial, relu_ss)
         sums = torch.empty(C, 2, device=dev, dtype=torch.float32)
-        K.reduce_pairs(partial, nparts, C, sums)
-        K.split_pairs(sums, C, bn.beta.grad(), bn.gamma.grad())  # local sums: (sum g -> dbeta, sum g*xhat -> dgamma)
+        # local sums: (sum g -> dbeta, sum g*xhat -> dgamma) and the pair vector for the second pass
+        if nparts <= FUSED_REDUCE_MAX_PARTS:
+            K.reduce_split(partial, nparts, C, sums, bn.beta.grad(), bn.gamma.grad())
+        else:
+            K.reduce_pairs(partial, nparts, C, sums)
+            K.split_pairs(sums, C, bn.beta.grad(), bn.gamma.grad())
         bn.beta.done()
         bn.gamma.done()
         if RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force):
             RT.comm.all_reduce_sum(sums)
         dz = torch.empty(lead + (C,), device=dev, dtype=dtype)
         dres = torch.empty(lead + (C,), device=dev, dtype=dtype) if ctx.has_res else None
-        K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres)
+        K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss)
         dx = None
         if ksize == 0:
             dx = dz
@@ -258,25 +275,27 @@ class ConvBnAct(Function):
             else:
                 wt, woff, wcols = w.w(dtype), w.off, w.cols
                 gt, goff = w.G, w.off
-            if ksize == "s":
-                sk = K.pick_splitk(C, 32, M, _bk(dt))
-                K.gemm(dt, K.A_MC, K.B_NC, dz, x, gt, C, 32, M, C, 32, 32, c_off=goff, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
-            elif ksize == 1:
-                sk = K.pick_splitk(C, cin, M, _bk(dt))
-                K.gemm(dt, K.A_MC, K.B_NC, dz, x, gt, C, cin, M, C, K.mat(x)[2], wcols, c_off=goff, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
-                if ctx.x_needs:
-                    dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
-                    K.gemm(dt, K.A_KC, K.B_NC, dz, wt, dx, M, cin, C, C, wcols, cin, b_off=woff)
-            else:
+            def wgrad():
+                if ksize == "s":
+                    sk = K.pick_splitk(C, 32, M, _bk(dt))
+                    K.gemm(dt, K.A_MC, K.B_NC, dz, x, gt, C, 32, M, C, 32, 32, c_off=goff, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+                elif ksize == 1:
+                    sk = K.pick_splitk(C, cin, M, _bk(dt))
+                    K.gemm(dt, K.A_MC, K.B_NC, dz, x, gt, C, cin, M, C, K.mat(x)[2], wcols, c_off=goff, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+                else:
+                    sk = K.pick_splitk(C, 9 * cin, M, _bk(dt))
+                    K.gemm(dt, K.A_MC, K.B_NC_IM2COL, dz, x, gt, C, 9 * cin, M, C, K.mat(x)[2], wcols, c_off=goff, conv=(lead[1], lead[2], cin),
+                           splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+                if wpad is not None:  # strip the zero padding back out into the real gradient
+                    K.cast_pad2d(gscratch, dst_cols, dst_cols, w.G, src_cols, src_cols, rows, dst_off=w.off)
+            RT.on_wgrad_stream(wgrad, dz, x, gt if wpad is not None else None)
+            if ksize == 1 and ctx.x_needs:
+                dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
+                K.gemm(dt, K.A_KC, K.B_NC, dz, wt, dx, M, cin, C, C, wcols, cin, b_off=woff)
+            elif ksize == 3 and ctx.x_needs:
                 B, H, W = lead
-                sk = K.pick_splitk(C, 9 * cin, M, _bk(dt))
-                K.gemm(dt, K.A_MC, K.B_NC_IM2COL, dz, x, gt, C, 9 * cin, M, C, K.mat(x)[2], wcols, c_off=goff, conv=(H, W, cin), splitk=sk,
-                       out_mode=K.OUT_F32_ATOMIC)
-                if ctx.x_needs:
-                    dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
-                    K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, dz, wt, dx, M, cin, 9 * C, C, cin, cin, b_off=woff, conv=(H, W, C))
-            if wpad is not None:  # strip the zero padding back out into the real gradient
-                K.cast_pad2d(gscratch, dst_cols, dst_cols, w.G, src_cols, src_cols, rows, dst_off=w.off)
+                dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
+                K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, dz, wt, dx, M, cin, 9 * C, C, cin, cin, b_off=woff, conv=(H, W, C))
             w.done()
         return (dx, dres) + (None,) * 11
 
@@ -315,10 +334,16 @@ class LinearFn(Function):
                 raise NotImplementedError("relu + residual epilogue backward")
             g = torch.empty(dy.shape, device=dy.device, dtype=dy.dtype)
             K.act_bwd(dy, y, g, 0)
-        lin_wgrad(g, x, w)
+        def wgrad():
+            lin_wgrad(g, x, w)
+            if b is not None:
+                bias_grad(g, b)
+        if has_res and g is dy:
+            wgrad()   # dy is handed on as the residual's gradient and autograd may accumulate into it IN PLACE: keep the read ordered
+        else:
+            RT.on_wgrad_stream(wgrad, g, x)
         w.done()
         if b is not None:
-            bias_grad(g, b)
             b.done()
         dx = None
         if ctx.needs_input_grad[0]:
@@ -393,9 +418,7 @@ class LayerNormFn(Function):
         nb = (M + rpb - 1) // rpb
         partial = torch.empty(nb, C, 2, device=x.device, dtype=torch.float32)
         K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, partial, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out)
-        sums = torch.empty(C, 2, device=x.device, dtype=torch.float32)
-        K.reduce_pairs(partial, nb, C, sums)
-        K.split_pairs(sums, C, gamma.grad(), beta.grad())
+        K.reduce_split(partial, nb, C, None, gamma.grad(), beta.grad())
         gamma.done()
         beta.done()
         dres = None
@@ -486,10 +509,16 @@ class MhaFn(Function):
         dt = K.dcode(dtype)
         dout = K.as_mat(dout)
         # out projection
-        lin_wgrad(dout, O, wo)
+        def wgrad_out():
+            lin_wgrad(dout, O, wo)
+            if bo is not None:
+                bias_grad(dout, bo)
+        if has_res:
+            wgrad_out()   # dout doubles as the residual's gradient (possible in-place accumulation by autograd): stay on this stream
+        else:
+            RT.on_wgrad_stream(wgrad_out, dout, O)
         wo.done()
         if bo is not None:
-            bias_grad(dout, bo)
             bo.done()
         dO = torch.empty(B * Lq, E, device=dev, dtype=dtype)
         lin_dgrad(dout, wo, dO)
@@ -521,11 +550,13 @@ class MhaFn(Function):
         grads = {}
         for x_, w_, b_, (buf, col, ld) in merged:
             dbuf = dqb[0] if buf is qb[0] else dkb[0]
-            M = x_.shape[0]
-            lin_wgrad(dbuf, x_, w_, a_off=col, lda=ld, N=w_.rows)
+            def wgrad_proj(dbuf=dbuf, x_=x_, w_=w_, b_=b_, col=col, ld=ld):
+                lin_wgrad(dbuf, x_, w_, a_off=col, lda=ld, N=w_.rows)
+                if b_ is not None:
+                    bias_grad(dbuf[:, col:col + w_.rows], b_)
+            RT.on_wgrad_stream(wgrad_proj, dbuf, x_)
             w_.done()
             if b_ is not None:
-                bias_grad(dbuf[:, col:col + w_.rows], b_)
                 b_.done()
             prev = grads.get(id(x_))
             dx = prev if prev is not None else torch.empty(x_.shape, device=dev, dtype=dtype)

@@ -152,6 +152,7 @@ class CROG(nn.Module):
         store = self._store
         store.invalidate_shadow()          # parameters may have been stepped since the last forward
         if self.training and torch.is_grad_enabled():
+            RT.join_streams()               # e.g. a previous backward's weight-gradient stream when no fused optimizer joined it
             store.relink_grads()
             store.zero_grad()
         with torch.autocast("cuda", enabled=False):

@@ -66,6 +66,7 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        RT.join_streams()                       # weight-gradient / text-tower side streams must have landed in G
         if RT.reducer is not None:
             RT.reducer.wait()
         if self._segments is None or not self._store.valid():

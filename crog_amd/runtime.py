@@ -10,6 +10,7 @@ the nn.Parameter keeps the reference's logical [Cout,Cin,3,3] shape, so state_di
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -23,9 +24,61 @@ class Runtime:
     def __init__(self):
         self.comm = None       # object with .world_size and .all_reduce_sum(tensor) for SyncBatchNorm
         self.reducer = None    # gradient reducer (crog_amd.parallel); .mark_ready(param)
-        self.streams = []      # HIP streams the model's kernels run on (main + text-tower side stream)
+        self.streams = []      # HIP streams the model's kernels run on (main + text-tower side stream + wgrad stream)
+        self.overlap_wgrad = os.environ.get("CROG_OVERLAP_WGRAD", "1") != "0"
+        self._wgrad_stream = None
+        self._join_armed = False
         self.seed_base = 0x5EED
         self._seed_ctr = 0
+
+    # ---- weight-gradient side stream -----------------------------------------------------------------
+    # Weight gradients are only consumed by the optimizer (or the gradient all-reduce), never by the rest of backward,
+    # so their GEMMs run on a second stream and fill the CUs that the skinny data-gradient / BatchNorm kernels of the
+    # dependency chain leave idle.
+    def wgrad_stream(self):
+        if not self.overlap_wgrad or not torch.cuda.is_available():
+            return None
+        if self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream()
+        if self._wgrad_stream not in self.streams:
+            self.streams.append(self._wgrad_stream)
+        return self._wgrad_stream
+
+    def on_wgrad_stream(self, fn, *tensors):
+        """Run fn() (kernel launches only) on the weight-gradient stream, after everything enqueued so far on the current
+        stream; `tensors` are the operands it reads (kept alive for that stream)."""
+        s = self.wgrad_stream()
+        if s is None:
+            fn()
+            return
+        if not self._join_armed:
+            # at the end of this backward pass the caller's stream waits for the side streams, so that whatever the user
+            # does next with the gradients (any optimizer, .norm(), clipping, ...) is ordered after them
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+                self._join_armed = True
+            except RuntimeError:
+                pass
+        cur = torch.cuda.current_stream()
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(s)
+
+    def _end_of_backward(self):
+        self._join_armed = False
+        self.join_streams()
+
+    def join_streams(self):
+        """Make the current stream wait for every side stream (before the optimizer step / gradient zeroing)."""
+        if not torch.cuda.is_available():
+            return
+        cur = torch.cuda.current_stream()
+        for s in self.streams:
+            if s != cur:
+                cur.wait_stream(s)
 
     def next_seed(self) -> int:
         self._seed_ctr += 1

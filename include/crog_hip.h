@@ -120,14 +120,21 @@ int crog_bn_eval_scale(const float* gamma, const float* beta, const float* runni
 /* y = [relu](z*scale + shift [+ res])  — bn + residual add + ReLU of Bottleneck (clip.py:47-56) */
 int crog_bn_apply(int dtype, const void* z, int64_t ldz, const float* scale_shift, const void* res,
                   int64_t ldr, int relu, void* y, int64_t ldy, int64_t M, int C, crog_stream_t stream);
-/* g = dy * (y > 0) when y != NULL;  partial[block][C][2] = (sum g, sum g*xhat) */
+/* g = dy * mask;  mask = (y > 0) when y != NULL, or (z*scale+shift > 0) when relu_scale_shift != NULL (ReLU without a
+ * residual: the output is not re-read), else 1;  partial[block][C][2] = (sum g, sum g*xhat) */
 int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
-                        int64_t ldz, const float* mean_invstd, int64_t M, int C, int rows_per_block,
-                        float* partial, crog_stream_t stream);
+                        int64_t ldz, const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C,
+                        int rows_per_block, float* partial, crog_stream_t stream);
 /* dz = gamma*invstd*(g - sums.g/count - xhat*sums.gx/count);  dres = g when dres != NULL */
 int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
                       int64_t ldz, const float* mean_invstd, const float* gamma, const float* sums,
-                      float count, void* dz, int64_t lddz, void* dres, int64_t lddres, int64_t M, int C,
+                      float count, const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres,
+                      int64_t M, int C, crog_stream_t stream);
+/* single-replica fast paths: slab [nparts][C][2] -> (reduce + finalize) / (reduce + split into two vectors) in one launch */
+int crog_bn_reduce_finalize(const float* partial, int nparts, float count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, int C,
+                            float* scale_shift, float* mean_invstd, crog_stream_t stream);
+int crog_reduce_split(const float* partial, int nparts, int C, float* sums, float* a, float* b,
                       crog_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -212,9 +212,16 @@ def test_batchnorm_train_fwd_bwd(K, dt):
     mask = (y.float() > 0).float()
     (ref2 * 0 + (F.batch_norm(zt, None, None, g_, b_, True, 0.1, 1e-5) + rt) * mask).backward(dy.float())
     K.bn_bwd_partial(dy, y, z, mi, rpb, partial)
-    K.reduce_pairs(partial, nb, C, sums)
+    dbeta, dgamma = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    K.reduce_split(partial, nb, C, sums, dbeta, dgamma)
+    assert torch.equal(dbeta, sums[:, 0]) and torch.equal(dgamma, sums[:, 1])
     dz, dres = torch.empty_like(z), torch.empty_like(z)
     K.bn_bwd_apply(dy, y, z, mi, gamma, sums, M, dz, dres)
+    # fused single-replica forward statistics == two-step path
+    ss2, mi2 = torch.empty(C, 2, device="cuda"), torch.empty(C, 2, device="cuda")
+    K.bn_partial_stats(z, partial, rpb)
+    K.bn_reduce_finalize(partial, nb, M, gamma, beta, None, None, 0.1, 1e-5, C, ss2, mi2)
+    assert torch.allclose(ss2, ss, rtol=1e-5, atol=1e-6) and torch.allclose(mi2, mi, rtol=1e-5, atol=1e-6)
     close(dz, zt.grad, dt, scale=4)
     close(dres, rt.grad, dt)
     close(sums[:, 0], b_.grad, dt, scale=30)
@@ -507,3 +514,28 @@ def test_colsum(K, dt, M, C):
     K.colsum(x, out, out_off=0)
     close(out[:C], 1.0 + x.float().sum(0), dt, scale=math.sqrt(M))
     assert (out[C:] == 1).all()
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_bn_backward_relu_mask_from_z_equals_mask_from_y(K, dt):
+    M, C = 777, 128
+    z = (rnd(M, C, dt=dt) * 1.5 - 0.2).to(dt)
+    gamma, beta = rnd(C, seed=1), rnd(C, seed=2)          # negative gammas included
+    rpb = 64
+    nb = (M + rpb - 1) // rpb
+    partial = torch.empty(nb, C, 2, device="cuda")
+    K.bn_partial_stats(z, partial, rpb)
+    ss, mi = torch.empty(C, 2, device="cuda"), torch.empty(C, 2, device="cuda")
+    K.bn_reduce_finalize(partial, nb, M, gamma, beta, None, None, 0.1, 1e-5, C, ss, mi)
+    y = torch.empty_like(z)
+    K.bn_apply(z, ss, None, True, y)
+    dy = rnd(M, C, dt=dt, seed=5)
+    outs = []
+    for use_z in (False, True):
+        K.bn_bwd_partial(dy, None if use_z else y, z, mi, rpb, partial, ss if use_z else None)
+        sums = torch.empty(C, 2, device="cuda")
+        K.reduce_split(partial, nb, C, sums, None, None)
+        dz = torch.empty_like(z)
+        K.bn_bwd_apply(dy, None if use_z else y, z, mi, gamma, sums, M, dz, None, ss if use_z else None)
+        outs.append((sums.clone(), dz.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
