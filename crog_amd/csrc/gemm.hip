@@ -408,6 +408,29 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[S::WM][S::WN], const crog_gem
   }
 }
 
+
+// Workgroups are dealt to the 8 XCDs round-robin in launch order (linear id % 8), and every XCD has its own L2.
+//  * plain grid (tiles, batch*splitk): each XCD gets a contiguous run of output tiles, so neighbouring tiles share their
+//    A rows / B columns in one L2;
+//  * split-K grid (tiles*splitk, 1), used when splitk is a multiple of 8 (see splitk_by_xcd): each XCD owns splitk/8 whole
+//    reduction slices and runs all output tiles of a slice back to back, so a slice of the two operands (the huge dimension
+//    of a weight-gradient GEMM) is fetched into ONE L2 instead of all eight.
+__device__ inline void xcd_map(int nwg, int splitk, int& id, int& z) {
+  const int xcd = id & 7, loc = id >> 3;
+  if (gridDim.y == 1 && splitk > 1) {
+    z = xcd * (splitk >> 3) + loc / nwg;
+    id = loc % nwg;
+  } else {
+    const int q = nwg >> 3, rr = nwg & 7;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  }
+}
+inline bool splitk_by_xcd(const crog_gemm_desc& d) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("CROG_GEMM_NO_XCD_SPLITK"); off = (e && e[0] == '1') ? 1 : 0; }
+  return !off && d.batch == 1 && d.splitk >= 8 && (d.splitk & 7) == 0;
+}
+
 template <typename T, int AL, int BL, bool HWTR, typename S>
 __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))) gemm_kernel(const crog_gemm_desc p) {
   using Cfg = TileCfg<T>;
@@ -427,15 +450,11 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))
   // XCD-aware tile order: blocks that share an XCD (id % 8) get a contiguous run of tiles.
   const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
   const int nwg = tilesM * tilesN;
-  int id = blockIdx.x;
-  {
-    const int q = nwg >> 3, rr = nwg & 7, xcd = id & 7, loc = id >> 3;
-    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-  }
+  int id = blockIdx.x, z = blockIdx.y;
+  xcd_map(nwg, p.splitk, id, z);
   const int tm = id / tilesN, tn = id % tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const int z = blockIdx.y;
   const int zb = z / p.splitk, zs = z % p.splitk;
   const int zo = zb / p.batch_inner, zi = zb % p.batch_inner;
   const T* A = reinterpret_cast<const T*>(p.A) + zo * p.sAo + zi * p.sAi;
@@ -532,7 +551,11 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))
 // Out-of-range rows/columns, conv padding and ragged K are an out-of-bounds buffer offset: the hardware writes zeros.
 // =================================================================================================
 constexpr unsigned DMA_OOB = 0x80000000u;
-constexpr int DMA_NSTAGE = 3;   // tile edge = 32 * (waves per block): 128 (4 waves) or 256 (8 waves); one operand tile = edge * 64 bytes
+// LDS ring depth (k-tiles in flight = depth - 1); tile edge = 32 * (waves per block): 128 (4 waves) or 256 (8 waves); one
+// operand tile = edge * 64 bytes.  128^2: 3 stages x 16 KiB, 3 blocks per CU (a 4-stage ring at 2 blocks per CU measured 10 %
+// slower: occupancy beats depth).  256^2: one 8-wave block per CU owns all 256 VGPRs per lane (128 of them accumulators), so
+// the ring is 4 x 32 KiB deep instead.
+template <typename S> constexpr int dma_nstage() { return S::NT == 512 ? 4 : 3; }
 
 // K-contiguous operand (MODE 0 dense rows, MODE 1 im2col patches of an NHWC map)
 template <typename T, int MODE>
@@ -725,7 +748,8 @@ __device__ inline void dma_issue(const OA& da, const OB& db, const ConvGeom& g, 
 using ShapeDma8 = Shape<4, 2, 2, 4>;   // 256 x 256, 8 waves, 128 accumulator registers per lane
 
 template <typename T, int AL, int BL, typename S>
-__global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 2 : 3)) gemm_dma_kernel(const crog_gemm_desc p) {
+__global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : 3)) gemm_dma_kernel(const crog_gemm_desc p) {
+  constexpr int DMA_NSTAGE = dma_nstage<S>();
   static_assert(S::BM == S::BN && S::BM == 32 * (S::NT / 64), "DMA tiles are (32 * waves)^2: every wave issues 2+2 KiB per k-tile");
   using OA = typename DmaASel<T, AL, S::BM>::type;
   using OB = typename DmaBSel<T, BL, S::BN>::type;
@@ -739,14 +763,10 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 2 : 3)) gemm_dma_kernel
 
   const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
   const int nwg = tilesM * tilesN;
-  int id = blockIdx.x;
-  {
-    const int q = nwg >> 3, rr = nwg & 7, xcd = id & 7, loc = id >> 3;
-    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-  }
+  int id = blockIdx.x, z = blockIdx.y;
+  xcd_map(nwg, p.splitk, id, z);
   const int tm = id / tilesN, tn = id % tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.y;
   const int zb = z / p.splitk, zs = z % p.splitk;
   const int zo = zb / p.batch_inner, zi = zb % p.batch_inner;
   const T* A = reinterpret_cast<const T*>(p.A) + zo * p.sAo + zi * p.sAi;
@@ -785,14 +805,21 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 2 : 3)) gemm_dma_kernel
     }
   };
 #define CROG_KMEM(kt) kmem_of(kt)
-  dma_issue<DMA_TILE_B>(da, db, g, smem, wave, kt0, CROG_KMEM(kt0), 0);
-  if (nt > 1) dma_issue<DMA_TILE_B>(da, db, g, smem, wave, kt0 + 1, CROG_KMEM(kt0 + 1), 1);
+#pragma unroll
+  for (int s = 0; s < DMA_NSTAGE - 1; s++)
+    if (s < nt) dma_issue<DMA_TILE_B>(da, db, g, smem, wave, kt0 + s, CROG_KMEM(kt0 + s), s);
   int stage = 0;
   for (int t = 0; t < nt; t++) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // k-tiles still allowed in flight behind tile t: min(depth - 2, tiles left); 4 DMA instructions per tile and wave
+    const int behind = min(DMA_NSTAGE - 2, nt - 1 - t);
+    if (behind >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < nt && !(p.debug & 1)) dma_issue<DMA_TILE_B>(da, db, g, smem, wave, kt0 + t + 2, CROG_KMEM(kt0 + t + 2), stage >= 1 ? stage - 1 : 2);
+    if (t + DMA_NSTAGE - 1 < nt && !(p.debug & 1)) {
+      const int tn = t + DMA_NSTAGE - 1;
+      dma_issue<DMA_TILE_B>(da, db, g, smem, wave, kt0 + tn, CROG_KMEM(kt0 + tn), stage == 0 ? DMA_NSTAGE - 1 : stage - 1);
+    }
     const char* at = smem + stage * DMA_STAGE_B;
     const char* bt = at + DMA_TILE_B;
     if (!(p.debug & 2))
@@ -808,7 +835,7 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 2 : 3)) gemm_dma_kernel
 #pragma unroll
         for (int j = 0; j < WN; j++) mma16(fa[i], fb[j], acc[i][j]);
     }
-    stage = stage == 2 ? 0 : stage + 1;
+    stage = stage == DMA_NSTAGE - 1 ? 0 : stage + 1;
   }
 #undef CROG_KMEM
   __syncthreads();
@@ -817,7 +844,7 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 2 : 3)) gemm_dma_kernel
 
 template <typename T, int AL, int BL, typename S>
 int launch_dma(const crog_gemm_desc& d, hipStream_t s) {
-  constexpr int LDS = DMA_NSTAGE * 2 * S::BM * 64;
+  constexpr int LDS = dma_nstage<S>() * 2 * S::BM * 64;
   static bool attr_set = false;
   auto kern = gemm_dma_kernel<T, AL, BL, S>;
   if (!attr_set) {
@@ -829,6 +856,7 @@ int launch_dma(const crog_gemm_desc& d, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(cdiv(d.M, S::BM) * cdiv(d.N, S::BN), d.batch * d.splitk, 1);
+  if (splitk_by_xcd(d)) grid = dim3(grid.x * d.splitk, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(S::NT), LDS, s, d);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
@@ -914,6 +942,7 @@ int launch(const crog_gemm_desc& d, hipStream_t s) {
   }
   const int tilesM = cdiv(d.M, S::BM), tilesN = cdiv(d.N, S::BN);
   dim3 grid(tilesM * tilesN, d.batch * d.splitk, 1);
+  if (splitk_by_xcd(d)) grid = dim3(grid.x * d.splitk, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(S::NT), LDS, s, d);
   CROG_LAUNCH_CHECK();
   return CROG_OK;

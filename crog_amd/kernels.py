@@ -7,6 +7,7 @@ operator computes anything on this path.  Nothing in this file falls back to CPU
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch

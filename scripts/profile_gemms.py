@@ -11,6 +11,7 @@ from crog_amd.testing import make_cfg, synthetic_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 cfg = make_cfg(); torch.manual_seed(0)
 model, groups = build_crog(cfg); model = model.cuda().prepare()
+if os.environ.get("CROG_NO_TEXT_OVERLAP") == "1": model.overlap_text = False
 opt = FusedAdam(groups, lr=1e-4, store=model.store)
 batch = synthetic_batch(B, 416, 20, 49408, seed=1, device="cuda"); model.train()
 for _ in range(2): train_step(model, opt, None, batch, cfg)
@@ -25,6 +26,9 @@ for e0, e1, fl, key in recs:
     a = agg.setdefault(key, [0, 0.0, fl])
     a[0] += 1; a[1] += d
 tot = sum(a[1] for a in agg.values())
+if os.environ.get("CROG_GEMM_DUMP"):
+    import json
+    json.dump([dict(key=list(k), n=a[0], ms=a[1], flops=a[2]) for k, a in agg.items()], open(os.environ["CROG_GEMM_DUMP"], "w"))
 print(f"GEMM launches {len(recs)} total {tot:.2f} ms")
 names = {(0,0):"fwd/NT", (1,0):"conv3 fwd", (0,1):"dgrad/NN", (1,2):"conv3 dgrad", (2,1):"wgrad/TN", (2,3):"conv3 wgrad", (2,0): "TN-kc"}
 for key, (n, d, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
