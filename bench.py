@@ -165,8 +165,14 @@ def main():
             durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _, _ in recs]
             flops = [f for _, _, f, _ in recs]
             avg_d, avg_f = sum(durs) / len(durs), sum(flops) / len(flops)
+            traffic = None   # HBM bytes per launch of this kernel from the committed PMC passes (profiles/pmc_traffic.json)
+            try:
+                pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+                traffic = pm[args.roofline_kernel]["bytes_per_launch"] if args.dtype == "bf16" and args.batch == 32 else None
+            except (OSError, KeyError, ValueError):
+                pass
             roof = dict(bound="mfma", achieved=round(avg_f / avg_d / 1e12, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
-                        frac=round(avg_f / avg_d / 1e12 / PEAK_MFMA_TF, 4), traffic=None,
+                        frac=round(avg_f / avg_d / 1e12 / PEAK_MFMA_TF, 4), traffic=traffic,
                         kernel=K.GEMM_SYMBOL[key], launches_per_step=len(recs) // args.steps,
                         avg_launch_us=round(avg_d * 1e6, 1), avg_gflop_per_launch=round(avg_f / 1e9, 2),
                         share_of_step=round(sum(durs) / dt, 4))

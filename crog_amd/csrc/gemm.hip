@@ -412,23 +412,25 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[S::WM][S::WN], const crog_gem
 // Workgroups are dealt to the 8 XCDs round-robin in launch order (linear id % 8), and every XCD has its own L2.
 //  * plain grid (tiles, batch*splitk): each XCD gets a contiguous run of output tiles, so neighbouring tiles share their
 //    A rows / B columns in one L2;
-//  * split-K grid (tiles*splitk, 1), used when splitk is a multiple of 8 (see splitk_by_xcd): each XCD owns splitk/8 whole
-//    reduction slices and runs all output tiles of a slice back to back, so a slice of the two operands (the huge dimension
-//    of a weight-gradient GEMM) is fetched into ONE L2 instead of all eight.
+//  * split-K grid (tiles*splitk, 1) (see splitk_by_xcd): the work items (reduction slice, tile), slice-major, are cut into 8
+//    contiguous runs, so an XCD runs all output tiles of a slice back to back and a slice of the two operands (the huge
+//    dimension of a weight-gradient GEMM) is fetched into one L2 (two at a run boundary) instead of all eight.
 __device__ inline void xcd_map(int nwg, int splitk, int& id, int& z) {
   const int xcd = id & 7, loc = id >> 3;
-  if (gridDim.y == 1 && splitk > 1) {
-    z = xcd * (splitk >> 3) + loc / nwg;
-    id = loc % nwg;
+  const int total = (gridDim.y == 1 && splitk > 1) ? nwg * splitk : nwg;
+  const int q = total >> 3, rr = total & 7;
+  const int w = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  if (total != nwg) {
+    z = w / nwg;
+    id = w - z * nwg;
   } else {
-    const int q = nwg >> 3, rr = nwg & 7;
-    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    id = w;
   }
 }
 inline bool splitk_by_xcd(const crog_gemm_desc& d) {
   static int off = -1;
   if (off < 0) { const char* e = getenv("CROG_GEMM_NO_XCD_SPLITK"); off = (e && e[0] == '1') ? 1 : 0; }
-  return !off && d.batch == 1 && d.splitk >= 8 && (d.splitk & 7) == 0;
+  return !off && d.batch == 1 && d.splitk > 1;
 }
 
 template <typename T, int AL, int BL, bool HWTR, typename S>

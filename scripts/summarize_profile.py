@@ -1,16 +1,17 @@
 """Turn rocprofv3 output (kernel stats + PMC passes) into profiles/<tag>_summary.md and copy the raw stats CSV."""
 import collections, csv, glob, os, re, shutil, sys
 tag, stats_dir, fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
+PMC_STEPS = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
-sf = max(glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+sf = max(glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(stats_dir, "*_kernel_stats.csv")), key=os.path.getmtime)
 shutil.copy(sf, os.path.join(out, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(sf)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 def agg(d, counter):
     acc = collections.defaultdict(lambda: [0, 0.0])
-    fs = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    fs = glob.glob(os.path.join(d, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(d, "*_counter_collection.csv"))
     if not fs: return acc
     for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         if r["Counter_Name"] == counter:
@@ -23,13 +24,24 @@ L = [f"# rocprofv3 summary — {tag}", "",
      f"PMC passes (separate runs): `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction, MI355X_MICROARCH.md §HBM).", "",
      f"Total kernel time: {tot/1e6/steps:.2f} ms per step ({steps} steps profiled).", "",
      "| ms/step | % | launches/step | avg us | HBM MB/launch (PMC) | kernel |", "|---|---|---|---|---|---|"]
-for r in rows[:30]:
+for r in rows[:40]:
     k = r["Name"]
     hb = ""
     if k in f and f[k][0]:
         hb = f"{(2*f[k][1]/f[k][0] + (w[k][1]/w[k][0] if k in w and w[k][0] else 0))*1024/1e6:.0f}"
     L.append(f"| {float(r['TotalDurationNs'])/1e6/steps:.3f} | {float(r['Percentage']):.2f} | {int(r['Calls'])/steps:.1f} | {float(r['AverageNs'])/1e3:.1f} | {hb} | `{clean(k)[:110]}` |")
 tb = sum(2*f[k][1] + w.get(k, [0, 0.0])[1] for k in f) * 1024
-if tb: L += ["", f"Measured HBM traffic (all kernels): {tb/1e9/ (f[next(iter(f))][0] and 1):.1f} GB over the PMC run = {tb/1e9/3:.1f} GB/step (3 steps in the PMC runs); algorithmic 56.2 GB/step (1.58 GB/img x 32 + 5.6 GB)."]
+if tb: L += ["", f"Measured HBM traffic (all kernels): {tb/1e9/ (f[next(iter(f))][0] and 1):.1f} GB over the PMC run = {tb/1e9/PMC_STEPS:.1f} GB/step ({PMC_STEPS} steps in the PMC runs); algorithmic 56.2 GB/step (1.58 GB/img x 32 + 5.6 GB)."]
+# per-launch HBM traffic of the GEMM kernels whose (A layout, B layout) can be read off the mangled name; bench.py reports it as roofline.traffic
+import json
+names = {(1, 0): "conv3x3_fwd", (1, 2): "conv3x3_dgrad", (2, 3): "conv3x3_wgrad", (0, 0): "lin_fwd"}
+pm = {}
+for k in f:
+    m = re.search(r"gemm_dma_kernelIDF16bLi(\d)ELi(\d)E", k)
+    if m and (int(m.group(1)), int(m.group(2))) in names and f[k][0]:
+        pm[names[(int(m.group(1)), int(m.group(2)))]] = dict(
+            kernel=k, launches=f[k][0], bytes_per_launch=round((2 * f[k][1] / f[k][0] + (w[k][1] / w[k][0] if k in w and w[k][0] else 0)) * 1024),
+            source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, {tag}")
+if pm: json.dump(pm, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(out, f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
 print("\n".join(L[:16]))
