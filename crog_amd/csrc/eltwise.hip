@@ -381,6 +381,62 @@ __global__ void __launch_bounds__(NT) stem_im2col_kernel(const float* __restrict
   }
 }
 
+// ---- ViT patch embedding front end (clip.py:290-296,309-321) ----------------------------------------------------------
+// Non-overlapping PxP patches of an NCHW fp32 image -> rows [B*(H/P)*(W/P)][P*P*3], column (ky*P + kx)*3 + ci (the
+// channels-last KRSC weight row), so conv1 (kernel = stride = P, no bias) is one crog_gemm.
+template <typename T>
+__global__ void __launch_bounds__(NT) patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W, int P) {
+  const int GH = H / P, GW = W / P;
+  const long total = (long)B * GH * GW * P * P;   // one thread per (patch, ky, kx): 3 channels
+  GRID_STRIDE(i, total) {
+    const int kx = (int)(i % P);
+    const int ky = (int)((i / P) % P);
+    const long patch = i / ((long)P * P);
+    const int gx = (int)(patch % GW), gy = (int)((patch / GW) % GH);
+    const long b = patch / ((long)GW * GH);
+    const long src = ((b * 3) * H + (long)gy * P + ky) * W + (long)gx * P + kx;
+    T* dst = out + (patch * P * P + (long)ky * P + kx) * 3;
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) dst[ci] = Elem<T>::from_f(img[src + (long)ci * H * W]);
+  }
+}
+
+// tokens[b][0] = class_embedding + pos[0];  tokens[b][1 + i] = y[b*G + i] + pos[1 + i]      (T = G + 1 tokens)
+template <typename T>
+__global__ void __launch_bounds__(NT) vit_tokens_fwd_kernel(const T* __restrict__ y, long ldy, const T* __restrict__ cls, const T* __restrict__ pos,
+                                                            T* __restrict__ out, long rows, int Tn, int C) {
+  const int cv = C / Elem<T>::VEC;
+  GRID_STRIDE(i, rows * cv) {
+    const long r = i / cv;
+    const int c = (int)(i % cv) * Elem<T>::VEC;
+    const int t = (int)(r % Tn);
+    const long b = r / Tn;
+    const Vec16<T> a = t == 0 ? ldg16(cls + c) : ldg16(y + (b * (Tn - 1) + t - 1) * ldy + c);
+    const Vec16<T> pp = ldg16(pos + (long)t * C + c);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < Elem<T>::VEC; e++) o.v[e] = Elem<T>::from_f(Elem<T>::to_f(a.v[e]) + Elem<T>::to_f(pp.v[e]));
+    stg16(out + r * C + c, o);
+  }
+}
+
+// dy[b*G + i] = dtok[b][1 + i];  gpos[t] += sum_b dtok[b][t];  gcls += sum_b dtok[b][0]   (fp32 gradient buffers)
+template <typename T>
+__global__ void __launch_bounds__(NT) vit_tokens_bwd_kernel(const T* __restrict__ dtok, T* __restrict__ dy, long lddy, float* __restrict__ gcls,
+                                                            float* __restrict__ gpos, int B, int Tn, int C) {
+  GRID_STRIDE(i, (long)Tn * C) {
+    const int t = (int)(i / C), c = (int)(i % C);
+    float acc = 0.f;
+    for (int b = 0; b < B; b++) {
+      const T v = dtok[((long)b * Tn + t) * C + c];
+      acc += Elem<T>::to_f(v);
+      if (t > 0) dy[((long)b * (Tn - 1) + t - 1) * lddy + c] = v;
+    }
+    gpos[i] += acc;
+    if (t == 0) gcls[c] += acc;
+  }
+}
+
 // ---- dst[r][c] = c < cols_src ? src[r][c] : 0, c < cols_dst   (fp32 source; T or fp32 destination) ------
 template <typename TD>
 __global__ void __launch_bounds__(NT) cast_pad2d_kernel(const float* __restrict__ src, long lds_, int cols_src, TD* __restrict__ dst, long ldd,
@@ -639,6 +695,31 @@ extern "C" int crog_quickgelu_fwd(int dtype, const void* u, int64_t ldu, void* o
 extern "C" int crog_stem_im2col(int dtype, const float* img, void* out, int B, int H, int W, crog_stream_t s) {
   CROG_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "stem_im2col: H, W must be even");
   DISPATCH_T(dtype, LAUNCH((stem_im2col_kernel<T>), (long)B * (H / 2) * (W / 2), s, img, (T*)out, B, H, W));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_patchify(int dtype, const float* img, void* out, int B, int H, int W, int P, crog_stream_t s) {
+  CROG_CHECK_ARG(P > 0 && H % P == 0 && W % P == 0, "patchify: H, W must be multiples of the patch size");
+  DISPATCH_T(dtype, LAUNCH((patchify_kernel<T>), (long)B * H * W, s, img, (T*)out, B, H, W, P));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_vit_tokens_fwd(int dtype, const void* y, int64_t ldy, const void* cls, const void* pos, void* out, int B, int T_, int C,
+                                   crog_stream_t s) {
+  CROG_CHECK_ARG(T_ >= 2, "vit_tokens: needs at least one patch token");
+  const int vec = VECOF(dtype);
+  CROG_CHECK_ARG(C % vec == 0 && ldy % vec == 0, "vit_tokens: C and ldy must be multiples of %d", vec);
+  CROG_CHECK_ARG(((uintptr_t)y % 16) == 0 && ((uintptr_t)cls % 16) == 0 && ((uintptr_t)pos % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                 "vit_tokens: pointers must be 16-byte aligned");
+  DISPATCH_T(dtype, LAUNCH((vit_tokens_fwd_kernel<T>), (long)B * T_ * (C / vec), s, (const T*)y, (long)ldy, (const T*)cls, (const T*)pos, (T*)out,
+                           (long)B * T_, T_, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_vit_tokens_bwd(int dtype, const void* dtok, void* dy, int64_t lddy, float* gcls, float* gpos, int B, int T_, int C,
+                                   crog_stream_t s) {
+  CROG_CHECK_ARG(T_ >= 2, "vit_tokens: needs at least one patch token");
+  DISPATCH_T(dtype, LAUNCH((vit_tokens_bwd_kernel<T>), (long)T_ * C, s, (const T*)dtok, (T*)dy, (long)lddy, gcls, gpos, B, T_, C));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

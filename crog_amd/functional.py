@@ -788,6 +788,38 @@ def embedding(word, tok: WRef, pos: WRef, dtype):
     return EmbeddingFn.apply(word, tok.param, pos.param, tok, pos, dtype)
 
 
+class VitTokensFn(Function):
+    """[class_embedding; patch rows] + positional_embedding  (clip.py:313-320) -> token rows [B*T, C], batch-major."""
+
+    @staticmethod
+    def forward(ctx, y, _cp, _pp, cls: WRef, pos: WRef, B):
+        T, C = pos.rows, pos.cols
+        _, _, ldy = K.mat(y)
+        out = torch.empty(B * T, C, device=y.device, dtype=y.dtype)
+        wbuf = cls.w(y.dtype)
+        esz = 2 if y.dtype == torch.bfloat16 else 4
+        K.check(K.lib().crog_vit_tokens_fwd(K.dcode(y), K.ptr(y), ldy, K.ptr(wbuf) + esz * cls.off, K.ptr(wbuf) + esz * pos.off, K.ptr(out),
+                                            B, T, C, K.stream()), "vit_tokens_fwd")
+        ctx.cfg = (cls, pos, B)
+        return out
+
+    @staticmethod
+    def backward(ctx, dtok):
+        cls, pos, B = ctx.cfg
+        dtok = K.as_mat(dtok)
+        T, C = pos.rows, pos.cols
+        dy = torch.empty(B * (T - 1), C, device=dtok.device, dtype=dtok.dtype)
+        K.check(K.lib().crog_vit_tokens_bwd(K.dcode(dtok), K.ptr(dtok), K.ptr(dy), C, K.ptr(cls.G) + 4 * cls.off, K.ptr(pos.G) + 4 * pos.off,
+                                            B, T, C, K.stream()), "vit_tokens_bwd")
+        cls.done()
+        pos.done()
+        return dy, None, None, None, None, None
+
+
+def vit_tokens(y, cls: WRef, pos: WRef, B):
+    return VitTokensFn.apply(y, cls.param, pos.param, cls, pos, B)
+
+
 class GatherRowsFn(Function):
     """x[idx] over rows (EOT token select, clip.py:451-452)."""
 

@@ -343,6 +343,11 @@ def stem_im2col(img, out):
     check(lib().crog_stem_im2col(dcode(out), ptr(img), ptr(out), B, H, W, stream()), "stem_im2col")
 
 
+def patchify(img, out, patch: int):
+    B, _, H, W = img.shape
+    check(lib().crog_patchify(dcode(out), ptr(img), ptr(out), B, H, W, patch, stream()), "patchify")
+
+
 def cast_pad2d(src, lds, cols_src, dst, ldd, cols_dst, rows, src_off=0, dst_off=0):
     dt = dcode(dst)
     sz = 2 if dt == BF16 else 4

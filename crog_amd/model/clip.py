@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as TF
 
 from .. import functional as Fn
+from .. import kernels as K
 from ..functional import WRef
 from .blocks import BatchNorm, Bound, Conv2d, ConvBN, LayerNorm, Linear, MultiheadAttention
 
@@ -183,8 +184,32 @@ class VisionTransformer(Bound):
         self.ln_post = LayerNorm(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
+    def _make_refs(self, store):
+        W = self.class_embedding.shape[0]
+        self.cls = WRef(store, self.class_embedding, 0, 1, W)
+        self.pos = WRef(store, self.positional_embedding)
+        self.wproj = WRef(store, self.proj)
+
     def forward(self, img, dtype):
-        raise NotImplementedError("CROG-ViT image tower on the HIP path is scheduled after the R50 path (SURVEY.md §8a row V)")
+        """[B, 3, R, R] fp32 -> patch-token features [B, (R/P)^2, output_dim]  (the CRIS variant keeps the patch tokens and
+        drops CLS after the blocks, clip.py:326-330)."""
+        B, _, H, Wd = img.shape
+        P = self.patch_size
+        if H != self.input_resolution or Wd != self.input_resolution:
+            # the reference adds a fixed-length positional table (clip.py:320): any other grid fails there with a shape error
+            raise RuntimeError(f"The size of tensor a ({(H // P) * (Wd // P) + 1}) must match the size of tensor b "
+                               f"({self.positional_embedding.shape[0]}) at non-singleton dimension 1")
+        G = (H // P) * (Wd // P)
+        X = torch.empty(B * G, 3 * P * P, device=img.device, dtype=dtype)
+        K.patchify(img, X, P)
+        y = Fn.linear(X, self.conv1.w, None)
+        x = Fn.vit_tokens(y, self.cls, self.pos, B)
+        x = self.ln_pre(x)
+        x = self.transformer(x, B)
+        T = G + 1
+        keep = (torch.arange(B * T, device=img.device).view(B, T)[:, 1:]).reshape(-1)
+        x = self.ln_post(Fn.gather_rows(x, keep))
+        return Fn.table_matmul(x, self.wproj, dtype).view(B, G, -1)
 
 
 class CLIP(Bound):

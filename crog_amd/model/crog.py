@@ -176,6 +176,11 @@ class CROG(nn.Module):
             else:
                 vis = self.backbone.image_features(img, dtype)
                 wfeat, state = self.backbone.text_features(word, dtype)
+            if not isinstance(vis, tuple):
+                # layers.py:373 unpacks three pyramid levels; a ViT tower returns one token tensor, so the reference fails here
+                # too: ViT parity is encoder-level (encode_image / encode_text).
+                raise ValueError("too many values to unpack (expected 3): the FPN neck needs the (C3, C4, C5) maps of the "
+                                 "ModifiedResNet tower; with a ViT tower use backbone.encode_image / encode_text")
             fq = self.neck(vis, state)
             if self.use_contrastive:
                 fq = self.decoder(fq, wfeat, pad_mask)

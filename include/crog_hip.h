@@ -212,6 +212,15 @@ int crog_quickgelu_fwd(int dtype, const void* u, int64_t ldu, void* out, int64_t
 /* stem conv1 (3->32, 3x3, stride 2, pad 1; clip.py:165-170): NCHW fp32 image -> patch rows
  * [B*(H/2)*(W/2)][32], column (ky*3+kx)*3+ci, columns 27..31 zero; the conv is then crog_gemm */
 int crog_stem_im2col(int dtype, const float* img, void* out, int B, int H, int W, crog_stream_t stream);
+/* ViT patch embedding front end (VisionTransformer.forward clip.py:309-321; conv1 = clip.py:290-294).
+ * crog_patchify: NCHW fp32 image -> rows [B*(H/P)*(W/P)][P*P*3], column (ky*P+kx)*3+ci; conv1 is then crog_gemm.
+ * crog_vit_tokens_fwd: out[b][0] = class_embedding + pos[0], out[b][1+i] = y[b*G+i] + pos[1+i]  (T = G+1 tokens).
+ * crog_vit_tokens_bwd: dy[b*G+i] = dtok[b][1+i]; gpos[t] += sum_b dtok[b][t]; gcls += sum_b dtok[b][0] (fp32). */
+int crog_patchify(int dtype, const float* img, void* out, int B, int H, int W, int P, crog_stream_t stream);
+int crog_vit_tokens_fwd(int dtype, const void* y, int64_t ldy, const void* cls, const void* pos, void* out,
+                        int B, int T, int C, crog_stream_t stream);
+int crog_vit_tokens_bwd(int dtype, const void* dtok, void* dy, int64_t lddy, float* gcls, float* gpos,
+                        int B, int T, int C, crog_stream_t stream);
 /* dst[r][c] = c < cols_src ? src[r][c] : 0 for c < cols_dst (fp32 source) */
 int crog_cast_pad2d(int dtype_dst, const float* src, int64_t lds, int cols_src, void* dst, int64_t ldd,
                     int cols_dst, int64_t rows, crog_stream_t stream);

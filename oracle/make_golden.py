@@ -171,6 +171,30 @@ def op_fixtures(ref_clip, ref_layers):
     print("ops fixtures:", len(fx), flush=True)
 
 
+def vit_fixture(ref_clip):
+    """BASELINE config 4 (CLIP ViT tower), encoder-level pin at a small shape: VisionTransformer(64, 16, 128, 2 layers, 2 heads, 64)
+    -> output, loss-weighted parameter gradients."""
+    torch.manual_seed(11)
+    m = ref_clip.VisionTransformer(64, 16, 128, 2, 2, 64).train()
+    for n, p in m.named_parameters():
+        if n.endswith("ln_pre.weight") or n.endswith("ln_post.weight") or ".ln_1.weight" in n or ".ln_2.weight" in n:
+            p.data.normal_(1.0, 0.1)
+        elif p.dim() == 1:
+            p.data.normal_(0, 0.1)
+        else:
+            p.data.normal_(0, p.shape[-1] ** -0.5 if p.dim() == 2 else 0.04)
+    fx = {"w::" + k: v.clone() for k, v in m.state_dict().items()}
+    img = torch.randn(2, 3, 64, 64)
+    o = m(img)
+    (o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum().backward()
+    fx["in0"] = img
+    fx["out"] = o.detach()
+    for n, p in m.named_parameters():
+        fx["dw::" + n] = p.grad
+    np.savez_compressed(os.path.join(GOLD, "vit_tiny.npz"), **{k: v.detach().numpy() for k, v in fx.items()})
+    print("vit fixture: out", tuple(o.shape), "absmax", float(o.abs().max()), flush=True)
+
+
 def shapes_only(ref_clip):
     """Parameter names/shapes of the real CLIP RN50 and ViT-B/16 towers + CROG heads (names are the checkpoint contract)."""
     vit = ref_clip.CLIP(512, 224, 12, 768, 16, 77, 20, 49408, 512, 8, 12)
@@ -180,13 +204,15 @@ def shapes_only(ref_clip):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_clip, ref_crog, ref_layers = import_reference()
-    which = sys.argv[1:] or ["tiny", "ops", "shapes", "full"]
+    which = sys.argv[1:] or ["tiny", "ops", "vit", "shapes", "full"]
     if "tiny" in which:
         run_case("tiny_crog", tiny_cfg(), B=4, seed=3, ref_model=ref_model, ref_clip=ref_clip, store_intermediates=True)
         run_case("tiny_crog_nomask", tiny_cfg(use_grasp_masks=False), B=4, seed=4, ref_model=ref_model, ref_clip=ref_clip,
                  store_intermediates=False)
     if "ops" in which:
         op_fixtures(ref_clip, ref_layers)
+    if "vit" in which:
+        vit_fixture(ref_clip)
     if "shapes" in which:
         shapes_only(ref_clip)
     if "full" in which:

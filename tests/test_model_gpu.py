@@ -221,3 +221,41 @@ def test_config1_crog_r50_fp32_matches_reference():
                                or n == "backbone.positional_embedding" or "txt_proj" in n) for n in names])
     tight = ((gn - ref).abs() > 8e-2 * ref + 2e-5) & ~text_side  # ReLU knife-edge flips move trunk gradients by a few % (see tiny test)
     assert not tight.any(), [(names[i], float(gn[i]), float(ref[i])) for i in tight.nonzero().flatten()[:8]]
+
+
+def test_vit_tower_matches_reference_fixture():
+    """SURVEY §8a row V / BASELINE config 4: the CLIP ViT image tower on the HIP path, encoder-level parity (the reference cannot
+    run CROG end to end with a ViT backbone).  fp32 output within 1e-3 of the reference fixture; parameter gradients within
+    1e-3 relative to each gradient's scale."""
+    from crog_amd.model.blocks import bind_all
+    from crog_amd.model.clip import VisionTransformer
+    from crog_amd.runtime import ParamStore
+    d = np.load(os.path.join(GOLD, "vit_tiny.npz"))
+    fx = {k: torch.from_numpy(d[k]) for k in d.files}
+    vit = VisionTransformer(64, 16, 128, 2, 2, 64)
+    vit.load_state_dict({k[3:]: v for k, v in fx.items() if k.startswith("w::")})
+    store = ParamStore(vit, torch.device("cuda"))
+    bind_all(vit, store)
+    vit.train()
+    store.zero_grad()
+    out = vit(fx["in0"].cuda(), torch.float32)
+    assert tuple(out.shape) == tuple(fx["out"].shape)
+    e = err(out, fx["out"])
+    assert e < 1e-3, f"vit out err {e}"
+    w = torch.linspace(-1, 1, out.numel(), device="cuda").view_as(out)
+    (out * w).sum().backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n, p in vit.named_parameters():
+        ref = fx["dw::" + n]
+        scale = ref.abs().max().item() + 1e-6
+        worst = max(worst, err(p.grad, ref) / scale)
+        assert err(p.grad, ref) / scale < 1e-3, f"vit grad {n}: {err(p.grad, ref)} vs scale {scale}"
+    # wrong input resolution: same failure class as the reference's positional add (RuntimeError)
+    with pytest.raises(RuntimeError):
+        vit(torch.zeros(1, 3, 32, 32, device="cuda"), torch.float32)
+    # bf16 compute follows fp32 (cosine of the outputs)
+    store.invalidate_shadow()
+    ob = vit(fx["in0"].cuda(), torch.bfloat16).float().flatten()
+    cos = torch.nn.functional.cosine_similarity(ob, out.detach().flatten(), dim=0).item()
+    assert cos > 0.999, cos

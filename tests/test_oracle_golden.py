@@ -158,3 +158,17 @@ def test_oracle_matches_reference_config1():
     for i, nm in enumerate(["ins", "qua", "sin", "cos", "wid"]):
         check(out["preds"][i], g["pred_" + nm], atol=5e-5, rtol=1e-4, what="pred_" + nm)
     check(out["total"], g["loss_total"], atol=1e-5, what="total")
+
+
+def test_oracle_vit_tower_matches_reference():
+    """BASELINE config 4 (CLIP ViT tower): encoder-level pin of the oracle against the reference's VisionTransformer
+    (clip.py:286-332) on the tiny fixture written by oracle/make_golden.py."""
+    d = np.load(os.path.join(GOLD, "vit_tiny.npz"))
+    fx = {k: torch.from_numpy(d[k]) for k in d.files}
+    P = {"v." + k[3:]: v.clone().requires_grad_(True) for k, v in fx.items() if k.startswith("w::")}
+    o = O.encode_image_vit(P, fx["in0"], pre="v")
+    (o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum().backward()
+    check(o, fx["out"], atol=2e-5, what="vit out")
+    for k, v in fx.items():
+        if k.startswith("dw::"):
+            check(P["v." + k[4:]].grad, v, atol=5e-5, rtol=1e-3, what="vit " + k)
