@@ -321,6 +321,7 @@ __global__ void __launch_bounds__(NT) act_bwd_kernel(const T* __restrict__ dy, l
       const float gf = Elem<T>::to_f(g.v[e]), u = Elem<T>::to_f(yv.v[e]);
       float d;
       if (mode == 0) d = u > 0.f ? gf : 0.f;
+      else if (mode == 2) d = gf * (1.f - u * u);   // tanh, from the saved OUTPUT (ssg.py:128,133)
       else {
         const float sg = 1.f / (1.f + expf(-1.702f * u));
         d = gf * sg * (1.f + 1.702f * u * (1.f - sg));

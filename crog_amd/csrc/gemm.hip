@@ -258,6 +258,7 @@ template <typename T, int R, int NT> struct BLoaderSel<T, CROG_B_NC_IM2COL, R, N
 __device__ inline float apply_act(float v, int act) {
   if (act == CROG_ACT_RELU) return fmaxf(v, 0.f);
   if (act == CROG_ACT_QUICKGELU) return v / (1.f + expf(-1.702f * v));
+  if (act == CROG_ACT_TANH) return tanhf(v);
   return v;
 }
 

@@ -310,30 +310,51 @@ def conv_bn_act(x, w: Optional[WRef], bn: BnBuffers, *, ksize, relu=True, res=No
 # Linear with fused bias / activation / residual epilogue
 # ------------------------------------------------------------------------------------------------
 class LinearFn(Function):
-    """y = act(x W^T + b) + res.  act in {none, relu}.  nn.Linear call sites: clip.py:249-251 (c_fc/c_proj),
-    layers.py:298-301 (ffn), proj.vis.4 1x1 conv with bias (layers.py:58)."""
+    """y = act(x W^T + b) + res.  act in {none, relu, tanh}.  nn.Linear call sites: clip.py:249-251 (c_fc/c_proj),
+    layers.py:298-301 (ffn), proj.vis.4 1x1 conv with bias (layers.py:58); SSG's bias convolutions on im2col / 1x1 rows
+    (ssg.py:123-133,163-164,178,188-191,230).  An output width that is not a multiple of the 16-byte vector (SSG's 12 box
+    channels) lives in a padded buffer; the Function hands out the [.., :N] view."""
 
     @staticmethod
     def forward(ctx, x, res, _wp, _bp, w: WRef, b: Optional[WRef], act, out):
         M, Kd, _ = K.mat(x)
-        y = _dest(out) if out is not None else torch.empty(tuple(x.shape[:-1]) + (w.rows,), device=x.device, dtype=x.dtype)
+        N = w.rows
+        Np = _pad(N, _vec(_cdt(x)))
+        if out is not None:
+            y = _dest(out)
+        elif Np != N:
+            y = torch.zeros(tuple(x.shape[:-1]) + (Np,), device=x.device, dtype=x.dtype)[..., :N]
+        else:
+            y = torch.empty(tuple(x.shape[:-1]) + (N,), device=x.device, dtype=x.dtype)
         lin_fwd(x, w, y, bias=b, act=act, res=res)
         ctx.cfg = (w, b, act, res is not None)
-        ctx.save_for_backward(x, y if act == K.ACT_RELU else None)
+        ctx.save_for_backward(x, y if act in (K.ACT_RELU, K.ACT_TANH) else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         w, b, act, has_res = ctx.cfg
         x, y = ctx.saved_tensors
-        dy = K.as_mat(dy)
+        N = w.rows
+        Np = _pad(N, _vec(_cdt(x)))
+        if Np != N:   # ragged width: re-pad the incoming gradient so that its rows are 16-byte vectors
+            dyp = torch.zeros(tuple(dy.shape[:-1]) + (Np,), device=dy.device, dtype=dy.dtype)
+            dyp[..., :N].copy_(dy)
+            dy = dyp[..., :N]
+        else:
+            dy = K.as_mat(dy)
         dres = dy if has_res else None
         g = dy
-        if act == K.ACT_RELU:
+        if act in (K.ACT_RELU, K.ACT_TANH):
             if has_res:
-                raise NotImplementedError("relu + residual epilogue backward")
-            g = torch.empty(dy.shape, device=dy.device, dtype=dy.dtype)
-            K.act_bwd(dy, y, g, 0)
+                raise NotImplementedError("activation + residual epilogue backward")
+            if Np != N:
+                g = torch.zeros(tuple(dy.shape[:-1]) + (Np,), device=dy.device, dtype=dy.dtype)
+                K.act_bwd(dyp, y_full(y, Np), g, 0 if act == K.ACT_RELU else 2)
+                g = g[..., :N]
+            else:
+                g = torch.empty(dy.shape, device=dy.device, dtype=dy.dtype)
+                K.act_bwd(dy, y, g, 0 if act == K.ACT_RELU else 2)
         def wgrad():
             lin_wgrad(g, x, w)
             if b is not None:
@@ -350,6 +371,11 @@ class LinearFn(Function):
             dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
             lin_dgrad(g, w, dx)
         return dx, dres, None, None, None, None, None, None
+
+
+def y_full(y: torch.Tensor, Np: int) -> torch.Tensor:
+    """The padded buffer behind a [.., :N] view handed out by LinearFn.forward."""
+    return y.as_strided(tuple(y.shape[:-1]) + (Np,), y.stride(), y.storage_offset())
 
 
 def linear(x, w: WRef, b: Optional[WRef] = None, *, act=K.ACT_NONE, res=None, out=None):
@@ -750,6 +776,155 @@ class AddDropoutFn(Function):
 
 def add_dropout(a, b, p):
     return AddDropoutFn.apply(a, b, float(p))
+
+
+# ------------------------------------------------------------------------------------------------
+# SSG trunk pieces (model/ssg.py): explicit im2col, 3x3 bias convolution, max pool, align_corners bilinear
+# ------------------------------------------------------------------------------------------------
+class Im2colFn(Function):
+    """x [B, H, W, C] -> patch rows [B, OH, OW, kh*kw*C]; the transpose (col2im) is the backward.  Strided convolutions are
+    `linear(im2col(x), w, b)` / `conv_bn_act(im2col(x), w, bn, ksize=1)` with the weight's physical [Cout][ky][kx][ci] rows."""
+
+    @staticmethod
+    def forward(ctx, x, kh, kw, stride, pad):
+        B, H, W, C = x.shape
+        OH, OW = K.conv_out(H, kh, stride, pad), K.conv_out(W, kw, stride, pad)
+        col = torch.empty(B, OH, OW, kh * kw * C, device=x.device, dtype=x.dtype)
+        K.im2col_nhwc(x, col, kh, kw, stride, pad)
+        ctx.cfg = (tuple(x.shape), kh, kw, stride, pad)
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        shape, kh, kw, stride, pad = ctx.cfg
+        dx = torch.empty(shape, device=dcol.device, dtype=dcol.dtype)
+        K.col2im_nhwc(K.as_mat(dcol), dx, kh, kw, stride, pad)
+        return dx, None, None, None, None
+
+
+def im2col(x, kh, kw, stride, pad):
+    return Im2colFn.apply(x, kh, kw, stride, pad)
+
+
+class Conv3BiasActFn(Function):
+    """y = act(conv3x3_s1_p1(x) + b) as an implicit GEMM (ssg.py:123-133,151-164,178-181), act in {none, relu, tanh}."""
+
+    @staticmethod
+    def forward(ctx, x, _wp, _bp, w: WRef, b: Optional[WRef], act):
+        B, H, W, cin = x.shape
+        C = w.rows
+        dt = _cdt(x)
+        y = torch.empty(B, H, W, C, device=x.device, dtype=x.dtype)
+        K.gemm(dt, K.A_IM2COL, K.B_KC, x, w.w(x.dtype), y, B * H * W, C, 9 * cin, K.mat(x)[2], w.cols, C, b_off=w.off, conv=(H, W, cin),
+               bias=b.master() if b is not None else None, act=act)
+        ctx.cfg = (w, b, act)
+        ctx.save_for_backward(x, y if act != K.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, b, act = ctx.cfg
+        x, y = ctx.saved_tensors
+        B, H, W, cin = x.shape
+        C = w.rows
+        dt = _cdt(x)
+        g = K.as_mat(dy)
+        if act != K.ACT_NONE:
+            g = torch.empty(B, H, W, C, device=dy.device, dtype=dy.dtype)
+            K.act_bwd(K.as_mat(dy), y, g, 0 if act == K.ACT_RELU else 2)
+        M = B * H * W
+        def wgrad():
+            sk = K.pick_splitk(C, 9 * cin, M, _bk(dt))
+            K.gemm(dt, K.A_MC, K.B_NC_IM2COL, g, x, w.G, C, 9 * cin, M, C, K.mat(x)[2], w.cols, c_off=w.off, conv=(H, W, cin), splitk=sk,
+                   out_mode=K.OUT_F32_ATOMIC)
+            if b is not None:
+                bias_grad(g, b)
+        RT.on_wgrad_stream(wgrad, g, x)
+        w.done()
+        if b is not None:
+            b.done()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+            K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, g, w.w(x.dtype), dx, M, cin, 9 * C, C, cin, cin, b_off=w.off, conv=(H, W, C))
+        return dx, None, None, None, None, None
+
+
+def conv_bias_act(x, w: WRef, b: Optional[WRef], *, ksize, stride=1, act=K.ACT_NONE):
+    """Bias convolution of the SSG heads.  3x3/s1 with vector-friendly channel counts -> implicit GEMM; 1x1/s1 -> plain GEMM;
+    anything else (stride 2, 12 box channels) -> explicit im2col rows + GEMM."""
+    cin, cout = x.shape[-1], w.rows
+    if ksize == 1 and stride == 1:
+        return linear(x, w, b, act=act)
+    if ksize == 3 and stride == 1 and cin % 32 == 0 and cout % 32 == 0:
+        return Conv3BiasActFn.apply(x, w.param, b.param if b is not None else None, w, b, act)
+    return linear(im2col(x, ksize, ksize, stride, ksize // 2), w, b, act=act)
+
+
+class MaxPool3s2Fn(Function):
+    """nn.MaxPool2d(3, 2, 1) (ssg.py:66) on channels-last maps."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(B, OH, OW, C, device=x.device, dtype=x.dtype)
+        arg = torch.empty(B, OH, OW, C, device=x.device, dtype=torch.uint8)
+        K.maxpool3s2_fwd(x, y, arg)
+        ctx.shape = tuple(x.shape)
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=dy.dtype)
+        K.maxpool3s2_bwd(K.as_mat(dy), arg, dx)
+        return dx
+
+
+def maxpool3s2(x):
+    return MaxPool3s2Fn.apply(x)
+
+
+class Upsample2AcFn(Function):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (ssg.py:159)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        y = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=x.dtype)
+        K.upsample2ac_fwd(x, y)
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=dy.dtype)
+        K.upsample2ac_bwd(K.as_mat(dy), dx)
+        return dx
+
+
+def upsample2ac(x):
+    return Upsample2AcFn.apply(x)
+
+
+class AddFn(Function):
+    """a + b (FPN top-down merge, ssg.py:196,199) — one streaming kernel (add_dropout with p = 0)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(b)
+        K.add_dropout(a, b, out, 0.0, 0)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout, dout
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ from ._lib import GemmDesc, check
 F32, BF16 = 0, 1
 A_KC, A_IM2COL, A_MC = 0, 1, 2
 B_KC, B_NC, B_NC_DGRAD, B_NC_IM2COL = 0, 1, 2, 3
-ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_TANH = 0, 1, 2, 3
 OUT_T, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 
 
@@ -341,6 +341,50 @@ def quickgelu_fwd(u, out):
 def stem_im2col(img, out):
     B, _, H, W = img.shape
     check(lib().crog_stem_im2col(dcode(out), ptr(img), ptr(out), B, H, W, stream()), "stem_im2col")
+
+
+def conv_out(n: int, k: int, s: int, p: int) -> int:
+    return (n + 2 * p - k) // s + 1
+
+
+def im2col_nhwc(x, col, kh, kw, stride, pad):
+    """x [B, H, W, C] -> col [B, OH, OW, kh*kw*C]"""
+    B, H, W, C = x.shape
+    OH, OW = conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad)
+    check(lib().crog_im2col_nhwc(dcode(x), ptr(x), mat(x)[2], ptr(col), mat(col)[2], B, H, W, C, kh, kw, stride, pad, OH, OW, stream()), "im2col_nhwc")
+
+
+def col2im_nhwc(dcol, dx, kh, kw, stride, pad):
+    B, H, W, C = dx.shape
+    OH, OW = conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad)
+    check(lib().crog_col2im_nhwc(dcode(dx), ptr(dcol), mat(dcol)[2], ptr(dx), mat(dx)[2], B, H, W, C, kh, kw, stride, pad, OH, OW, stream()), "col2im_nhwc")
+
+
+def im2col_image(img, col, kh, kw, stride, pad):
+    """NCHW fp32 image -> col [B, OH, OW, ldo] (zero beyond kh*kw*C)"""
+    B, C, H, W = img.shape
+    OH, OW = conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad)
+    check(lib().crog_im2col_image(dcode(col), ptr(img), ptr(col), col.shape[-1], B, C, H, W, kh, kw, stride, pad, OH, OW, stream()), "im2col_image")
+
+
+def maxpool3s2_fwd(x, y, arg):
+    B, H, W, C = x.shape
+    check(lib().crog_maxpool3s2_fwd(dcode(x), ptr(x), mat(x)[2], ptr(y), mat(y)[2], ptr(arg), B, H, W, C, stream()), "maxpool3s2_fwd")
+
+
+def maxpool3s2_bwd(dy, arg, dx):
+    B, H, W, C = dx.shape
+    check(lib().crog_maxpool3s2_bwd(dcode(dx), ptr(dy), mat(dy)[2], ptr(arg), ptr(dx), mat(dx)[2], B, H, W, C, stream()), "maxpool3s2_bwd")
+
+
+def upsample2ac_fwd(x, y):
+    B, H, W, C = x.shape
+    check(lib().crog_upsample2ac_fwd(dcode(x), ptr(x), mat(x)[2], ptr(y), mat(y)[2], B, H, W, C, stream()), "upsample2ac_fwd")
+
+
+def upsample2ac_bwd(dy, dx):
+    B, H, W, C = dx.shape
+    check(lib().crog_upsample2ac_bwd(dcode(dx), ptr(dy), mat(dy)[2], ptr(dx), mat(dx)[2], B, H, W, C, stream()), "upsample2ac_bwd")
 
 
 def patchify(img, out, patch: int):

@@ -111,3 +111,43 @@ def synthetic_batch(B: int, size: int = 416, L: int = 20, vocab: int = 49408, se
     cos = torch.cos(2 * theta) * mask
     out = dict(img=img, word=word, mask=mask, qua=qua, sin=sin, cos=cos, wid=wid)
     return {k: v.to(device) for k, v in out.items()}
+
+
+# ---- SSG-R50 (BASELINE config 5) ---------------------------------------------------------------------------------
+def ssg_cfg(**over):
+    """Model keys of config/OCID-Grasp/ssg_r50.yaml."""
+    cfg = dict(backbone="resnet", resnet_layers=[3, 4, 6, 3], fpn_in_channels=[512, 1024, 2048], num_protos=32, num_classes=32,
+               anchor_strides=[8, 16, 32, 64, 128], aspect_ratios=[1, 0.5, 2], img_size=544, with_depth=True, with_grasp_masks=True,
+               path_to_pretrained_resnet=None, resume=None)
+    cfg.update(over)
+    return SimpleNamespace(**cfg)
+
+
+def ssg_tiny_cfg(**over):
+    """Real channel widths, one Bottleneck per stage, 96x96 input (pyramid 12, 6, 3, 2, 1)."""
+    base = dict(resnet_layers=[1, 1, 1, 1], img_size=96)
+    base.update(over)
+    return ssg_cfg(**base)
+
+
+def synthetic_ssg_batch(B: int, size: int, with_depth: bool, seed: int = 1234, device="cpu"):
+    """rgb ~ U(0,1) (augmentation.py:150 scales to [0,1]), depth ~ U(0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    out = dict(rgb=torch.rand(B, 3, size, size, generator=g))
+    if with_depth:
+        out["depth"] = torch.rand(B, 1, size, size, generator=g)
+    return {k: v.to(device) for k, v in out.items()}
+
+
+SSG_OUTPUTS = ("class_pred", "box_pred", "ins_coef_pred", "grasp_coef_pred", "protos", "seg_pred")
+
+
+def ssg_surrogate_loss(raw: Dict[str, torch.Tensor], seed: int = 0) -> torch.Tensor:
+    """Fixed pseudo-random linear functional of the six raw trunk outputs: drives a backward pass through every head
+    without the data-dependent matching loss (ssg.py:297-530), so trunk gradients can be pinned against the reference."""
+    total = 0.0
+    for k in SSG_OUTPUTS:
+        t = raw[k]
+        r = torch.randn(t.shape, generator=_gen("ssg-loss::" + k, seed)).to(device=t.device, dtype=t.dtype)
+        total = total + (t * r).mean()
+    return total

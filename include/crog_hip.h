@@ -57,7 +57,7 @@ enum crog_b_layout {
   CROG_B_NC_IM2COL = 3  /* wgrad of conv3x3: B_mem[k = pixel][n = tap*convC + c] gathered from an
                            NHWC map [B,H,W,convC] (row stride ldb); K = B*H*W                    */
 };
-enum crog_act { CROG_ACT_NONE = 0, CROG_ACT_RELU = 1, CROG_ACT_QUICKGELU = 2 };
+enum crog_act { CROG_ACT_NONE = 0, CROG_ACT_RELU = 1, CROG_ACT_QUICKGELU = 2, CROG_ACT_TANH = 3 };
 enum crog_out_mode {
   CROG_OUT_T = 0,         /* store as dtype                                                      */
   CROG_OUT_F32 = 1,       /* store fp32                                                          */
@@ -221,6 +221,27 @@ int crog_vit_tokens_fwd(int dtype, const void* y, int64_t ldy, const void* cls, 
                         int B, int T, int C, crog_stream_t stream);
 int crog_vit_tokens_bwd(int dtype, const void* dtok, void* dy, int64_t lddy, float* gcls, float* gpos,
                         int B, int T, int C, crog_stream_t stream);
+/* ---- SSG trunk staging (BASELINE config 5; model/ssg.py) -------------------------------------------------------------
+ * Strided / large-window convolutions (7x7 s2 stem ssg.py:63, 3x3 s2 ssg.py:22,188-191, 1x1 s2 ssg.py:79) run as
+ * im2col rows -> crog_gemm (K = KH*KW*C, weights physically [Cout][ky][kx][ci]); the data gradient is crog_gemm
+ * (dcol = dz W) -> col2im.  Column order (ky*KW + kx)*C + c; OH = floor((H + 2P - KH)/S) + 1. */
+int crog_im2col_nhwc(int dtype, const void* x, int64_t ldx, void* col, int64_t ldo, int B, int H, int W, int C,
+                     int KH, int KW, int S, int P, int OH, int OW, crog_stream_t stream);
+int crog_col2im_nhwc(int dtype, const void* dcol, int64_t ldc, void* dx, int64_t lddx, int B, int H, int W, int C,
+                     int KH, int KW, int S, int P, int OH, int OW, crog_stream_t stream);
+/* NCHW fp32 image (C = 3 RGB or 4 RGB-D, ssg.py:217-222,250-253) -> patch rows, columns >= KH*KW*C zero up to ldo */
+int crog_im2col_image(int dtype, const float* img, void* col, int64_t ldo, int B, int C, int H, int W,
+                      int KH, int KW, int S, int P, int OH, int OW, crog_stream_t stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) ssg.py:66; argmax: one byte per output element (window position) */
+int crog_maxpool3s2_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, void* argmax,
+                        int B, int H, int W, int C, crog_stream_t stream);
+int crog_maxpool3s2_bwd(int dtype, const void* dy, int64_t lddy, const void* argmax, void* dx, int64_t lddx,
+                        int B, int H, int W, int C, crog_stream_t stream);
+/* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) ssg.py:159.  (H, W) is the INPUT size. */
+int crog_upsample2ac_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C,
+                         crog_stream_t stream);
+int crog_upsample2ac_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int H, int W,
+                         int C, crog_stream_t stream);
 /* dst[r][c] = c < cols_src ? src[r][c] : 0 for c < cols_dst (fp32 source) */
 int crog_cast_pad2d(int dtype_dst, const float* src, int64_t lds, int cols_src, void* dst, int64_t ldd,
                     int cols_dst, int64_t rows, crog_stream_t stream);

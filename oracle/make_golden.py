@@ -19,7 +19,8 @@ REF = os.environ.get("CROG_REFERENCE", "/root/reference")
 import numpy as np
 import torch
 
-from crog_amd.testing import make_cfg, seeded_state, synthetic_batch, tiny_cfg
+from crog_amd.testing import (SSG_OUTPUTS, make_cfg, seeded_state, ssg_surrogate_loss, ssg_tiny_cfg, synthetic_batch,
+                              synthetic_ssg_batch, tiny_cfg)
 
 GOLD = os.path.join(REPO, "tests", "golden")
 
@@ -195,6 +196,47 @@ def vit_fixture(ref_clip):
     print("vit fixture: out", tuple(o.shape), "absmax", float(o.abs().max()), flush=True)
 
 
+def ssg_fixture(name, cfg, B, seed):
+    """BASELINE config 5 (SSG-R50), trunk-level pin: the reference's own SSG sub-modules driven exactly as SSG.forward does
+    (ssg.py:248-281) on a seeded state and batch; raw predictions, surrogate-loss gradients, BN running statistics, and the
+    eval-mode output_dict (anchors, class softmax)."""
+    import model.ssg as ref_ssg
+    torch.manual_seed(0)
+    m = ref_ssg.SSG(cfg)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(seeded_state(shapes, seed=seed))
+    batch = synthetic_ssg_batch(B, cfg.img_size, cfg.with_depth, seed=1234 + seed)
+    img = torch.cat([batch["rgb"], batch["depth"]], 1) if cfg.with_depth else batch["rgb"]
+    m.train()
+    x = m.backbone(img)
+    x = m.fpn(x[1:4])
+    protos = m.proto_net(x[0]).permute(0, 2, 3, 1).contiguous()
+    per = [m.prediction_layers(a) for a in x]
+    raw = {k: torch.cat([p[i] for p in per], dim=1) for i, k in enumerate(SSG_OUTPUTS[:4])}
+    raw["protos"] = protos
+    raw["seg_pred"] = m.semantic_seg_conv(x[0])
+    loss = ssg_surrogate_loss(raw, seed)
+    loss.backward()
+    out = {k: v.detach() for k, v in raw.items()}
+    out["loss"] = loss.detach()
+    names = [n for n, _ in m.named_parameters()]
+    out["grad_norms"] = torch.tensor([float(p.grad.norm()) for _, p in m.named_parameters()])
+    for n, p in m.named_parameters():   # direction pins: the head of every gradient
+        out["grad::" + n] = p.grad.flatten()[:64].clone()
+    bn = {k: float(v.double().sum()) for k, v in m.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    out["bn_running_checksum"] = torch.tensor([bn[k] for k in sorted(bn)])
+    m.eval()
+    with torch.no_grad():
+        ev = m(batch)
+    out["eval_cls_pred"] = ev["cls_pred"]
+    out["eval_box_pred"] = ev["box_pred"]
+    out["anchors"] = torch.tensor(ev["anchors"])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **{k: v.detach().numpy() for k, v in out.items()})
+    json.dump(dict(param_names=names, shapes={k: list(v) for k, v in shapes.items()}, seed=seed, B=B, bn_keys=sorted(bn),
+                   cfg={k: v for k, v in vars(cfg).items()}), open(os.path.join(GOLD, name + ".json"), "w"))
+    print(name, "loss", float(loss), "anchors", len(ev["anchors"]) // 4, flush=True)
+
+
 def shapes_only(ref_clip):
     """Parameter names/shapes of the real CLIP RN50 and ViT-B/16 towers + CROG heads (names are the checkpoint contract)."""
     vit = ref_clip.CLIP(512, 224, 12, 768, 16, 77, 20, 49408, 512, 8, 12)
@@ -204,7 +246,7 @@ def shapes_only(ref_clip):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_clip, ref_crog, ref_layers = import_reference()
-    which = sys.argv[1:] or ["tiny", "ops", "vit", "shapes", "full"]
+    which = sys.argv[1:] or ["tiny", "ops", "vit", "ssg", "shapes", "full"]
     if "tiny" in which:
         run_case("tiny_crog", tiny_cfg(), B=4, seed=3, ref_model=ref_model, ref_clip=ref_clip, store_intermediates=True)
         run_case("tiny_crog_nomask", tiny_cfg(use_grasp_masks=False), B=4, seed=4, ref_model=ref_model, ref_clip=ref_clip,
@@ -213,6 +255,9 @@ def main():
         op_fixtures(ref_clip, ref_layers)
     if "vit" in which:
         vit_fixture(ref_clip)
+    if "ssg" in which:
+        ssg_fixture("ssg_tiny_rgbd", ssg_tiny_cfg(), B=2, seed=6)
+        ssg_fixture("ssg_tiny_rgb", ssg_tiny_cfg(with_depth=False), B=2, seed=7)
     if "shapes" in which:
         shapes_only(ref_clip)
     if "full" in which:

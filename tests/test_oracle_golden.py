@@ -172,3 +172,36 @@ def test_oracle_vit_tower_matches_reference():
     for k, v in fx.items():
         if k.startswith("dw::"):
             check(P["v." + k[4:]].grad, v, atol=5e-5, rtol=1e-3, what="vit " + k)
+
+
+@pytest.mark.parametrize("case", ["ssg_tiny_rgbd", "ssg_tiny_rgb"])
+def test_oracle_ssg_trunk_matches_reference(case):
+    """BASELINE config 5 (SSG-R50): oracle/ssg_oracle.py against the reference's own SSG modules (fixture written by
+    oracle/make_golden.py ssg): raw predictions, surrogate-loss gradients, BN running statistics, anchors, class softmax."""
+    from types import SimpleNamespace
+    from crog_amd.testing import SSG_OUTPUTS, ssg_surrogate_loss, synthetic_ssg_batch
+    from oracle import ssg_oracle as S
+    fx, meta = load_case(case)
+    cfg = SimpleNamespace(**meta["cfg"])
+    P = seeded_state({k: tuple(v) for k, v in meta["shapes"].items()}, seed=meta["seed"])
+    for n in meta["param_names"]:
+        P[n].requires_grad_(True)
+    batch = synthetic_ssg_batch(meta["B"], cfg.img_size, cfg.with_depth, seed=1234 + meta["seed"])
+    img = torch.cat([batch["rgb"], batch["depth"]], 1) if cfg.with_depth else batch["rgb"]
+    raw = S.ssg_trunk(P, img, cfg.num_classes, cfg.num_protos, training=True)
+    for k in SSG_OUTPUTS:
+        check(raw[k], fx[k], atol=2e-5, what=f"{case} {k}")
+    loss = ssg_surrogate_loss(raw, meta["seed"])
+    check(loss, fx["loss"], atol=1e-6, what="loss")
+    loss.backward()
+    gn = torch.tensor([float(P[n].grad.norm()) for n in meta["param_names"]])
+    check(gn, fx["grad_norms"], atol=1e-6, rtol=2e-3, what="grad norms")
+    for n in meta["param_names"]:
+        check(P[n].grad.flatten()[:64], fx["grad::" + n], atol=2e-6, rtol=2e-3, what="grad " + n)
+    bn = torch.tensor([float(P[k].double().sum()) for k in meta["bn_keys"]])
+    check(bn, fx["bn_running_checksum"], atol=1e-3, what="bn running stats")
+    check(torch.tensor(S.anchors(cfg.aspect_ratios, cfg.img_size, cfg.anchor_strides)), fx["anchors"], atol=1e-7, what="anchors")
+    with torch.no_grad():
+        ev = S.ssg_trunk(P, img, cfg.num_classes, cfg.num_protos, training=False)
+    check(torch.softmax(ev["class_pred"], -1), fx["eval_cls_pred"], atol=2e-5, what="eval cls_pred")
+    check(ev["box_pred"], fx["eval_box_pred"], atol=2e-5, what="eval box_pred")
