@@ -539,3 +539,97 @@ def test_bn_backward_relu_mask_from_z_equals_mask_from_y(K, dt):
         K.bn_bwd_apply(dy, None if use_z else y, z, mi, gamma, sums, M, dz, None, ss if use_z else None)
         outs.append((sums.clone(), dz.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+# ---- SSG / ViT staging kernels ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("H,W,C,k,s,p", [(9, 7, 16, 3, 2, 1), (8, 8, 32, 1, 2, 0), (5, 6, 8, 3, 1, 1), (1, 1, 8, 3, 2, 1), (13, 13, 8, 7, 2, 3)])
+def test_im2col_col2im(K, dt, H, W, C, k, s, p):
+    """im2col rows == F.unfold in (ky, kx, c) column order; col2im == its exact transpose (fold)."""
+    B = 2
+    x = rnd(B, H, W, C, dt=dt)
+    OH, OW = K.conv_out(H, k, s, p), K.conv_out(W, k, s, p)
+    col = torch.empty(B, OH, OW, k * k * C, device="cuda", dtype=dt)
+    K.im2col_nhwc(x, col, k, k, s, p)
+    xt = x.float().permute(0, 3, 1, 2)
+    ref = F.unfold(xt, k, padding=p, stride=s).view(B, C, k * k, OH * OW).permute(0, 3, 2, 1).reshape(B, OH, OW, k * k * C)
+    assert torch.equal(col.float(), ref)          # pure data movement: bit exact
+    dcol = rnd(B, OH, OW, k * k * C, dt=dt, seed=5)
+    dx = torch.empty_like(x)
+    K.col2im_nhwc(dcol, dx, k, k, s, p)
+    fold_in = dcol.float().view(B, OH * OW, k * k, C).permute(0, 3, 2, 1).reshape(B, C * k * k, OH * OW)
+    refdx = F.fold(fold_in, (H, W), k, padding=p, stride=s).permute(0, 2, 3, 1)
+    close(dx, refdx, dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("Cimg", [3, 4])
+def test_im2col_image_and_patchify(K, dt, Cimg):
+    B, H, W = 2, 18, 22
+    img = rnd(B, Cimg, H, W)
+    k, s, p = 7, 2, 3
+    OH, OW = K.conv_out(H, k, s, p), K.conv_out(W, k, s, p)
+    kc = k * k * Cimg
+    kp = (kc + 7) // 8 * 8
+    col = torch.full((B, OH, OW, kp), 7.0, device="cuda", dtype=dt)
+    K.im2col_image(img, col, k, k, s, p)
+    ref = F.unfold(img, k, padding=p, stride=s).view(B, Cimg, k * k, OH * OW).permute(0, 3, 2, 1).reshape(B, OH, OW, kc)
+    assert torch.equal(col[..., :kc].float(), ref.to(dt).float())
+    assert float(col[..., kc:].abs().max()) == 0.0 if kp > kc else True
+    if Cimg == 3:
+        P = 2
+        out = torch.empty(B * (H // P) * (W // P), 3 * P * P, device="cuda", dtype=dt)
+        K.patchify(img, out, P)
+        refp = F.unfold(img, P, stride=P).view(B, 3, P * P, -1).permute(0, 3, 2, 1).reshape(-1, 3 * P * P)
+        assert torch.equal(out.float(), refp.to(dt).float())
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("H,W", [(8, 8), (7, 9), (1, 3)])
+def test_maxpool3s2(K, dt, H, W):
+    B, C = 2, 16
+    x = rnd(B, H, W, C, dt=dt)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, OH, OW, C, device="cuda", dtype=dt)
+    arg = torch.empty(B, OH, OW, C, device="cuda", dtype=torch.uint8)
+    K.maxpool3s2_fwd(x, y, arg)
+    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.max_pool2d(xt, 3, 2, 1)
+    assert torch.equal(y.float(), ref.permute(0, 2, 3, 1))
+    dy = rnd(B, OH, OW, C, dt=dt, seed=3)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    dx = torch.empty_like(x)
+    K.maxpool3s2_bwd(dy, arg, dx)
+    close(dx, xt.grad.permute(0, 2, 3, 1), dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("H,W", [(6, 10), (17, 17), (1, 2)])
+def test_upsample2_align_corners(K, dt, H, W):
+    B, C = 2, 16
+    x = rnd(B, H, W, C, dt=dt)
+    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    up = torch.empty(B, 2 * H, 2 * W, C, device="cuda", dtype=dt)
+    K.upsample2ac_fwd(x, up)
+    ref = F.interpolate(xt, scale_factor=2, mode="bilinear", align_corners=True)
+    close(up, ref.permute(0, 2, 3, 1), dt)
+    dup = rnd(B, 2 * H, 2 * W, C, dt=dt, seed=3)
+    ref.backward(dup.float().permute(0, 3, 1, 2))
+    dx = torch.empty_like(x)
+    K.upsample2ac_bwd(dup, dx)
+    close(dx, xt.grad.permute(0, 2, 3, 1), dt, scale=2)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_tanh_epilogue_and_act_bwd(K, dt):
+    M, N, Kd = 100, 24, 40
+    x, w = rnd(M, Kd, dt=dt), rnd(N, Kd, dt=dt, seed=1) * 0.2
+    b = rnd(N, seed=2)
+    y = torch.empty(M, N, device="cuda", dtype=dt)
+    K.gemm(K.dcode(dt), K.A_KC, K.B_KC, x, w, y, M, N, Kd, Kd, Kd, N, bias=b, act=K.ACT_TANH)
+    ref = torch.tanh(x.float() @ w.float().t() + b)
+    close(y, ref, dt)
+    dy = rnd(M, N, dt=dt, seed=4)
+    dz = torch.empty_like(dy)
+    K.act_bwd(dy, y, dz, 2)
+    close(dz, dy.float() * (1 - y.float() ** 2), dt)
