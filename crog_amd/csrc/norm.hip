@@ -1,6 +1,7 @@
 // BatchNorm (training, cross-replica capable), LayerNorm and masked softmax kernels.
 // All are HBM-bound streaming kernels: 16-byte vector loads, fp32 math, wave-shuffle reductions.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -313,163 +314,287 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
 //   out2 = out + pos[row % pos_rows]                       (with_pos_embed, layers.py:310-311,323)
 // stats[row] = (mean, rstd) for backward.
 // =============================================================================================
-template <typename T>
+template <int VEC>
+__device__ inline void ld_f32v(const float* __restrict__ p, float (&o)[VEC]) {   // p is 16-byte aligned (parameter blocks are)
+#pragma unroll
+  for (int i = 0; i < VEC / 4; i++) {
+    const float4 t = *reinterpret_cast<const float4*>(p + 4 * i);
+    o[4 * i] = t.x; o[4 * i + 1] = t.y; o[4 * i + 2] = t.z; o[4 * i + 3] = t.w;
+  }
+}
+
+// NV = 16-byte vectors per lane (C <= 64 * VEC * NV): registers and instruction count scale with the row width instead of
+// the 2048-wide worst case.  Each wave walks rows with a grid stride and issues the NEXT row's loads before it reduces the
+// current one, so two rows of loads are always in flight per wave (a lone 16-byte load per lane is latency-, not
+// bandwidth-bound: the single-row version measured 0.9 TB/s).
+template <typename T, int NV>
 __global__ void __launch_bounds__(NT) ln_fwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float eps, long M, int C, T* __restrict__ out,
                                                     long ldo, float* __restrict__ stats, const T* __restrict__ res, long ldr,
                                                     T* __restrict__ out2, long ldo2, const T* __restrict__ pos, int pos_rows, long ldp,
                                                     float p_in, uint64_t seed_in, float p_out, uint64_t seed_out) {
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int MAXV = 2048 / (64 * VEC);  // up to C = 2048: 4 (bf16) or 8 (f32) 16-byte vectors per lane
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  const long stride = (long)gridDim.x * (NT / 64);
+  long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
   if (row >= M) return;
   const int cvec = C / VEC;
   const uint32_t thr_in = (uint32_t)(p_in * 4294967296.0), thr_out = (uint32_t)(p_out * 4294967296.0);
   const float sc_in = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, sc_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
-  float vals[MAXV][VEC];
-  float s = 0.f;
+  const float invC = 1.f / C;
+  constexpr bool PF = NV <= 2;   // wide rows already keep >= 4 loads per lane in flight; prefetching them only costs registers
+  constexpr int NP = PF ? NV : 1;
+  Vec16<T> cur[NV], nxt[NP];
+  if (PF) {
 #pragma unroll
-  for (int j = 0; j < MAXV; j++) {
-    const int cv = lane + j * 64;
-    if (cv < cvec) {
-      Vec16<T> v = ldg16(x + row * ldx + cv * VEC);
-#pragma unroll
-      for (int e = 0; e < VEC; e++) {
-        float f = Elem<T>::to_f(v.v[e]);
-        if (p_in > 0.f) f = dropout_keep(seed_in, (uint64_t)row * C + cv * VEC + e, thr_in) ? f * sc_in : 0.f;
-        vals[j][e] = f;
-        s += f;
-      }
+    for (int j = 0; j < NV; j++) {
+      const int cv = lane + j * 64;
+      if (cv < cvec) cur[j] = ldg16(x + row * ldx + cv * VEC);
     }
   }
-  const float mean = wave_sum(s) / C;
-  float q = 0.f;
+  for (; row < M; row += stride) {
+    const long nrow = row + stride;
+    if (!PF) {
 #pragma unroll
-  for (int j = 0; j < MAXV; j++) {
-    const int cv = lane + j * 64;
-    if (cv < cvec)
-#pragma unroll
-      for (int e = 0; e < VEC; e++) {
-        const float d = vals[j][e] - mean;
-        q += d * d;
+      for (int j = 0; j < NV; j++) {
+        const int cv = lane + j * 64;
+        if (cv < cvec) cur[j] = ldg16(x + row * ldx + cv * VEC);
       }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / C + eps);
-  if (lane == 0 && stats) {
-    stats[2 * row] = mean;
-    stats[2 * row + 1] = rstd;
-  }
+    }
+    if (PF && nrow < M) {
 #pragma unroll
-  for (int j = 0; j < MAXV; j++) {
-    const int cv = lane + j * 64;
-    if (cv < cvec) {
-      const int c = cv * VEC;
-      Vec16<T> o, o2, rv, pv;
-      if (res) rv = ldg16(res + row * ldr + c);
-      if (out2 && pos) pv = ldg16(pos + (row % pos_rows) * ldp + c);
-#pragma unroll
-      for (int e = 0; e < VEC; e++) {
-        float f = (vals[j][e] - mean) * rstd * gamma[c + e] + beta[c + e];
-        if (p_out > 0.f) f = dropout_keep(seed_out, (uint64_t)row * C + c + e, thr_out) ? f * sc_out : 0.f;
-        if (res) f += Elem<T>::to_f(rv.v[e]);
-        o.v[e] = Elem<T>::from_f(f);
-        if (out2) o2.v[e] = Elem<T>::from_f(Elem<T>::to_f(o.v[e]) + (pos ? Elem<T>::to_f(pv.v[e]) : 0.f));
+      for (int j = 0; j < NV; j++) {
+        const int cv = lane + j * 64;
+        if (cv < cvec) nxt[j % NP] = ldg16(x + nrow * ldx + cv * VEC);
       }
-      stg16(out + row * ldo + c, o);
-      if (out2) stg16(out2 + row * ldo2 + c, o2);
+    }
+    Vec16<T> rv[NV], pv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int cv = lane + j * 64;
+      if (cv < cvec) {
+        if (res) rv[j] = ldg16(res + row * ldr + cv * VEC);
+        if (out2 && pos) pv[j] = ldg16(pos + (row % pos_rows) * ldp + cv * VEC);
+      }
+    }
+    float vals[NV][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int cv = lane + j * 64;
+      if (cv < cvec) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) vals[j][e] = Elem<T>::to_f(cur[j].v[e]);
+        if (p_in > 0.f) {   // wave-uniform: hoisted around the whole vector so the common p = 0 path stays branch-free
+#pragma unroll
+          for (int e = 0; e < VEC; e++)
+            vals[j][e] = dropout_keep(seed_in, (uint64_t)row * C + cv * VEC + e, thr_in) ? vals[j][e] * sc_in : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) s += vals[j][e];
+      }
+    }
+    const float mean = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int cv = lane + j * 64;
+      if (cv < cvec)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          const float d = vals[j][e] - mean;
+          q += d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+    if (lane == 0 && stats) {
+      stats[2 * row] = mean;
+      stats[2 * row + 1] = rstd;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int cv = lane + j * 64;
+      if (cv < cvec) {
+        const int c = cv * VEC;
+        Vec16<T> o;
+        float gv[VEC], bv[VEC], f[VEC];
+        ld_f32v<VEC>(gamma + c, gv);
+        ld_f32v<VEC>(beta + c, bv);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) f[e] = (vals[j][e] - mean) * rstd * gv[e] + bv[e];
+        if (p_out > 0.f) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) f[e] = dropout_keep(seed_out, (uint64_t)row * C + c + e, thr_out) ? f[e] * sc_out : 0.f;
+        }
+        if (res) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) f[e] += Elem<T>::to_f(rv[j].v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(f[e]);
+        stg16(out + row * ldo + c, o);
+        if (out2) {
+          Vec16<T> o2;
+#pragma unroll
+          for (int e = 0; e < VEC; e++) o2.v[e] = Elem<T>::from_f(Elem<T>::to_f(o.v[e]) + (pos ? Elem<T>::to_f(pv[j].v[e]) : 0.f));
+          stg16(out2 + row * ldo2 + c, o2);
+        }
+      }
+    }
+    if (PF) {
+#pragma unroll
+      for (int j = 0; j < NV; j++) cur[j] = nxt[j % NP];
     }
   }
 }
 
 // LayerNorm backward.  g = dout (+ dout2);  dy = dropout_out_bwd(g);  dxin via LN backward;
 // dx = dropout_in_bwd(dxin).  Per-block partial (dgamma, dbeta) rows go to partial[block][C][2].
-template <typename T>
+template <typename T, int NV>
 __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, long lddo, const T* __restrict__ dout2, long lddo2,
                                                     const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                     const float* __restrict__ stats, long M, int C, T* __restrict__ dx, long lddx,
                                                     float* __restrict__ partial, int rows_per_block, float p_in, uint64_t seed_in,
                                                     float p_out, uint64_t seed_out) {
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int MAXV = 2048 / (64 * VEC);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int cvec = C / VEC;
   const uint32_t thr_in = (uint32_t)(p_in * 4294967296.0), thr_out = (uint32_t)(p_out * 4294967296.0);
   const float sc_in = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, sc_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
-  float dg[MAXV][VEC], db[MAXV][VEC];
+  const float invC = 1.f / C;
+  constexpr bool PF = NV <= 2;   // see ln_fwd_kernel
+  constexpr int NP = PF ? NV : 1;
+  float dg[NV][VEC], db[NV][VEC], gm[NP][VEC];
 #pragma unroll
-  for (int j = 0; j < MAXV; j++)
+  for (int j = 0; j < NV; j++) {
+    const int cv = lane + j * 64;
 #pragma unroll
     for (int e = 0; e < VEC; e++) dg[j][e] = db[j][e] = 0.f;
-
+    if (PF && cv < cvec) ld_f32v<VEC>(gamma + cv * VEC, gm[j % NP]);
+  }
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = min(r0 + rows_per_block, M);
-  for (long row = r0 + wv; row < r1; row += NT / 64) {
+  long row = r0 + wv;
+  Vec16<T> cg[NV], cg2[NV], cx[NV], ng[NP], ng2[NP], nx[NP];
+  if (PF && row < r1) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int cv = lane + j * 64;
+      if (cv < cvec) {
+        cg[j] = ldg16(dout + row * lddo + cv * VEC);
+        if (dout2) cg2[j] = ldg16(dout2 + row * lddo2 + cv * VEC);
+        cx[j] = ldg16(x + row * ldx + cv * VEC);
+      }
+    }
+  }
+  for (; row < r1; row += NT / 64) {
+    const long nrow = row + NT / 64;
+    if (!PF) {
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        const int cv = lane + j * 64;
+        if (cv < cvec) {
+          cg[j] = ldg16(dout + row * lddo + cv * VEC);
+          if (dout2) cg2[j] = ldg16(dout2 + row * lddo2 + cv * VEC);
+          cx[j] = ldg16(x + row * ldx + cv * VEC);
+        }
+      }
+    }
+    if (PF && nrow < r1) {
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        const int cv = lane + j * 64;
+        if (cv < cvec) {
+          ng[j % NP] = ldg16(dout + nrow * lddo + cv * VEC);
+          if (dout2) ng2[j % NP] = ldg16(dout2 + nrow * lddo2 + cv * VEC);
+          nx[j % NP] = ldg16(x + nrow * ldx + cv * VEC);
+        }
+      }
+    }
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    float xh[MAXV][VEC], gy[MAXV][VEC];
+    float xh[NV][VEC], gy[NV][VEC];
     float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXV; j++) {
+    for (int j = 0; j < NV; j++) {
       const int cv = lane + j * 64;
       if (cv < cvec) {
         const int c = cv * VEC;
-        Vec16<T> g = ldg16(dout + row * lddo + c);
-        Vec16<T> g2;
-        if (dout2) g2 = ldg16(dout2 + row * lddo2 + c);
-        Vec16<T> xv = ldg16(x + row * ldx + c);
+        float gf[VEC], xf[VEC], gmv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) { gf[e] = Elem<T>::to_f(cg[j].v[e]); xf[e] = Elem<T>::to_f(cx[j].v[e]); }
+        if (dout2) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) gf[e] += Elem<T>::to_f(cg2[j].v[e]);
+        }
+        if (p_out > 0.f) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) gf[e] = dropout_keep(seed_out, (uint64_t)row * C + c + e, thr_out) ? gf[e] * sc_out : 0.f;
+        }
+        if (p_in > 0.f) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) xf[e] = dropout_keep(seed_in, (uint64_t)row * C + c + e, thr_in) ? xf[e] * sc_in : 0.f;
+        }
+        if (PF) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) gmv[e] = gm[j % NP][e];
+        } else {
+          ld_f32v<VEC>(gamma + c, gmv);
+        }
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
-          float gf = Elem<T>::to_f(g.v[e]);
-          if (dout2) gf += Elem<T>::to_f(g2.v[e]);
-          if (p_out > 0.f) gf = dropout_keep(seed_out, (uint64_t)row * C + c + e, thr_out) ? gf * sc_out : 0.f;
-          float xf = Elem<T>::to_f(xv.v[e]);
-          if (p_in > 0.f) xf = dropout_keep(seed_in, (uint64_t)row * C + c + e, thr_in) ? xf * sc_in : 0.f;
-          const float h = (xf - mean) * rstd;
+          const float h = (xf[e] - mean) * rstd;
           xh[j][e] = h;
-          dg[j][e] += gf * h;
-          db[j][e] += gf;
-          const float gyv = gf * gamma[c + e];
+          dg[j][e] += gf[e] * h;
+          db[j][e] += gf[e];
+          const float gyv = gf[e] * gmv[e];
           gy[j][e] = gyv;
           a += gyv;
           b += gyv * h;
         }
       }
     }
-    a = wave_sum(a) / C;
-    b = wave_sum(b) / C;
+    a = wave_sum(a) * invC;
+    b = wave_sum(b) * invC;
 #pragma unroll
-    for (int j = 0; j < MAXV; j++) {
+    for (int j = 0; j < NV; j++) {
       const int cv = lane + j * 64;
       if (cv < cvec) {
         const int c = cv * VEC;
         Vec16<T> o;
+        float d[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; e++) {
-          float d = rstd * (gy[j][e] - a - xh[j][e] * b);
-          if (p_in > 0.f) d = dropout_keep(seed_in, (uint64_t)row * C + c + e, thr_in) ? d * sc_in : 0.f;
-          o.v[e] = Elem<T>::from_f(d);
+        for (int e = 0; e < VEC; e++) d[e] = rstd * (gy[j][e] - a - xh[j][e] * b);
+        if (p_in > 0.f) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) d[e] = dropout_keep(seed_in, (uint64_t)row * C + c + e, thr_in) ? d[e] * sc_in : 0.f;
         }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(d[e]);
         stg16(dx + row * lddx + c, o);
       }
+    }
+    if (PF) {
+#pragma unroll
+      for (int j = 0; j < NV; j++) { cg[j] = ng[j % NP]; cg2[j] = ng2[j % NP]; cx[j] = nx[j % NP]; }
     }
   }
   // combine the block's 4 waves through LDS, then one plain store per value into this block's partial row
   __shared__ float red[NT / 64][2 * 2048 / 8 + 1];
   float* dst = partial + (long)blockIdx.x * C * 2;
-  for (int cg = 0; cg < 2 * C; cg += 2 * 2048 / 8) {  // 512 floats (256 channels) per round keeps LDS at 8 KB
+  for (int cg_ = 0; cg_ < 2 * C; cg_ += 2 * 2048 / 8) {  // 512 floats (256 channels) per round keeps LDS at 8 KB
 #pragma unroll
-    for (int j = 0; j < MAXV; j++) {
+    for (int j = 0; j < NV; j++) {
       const int cv = lane + j * 64;
       if (cv < cvec)
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
-          const int f = 2 * (cv * VEC + e) - cg;
+          const int f = 2 * (cv * VEC + e) - cg_;
           if (f >= 0 && f < 2 * 2048 / 8) { red[wv][f] = dg[j][e]; red[wv][f + 1] = db[j][e]; }
         }
     }
     __syncthreads();
-    for (int f = threadIdx.x; f < 2 * 2048 / 8 && cg + f < 2 * C; f += NT)
-      dst[cg + f] = red[0][f] + red[1][f] + red[2][f] + red[3][f];
+    for (int f = threadIdx.x; f < 2 * 2048 / 8 && cg_ + f < 2 * C; f += NT)
+      dst[cg_ + f] = red[0][f] + red[1][f] + red[2][f] + red[3][f];
     __syncthreads();
   }
 }
@@ -489,87 +614,141 @@ __global__ void split_pairs_kernel(const float* __restrict__ sums, int C, float*
 //   columns >= Lk (row padding up to ldp) are written as 0 so they can feed the P.V GEMM.
 //   P  = softmax probabilities;  Pd (optional) = dropout(P)  (nn.MultiheadAttention dropout, layers.py:291)
 // =============================================================================================
-template <typename T>
+// LPR lanes share one row (64 / LPR rows per wave), each lane owns NJ 16-byte vectors: (LPR, NJ) = (4, 1) covers the
+// 20-key rows of the text tower / cross attention (16 rows per wave instead of one), (64, 2) the 676-key decoder rows.
+template <int LPR>
+__device__ inline float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int LPR>
+__device__ inline float group_max(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <typename T, int LPR, int NJ>
 __global__ void __launch_bounds__(NT) softmax_fwd_kernel(T* __restrict__ S, long rows, int Lq, int Lk, int ldp, int heads,
                                                          int causal, const uint8_t* __restrict__ kpm, T* __restrict__ Pd,
                                                          float p_drop, uint64_t seed) {
-  constexpr int MAXE = 12;  // Lk up to 768
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int q = (int)(row % Lq);
-  const long b = row / ((long)heads * Lq);
-  T* s = S + row * ldp;
-  float v[MAXE];
+  constexpr int VEC = Elem<T>::VEC, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const long row = ((long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool live = row < rows;
+  const long rr = live ? row : rows - 1;          // dead lanes shadow the last row: the group shuffles stay convergent
+  const int q = (int)(rr % Lq);
+  const long b = rr / ((long)heads * Lq);
+  T* s = S + rr * ldp;
+  const int nvec = ldp / VEC;
+  float v[NJ][VEC];
   float mx = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < MAXE; j++) {
-    const int k = lane + j * 64;
-    float f = -INFINITY;
-    if (k < Lk) {
-      f = Elem<T>::to_f(s[k]);
-      if (causal && k > q) f = -INFINITY;
-      if (kpm && kpm[b * Lk + k]) f = -INFINITY;
+  for (int j = 0; j < NJ; j++) {
+    const int k0 = (sub + j * LPR) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) v[j][e] = -INFINITY;
+    if (sub + j * LPR < nvec) {
+      const Vec16<T> t = ldg16(s + k0);
+#pragma unroll
+      for (int e = 0; e < VEC; e++)
+        if (k0 + e < Lk) v[j][e] = Elem<T>::to_f(t.v[e]);
+      if (causal) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++)
+          if (k0 + e > q) v[j][e] = -INFINITY;
+      }
+      if (kpm) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++)
+          if (k0 + e < Lk && kpm[b * Lk + k0 + e]) v[j][e] = -INFINITY;
+      }
     }
-    v[j] = f;
-    mx = fmaxf(mx, f);
+#pragma unroll
+    for (int e = 0; e < VEC; e++) mx = fmaxf(mx, v[j][e]);
   }
-  mx = wave_max(mx);
+  mx = group_max<LPR>(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < MAXE; j++) {
-    const float e = (v[j] == -INFINITY) ? 0.f : expf(v[j] - mx);
-    v[j] = e;
-    sum += e;
-  }
-  sum = wave_sum(sum);
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      const float ex = (v[j][e] == -INFINITY) ? 0.f : expf(v[j][e] - mx);
+      v[j][e] = ex;
+      sum += ex;
+    }
+  sum = group_sum<LPR>(sum);
   const float inv = 1.f / sum;  // a fully masked row gives NaN exactly as torch does
   const uint32_t thr = (uint32_t)(p_drop * 4294967296.0);
   const float sc = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  if (!live) return;
 #pragma unroll
-  for (int j = 0; j < MAXE; j++) {
-    const int k = lane + j * 64;
-    if (k < ldp) {
-      const float pv = (k < Lk) ? v[j] * inv : 0.f;
-      s[k] = Elem<T>::from_f(pv);
+  for (int j = 0; j < NJ; j++) {
+    const int k0 = (sub + j * LPR) * VEC;
+    if (sub + j * LPR < nvec) {
+      Vec16<T> o;
+      float pv[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        pv[e] = (k0 + e < Lk) ? v[j][e] * inv : 0.f;     // padding columns are written as 0: they feed the P.V GEMM
+        o.v[e] = Elem<T>::from_f(pv[e]);
+      }
+      stg16(s + k0, o);
       if (Pd) {
-        float pd = pv;
-        if (p_drop > 0.f) pd = dropout_keep(seed, (uint64_t)row * ldp + k, thr) ? pv * sc : 0.f;
-        Pd[row * ldp + k] = Elem<T>::from_f(pd);
+        if (p_drop > 0.f) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(dropout_keep(seed, (uint64_t)row * ldp + k0 + e, thr) ? pv[e] * sc : 0.f);
+        }
+        stg16(Pd + row * ldp + k0, o);
       }
     }
   }
 }
 
 // dS = P * (dP - sum_k dP*P) with dP = dropout_bwd(dPd); written in place over dPd.
-template <typename T>
+template <typename T, int LPR, int NJ>
 __global__ void __launch_bounds__(NT) softmax_bwd_kernel(const T* __restrict__ P, T* __restrict__ dPd, long rows, int Lk, int ldp,
                                                          float p_drop, uint64_t seed) {
-  constexpr int MAXE = 12;
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  constexpr int VEC = Elem<T>::VEC, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const long row = ((long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool live = row < rows;
+  const long rr = live ? row : rows - 1;
   const uint32_t thr = (uint32_t)(p_drop * 4294967296.0);
   const float sc = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-  float pv[MAXE], dp[MAXE];
+  const int nvec = ldp / VEC;
+  float pv[NJ][VEC], dp[NJ][VEC];
   float dot = 0.f;
 #pragma unroll
-  for (int j = 0; j < MAXE; j++) {
-    const int k = lane + j * 64;
-    pv[j] = dp[j] = 0.f;
-    if (k < Lk) {
-      pv[j] = Elem<T>::to_f(P[row * ldp + k]);
-      float d = Elem<T>::to_f(dPd[row * ldp + k]);
-      if (p_drop > 0.f) d = dropout_keep(seed, (uint64_t)row * ldp + k, thr) ? d * sc : 0.f;
-      dp[j] = d;
-      dot += d * pv[j];
+  for (int j = 0; j < NJ; j++) {
+    const int k0 = (sub + j * LPR) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) pv[j][e] = dp[j][e] = 0.f;
+    if (sub + j * LPR < nvec) {
+      const Vec16<T> a = ldg16(P + rr * ldp + k0), g = ldg16(dPd + rr * ldp + k0);
+#pragma unroll
+      for (int e = 0; e < VEC; e++)
+        if (k0 + e < Lk) { pv[j][e] = Elem<T>::to_f(a.v[e]); dp[j][e] = Elem<T>::to_f(g.v[e]); }
+      if (p_drop > 0.f) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) dp[j][e] = dropout_keep(seed, (uint64_t)rr * ldp + k0 + e, thr) ? dp[j][e] * sc : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; e++) dot += dp[j][e] * pv[j][e];
     }
   }
-  dot = wave_sum(dot);
+  dot = group_sum<LPR>(dot);
+  if (!live) return;
 #pragma unroll
-  for (int j = 0; j < MAXE; j++) {
-    const int k = lane + j * 64;
-    if (k < ldp) dPd[row * ldp + k] = Elem<T>::from_f(k < Lk ? pv[j] * (dp[j] - dot) : 0.f);
+  for (int j = 0; j < NJ; j++) {
+    const int k0 = (sub + j * LPR) * VEC;
+    if (sub + j * LPR < nvec) {
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(k0 + e < Lk ? pv[j][e] * (dp[j][e] - dot) : 0.f);
+      stg16(dPd + row * ldp + k0, o);
+    }
   }
 }
 
@@ -686,9 +865,17 @@ extern "C" int crog_ln_fwd(int dtype, const void* x, int64_t ldx, const float* g
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0 && C <= 2048, "ln_fwd: C=%d must be a multiple of %d and <= 2048", C, vec);
   CROG_CHECK_ARG(!pos || pos_rows > 0, "ln_fwd: pos_rows");
-  DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3(cdiv(M, NT / 64)), dim3(NT), 0, (hipStream_t)stream, (const T*)x,
-                                       (long)ldx, gamma, beta, eps, (long)M, C, (T*)out, (long)ldo, stats, (const T*)res, (long)ldr,
-                                       (T*)out2, (long)ldo2, (const T*)pos, pos_rows, (long)ldp, p_in, seed_in, p_out, seed_out));
+  const int nv = cdiv(C / vec, 64);
+  const int blocks = (int)std::min<long>(cdiv(M, NT / 64), 256 * 8);   // 8 blocks (32 waves) per CU, rows by grid stride
+#define CROG_LN_FWD(NV)                                                                                                          \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)x,     \
+                                       (long)ldx, gamma, beta, eps, (long)M, C, (T*)out, (long)ldo, stats, (const T*)res, (long)ldr, \
+                                       (T*)out2, (long)ldo2, (const T*)pos, pos_rows, (long)ldp, p_in, seed_in, p_out, seed_out))
+  if (nv <= 1) CROG_LN_FWD(1);
+  else if (nv <= 2) CROG_LN_FWD(2);
+  else if (nv <= 4) CROG_LN_FWD(4);
+  else CROG_LN_FWD(8);
+#undef CROG_LN_FWD
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
@@ -701,9 +888,16 @@ extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0 && C <= 2048, "ln_bwd: C=%d must be a multiple of %d and <= 2048", C, vec);
   const int blocks = cdiv(M, rows_per_block);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dout, (long)lddo,
-                                       (const T*)dout2, (long)lddo2, (const T*)x, (long)ldx, gamma, stats, (long)M, C, (T*)dx,
-                                       (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out));
+  const int nv = cdiv(C / vec, 64);
+#define CROG_LN_BWD(NV)                                                                                                           \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dout, (long)lddo, \
+                                       (const T*)dout2, (long)lddo2, (const T*)x, (long)ldx, gamma, stats, (long)M, C, (T*)dx,       \
+                                       (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out))
+  if (nv <= 1) CROG_LN_BWD(1);
+  else if (nv <= 2) CROG_LN_BWD(2);
+  else if (nv <= 4) CROG_LN_BWD(4);
+  else CROG_LN_BWD(8);
+#undef CROG_LN_BWD
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
@@ -711,8 +905,19 @@ extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void
 extern "C" int crog_softmax_fwd(int dtype, void* S, int64_t rows, int Lq, int Lk, int ldp, int heads, int causal,
                                 const uint8_t* key_padding_mask, void* Pd, float p_drop, uint64_t seed, crog_stream_t stream) {
   CROG_CHECK_ARG(Lk > 0 && Lk <= ldp && ldp <= 768, "softmax_fwd: need Lk <= ldp <= 768 (Lk=%d ldp=%d)", Lk, ldp);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_fwd_kernel<T>), dim3(cdiv(rows, NT / 64)), dim3(NT), 0, (hipStream_t)stream, (T*)S,
-                                       (long)rows, Lq, Lk, ldp, heads, causal, key_padding_mask, (T*)Pd, p_drop, seed));
+  const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(ldp % vec == 0 && ((uintptr_t)S % 16) == 0 && (!Pd || ((uintptr_t)Pd % 16) == 0), "softmax_fwd: ldp %% %d == 0 and 16-byte aligned rows required", vec);
+  const int nvec = ldp / vec;
+#define CROG_SM_FWD(LPR, NJ)                                                                                                       \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_fwd_kernel<T, LPR, NJ>), dim3(cdiv(rows, (NT / 64) * (64 / LPR))), dim3(NT), 0,    \
+                                       (hipStream_t)stream, (T*)S, (long)rows, Lq, Lk, ldp, heads, causal, key_padding_mask, (T*)Pd, \
+                                       p_drop, seed))
+  if (nvec <= 4) CROG_SM_FWD(4, 1);
+  else if (nvec <= 16) CROG_SM_FWD(16, 1);
+  else if (nvec <= 64) CROG_SM_FWD(64, 1);
+  else if (nvec <= 128) CROG_SM_FWD(64, 2);
+  else CROG_SM_FWD(64, 3);
+#undef CROG_SM_FWD
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
@@ -720,8 +925,18 @@ extern "C" int crog_softmax_fwd(int dtype, void* S, int64_t rows, int Lq, int Lk
 extern "C" int crog_softmax_bwd(int dtype, const void* P, void* dPd, int64_t rows, int Lk, int ldp, float p_drop, uint64_t seed,
                                 crog_stream_t stream) {
   CROG_CHECK_ARG(Lk > 0 && Lk <= ldp && ldp <= 768, "softmax_bwd: need Lk <= ldp <= 768");
-  DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_bwd_kernel<T>), dim3(cdiv(rows, NT / 64)), dim3(NT), 0, (hipStream_t)stream,
-                                       (const T*)P, (T*)dPd, (long)rows, Lk, ldp, p_drop, seed));
+  const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(ldp % vec == 0 && ((uintptr_t)P % 16) == 0 && ((uintptr_t)dPd % 16) == 0, "softmax_bwd: ldp %% %d == 0 and 16-byte aligned rows required", vec);
+  const int nvec = ldp / vec;
+#define CROG_SM_BWD(LPR, NJ)                                                                                                       \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_bwd_kernel<T, LPR, NJ>), dim3(cdiv(rows, (NT / 64) * (64 / LPR))), dim3(NT), 0,    \
+                                       (hipStream_t)stream, (const T*)P, (T*)dPd, (long)rows, Lk, ldp, p_drop, seed))
+  if (nvec <= 4) CROG_SM_BWD(4, 1);
+  else if (nvec <= 16) CROG_SM_BWD(16, 1);
+  else if (nvec <= 64) CROG_SM_BWD(64, 1);
+  else if (nvec <= 128) CROG_SM_BWD(64, 2);
+  else CROG_SM_BWD(64, 3);
+#undef CROG_SM_BWD
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -350,7 +350,7 @@ def test_embedding_gather(K, dt):
     assert torch.equal(g, out[idx])
     dx = torch.zeros_like(out)
     K.scatter_rows(g, idx, dx)
-    assert torch.equal(dx[idx], g) and dx.float().abs().sum() == g.float().abs().sum()
+    assert torch.equal(dx[idx], g) and torch.count_nonzero(dx) == torch.count_nonzero(g)   # rows outside idx stay zero
 
 
 @pytest.mark.parametrize("dt", DT)
