@@ -172,6 +172,25 @@ __global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const floa
   scale_shift[2 * c + 1] = beta[c] - running_mean[c] * sc;
 }
 
+template <int VEC>
+__device__ inline void ld_f32v(const float* __restrict__ p, float (&o)[VEC]) {   // p is 16-byte aligned (parameter blocks are)
+#pragma unroll
+  for (int i = 0; i < VEC / 4; i++) {
+    const float4 t = *reinterpret_cast<const float4*>(p + 4 * i);
+    o[4 * i] = t.x; o[4 * i + 1] = t.y; o[4 * i + 2] = t.z; o[4 * i + 3] = t.w;
+  }
+}
+
+// interleaved per-channel pairs p[2*c], p[2*c+1] for VEC consecutive channels -> two arrays (32-byte aligned source)
+template <int VEC>
+__device__ inline void ld_pairs(const float* __restrict__ p, float (&a)[VEC], float (&b)[VEC]) {
+#pragma unroll
+  for (int i = 0; i < VEC / 2; i++) {
+    const float4 t = *reinterpret_cast<const float4*>(p + 4 * i);
+    a[2 * i] = t.x; b[2 * i] = t.y; a[2 * i + 1] = t.z; b[2 * i + 1] = t.w;
+  }
+}
+
 // y = [relu]( z*scale + shift [+ res] )
 template <typename T>
 __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ z, long ldz, const float* __restrict__ scale_shift,
@@ -187,13 +206,20 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ z, l
     Vec16<T> rv;
     if (res) rv = ldg16(res + r * ldr + c);
     Vec16<T> o;
+    float sc[VEC], sh[VEC], f[VEC];
+    ld_pairs<VEC>(scale_shift + 2 * c, sc, sh);
 #pragma unroll
-    for (int e = 0; e < VEC; e++) {
-      float f = Elem<T>::to_f(v.v[e]) * scale_shift[2 * (c + e)] + scale_shift[2 * (c + e) + 1];
-      if (res) f += Elem<T>::to_f(rv.v[e]);
-      if (relu) f = fmaxf(f, 0.f);
-      o.v[e] = Elem<T>::from_f(f);
+    for (int e = 0; e < VEC; e++) f[e] = Elem<T>::to_f(v.v[e]) * sc[e] + sh[e];
+    if (res) {   // wave-uniform flags are tested once per vector, not per element
+#pragma unroll
+      for (int e = 0; e < VEC; e++) f[e] += Elem<T>::to_f(rv.v[e]);
     }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) f[e] = fmaxf(f[e], 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(f[e]);
     stg16(y + r * ldy + c, o);
   }
 }
@@ -215,27 +241,29 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
     const int c = (cg + tx) * VEC;
     float s1[VEC], s2[VEC], mu[VEC], is[VEC], rsc[VEC], rsh[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; e++) {
-      s1[e] = s2[e] = 0.f;
-      mu[e] = mean_invstd[2 * (c + e)];
-      is[e] = mean_invstd[2 * (c + e) + 1];
-      rsc[e] = relu_ss ? relu_ss[2 * (c + e)] : 0.f;
-      rsh[e] = relu_ss ? relu_ss[2 * (c + e) + 1] : 0.f;
-    }
+    for (int e = 0; e < VEC; e++) s1[e] = s2[e] = rsc[e] = rsh[e] = 0.f;
+    ld_pairs<VEC>(mean_invstd + 2 * c, mu, is);
+    if (relu_ss) ld_pairs<VEC>(relu_ss + 2 * c, rsc, rsh);
     for (long r = r0 + ty; r < r1; r += nty) {
       Vec16<T> g = ldg16(dy + r * lddy + c);
       Vec16<T> zz = ldg16(z + r * ldz + c);
       Vec16<T> yy;
       if (y) yy = ldg16(y + r * ldy + c);
+      float gf[VEC], zf[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; e++) { gf[e] = Elem<T>::to_f(g.v[e]); zf[e] = Elem<T>::to_f(zz.v[e]); }
+      if (y) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) gf[e] = Elem<T>::to_f(yy.v[e]) > 0.f ? gf[e] : 0.f;
+      }
+      if (relu_ss) {   // ReLU mask recomputed from z (no residual): y is not read
+#pragma unroll
+        for (int e = 0; e < VEC; e++) gf[e] = zf[e] * rsc[e] + rsh[e] > 0.f ? gf[e] : 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < VEC; e++) {
-        float gf = Elem<T>::to_f(g.v[e]);
-        const float zf = Elem<T>::to_f(zz.v[e]);
-        if (y && !(Elem<T>::to_f(yy.v[e]) > 0.f)) gf = 0.f;
-        if (relu_ss && !(zf * rsc[e] + rsh[e] > 0.f)) gf = 0.f;   // ReLU mask recomputed from z (no residual): y is not read
-        const float zh = (zf - mu[e]) * is[e];
-        s1[e] += gf;
-        s2[e] += gf * zh;
+        s1[e] += gf[e];
+        s2[e] += gf[e] * ((zf[e] - mu[e]) * is[e]);
       }
     }
 #pragma unroll
@@ -289,17 +317,27 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
     Vec16<T> yy;
     if (y) yy = ldg16(y + r * ldy + c);
     Vec16<T> o, gr;
+    float gf[VEC], zf[VEC], mu[VEC], is[VEC], sg[VEC], sgz[VEC], gm[VEC];
+    ld_pairs<VEC>(mean_invstd + 2 * c, mu, is);
+    ld_pairs<VEC>(sums + 2 * c, sg, sgz);
+    ld_f32v<VEC>(gamma + c, gm);
+#pragma unroll
+    for (int e = 0; e < VEC; e++) { gf[e] = Elem<T>::to_f(g.v[e]); zf[e] = Elem<T>::to_f(zz.v[e]); }
+    if (y) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) gf[e] = Elem<T>::to_f(yy.v[e]) > 0.f ? gf[e] : 0.f;
+    }
+    if (relu_ss) {
+      float rsc[VEC], rsh[VEC];
+      ld_pairs<VEC>(relu_ss + 2 * c, rsc, rsh);
+#pragma unroll
+      for (int e = 0; e < VEC; e++) gf[e] = zf[e] * rsc[e] + rsh[e] > 0.f ? gf[e] : 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < VEC; e++) {
-      float gf = Elem<T>::to_f(g.v[e]);
-      const float zf = Elem<T>::to_f(zz.v[e]);
-      if (y && !(Elem<T>::to_f(yy.v[e]) > 0.f)) gf = 0.f;
-      if (relu_ss && !(zf * relu_ss[2 * (c + e)] + relu_ss[2 * (c + e) + 1] > 0.f)) gf = 0.f;
-      const float mu = mean_invstd[2 * (c + e)], is = mean_invstd[2 * (c + e) + 1];
-      const float zh = (zf - mu) * is;
-      const float d = gamma[c + e] * is * (gf - sums[2 * (c + e)] * inv_count - zh * sums[2 * (c + e) + 1] * inv_count);
-      o.v[e] = Elem<T>::from_f(d);
-      gr.v[e] = Elem<T>::from_f(gf);
+      const float zh = (zf[e] - mu[e]) * is[e];
+      o.v[e] = Elem<T>::from_f(gm[e] * is[e] * (gf[e] - sg[e] * inv_count - zh * sgz[e] * inv_count));
+      gr.v[e] = Elem<T>::from_f(gf[e]);
     }
     stg16(dz + r * lddz + c, o);
     if (dres) stg16(dres + r * lddres + c, gr);
@@ -314,15 +352,6 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
 //   out2 = out + pos[row % pos_rows]                       (with_pos_embed, layers.py:310-311,323)
 // stats[row] = (mean, rstd) for backward.
 // =============================================================================================
-template <int VEC>
-__device__ inline void ld_f32v(const float* __restrict__ p, float (&o)[VEC]) {   // p is 16-byte aligned (parameter blocks are)
-#pragma unroll
-  for (int i = 0; i < VEC / 4; i++) {
-    const float4 t = *reinterpret_cast<const float4*>(p + 4 * i);
-    o[4 * i] = t.x; o[4 * i + 1] = t.y; o[4 * i + 2] = t.z; o[4 * i + 3] = t.w;
-  }
-}
-
 // NV = 16-byte vectors per lane (C <= 64 * VEC * NV): registers and instruction count scale with the row width instead of
 // the 2048-wide worst case.  Each wave walks rows with a grid stride and issues the NEXT row's loads before it reduces the
 // current one, so two rows of loads are always in flight per wave (a lone 16-byte load per lane is latency-, not
