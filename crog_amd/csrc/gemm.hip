@@ -299,19 +299,51 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[S::WM][S::WN], const crog_gem
   float s1[WN], s2[WN];
 #pragma unroll
   for (int j = 0; j < WN; j++) s1[j] = s2[j] = 0.f;
+  // every flag below is block-uniform: test it once around the register loops, never per element
+  if (alpha != 1.f || bias) {
 #pragma unroll
-  for (int i = 0; i < WM; i++)
+    for (int i = 0; i < WM; i++)
 #pragma unroll
-    for (int j = 0; j < WN; j++)
+      for (int j = 0; j < WN; j++)
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        float v = alpha * acc[i][j][e] + bcol[j];
-        if (p.col_stats) {
-          const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (m < p.M) { s1[j] += v; s2[j] += v * v; }
+        for (int e = 0; e < 16; e++) acc[i][j][e] = alpha * acc[i][j][e] + bcol[j];
+  }
+  if (p.col_stats) {
+    if (m0 + BM <= p.M) {   // interior tile: no row guard
+#pragma unroll
+      for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+          for (int e = 0; e < 16; e++) { const float v = acc[i][j][e]; s1[j] += v; s2[j] += v * v; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float v = m < p.M ? acc[i][j][e] : 0.f;
+            s1[j] += v;
+            s2[j] += v * v;
+          }
+    }
+  }
+  if (p.act != CROG_ACT_NONE) {
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+      for (int j = 0; j < WN; j++) {
+        if (p.act == CROG_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; e++) acc[i][j][e] = apply_act(acc[i][j][e], p.act);
         }
-        acc[i][j][e] = apply_act(v, p.act);
       }
+  }
 
   if (p.col_stats) {  // block-uniform branch; slab rows are 128 matrix rows each
     constexpr int RG = 32 * WM;          // rows per wave-row
@@ -350,23 +382,51 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[S::WM][S::WN], const crog_gem
   const T* R = reinterpret_cast<const T*>(p.R);
   if (p.out_mode != CROG_OUT_T || sizeof(T) == 4) {
     // direct stores from the accumulator layout: a register covers 2 rows x 32 consecutive columns
+    if (R) {
 #pragma unroll
-    for (int i = 0; i < WM; i++)
+      for (int i = 0; i < WM; i++)
 #pragma unroll
-      for (int j = 0; j < WN; j++)
+        for (int j = 0; j < WN; j++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const int n = ncol[j];
-          if (m < p.M && n < p.N) {
-            float v = acc[i][j][e];
-            if (R) v += Elem<T>::to_f(R[(int64_t)m * p.ldr + n]);
-            const int64_t o = coff + (int64_t)m * p.ldc + n;
-            if (p.out_mode == CROG_OUT_F32_ATOMIC) atomicAdd(reinterpret_cast<float*>(p.C) + o, v);
-            else if (p.out_mode == CROG_OUT_F32) reinterpret_cast<float*>(p.C)[o] = v;
-            else reinterpret_cast<T*>(p.C)[o] = Elem<T>::from_f(v);
+          for (int e = 0; e < 16; e++) {
+            const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < p.M && ncol[j] < p.N) acc[i][j][e] += Elem<T>::to_f(R[(int64_t)m * p.ldr + ncol[j]]);
           }
-        }
+    }
+    if (p.out_mode == CROG_OUT_F32_ATOMIC) {
+      float* Cf = reinterpret_cast<float*>(p.C) + coff;
+#pragma unroll
+      for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < p.M && ncol[j] < p.N) atomicAdd(Cf + (int64_t)m * p.ldc + ncol[j], acc[i][j][e]);
+          }
+    } else if (p.out_mode == CROG_OUT_F32) {
+      float* Cf = reinterpret_cast<float*>(p.C) + coff;
+#pragma unroll
+      for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < p.M && ncol[j] < p.N) Cf[(int64_t)m * p.ldc + ncol[j]] = acc[i][j][e];
+          }
+    } else {
+      T* Ct = reinterpret_cast<T*>(p.C) + coff;
+#pragma unroll
+      for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < p.M && ncol[j] < p.N) Ct[(int64_t)m * p.ldc + ncol[j]] = Elem<T>::from_f(acc[i][j][e]);
+          }
+    }
   } else {
     // 2-byte output: each wave stages 32 x (32*WN) of its tile in a private LDS region, then adds the residual
     // and stores 16 bytes per lane (full 64/128-byte row segments)
