@@ -293,13 +293,19 @@ __global__ void __launch_bounds__(NT) add_dropout_kernel(const T* __restrict__ a
     const int c = (int)(i % cvec) * VEC;
     Vec16<T> y = ldg16(b + r * ldb + c), x, o;
     if (a) x = ldg16(a + r * lda + c);
+    float f[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; e++) {
-      float f = Elem<T>::to_f(y.v[e]);
-      if (p > 0.f) f = dropout_keep(seed, (uint64_t)r * C + c + e, thr) ? f * sc : 0.f;
-      if (a) f += Elem<T>::to_f(x.v[e]);
-      o.v[e] = Elem<T>::from_f(f);
+    for (int e = 0; e < VEC; e++) f[e] = Elem<T>::to_f(y.v[e]);
+    if (p > 0.f) {   // launch-uniform flags: tested once per vector
+#pragma unroll
+      for (int e = 0; e < VEC; e++) f[e] = dropout_keep(seed, (uint64_t)r * C + c + e, thr) ? f[e] * sc : 0.f;
     }
+    if (a) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) f[e] += Elem<T>::to_f(x.v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(f[e]);
     stg16(out + r * ldo + c, o);
   }
 }
@@ -316,18 +322,24 @@ __global__ void __launch_bounds__(NT) act_bwd_kernel(const T* __restrict__ dy, l
     const long r = i / cvec;
     const int c = (int)(i % cvec) * VEC;
     Vec16<T> g = ldg16(dy + r * lddy + c), yv = ldg16(y + r * ldy + c), o;
+    float gf[VEC], u[VEC], d[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; e++) {
-      const float gf = Elem<T>::to_f(g.v[e]), u = Elem<T>::to_f(yv.v[e]);
-      float d;
-      if (mode == 0) d = u > 0.f ? gf : 0.f;
-      else if (mode == 2) d = gf * (1.f - u * u);   // tanh, from the saved OUTPUT (ssg.py:128,133)
-      else {
-        const float sg = 1.f / (1.f + expf(-1.702f * u));
-        d = gf * sg * (1.f + 1.702f * u * (1.f - sg));
+    for (int e = 0; e < VEC; e++) { gf[e] = Elem<T>::to_f(g.v[e]); u[e] = Elem<T>::to_f(yv.v[e]); }
+    if (mode == 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) d[e] = u[e] > 0.f ? gf[e] : 0.f;
+    } else if (mode == 2) {   // tanh, from the saved OUTPUT (ssg.py:128,133)
+#pragma unroll
+      for (int e = 0; e < VEC; e++) d[e] = gf[e] * (1.f - u[e] * u[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        const float sg = 1.f / (1.f + expf(-1.702f * u[e]));
+        d[e] = gf[e] * sg * (1.f + 1.702f * u[e] * (1.f - sg));
       }
-      o.v[e] = Elem<T>::from_f(d);
     }
+#pragma unroll
+    for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(d[e]);
     stg16(dx + r * lddx + c, o);
   }
 }
