@@ -11,7 +11,7 @@ so reference checkpoints and optimizer state load unchanged.  Internally every m
   * the heads' `permute(0, 2, 3, 1).reshape(B, -1, k)` (ssg.py:138-142) is free: channels-last rows already are that layout.
 
 The data-dependent loss (ssg.py:297-530, row S2: per-image anchor matching, OHEM, cropped proto masks) stays PyTorch-ROCm host
-logic by the scope table and is not part of this file yet: `forward` in training mode returns the raw predictions it needs.
+logic by the scope table: crog_amd/ssg_loss.py, called from `SSG.compute_loss`.
 """
 from __future__ import annotations
 
@@ -269,15 +269,25 @@ class SSG(nn.Module):
                     seg_pred=seg.permute(0, 3, 1, 2).float())
 
     def forward(self, data_dict):
-        """ssg.py:248-293.  Eval: the reference's output_dict.  Train: (output_dict, raw predictions) — the loss (ssg.py:297-530,
-        SURVEY.md §8a row S2) consumes exactly these tensors and is host-side PyTorch logic outside this module."""
+        """ssg.py:248-293.  Eval: the reference's output_dict.  Train with targets in `data_dict`: (output_dict, loss_dict);
+        train without targets: (output_dict, raw predictions)."""
         img = torch.cat([data_dict["rgb"], data_dict["depth"]], dim=1) if self.cfg.with_depth else data_dict["rgb"]
         raw = self.trunk(img)
         out = {"anchors": self.anchors, "protos": raw["protos"], "cls_pred": torch.softmax(raw["class_pred"], -1),
                "box_pred": raw["box_pred"], "ins_coef_pred": raw["ins_coef_pred"], "grasp_coef_pred": raw["grasp_coef_pred"]}
         if self.training:
+            if "bboxes" in data_dict:
+                return out, self.compute_loss(raw, data_dict, out)
             return out, raw
         return out
+
+    def compute_loss(self, raw, data_dict, output_dict=None):
+        """ssg.py:297-350 -> the reference's eight-entry loss dict (host-side PyTorch logic, crog_amd/ssg_loss.py)."""
+        from ..ssg_loss import ssg_loss
+        dev = raw["class_pred"].device
+        if isinstance(self.anchors, list):
+            self.anchors = torch.tensor(self.anchors, device=dev).reshape(-1, 4)
+        return ssg_loss(self.cfg, self.anchors.to(dev), raw, data_dict, output_dict)
 
 
 def build_ssg(cfg):

@@ -118,7 +118,10 @@ def ssg_cfg(**over):
     """Model keys of config/OCID-Grasp/ssg_r50.yaml."""
     cfg = dict(backbone="resnet", resnet_layers=[3, 4, 6, 3], fpn_in_channels=[512, 1024, 2048], num_protos=32, num_classes=32,
                anchor_strides=[8, 16, 32, 64, 128], aspect_ratios=[1, 0.5, 2], img_size=544, with_depth=True, with_grasp_masks=True,
-               path_to_pretrained_resnet=None, resume=None)
+               path_to_pretrained_resnet=None, resume=None,
+               # loss keys (TRAIN / MODEL sections of the yaml)
+               pos_iou_thre=0.5, neg_iou_thre=0.4, alpha_conf=1, alpha_bbox=1.5, alpha_ins=6.126, alpha_sem=1, alpha_grasp=6.125,
+               masks_to_train=100, intermidiate_output=True)
     cfg.update(over)
     return SimpleNamespace(**cfg)
 
@@ -151,3 +154,32 @@ def ssg_surrogate_loss(raw: Dict[str, torch.Tensor], seed: int = 0) -> torch.Ten
         r = torch.randn(t.shape, generator=_gen("ssg-loss::" + k, seed)).to(device=t.device, dtype=t.dtype)
         total = total + (t * r).mean()
     return total
+
+
+def synthetic_ssg_targets(B: int, size: int, num_classes: int, seed: int = 1234, device="cpu"):
+    """Ground truth in the collate format of utils/dataset.py:1396-1416: 2-4 objects per image with corner boxes (+ class),
+    elliptical instance masks, per-instance grasp maps (quality / sin 2t / cos 2t / width, masked by the instance), a
+    single-channel semantic mask and the label list."""
+    g = torch.Generator().manual_seed(seed ^ 0x55AA)
+    yy, xx = torch.meshgrid(torch.arange(size, dtype=torch.float32), torch.arange(size, dtype=torch.float32), indexing="ij")
+    out = dict(bboxes=[], labels=[], ins_masks=[], sem_mask=[], grasp_masks={k: [] for k in ("qua", "sin", "cos", "wid")})
+    for _ in range(B):
+        n = int(torch.randint(2, 5, (1,), generator=g))
+        cx, cy = 0.25 + 0.5 * torch.rand(n, generator=g), 0.25 + 0.5 * torch.rand(n, generator=g)
+        w, h = 0.15 + 0.3 * torch.rand(n, generator=g), 0.15 + 0.3 * torch.rand(n, generator=g)
+        box = torch.stack([(cx - w / 2).clamp(0.01), (cy - h / 2).clamp(0.01), (cx + w / 2).clamp(max=0.99), (cy + h / 2).clamp(max=0.99)], 1)
+        cls = torch.randint(1, num_classes, (n,), generator=g)
+        masks = torch.stack([(((xx / size - cx[j]) / (w[j] / 2)) ** 2 + ((yy / size - cy[j]) / (h[j] / 2)) ** 2 <= 1).float() for j in range(n)])
+        theta = (torch.rand(n, size, size, generator=g) - 0.5) * math.pi
+        out["bboxes"].append(torch.cat([box, cls[:, None].float()], 1))
+        out["labels"].append(cls)
+        out["ins_masks"].append(masks)
+        out["sem_mask"].append(masks.amax(0))
+        out["grasp_masks"]["qua"].append(torch.rand(n, size, size, generator=g) * masks)
+        out["grasp_masks"]["sin"].append(torch.sin(2 * theta) * masks)
+        out["grasp_masks"]["cos"].append(torch.cos(2 * theta) * masks)
+        out["grasp_masks"]["wid"].append(torch.rand(n, size, size, generator=g) * masks)
+    out["sem_mask"] = torch.stack(out["sem_mask"])
+    mv = lambda t: t.to(device)
+    return dict(bboxes=[mv(t) for t in out["bboxes"]], labels=[mv(t) for t in out["labels"]], ins_masks=[mv(t) for t in out["ins_masks"]],
+                sem_mask=mv(out["sem_mask"]), grasp_masks={k: [mv(t) for t in v] for k, v in out["grasp_masks"].items()})

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from crog_amd.testing import (SSG_OUTPUTS, make_cfg, seeded_state, ssg_surrogate_loss, ssg_tiny_cfg, synthetic_batch,
-                              synthetic_ssg_batch, tiny_cfg)
+                              synthetic_ssg_batch, synthetic_ssg_targets, tiny_cfg)
 
 GOLD = os.path.join(REPO, "tests", "golden")
 
@@ -225,6 +225,17 @@ def ssg_fixture(name, cfg, B, seed):
         out["grad::" + n] = p.grad.flatten()[:64].clone()
     bn = {k: float(v.double().sum()) for k, v in m.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
     out["bn_running_checksum"] = torch.tensor([bn[k] for k in sorted(bn)])
+    # the reference's own compute_loss (ssg.py:297-530) on these predictions and synthetic ground truth: eight losses and
+    # d(sum of losses)/d(prediction) for the six prediction tensors
+    tg = synthetic_ssg_targets(B, cfg.img_size, cfg.num_classes, seed=1234 + seed)
+    leaf = {k: raw[k].detach().clone().requires_grad_(True) for k in SSG_OUTPUTS}
+    losses = m.compute_loss(leaf["class_pred"], leaf["box_pred"], leaf["ins_coef_pred"], leaf["grasp_coef_pred"], leaf["protos"],
+                            leaf["seg_pred"], {**batch, **tg}, {})
+    sum(losses.values()).backward()
+    for k, v in losses.items():
+        out["S2::" + k] = v.detach()
+    for k in SSG_OUTPUTS:
+        out["S2::d_" + k] = leaf[k].grad
     m.eval()
     with torch.no_grad():
         ev = m(batch)

@@ -200,8 +200,32 @@ def test_oracle_ssg_trunk_matches_reference(case):
         check(P[n].grad.flatten()[:64], fx["grad::" + n], atol=2e-6, rtol=2e-3, what="grad " + n)
     bn = torch.tensor([float(P[k].double().sum()) for k in meta["bn_keys"]])
     check(bn, fx["bn_running_checksum"], atol=1e-3, what="bn running stats")
-    check(torch.tensor(S.anchors(cfg.aspect_ratios, cfg.img_size, cfg.anchor_strides)), fx["anchors"], atol=1e-7, what="anchors")
+    check(torch.tensor(S.anchors(cfg.aspect_ratios, cfg.img_size, cfg.anchor_strides)), fx["anchors"].flatten(), atol=1e-7, what="anchors")
     with torch.no_grad():
         ev = S.ssg_trunk(P, img, cfg.num_classes, cfg.num_protos, training=False)
     check(torch.softmax(ev["class_pred"], -1), fx["eval_cls_pred"], atol=2e-5, what="eval cls_pred")
     check(ev["box_pred"], fx["eval_box_pred"], atol=2e-5, what="eval box_pred")
+
+
+@pytest.mark.parametrize("case", ["ssg_tiny_rgbd", "ssg_tiny_rgb"])
+def test_ssg_loss_matches_reference(case):
+    """SURVEY §8a row S2 (host logic): crog_amd.ssg_loss on the fixture's raw predictions + synthetic ground truth against the
+    reference's own SSG.compute_loss (ssg.py:297-530): eight losses and the gradient of their sum w.r.t. every prediction."""
+    from types import SimpleNamespace
+    from crog_amd.ssg_loss import ssg_loss
+    from crog_amd.testing import SSG_OUTPUTS, synthetic_ssg_targets
+    from oracle import ssg_oracle as S
+    fx, meta = load_case(case)
+    cfg = SimpleNamespace(**meta["cfg"])
+    tg = synthetic_ssg_targets(meta["B"], cfg.img_size, cfg.num_classes, seed=1234 + meta["seed"])
+    raw = {k: fx[k].clone().requires_grad_(True) for k in SSG_OUTPUTS}
+    anchors = torch.tensor(S.anchors(cfg.aspect_ratios, cfg.img_size, cfg.anchor_strides)).reshape(-1, 4)
+    out = {}
+    losses = ssg_loss(cfg, anchors, raw, tg, out)
+    assert list(losses) == ["loss_cls", "loss_box", "loss_ins", "loss_sem", "loss_qua", "loss_sin", "loss_cos", "loss_wid"]
+    for k, v in losses.items():
+        check(v, fx["S2::" + k], atol=1e-6, rtol=1e-5, what=f"{case} {k}")
+    sum(losses.values()).backward()
+    for k in SSG_OUTPUTS:
+        check(raw[k].grad, fx["S2::d_" + k], atol=1e-7, rtol=1e-4, what=f"{case} d{k}")
+    assert out["inter_mask_p"].shape == out["inter_mask_gt"].shape and out["inter_mask_p"].dim() == 3

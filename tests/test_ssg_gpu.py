@@ -14,7 +14,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from crog_amd.testing import SSG_OUTPUTS, seeded_state, ssg_surrogate_loss, synthetic_ssg_batch  # noqa: E402
+from crog_amd.testing import SSG_OUTPUTS, seeded_state, ssg_surrogate_loss, synthetic_ssg_batch, synthetic_ssg_targets  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -66,7 +66,7 @@ def test_ssg_trunk_fp32_matches_reference_fixture(case):
     sd = model.state_dict()
     bn = torch.tensor([float(sd[k].double().sum()) for k in meta["bn_keys"]])
     assert err(bn, fx["bn_running_checksum"]) < 2e-3
-    assert err(torch.tensor(out["anchors"]), fx["anchors"]) < 1e-7
+    assert err(torch.tensor(out["anchors"]).flatten(), fx["anchors"].flatten()) < 1e-7
     model.eval()
     with torch.no_grad():
         ev = model(batch)
@@ -90,3 +90,28 @@ def test_ssg_trunk_bf16_tracks_fp32():
     for k in SSG_OUTPUTS:
         cos = torch.nn.functional.cosine_similarity(a[k].flatten(), b[k].flatten(), dim=0).item()
         assert cos > 0.99, (k, cos)
+
+
+@pytest.mark.parametrize("case", ["ssg_tiny_rgbd"])
+def test_ssg_training_forward_with_targets_returns_reference_losses(case):
+    """Rows S1 + S2 together: SSG.forward(train, data_dict with ground truth) -> (output_dict, loss_dict); the eight losses match
+    the reference's compute_loss on its own predictions (fixture) within 1e-3, and their sum back-propagates into the HIP trunk."""
+    from crog_amd.model.ssg import build_ssg
+    fx, meta = load_case(case)
+    cfg = SimpleNamespace(**meta["cfg"])
+    model = build_ssg(cfg)
+    model.load_state_dict(seeded_state({k: tuple(v) for k, v in meta["shapes"].items()}, seed=meta["seed"]))
+    model = model.cuda()
+    model.compute_dtype = torch.float32
+    model.prepare().train()
+    batch = synthetic_ssg_batch(meta["B"], cfg.img_size, cfg.with_depth, seed=1234 + meta["seed"], device="cuda")
+    tg = synthetic_ssg_targets(meta["B"], cfg.img_size, cfg.num_classes, seed=1234 + meta["seed"], device="cuda")
+    out, losses = model({**batch, **tg})
+    for k, v in losses.items():
+        ref = float(fx["S2::" + k])
+        assert abs(float(v) - ref) <= 1e-3 * max(1.0, abs(ref)), (k, float(v), ref)
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    g = model.backbone.conv1.weight.grad
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    assert "inter_mask_p" in out
