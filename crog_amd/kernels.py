@@ -26,13 +26,13 @@ OUT_T, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 PROF = None
 DEBUG_FLAGS = 0  # timing-only ablation bits of crog_gemm_desc.debug (scripts/ablate_gemm.py); 0 in production
 GEMM_SYMBOL = {
-    (A_KC, B_KC): "gemm_kernel<T, A_KC, B_KC>  (1x1 conv / linear forward, Q.K^T)",
-    (A_IM2COL, B_KC): "gemm_kernel<T, A_IM2COL, B_KC>  (3x3 conv forward, implicit GEMM)",
-    (A_KC, B_NC): "gemm_kernel<T, A_KC, B_NC>  (1x1 / linear dgrad, P.V)",
-    (A_IM2COL, B_NC_DGRAD): "gemm_kernel<T, A_IM2COL, B_NC_DGRAD>  (3x3 conv dgrad)",
-    (A_MC, B_NC): "gemm_kernel<T, A_MC, B_NC>  (1x1 / linear wgrad)",
-    (A_MC, B_NC_IM2COL): "gemm_kernel<T, A_MC, B_NC_IM2COL>  (3x3 conv wgrad)",
-    (A_MC, B_KC): "gemm_kernel<T, A_MC, B_KC>",
+    (A_KC, B_KC): "gemm_dma_kernel<T, A_KC, B_KC>  (1x1 conv / linear forward, Q.K^T)",
+    (A_IM2COL, B_KC): "gemm_dma_kernel<T, A_IM2COL, B_KC>  (3x3 conv forward, implicit GEMM)",
+    (A_KC, B_NC): "gemm_dma_kernel<T, A_KC, B_NC>  (1x1 / linear dgrad, P.V)",
+    (A_IM2COL, B_NC_DGRAD): "gemm_dma_kernel<T, A_IM2COL, B_NC_DGRAD>  (3x3 conv dgrad)",
+    (A_MC, B_NC): "gemm_dma_kernel<T, A_MC, B_NC>  (1x1 / linear wgrad)",
+    (A_MC, B_NC_IM2COL): "gemm_dma_kernel<T, A_MC, B_NC_IM2COL>  (3x3 conv wgrad)",
+    (A_MC, B_KC): "gemm_dma_kernel<T, A_MC, B_KC>",
 }
 
 
