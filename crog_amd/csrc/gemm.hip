@@ -621,14 +621,14 @@ constexpr unsigned DMA_OOB = 0x80000000u;
 template <typename S> constexpr int dma_nstage() { return S::NT == 512 ? 4 : 3; }
 
 // K-contiguous operand (MODE 0 dense rows, MODE 1 im2col patches of an NHWC map)
-template <typename T, int MODE>
+template <typename T, int MODE, int NI>
 struct DmaKc {
   static constexpr int VEC = TileCfg<T>::VEC, BK = TileCfg<T>::BK;
   static constexpr bool TR = false;
   __amdgpu_buffer_rsrc_t rsrc;
-  unsigned base[2];   // byte offset of (row, swizzled chunk) at k = 0; DMA_OOB when the row is out of range
-  unsigned cb[2];     // byte position of the lane's logical chunk inside the k-tile
-  int py[2], px[2];
+  unsigned base[NI];  // byte offset of (row, swizzled chunk) at k = 0; DMA_OOB when the row is out of range
+  unsigned cb[NI];    // byte position of the lane's logical chunk inside the k-tile
+  int py[NI], px[NI];
   int ldb_;           // row stride in bytes
   unsigned kbytes;
 
@@ -640,8 +640,8 @@ struct DmaKc {
     ldb_ = (int)(ld * sizeof(T));
     kbytes = (unsigned)(K * sizeof(T));
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int row = (wave * 2 + i) * 16 + (lane >> 2);
+    for (int i = 0; i < NI; i++) {
+      const int row = (wave * NI + i) * 16 + (lane >> 2);
       cb[i] = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
       const long m = (long)row0 + row;
       base[i] = (m < rows_total) ? (unsigned)(m * ld * sizeof(T)) + cb[i] : DMA_OOB;
@@ -668,43 +668,51 @@ struct DmaKc {
   }
   __device__ static Frag<T> frag(const char* tile, int rbase, int ks, int lane);
 };
-template <> __device__ inline Frag<bf16> DmaKc<bf16, 0>::frag(const char* tile, int rbase, int ks, int lane) {
-  const int row = rbase + (lane & 31), c = (ks * 2 + (lane >> 5)) ^ ((row >> 2) & 3);
-  Frag<bf16> f;
-  f.v = *reinterpret_cast<const bf16x8*>(tile + row * 64 + c * 16);
-  return f;
-}
-template <> __device__ inline Frag<bf16> DmaKc<bf16, 1>::frag(const char* tile, int rbase, int ks, int lane) {
-  return DmaKc<bf16, 0>::frag(tile, rbase, ks, lane);
-}
-template <> __device__ inline Frag<float> DmaKc<float, 0>::frag(const char* tile, int rbase, int ks, int lane) {
-  const int row = rbase + (lane & 31), h = lane >> 5, sw = (row >> 2) & 3;
-  const f32x4 a = *reinterpret_cast<const f32x4*>(tile + row * 64 + ((2 * h) ^ sw) * 16);
-  const f32x4 b = *reinterpret_cast<const f32x4*>(tile + row * 64 + ((2 * h + 1) ^ sw) * 16);
-  Frag<float> f;
-  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
-  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
-  return f;
-}
-template <> __device__ inline Frag<float> DmaKc<float, 1>::frag(const char* tile, int rbase, int ks, int lane) {
-  return DmaKc<float, 0>::frag(tile, rbase, ks, lane);
-}
+template <typename T> struct DmaKcFrag;
+template <> struct DmaKcFrag<bf16> {
+  __device__ static Frag<bf16> get(const char* tile, int rbase, int ks, int lane) {
+    const int row = rbase + (lane & 31), c = (ks * 2 + (lane >> 5)) ^ ((row >> 2) & 3);
+    Frag<bf16> f;
+    f.v = *reinterpret_cast<const bf16x8*>(tile + row * 64 + c * 16);
+    return f;
+  }
+};
+template <> struct DmaKcFrag<float> {
+  __device__ static Frag<float> get(const char* tile, int rbase, int ks, int lane) {
+    const int row = rbase + (lane & 31), h = lane >> 5, sw = (row >> 2) & 3;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(tile + row * 64 + ((2 * h) ^ sw) * 16);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(tile + row * 64 + ((2 * h + 1) ^ sw) * 16);
+    Frag<float> f;
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+    return f;
+  }
+};
+template <typename T, int MODE, int NI>
+__device__ inline Frag<T> DmaKc<T, MODE, NI>::frag(const char* tile, int rbase, int ks, int lane) { return DmaKcFrag<T>::get(tile, rbase, ks, lane); }
 
 // Transposed operand: the tile is [BK reduction rows][128 columns] of memory (MODE as TrLoader: 0 dense, 1 dgrad weights, 2 wgrad im2col)
-template <typename T, int MODE, int COLS>
+// XOR applied to the 16-byte chunk index of a transposed bf16 tile row (the four reduction rows a ds_read_b64_tr_b16 group
+// touches must land in different quarters of the 256-byte bank row).  Rows of >= 256 bytes: quarter ^= row & 3.  128-byte rows
+// (64-column tiles) alternate between the two halves of the bank row by themselves, so only rows r and r+2 collide: half ^= bit 1.
+template <int COLS>
+__device__ inline int tr_swz(int row) { return COLS >= 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : (((row >> 1) & 1) << 2); }
+
+template <typename T, int MODE, int COLS, int NI>
 struct DmaTr {
   static constexpr int VEC = TileCfg<T>::VEC, BK = TileCfg<T>::BK;
   static constexpr bool TR = true;
   static constexpr int CPR = COLS / VEC;         // chunks per tile row
   static constexpr int ROWB = COLS * (int)sizeof(T);
   static constexpr int RPI1024 = 1024 / ROWB;    // whole tile rows per 1 KiB wave-instruction (>= 1 for all shapes used)
+  static_assert(RPI1024 >= 1, "a transposed tile row must fit one 1 KiB wave-instruction");
   __amdgpu_buffer_rsrc_t rsrc;
-  int rowin[2];       // reduction row of this lane inside the k-tile
-  unsigned colb[2];   // byte offset of the lane's logical column chunk (DMA_OOB when the columns are out of range)
-  int tdy[2], tdx[2]; // MODE 2
+  int rowin[NI];       // reduction row of this lane inside the k-tile
+  unsigned colb[NI];   // byte offset of the lane's logical column chunk (DMA_OOB when the columns are out of range)
+  int tdy[NI], tdx[NI]; // MODE 2
   int ldb_, K;
 
-  __device__ static int swz(int row) { return sizeof(T) == 2 ? (((row & 3) << 2) | ((row >> 2) & 3)) : 0; }
+  __device__ static int swz(int row) { return sizeof(T) == 2 ? tr_swz<COLS>(row) : 0; }
 
   __device__ void init(const T* ptr, int64_t ld, int ncols, int K_, int col0, int wave, int lane, const ConvGeom& g) {
     long rows = K_;                                    // rows of memory the tile can touch
@@ -715,8 +723,8 @@ struct DmaTr {
     ldb_ = (int)(ld * sizeof(T));
     K = K_;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int row = (wave * 2 + i) * RPI1024 + lane / CPR;
+    for (int i = 0; i < NI; i++) {
+      const int row = (wave * NI + i) * RPI1024 + lane / CPR;
       const int c = (lane % CPR) ^ swz(row);
       rowin[i] = row;
       const int col = col0 + c * VEC;
@@ -757,7 +765,7 @@ template <int COLS> struct DmaTrFrag {
     const int chunk = col >> 3, inb = (col & 7) * 2;
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     const int r0 = ks * 16 + 8 * h + q, r1 = r0 + 4;
-    const int x0 = ((r0 & 3) << 2) | ((r0 >> 2) & 3), x1 = ((r1 & 3) << 2) | ((r1 >> 2) & 3);
+    const int x0 = tr_swz<COLS>(r0), x1 = tr_swz<COLS>(r1);
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * ROWB + ((chunk ^ x0) << 4) + inb));
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * ROWB + ((chunk ^ x1) << 4) + inb));
     Frag<bf16> f;
@@ -780,44 +788,56 @@ template <int MODE, int COLS> struct DmaTrFragSel<bf16, MODE, COLS> {
 template <int MODE, int COLS> struct DmaTrFragSel<float, MODE, COLS> {
   __device__ static Frag<float> get(const char* t, int c, int ks, int l) { return DmaTrFrag<COLS>::getf(t, c, ks, l); }
 };
-template <typename T, int MODE, int COLS>
-__device__ inline Frag<T> DmaTr<T, MODE, COLS>::frag(const char* t, int c, int ks, int l) { return DmaTrFragSel<T, MODE, COLS>::get(t, c, ks, l); }
+template <typename T, int MODE, int COLS, int NI>
+__device__ inline Frag<T> DmaTr<T, MODE, COLS, NI>::frag(const char* t, int c, int ks, int l) { return DmaTrFragSel<T, MODE, COLS>::get(t, c, ks, l); }
 
-template <typename T, int AL, int EDGE> struct DmaASel;
-template <typename T, int E> struct DmaASel<T, CROG_A_KC, E> { using type = DmaKc<T, 0>; };
-template <typename T, int E> struct DmaASel<T, CROG_A_IM2COL, E> { using type = DmaKc<T, 1>; };
-template <typename T, int E> struct DmaASel<T, CROG_A_MC, E> { using type = DmaTr<T, 0, E>; };
-template <typename T, int BL, int EDGE> struct DmaBSel;
-template <typename T, int E> struct DmaBSel<T, CROG_B_KC, E> { using type = DmaKc<T, 0>; };
-template <typename T, int E> struct DmaBSel<T, CROG_B_NC, E> { using type = DmaTr<T, 0, E>; };
-template <typename T, int E> struct DmaBSel<T, CROG_B_NC_DGRAD, E> { using type = DmaTr<T, 1, E>; };
-template <typename T, int E> struct DmaBSel<T, CROG_B_NC_IM2COL, E> { using type = DmaTr<T, 2, E>; };
+template <typename T, int AL, int EDGE, int NI> struct DmaASel;
+template <typename T, int E, int NI> struct DmaASel<T, CROG_A_KC, E, NI> { using type = DmaKc<T, 0, NI>; };
+template <typename T, int E, int NI> struct DmaASel<T, CROG_A_IM2COL, E, NI> { using type = DmaKc<T, 1, NI>; };
+template <typename T, int E, int NI> struct DmaASel<T, CROG_A_MC, E, NI> { using type = DmaTr<T, 0, E, NI>; };
+template <typename T, int BL, int EDGE, int NI> struct DmaBSel;
+template <typename T, int E, int NI> struct DmaBSel<T, CROG_B_KC, E, NI> { using type = DmaKc<T, 0, NI>; };
+template <typename T, int E, int NI> struct DmaBSel<T, CROG_B_NC, E, NI> { using type = DmaTr<T, 0, E, NI>; };
+template <typename T, int E, int NI> struct DmaBSel<T, CROG_B_NC_DGRAD, E, NI> { using type = DmaTr<T, 1, E, NI>; };
+template <typename T, int E, int NI> struct DmaBSel<T, CROG_B_NC_IM2COL, E, NI> { using type = DmaTr<T, 2, E, NI>; };
 
-// Issue the LDS-DMA loads of one k-tile into ring stage `stage` (2 A + 2 B wave-instructions of 1 KiB per wave).
-// A plain __device__ function on purpose: a lambda here makes hipcc's HOST pass drop the kernel stub silently.
-template <int TILE_B, typename OA, typename OB>
+// Issue the LDS-DMA loads of one k-tile into ring stage `stage`: every wave moves NIA 1-KiB slices of the A tile and NIB of
+// the B tile.  A plain __device__ function on purpose: a lambda here makes hipcc's HOST pass drop the kernel stub silently.
+template <int TILE_A_B, int TILE_B_B, int NIA, int NIB, typename OA, typename OB>
 __device__ inline void dma_issue(const OA& da, const OB& db, const ConvGeom& g, char* smem, int wave, int kt, int kmem, int stage) {
   typedef __attribute__((address_space(3))) void lds_void;
-  char* sa = smem + stage * 2 * TILE_B + wave * 2 * 1024;
-  char* sb = sa + TILE_B;
+  char* sa = smem + stage * (TILE_A_B + TILE_B_B) + wave * NIA * 1024;
+  char* sb = smem + stage * (TILE_A_B + TILE_B_B) + TILE_A_B + wave * NIB * 1024;
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const unsigned oa = da.off(i, kt, kmem, g), ob = db.off(i, kt, kmem, g);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(da.rsrc, (lds_void*)(sa + i * 1024), 16, oa, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(db.rsrc, (lds_void*)(sb + i * 1024), 16, ob, 0, 0, 0);
-  }
+  for (int i = 0; i < NIA; i++) __builtin_amdgcn_raw_ptr_buffer_load_lds(da.rsrc, (lds_void*)(sa + i * 1024), 16, da.off(i, kt, kmem, g), 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < NIB; i++) __builtin_amdgcn_raw_ptr_buffer_load_lds(db.rsrc, (lds_void*)(sb + i * 1024), 16, db.off(i, kt, kmem, g), 0, 0, 0);
+}
+
+template <int N> __device__ inline void wait_vmcnt() {
+  static_assert(N == 0 || N == 2 || N == 4 || N == 5 || N == 8 || N == 10, "add the immediate");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
 }
 
 using ShapeDma8 = Shape<4, 2, 2, 4>;   // 256 x 256, 8 waves, 128 accumulator registers per lane
+using ShapeTall = Shape<2, 2, 4, 1>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
+using ShapeWide = Shape<2, 2, 1, 4>;   //  64 x 256, 4 waves: weight gradients of those layers (M = Cout = 32 / 64)
+using ShapeDma64 = Shape<1, 1, 2, 2>;  //  64 x  64, 4 waves: small GEMMs (text tower, attention pooling), no BN statistics
 
 template <typename T, int AL, int BL, typename S>
-__global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : 3)) gemm_dma_kernel(const crog_gemm_desc p) {
+__global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 256 ? 2 : (S::BM + S::BN <= 128 ? 4 : 3)))) gemm_dma_kernel(const crog_gemm_desc p) {
   constexpr int DMA_NSTAGE = dma_nstage<S>();
-  static_assert(S::BM == S::BN && S::BM == 32 * (S::NT / 64), "DMA tiles are (32 * waves)^2: every wave issues 2+2 KiB per k-tile");
-  using OA = typename DmaASel<T, AL, S::BM>::type;
-  using OB = typename DmaBSel<T, BL, S::BN>::type;
+  constexpr int NW = S::NT / 64, NIA = S::BM / (16 * NW), NIB = S::BN / (16 * NW);   // 1-KiB DMA slices per wave and k-tile
+  static_assert(NIA >= 1 && NIB >= 1 && NIA * 16 * NW == S::BM && NIB * 16 * NW == S::BN, "every wave must move whole 1 KiB slices of both tiles");
+  using OA = typename DmaASel<T, AL, S::BM, NIA>::type;
+  using OB = typename DmaBSel<T, BL, S::BN, NIB>::type;
   constexpr int BK = TileCfg<T>::BK, BM = S::BM, BN = S::BN, WM = S::WM, WN = S::WN;
-  constexpr int DMA_TILE_B = BM * 64, DMA_STAGE_B = 2 * DMA_TILE_B;
+  constexpr int TILE_A_B = BM * 64, TILE_B_B = BN * 64, DMA_STAGE_B = TILE_A_B + TILE_B_B;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -870,21 +890,21 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : 3)) gemm_dma_kernel
 #define CROG_KMEM(kt) kmem_of(kt)
 #pragma unroll
   for (int s = 0; s < DMA_NSTAGE - 1; s++)
-    if (s < nt) dma_issue<DMA_TILE_B>(da, db, g, smem, wave, kt0 + s, CROG_KMEM(kt0 + s), s);
+    if (s < nt) dma_issue<TILE_A_B, TILE_B_B, NIA, NIB>(da, db, g, smem, wave, kt0 + s, CROG_KMEM(kt0 + s), s);
   int stage = 0;
   for (int t = 0; t < nt; t++) {
     // k-tiles still allowed in flight behind tile t: min(depth - 2, tiles left); 4 DMA instructions per tile and wave
     const int behind = min(DMA_NSTAGE - 2, nt - 1 - t);
-    if (behind >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (behind >= 2) wait_vmcnt<2 * (NIA + NIB)>();
+    else if (behind == 1) wait_vmcnt<NIA + NIB>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (t + DMA_NSTAGE - 1 < nt && !(p.debug & 1)) {
       const int tn = t + DMA_NSTAGE - 1;
-      dma_issue<DMA_TILE_B>(da, db, g, smem, wave, kt0 + tn, CROG_KMEM(kt0 + tn), stage == 0 ? DMA_NSTAGE - 1 : stage - 1);
+      dma_issue<TILE_A_B, TILE_B_B, NIA, NIB>(da, db, g, smem, wave, kt0 + tn, CROG_KMEM(kt0 + tn), stage == 0 ? DMA_NSTAGE - 1 : stage - 1);
     }
     const char* at = smem + stage * DMA_STAGE_B;
-    const char* bt = at + DMA_TILE_B;
+    const char* bt = at + TILE_A_B;
     if (!(p.debug & 2))
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
@@ -907,7 +927,8 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : 3)) gemm_dma_kernel
 
 template <typename T, int AL, int BL, typename S>
 int launch_dma(const crog_gemm_desc& d, hipStream_t s) {
-  constexpr int LDS = dma_nstage<S>() * 2 * S::BM * 64;
+  constexpr int ring = dma_nstage<S>() * (S::BM + S::BN) * 64, epi = lds_bytes<T, S>();   // the epilogue reuses the ring
+  constexpr int LDS = ring > epi ? ring : epi;
   static bool attr_set = false;
   auto kern = gemm_dma_kernel<T, AL, BL, S>;
   if (!attr_set) {
@@ -1067,7 +1088,25 @@ int pick_shape(const crog_gemm_desc& d) {
 template <typename T, bool HWTR>
 int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
   const int shape = pick_shape(d);
-  if (shape == 2 && dma_eligible(d)) return dma_prefers_256(d) ? dispatch_dma<T, ShapeDma8>(d, s) : dispatch_dma<T, ShapeMid>(d, s);
+  if (dma_eligible(d)) {
+    // tile shape of the LDS-DMA kernel by padding waste: 64-wide sides for <= 64 columns / rows, 64 x 64 for small problems
+    static int alt = -1;
+    if (alt < 0) { const char* e = getenv("CROG_GEMM_NO_ALT_TILES"); alt = (e && e[0] == '1') ? 0 : 1; }
+    if (shape == 2 && dma_prefers_256(d)) return dispatch_dma<T, ShapeDma8>(d, s);
+    if (alt && forced_shape() == 0) {
+      if (d.col_stats) {
+        if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
+      } else {
+        if (d.M <= 64 && d.N <= 64) return dispatch_dma<T, ShapeDma64>(d, s);
+        if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
+        static int wide = -1;   // 64 x 256: measured slower than 128 x 128 on the Cout = 64 weight gradients (2 blocks/CU, 20 KiB per k-tile)
+        if (wide < 0) { const char* e = getenv("CROG_GEMM_WIDE"); wide = (e && e[0] == '1') ? 1 : 0; }
+        if (wide && d.M <= 64) return dispatch_dma<T, ShapeWide>(d, s);
+        if (shape == 1) return dispatch_dma<T, ShapeDma64>(d, s);
+      }
+    }
+    if (shape == 2) return dispatch_dma<T, ShapeMid>(d, s);
+  }
   switch (shape) {
     case 3: return dispatch_layout<T, HWTR, ShapeBig>(d, s);
     case 1: return dispatch_layout<T, HWTR, ShapeSmall>(d, s);

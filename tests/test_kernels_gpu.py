@@ -137,7 +137,7 @@ def test_gemm_batched_heads(K, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 13, 13, 64, 96), (1, 26, 20, 32, 32), (3, 8, 8, 128, 256)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 13, 13, 64, 96), (1, 26, 20, 32, 32), (3, 8, 8, 128, 256), (2, 20, 20, 64, 64)])
 def test_conv3x3_fwd_dgrad_wgrad(K, dt, B, H, W, Cin, Cout):
     x = rnd(B, H, W, Cin, dt=dt)
     w = (rnd(Cout, 3, 3, Cin, dt=dt, seed=1) * 0.1).to(dt)  # KRSC
