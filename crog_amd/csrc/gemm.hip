@@ -17,6 +17,7 @@
 //   transposed on the READ side: ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -1085,19 +1086,45 @@ int pick_shape(const crog_gemm_desc& d) {
   return 2;
 }
 
+// Small-output weight gradients (M x N up to 512 x 2048 for 1x1 / linear layers, up to 128 x 1152 for 3x3) are bound by the
+// fp32-atomic epilogue and by how many blocks stream the huge reduction dimension, not by MFMA: 64 x 64 tiles quarter the
+// atomic bytes per split and give 4x the blocks (measured 8-36 % faster, scripts/bench_wgrad2.py).
+inline bool alt_tiles_enabled() {
+  static int alt = -1;
+  if (alt < 0) { const char* e = getenv("CROG_GEMM_NO_ALT_TILES"); alt = (e && e[0] == '1') ? 0 : 1; }
+  return alt == 1;
+}
+inline bool small_wgrad(int a_layout, int b_layout, int out_mode, long M, long N) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("CROG_GEMM_NO_SMALL_WGRAD"); off = (e && e[0] == '1') ? 1 : 0; }
+  if (off || !alt_tiles_enabled() || out_mode != CROG_OUT_F32_ATOMIC || a_layout != CROG_A_MC) return false;
+  if (b_layout == CROG_B_NC) return M * N <= (1L << 20);
+  if (b_layout == CROG_B_NC_IM2COL) return M * N <= 160L * 1024;
+  return false;
+}
+
 template <typename T, bool HWTR>
 int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
   const int shape = pick_shape(d);
   if (dma_eligible(d)) {
     // tile shape of the LDS-DMA kernel by padding waste: 64-wide sides for <= 64 columns / rows, 64 x 64 for small problems
-    static int alt = -1;
-    if (alt < 0) { const char* e = getenv("CROG_GEMM_NO_ALT_TILES"); alt = (e && e[0] == '1') ? 0 : 1; }
+    const bool alt = alt_tiles_enabled();
     if (shape == 2 && dma_prefers_256(d)) return dispatch_dma<T, ShapeDma8>(d, s);
+    static int force = -1;   // CROG_GEMM_DMA_TILE = mid | tall | wide | 64 : A/B runs only (never with BN statistics on 64-row tiles)
+    if (force < 0) {
+      const char* e = getenv("CROG_GEMM_DMA_TILE");
+      force = !e ? 0 : (e[0] == 'm' ? 1 : (e[0] == 't' ? 2 : (e[0] == 'w' ? 3 : (e[0] == '6' ? 4 : 0))));
+    }
+    if (force == 1) return dispatch_dma<T, ShapeMid>(d, s);
+    if (force == 2) return dispatch_dma<T, ShapeTall>(d, s);
+    if (force == 3 && !d.col_stats) return dispatch_dma<T, ShapeWide>(d, s);
+    if (force == 4 && !d.col_stats) return dispatch_dma<T, ShapeDma64>(d, s);
     if (alt && forced_shape() == 0) {
       if (d.col_stats) {
         if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
       } else {
         if (d.M <= 64 && d.N <= 64) return dispatch_dma<T, ShapeDma64>(d, s);
+        if (small_wgrad(d.a_layout, d.b_layout, d.out_mode, d.M, d.N)) return dispatch_dma<T, ShapeDma64>(d, s);
         if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
         static int wide = -1;   // 64 x 256: measured slower than 128 x 128 on the Cout = 64 weight gradients (2 blocks/CU, 20 KiB per k-tile)
         if (wide < 0) { const char* e = getenv("CROG_GEMM_WIDE"); wide = (e && e[0] == '1') ? 1 : 0; }
@@ -1117,6 +1144,23 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
 }  // namespace
 
 extern "C" int crog_gemm_stat_tiles(int M) { return cdiv(M, 128); }
+
+// Split count for a weight-gradient GEMM C[M,N] += A^T B over K (out_mode CROG_OUT_F32_ATOMIC), matched to the tile shape
+// crog_gemm will pick: enough blocks to fill 256 CUs, but at least 16-24 k-tiles per block (every split pays an atomic epilogue).
+extern "C" int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int M, int N, int K) {
+  const int bk = dtype == CROG_BF16 ? 32 : 16;
+  const long ktiles = cdiv(K, bk);
+  long s;
+  if (small_wgrad(a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N)) {
+    const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+    const long target = b_layout == CROG_B_NC_IM2COL ? 2048 : 1024;
+    s = std::min(std::max(1L, target / tiles), std::max(1L, ktiles / 16));
+  } else {
+    const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+    s = std::min(std::max(1L, 768 / tiles), std::max(1L, ktiles / 24));
+  }
+  return (int)std::max(1L, std::min(s, 1024L));
+}
 
 extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
   CROG_CHECK_ARG(dp != nullptr, "crog_gemm: null descriptor");

@@ -283,7 +283,7 @@ class ConvBnAct(Function):
                     sk = K.pick_splitk(C, cin, M, _bk(dt))
                     K.gemm(dt, K.A_MC, K.B_NC, dz, x, gt, C, cin, M, C, K.mat(x)[2], wcols, c_off=goff, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
                 else:
-                    sk = K.pick_splitk(C, 9 * cin, M, _bk(dt))
+                    sk = K.pick_splitk(C, 9 * cin, M, _bk(dt), conv=True)
                     K.gemm(dt, K.A_MC, K.B_NC_IM2COL, dz, x, gt, C, 9 * cin, M, C, K.mat(x)[2], wcols, c_off=goff, conv=(lead[1], lead[2], cin),
                            splitk=sk, out_mode=K.OUT_F32_ATOMIC)
                 if wpad is not None:  # strip the zero padding back out into the real gradient
@@ -834,7 +834,7 @@ class Conv3BiasActFn(Function):
             K.act_bwd(K.as_mat(dy), y, g, 0 if act == K.ACT_RELU else 2)
         M = B * H * W
         def wgrad():
-            sk = K.pick_splitk(C, 9 * cin, M, _bk(dt))
+            sk = K.pick_splitk(C, 9 * cin, M, _bk(dt), conv=True)
             K.gemm(dt, K.A_MC, K.B_NC_IM2COL, g, x, w.G, C, 9 * cin, M, C, K.mat(x)[2], w.cols, c_off=w.off, conv=(H, W, cin), splitk=sk,
                    out_mode=K.OUT_F32_ATOMIC)
             if b is not None:

@@ -142,14 +142,11 @@ def stat_tiles(M: int) -> int:
     return (M + 127) // 128
 
 
-def pick_splitk(M: int, N: int, K: int, bk: int) -> int:
-    """Split the reduction of a weight-gradient GEMM (small MxN, huge K) so that it fills 256 CUs, but keep at
-    least ~24 k-tiles per block: every split pays one 128x128 fp32 atomic epilogue (64 KiB), and fp32 atomics run at
-    ~1.3 TB/s chip-wide, so many thin splits turn the GEMM into an atomic-add benchmark."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    ktiles = (K + bk - 1) // bk
-    s = min(max(1, 768 // max(tiles, 1)), max(1, ktiles // 24))
-    return max(1, min(s, 1024))
+def pick_splitk(M: int, N: int, K: int, bk: int, conv: bool = False) -> int:
+    """Split the reduction of a weight-gradient GEMM (small MxN, huge K).  The policy lives next to the tile selection in
+    csrc/gemm.hip (crog_gemm_splitk_hint): enough blocks to fill 256 CUs, but >= 16-24 k-tiles per block, because every split pays
+    one fp32 atomic epilogue and fp32 atomics run at ~1.3 TB/s chip-wide."""
+    return lib().crog_gemm_splitk_hint(BF16 if bk >= 32 else F32, A_MC, B_NC_IM2COL if conv else B_NC, int(M), int(N), int(K))
 
 
 # --------------------------------------------------------------------------------------------

@@ -98,6 +98,9 @@ typedef struct crog_gemm_desc {
 int crog_gemm(const crog_gemm_desc* d, crog_stream_t stream);
 /* number of 128-row tiles (= rows of the col_stats slab) for a given M */
 int crog_gemm_stat_tiles(int M);
+/* Split count for a weight-gradient GEMM (out_mode CROG_OUT_F32_ATOMIC) of logical size M x N over K, matched to the tile
+ * shape crog_gemm selects for it (wgrad call sites: every conv / linear backward, e.g. clip.py:44-57, layers.py:298-301). */
+int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int M, int N, int K);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm, training mode with optional cross-replica statistics (nn.BatchNorm2d/1d under

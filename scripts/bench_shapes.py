@@ -21,7 +21,7 @@ def conv(name, B, HW, Cin, Cout):
     fl = 2.0 * M * Cout * 9 * Cin
     tf = timeit(lambda: K.gemm(dc, K.A_IM2COL, K.B_KC, x, w, y, M, Cout, 9 * Cin, Cin, 9 * Cin, Cout, conv=(HW, HW, Cin)))
     td = timeit(lambda: K.gemm(dc, K.A_IM2COL, K.B_NC_DGRAD, dy, w, dx, M, Cin, 9 * Cout, Cout, Cin, Cin, conv=(HW, HW, Cout)))
-    sk = K.pick_splitk(Cout, 9 * Cin, M, 32)
+    sk = K.pick_splitk(Cout, 9 * Cin, M, 32, conv=True)
     tg = timeit(lambda: K.gemm(dc, K.A_MC, K.B_NC_IM2COL, dy, x, dw, Cout, 9 * Cin, M, Cout, Cin, 9 * Cin, conv=(HW, HW, Cin), splitk=sk, out_mode=K.OUT_F32_ATOMIC))
     print(f"{tag:10s} {name:28s} fwd {fl/tf/1e9:6.1f}  dgrad {fl/td/1e9:6.1f}  wgrad {fl/tg/1e9:6.1f} TF/s", flush=True)
 def lin(name, M, Kd, N):

@@ -12,7 +12,7 @@ def lin(M, N, Kd):
     dx = torch.empty(M, Kd, device="cuda", dtype=dt); dw = torch.zeros(N, Kd, device="cuda")
     f = lambda: K.gemm(dc, K.A_KC, K.B_KC, x, w, y, M, N, Kd, Kd, Kd, N)
     d = lambda: K.gemm(dc, K.A_KC, K.B_NC, dy, w, dx, M, Kd, N, N, Kd, Kd)
-    sk = K.pick_splitk(N, Kd, M, 1)
+    sk = K.pick_splitk(N, Kd, M, 32)
     g = lambda: K.gemm(dc, K.A_MC, K.B_NC, dy, x, dw, N, Kd, M, N, Kd, Kd, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
     fl = 2.0 * M * N * Kd
     tf, td, tg = timeit(f, 50), timeit(d, 50), timeit(g, 50)
