@@ -1,0 +1,430 @@
+// Fused multi-head attention for the unmasked, head_dim = 64, bf16 case: the decoder's 676-token self-attention
+// (layers.py:291-296,324) and the ViT tower's 197-token blocks (clip.py:246-260) — the "MFMA attention path" of BASELINE
+// config 4.  Scores are never written to HBM: the unfused path moves ~1 GB per decoder layer forward (S, P, dropout(P)) and
+// ~2 GB backward at B = 32; this one reads Q, K, V (+ O, dO) once per 128-row block.
+//
+// Layout trick (all three kernels): the 32x32x16 MFMA returns C with lane = column, 16 rows in registers.  Computing the
+// score tile TRANSPOSED to what the next product needs makes those registers directly an MFMA operand of the next product —
+//   forward / dQ :  S^T = K Q^T  [keys x queries]   lane = query: the softmax row statistics are per-lane scalars, and the
+//                   registers are the operand of  O^T += V^T P^T  resp.  dQ += dS K   (reduction over keys)
+//   dK, dV       :  S   = Q K^T  [queries x keys]   lane = key:   registers are the operand of  dV += P^T dO,  dK += dS^T Q
+// with the reduction index permuted consistently on both operands (slot (h, j) of k-step t <-> row 16t + 8(j>>2) + 4h + (j&3));
+// the other operand comes out of LDS through ds_read_b64_tr_b16 with the same permutation.  No shuffles, no LDS round trip
+// for P.  Attention dropout uses the same counter hash and index (row * ldp + key) as crog_softmax_fwd, so the fused and the
+// unfused paths drop identical elements for a given seed.
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 64;     // head dimension
+constexpr int TT = 32;     // rows of a streamed LDS tile (keys in fwd / dQ, queries in dK/dV)
+constexpr int NTHR = 256;  // 4 waves, 32 rows of the resident operand each
+constexpr int TILE = TT * DH;
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+struct AttnArgs {
+  const bf16 *Q, *K, *V, *O, *dO;
+  bf16 *Out, *dQ, *dK, *dV;
+  float *lse, *D;
+  long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int Lq, Lk, heads, ldp;
+  float scale, p_drop;
+  uint64_t seed;
+};
+
+// ---- LDS images of a [32][64] bf16 tile (128-byte rows) -------------------------------------------------------------
+// "kc": read as rows (ds_read_b128, lane = row): 16-byte slot = chunk ^ ((row >> 1) & 7) -> the 16 rows of a b128 lane group
+//       hit 16 different slots of the 256-byte bank row.
+// "tr": read transposed (ds_read_b64_tr_b16, 4 rows x 64 bytes per 32-lane half): rows r and r+2 share a bank-row half, so
+//       the 64-byte half is flipped by bit 1 of the row.
+__device__ inline int kc_off(int row, int chunk) { return row * DH + ((chunk ^ ((row >> 1) & 7)) << 3); }
+__device__ inline int tr_off(int row, int chunk) { return row * DH + ((chunk ^ (((row >> 1) & 1) << 2)) << 3); }
+
+__device__ inline bf16x8 kc_frag(const bf16* tile, int row, int chunk) { return *reinterpret_cast<const bf16x8*>(tile + kc_off(row, chunk)); }
+
+// transposed fragment: lane receives column cbase + (lane & 31), rows R0..R0+3 and R1..R1+3
+__device__ inline bf16x8 tr_frag(const bf16* tile, int cbase, int R0, int R1, int lane) {
+  const int i = lane & 15, q = i >> 2, pp = i & 3;
+  const int col = cbase + 16 * ((lane >> 4) & 1) + 4 * pp;
+  const int chunk = col >> 3, inb = col & 7;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + tr_off(R0 + q, chunk) + inb));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + tr_off(R1 + q, chunk) + inb));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ inline f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+// row (0..31) of accumulator register r for the lane's half h
+__device__ inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ inline bf16x8 pack8(const f32x16& v, int t) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; j++) o[j] = (bf16)v[8 * t + j];
+  return o;
+}
+
+__device__ inline float xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+// =====================================================================================================================
+// forward: O = softmax(scale Q K^T) [dropout] V, lse = row log-sum-exp.  grid (ceil(Lq / 128), B * heads)
+// =====================================================================================================================
+__global__ void __launch_bounds__(NTHR) flash_fwd_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16 sK[2][TILE];
+  __shared__ __attribute__((aligned(16))) bf16 sV[2][TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ln = lane & 31;
+  const int bh = blockIdx.y, b = bh / a.heads, hd = bh % a.heads;
+  const int q = blockIdx.x * 128 + wave * 32 + ln;
+  const int qc = min(q, a.Lq - 1);
+  const bf16* qp = a.Q + ((long)b * a.Lq + qc) * a.ldq + hd * DH + h * 8;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  f32x16 o[2];
+#pragma unroll
+  for (int e = 0; e < 16; e++) o[0][e] = o[1][e] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  const int lrow = tid >> 3, lch = tid & 7;
+  const bf16* kg = a.K + (long)b * a.Lk * a.ldk + hd * DH + lch * 8;
+  const bf16* vg = a.V + (long)b * a.Lk * a.ldv + hd * DH + lch * 8;
+  const int nkt = (a.Lk + TT - 1) / TT;
+  const uint32_t thr = (uint32_t)(a.p_drop * 4294967296.0);
+  const float sc = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const uint64_t rowbase = ((uint64_t)bh * a.Lq + q) * a.ldp;
+
+  bf16x8 rk, rv;
+  {
+    const int key = min(lrow, a.Lk - 1);
+    rk = *reinterpret_cast<const bf16x8*>(kg + (long)key * a.ldk);
+    rv = *reinterpret_cast<const bf16x8*>(vg + (long)key * a.ldv);
+    *reinterpret_cast<bf16x8*>(&sK[0][kc_off(lrow, lch)]) = rk;
+    *reinterpret_cast<bf16x8*>(&sV[0][tr_off(lrow, lch)]) = rv;
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) {
+      const int key = min((kt + 1) * TT + lrow, a.Lk - 1);
+      rk = *reinterpret_cast<const bf16x8*>(kg + (long)key * a.ldk);
+      rv = *reinterpret_cast<const bf16x8*>(vg + (long)key * a.ldv);
+    }
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) s = mfma(kc_frag(sK[buf], ln, 2 * ks + h), qf[ks], s);
+    const int kb = kt * TT;
+    float mt = -INFINITY;
+    if (kb + TT <= a.Lk) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s[r] *= a.scale; mt = fmaxf(mt, s[r]); }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s[r] = (kb + acc_row(r, h) < a.Lk) ? s[r] * a.scale : -INFINITY; mt = fmaxf(mt, s[r]); }
+    }
+    mt = fmaxf(mt, xor32(mt));
+    const float mn = fmaxf(m, mt);
+    const float alpha = __expf(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { s[r] = __expf(s[r] - mn); ps += s[r]; }
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int e = 0; e < 16; e++) { o[0][e] *= alpha; o[1][e] *= alpha; }
+    if (a.p_drop > 0.f) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] = dropout_keep(a.seed, rowbase + kb + acc_row(r, h), thr) ? s[r] * sc : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const bf16x8 pb = pack8(s, t);
+#pragma unroll
+      for (int mt2 = 0; mt2 < 2; mt2++) o[mt2] = mfma(tr_frag(sV[buf], mt2 * 32, 16 * t + 4 * h, 16 * t + 8 + 4 * h, lane), pb, o[mt2]);
+    }
+    if (kt + 1 < nkt) {
+      *reinterpret_cast<bf16x8*>(&sK[buf ^ 1][kc_off(lrow, lch)]) = rk;
+      *reinterpret_cast<bf16x8*>(&sV[buf ^ 1][tr_off(lrow, lch)]) = rv;
+    }
+    __syncthreads();
+  }
+  l += xor32(l);
+  if (q < a.Lq) {
+    const float inv = 1.f / l;
+    bf16* op = a.Out + ((long)b * a.Lq + q) * a.ldo + hd * DH + 4 * h;
+#pragma unroll
+    for (int mt2 = 0; mt2 < 2; mt2++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        bf16x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = (bf16)(o[mt2][4 * g + j] * inv);
+        *reinterpret_cast<bf16x4*>(op + mt2 * 32 + 8 * g) = w;
+      }
+    if (h == 0) a.lse[(long)bh * a.Lq + q] = m + __logf(l);
+  }
+}
+
+// =====================================================================================================================
+// backward 1: D = rowsum(dO * O);  dQ = scale * dS K  with dS = P * (dropout'(dO V^T) - D).  Same blocking as the forward.
+// =====================================================================================================================
+__global__ void __launch_bounds__(NTHR) flash_bwd_dq_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16 sKc[2][TILE];
+  __shared__ __attribute__((aligned(16))) bf16 sKt[2][TILE];
+  __shared__ __attribute__((aligned(16))) bf16 sVc[2][TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ln = lane & 31;
+  const int bh = blockIdx.y, b = bh / a.heads, hd = bh % a.heads;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q = q0 + ln;
+  const int qc = min(q, a.Lq - 1);
+  const long qrow = (long)b * a.Lq + qc;
+  bf16x8 qf[4], dof[4];
+  float Dq = 0.f;
+  {
+    const bf16* qp = a.Q + qrow * a.ldq + hd * DH + h * 8;
+    const bf16* dp = a.dO + qrow * a.lddo + hd * DH + h * 8;
+    const bf16* op = a.O + qrow * a.ldo + hd * DH + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(dp + ks * 16);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(op + ks * 16);
+#pragma unroll
+      for (int j = 0; j < 8; j++) Dq += (float)dof[ks][j] * (float)of[j];
+    }
+    Dq += xor32(Dq);
+  }
+  const float Lr = a.lse[(long)bh * a.Lq + qc];
+  if (h == 0 && q < a.Lq) a.D[(long)bh * a.Lq + q] = Dq;
+  f32x16 dq[2];
+#pragma unroll
+  for (int e = 0; e < 16; e++) dq[0][e] = dq[1][e] = 0.f;
+
+  const int lrow = tid >> 3, lch = tid & 7;
+  const bf16* kg = a.K + (long)b * a.Lk * a.ldk + hd * DH + lch * 8;
+  const bf16* vg = a.V + (long)b * a.Lk * a.ldv + hd * DH + lch * 8;
+  const int nkt = (a.Lk + TT - 1) / TT;
+  const uint32_t thr = (uint32_t)(a.p_drop * 4294967296.0);
+  const float sc = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const uint64_t rowbase = ((uint64_t)bh * a.Lq + q) * a.ldp;
+
+  bf16x8 rk, rv;
+  {
+    const int key = min(lrow, a.Lk - 1);
+    rk = *reinterpret_cast<const bf16x8*>(kg + (long)key * a.ldk);
+    rv = *reinterpret_cast<const bf16x8*>(vg + (long)key * a.ldv);
+    *reinterpret_cast<bf16x8*>(&sKc[0][kc_off(lrow, lch)]) = rk;
+    *reinterpret_cast<bf16x8*>(&sKt[0][tr_off(lrow, lch)]) = rk;
+    *reinterpret_cast<bf16x8*>(&sVc[0][kc_off(lrow, lch)]) = rv;
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) {
+      const int key = min((kt + 1) * TT + lrow, a.Lk - 1);
+      rk = *reinterpret_cast<const bf16x8*>(kg + (long)key * a.ldk);
+      rv = *reinterpret_cast<const bf16x8*>(vg + (long)key * a.ldv);
+    }
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      s = mfma(kc_frag(sKc[buf], ln, 2 * ks + h), qf[ks], s);
+      dp = mfma(kc_frag(sVc[buf], ln, 2 * ks + h), dof[ks], dp);
+    }
+    const int kb = kt * TT;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float p = (kb + acc_row(r, h) < a.Lk) ? __expf(s[r] * a.scale - Lr) : 0.f;
+      s[r] = p;
+    }
+    if (a.p_drop > 0.f) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) dp[r] = dropout_keep(a.seed, rowbase + kb + acc_row(r, h), thr) ? dp[r] * sc : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) s[r] = s[r] * (dp[r] - Dq) * a.scale;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const bf16x8 af = pack8(s, t);
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) dq[nt] = mfma(af, tr_frag(sKt[buf], nt * 32, 16 * t + 4 * h, 16 * t + 8 + 4 * h, lane), dq[nt]);
+    }
+    if (kt + 1 < nkt) {
+      *reinterpret_cast<bf16x8*>(&sKc[buf ^ 1][kc_off(lrow, lch)]) = rk;
+      *reinterpret_cast<bf16x8*>(&sKt[buf ^ 1][tr_off(lrow, lch)]) = rk;
+      *reinterpret_cast<bf16x8*>(&sVc[buf ^ 1][kc_off(lrow, lch)]) = rv;
+    }
+    __syncthreads();
+  }
+  // dq[nt]: lane = column (dh = nt*32 + ln), register r = query q0 + acc_row(r, h)
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int qq = q0 + acc_row(r, h);
+      if (qq < a.Lq) a.dQ[((long)b * a.Lq + qq) * a.lddq + hd * DH + nt * 32 + ln] = (bf16)dq[nt][r];
+    }
+}
+
+// =====================================================================================================================
+// backward 2: dV = dropout(P)^T dO,  dK = scale * dS^T Q.  Each wave owns 32 keys; queries stream through LDS.
+// grid (ceil(Lk / 128), B * heads).  Needs lse (forward) and D (flash_bwd_dq_kernel).
+// =====================================================================================================================
+__global__ void __launch_bounds__(NTHR) flash_bwd_dkdv_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16 sQc[2][TILE];
+  __shared__ __attribute__((aligned(16))) bf16 sQt[2][TILE];
+  __shared__ __attribute__((aligned(16))) bf16 sOc[2][TILE];
+  __shared__ __attribute__((aligned(16))) bf16 sOt[2][TILE];
+  __shared__ __attribute__((aligned(16))) float sL[2][TT];
+  __shared__ __attribute__((aligned(16))) float sD[2][TT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ln = lane & 31;
+  const int bh = blockIdx.y, b = bh / a.heads, hd = bh % a.heads;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int key = k0 + ln;
+  const int kc = min(key, a.Lk - 1);
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16* kp = a.K + ((long)b * a.Lk + kc) * a.ldk + hd * DH + h * 8;
+    const bf16* vp = a.V + ((long)b * a.Lk + kc) * a.ldv + hd * DH + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(kp + ks * 16);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(vp + ks * 16);
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int e = 0; e < 16; e++) dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f;
+
+  const int lrow = tid >> 3, lch = tid & 7;
+  const bf16* qg = a.Q + (long)b * a.Lq * a.ldq + hd * DH + lch * 8;
+  const bf16* og = a.dO + (long)b * a.Lq * a.lddo + hd * DH + lch * 8;
+  const float* lg = a.lse + (long)bh * a.Lq;
+  const float* dg = a.D + (long)bh * a.Lq;
+  const int nqt = (a.Lq + TT - 1) / TT;
+  const uint32_t thr = (uint32_t)(a.p_drop * 4294967296.0);
+  const float sc = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+
+  bf16x8 rq, ro;
+  float rs = 0.f;
+  {
+    const int qq = min(lrow, a.Lq - 1);
+    rq = *reinterpret_cast<const bf16x8*>(qg + (long)qq * a.ldq);
+    ro = *reinterpret_cast<const bf16x8*>(og + (long)qq * a.lddo);
+    *reinterpret_cast<bf16x8*>(&sQc[0][kc_off(lrow, lch)]) = rq;
+    *reinterpret_cast<bf16x8*>(&sQt[0][tr_off(lrow, lch)]) = rq;
+    *reinterpret_cast<bf16x8*>(&sOc[0][kc_off(lrow, lch)]) = ro;
+    *reinterpret_cast<bf16x8*>(&sOt[0][tr_off(lrow, lch)]) = ro;
+    if (tid < TT) sL[0][tid] = lg[min(tid, a.Lq - 1)];
+    else if (tid < 2 * TT) sD[0][tid - TT] = dg[min(tid - TT, a.Lq - 1)];
+  }
+  __syncthreads();
+  for (int qt = 0; qt < nqt; qt++) {
+    const int buf = qt & 1;
+    if (qt + 1 < nqt) {
+      const int qq = min((qt + 1) * TT + lrow, a.Lq - 1);
+      rq = *reinterpret_cast<const bf16x8*>(qg + (long)qq * a.ldq);
+      ro = *reinterpret_cast<const bf16x8*>(og + (long)qq * a.lddo);
+      if (tid < TT) rs = lg[min((qt + 1) * TT + tid, a.Lq - 1)];
+      else if (tid < 2 * TT) rs = dg[min((qt + 1) * TT + tid - TT, a.Lq - 1)];
+    }
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      s = mfma(kc_frag(sQc[buf], ln, 2 * ks + h), kf[ks], s);      // S[query][key]
+      dp = mfma(kc_frag(sOc[buf], ln, 2 * ks + h), vf[ks], dp);    // (dO V^T)[query][key]
+    }
+    const int qb = qt * TT;
+    f32x16 pd;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int qr = acc_row(r, h);
+      const float p = (qb + qr < a.Lq) ? __expf(s[r] * a.scale - sL[buf][qr]) : 0.f;
+      float g = dp[r], pk = p;
+      if (a.p_drop > 0.f) {
+        const bool keep = dropout_keep(a.seed, ((uint64_t)bh * a.Lq + qb + qr) * a.ldp + key, thr);
+        g = keep ? g * sc : 0.f;
+        pk = keep ? p * sc : 0.f;
+      }
+      pd[r] = pk;
+      s[r] = p * (g - sD[buf][qr]) * a.scale;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const bf16x8 ap = pack8(pd, t), as = pack8(s, t);
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        dv[nt] = mfma(ap, tr_frag(sOt[buf], nt * 32, 16 * t + 4 * h, 16 * t + 8 + 4 * h, lane), dv[nt]);
+        dk[nt] = mfma(as, tr_frag(sQt[buf], nt * 32, 16 * t + 4 * h, 16 * t + 8 + 4 * h, lane), dk[nt]);
+      }
+    }
+    if (qt + 1 < nqt) {
+      *reinterpret_cast<bf16x8*>(&sQc[buf ^ 1][kc_off(lrow, lch)]) = rq;
+      *reinterpret_cast<bf16x8*>(&sQt[buf ^ 1][tr_off(lrow, lch)]) = rq;
+      *reinterpret_cast<bf16x8*>(&sOc[buf ^ 1][kc_off(lrow, lch)]) = ro;
+      *reinterpret_cast<bf16x8*>(&sOt[buf ^ 1][tr_off(lrow, lch)]) = ro;
+      if (tid < TT) sL[buf ^ 1][tid] = rs;
+      else if (tid < 2 * TT) sD[buf ^ 1][tid - TT] = rs;
+    }
+    __syncthreads();
+  }
+  // dk/dv[nt]: lane = column (dh = nt*32 + ln), register r = key k0 + acc_row(r, h)
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int kk = k0 + acc_row(r, h);
+      if (kk < a.Lk) {
+        a.dK[((long)b * a.Lk + kk) * a.lddk + hd * DH + nt * 32 + ln] = (bf16)dk[nt][r];
+        a.dV[((long)b * a.Lk + kk) * a.lddv + hd * DH + nt * 32 + ln] = (bf16)dv[nt][r];
+      }
+    }
+}
+
+bool aligned8(long ld, const void* p) { return ld % 8 == 0 && ((uintptr_t)p % 16) == 0; }
+
+}  // namespace
+
+extern "C" int crog_flash_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
+                                   float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed, int ldp,
+                                   crog_stream_t stream) {
+  CROG_CHECK_ARG(head_dim == DH, "flash_attn: head_dim must be %d (got %d)", DH, head_dim);
+  CROG_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && ldp >= Lk && p_drop >= 0.f && p_drop < 1.f, "flash_attn_fwd: bad sizes");
+  CROG_CHECK_ARG(aligned8(ldq, Q) && aligned8(ldk, K) && aligned8(ldv, V) && ldo % 4 == 0 && ((uintptr_t)O % 8) == 0 && lse,
+                 "flash_attn_fwd: Q/K/V rows must be 16-byte aligned (ld %% 8 == 0), O 8-byte aligned");
+  CROG_CHECK_ARG((long)B * heads <= 65535, "flash_attn_fwd: B * heads too large");
+  AttnArgs a{};
+  a.Q = (const bf16*)Q; a.K = (const bf16*)K; a.V = (const bf16*)V; a.Out = (bf16*)O; a.lse = lse;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.Lq = Lq; a.Lk = Lk; a.heads = heads; a.ldp = ldp; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+  hipLaunchKernelGGL(flash_fwd_kernel, dim3(cdiv(Lq, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_flash_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo,
+                                   const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq, void* dK, int64_t lddk,
+                                   void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop,
+                                   uint64_t seed, int ldp, crog_stream_t stream) {
+  CROG_CHECK_ARG(head_dim == DH, "flash_attn: head_dim must be %d (got %d)", DH, head_dim);
+  CROG_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && ldp >= Lk && p_drop >= 0.f && p_drop < 1.f, "flash_attn_bwd: bad sizes");
+  CROG_CHECK_ARG(aligned8(ldq, Q) && aligned8(ldk, K) && aligned8(ldv, V) && aligned8(ldo, O) && aligned8(lddo, dO) && lse && D && dQ && dK && dV,
+                 "flash_attn_bwd: Q/K/V/O/dO rows must be 16-byte aligned (ld %% 8 == 0)");
+  CROG_CHECK_ARG((long)B * heads <= 65535, "flash_attn_bwd: B * heads too large");
+  AttnArgs a{};
+  a.Q = (const bf16*)Q; a.K = (const bf16*)K; a.V = (const bf16*)V; a.O = (const bf16*)O; a.dO = (const bf16*)dO;
+  a.dQ = (bf16*)dQ; a.dK = (bf16*)dK; a.dV = (bf16*)dV; a.lse = const_cast<float*>(lse); a.D = D;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.Lq = Lq; a.Lk = Lk; a.heads = heads; a.ldp = ldp; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+  hipLaunchKernelGGL(flash_bwd_dq_kernel, dim3(cdiv(Lq, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
+  CROG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(flash_bwd_dkdv_kernel, dim3(cdiv(Lk, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}

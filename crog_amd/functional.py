@@ -41,6 +41,8 @@ def _pad(n: int, m: int) -> int:
 
 import os as _os
 FUSED_REDUCE_MAX_PARTS = int(_os.environ.get("CROG_FUSED_REDUCE_MAX_PARTS", "256"))
+FLASH_ATTN = _os.environ.get("CROG_FLASH_ATTN", "1") != "0"     # fused attention kernels (csrc/attn.hip) where they apply
+FLASH_MIN_KEYS = 64
 
 
 class OutRef:
@@ -504,10 +506,23 @@ class MhaFn(Function):
             merged.append(list(j))
         for x_, w_, b_, (buf, col, ld) in merged:
             lin_fwd(x_, w_, buf, bias=b_, c_off=col, ldc=ld)
-        # ---- scores, softmax ----
         Lkp = _pad(Lk, 8)
-        S = torch.empty(B * heads, Lq, Lkp, device=dev, dtype=dtype)
         scale = dh ** -0.5
+        # ---- fused attention: no score matrix in HBM (unmasked bf16, head_dim 64, long key rows) ----
+        if FLASH_ATTN and dtype == torch.bfloat16 and dh == 64 and not causal and kpm is None and Lk >= FLASH_MIN_KEYS:
+            seed = RT.next_seed() if p_drop > 0 else 0
+            O = torch.empty(B * Lq, E, device=dev, dtype=dtype)
+            lse = torch.empty(B * heads * Lq, device=dev, dtype=torch.float32)
+            K.flash_attn_fwd(qb, kb, vb, (O, 0, E), lse, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp)
+            out = torch.empty(B * Lq, wo.rows, device=dev, dtype=dtype)
+            lin_fwd(O, wo, out, bias=bo, res=res)
+            ctx.cfg = (merged, qb, kb, vb, wo, bo, B, heads, Lq, Lk, Lkp, E, dh, scale, p_drop, seed, res is not None, same_qk, same_kv)
+            ctx.flash = True
+            ctx.save_for_backward(xq, xk, xv, lse, None, O)
+            return out
+        ctx.flash = False
+        # ---- scores, softmax ----
+        S = torch.empty(B * heads, Lq, Lkp, device=dev, dtype=dtype)
         K.gemm(dt, K.A_KC, K.B_KC, qb[0], kb[0], S, Lq, Lk, dh, qb[2], kb[2], Lkp, batch=B * heads, batch_inner=heads,
                sA=(Lq * qb[2], dh), sB=(Lk * kb[2], dh), sC=(heads * Lq * Lkp, Lq * Lkp), a_off=qb[1], b_off=kb[1], alpha=scale)
         Pd = None
@@ -556,6 +571,11 @@ class MhaFn(Function):
             dq_ = torch.empty_like(qb[0])
             dkv_ = torch.empty_like(kb[0])
             dqb, dkb, dvb = (dq_, 0, E), (dkv_, 0, 2 * E), (dkv_, E, 2 * E)
+        if ctx.flash:
+            lse = S
+            D = torch.empty_like(lse)
+            K.flash_attn_bwd(qb, kb, vb, (O, 0, E), (dO, 0, E), lse, D, dqb, dkb, dvb, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp)
+            return MhaFn._proj_backward(ctx, merged, qb, dqb, dkb, xq, xk, xv, dout, has_res, same_qk, same_kv, dev, dtype)
         Pm = Pd if Pd is not None else S
         bh = B * heads
         # dV[b,h] = Pm^T dO
@@ -571,8 +591,11 @@ class MhaFn(Function):
                sA=(heads * Lq * Lkp, Lq * Lkp), sB=(Lk * kb[2], dh), sC=(Lq * dqb[2], dh), b_off=kb[1], c_off=dqb[1], alpha=scale)
         K.gemm(dt, K.A_MC, K.B_NC, dP, qb[0], dkb[0], Lk, dh, Lq, Lkp, qb[2], dkb[2], batch=bh, batch_inner=heads,
                sA=(heads * Lq * Lkp, Lq * Lkp), sB=(Lq * qb[2], dh), sC=(Lk * dkb[2], dh), b_off=qb[1], c_off=dkb[1], alpha=scale)
-        # projections backward
-        dbufs = {id(qb[0]): None}
+        return MhaFn._proj_backward(ctx, merged, qb, dqb, dkb, xq, xk, xv, dout, has_res, same_qk, same_kv, dev, dtype)
+
+    @staticmethod
+    def _proj_backward(ctx, merged, qb, dqb, dkb, xq, xk, xv, dout, has_res, same_qk, same_kv, dev, dtype):
+        """Backward of the q/k/v input projections from the gradient buffers that mirror the projection buffers."""
         grads = {}
         for x_, w_, b_, (buf, col, ld) in merged:
             dbuf = dqb[0] if buf is qb[0] else dkb[0]

@@ -209,6 +209,18 @@ int crog_add_dropout(int dtype, const void* a, int64_t lda, const void* b, int64
 /* mode 0: dx = dy*(y>0) (ReLU, y = output);  mode 1: QuickGELU backward, y = pre-activation */
 int crog_act_bwd(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, void* dx, int64_t lddx,
                  int64_t M, int C, int mode, crog_stream_t stream);
+/* Fused attention (no score matrix in HBM) for the unmasked bf16, head_dim = 64 case: decoder self-attention layers.py:291-296,324,
+ * ViT blocks clip.py:246-260, attention pooling clip.py:119-139.  Element (b, l, head, d) of X lives at X + (b*L + l)*ldx + head*64 + d
+ * (so Q/K/V may be column slices of one packed projection buffer).  lse[(b*heads + head)*Lq + q] = log-sum-exp of the scaled
+ * scores; attention dropout uses the hash of crog_softmax_fwd with index row*ldp + key (ldp = the unfused path's padded row).
+ * The backward needs O, dO, lse and a float workspace D of B*heads*Lq entries. */
+int crog_flash_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O,
+                        int64_t ldo, float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale,
+                        float p_drop, uint64_t seed, int ldp, crog_stream_t stream);
+int crog_flash_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O,
+                        int64_t ldo, const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq,
+                        void* dK, int64_t lddk, void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim,
+                        float scale, float p_drop, uint64_t seed, int ldp, crog_stream_t stream);
 /* QuickGELU x*sigmoid(1.702x): clip.py:234-236 */
 int crog_quickgelu_fwd(int dtype, const void* u, int64_t ldu, void* out, int64_t ldo, int64_t M, int C,
                        crog_stream_t stream);
