@@ -81,14 +81,20 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
-// Counter-based RNG for dropout: one 32-bit hash per (seed, offset); keep-mask reproducible
-// between forward and backward because both recompute it from the same (seed, index).
+// Counter-based RNG for dropout: one 32-bit hash per (seed, offset); the keep-mask is reproducible between forward and
+// backward (and between the fused and unfused attention paths) because every kernel recomputes it from the same
+// (seed, element index).  32-bit multiply-xorshift rounds (murmur3-style finaliser): ~10 VALU instructions per element — the
+// 64-bit splitmix used before cost ~40 and made the attention kernels VALU-bound.
 __device__ inline uint32_t hash_u32(uint64_t seed, uint64_t idx) {
-  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  uint32_t x = (uint32_t)idx ^ ((uint32_t)(idx >> 32) * 0x9E3779B1u) ^ (uint32_t)seed;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x += (uint32_t)(seed >> 32);
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  x *= 0x27D4EB2Fu;
+  x ^= x >> 15;
+  return x;
 }
 // returns true when the element is KEPT with probability (1-p); thr = p * 2^32
 __device__ inline bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thr) {
