@@ -70,7 +70,7 @@ __device__ inline float xor32(float v) { return __shfl_xor(v, 32, 64); }
 // =====================================================================================================================
 // forward: O = softmax(scale Q K^T) [dropout] V, lse = row log-sum-exp.  grid (ceil(Lq / 128), B * heads)
 // =====================================================================================================================
-__global__ void __launch_bounds__(NTHR) flash_fwd_kernel(const AttnArgs a) {
+__global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 sK[2][TILE];
   __shared__ __attribute__((aligned(16))) bf16 sV[2][TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ln = lane & 31;
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(NTHR) flash_fwd_kernel(const AttnArgs a) {
 // =====================================================================================================================
 // backward 1: D = rowsum(dO * O);  dQ = scale * dS K  with dS = P * (dropout'(dO V^T) - D).  Same blocking as the forward.
 // =====================================================================================================================
-__global__ void __launch_bounds__(NTHR) flash_bwd_dq_kernel(const AttnArgs a) {
+__global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 sKc[2][TILE];
   __shared__ __attribute__((aligned(16))) bf16 sKt[2][TILE];
   __shared__ __attribute__((aligned(16))) bf16 sVc[2][TILE];
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(NTHR) flash_bwd_dq_kernel(const AttnArgs a) {
 // backward 2: dV = dropout(P)^T dO,  dK = scale * dS^T Q.  Each wave owns 32 keys; queries stream through LDS.
 // grid (ceil(Lk / 128), B * heads).  Needs lse (forward) and D (flash_bwd_dq_kernel).
 // =====================================================================================================================
-__global__ void __launch_bounds__(NTHR) flash_bwd_dkdv_kernel(const AttnArgs a) {
+__global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 sQc[2][TILE];
   __shared__ __attribute__((aligned(16))) bf16 sQt[2][TILE];
   __shared__ __attribute__((aligned(16))) bf16 sOc[2][TILE];
