@@ -36,12 +36,17 @@ if tb: L += ["", f"Measured HBM traffic (all kernels): {tb/1e9/ (f[next(iter(f))
 import json
 names = {(1, 0): "conv3x3_fwd", (1, 2): "conv3x3_dgrad", (2, 3): "conv3x3_wgrad", (0, 0): "lin_fwd"}
 pm = {}
-for k in f:
+for k in f:   # one roofline key can cover several tile-shape instantiations of the kernel: aggregate launches and bytes
     m = re.search(r"gemm_dma_kernelIDF16bLi(\d)ELi(\d)E", k)
     if m and (int(m.group(1)), int(m.group(2))) in names and f[k][0]:
-        pm[names[(int(m.group(1)), int(m.group(2)))]] = dict(
-            kernel=k, launches=f[k][0], bytes_per_launch=round((2 * f[k][1] / f[k][0] + (w[k][1] / w[k][0] if k in w and w[k][0] else 0)) * 1024),
-            source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, {tag}")
+        key = names[(int(m.group(1)), int(m.group(2)))]
+        e = pm.setdefault(key, dict(kernels=[], launches=0, _bytes=0.0,
+                                    source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, {tag}"))
+        e["kernels"].append(k)
+        e["launches"] += f[k][0]
+        e["_bytes"] += (2 * f[k][1] + (w[k][1] if k in w else 0)) * 1024
+for e in pm.values():
+    e["bytes_per_launch"] = round(e.pop("_bytes") / e["launches"])
 if pm: json.dump(pm, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(out, f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
 print("\n".join(L[:16]))
