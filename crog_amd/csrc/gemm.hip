@@ -256,6 +256,29 @@ template <typename T, int R, int NT> struct BLoaderSel<T, CROG_B_NC, R, NT> { us
 template <typename T, int R, int NT> struct BLoaderSel<T, CROG_B_NC_DGRAD, R, NT> { using type = TrLoader<T, 1, R, NT>; static constexpr bool TR = true; };
 template <typename T, int R, int NT> struct BLoaderSel<T, CROG_B_NC_IM2COL, R, NT> { using type = TrLoader<T, 2, R, NT>; static constexpr bool TR = true; };
 
+__device__ inline float frag_sum(const Frag<bf16>& f) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; j++) s += (float)f.v[j];
+  return s;
+}
+__device__ inline float frag_sum(const Frag<float>& f) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; j++) s += f.v[j];
+  return s;
+}
+// a_sum[m] += sum over this block's k range of A(m, k): lanes of the two half-waves hold disjoint k slots of the same row
+template <int WM>
+__device__ inline void flush_a_sum(const float (&asum)[WM], float* dst, int mbase, int M, int lane) {
+#pragma unroll
+  for (int i = 0; i < WM; i++) {
+    const float v = asum[i] + __shfl_xor(asum[i], 32, 64);
+    const int m = mbase + i * 32 + (lane & 31);
+    if ((lane >> 5) == 0 && m < M) atomicAdd(dst + m, v);
+  }
+}
+
 __device__ inline float apply_act(float v, int act) {
   if (act == CROG_ACT_RELU) return fmaxf(v, 0.f);
   if (act == CROG_ACT_QUICKGELU) return v / (1.f + expf(-1.702f * v));
@@ -564,6 +587,10 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))
   lb.store(reinterpret_cast<T*>(smem + 2 * OPA));
   __syncthreads();
 
+  const bool do_asum = p.a_sum != nullptr && tn == 0 && wc == 0;   // block- and wave-uniform
+  float asum[WM];
+#pragma unroll
+  for (int i = 0; i < WM; i++) asum[i] = 0.f;
   int cur = 0;
   for (int kt = kt0; kt < kt1; kt++) {
     const bool more = kt + 1 < kt1;
@@ -587,6 +614,10 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))
         if constexpr (BTR) fb[j] = frag_tr<HWTR, BROW>(bt, (wc * WN + j) * 32, ks, lane);
         else fb[j] = frag_kc(bt, (wc * WN + j) * 32 + r, ks, h);
       }
+      if (do_asum) {
+#pragma unroll
+        for (int i = 0; i < WM; i++) asum[i] += frag_sum(fa[i]);
+      }
 #pragma unroll
       for (int i = 0; i < WM; i++)
 #pragma unroll
@@ -599,6 +630,7 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))
     __syncthreads();
     cur ^= 1;
   }
+  if (do_asum) flush_a_sum<WM>(asum, p.a_sum, m0 + wr * WM * 32, p.M, lane);
 
   gemm_epilogue<T, S>(acc, p, smem, m0, n0, zs, coff);
 }
@@ -892,6 +924,10 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 25
 #pragma unroll
   for (int s = 0; s < DMA_NSTAGE - 1; s++)
     if (s < nt) dma_issue<TILE_A_B, TILE_B_B, NIA, NIB>(da, db, g, smem, wave, kt0 + s, CROG_KMEM(kt0 + s), s);
+  const bool do_asum = p.a_sum != nullptr && tn == 0 && wc == 0;   // block- and wave-uniform
+  float asum[WM];
+#pragma unroll
+  for (int i = 0; i < WM; i++) asum[i] = 0.f;
   int stage = 0;
   for (int t = 0; t < nt; t++) {
     // k-tiles still allowed in flight behind tile t: min(depth - 2, tiles left); 4 DMA instructions per tile and wave
@@ -914,6 +950,10 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 25
       for (int i = 0; i < WM; i++) fa[i] = OA::frag(at, (wr * WM + i) * 32, ks, lane);
 #pragma unroll
       for (int j = 0; j < WN; j++) fb[j] = OB::frag(bt, (wc * WN + j) * 32, ks, lane);
+      if (do_asum) {
+#pragma unroll
+        for (int i = 0; i < WM; i++) asum[i] += frag_sum(fa[i]);
+      }
 #pragma unroll
       for (int i = 0; i < WM; i++)
 #pragma unroll
@@ -922,6 +962,7 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 25
     stage = stage == DMA_NSTAGE - 1 ? 0 : stage + 1;
   }
 #undef CROG_KMEM
+  if (do_asum) flush_a_sum<WM>(asum, p.a_sum, m0 + wr * WM * 32, p.M, lane);
   __syncthreads();
   gemm_epilogue<T, S>(acc, p, smem, m0, n0, zs, coff);
 }
@@ -1195,6 +1236,7 @@ extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
                  "crog_gemm: splitk > 1 needs atomic fp32 output, no activation, no residual");
   CROG_CHECK_ARG(!d.R || d.batch == 1, "crog_gemm: residual only for unbatched GEMM");
   CROG_CHECK_ARG(!d.col_stats || (d.batch == 1 && d.splitk == 1), "crog_gemm: col_stats needs batch == 1 and splitk == 1");
+  CROG_CHECK_ARG(!d.a_sum || d.batch == 1, "crog_gemm: a_sum needs batch == 1");
   CROG_CHECK_ARG((long)d.batch * d.splitk <= 65535, "crog_gemm: batch*splitk too large");
   hipStream_t s = (hipStream_t)stream;
   const bool hw = hwtr_enabled();

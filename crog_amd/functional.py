@@ -118,8 +118,8 @@ def lin_dgrad(dy, w: WRef, dx, *, accumulate_into: Optional[torch.Tensor] = None
            a_off=a_off, b_off=w.off, R=accumulate_into, ldr=K.mat(accumulate_into)[2] if accumulate_into is not None else 0)
 
 
-def lin_wgrad(dy, x, w: WRef, *, a_off=0, lda=None, N=None):
-    """G[w] += dy[M, N]^T @ x[M, K]"""
+def lin_wgrad(dy, x, w: WRef, *, a_off=0, lda=None, N=None, bias: Optional[WRef] = None):
+    """G[w] += dy[M, N]^T @ x[M, K];  with `bias`: G[bias] += column sums of dy, folded into the same launch (a_sum)."""
     M, n, ld = K.mat(dy)
     if N is not None:
         n = N
@@ -127,7 +127,7 @@ def lin_wgrad(dy, x, w: WRef, *, a_off=0, lda=None, N=None):
     dt = _cdt(x)
     sk = K.pick_splitk(n, Kd, M, _bk(dt))
     K.gemm(dt, K.A_MC, K.B_NC, dy, x, w.G, n, Kd, M, lda if lda is not None else ld, ldx, w.cols, a_off=a_off, c_off=w.off,
-           splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+           splitk=sk, out_mode=K.OUT_F32_ATOMIC, a_sum=bias.G if bias is not None else None, a_sum_off=bias.off if bias is not None else 0)
 
 
 def bias_grad(dy, b: WRef, col0=0, n=None):
@@ -358,9 +358,7 @@ class LinearFn(Function):
                 g = torch.empty(dy.shape, device=dy.device, dtype=dy.dtype)
                 K.act_bwd(dy, y, g, 0 if act == K.ACT_RELU else 2)
         def wgrad():
-            lin_wgrad(g, x, w)
-            if b is not None:
-                bias_grad(g, b)
+            lin_wgrad(g, x, w, bias=b)
         if has_res and g is dy:
             wgrad()   # dy is handed on as the residual's gradient and autograd may accumulate into it IN PLACE: keep the read ordered
         else:
@@ -551,9 +549,7 @@ class MhaFn(Function):
         dout = K.as_mat(dout)
         # out projection
         def wgrad_out():
-            lin_wgrad(dout, O, wo)
-            if bo is not None:
-                bias_grad(dout, bo)
+            lin_wgrad(dout, O, wo, bias=bo)
         if has_res:
             wgrad_out()   # dout doubles as the residual's gradient (possible in-place accumulation by autograd): stay on this stream
         else:
@@ -600,9 +596,7 @@ class MhaFn(Function):
         for x_, w_, b_, (buf, col, ld) in merged:
             dbuf = dqb[0] if buf is qb[0] else dkb[0]
             def wgrad_proj(dbuf=dbuf, x_=x_, w_=w_, b_=b_, col=col, ld=ld):
-                lin_wgrad(dbuf, x_, w_, a_off=col, lda=ld, N=w_.rows)
-                if b_ is not None:
-                    bias_grad(dbuf[:, col:col + w_.rows], b_)
+                lin_wgrad(dbuf, x_, w_, a_off=col, lda=ld, N=w_.rows, bias=b_)
             RT.on_wgrad_stream(wgrad_proj, dbuf, x_)
             w_.done()
             if b_ is not None:
@@ -859,9 +853,7 @@ class Conv3BiasActFn(Function):
         def wgrad():
             sk = K.pick_splitk(C, 9 * cin, M, _bk(dt), conv=True)
             K.gemm(dt, K.A_MC, K.B_NC_IM2COL, g, x, w.G, C, 9 * cin, M, C, K.mat(x)[2], w.cols, c_off=w.off, conv=(H, W, cin), splitk=sk,
-                   out_mode=K.OUT_F32_ATOMIC)
-            if b is not None:
-                bias_grad(g, b)
+                   out_mode=K.OUT_F32_ATOMIC, a_sum=b.G if b is not None else None, a_sum_off=b.off if b is not None else 0)
         RT.on_wgrad_stream(wgrad, g, x)
         w.done()
         if b is not None:

@@ -100,7 +100,7 @@ def as_mat(t: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, ldc, *, batch=1, batch_inner=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, conv=(0, 0, 0), alpha=1.0, bias=None, act=ACT_NONE, R=None,
-         ldr=0, out_mode=OUT_T, col_stats=None, a_off=0, b_off=0, c_off=0):
+         ldr=0, out_mode=OUT_T, col_stats=None, a_off=0, b_off=0, c_off=0, a_sum=None, a_sum_off=0):
     """Raw descriptor launch. A/B/C are tensors (or ints = device addresses); *_off are element offsets."""
     esz = 2 if dtype == BF16 else 4
     csz = esz if out_mode == OUT_T else 4
@@ -127,6 +127,7 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
     d.ldr = int(ldr)
     d.out_mode = int(out_mode)
     d.col_stats = ptr(col_stats)
+    d.a_sum = (ptr(a_sum) + 4 * a_sum_off) if a_sum is not None else None
     d.debug = DEBUG_FLAGS
     if PROF is not None and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -93,6 +93,10 @@ typedef struct crog_gemm_desc {
   float* col_stats;  /* NULL, or [ceil(M/128)][N][2] fp32 partial (sum, sum of squares) over the
                         rows of each 128-row tile of v = alpha*acc + bias (BatchNorm statistics,
                         clip.py:18,21,26; layers.py:11).  batch must be 1, splitk 1. */
+  float* a_sum;      /* NULL, or fp32 [M]: a_sum[m] += sum_k A(m, k), accumulated atomically by the blocks of the first
+                        N-tile (every split adds its share).  With A = dy^T (CROG_A_MC) this is the bias gradient of the
+                        nn.Linear / bias-conv whose weight gradient the GEMM computes (clip.py:249-251, layers.py:58,
+                        298-301, ssg.py:123-133): no separate column-sum pass over dy.  batch must be 1. */
 } crog_gemm_desc;
 
 int crog_gemm(const crog_gemm_desc* d, crog_stream_t stream);

@@ -99,9 +99,12 @@ def test_gemm_tn(K, dt, M, N, K_, split):
     # wgrad shape: C[m][n] = sum_k A_mem[k][m] * B_mem[k][n]
     a, b = rnd(K_, M, dt=dt), rnd(K_, N, dt=dt, seed=1)
     c = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+    asum = torch.zeros(M + 3, device="cuda")   # bias gradient folded into the weight-gradient launch (a_sum[m] += sum_k A(m, k))
     K.gemm(K.dcode(dt), K.A_MC, K.B_NC, a, b, c, M, N, K_, M, N, N, splitk=split,
-           out_mode=K.OUT_F32_ATOMIC if split > 1 else K.OUT_F32)
+           out_mode=K.OUT_F32_ATOMIC if split > 1 else K.OUT_F32, a_sum=asum, a_sum_off=1)
     close(c, a.float().t() @ b.float(), dt, scale=math.sqrt(K_) / 4)
+    close(asum[1:M + 1], a.float().sum(0), dt, scale=math.sqrt(K_) / 4)
+    assert float(asum[0]) == 0.0 and float(asum[M + 1:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dt", DT)
