@@ -148,6 +148,17 @@ class BnBuffers:
         self.momentum, self.eps = momentum, eps
 
 
+class GradSlot:
+    """Side channel that carries a residual branch's gradient from the op that consumes the identity (`res_slot`) to the op
+    whose data gradient it must be added to (`grad_slot`), so the sum happens in that GEMM's residual epilogue instead of a
+    separate autograd accumulation pass (Bottleneck without downsample, clip.py:44-57: grad(x) = dgrad(conv1) + grad(identity))."""
+
+    __slots__ = ("t",)
+
+    def __init__(self):
+        self.t = None
+
+
 class ConvBnAct(Function):
     """y = [relu]( BN( conv_k(x) ) [+ res] ).   ksize: 0 (no conv), 1, 3, or 's' (stem 3x3/s2 on an NCHW fp32 image).
     Reference: Bottleneck clip.py:44-57, stem clip.py:208-213, conv_layer layers.py:8-11, linear_layer layers.py:14-16,
@@ -156,8 +167,10 @@ class ConvBnAct(Function):
     train_crog.py:113-114)."""
 
     @staticmethod
-    def forward(ctx, x, res, _wp, _gp, _bp, w: Optional[WRef], bn: BnBuffers, ksize, relu: bool, training: bool, out, wpad, dtype):
+    def forward(ctx, x, res, _wp, _gp, _bp, w: Optional[WRef], bn: BnBuffers, ksize, relu: bool, training: bool, out, wpad, dtype,
+                grad_slot=None, res_slot=None):
         dev = x.device
+        ctx.slots = (grad_slot, res_slot)
         if ksize == "s":
             B, _, Hi, Wi = x.shape
             H, W = Hi // 2, Wi // 2
@@ -264,6 +277,13 @@ class ConvBnAct(Function):
         dz = torch.empty(lead + (C,), device=dev, dtype=dtype)
         dres = torch.empty(lead + (C,), device=dev, dtype=dtype) if ctx.has_res else None
         K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss)
+        grad_slot, res_slot = ctx.slots
+        if res_slot is not None and dres is not None:   # hand the identity's gradient to the block's first convolution
+            res_slot.t = dres
+            dres = None
+        extra = None
+        if grad_slot is not None and grad_slot.t is not None and ksize == 1 and ctx.x_needs:
+            extra, grad_slot.t = grad_slot.t, None
         dx = None
         if ksize == 0:
             dx = dz
@@ -293,19 +313,20 @@ class ConvBnAct(Function):
             RT.on_wgrad_stream(wgrad, dz, x, gt if wpad is not None else None)
             if ksize == 1 and ctx.x_needs:
                 dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
-                K.gemm(dt, K.A_KC, K.B_NC, dz, wt, dx, M, cin, C, C, wcols, cin, b_off=woff)
+                K.gemm(dt, K.A_KC, K.B_NC, dz, wt, dx, M, cin, C, C, wcols, cin, b_off=woff, R=extra, ldr=K.mat(extra)[2] if extra is not None else 0)
             elif ksize == 3 and ctx.x_needs:
                 B, H, W = lead
                 dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
                 K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, dz, wt, dx, M, cin, 9 * C, C, cin, cin, b_off=woff, conv=(H, W, C))
             w.done()
-        return (dx, dres) + (None,) * 11
+        return (dx, dres) + (None,) * 13
 
 
-def conv_bn_act(x, w: Optional[WRef], bn: BnBuffers, *, ksize, relu=True, res=None, training=True, out=None, wpad=None, dtype=None):
+def conv_bn_act(x, w: Optional[WRef], bn: BnBuffers, *, ksize, relu=True, res=None, training=True, out=None, wpad=None, dtype=None,
+                grad_slot=None, res_slot=None):
     dtype = dtype if dtype is not None else x.dtype
     wp = w.param if w is not None else None
-    return ConvBnAct.apply(x, res, wp, bn.gamma.param, bn.beta.param, w, bn, ksize, relu, training, out, wpad, dtype)
+    return ConvBnAct.apply(x, res, wp, bn.gamma.param, bn.beta.param, w, bn, ksize, relu, training, out, wpad, dtype, grad_slot, res_slot)
 
 
 # ------------------------------------------------------------------------------------------------

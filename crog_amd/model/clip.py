@@ -38,7 +38,9 @@ class Bottleneck(Bound):
 
     def forward(self, x):
         tr = self.training
-        out = Fn.conv_bn_act(x, self.conv1.w, self.bn1.buffers_ref(), ksize=1, relu=True, training=tr)
+        # identity blocks: the residual's gradient rides a slot into conv1's dgrad epilogue (no separate accumulation pass)
+        slot = Fn.GradSlot() if (self.downsample is None and tr and x.requires_grad) else None
+        out = Fn.conv_bn_act(x, self.conv1.w, self.bn1.buffers_ref(), ksize=1, relu=True, training=tr, grad_slot=slot)
         out = Fn.conv_bn_act(out, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr)
         if self.stride > 1:
             out = Fn.avgpool2(out)
@@ -47,7 +49,7 @@ class Bottleneck(Bound):
             if self.stride > 1:
                 identity = Fn.avgpool2(x)
             identity = Fn.conv_bn_act(identity, self.downsample["0"].w, self.downsample["1"].buffers_ref(), ksize=1, relu=False, training=tr)
-        return Fn.conv_bn_act(out, self.conv3.w, self.bn3.buffers_ref(), ksize=1, relu=True, res=identity, training=tr)
+        return Fn.conv_bn_act(out, self.conv3.w, self.bn3.buffers_ref(), ksize=1, relu=True, res=identity, training=tr, res_slot=slot)
 
 
 _BICUBIC_CACHE = {}
