@@ -122,7 +122,9 @@ class ModifiedResNet(Bound):
         mods += [Bottleneck(self._inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*mods)
 
-    def forward(self, img, dtype):
+    def forward(self, img, dtype, after_layer1=None):
+        """`after_layer1`: host-side hook called once the stem and layer1 (few launches, most of the tower's GPU time) are
+        enqueued — CROG.forward issues the launch-bound text tower there, so the GPU has bulk work while the host catches up."""
         tr = self.training
         c1 = self.conv1.weight.shape[0]
         if c1 != 32:
@@ -132,6 +134,8 @@ class ModifiedResNet(Bound):
         x = Fn.conv_bn_act(x, self.conv3.w, self.bn3.buffers_ref(), ksize=3, relu=True, training=tr)
         x = Fn.avgpool2(x)
         x = self.layer1(x)
+        if after_layer1 is not None:
+            after_layer1()
         x2 = self.layer2(x)
         x3 = self.layer3(x2)
         x4 = self.layer4(x3)
@@ -263,7 +267,11 @@ class CLIP(Bound):
         self.tproj = WRef(store, self.text_projection)
 
     # channels-last internal forms -------------------------------------------------------------
-    def image_features(self, image, dtype):
+    def image_features(self, image, dtype, after_layer1=None):
+        if after_layer1 is not None and isinstance(self.visual, ModifiedResNet):
+            return self.visual(image.float().contiguous(), dtype, after_layer1)
+        if after_layer1 is not None:
+            after_layer1()
         return self.visual(image.float().contiguous(), dtype)
 
     def text_features(self, text, dtype):

@@ -7,6 +7,8 @@ Compute dtype: bf16 when called under torch autocast (the reference's training s
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -167,9 +169,16 @@ class CROG(nn.Module):
                     self._side = torch.cuda.Stream(device=dev)
                 RT.streams = [main, self._side]
                 self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    wfeat, state = self.backbone.text_features(word, dtype)
-                vis = self.backbone.image_features(img, dtype)
+                txt = []
+
+                def issue_text():   # called by the image tower after its stem + layer1 are enqueued (host issue order only)
+                    with torch.cuda.stream(self._side):
+                        txt.extend(self.backbone.text_features(word, dtype))
+                early = os.environ.get("CROG_TEXT_FIRST", "0") == "1"
+                if early:
+                    issue_text()
+                vis = self.backbone.image_features(img, dtype, None if early else issue_text)
+                wfeat, state = txt
                 main.wait_stream(self._side)
                 wfeat.record_stream(main)
                 state.record_stream(main)
