@@ -49,8 +49,27 @@ def dcode(t_or_dtype) -> int:
     raise TypeError(f"crog_amd kernels support float32 / bfloat16 activations, got {dt}")
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_DEV_INDEX = None
+_STREAM_OVERRIDE = None   # raw handle set by Runtime.on_wgrad_stream while it enqueues weight-gradient kernels on the side stream
+
+
+def set_stream_override(raw):
+    global _STREAM_OVERRIDE
+    _STREAM_OVERRIDE = raw
+
+
 def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream.  torch.cuda.current_stream() costs ~8 us of Python per call (device-index
+    plumbing) and is hit once per kernel launch (~1300 per step); the raw accessor is ~0.3 us."""
+    global _DEV_INDEX
+    if _STREAM_OVERRIDE is not None:
+        return _STREAM_OVERRIDE
+    if _RAW_STREAM is None:
+        return torch.cuda.current_stream().cuda_stream
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()
+    return _RAW_STREAM(_DEV_INDEX)
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -64,7 +83,13 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 def mat(t: torch.Tensor):
     """View a tensor as a row matrix: returns (rows, cols, ld). Last dim must be unit-stride and
     the leading dims must collapse to a single row index with constant stride ld."""
-    if t.dim() == 1:
+    nd = t.dim()
+    if nd == 2:   # fast path: the common case on the hot path
+        r, c = t.shape
+        s0, s1 = t.stride()
+        if (s1 == 1 or c == 1) and s0 >= c:
+            return r, c, s0
+    if nd == 1:
         if t.stride(0) != 1 and t.numel() > 1:
             raise ValueError("1-D tensor must be contiguous")
         return 1, t.shape[0], t.shape[0]
@@ -72,9 +97,9 @@ def mat(t: torch.Tensor):
         raise ValueError(f"last dim must be contiguous, strides={t.stride()}")
     ld = t.stride(-2)
     rows = 1
-    for i in range(t.dim() - 1):
+    for i in range(nd - 1):
         rows *= t.shape[i]
-    for i in range(t.dim() - 2):
+    for i in range(nd - 2):
         if t.shape[i] != 1 and t.stride(i) != t.stride(i + 1) * t.shape[i + 1]:
             raise ValueError(f"leading dims do not collapse: shape={tuple(t.shape)} strides={t.stride()}")
     if ld < t.shape[-1]:

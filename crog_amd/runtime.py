@@ -61,8 +61,13 @@ class Runtime:
                 pass
         cur = torch.cuda.current_stream()
         s.wait_stream(cur)
-        with torch.cuda.stream(s):
+        # fn() only launches kernels of this library: point them at the side stream directly instead of paying torch's
+        # stream-context manager (~25 us of Python) ~150 times per step
+        K.set_stream_override(s.cuda_stream)
+        try:
             fn()
+        finally:
+            K.set_stream_override(None)
         for t in tensors:
             if t is not None:
                 t.record_stream(s)
