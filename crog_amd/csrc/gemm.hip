@@ -848,16 +848,19 @@ __device__ inline void dma_issue(const OA& da, const OB& db, const ConvGeom& g, 
 }
 
 template <int N> __device__ inline void wait_vmcnt() {
-  static_assert(N == 0 || N == 2 || N == 4 || N == 5 || N == 8 || N == 10, "add the immediate");
+  static_assert(N >= 0 && N <= 10 && N != 1 && N != 7 && N != 9, "add the immediate");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
 }
 
 using ShapeDma8 = Shape<4, 2, 2, 4>;   // 256 x 256, 8 waves, 128 accumulator registers per lane
+using ShapeDma8x = Shape<2, 2, 4, 2>;  // 256 x 128, 8 waves of 64 x 64 (64 accumulator registers, as the 128^2 tile): A/B experiments
 using ShapeTall = Shape<2, 2, 4, 1>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
 using ShapeWide = Shape<2, 2, 1, 4>;   //  64 x 256, 4 waves: weight gradients of those layers (M = Cout = 32 / 64)
 using ShapeDma64 = Shape<1, 1, 2, 2>;  //  64 x  64, 4 waves: small GEMMs (text tower, attention pooling), no BN statistics
@@ -1154,12 +1157,13 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     static int force = -1;   // CROG_GEMM_DMA_TILE = mid | tall | wide | 64 : A/B runs only (never with BN statistics on 64-row tiles)
     if (force < 0) {
       const char* e = getenv("CROG_GEMM_DMA_TILE");
-      force = !e ? 0 : (e[0] == 'm' ? 1 : (e[0] == 't' ? 2 : (e[0] == 'w' ? 3 : (e[0] == '6' ? 4 : 0))));
+      force = !e ? 0 : (e[0] == 'm' ? 1 : (e[0] == 't' ? 2 : (e[0] == 'w' ? 3 : (e[0] == '6' ? 4 : (e[0] == 'x' ? 5 : 0)))));
     }
     if (force == 1) return dispatch_dma<T, ShapeMid>(d, s);
     if (force == 2) return dispatch_dma<T, ShapeTall>(d, s);
     if (force == 3 && !d.col_stats) return dispatch_dma<T, ShapeWide>(d, s);
     if (force == 4 && !d.col_stats) return dispatch_dma<T, ShapeDma64>(d, s);
+    if (force == 5) return dispatch_dma<T, ShapeDma8x>(d, s);
     if (alt && forced_shape() == 0) {
       if (d.col_stats) {
         if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
