@@ -44,9 +44,10 @@ __global__ void __launch_bounds__(NT) head_unpack_wgrad_kernel(const float* __re
   }
 }
 
-// out[b,h,y,x] = bias[b] + sum_tap t[((b*P + p')*heads + h)*16 + tap]
+// out[b,h,y,x] = bias[b] + sum_tap (t[((b*P + p')*heads + h)*16 + tap] + tbias[(b*heads + h)*16 + tap])   (tbias optional)
 __global__ void __launch_bounds__(NT) head_stencil_fwd_kernel(const float* __restrict__ t, const float* __restrict__ word, long ldw, int bias_col,
-                                                              float* __restrict__ out, int B, int heads, int H, int W) {
+                                                              const float* __restrict__ tbias, float* __restrict__ out, int B, int heads, int H,
+                                                              int W) {
   const long P = (long)H * W;
   GRID_STRIDE(i, (long)B * heads * P) {
     const int x = (int)(i % W), y = (int)((i / W) % H);
@@ -56,7 +57,10 @@ __global__ void __launch_bounds__(NT) head_stencil_fwd_kernel(const float* __res
 #pragma unroll
     for (int tap = 0; tap < 9; tap++) {
       const int sy = y + tap / 3 - 1, sx = x + tap % 3 - 1;
-      if (sy >= 0 && sy < H && sx >= 0 && sx < W) acc += t[((b * P + (long)sy * W + sx) * heads + h) * 16 + tap];
+      if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+        acc += t[((b * P + (long)sy * W + sx) * heads + h) * 16 + tap];
+        if (tbias) acc += tbias[(b * heads + h) * 16 + tap];
+      }
     }
     out[i] = acc;
   }
@@ -84,6 +88,57 @@ __global__ void __launch_bounds__(NT) head_stencil_bwd_kernel(const float* __res
     for (int v = 0; v < 16 / Elem<T>::VEC; v++) stg16(dt + i * 16 + v * Elem<T>::VEC, o[v]);
   }
 }
+// ---- folded 1x1 conv (vis.4, layers.py:58) + dynamic 3x3 head: the conv's bias reaches the logits through the per-sample
+// constants cb[b][h][tap] = sum_c b5[h*C + c] * w_b[c][tap] (one per source pixel and tap) ------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT) head_cb_fwd_kernel(const float* __restrict__ b5, const T* __restrict__ wpad, float* __restrict__ cb, int B,
+                                                         int heads, int C) {
+  GRID_STRIDE(i, (long)B * heads * 16) {
+    const int tap = (int)(i & 15);
+    const int h = (int)((i >> 4) % heads);
+    const long b = (i >> 4) / heads;
+    float acc = 0.f;
+    for (int c = 0; c < C; c++) acc += b5[h * C + c] * Elem<T>::to_f(wpad[(b * C + c) * 16 + tap]);
+    cb[i] = acc;
+  }
+}
+// dcb[(b*heads + h)*16 + tap] += sum_p dt[((b*P + p)*heads + h)*16 + tap]      grid (chunks, B), dcb zeroed by the launcher
+template <typename T>
+__global__ void __launch_bounds__(NT) head_tap_sums_kernel(const T* __restrict__ dt, float* __restrict__ dcb, long P, int heads) {
+  const int cols = heads * 16;
+  const int groups = NT / cols;
+  const int col = threadIdx.x % cols, grp = threadIdx.x / cols;
+  if (grp >= groups) return;
+  const long b = blockIdx.y;
+  const long per = (P + gridDim.x - 1) / gridDim.x;
+  const long p0 = blockIdx.x * per, p1 = min(p0 + per, P);
+  float acc = 0.f;
+  for (long p = p0 + grp; p < p1; p += groups) acc += Elem<T>::to_f(dt[(b * P + p) * cols + col]);
+  atomicAdd(dcb + b * cols + col, acc);
+}
+// db5[h*C + c] += sum_{b,tap} dcb[b][h][tap] * w_b[c][tap];   dwpad[b][c][tap] += sum_h b5[h*C + c] * dcb[b][h][tap]
+template <typename T>
+__global__ void __launch_bounds__(NT) head_cb_bwd_kernel(const float* __restrict__ b5, const T* __restrict__ wpad, const float* __restrict__ dcb,
+                                                         float* __restrict__ db5, float* __restrict__ dwpad, int B, int heads, int C) {
+  GRID_STRIDE(i, (long)B * C) {
+    const int c = (int)(i % C);
+    const long b = i / C;
+    float w[16], dw[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) { w[t] = Elem<T>::to_f(wpad[i * 16 + t]); dw[t] = 0.f; }
+    for (int h = 0; h < heads; h++) {
+      const float* d = dcb + (b * heads + h) * 16;
+      const float bb = b5[h * C + c];
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; t++) { s += d[t] * w[t]; dw[t] += bb * d[t]; }
+      atomicAdd(db5 + h * C + c, s);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) atomicAdd(dwpad + i * 16 + t, dw[t]);
+  }
+}
+
 // dbias[b] = sum over heads, pixels of dout[b]
 __global__ void __launch_bounds__(NT) head_bias_grad_kernel(const float* __restrict__ dout, float* __restrict__ dbias, long per_b) {
   __shared__ float red[NT / 64];
@@ -199,9 +254,28 @@ extern "C" int crog_head_unpack_wgrad(int dtype, const float* dwpad, const float
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
-extern "C" int crog_head_stencil_fwd(const float* t, const float* word, int64_t ldw, int bias_col, float* out, int B, int heads, int H, int W,
-                                     crog_stream_t s) {
-  LAUNCH(head_stencil_fwd_kernel, (long)B * heads * H * W, s, t, word, (long)ldw, bias_col, out, B, heads, H, W);
+extern "C" int crog_head_cb_fwd(int dtype, const float* b5, const void* wpad, float* cb, int B, int heads, int C, crog_stream_t s) {
+  DISPATCH_T(dtype, LAUNCH((head_cb_fwd_kernel<T>), (long)B * heads * 16, s, b5, (const T*)wpad, cb, B, heads, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_head_tap_sums(int dtype, const void* dt, float* dcb, int B, int heads, int64_t P, crog_stream_t s) {
+  CROG_CHECK_ARG(heads >= 1 && heads * 16 <= NT, "head_tap_sums: heads must be in [1, %d]", NT / 16);
+  hipError_t e = hipMemsetAsync(dcb, 0, (size_t)B * heads * 16 * sizeof(float), (hipStream_t)s);
+  if (e != hipSuccess) { crog_set_error("head_tap_sums: memset failed"); return CROG_ERR_LAUNCH; }
+  DISPATCH_T(dtype, hipLaunchKernelGGL((head_tap_sums_kernel<T>), dim3(32, B), dim3(NT), 0, (hipStream_t)s, (const T*)dt, dcb, (long)P, heads));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_head_cb_bwd(int dtype, const float* b5, const void* wpad, const float* dcb, float* db5, float* dwpad, int B, int heads, int C,
+                                crog_stream_t s) {
+  DISPATCH_T(dtype, LAUNCH((head_cb_bwd_kernel<T>), (long)B * C, s, b5, (const T*)wpad, dcb, db5, dwpad, B, heads, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_head_stencil_fwd(const float* t, const float* word, int64_t ldw, int bias_col, const float* tbias, float* out, int B, int heads,
+                                     int H, int W, crog_stream_t s) {
+  LAUNCH(head_stencil_fwd_kernel, (long)B * heads * H * W, s, t, word, (long)ldw, bias_col, tbias, out, B, heads, H, W);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -43,6 +43,7 @@ import os as _os
 FUSED_REDUCE_MAX_PARTS = int(_os.environ.get("CROG_FUSED_REDUCE_MAX_PARTS", "256"))
 FLASH_ATTN = _os.environ.get("CROG_FLASH_ATTN", "1") != "0"     # fused attention kernels (csrc/attn.hip) where they apply
 FLASH_MIN_KEYS = 64
+FUSED_HEAD = _os.environ.get("CROG_FUSED_HEAD", "1") != "0"    # fold vis.4 into the dynamic head (no groups*C-channel map)
 
 
 class OutRef:
@@ -1159,6 +1160,94 @@ class DynHeadFn(Function):
 
 def dyn_head(x5, state, tw: WRef, tb: WRef, C):
     return DynHeadFn.apply(x5, state, tw.param, tb.param, tw, tb, C)
+
+
+class FusedHeadFn(Function):
+    """vis.4 (1x1 conv in_dim -> groups*in_dim with bias, layers.py:58) folded into the dynamic per-sample 3x3 head
+    (layers.py:90-132): per sample the two linear maps compose into Wf[g][tap][k] = sum_c W5[g*C+c][k] * w_b[c][tap], so the taps
+    come straight from x4 (t = x4 . Wf^T) and the groups*C-channel map (0.89 GB at B = 32) is neither written nor re-read, in
+    either direction.  The conv bias reaches the logits as per-sample constants cb[b][g][tap] (csrc/head.hip)."""
+
+    @staticmethod
+    def forward(ctx, x4, state, _p1, _p2, _p3, _p4, w5: WRef, b5: WRef, tw: WRef, tb: WRef, C, groups):
+        B, H, W, Cx = x4.shape
+        dev, dtype = x4.device, x4.dtype
+        dt = K.dcode(dtype)
+        P, g = H * W, groups
+        nout = C * 9 + 1
+        ldw = _pad(nout, 8)
+        word = torch.empty(B, ldw, device=dev, dtype=torch.float32)
+        lin_fwd(state, tw, word, bias=tb, out_mode=K.OUT_F32, ldc=ldw)
+        wpad = torch.empty(B, C, 16, device=dev, dtype=dtype)
+        K.head_pack_weights(word, wpad, B, C)
+        # Wf[b][g][tap][k] = sum_c wpad[b][c][tap] * W5[g*C + c][k]
+        Wf = torch.empty(B, g * 16, C, device=dev, dtype=dtype)
+        K.gemm(dt, K.A_MC, K.B_NC, wpad, w5.w(dtype), Wf, 16, C, C, 16, w5.cols, C, batch=B * g, batch_inner=g,
+               sA=(C * 16, 0), sB=(0, C * w5.cols), sC=(g * 16 * C, 16 * C), b_off=w5.off)
+        cb = torch.empty(B, g, 16, device=dev, dtype=torch.float32)
+        K.head_cb_fwd(b5.P, b5.off, wpad, cb, B, g, C)
+        ldx = K.mat(x4)[2]
+        t = torch.empty(B * P * g, 16, device=dev, dtype=torch.float32)
+        K.gemm(dt, K.A_KC, K.B_KC, x4, Wf, t, P, g * 16, C, ldx, C, g * 16, batch=B, sA=(P * ldx, 0), sB=(g * 16 * C, 0),
+               sC=(P * g * 16, 0), out_mode=K.OUT_F32)
+        out = torch.empty(B, g, H, W, device=dev, dtype=torch.float32)
+        K.head_stencil_fwd(t, word, C * 9, out, B, g, H, W, tbias=cb)
+        ctx.cfg = (w5, b5, tw, tb, C, g, ldw)
+        ctx.save_for_backward(x4, state, wpad, Wf)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w5, b5, tw, tb, C, g, ldw = ctx.cfg
+        x4, state, wpad, Wf = ctx.saved_tensors
+        B, H, W, _ = x4.shape
+        dev, dtype = x4.device, x4.dtype
+        dt = K.dcode(dtype)
+        P = H * W
+        ldx = K.mat(x4)[2]
+        dout = dout.contiguous()
+        dtb = torch.empty(B * P * g, 16, device=dev, dtype=dtype)
+        dbias = torch.empty(B, device=dev, dtype=torch.float32)
+        K.head_stencil_bwd(dout, dtb, dbias, B, g, H, W)
+        dcb = torch.empty(B, g, 16, device=dev, dtype=torch.float32)
+        K.head_tap_sums(dtb, dcb, B, g, P)
+        # dx4[b][p][k] = sum_(g,tap) dt[b][p][(g,tap)] * Wf[b][(g,tap)][k]
+        dx4 = torch.empty(B, H, W, C, device=dev, dtype=dtype)
+        K.gemm(dt, K.A_KC, K.B_NC, dtb, Wf, dx4, P, C, g * 16, g * 16, C, C, batch=B, sA=(P * g * 16, 0), sB=(g * 16 * C, 0), sC=(P * C, 0))
+        # dWf[b][(g,tap)][k] = sum_p dt[b][p][(g,tap)] * x4[b][p][k]
+        dWf = torch.zeros(B, g * 16, C, device=dev, dtype=torch.float32)
+        sk = max(1, min(24, P // 1024))
+        K.gemm(dt, K.A_MC, K.B_NC, dtb, x4, dWf, g * 16, C, P, g * 16, ldx, C, batch=B, sA=(P * g * 16, 0), sB=(P * ldx, 0), sC=(g * 16 * C, 0),
+               splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+        if dtype == torch.float32:
+            dWf_c = dWf
+        else:
+            dWf_c = torch.empty(B, g * 16, C, device=dev, dtype=dtype)
+            K.cast_pad2d(dWf, C, C, dWf_c, C, C, B * g * 16)
+        # dW5[g*C + c][k] += sum_b sum_tap wpad[b][c][tap] * dWf[b][g][tap][k]
+        K.gemm(dt, K.A_KC, K.B_NC, wpad, dWf_c, w5.G, C, C, 16, 16, C, w5.cols, batch=B * g, batch_inner=g, sA=(C * 16, 0),
+               sB=(g * 16 * C, 16 * C), sC=(0, C * w5.cols), c_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
+        w5.done()
+        # dwpad[b][c][tap] = sum_g sum_k W5[g*C + c][k] * dWf[b][g][tap][k]   (+ the cb share below)
+        dwpad = torch.zeros(B, C, 16, device=dev, dtype=torch.float32)
+        K.gemm(dt, K.A_KC, K.B_KC, w5.w(dtype), dWf_c, dwpad, C, 16, C, w5.cols, C, 16, batch=B * g, batch_inner=g, sA=(0, C * w5.cols),
+               sB=(g * 16 * C, 16 * C), sC=(C * 16, 0), a_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
+        K.head_cb_bwd(b5.P, b5.off, wpad, dcb, b5.G, b5.off, dwpad, B, g, C)
+        b5.done()
+        dword = torch.empty(B, ldw, device=dev, dtype=dtype)
+        K.head_unpack_wgrad(dwpad, dbias, dword, B, C)
+        nout = C * 9 + 1
+        lin_wgrad(dword, state, tw, N=nout)
+        tw.done()
+        bias_grad(dword[:, :nout], tb)
+        tb.done()
+        dstate = torch.empty_like(state)
+        lin_dgrad(dword, tw, dstate, N=nout)
+        return (dx4, dstate) + (None,) * 10
+
+
+def fused_head(x4, state, w5: WRef, b5: WRef, tw: WRef, tb: WRef, C, groups):
+    return FusedHeadFn.apply(x4, state, w5.param, b5.param, tw.param, tb.param, w5, b5, tw, tb, C, groups)
 
 
 class LossFn(Function):

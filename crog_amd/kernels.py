@@ -477,8 +477,22 @@ def head_unpack_wgrad(dwpad, dbias, dword, B, C):
           "head_unpack_wgrad")
 
 
-def head_stencil_fwd(t, word, bias_col, out, B, heads, H, W):
-    check(lib().crog_head_stencil_fwd(ptr(t), ptr(word), mat(word)[2], bias_col, ptr(out), B, heads, H, W, stream()), "head_stencil_fwd")
+def head_stencil_fwd(t, word, bias_col, out, B, heads, H, W, tbias=None):
+    check(lib().crog_head_stencil_fwd(ptr(t), ptr(word), mat(word)[2], bias_col, ptr(tbias), ptr(out), B, heads, H, W, stream()),
+          "head_stencil_fwd")
+
+
+def head_cb_fwd(b5, b5_off, wpad, cb, B, heads, C):
+    check(lib().crog_head_cb_fwd(dcode(wpad), ptr(b5) + 4 * b5_off, ptr(wpad), ptr(cb), B, heads, C, stream()), "head_cb_fwd")
+
+
+def head_tap_sums(dt, dcb, B, heads, P):
+    check(lib().crog_head_tap_sums(dcode(dt), ptr(dt), ptr(dcb), B, heads, P, stream()), "head_tap_sums")
+
+
+def head_cb_bwd(b5, b5_off, wpad, dcb, db5, db5_off, dwpad, B, heads, C):
+    check(lib().crog_head_cb_bwd(dcode(wpad), ptr(b5) + 4 * b5_off, ptr(wpad), ptr(dcb), ptr(db5) + 4 * db5_off, ptr(dwpad), B, heads, C,
+                                 stream()), "head_cb_bwd")
 
 
 def head_stencil_bwd(dout, dt, dbias, B, heads, H, W):

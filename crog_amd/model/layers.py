@@ -185,6 +185,8 @@ class _ProjectorBase(Bound):
         """x: [B, h, w, 2*in_dim] channels-last, state: [B, word_dim] -> fp32 logits [B, groups, 4h, 4w]."""
         x = self.vis["1"].run(Fn.upsample2(x))
         x = self.vis["3"].run(Fn.upsample2(x))
+        if Fn.FUSED_HEAD:
+            return Fn.fused_head(x, state, self.vis["4"].w, self.vis["4"].b, self.txt.w, self.txt.b, self.in_dim, self.groups)
         x5 = Fn.linear(x, self.vis["4"].w, self.vis["4"].b)
         return Fn.dyn_head(x5, state, self.txt.w, self.txt.b, self.in_dim)
 

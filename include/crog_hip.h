@@ -286,8 +286,19 @@ int crog_head_pack_weights(int dtype, const float* word, int64_t ldw, void* wpad
                            crog_stream_t stream);
 int crog_head_unpack_wgrad(int dtype, const float* dwpad, const float* dbias, void* dword, int64_t ldd, int B,
                            int C, crog_stream_t stream);
-int crog_head_stencil_fwd(const float* t, const float* word, int64_t ldw, int bias_col, float* out, int B,
-                          int heads, int H, int W, crog_stream_t stream);
+/* tbias: NULL, or fp32 [B][heads][16] constants added per valid source pixel and tap (the folded vis.4 bias below) */
+int crog_head_stencil_fwd(const float* t, const float* word, int64_t ldw, int bias_col, const float* tbias, float* out,
+                          int B, int heads, int H, int W, crog_stream_t stream);
+/* Folding the 1x1 conv vis.4 (layers.py:58: in_dim -> heads*in_dim, bias b5) into the dynamic 3x3 head (layers.py:116-128): the
+ * 1280-channel map is never materialised.  Per sample: Wf[h][tap][k] = sum_c W5[h*C+c][k] * w_b[c][tap] (a crog_gemm), then
+ * t = x4 . Wf^T (a crog_gemm), and the conv bias enters as cb[b][h][tap] = sum_c b5[h*C+c] * w_b[c][tap] (crog_head_cb_fwd),
+ * added by crog_head_stencil_fwd.  Backward: crog_head_tap_sums gives dcb[b][h][tap] = sum_pixels dt; crog_head_cb_bwd
+ * accumulates db5 (atomic) and the cb share of dwpad. */
+int crog_head_cb_fwd(int dtype, const float* b5, const void* wpad, float* cb, int B, int heads, int C,
+                     crog_stream_t stream);
+int crog_head_tap_sums(int dtype, const void* dt, float* dcb, int B, int heads, int64_t P, crog_stream_t stream);
+int crog_head_cb_bwd(int dtype, const float* b5, const void* wpad, const float* dcb, float* db5, float* dwpad, int B,
+                     int heads, int C, crog_stream_t stream);
 int crog_head_stencil_bwd(int dtype, const float* dout, void* dt, float* dbias, int B, int heads, int H, int W,
                           crog_stream_t stream);
 /* targets: host array of `heads` device pointers, each fp32 [B][1][Hin][Win] */

@@ -720,3 +720,25 @@ def test_flash_attention_equals_unfused_path_with_dropout():
         assert err <= 3e-2 * ref + 1e-3, f"{name}: {err} vs scale {ref}"
         cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
         assert cos > 0.999, (name, cos)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_fused_head_bias_kernels(K, dt):
+    """Helpers of the folded vis.4 + dynamic head (csrc/head.hip) against einsum."""
+    B, g, C, P = 3, 5, 32, 101
+    b5 = rnd(g * C)
+    wpad = (rnd(B, C, 16, dt=dt, seed=1) * 0.3)
+    wpad[..., 9:] = 0
+    cb = torch.empty(B, g, 16, device="cuda")
+    K.head_cb_fwd(b5, 0, wpad, cb, B, g, C)
+    close(cb, torch.einsum("hc,bct->bht", b5.view(g, C), wpad.float()), dt)
+    dtb = rnd(B * P * g, 16, dt=dt, seed=2)
+    dcb = torch.empty(B, g, 16, device="cuda")
+    K.head_tap_sums(dtb, dcb, B, g, P)
+    close(dcb, dtb.float().view(B, P, g, 16).sum(1), dt, scale=4)
+    db5 = torch.zeros(g * C + 2, device="cuda")
+    dwpad = torch.zeros(B, C, 16, device="cuda")
+    K.head_cb_bwd(b5, 0, wpad, dcb, db5, 1, dwpad, B, g, C)
+    close(db5[1:g * C + 1].view(g, C), torch.einsum("bht,bct->hc", dcb, wpad.float()), dt, scale=4)
+    close(dwpad[..., :9], torch.einsum("hc,bht->bct", b5.view(g, C), dcb)[..., :9], dt, scale=4)
+    assert float(db5[0]) == 0.0 and float(db5[-1]) == 0.0 and float(dwpad[..., 9:].abs().max()) == 0.0
