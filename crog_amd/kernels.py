@@ -51,6 +51,7 @@ def dcode(t_or_dtype) -> int:
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _DEV_INDEX = None
+_EXT_STREAMS = {}
 _STREAM_OVERRIDE = None   # raw handle set by Runtime.on_wgrad_stream while it enqueues weight-gradient kernels on the side stream
 
 
@@ -155,10 +156,15 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
     d.a_sum = (ptr(a_sum) + 4 * a_sum_off) if a_sum is not None else None
     d.debug = DEBUG_FLAGS
     if PROF is not None and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
+        # events go on the stream the kernel is actually launched on (the weight-gradient side stream while it is overridden)
+        raw = stream()
+        st = _EXT_STREAMS.get(raw)
+        if st is None:
+            st = _EXT_STREAMS[raw] = torch.cuda.ExternalStream(raw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib().crog_gemm(ctypes.byref(d), stream()), "crog_gemm")
-        e1.record()
+        e0.record(st)
+        check(lib().crog_gemm(ctypes.byref(d), raw), "crog_gemm")
+        e1.record(st)
         PROF["records"].append((e0, e1, 2.0 * M * N * K * batch, (a_layout, b_layout, M, N, K, batch, splitk)))
         return
     check(lib().crog_gemm(ctypes.byref(d), stream()), "crog_gemm")
