@@ -859,6 +859,9 @@ template <int N> __device__ inline void wait_vmcnt() {
   if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
 }
 
+// Tile shapes that were measured and lost (kept for A/B work, compiled only with -DCROG_GEMM_EXPERIMENTAL_TILES): 256 x 256 and
+// 256 x 128 with 8 waves at one block per CU (barrier stalls are not hidden by a second block: 5-30 % slower than 128 x 128 at
+// three blocks per CU), 64 x 256 for Cout <= 64 weight gradients (two blocks per CU, 20 KiB per k-tile: 14 % slower).
 using ShapeDma8 = Shape<4, 2, 2, 4>;   // 256 x 256, 8 waves, 128 accumulator registers per lane
 using ShapeDma8x = Shape<2, 2, 4, 2>;  // 256 x 128, 8 waves of 64 x 64 (64 accumulator registers, as the 128^2 tile): A/B experiments
 using ShapeTall = Shape<2, 2, 4, 1>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
@@ -1153,7 +1156,9 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
   if (dma_eligible(d)) {
     // tile shape of the LDS-DMA kernel by padding waste: 64-wide sides for <= 64 columns / rows, 64 x 64 for small problems
     const bool alt = alt_tiles_enabled();
+#ifdef CROG_GEMM_EXPERIMENTAL_TILES
     if (shape == 2 && dma_prefers_256(d)) return dispatch_dma<T, ShapeDma8>(d, s);
+#endif
     static int force = -1;   // CROG_GEMM_DMA_TILE = mid | tall | wide | 64 : A/B runs only (never with BN statistics on 64-row tiles)
     if (force < 0) {
       const char* e = getenv("CROG_GEMM_DMA_TILE");
@@ -1161,9 +1166,11 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     }
     if (force == 1) return dispatch_dma<T, ShapeMid>(d, s);
     if (force == 2) return dispatch_dma<T, ShapeTall>(d, s);
-    if (force == 3 && !d.col_stats) return dispatch_dma<T, ShapeWide>(d, s);
     if (force == 4 && !d.col_stats) return dispatch_dma<T, ShapeDma64>(d, s);
+#ifdef CROG_GEMM_EXPERIMENTAL_TILES
+    if (force == 3 && !d.col_stats) return dispatch_dma<T, ShapeWide>(d, s);
     if (force == 5) return dispatch_dma<T, ShapeDma8x>(d, s);
+#endif
     if (alt && forced_shape() == 0) {
       if (d.col_stats) {
         if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
@@ -1171,9 +1178,11 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
         if (d.M <= 64 && d.N <= 64) return dispatch_dma<T, ShapeDma64>(d, s);
         if (small_wgrad(d.a_layout, d.b_layout, d.out_mode, d.M, d.N)) return dispatch_dma<T, ShapeDma64>(d, s);
         if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
+#ifdef CROG_GEMM_EXPERIMENTAL_TILES
         static int wide = -1;   // 64 x 256: measured slower than 128 x 128 on the Cout = 64 weight gradients (2 blocks/CU, 20 KiB per k-tile)
         if (wide < 0) { const char* e = getenv("CROG_GEMM_WIDE"); wide = (e && e[0] == '1') ? 1 : 0; }
         if (wide && d.M <= 64) return dispatch_dma<T, ShapeWide>(d, s);
+#endif
         if (shape == 1) return dispatch_dma<T, ShapeDma64>(d, s);
       }
     }

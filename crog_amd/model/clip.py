@@ -123,8 +123,9 @@ class ModifiedResNet(Bound):
         return nn.Sequential(*mods)
 
     def forward(self, img, dtype, after_layer1=None):
-        """`after_layer1`: host-side hook called once the stem and layer1 (few launches, most of the tower's GPU time) are
-        enqueued — CROG.forward issues the launch-bound text tower there, so the GPU has bulk work while the host catches up."""
+        """`after_layer1`: host-side hook called after each of layer1, layer2, layer3 is enqueued (few launches, most of the
+        tower's GPU time) — CROG.forward issues a slice of the launch-bound text tower there, so the GPU always has bulk work
+        queued while the host works through the ~250 small text launches."""
         tr = self.training
         c1 = self.conv1.weight.shape[0]
         if c1 != 32:
@@ -137,7 +138,11 @@ class ModifiedResNet(Bound):
         if after_layer1 is not None:
             after_layer1()
         x2 = self.layer2(x)
+        if after_layer1 is not None:
+            after_layer1()
         x3 = self.layer3(x2)
+        if after_layer1 is not None:
+            after_layer1()
         x4 = self.layer4(x3)
         x4 = self.attnpool(x4)
         return x2, x3, x4
@@ -276,15 +281,28 @@ class CLIP(Bound):
 
     def text_features(self, text, dtype):
         """clip.py:439-456 -> (token features [B, L, D], state [B, embed])."""
+        out = None
+        for out in self.text_features_steps(text, dtype, parts=1):
+            pass
+        return out
+
+    def text_features_steps(self, text, dtype, parts=3):
+        """Generator form of text_features: yields None after each 1/parts of the transformer blocks has been enqueued and the
+        (token features, state) pair at the end, so a caller can interleave the host-side issue with other work."""
         B, L = text.shape
         if L != self.txt_length:
             raise RuntimeError(f"The shape of the 2D attn_mask is ({self.txt_length}, {self.txt_length}), but should be ({L}, {L}).")
         x = Fn.embedding(text, self.tok, self.pos, dtype)
-        x = self.transformer(x, B)
+        blocks = list(self.transformer.resblocks)
+        per = max(1, (len(blocks) + parts - 1) // parts)
+        for i, blk in enumerate(blocks):
+            x = blk(x, B)
+            if (i + 1) % per == 0 and i + 1 < len(blocks):
+                yield None
         x = self.ln_final(x)
         idx = torch.arange(B, device=text.device) * L + text.argmax(dim=-1)
         state = Fn.table_matmul(Fn.gather_rows(x, idx), self.tproj, dtype)
-        return x.view(B, L, -1), state
+        yield x.view(B, L, -1), state
 
     # reference-shaped public API ------------------------------------------------------------------
     def encode_image(self, image, dtype=None):

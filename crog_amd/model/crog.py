@@ -170,14 +170,16 @@ class CROG(nn.Module):
                 RT.streams = [main, self._side]
                 self._side.wait_stream(main)
                 txt = []
+                steps = self.backbone.text_features_steps(word, dtype, parts=int(os.environ.get("CROG_TEXT_PARTS", "3")))
 
-                def issue_text():   # called by the image tower after its stem + layer1 are enqueued (host issue order only)
+                def issue_text():   # called by the image tower after layer1 / layer2 / layer3 are enqueued (host issue order only)
                     with torch.cuda.stream(self._side):
-                        txt.extend(self.backbone.text_features(word, dtype))
-                early = os.environ.get("CROG_TEXT_FIRST", "0") == "1"
-                if early:
+                        r = next(steps, None)
+                        if r is not None:
+                            txt.extend(r)
+                vis = self.backbone.image_features(img, dtype, issue_text)
+                while not txt:          # whatever the image tower's hooks did not get to
                     issue_text()
-                vis = self.backbone.image_features(img, dtype, None if early else issue_text)
                 wfeat, state = txt
                 main.wait_stream(self._side)
                 wfeat.record_stream(main)
