@@ -848,7 +848,8 @@ __device__ inline void dma_issue(const OA& da, const OB& db, const ConvGeom& g, 
 }
 
 template <int N> __device__ inline void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 10 && N != 1 && N != 7 && N != 9, "add the immediate");
+  static_assert((N >= 0 && N <= 10 && N != 1 && N != 7 && N != 9) || N == 12, "add the immediate");
+  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -864,6 +865,7 @@ template <int N> __device__ inline void wait_vmcnt() {
 // three blocks per CU), 64 x 256 for Cout <= 64 weight gradients (two blocks per CU, 20 KiB per k-tile: 14 % slower).
 using ShapeDma8 = Shape<4, 2, 2, 4>;   // 256 x 256, 8 waves, 128 accumulator registers per lane
 using ShapeDma8x = Shape<2, 2, 4, 2>;  // 256 x 128, 8 waves of 64 x 64 (64 accumulator registers, as the 128^2 tile): A/B experiments
+using ShapeFat = Shape<2, 4, 2, 2>;    // 128 x 256, 4 waves of 64 x 128 (128 accumulator registers, 2 blocks per CU): 20-45 % slower (experimental)
 using ShapeTall = Shape<2, 2, 4, 1>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
 using ShapeWide = Shape<2, 2, 1, 4>;   //  64 x 256, 4 waves: weight gradients of those layers (M = Cout = 32 / 64)
 using ShapeDma64 = Shape<1, 1, 2, 2>;  //  64 x  64, 4 waves: small GEMMs (text tower, attention pooling), no BN statistics
@@ -1162,12 +1164,13 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     static int force = -1;   // CROG_GEMM_DMA_TILE = mid | tall | wide | 64 : A/B runs only (never with BN statistics on 64-row tiles)
     if (force < 0) {
       const char* e = getenv("CROG_GEMM_DMA_TILE");
-      force = !e ? 0 : (e[0] == 'm' ? 1 : (e[0] == 't' ? 2 : (e[0] == 'w' ? 3 : (e[0] == '6' ? 4 : (e[0] == 'x' ? 5 : 0)))));
+      force = !e ? 0 : (e[0] == 'm' ? 1 : (e[0] == 't' ? 2 : (e[0] == 'w' ? 3 : (e[0] == '6' ? 4 : (e[0] == 'x' ? 5 : (e[0] == 'f' ? 6 : 0))))));
     }
     if (force == 1) return dispatch_dma<T, ShapeMid>(d, s);
     if (force == 2) return dispatch_dma<T, ShapeTall>(d, s);
     if (force == 4 && !d.col_stats) return dispatch_dma<T, ShapeDma64>(d, s);
 #ifdef CROG_GEMM_EXPERIMENTAL_TILES
+    if (force == 6) return dispatch_dma<T, ShapeFat>(d, s);
     if (force == 3 && !d.col_stats) return dispatch_dma<T, ShapeWide>(d, s);
     if (force == 5) return dispatch_dma<T, ShapeDma8x>(d, s);
 #endif
