@@ -450,6 +450,22 @@ __global__ void __launch_bounds__(NT) vit_tokens_bwd_kernel(const T* __restrict_
   }
 }
 
+// ---- data-gradient layout of the 3x3 convolution weights: dst[ci][8 - tap][co] = src[co][tap][ci] for every listed conv ----
+// With this copy the data gradient of a 3x3 convolution is the same K-contiguous implicit GEMM as its forward (both operands
+// read with ds_read_b128) instead of reading the forward layout transposed out of LDS: measured 707 -> 811 TFLOP/s at 512 ch.
+// table[i] = (element offset in the flat buffers, Cout, Cin); one launch per step covers all of a model's 3x3 convs.
+template <typename T>
+__global__ void __launch_bounds__(NT) conv3_dgrad_weights_kernel(const T* __restrict__ src, T* __restrict__ dst, const long* __restrict__ table) {
+  const long off = table[3 * blockIdx.y], co_n = table[3 * blockIdx.y + 1], ci_n = table[3 * blockIdx.y + 2];
+  const long total = co_n * 9 * ci_n;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const long co = i % co_n;              // destination index i = (ci * 9 + t) * Cout + co
+    const long t = (i / co_n) % 9;
+    const long ci = i / (co_n * 9);
+    dst[off + i] = src[off + (co * 9 + (8 - t)) * ci_n + ci];
+  }
+}
+
 // ---- dst[r][c] = c < cols_src ? src[r][c] : 0, c < cols_dst   (fp32 source; T or fp32 destination) ------
 template <typename TD>
 __global__ void __launch_bounds__(NT) cast_pad2d_kernel(const float* __restrict__ src, long lds_, int cols_src, TD* __restrict__ dst, long ldd,
@@ -733,6 +749,15 @@ extern "C" int crog_vit_tokens_bwd(int dtype, const void* dtok, void* dy, int64_
                                    crog_stream_t s) {
   CROG_CHECK_ARG(T_ >= 2, "vit_tokens: needs at least one patch token");
   DISPATCH_T(dtype, LAUNCH((vit_tokens_bwd_kernel<T>), (long)T_ * C, s, (const T*)dtok, (T*)dy, (long)lddy, gcls, gpos, B, T_, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_conv3_dgrad_weights(int dtype, const void* src, void* dst, const int64_t* table, int count, crog_stream_t s) {
+  if (count <= 0) return CROG_OK;
+  CROG_CHECK_ARG(src && dst && table, "conv3_dgrad_weights: null pointer");
+  static_assert(sizeof(long) == sizeof(int64_t), "table entries are 64-bit");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((conv3_dgrad_weights_kernel<T>), dim3(64, count), dim3(NT), 0, (hipStream_t)s, (const T*)src, (T*)dst,
+                                       reinterpret_cast<const long*>(table)));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

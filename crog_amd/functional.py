@@ -43,6 +43,7 @@ import os as _os
 FUSED_REDUCE_MAX_PARTS = int(_os.environ.get("CROG_FUSED_REDUCE_MAX_PARTS", "256"))
 FLASH_ATTN = _os.environ.get("CROG_FLASH_ATTN", "1") != "0"     # fused attention kernels (csrc/attn.hip) where they apply
 FLASH_MIN_KEYS = 64
+DGRAD_T = _os.environ.get("CROG_DGRAD_T", "1") != "0"          # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
 FUSED_HEAD = _os.environ.get("CROG_FUSED_HEAD", "1") != "0"    # fold vis.4 into the dynamic head (no groups*C-channel map)
 
 
@@ -318,7 +319,11 @@ class ConvBnAct(Function):
             elif ksize == 3 and ctx.x_needs:
                 B, H, W = lead
                 dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
-                K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, dz, wt, dx, M, cin, 9 * C, C, cin, cin, b_off=woff, conv=(H, W, C))
+                if DGRAD_T and wpad is None and cin % 8 == 0:
+                    # data gradient as a forward-shaped implicit GEMM on the [Cin][flipped tap][Cout] copy of the weight
+                    K.gemm(dt, K.A_IM2COL, K.B_KC, dz, w.store.weights_t(dtype), dx, M, cin, 9 * C, C, 9 * C, cin, b_off=woff, conv=(H, W, C))
+                else:
+                    K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, dz, wt, dx, M, cin, 9 * C, C, cin, cin, b_off=woff, conv=(H, W, C))
             w.done()
         return (dx, dres) + (None,) * 13
 
@@ -883,7 +888,10 @@ class Conv3BiasActFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
-            K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, g, w.w(x.dtype), dx, M, cin, 9 * C, C, cin, cin, b_off=w.off, conv=(H, W, C))
+            if DGRAD_T:
+                K.gemm(dt, K.A_IM2COL, K.B_KC, g, w.store.weights_t(x.dtype), dx, M, cin, 9 * C, C, 9 * C, cin, b_off=w.off, conv=(H, W, C))
+            else:
+                K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, g, w.w(x.dtype), dx, M, cin, 9 * C, C, cin, cin, b_off=w.off, conv=(H, W, C))
         return dx, None, None, None, None, None
 
 

@@ -437,6 +437,10 @@ def patchify(img, out, patch: int):
     check(lib().crog_patchify(dcode(out), ptr(img), ptr(out), B, H, W, patch, stream()), "patchify")
 
 
+def conv3_dgrad_weights(src, dst, table, count):
+    check(lib().crog_conv3_dgrad_weights(dcode(src), ptr(src), ptr(dst), ptr(table), count, stream()), "conv3_dgrad_weights")
+
+
 def cast_pad2d(src, lds, cols_src, dst, ldd, cols_dst, rows, src_off=0, dst_off=0):
     dt = dcode(dst)
     sz = 2 if dt == BF16 else 4

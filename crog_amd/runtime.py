@@ -113,11 +113,16 @@ class ParamStore:
         self.G = torch.zeros(off, device=device, dtype=torch.float32)
         self.S: Optional[torch.Tensor] = None
         self.shadow_fresh = False
+        self.T: Dict[torch.dtype, torch.Tensor] = {}   # data-gradient layout of the 3x3 conv weights, per compute dtype
+        self.t_fresh: Dict[torch.dtype, bool] = {}
         self.by_param: Dict[int, int] = {}
+        conv3 = []
         for name, p, o in plan:
             n = p.numel()
             if p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
                 co, ci, kh, kw = p.shape
+                if kh == 3 and kw == 3:
+                    conv3 += [o, co, ci]
                 v = self.P[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
                 g = self.G[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
             else:
@@ -129,6 +134,8 @@ class ParamStore:
             p.grad = g
             self.entries.append((name, p, o, n, g))
             self.by_param[id(p)] = o
+        self.conv3_count = len(conv3) // 3
+        self.conv3_table = torch.tensor(conv3, dtype=torch.int64, device=device) if conv3 else None
 
     # -- lookups ---------------------------------------------------------------------------------
     def off(self, p) -> int:
@@ -146,6 +153,19 @@ class ParamStore:
             self.shadow_fresh = True
         return self.S
 
+    def weights_t(self, dtype: torch.dtype) -> torch.Tensor:
+        """Flat buffer (same offsets as `weights`) whose 3x3 convolution entries hold the data-gradient layout
+        [Cin][8 - tap][Cout]; refreshed by one launch per step, on first use after the weights changed."""
+        src = self.weights(dtype)
+        if dtype not in self.T:
+            self.T[dtype] = torch.zeros(self.total, device=self.device, dtype=dtype)
+            self.t_fresh[dtype] = False
+        if not self.t_fresh[dtype]:
+            if self.conv3_count:
+                K.conv3_dgrad_weights(src, self.T[dtype], self.conv3_table, self.conv3_count)
+            self.t_fresh[dtype] = True
+        return self.T[dtype]
+
     def valid(self) -> bool:
         name, p, o, n, g = self.entries[0]
         return p.data_ptr() == self.P.data_ptr() + 4 * o
@@ -161,3 +181,5 @@ class ParamStore:
 
     def invalidate_shadow(self):
         self.shadow_fresh = False
+        for k in self.t_fresh:
+            self.t_fresh[k] = False

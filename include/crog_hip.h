@@ -261,6 +261,11 @@ int crog_upsample2ac_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t
                          crog_stream_t stream);
 int crog_upsample2ac_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int H, int W,
                          int C, crog_stream_t stream);
+/* Data-gradient layout of 3x3 convolution weights, all convolutions of a model in one launch: for each table entry
+ * (element offset, Cout, Cin) dst[off + (ci*9 + 8-tap)*Cout + co] = src[off + (co*9 + tap)*Cin + ci].  The data gradient of
+ * F.conv2d(k=3, s=1, p=1) (clip.py:21,166-170; layers.py:8-11) is then crog_gemm(CROG_A_IM2COL, CROG_B_KC) on dy and this copy. */
+int crog_conv3_dgrad_weights(int dtype, const void* src, void* dst, const int64_t* table, int count,
+                             crog_stream_t stream);
 /* dst[r][c] = c < cols_src ? src[r][c] : 0 for c < cols_dst (fp32 source) */
 int crog_cast_pad2d(int dtype_dst, const float* src, int64_t lds, int cols_src, void* dst, int64_t ldd,
                     int cols_dst, int64_t rows, crog_stream_t stream);
