@@ -813,10 +813,12 @@ extern "C" int crog_bn_partial_stats(int dtype, const void* x, int64_t M, int C,
   return CROG_OK;
 }
 
-extern "C" int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, crog_stream_t stream) {
+extern "C" int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, int sums_is_zero, crog_stream_t stream) {
   CROG_CHECK_ARG(nparts > 0 && C > 0, "reduce_pairs: bad sizes");
-  hipError_t e = hipMemsetAsync(sums, 0, (size_t)C * 2 * sizeof(float), (hipStream_t)stream);
-  if (e != hipSuccess) { crog_set_error("reduce_pairs: memset failed"); return CROG_ERR_LAUNCH; }
+  if (!sums_is_zero) {   // callers that hand out pre-zeroed scratch (one memset per step for all layers) skip this launch
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)C * 2 * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) { crog_set_error("reduce_pairs: memset failed"); return CROG_ERR_LAUNCH; }
+  }
   int splits = nparts / 16;
   if (splits < 1) splits = 1;
   if (splits > 128) splits = 128;

@@ -222,8 +222,8 @@ class ConvBnAct(Function):
                 K.bn_partial_stats(z, stats, rpb)
             mi = torch.empty(C, 2, device=dev, dtype=torch.float32)
             if RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force):
-                sums = torch.empty(C, 2, device=dev, dtype=torch.float32)
-                K.reduce_pairs(stats, stats.shape[0], C, sums)
+                sums = RT.zeros(2 * C, dev).view(C, 2)
+                K.reduce_pairs(stats, stats.shape[0], C, sums, zeroed=True)
                 RT.comm.all_reduce_sum(sums)
                 count = float(M * RT.comm.world_size)
                 K.bn_finalize(sums, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum, bn.eps, C, ss, mi)
@@ -231,8 +231,8 @@ class ConvBnAct(Function):
                 K.bn_reduce_finalize(stats, stats.shape[0], count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var,
                                      bn.momentum, bn.eps, C, ss, mi)
             else:                                            # long slab (>= 100k rows): split reduction across blocks first
-                sums = torch.empty(C, 2, device=dev, dtype=torch.float32)
-                K.reduce_pairs(stats, stats.shape[0], C, sums)
+                sums = RT.zeros(2 * C, dev).view(C, 2)
+                K.reduce_pairs(stats, stats.shape[0], C, sums, zeroed=True)
                 K.bn_finalize(sums, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum, bn.eps, C, ss, mi)
         else:
             K.bn_eval_scale(bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.eps, C, ss)
@@ -265,12 +265,12 @@ class ConvBnAct(Function):
         relu_ss = ctx.relu_ss
         ymask = y if (relu and relu_ss is None) else None
         K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial, relu_ss)
-        sums = torch.empty(C, 2, device=dev, dtype=torch.float32)
+        sums = RT.zeros(2 * C, dev).view(C, 2) if nparts > FUSED_REDUCE_MAX_PARTS else torch.empty(C, 2, device=dev, dtype=torch.float32)
         # local sums: (sum g -> dbeta, sum g*xhat -> dgamma) and the pair vector for the second pass
         if nparts <= FUSED_REDUCE_MAX_PARTS:
             K.reduce_split(partial, nparts, C, sums, bn.beta.grad(), bn.gamma.grad())
         else:
-            K.reduce_pairs(partial, nparts, C, sums)
+            K.reduce_pairs(partial, nparts, C, sums, zeroed=True)
             K.split_pairs(sums, C, bn.beta.grad(), bn.gamma.grad())
         bn.beta.done()
         bn.gamma.done()

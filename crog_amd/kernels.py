@@ -193,8 +193,8 @@ def bn_partial_stats(x: torch.Tensor, partial: torch.Tensor, rows_per_block: int
     check(lib().crog_bn_partial_stats(dcode(x), ptr(x), M, C, ld, rows_per_block, ptr(partial), stream()), "bn_partial_stats")
 
 
-def reduce_pairs(partial: torch.Tensor, nparts: int, C: int, sums: torch.Tensor):
-    check(lib().crog_reduce_pairs(ptr(partial), nparts, C, ptr(sums), stream()), "reduce_pairs")
+def reduce_pairs(partial: torch.Tensor, nparts: int, C: int, sums: torch.Tensor, zeroed: bool = False):
+    check(lib().crog_reduce_pairs(ptr(partial), nparts, C, ptr(sums), 1 if zeroed else 0, stream()), "reduce_pairs")
 
 
 def split_pairs(sums: torch.Tensor, C: int, a: torch.Tensor, b: torch.Tensor):

@@ -157,6 +157,7 @@ class CROG(nn.Module):
             RT.join_streams()               # e.g. a previous backward's weight-gradient stream when no fused optimizer joined it
             store.relink_grads()
             store.zero_grad()
+            RT.begin_step(dev)
         with torch.autocast("cuda", enabled=False):
             pad_mask = (word == 0).contiguous()
             # The text tower (640 token rows: ~100 latency-bound launches) is independent of the image tower until the

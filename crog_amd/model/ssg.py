@@ -254,6 +254,7 @@ class SSG(nn.Module):
             RT.join_streams()
             st.relink_grads()
             st.zero_grad()
+            RT.begin_step(dev)
         with torch.autocast("cuda", enabled=False):
             RT.streams = [torch.cuda.current_stream()]
             st.weights(dtype)

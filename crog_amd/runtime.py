@@ -85,6 +85,27 @@ class Runtime:
             if s != cur:
                 cur.wait_stream(s)
 
+    # ---- pre-zeroed fp32 scratch: one memset per step instead of one per BatchNorm reduction ---------------------------
+    ZERO_POOL = 1 << 20   # floats (4 MiB): ~90 reductions of <= 4096 floats per step
+
+    def begin_step(self, device):
+        """Called once per training forward: clears the zero pool and rewinds its bump pointer."""
+        if getattr(self, "_zpool", None) is None or self._zpool.device != device:
+            self._zpool = torch.zeros(self.ZERO_POOL, device=device, dtype=torch.float32)
+        else:
+            self._zpool.zero_()
+        self._zptr = 0
+
+    def zeros(self, n: int, device):
+        """n pre-zeroed floats valid until the next begin_step() -> (tensor, True), or a fresh torch.zeros -> (tensor, True)."""
+        pool = getattr(self, "_zpool", None)
+        n8 = (n + 7) // 8 * 8
+        if pool is None or pool.device != device or self._zptr + n8 > pool.numel():
+            return torch.zeros(n, device=device, dtype=torch.float32)
+        t = pool[self._zptr:self._zptr + n]
+        self._zptr += n8
+        return t
+
     def next_seed(self) -> int:
         self._seed_ctr += 1
         return ((self.seed_base & 0xFFFFFFFF) << 32) | (self._seed_ctr & 0xFFFFFFFF)

@@ -116,7 +116,8 @@ int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int M, int N, i
 int crog_bn_stat_blocks(int64_t M, int rows_per_block);
 int crog_bn_partial_stats(int dtype, const void* x, int64_t M, int C, int64_t ld, int rows_per_block,
                           float* partial, crog_stream_t stream);
-int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, crog_stream_t stream);
+/* sums_is_zero != 0: `sums` was zeroed by the caller (the reduction accumulates with atomics) */
+int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, int sums_is_zero, crog_stream_t stream);
 int crog_split_pairs(const float* sums, int C, float* a, float* b, crog_stream_t stream);
 int crog_bn_finalize(const float* sums, float count, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps, int C,
