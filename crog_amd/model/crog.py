@@ -167,7 +167,7 @@ class CROG(nn.Module):
             store.weights(dtype)               # refresh the bf16 shadow on the main stream BEFORE the streams fork
             if self.overlap_text:
                 if self._side is None:
-                    self._side = torch.cuda.Stream(device=dev)
+                    self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CROG_SIDE_PRIORITY", "0")))
                 RT.streams = [main, self._side]
                 self._side.wait_stream(main)
                 txt = []

@@ -39,7 +39,8 @@ class Runtime:
         if not self.overlap_wgrad or not torch.cuda.is_available():
             return None
         if self._wgrad_stream is None:
-            self._wgrad_stream = torch.cuda.Stream()
+            # CROG_SIDE_PRIORITY: HIP stream priority of the side streams (-1 high, 0 normal, 1 low where supported)
+            self._wgrad_stream = torch.cuda.Stream(priority=int(os.environ.get("CROG_SIDE_PRIORITY", "0")))
         if self._wgrad_stream not in self.streams:
             self.streams.append(self._wgrad_stream)
         return self._wgrad_stream
