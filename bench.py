@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
-    ap.add_argument("--roofline-kernel", default="conv3x3_wgrad", choices=["conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "lin_fwd", "none"])
+    ap.add_argument("--roofline-kernel", default="conv3x3_fwd", choices=["conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "lin_fwd", "none"])
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.cpu_baseline_worker, args.cpu_threads)

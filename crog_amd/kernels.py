@@ -27,7 +27,7 @@ PROF = None
 DEBUG_FLAGS = 0  # timing-only ablation bits of crog_gemm_desc.debug (scripts/ablate_gemm.py); 0 in production
 GEMM_SYMBOL = {
     (A_KC, B_KC): "gemm_dma_kernel<T, A_KC, B_KC>  (1x1 conv / linear forward, Q.K^T)",
-    (A_IM2COL, B_KC): "gemm_dma_kernel<T, A_IM2COL, B_KC>  (3x3 conv forward, implicit GEMM)",
+    (A_IM2COL, B_KC): "gemm_dma_kernel<T, A_IM2COL, B_KC>  (3x3 conv forward and data gradient, implicit GEMM)",
     (A_KC, B_NC): "gemm_dma_kernel<T, A_KC, B_NC>  (1x1 / linear dgrad, P.V)",
     (A_IM2COL, B_NC_DGRAD): "gemm_dma_kernel<T, A_IM2COL, B_NC_DGRAD>  (3x3 conv dgrad)",
     (A_MC, B_NC): "gemm_dma_kernel<T, A_MC, B_NC>  (1x1 / linear wgrad)",

@@ -38,8 +38,15 @@ names = {(1, 0): "conv3x3_fwd", (1, 2): "conv3x3_dgrad", (2, 3): "conv3x3_wgrad"
 pm = {}
 for k in f:   # one roofline key can cover several tile-shape instantiations of the kernel: aggregate launches and bytes
     m = re.search(r"gemm_dma_kernelIDF16bLi(\d)ELi(\d)E", k)
-    if m and (int(m.group(1)), int(m.group(2))) in names and f[k][0]:
-        key = names[(int(m.group(1)), int(m.group(2)))]
+    lay = (int(m.group(1)), int(m.group(2))) if m else None
+    if lay is None:   # rocprofv3 mis-demangles some instantiations: "<bool _Accum, int, E, N, Shape" is (A=1, B=N), "int, EL, int, E," is (2, 1)
+        m2 = re.search(r"gemm_dma_kernel<bool _Accum, int, E, (\d), ", k)
+        if m2:
+            lay = (1, int(m2.group(1)))
+        elif "gemm_dma_kernel<bool _Accum, int, EL, int, E," in k:
+            lay = (2, 1)
+    if lay in names and f[k][0]:
+        key = names[lay]
         e = pm.setdefault(key, dict(kernels=[], launches=0, _bytes=0.0,
                                     source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, {tag}"))
         e["kernels"].append(k)
