@@ -158,9 +158,11 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
     if PROF is not None and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
         # events go on the stream the kernel is actually launched on (the weight-gradient side stream while it is overridden)
         raw = stream()
-        st = _EXT_STREAMS.get(raw)
-        if st is None:
-            st = _EXT_STREAMS[raw] = torch.cuda.ExternalStream(raw)
+        st = None   # torch's current stream unless the launch is redirected to the side stream
+        if _STREAM_OVERRIDE is not None:
+            st = _EXT_STREAMS.get(raw)
+            if st is None:
+                st = _EXT_STREAMS[raw] = torch.cuda.ExternalStream(raw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
         check(lib().crog_gemm(ctypes.byref(d), raw), "crog_gemm")
