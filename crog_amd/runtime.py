@@ -36,14 +36,20 @@ class Runtime:
     # so their GEMMs run on a second stream and fill the CUs that the skinny data-gradient / BatchNorm kernels of the
     # dependency chain leave idle.
     def wgrad_stream(self):
+        """Weight-gradient side stream (CROG_WGRAD_STREAMS > 1 round-robins over several: measured 1 % slower with 2-3, the small
+        atomic-bound weight gradients contend with each other)."""
         if not self.overlap_wgrad or not torch.cuda.is_available():
             return None
         if self._wgrad_stream is None:
-            # CROG_SIDE_PRIORITY: HIP stream priority of the side streams (-1 high, 0 normal, 1 low where supported)
-            self._wgrad_stream = torch.cuda.Stream(priority=int(os.environ.get("CROG_SIDE_PRIORITY", "0")))
-        if self._wgrad_stream not in self.streams:
-            self.streams.append(self._wgrad_stream)
-        return self._wgrad_stream
+            n = max(1, int(os.environ.get("CROG_WGRAD_STREAMS", "1")))
+            prio = int(os.environ.get("CROG_SIDE_PRIORITY", "0"))
+            self._wgrad_stream = [torch.cuda.Stream(priority=prio) for _ in range(n)]
+            self._wgrad_next = 0
+        s = self._wgrad_stream[self._wgrad_next % len(self._wgrad_stream)]
+        self._wgrad_next += 1
+        if s not in self.streams:
+            self.streams.append(s)
+        return s
 
     def on_wgrad_stream(self, fn, *tensors):
         """Run fn() (kernel launches only) on the weight-gradient stream, after everything enqueued so far on the current
