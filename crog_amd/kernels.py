@@ -130,31 +130,18 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
     """Raw descriptor launch. A/B/C are tensors (or ints = device addresses); *_off are element offsets."""
     esz = 2 if dtype == BF16 else 4
     csz = esz if out_mode == OUT_T else 4
-
-    def addr(x, off, sz):
-        base = x if isinstance(x, int) else ptr(x)
-        return base + off * sz
-
-    d = GemmDesc()
-    d.dtype, d.a_layout, d.b_layout = dtype, a_layout, b_layout
-    d.A, d.B, d.C = addr(A, a_off, esz), addr(B, b_off, esz), addr(C, c_off, csz)
-    d.M, d.N, d.K = int(M), int(N), int(K)
-    d.lda, d.ldb, d.ldc = int(lda), int(ldb), int(ldc)
-    d.batch, d.batch_inner = int(batch), int(batch_inner)
-    d.sAo, d.sAi = int(sA[0]), int(sA[1])
-    d.sBo, d.sBi = int(sB[0]), int(sB[1])
-    d.sCo, d.sCi = int(sC[0]), int(sC[1])
-    d.splitk = int(splitk)
-    d.convH, d.convW, d.convC = int(conv[0]), int(conv[1]), int(conv[2])
-    d.alpha = float(alpha)
-    d.bias = ptr(bias)
-    d.act = int(act)
-    d.R = ptr(R)
-    d.ldr = int(ldr)
-    d.out_mode = int(out_mode)
-    d.col_stats = ptr(col_stats)
-    d.a_sum = (ptr(a_sum) + 4 * a_sum_off) if a_sum is not None else None
-    d.debug = DEBUG_FLAGS
+    # one positional constructor call (field order of crog_gemm_desc) instead of ~35 attribute stores: this wrapper runs ~550
+    # times per step and was the largest single item of host time
+    if A.__class__ is not int and not A.is_cuda:
+        raise RuntimeError("crog_amd kernels need GPU tensors (there is no CPU path)")
+    pa = (A if A.__class__ is int else A.data_ptr()) + a_off * esz
+    pb = (B if B.__class__ is int else B.data_ptr()) + b_off * esz
+    pc = (C if C.__class__ is int else C.data_ptr()) + c_off * csz
+    d = GemmDesc(dtype, a_layout, b_layout, pa, pb, pc, M, N, K, lda, ldb, ldc, batch, batch_inner,
+                 sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], splitk, conv[0], conv[1], conv[2], alpha,
+                 None if bias is None else bias.data_ptr(), act, None if R is None else R.data_ptr(), ldr, out_mode, DEBUG_FLAGS,
+                 None if col_stats is None else col_stats.data_ptr(),
+                 None if a_sum is None else a_sum.data_ptr() + 4 * a_sum_off)
     if PROF is not None and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
         # events go on the stream the kernel is actually launched on (the weight-gradient side stream while it is overridden)
         raw = stream()

@@ -21,6 +21,10 @@ import torch.distributed as dist
 from .runtime import ALIGN, RT
 
 
+import os as _os
+_DRY = _os.environ.get("CROG_DDP_DRY") == "1"   # diagnostics: run the reducer's bookkeeping without issuing collectives
+
+
 class SyncBNComm:
     def __init__(self, group=None):
         self.group = group
@@ -82,13 +86,25 @@ class Reducer:
         b["launched"] = True
         # a bucket can hold gradients written on different streams (image tower: main, text tower: side stream):
         # make the launching stream wait for the others before RCCL's stream takes its dependency on it
-        if self.G.is_cuda:
-            cur = torch.cuda.current_stream()
-            for s in RT.streams:
-                if s != cur:
-                    cur.wait_stream(s)
         view = self.G[b["start"]:b["start"] + b["numel"]]
         op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+        if _DRY:
+            b["work"] = None
+            return
+        if self.G.is_cuda:
+            cur = torch.cuda.current_stream()
+            side = [s for s in RT.streams if s != cur]
+            if side:
+                # Issue the collective from a side stream that has waited for every other writer: RCCL's stream then depends
+                # on all of them, while the main stream (the backward critical path) is NOT stalled behind the weight-gradient
+                # stream at every bucket boundary.
+                carrier = side[-1]
+                carrier.wait_stream(cur)
+                for s in side[:-1]:
+                    carrier.wait_stream(s)
+                with torch.cuda.stream(carrier):
+                    b["work"] = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+                return
         b["work"] = dist.all_reduce(view, op=op, group=self.group, async_op=True)
 
     def mark_ready(self, param):
@@ -114,7 +130,8 @@ class Reducer:
         for b in self.buckets:
             self._launch(b)
         for b in self.buckets:
-            b["work"].wait()
+            if b["work"] is not None:
+                b["work"].wait()
             if not self._use_avg:
                 self.G[b["start"]:b["start"] + b["numel"]].div_(self.world)
         self.reset()

@@ -1,0 +1,28 @@
+"""Host issue time and step time with the DDP wrapper forced at world size 1 (GPU box). Env: CROG_DDP_DRY, CROG_NO_SYNCBN."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29555")
+dist.init_process_group("nccl", rank=0, world_size=1)
+from crog_amd.engine import train_step
+from crog_amd.model import build_crog
+from crog_amd.optim import FusedAdam
+from crog_amd.parallel import DistributedDataParallel, convert_sync_batchnorm
+from crog_amd.testing import make_cfg, synthetic_batch
+cfg = make_cfg(); torch.manual_seed(0)
+model, groups = build_crog(cfg); model = model.cuda().prepare()
+mode = sys.argv[1] if len(sys.argv) > 1 else "ddp"
+net = model
+if mode != "plain":
+    if os.environ.get("CROG_NO_SYNCBN") != "1":
+        convert_sync_batchnorm(model, force=True)
+    net = DistributedDataParallel(model, device_ids=[0], force=True)
+opt = FusedAdam(groups, lr=1e-4, store=model.store)
+batch = synthetic_batch(32, 416, 20, 49408, seed=1, device="cuda"); net.train()
+for _ in range(4): train_step(net, opt, None, batch, cfg)
+torch.cuda.synchronize()
+for _ in range(3):
+    t0 = time.perf_counter(); train_step(net, opt, None, batch, cfg); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"{mode}: host issue {1e3*(t1-t0):.1f} ms, total {1e3*(t2-t0):.1f} ms")
+dist.destroy_process_group()

@@ -13,7 +13,8 @@ opt = FusedAdam(groups, lr=1e-4, store=model.store)
 batch = synthetic_batch(32, 416, 20, 49408, seed=1, device="cuda"); model.train()
 for _ in range(3): train_step(model, opt, None, batch, cfg)
 torch.cuda.synchronize()
+torch.autograd.set_multithreading_enabled(False)   # run backward nodes on this thread so cProfile sees them
 pr = cProfile.Profile(); pr.enable()
 for _ in range(3): train_step(model, opt, None, batch, cfg)
 torch.cuda.synchronize(); pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
