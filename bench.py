@@ -105,7 +105,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # no `device_id=`: binding the process group to the device at init (eager communicator setup) measured 2.8 ms/step
+        # slower for the whole step on this stack (43.6 vs 40.8 ms with no collective issued at all); the device is selected by
+        # torch.cuda.set_device above and the barrier below names it explicitly
+        dist.init_process_group("nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -135,7 +138,7 @@ def main():
 
     def sync():
         if world > 1 or force_ddp:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -194,7 +197,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1 or force_ddp:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
