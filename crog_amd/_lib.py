@@ -41,7 +41,7 @@ class GemmDesc(ctypes.Structure):
         ("convH", ctypes.c_int), ("convW", ctypes.c_int), ("convC", ctypes.c_int),
         ("alpha", ctypes.c_float), ("bias", ctypes.c_void_p), ("act", ctypes.c_int),
         ("R", ctypes.c_void_p), ("ldr", ctypes.c_int64), ("out_mode", ctypes.c_int), ("debug", ctypes.c_int),
-        ("col_stats", ctypes.c_void_p), ("a_sum", ctypes.c_void_p),
+        ("col_stats", ctypes.c_void_p), ("stat_replicas", ctypes.c_int), ("a_sum", ctypes.c_void_p),
     ]
 
 

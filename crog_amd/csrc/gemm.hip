@@ -395,9 +395,15 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[S::WM][S::WN], const crog_gem
           a += red[((sl * GPS + q) * BN + c) * 2];
           b += red[((sl * GPS + q) * BN + c) * 2 + 1];
         }
-        float* dst = p.col_stats + ((int64_t)(m0 / 128 + sl) * p.N + n0 + c) * 2;
-        dst[0] = a;
-        dst[1] = b;
+        if (p.stat_replicas > 0) {   // accumulate into one of `stat_replicas` pre-zeroed [N][2] rows: no slab, no reduction kernel
+          float* dst = p.col_stats + ((int64_t)((m0 / 128 + sl) % p.stat_replicas) * p.N + n0 + c) * 2;
+          atomicAdd(dst, a);
+          atomicAdd(dst + 1, b);
+        } else {
+          float* dst = p.col_stats + ((int64_t)(m0 / 128 + sl) * p.N + n0 + c) * 2;
+          dst[0] = a;
+          dst[1] = b;
+        }
       }
     }
     __syncthreads();

@@ -224,6 +224,70 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ z, l
   }
 }
 
+// Same, with the statistics finalised in the kernel: `sums` is the [R][C][2] (sum x, sum x^2) buffer a GEMM epilogue accumulated
+// (crog_gemm_desc.stat_replicas) or, under SyncBatchNorm, the all-reduced [C][2] totals.  Every block derives scale/shift for
+// all C channels into LDS (R*2C floats from L2); block 0 also stores scale/shift and (mean, invstd) for the backward pass and
+// updates the running statistics.  Replaces reduce -> finalize -> apply (three launches) by one.
+template <typename T>
+__global__ void __launch_bounds__(NT) bn_apply_stats_kernel(const T* __restrict__ z, long ldz, const float* __restrict__ sums, int R, float count,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                                            float eps, float* __restrict__ scale_shift, float* __restrict__ mean_invstd,
+                                                            const T* __restrict__ res, long ldr, int relu, T* __restrict__ y, long ldy, long M,
+                                                            int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) float ss[];   // [C][2]
+  for (int c = threadIdx.x; c < C; c += NT) {
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < R; r++) {
+      s += sums[((long)r * C + c) * 2];
+      q += sums[((long)r * C + c) * 2 + 1];
+    }
+    const float mean = s / count;
+    const float var = fmaxf(q / count - mean * mean, 0.f);
+    const float invstd = rsqrtf(var + eps);
+    const float sc = gamma[c] * invstd, sh = beta[c] - mean * sc;
+    ss[2 * c] = sc;
+    ss[2 * c + 1] = sh;
+    if (blockIdx.x == 0) {
+      scale_shift[2 * c] = sc;
+      scale_shift[2 * c + 1] = sh;
+      mean_invstd[2 * c] = mean;
+      mean_invstd[2 * c + 1] = invstd;
+      if (running_mean) {
+        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+    }
+  }
+  __syncthreads();
+  const int cvec = C / VEC;
+  const long total = M * cvec;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const long r = i / cvec;
+    const int c = (int)(i % cvec) * VEC;
+    Vec16<T> v = ldg16(z + r * ldz + c);
+    Vec16<T> rv;
+    if (res) rv = ldg16(res + r * ldr + c);
+    Vec16<T> o;
+    float f[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) f[e] = Elem<T>::to_f(v.v[e]) * ss[2 * (c + e)] + ss[2 * (c + e) + 1];
+    if (res) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) f[e] += Elem<T>::to_f(rv.v[e]);
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) f[e] = fmaxf(f[e], 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(f[e]);
+    stg16(y + r * ldy + c, o);
+  }
+}
+
 // Backward pass 1: g = dy * (y > 0 if relu);  partial[block][C][2] = (sum g, sum g*zhat)
 template <typename T>
 __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
@@ -858,6 +922,21 @@ extern "C" int crog_bn_apply(int dtype, const void* z, int64_t ldz, const float*
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(stream_grid(M * (C / vec))), dim3(NT), 0, (hipStream_t)stream,
                                        (const T*)z, (long)ldz, scale_shift, (const T*)res, (long)ldr, relu, (T*)y, (long)ldy,
                                        (long)M, C));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_bn_apply_stats(int dtype, const void* z, int64_t ldz, const float* sums, int replicas, float count, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                   float* scale_shift, float* mean_invstd, const void* res, int64_t ldr, int relu, void* y, int64_t ldy,
+                                   int64_t M, int C, crog_stream_t stream) {
+  const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(C % vec == 0 && ldz % vec == 0 && ldy % vec == 0 && (!res || ldr % vec == 0), "bn_apply_stats: C/ld must be multiples of %d", vec);
+  CROG_CHECK_ARG(sums && replicas >= 1 && count > 0 && scale_shift && mean_invstd && C <= 8192, "bn_apply_stats: bad arguments");
+  const int grid = std::min(stream_grid(M * (C / vec)), 1024);   // every block re-derives the C scale/shift pairs: keep the grid modest
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_stats_kernel<T>), dim3(grid), dim3(NT), (size_t)C * 2 * sizeof(float), (hipStream_t)stream,
+                                       (const T*)z, (long)ldz, sums, replicas, count, gamma, beta, running_mean, running_var, momentum, eps,
+                                       scale_shift, mean_invstd, (const T*)res, (long)ldr, relu, (T*)y, (long)ldy, (long)M, C));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

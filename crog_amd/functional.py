@@ -43,6 +43,7 @@ import os as _os
 FUSED_REDUCE_MAX_PARTS = int(_os.environ.get("CROG_FUSED_REDUCE_MAX_PARTS", "256"))
 FLASH_ATTN = _os.environ.get("CROG_FLASH_ATTN", "1") != "0"     # fused attention kernels (csrc/attn.hip) where they apply
 FLASH_MIN_KEYS = 64
+BN_ATOMIC_STATS = _os.environ.get("CROG_BN_ATOMIC_STATS", "1") != "0"   # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize
 DGRAD_T = _os.environ.get("CROG_DGRAD_T", "1") != "0"          # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
 FUSED_HEAD = _os.environ.get("CROG_FUSED_HEAD", "1") != "0"    # fold vis.4 into the dynamic head (no groups*C-channel map)
 
@@ -196,25 +197,44 @@ class ConvBnAct(Function):
                 wbuf_off = 0
                 wcols = dst_cols * (9 if ksize == 3 else 1)
         stats = None
+        stat_R = 0
         if ksize == 0:
             z = x
         else:
             z = torch.empty(lead + (C,), device=dev, dtype=dtype)
             if training:
-                stats = torch.empty(K.stat_tiles(M), C, 2, device=dev, dtype=torch.float32)
+                slabs = K.stat_tiles(M)
+                comm_on = RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force)
+                if BN_ATOMIC_STATS and (not comm_on or slabs <= 4096):
+                    # statistics accumulate atomically into R pre-zeroed [C][2] rows in the GEMM epilogue and are finalised
+                    # inside bn_apply: GEMM -> (all-reduce) -> apply, no reduction / finalize launches in between
+                    stat_R = 1 if (comm_on or slabs <= 512) else (4 if slabs <= 4096 else 8)
+                    stats = RT.zeros(stat_R * C * 2, dev)
+                else:
+                    stats = torch.empty(slabs, C, 2, device=dev, dtype=torch.float32)
             if ksize == "s":
                 patches = torch.empty(M, 32, device=dev, dtype=dtype)
                 K.stem_im2col(x, patches)
-                K.gemm(dt, K.A_KC, K.B_KC, patches, wt, z, M, C, 32, 32, 32, C, b_off=wbuf_off, col_stats=stats)
+                K.gemm(dt, K.A_KC, K.B_KC, patches, wt, z, M, C, 32, 32, 32, C, b_off=wbuf_off, col_stats=stats, stat_replicas=stat_R)
             elif ksize == 1:
-                K.gemm(dt, K.A_KC, K.B_KC, x, wt, z, M, C, cin, K.mat(x)[2], wcols, C, b_off=wbuf_off, col_stats=stats)
+                K.gemm(dt, K.A_KC, K.B_KC, x, wt, z, M, C, cin, K.mat(x)[2], wcols, C, b_off=wbuf_off, col_stats=stats, stat_replicas=stat_R)
             else:
                 K.gemm(dt, K.A_IM2COL, K.B_KC, x, wt, z, M, C, 9 * cin, K.mat(x)[2], wcols, C, b_off=wbuf_off, conv=(H, W, cin),
-                       col_stats=stats)
+                       col_stats=stats, stat_replicas=stat_R)
         ss = torch.empty(C, 2, device=dev, dtype=torch.float32)
         mi = None
         count = float(M)
-        if training:
+        y = _dest(out) if out is not None else torch.empty(lead + (C,), device=dev, dtype=dtype)
+        applied = False
+        if training and stat_R > 0:
+            mi = torch.empty(C, 2, device=dev, dtype=torch.float32)
+            if RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force):
+                RT.comm.all_reduce_sum(stats)
+                count = float(M * RT.comm.world_size)
+            K.bn_apply_stats(z, stats, stat_R, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum,
+                             bn.eps, ss, mi, res, relu, y)
+            applied = True
+        elif training:
             if stats is None:
                 rpb = K.bn_rows_per_block(M)
                 nparts = (M + rpb - 1) // rpb
@@ -236,8 +256,8 @@ class ConvBnAct(Function):
                 K.bn_finalize(sums, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum, bn.eps, C, ss, mi)
         else:
             K.bn_eval_scale(bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.eps, C, ss)
-        y = _dest(out) if out is not None else torch.empty(lead + (C,), device=dev, dtype=dtype)
-        K.bn_apply(z, ss, res, relu, y)
+        if not applied:
+            K.bn_apply(z, ss, res, relu, y)
         ctx.cfg = (ksize, relu, training, w, bn, wpad, count, cin, C, lead, dtype)
         ctx.has_res = res is not None
         ctx.relu_ss = ss if (relu and res is None and training) else None   # ReLU mask can be recomputed from z: y is not re-read in backward

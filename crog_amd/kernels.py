@@ -126,7 +126,7 @@ def as_mat(t: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, ldc, *, batch=1, batch_inner=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, conv=(0, 0, 0), alpha=1.0, bias=None, act=ACT_NONE, R=None,
-         ldr=0, out_mode=OUT_T, col_stats=None, a_off=0, b_off=0, c_off=0, a_sum=None, a_sum_off=0):
+         ldr=0, out_mode=OUT_T, col_stats=None, a_off=0, b_off=0, c_off=0, a_sum=None, a_sum_off=0, stat_replicas=0):
     """Raw descriptor launch. A/B/C are tensors (or ints = device addresses); *_off are element offsets."""
     esz = 2 if dtype == BF16 else 4
     csz = esz if out_mode == OUT_T else 4
@@ -140,7 +140,7 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
     d = GemmDesc(dtype, a_layout, b_layout, pa, pb, pc, M, N, K, lda, ldb, ldc, batch, batch_inner,
                  sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], splitk, conv[0], conv[1], conv[2], alpha,
                  None if bias is None else bias.data_ptr(), act, None if R is None else R.data_ptr(), ldr, out_mode, DEBUG_FLAGS,
-                 None if col_stats is None else col_stats.data_ptr(),
+                 None if col_stats is None else col_stats.data_ptr(), stat_replicas,
                  None if a_sum is None else a_sum.data_ptr() + 4 * a_sum_off)
     if PROF is not None and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
         # events go on the stream the kernel is actually launched on (the weight-gradient side stream while it is overridden)
@@ -206,6 +206,14 @@ def bn_apply(z, scale_shift, res, relu: bool, y):
     ldr = mat(res)[2] if res is not None else 0
     check(lib().crog_bn_apply(dcode(z), ptr(z), ldz, ptr(scale_shift), ptr(res), ldr, int(relu), ptr(y), ldy, M, C, stream()),
           "bn_apply")
+
+
+def bn_apply_stats(z, sums, replicas, count, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, mean_invstd, res, relu, y):
+    M, C, ldz = mat(z)
+    ldr = mat(res)[2] if res is not None else 0
+    check(lib().crog_bn_apply_stats(dcode(z), ptr(z), ldz, ptr(sums), replicas, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
+                                    ptr(running_var), float(momentum), float(eps), ptr(scale_shift), ptr(mean_invstd), ptr(res), ldr,
+                                    int(relu), ptr(y), mat(y)[2], M, C, stream()), "bn_apply_stats")
 
 
 def bn_bwd_partial(dy, y, z, mean_invstd, rows_per_block, partial, relu_ss=None):

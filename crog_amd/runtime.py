@@ -93,7 +93,7 @@ class Runtime:
                 cur.wait_stream(s)
 
     # ---- pre-zeroed fp32 scratch: one memset per step instead of one per BatchNorm reduction ---------------------------
-    ZERO_POOL = 1 << 20   # floats (4 MiB): ~90 reductions of <= 4096 floats per step
+    ZERO_POOL = 1 << 22   # floats (16 MiB): BatchNorm statistic replicas and reduction targets of one step
 
     def begin_step(self, device):
         """Called once per training forward: clears the zero pool and rewinds its bump pointer."""

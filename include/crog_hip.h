@@ -93,6 +93,9 @@ typedef struct crog_gemm_desc {
   float* col_stats;  /* NULL, or [ceil(M/128)][N][2] fp32 partial (sum, sum of squares) over the
                         rows of each 128-row tile of v = alpha*acc + bias (BatchNorm statistics,
                         clip.py:18,21,26; layers.py:11).  batch must be 1, splitk 1. */
+  int stat_replicas; /* 0: col_stats is the [ceil(M/128)][N][2] slab above (plain stores, deterministic).  R > 0: col_stats is a
+                        PRE-ZEROED [R][N][2] buffer; the slab row s is added atomically into row s mod R (the consumer sums the
+                        R rows: crog_bn_apply_stats) — no reduction launch between the GEMM and the normalisation. */
   float* a_sum;      /* NULL, or fp32 [M]: a_sum[m] += sum_k A(m, k), accumulated atomically by the blocks of the first
                         N-tile (every split adds its share).  With A = dy^T (CROG_A_MC) this is the bias gradient of the
                         nn.Linear / bias-conv whose weight gradient the GEMM computes (clip.py:249-251, layers.py:58,
@@ -117,6 +120,13 @@ int crog_bn_stat_blocks(int64_t M, int rows_per_block);
 int crog_bn_partial_stats(int dtype, const void* x, int64_t M, int C, int64_t ld, int rows_per_block,
                           float* partial, crog_stream_t stream);
 /* sums_is_zero != 0: `sums` was zeroed by the caller (the reduction accumulates with atomics) */
+/* bn_apply with the statistics finalised inside the kernel: `sums` = [replicas][C][2] accumulated by a crog_gemm epilogue
+ * (stat_replicas) or the all-reduced [C][2] totals of SyncBatchNorm; also stores scale/shift and (mean, invstd) for the backward
+ * pass and updates the running statistics (nn.BatchNorm2d training forward, clip.py:18-26, layers.py:8-16). */
+int crog_bn_apply_stats(int dtype, const void* z, int64_t ldz, const float* sums, int replicas, float count,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                        float eps, float* scale_shift, float* mean_invstd, const void* res, int64_t ldr, int relu, void* y,
+                        int64_t ldy, int64_t M, int C, crog_stream_t stream);
 int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, int sums_is_zero, crog_stream_t stream);
 int crog_split_pairs(const float* sums, int C, float* a, float* b, crog_stream_t stream);
 int crog_bn_finalize(const float* sums, float count, const float* gamma, const float* beta,
