@@ -293,7 +293,7 @@ template <typename T>
 __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
                                                             const T* __restrict__ z, long ldz, const float* __restrict__ mean_invstd,
                                                             const float* __restrict__ relu_ss, long M, int C, int rows_per_block,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial, int replicas) {
   constexpr int VEC = Elem<T>::VEC;
   __shared__ float red[NT][2 * VEC + 1];
   const int cvec = C / VEC;
@@ -343,11 +343,20 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
           s1[e] += red[j * cw + tx][e];
           s2[e] += red[j * cw + tx][VEC + e];
         }
-      float* dst = partial + ((long)blockIdx.x * C + c) * 2;
+      if (replicas > 0) {   // accumulate into one of `replicas` pre-zeroed [C][2] rows: the consumer sums them in-kernel
+        float* dst = partial + ((long)(blockIdx.x % replicas) * C + c) * 2;
 #pragma unroll
-      for (int e = 0; e < VEC; e++) {
-        dst[2 * e] = s1[e];
-        dst[2 * e + 1] = s2[e];
+        for (int e = 0; e < VEC; e++) {
+          atomicAdd(dst + 2 * e, s1[e]);
+          atomicAdd(dst + 2 * e + 1, s2[e]);
+        }
+      } else {
+        float* dst = partial + ((long)blockIdx.x * C + c) * 2;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          dst[2 * e] = s1[e];
+          dst[2 * e + 1] = s2[e];
+        }
       }
     }
     __syncthreads();
@@ -368,8 +377,28 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
                                                           const T* __restrict__ z, long ldz, const float* __restrict__ mean_invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ sums, float count,
                                                           const float* __restrict__ relu_ss, T* __restrict__ dz, long lddz, T* __restrict__ dres,
-                                                          long lddres, long M, int C) {
+                                                          long lddres, long M, int C, int sum_rows, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
   constexpr int VEC = Elem<T>::VEC;
+  // sum_rows > 0: `sums` is [sum_rows][C][2] (atomic replicas of bn_bwd_partial, or the all-reduced totals): every block adds the
+  // rows up into LDS once; block 0 also stores the parameter gradients (dbeta = sum g, dgamma = sum g*zhat) when asked to.
+  extern __shared__ __attribute__((aligned(16))) float tot[];
+  if (sum_rows > 0) {
+    for (int c = threadIdx.x; c < C; c += NT) {
+      float a = 0.f, b = 0.f;
+      for (int r = 0; r < sum_rows; r++) {
+        a += sums[((long)r * C + c) * 2];
+        b += sums[((long)r * C + c) * 2 + 1];
+      }
+      tot[2 * c] = a;
+      tot[2 * c + 1] = b;
+      if (blockIdx.x == 0 && dgamma) {
+        dbeta[c] = a;
+        dgamma[c] = b;
+      }
+    }
+    __syncthreads();
+  }
   const int cvec = C / VEC;
   const long total = M * cvec;
   const float inv_count = 1.f / count;
@@ -383,7 +412,12 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
     Vec16<T> o, gr;
     float gf[VEC], zf[VEC], mu[VEC], is[VEC], sg[VEC], sgz[VEC], gm[VEC];
     ld_pairs<VEC>(mean_invstd + 2 * c, mu, is);
-    ld_pairs<VEC>(sums + 2 * c, sg, sgz);
+    if (sum_rows > 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) { sg[e] = tot[2 * (c + e)]; sgz[e] = tot[2 * (c + e) + 1]; }
+    } else {
+      ld_pairs<VEC>(sums + 2 * c, sg, sgz);
+    }
     ld_f32v<VEC>(gamma + c, gm);
 #pragma unroll
     for (int e = 0; e < VEC; e++) { gf[e] = Elem<T>::to_f(g.v[e]); zf[e] = Elem<T>::to_f(zz.v[e]); }
@@ -943,13 +977,14 @@ extern "C" int crog_bn_apply_stats(int dtype, const void* z, int64_t ldz, const 
 
 extern "C" int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
                                    const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C, int rows_per_block,
-                                   float* partial, crog_stream_t stream) {
+                                   float* partial, int replicas, crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0 && pow2(C / vec), "bn_bwd_partial: C/vec must be a power of two (C=%d)", C);
+  CROG_CHECK_ARG(replicas >= 0, "bn_bwd_partial: replicas must be >= 0");
   const int blocks = cdiv(M, rows_per_block);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dy,
                                        (long)lddy, (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, relu_scale_shift, (long)M, C,
-                                       rows_per_block, partial));
+                                       rows_per_block, partial, replicas));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
@@ -957,13 +992,16 @@ extern "C" int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, cons
 extern "C" int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
                                  const float* mean_invstd, const float* gamma, const float* sums, float count,
                                  const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres, int64_t M, int C,
-                                 crog_stream_t stream) {
+                                 int sum_rows, float* dgamma, float* dbeta, crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0, "bn_bwd_apply: C %% %d != 0", vec);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(stream_grid(M * (C / vec))), dim3(NT), 0,
-                                       (hipStream_t)stream, (const T*)dy, (long)lddy, (const T*)y, (long)ldy, (const T*)z,
-                                       (long)ldz, mean_invstd, gamma, sums, count, relu_scale_shift, (T*)dz, (long)lddz, (T*)dres, (long)lddres,
-                                       (long)M, C));
+  CROG_CHECK_ARG(sum_rows >= 0 && C <= 8192 && (!dgamma || (dbeta && sum_rows > 0)), "bn_bwd_apply: bad sum_rows / parameter-gradient outputs");
+  int grid = stream_grid(M * (C / vec));
+  if (sum_rows > 0) grid = std::min(grid, 1024);   // every block adds up the sum_rows x 2C partials once
+  const size_t lds = sum_rows > 0 ? (size_t)C * 2 * sizeof(float) : 0;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(NT), lds, (hipStream_t)stream, (const T*)dy, (long)lddy,
+                                       (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, gamma, sums, count, relu_scale_shift,
+                                       (T*)dz, (long)lddz, (T*)dres, (long)lddres, (long)M, C, sum_rows, dgamma, dbeta));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -44,6 +44,7 @@ FUSED_REDUCE_MAX_PARTS = int(_os.environ.get("CROG_FUSED_REDUCE_MAX_PARTS", "256
 FLASH_ATTN = _os.environ.get("CROG_FLASH_ATTN", "1") != "0"     # fused attention kernels (csrc/attn.hip) where they apply
 FLASH_MIN_KEYS = 64
 BN_ATOMIC_STATS = _os.environ.get("CROG_BN_ATOMIC_STATS", "1") != "0"   # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize
+BN_BWD_ATOMIC = _os.environ.get("CROG_BN_BWD_ATOMIC", "0") == "1"   # backward partial sums through atomics: measured slower
 DGRAD_T = _os.environ.get("CROG_DGRAD_T", "1") != "0"          # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
 FUSED_HEAD = _os.environ.get("CROG_FUSED_HEAD", "1") != "0"    # fold vis.4 into the dynamic head (no groups*C-channel map)
 
@@ -281,24 +282,60 @@ class ConvBnAct(Function):
         M = z.numel() // C
         rpb = K.bn_rows_per_block(M)
         nparts = (M + rpb - 1) // rpb
-        partial = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
         relu_ss = ctx.relu_ss
         ymask = y if (relu and relu_ss is None) else None
-        K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial, relu_ss)
-        sums = RT.zeros(2 * C, dev).view(C, 2) if nparts > FUSED_REDUCE_MAX_PARTS else torch.empty(C, 2, device=dev, dtype=torch.float32)
-        # local sums: (sum g -> dbeta, sum g*xhat -> dgamma) and the pair vector for the second pass
-        if nparts <= FUSED_REDUCE_MAX_PARTS:
-            K.reduce_split(partial, nparts, C, sums, bn.beta.grad(), bn.gamma.grad())
-        else:
-            K.reduce_pairs(partial, nparts, C, sums, zeroed=True)
-            K.split_pairs(sums, C, bn.beta.grad(), bn.gamma.grad())
-        bn.beta.done()
-        bn.gamma.done()
-        if RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force):
-            RT.comm.all_reduce_sum(sums)
+        comm_on = RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force)
         dz = torch.empty(lead + (C,), device=dev, dtype=dtype)
         dres = torch.empty(lead + (C,), device=dev, dtype=dtype) if ctx.has_res else None
-        K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss)
+        if BN_BWD_ATOMIC:
+            # (sum g, sum g*xhat) accumulate atomically into R pre-zeroed [C][2] rows and the apply kernel adds the rows up itself.
+            # Measured SLOWER (every block fires 2C atomics at the same few KB: 33 -> 115 us per launch), kept as a switch only.
+            R = 1 if (comm_on or nparts <= 512) else 4
+            sums = RT.zeros(R * 2 * C, dev)
+            K.bn_bwd_partial(dy, ymask, z, mi, rpb, sums, relu_ss, replicas=R)
+            if comm_on:
+                K.split_pairs(sums, C, bn.beta.grad(), bn.gamma.grad())   # parameter gradients stay LOCAL sums (DDP averages them later)
+                RT.comm.all_reduce_sum(sums[:2 * C])
+                K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=1)
+            else:
+                K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=R,
+                               dgamma=bn.gamma.grad(), dbeta=bn.beta.grad())
+            bn.beta.done()
+            bn.gamma.done()
+        elif BN_ATOMIC_STATS:
+            # per-block slab -> one reduction launch -> apply kernel that stages the totals in LDS and (block 0) stores dbeta / dgamma
+            partial = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
+            K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial, relu_ss)
+            fused = nparts <= FUSED_REDUCE_MAX_PARTS
+            sums = torch.empty(2 * C, device=dev, dtype=torch.float32) if fused else RT.zeros(2 * C, dev)
+            local_grads = fused or comm_on      # the parameter gradients are LOCAL sums: written before the all-reduce
+            if fused:
+                K.reduce_split(partial, nparts, C, sums, bn.beta.grad(), bn.gamma.grad())
+            else:
+                K.reduce_pairs(partial, nparts, C, sums, zeroed=True)
+                if comm_on:
+                    K.split_pairs(sums, C, bn.beta.grad(), bn.gamma.grad())
+            if comm_on:
+                RT.comm.all_reduce_sum(sums)
+            K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=1,
+                           dgamma=None if local_grads else bn.gamma.grad(), dbeta=None if local_grads else bn.beta.grad())
+            bn.beta.done()
+            bn.gamma.done()
+        else:
+            partial = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
+            K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial, relu_ss)
+            sums = RT.zeros(2 * C, dev).view(C, 2) if nparts > FUSED_REDUCE_MAX_PARTS else torch.empty(C, 2, device=dev, dtype=torch.float32)
+            # local sums: (sum g -> dbeta, sum g*xhat -> dgamma) and the pair vector for the second pass
+            if nparts <= FUSED_REDUCE_MAX_PARTS:
+                K.reduce_split(partial, nparts, C, sums, bn.beta.grad(), bn.gamma.grad())
+            else:
+                K.reduce_pairs(partial, nparts, C, sums, zeroed=True)
+                K.split_pairs(sums, C, bn.beta.grad(), bn.gamma.grad())
+            bn.beta.done()
+            bn.gamma.done()
+            if comm_on:
+                RT.comm.all_reduce_sum(sums)
+            K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss)
         grad_slot, res_slot = ctx.slots
         if res_slot is not None and dres is not None:   # hand the identity's gradient to the block's first convolution
             res_slot.t = dres

@@ -216,11 +216,11 @@ def bn_apply_stats(z, sums, replicas, count, gamma, beta, running_mean, running_
                                     int(relu), ptr(y), mat(y)[2], M, C, stream()), "bn_apply_stats")
 
 
-def bn_bwd_partial(dy, y, z, mean_invstd, rows_per_block, partial, relu_ss=None):
+def bn_bwd_partial(dy, y, z, mean_invstd, rows_per_block, partial, relu_ss=None, replicas=0):
     M, C, lddy = mat(dy)
     ldy = mat(y)[2] if y is not None else 0
     check(lib().crog_bn_bwd_partial(dcode(dy), ptr(dy), lddy, ptr(y), ldy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(relu_ss), M, C,
-                                    rows_per_block, ptr(partial), stream()), "bn_bwd_partial")
+                                    rows_per_block, ptr(partial), replicas, stream()), "bn_bwd_partial")
 
 
 def bn_reduce_finalize(partial, nparts, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale_shift, mean_invstd):
@@ -232,13 +232,13 @@ def reduce_split(partial, nparts, C, sums, a, b):
     check(lib().crog_reduce_split(ptr(partial), nparts, C, ptr(sums), ptr(a), ptr(b), stream()), "reduce_split")
 
 
-def bn_bwd_apply(dy, y, z, mean_invstd, gamma, sums, count, dz, dres, relu_ss=None):
+def bn_bwd_apply(dy, y, z, mean_invstd, gamma, sums, count, dz, dres, relu_ss=None, sum_rows=0, dgamma=None, dbeta=None):
     M, C, lddy = mat(dy)
     ldy = mat(y)[2] if y is not None else 0
     lddres = mat(dres)[2] if dres is not None else 0
     check(lib().crog_bn_bwd_apply(dcode(dy), ptr(dy), lddy, ptr(y), ldy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(gamma),
-                                  ptr(sums), float(count), ptr(relu_ss), ptr(dz), mat(dz)[2], ptr(dres), lddres, M, C, stream()),
-          "bn_bwd_apply")
+                                  ptr(sums), float(count), ptr(relu_ss), ptr(dz), mat(dz)[2], ptr(dres), lddres, M, C, sum_rows,
+                                  ptr(dgamma), ptr(dbeta), stream()), "bn_bwd_apply")
 
 
 # --------------------------------------------------------------------------------------------

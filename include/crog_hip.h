@@ -142,12 +142,15 @@ int crog_bn_apply(int dtype, const void* z, int64_t ldz, const float* scale_shif
  * residual: the output is not re-read), else 1;  partial[block][C][2] = (sum g, sum g*xhat) */
 int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
                         int64_t ldz, const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C,
-                        int rows_per_block, float* partial, crog_stream_t stream);
-/* dz = gamma*invstd*(g - sums.g/count - xhat*sums.gx/count);  dres = g when dres != NULL */
+                        int rows_per_block, float* partial, int replicas, crog_stream_t stream);
+/* dz = gamma*invstd*(g - sums.g/count - xhat*sums.gx/count);  dres = g when dres != NULL.
+ * replicas (partial) / sum_rows (apply) = 0: `partial` is the per-block slab [blocks][C][2] and `sums` the reduced [C][2].
+ * replicas = R > 0: the partial kernel adds atomically into a PRE-ZEROED [R][C][2]; the apply kernel is handed the same buffer
+ * with sum_rows = R, adds the rows up itself and (dgamma/dbeta != NULL) stores the parameter gradients — no reduction launch. */
 int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
                       int64_t ldz, const float* mean_invstd, const float* gamma, const float* sums,
                       float count, const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres,
-                      int64_t M, int C, crog_stream_t stream);
+                      int64_t M, int C, int sum_rows, float* dgamma, float* dbeta, crog_stream_t stream);
 /* single-replica fast paths: slab [nparts][C][2] -> (reduce + finalize) / (reduce + split into two vectors) in one launch */
 int crog_bn_reduce_finalize(const float* partial, int nparts, float count, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int C,

@@ -220,6 +220,17 @@ def test_batchnorm_train_fwd_bwd(K, dt):
     assert torch.equal(dbeta, sums[:, 0]) and torch.equal(dgamma, sums[:, 1])
     dz, dres = torch.empty_like(z), torch.empty_like(z)
     K.bn_bwd_apply(dy, y, z, mi, gamma, sums, M, dz, dres)
+    # atomic replicas + in-kernel totals (no reduction launch): same dz / dres, parameter gradients stored by the apply kernel
+    for R in (1, 4):
+        acc = torch.zeros(R, C, 2, device="cuda")
+        K.bn_bwd_partial(dy, y, z, mi, rpb, acc, replicas=R)
+        assert torch.allclose(acc.sum(0), sums, rtol=1e-4, atol=1e-3)
+        dz2, dres2 = torch.empty_like(z), torch.empty_like(z)
+        dg2, db2 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        K.bn_bwd_apply(dy, y, z, mi, gamma, acc, M, dz2, dres2, sum_rows=R, dgamma=dg2, dbeta=db2)
+        assert torch.allclose(db2, dbeta, rtol=1e-4, atol=1e-3) and torch.allclose(dg2, dgamma, rtol=1e-4, atol=1e-3)
+        close(dz2, dz.float(), dt, scale=1)
+        assert torch.equal(dres2, dres)
     # fused single-replica forward statistics == two-step path
     ss2, mi2 = torch.empty(C, 2, device="cuda"), torch.empty(C, 2, device="cuda")
     K.bn_partial_stats(z, partial, rpb)
