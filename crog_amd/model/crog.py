@@ -18,6 +18,11 @@ from .blocks import BatchNorm, bind_all
 from .clip import arch_from_state_dict, build_model
 from .layers import FPN, MultiTaskProjector, Projector, TransformerDecoder
 
+# Text tower forward/backward as two hipGraph replays (crog_amd/graphs.py).  Opt-in: it removes ~650 launches (~8 ms of host
+# time) per step, but the step is GPU-bound on one MI355X (measured 39.8 vs 39.7 ms/step, 43.2 vs 43.4 under DDP), so the eager
+# path stays the default until the host becomes the limiter.
+TEXT_GRAPH = os.environ.get("CROG_TEXT_GRAPH", "0") == "1"
+
 RN50_ARCH = dict(embed_dim=1024, image_resolution=224, vision_layers=(3, 4, 6, 3), vision_width=64, vision_patch_size=None,
                  context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12)
 
@@ -93,6 +98,7 @@ class CROG(nn.Module):
         self._bns = None
         self.overlap_text = True
         self._side = None
+        self._graphs = {}
         self.explicit_grad_ready = True  # kernels write gradients in place and call RT.reducer.mark_ready themselves
 
     @staticmethod
@@ -145,6 +151,13 @@ class CROG(nn.Module):
             self._store.invalidate_shadow()
         return out
 
+    def _text_graph(self, word, dtype):
+        key = (tuple(word.shape), dtype, id(self._store))
+        if self._graphs.get("key") != key:
+            from ..graphs import GraphedTower
+            self._graphs = {"key": key, "text": GraphedTower(lambda w: self.backbone.text_features(w, dtype), word, self._side)}
+        return self._graphs["text"]
+
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, img, word, mask=None, grasp_qua_mask=None, grasp_sin_mask=None, grasp_cos_mask=None, grasp_wid_mask=None):
         """img: [b,3,h,w] fp32; word: [b,L] int64; masks: [b,1,h,w] fp32 (crog.py:47)."""
@@ -170,6 +183,15 @@ class CROG(nn.Module):
                     self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CROG_SIDE_PRIORITY", "0")))
                 RT.streams = [main, self._side]
                 self._side.wait_stream(main)
+                graphed = self._text_graph(word, dtype) if (TEXT_GRAPH and self.training and torch.is_grad_enabled()) else None
+            if self.overlap_text and graphed is not None:
+                # both passes of the text tower are one hipGraph replay each (crog_amd/graphs.py): issued up front, it runs
+                # beside the image stem without costing the host ~650 launches per step
+                with torch.cuda.stream(self._side):
+                    wfeat, state = graphed(self.backbone.tok.param, word)
+                vis = self.backbone.image_features(img, dtype)
+                main.wait_stream(self._side)
+            elif self.overlap_text:
                 txt = []
                 steps = self.backbone.text_features_steps(word, dtype, parts=int(os.environ.get("CROG_TEXT_PARTS", "3")))
 
