@@ -287,6 +287,76 @@ inline bool win_ok(int H, int W, int KH, int KW, int S, int P, int OH, int OW) {
   return H > 0 && W > 0 && KH > 0 && KW > 0 && S > 0 && P >= 0 && OH == (H + 2 * P - KH) / S + 1 && OW == (W + 2 * P - KW) / S + 1;
 }
 
+// Evaluation maps (crog_engine.py:181-211): out[b][g] = bicubic(align_corners=True, A = -0.75)( g in sigmoid_mask ? sigmoid(x) : x ).
+// Planar fp32 [B*G][h][w] -> [B*G][H][W]; one thread per 4 consecutive output columns (one 16-byte store: the 16x larger output is
+// the HBM traffic, the input plane set stays in L2).  Taps are clamped to the plane like ATen's upsample_get_value_bounded.
+__device__ inline void cubic_taps(float t, float w[4]) {
+  constexpr float A = -0.75f;
+  const float t1 = t + 1.f, u = 1.f - t, u1 = 2.f - t;
+  w[0] = ((A * t1 - 5.f * A) * t1 + 8.f * A) * t1 - 4.f * A;
+  w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+  w[2] = ((A + 2.f) * u - (A + 3.f)) * u * u + 1.f;
+  w[3] = ((A * u1 - 5.f * A) * u1 + 8.f * A) * u1 - 4.f * A;
+}
+template <bool SIG>
+__device__ inline float eval_tap(const float* __restrict__ p) {
+  const float v = *p;
+  return SIG ? 1.f / (1.f + __expf(-v)) : v;
+}
+template <bool SIG>
+__device__ inline void eval_bicubic4(const float* __restrict__ plane, int h, int w, float sy, float sx, int oy, int ox0, int W, float out[4]) {
+#pragma clang fp contract(off)   // t = fy - y0 must see the ROUNDED product sy*oy, as ATen forms it: fused, the phase moves by the product's
+                                 // rounding error (4e-6 near source index 100) and a +-10 logit map by 1e-4
+  const float fy = sy * (float)oy;
+  const int y0 = (int)floorf(fy);
+  float wy[4];
+  cubic_taps(fy - y0, wy);
+  const float* rows[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) rows[j] = plane + (long)min(max(y0 - 1 + j, 0), h - 1) * w;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int ox = min(ox0 + e, W - 1);
+    const float fx = sx * (float)ox;
+    const int x0 = (int)floorf(fx);
+    float wx[4];
+    cubic_taps(fx - x0, wx);
+    int xs[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) xs[i] = min(max(x0 - 1 + i, 0), w - 1);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float r = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) r += wx[i] * eval_tap<SIG>(rows[j] + xs[i]);
+      acc += wy[j] * r;
+    }
+    out[e] = acc;
+  }
+}
+__global__ void __launch_bounds__(NT) eval_maps_kernel(const float* __restrict__ x, int planes, int G, int h, int w, unsigned sigmoid_mask,
+                                                       float* __restrict__ y, int H, int W, float sy, float sx) {
+  const int wq = (W + 3) / 4;
+  const long total = (long)planes * H * wq;
+  GRID_STRIDE(i, total) {
+    const int q = (int)(i % wq);
+    long p = i / wq;
+    const int oy = (int)(p % H);
+    const int pl = (int)(p / H);
+    const float* plane = x + (long)pl * h * w;
+    float o[4];
+    if ((sigmoid_mask >> (pl % G)) & 1u) eval_bicubic4<true>(plane, h, w, sy, sx, oy, q * 4, W, o);
+    else eval_bicubic4<false>(plane, h, w, sy, sx, oy, q * 4, W, o);
+    float* dst = y + ((long)pl * H + oy) * W + q * 4;
+    if (q * 4 + 4 <= W && (W & 3) == 0) {
+      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+      for (int e = 0; e < 4 && q * 4 + e < W; e++) dst[e] = o[e];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int crog_im2col_nhwc(int dtype, const void* x, int64_t ldx, void* col, int64_t ldo, int B, int H, int W, int C, int KH, int KW, int S,
@@ -336,6 +406,15 @@ extern "C" int crog_maxpool3s2_bwd(int dtype, const void* dy, int64_t lddy, cons
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   DISPATCH_T(dtype, LAUNCH((maxpool3s2_bwd_kernel<T>), (long)B * H * W * (C / vec), s, (const T*)dy, (long)lddy, (const unsigned char*)argmax,
                            (T*)dx, (long)lddx, B, H, W, C, OH, OW));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_eval_maps(const float* x, int B, int G, int h, int w, int sigmoid_mask, float* y, int H, int W, crog_stream_t s) {
+  CROG_CHECK_ARG(B >= 0 && G >= 1 && G <= 32 && h >= 1 && w >= 1 && H >= 1 && W >= 1, "eval_maps: bad shape");
+  if (B == 0) return CROG_OK;
+  // align_corners=True source scale (n_in - 1) / (n_out - 1), formed once on the host in fp32 as ATen does
+  const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  LAUNCH(eval_maps_kernel, (long)B * G * H * ((W + 3) / 4), s, x, B * G, G, h, w, (unsigned)sigmoid_mask, y, H, W, sy, sx);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -13,6 +13,7 @@ import torch
 import torch.distributed as dist
 
 from . import functional as Fn
+from . import kernels as K
 
 
 class AverageMeter:
@@ -56,6 +57,49 @@ def train_step(model, optimizer, scaler, batch, args=None, autocast_dtype=torch.
         dist.all_reduce(stats)
         stats = stats / dist.get_world_size()
     return stats, loss_dict
+
+
+EVAL_SIGMOID_GRASP = 0b10011   # crog_engine.py:182-184: sigmoid on (ins, qua, wid); sin / cos stay raw
+EVAL_SIGMOID_MASK_ONLY = 0b1
+
+
+@torch.no_grad()
+def eval_maps(model, batch, autocast_dtype=None):
+    """Device part of validate_with_grasp / validate_without_grasp (crog_engine.py:163-211, :348-361): eval forward, sigmoid on the
+    probability maps and bicubic (align_corners=True) resize to the input resolution, in ONE kernel over all five maps.
+    Returns (list of [B, H, W] fp32 prediction maps, tuple of targets as the model returns them); the per-image cv2 inverse warp,
+    `detect_grasps` and the Jacquard index that follow in the reference are host post-processing and stay with the caller."""
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.autocast("cuda", dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
+            pred, target = model(batch["img"], batch["word"], batch.get("mask"), batch.get("qua"), batch.get("sin"), batch.get("cos"),
+                                 batch.get("wid"))
+    finally:
+        model.train(was_training)
+    H, W = batch["img"].shape[-2:]
+    if isinstance(pred, tuple):
+        logits = torch.cat([p.float() for p in pred], 1)
+        mask = EVAL_SIGMOID_GRASP
+    else:
+        logits, mask = pred.float(), EVAL_SIGMOID_MASK_ONLY
+    if tuple(logits.shape[-2:]) != (H, W):
+        maps = K.eval_maps(logits, mask, H, W)
+    else:                                   # crog_engine.py:186: no resize when the sizes already agree
+        maps = logits.clone()
+        for g in range(maps.shape[1]):
+            if (mask >> g) & 1:
+                maps[:, g].sigmoid_()
+    return [maps[:, g] for g in range(maps.shape[1])], target
+
+
+def mask_iou(pred_map, target, thr=0.35):
+    """Per-image IoU of (pred > thr) against a {0,1} target, on the device (crog_engine.py:251-255 without the inverse warp)."""
+    p = pred_map > thr
+    t = target.reshape(p.shape) > 0.5
+    inter = (p & t).flatten(1).sum(1).float()
+    union = (p | t).flatten(1).sum(1).float()
+    return inter / (union + 1e-6)
 
 
 def train_with_grasp(train_loader, model, optimizer, scheduler, scaler, epoch, args, log=print):

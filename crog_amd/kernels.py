@@ -434,6 +434,15 @@ def patchify(img, out, patch: int):
     check(lib().crog_patchify(dcode(out), ptr(img), ptr(out), B, H, W, patch, stream()), "patchify")
 
 
+def eval_maps(x: torch.Tensor, sigmoid_mask: int, H: int, W: int) -> torch.Tensor:
+    """x: fp32 [B, G, h, w] logits -> fp32 [B, G, H, W] (sigmoid on the channels in `sigmoid_mask`, bicubic align_corners=True)."""
+    B, G, h, w = x.shape
+    x = x.contiguous()
+    y = torch.empty(B, G, H, W, device=x.device, dtype=torch.float32)
+    check(lib().crog_eval_maps(ptr(x), B, G, h, w, sigmoid_mask, ptr(y), H, W, stream()), "eval_maps")
+    return y
+
+
 def conv3_dgrad_weights(src, dst, table, count):
     check(lib().crog_conv3_dgrad_weights(dcode(src), ptr(src), ptr(dst), ptr(table), count, stream()), "conv3_dgrad_weights")
 

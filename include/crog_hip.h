@@ -275,6 +275,11 @@ int crog_upsample2ac_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t
                          crog_stream_t stream);
 int crog_upsample2ac_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int H, int W,
                          int C, crog_stream_t stream);
+/* Evaluation maps, engine/crog_engine.py:181-211 (validate_with_grasp) / :356-361 (validate_without_grasp): planar fp32 logits
+ * x[B][G][h][w] -> y[B][G][H][W] = F.interpolate(mode='bicubic', align_corners=True)(sigmoid(x) where bit g of sigmoid_mask is
+ * set, x elsewhere) — the reference applies sigmoid to the mask / quality / width maps and leaves sin / cos raw. */
+int crog_eval_maps(const float* x, int B, int G, int h, int w, int sigmoid_mask, float* y, int H, int W,
+                   crog_stream_t stream);
 /* Data-gradient layout of 3x3 convolution weights, all convolutions of a model in one launch: for each table entry
  * (element offset, Cout, Cin) dst[off + (ci*9 + 8-tap)*Cout + co] = src[off + (co*9 + tap)*Cin + ci].  The data gradient of
  * F.conv2d(k=3, s=1, p=1) (clip.py:21,166-170; layers.py:8-11) is then crog_gemm(CROG_A_IM2COL, CROG_B_KC) on dy and this copy. */

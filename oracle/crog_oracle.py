@@ -307,6 +307,40 @@ def train_metric(output: Tensor, target: Tensor, threshold: float = 0.35, pr_iou
     return 100.0 * ious.mean(), 100.0 * (ious > pr_iou).float().mean()
 
 
+def eval_maps(logits: Tensor, sigmoid_channels: Sequence[int], size: Tuple[int, int]) -> Tensor:
+    """Device part of validate_with_grasp, engine/crog_engine.py:181-211 (and :356-361): sigmoid on the listed channels, then
+    F.interpolate(mode='bicubic', align_corners=True) to `size`.  Restated with explicit loops over the 4x4 taps (cubic
+    convolution, A = -0.75, source index o*(n_in-1)/(n_out-1), taps clamped to the plane) so that it does not lean on the very
+    ATen routine the reference calls; tests/test_oracle_golden.py pins it against that routine."""
+    x = logits.double().clone()
+    for c in sigmoid_channels:
+        x[:, c] = torch.sigmoid(x[:, c])
+    B, G, h, w = x.shape
+    H, W = size
+    A = -0.75
+
+    def taps(n_in, n_out):
+        scale = torch.tensor((n_in - 1) / (n_out - 1) if n_out > 1 else 0.0, dtype=torch.float32)   # ATen computes the scale in fp32
+        src = (scale * torch.arange(n_out, dtype=torch.float32)).double()
+        i0 = torch.floor(src)
+        t = src - i0
+        wts = torch.stack([((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A,
+                           ((A + 2) * t - (A + 3)) * t * t + 1,
+                           ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1,
+                           ((A * (2 - t) - 5 * A) * (2 - t) + 8 * A) * (2 - t) - 4 * A], 1)          # [n_out, 4]
+        idx = (i0.long()[:, None] + torch.arange(-1, 3)[None, :]).clamp(0, n_in - 1)             # [n_out, 4]
+        return wts, idx
+
+    wy, iy = taps(h, H)
+    wx, ix = taps(w, W)
+    out = torch.zeros(B, G, H, W, dtype=torch.float64)
+    for j in range(4):
+        rows = x[:, :, iy[:, j], :]                                   # [B, G, H, w]
+        for i in range(4):
+            out += wy[:, j][None, None, :, None] * wx[:, i][None, None, None, :] * rows[:, :, :, ix[:, i]]
+    return out.float()
+
+
 # ---------------------------------------------------------------------------------------------
 # whole model (crog.py:47-133)
 # ---------------------------------------------------------------------------------------------

@@ -4,10 +4,14 @@ These run on the GPU box (`-m gpu`) and call through the C ABI (crog_amd.kernels
 torch ops are used here only as the checker.
 """
 import math
+import os
+import sys
 
 import pytest
 import torch
 import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -753,3 +757,20 @@ def test_fused_head_bias_kernels(K, dt):
     close(db5[1:g * C + 1].view(g, C), torch.einsum("bht,bct->hc", dcb, wpad.float()), dt, scale=4)
     close(dwpad[..., :9], torch.einsum("hc,bht->bct", b5.view(g, C), dcb)[..., :9], dt, scale=4)
     assert float(db5[0]) == 0.0 and float(db5[-1]) == 0.0 and float(dwpad[..., 9:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape,size,mask", [((2, 5, 13, 13), (52, 52), 0b10011), ((3, 1, 26, 26), (104, 104), 1),
+                                             ((1, 2, 7, 9), (30, 17), 0), ((2, 5, 104, 104), (416, 416), 0b10011)])
+def test_eval_maps(K, shape, size, mask):
+    """crog_eval_maps (sigmoid + bicubic align_corners=True, crog_engine.py:181-211) against the oracle and the ATen routine."""
+    sys.path.insert(0, ROOT)
+    from oracle import crog_oracle as O
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(5)) * 3
+    chans = [c for c in range(shape[1]) if (mask >> c) & 1]
+    y = K.eval_maps(x.cuda(), mask, *size).cpu()
+    assert (y - O.eval_maps(x, chans, size)).abs().max().item() < 1e-5
+    ref = x.clone()
+    for c in chans:
+        ref[:, c] = torch.sigmoid(ref[:, c])
+    ref = F.interpolate(ref, size=size, mode="bicubic", align_corners=True)
+    assert (y - ref).abs().max().item() < 1e-5

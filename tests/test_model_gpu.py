@@ -126,6 +126,32 @@ def test_tiny_nomask_variant():
     assert err(p, g["eval_pred_ins"]) < 1e-3 and m is b["mask"]
 
 
+def test_eval_maps_of_validate_with_grasp():
+    """Device part of validate_with_grasp (crog_engine.py:163-211): eval forward + sigmoid + bicubic resize to the input size,
+    from the reference's own eval logits (fixture) through the oracle, against engine.eval_maps on the HIP path."""
+    from crog_amd.engine import eval_maps, mask_iou
+    from oracle import crog_oracle as O
+    g, meta = load_case("tiny_crog")
+    cfg = tiny_cfg()
+    model, _ = build(cfg, meta)
+    b = batch_for(cfg, meta)
+    model.train()
+    with torch.no_grad():   # the fixture's eval logits follow ONE training forward (BatchNorm running statistics updated once)
+        model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+    maps, target = eval_maps(model, b)
+    assert model.training and len(maps) == 5 and target[0] is b["mask"]
+    logits = torch.cat([g["eval_pred_" + nm] for nm in NAMES], 1)
+    want = O.eval_maps(logits, (0, 1, 4), tuple(b["img"].shape[-2:]))
+    for i, nm in enumerate(NAMES):
+        assert tuple(maps[i].shape) == (meta["B"],) + tuple(b["img"].shape[-2:])
+        assert err(maps[i], want[:, i]) < 1e-3, nm
+    iou = mask_iou(maps[0], b["mask"])
+    p = want[:, 0] > 0.35
+    t = b["mask"].cpu().reshape(p.shape) > 0.5
+    ref_iou = (p & t).flatten(1).sum(1) / ((p | t).flatten(1).sum(1) + 1e-6)
+    assert (iou.cpu() - ref_iou).abs().max().item() < 2e-2   # a logit within 1e-3 of the 0.35 threshold may flip a pixel
+
+
 def test_text_tower_hip_graph_replays_match_eager(monkeypatch):
     """CROG_TEXT_GRAPH=1: text tower forward/backward as hipGraph replays (crog_amd/graphs.py) == the eager launches,
     step after step (static buffers are overwritten in place), for outputs, loss and every parameter gradient."""

@@ -160,6 +160,20 @@ def test_oracle_matches_reference_config1():
     check(out["total"], g["loss_total"], atol=1e-5, what="total")
 
 
+@pytest.mark.parametrize("shape,size,chans", [((2, 5, 13, 13), (52, 52), (0, 1, 4)), ((1, 1, 26, 26), (104, 104), (0,)),
+                                              ((1, 2, 7, 9), (30, 17), ()), ((1, 5, 104, 104), (416, 416), (0, 1, 4))])
+def test_oracle_eval_maps_matches_reference_statements(shape, size, chans):
+    """engine/crog_engine.py:181-211 verbatim in behaviour: torch.sigmoid on (ins, qua, wid), then F.interpolate(bicubic,
+    align_corners=True) — the ATen routine the reference runs — against the oracle's explicit-tap restatement."""
+    import torch.nn.functional as F
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(5)) * 3
+    ref = x.clone()
+    for c in chans:
+        ref[:, c] = torch.sigmoid(ref[:, c])
+    ref = F.interpolate(ref, size=size, mode="bicubic", align_corners=True)
+    assert (O.eval_maps(x, chans, size) - ref).abs().max().item() < 1e-5
+
+
 def test_oracle_vit_tower_matches_reference():
     """BASELINE config 4 (CLIP ViT tower): encoder-level pin of the oracle against the reference's VisionTransformer
     (clip.py:286-332) on the tiny fixture written by oracle/make_golden.py."""
