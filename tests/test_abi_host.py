@@ -110,3 +110,32 @@ def test_flat_store_layout_on_cpu_tensors():
     assert st.G.abs().sum() > 0 and m[0].weight.grad.data_ptr() == st.G.data_ptr()   # autograd accumulated in place into G
     st.zero_grad()
     assert m[2].weight.grad.abs().sum() == 0
+
+
+def test_checkpoint_prefix_handling(tmp_path):
+    """train_crog.py:213: the reference loads `module.`-prefixed keys into its DDP wrapper; crog_amd.checkpoint accepts either side
+    wrapped or bare, and refuses files that are not CROG checkpoints."""
+    import torch
+    from crog_amd.checkpoint import KEYS, load_checkpoint, save_checkpoint
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+
+    bare = torch.nn.Sequential(torch.nn.Linear(3, 2), torch.nn.BatchNorm1d(2))
+    opt = torch.optim.Adam(bare.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1], gamma=0.1)
+    p = str(tmp_path / "a.pth")
+    ck = save_checkpoint(p, Wrap(bare), opt, sched, epoch=4, best_iou=0.7)
+    assert tuple(ck.keys()) == KEYS and all(k.startswith("module.") for k in ck["state_dict"])
+    other = torch.nn.Sequential(torch.nn.Linear(3, 2), torch.nn.BatchNorm1d(2))
+    info = load_checkpoint(p, other, map_location="cpu")                      # wrapped file -> bare model
+    assert info["epoch"] == 4 and info["best_iou"] == 0.7 and torch.equal(other[0].weight, bare[0].weight)
+    p2 = str(tmp_path / "b.pth")
+    save_checkpoint(p2, bare, opt, sched, epoch=1)
+    load_checkpoint(p2, Wrap(other), map_location="cpu")                      # bare file -> wrapped model
+    torch.save({"weights": 1}, p)
+    import pytest
+    with pytest.raises(KeyError):
+        load_checkpoint(p, other)

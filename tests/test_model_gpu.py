@@ -152,6 +152,82 @@ def test_eval_maps_of_validate_with_grasp():
     assert (iou.cpu() - ref_iou).abs().max().item() < 2e-2   # a logit within 1e-3 of the 0.35 threshold may flip a pixel
 
 
+def test_checkpoint_wire_format_round_trips_with_torch_adam(tmp_path):
+    """SURVEY.md §8f N2 (train_crog.py:206-226,245-267): a checkpoint written by crog_amd resumes a torch.optim.Adam /
+    MultiStepLR over the same named parameters (what the reference holds), a `module.`-prefixed checkpoint written by that side
+    resumes crog_amd, and both continue in lock-step."""
+    from torch.optim.lr_scheduler import MultiStepLR
+    from crog_amd.checkpoint import KEYS, load_checkpoint, save_checkpoint
+    from crog_amd.optim import FusedAdam
+    g, meta = load_case("tiny_crog")
+    cfg = tiny_cfg()
+    b = batch_for(cfg, meta)
+
+    def fresh():
+        model, groups = build(cfg, meta)
+        model.train()
+        opt = FusedAdam(groups, lr=1e-3, weight_decay=0.0, store=model.store)
+        return model, groups, opt, MultiStepLR(opt, milestones=[1, 3], gamma=0.1)
+
+    def backward(model):
+        _, _, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+        loss.backward()
+        torch.cuda.synchronize()
+
+    model, groups, opt, sched = fresh()
+    for _ in range(2):
+        backward(model)
+        opt.step()
+    sched.step()
+    path = str(tmp_path / "last_model.pth")
+    save_checkpoint(path, model, opt, sched, epoch=1, cur_iou=0.25, best_iou=0.5, best_j_index=0.125, prec={"Pr@50": 0.5}, j_index=[0.1, 0.2])
+    blob = torch.load(path, weights_only=False)
+    assert tuple(blob.keys()) == KEYS and blob["optimizer"]["param_groups"][0]["initial_lr"] == cfg.lr_multi * cfg.base_lr
+
+    # the reference's side of the wire: plain parameters in build_crog's group order, torch.optim.Adam, MultiStepLR
+    names = [k for k, _ in model.named_parameters()]
+    ref_p = {k: torch.nn.Parameter(blob["state_dict"][k].clone().cuda()) for k in names}
+    ref_groups = [{"params": [ref_p[k] for k in names if k.startswith("backbone") and "positional_embedding" not in k],
+                   "initial_lr": cfg.lr_multi * cfg.base_lr},
+                  {"params": [ref_p[k] for k in names if not (k.startswith("backbone") and "positional_embedding" not in k)],
+                   "initial_lr": cfg.base_lr}]
+    ref_opt = torch.optim.Adam(ref_groups, lr=1e-3, weight_decay=0.0)
+    ref_sched = MultiStepLR(ref_opt, milestones=[1, 3], gamma=0.1)
+    ref_opt.load_state_dict(blob["optimizer"])
+    ref_sched.load_state_dict(blob["scheduler"])
+    assert [gr["lr"] for gr in ref_opt.param_groups] == [gr["lr"] for gr in opt.param_groups] == [1e-4, 1e-4]
+    mine = dict(model.named_parameters())
+    for k in names[::37]:
+        assert torch.equal(ref_opt.state[ref_p[k]]["exp_avg"], opt.state[mine[k]]["exp_avg"]), k
+        assert float(ref_opt.state[ref_p[k]]["step"]) == 2.0
+
+    def lockstep(model, opt):
+        backward(model)
+        for k in names:
+            ref_p[k].grad = dict(model.named_parameters())[k].grad.detach().clone()
+        opt.step()
+        ref_opt.step()
+        cur = dict(model.named_parameters())
+        worst = max((cur[k].detach() - ref_p[k].detach()).abs().max().item() for k in names)
+        assert worst < 1e-6, worst
+
+    lockstep(model, opt)
+
+    # the other direction: a checkpoint as the reference writes it (DDP wrapper -> `module.` keys) resumes a fresh crog_amd model
+    path2 = str(tmp_path / "ref_model.pth")
+    sd = {"module." + k: v.detach().clone() for k, v in ref_p.items()}
+    sd.update({"module." + k: v.clone() for k, v in model.state_dict().items() if k not in ref_p})   # BatchNorm buffers
+    torch.save({"epoch": 2, "cur_iou": 0.3, "best_iou": 0.5, "best_j_index": 0.125, "prec": {}, "j_index": [0, 0], "state_dict": sd,
+                "optimizer": ref_opt.state_dict(), "scheduler": ref_sched.state_dict()}, path2)
+    model2, _, opt2, sched2 = fresh()
+    info = load_checkpoint(path2, model2, opt2, sched2, map_location="cuda")
+    assert info["epoch"] == 2 and info["best_iou"] == 0.5 and sched2.last_epoch == ref_sched.last_epoch
+    assert opt2._step == 3 and [gr["lr"] for gr in opt2.param_groups] == [1e-4, 1e-4]
+    for k in names[::37]:
+        assert torch.equal(dict(model2.named_parameters())[k].detach(), ref_p[k].detach()), k
+    lockstep(model2, opt2)
+
+
 def test_text_tower_hip_graph_replays_match_eager(monkeypatch):
     """CROG_TEXT_GRAPH=1: text tower forward/backward as hipGraph replays (crog_amd/graphs.py) == the eager launches,
     step after step (static buffers are overwritten in place), for outputs, loss and every parameter gradient."""
