@@ -1,0 +1,84 @@
+"""The N > 1 code path with the real kernels: DistributedDataParallel + SyncBatchNorm over RCCL, forced on at world size 1
+(every BatchNorm exchange and every gradient bucket is really issued; a 1-rank all-reduce is the identity), against the plain
+single-process step on the same inputs.  world_size-2 semantics of the reducer / SyncBN pair exchange are covered on CPU
+(tests/test_ddp_gloo.py); 8-GPU runs are the driver's."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from crog_amd.testing import tiny_cfg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def rccl_world1():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    yield
+    from crog_amd.runtime import RT
+    RT.comm = None
+    RT.reducer = None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("text_graph", [False, True])
+def test_ddp_syncbn_world1_matches_plain_step(rccl_world1, monkeypatch, text_graph):
+    import test_model_gpu as T
+    import crog_amd.model.crog as crog_mod
+    from crog_amd.optim import FusedAdam
+    from crog_amd.parallel import DistributedDataParallel, convert_sync_batchnorm
+    from crog_amd.runtime import RT
+    g, meta = T.load_case("tiny_crog")
+    cfg = tiny_cfg()
+    b = T.batch_for(cfg, meta)
+
+    def step(wrap):
+        model, groups = T.build(cfg, meta)
+        model.train()
+        net = model
+        if wrap:
+            monkeypatch.setattr(crog_mod, "TEXT_GRAPH", text_graph)
+            convert_sync_batchnorm(model, force=True)
+            net = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True, force=True, bucket_cap_mb=0.25)
+            assert RT.comm is not None
+        opt = FusedAdam(groups, lr=1e-6, store=model.store)   # Adam moves every weight by ~lr: keep step 2 out of the chaotic regime
+        out = []
+        for _ in range(2):
+            RT.manual_seed(3)
+            preds, _, loss, _ = net(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+            opt.zero_grad()
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append((preds[0].clone(), float(loss), model.store.G.clone()))
+            opt.step()
+        torch.cuda.synchronize()
+        if wrap:   # the reducer is built at the first forward: several buckets must have been in flight
+            assert len(net.reducer.buckets) > 3
+        res = out, model.store.P.clone(), {k: v.clone() for k, v in model.state_dict().items() if "running_" in k}
+        if wrap:
+            RT.comm = None
+            RT.reducer = None
+        return res
+
+    plain, again, ddp = step(False), step(False), step(True)
+    # yardstick: the plain path's own run-to-run noise (atomic statistics / split-K sums amplified by the tiny model's 1x1 BatchNorms)
+    for i in range(2):
+        (p0, l0, g0), (p1, l1, g1), (p2, l2, g2) = plain[0][i], again[0][i], ddp[0][i]
+        assert T.err(p0, p2) < max(1e-3, 4 * T.err(p0, p1)) and abs(l0 - l2) < 1e-3
+        noise = (g0 - g1).abs().max().item()
+        assert (g0 - g2).abs().max().item() <= 4 * noise + 1e-4 * g0.abs().max().item()
+    assert (plain[1] - ddp[1]).abs().max().item() <= 4 * (plain[1] - again[1]).abs().max().item() + 1e-5
+    for k, v in plain[2].items():
+        assert torch.allclose(v, ddp[2][k], rtol=1e-3, atol=1e-4), k
