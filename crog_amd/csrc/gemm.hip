@@ -19,6 +19,10 @@
 #include <stdlib.h>
 #include <algorithm>
 
+#ifndef CROG_GEMM_PIPELINED
+#define CROG_GEMM_PIPELINED 1   // 0: the plain wait -> barrier -> issue -> compute loop (A/B builds)
+#endif
+
 namespace {
 
 template <typename T> struct TileCfg;
@@ -935,13 +939,79 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 25
     }
   };
 #define CROG_KMEM(kt) kmem_of(kt)
-#pragma unroll
-  for (int s = 0; s < DMA_NSTAGE - 1; s++)
-    if (s < nt) dma_issue<TILE_A_B, TILE_B_B, NIA, NIB>(da, db, g, smem, wave, kt0 + s, CROG_KMEM(kt0 + s), s);
   const bool do_asum = p.a_sum != nullptr && tn == 0 && wc == 0;   // block- and wave-uniform
   float asum[WM];
 #pragma unroll
   for (int i = 0; i < WM; i++) asum[i] = 0.f;
+  constexpr int PER_TILE = NIA + NIB;   // DMA instructions per k-tile and wave
+  if constexpr (BK / 16 == 2 && CROG_GEMM_PIPELINED) {
+    // Software-pipelined form (two 16-deep MFMA steps per k-tile): the wait for the NEXT tile's DMA, the workgroup barrier, the
+    // address arithmetic of the next DMA issue and the first LDS reads of the next tile all sit between the two MFMA groups of
+    // the CURRENT tile, so they run while this wave's own MFMAs execute instead of in front of them.  All DEPTH stages are in
+    // flight: tile t + DEPTH is requested into tile t's stage as soon as every wave has its second-step fragments in registers.
+#pragma unroll
+    for (int s = 0; s < DMA_NSTAGE; s++)
+      if (s < nt) dma_issue<TILE_A_B, TILE_B_B, NIA, NIB>(da, db, g, smem, wave, kt0 + s, CROG_KMEM(kt0 + s), s);
+    {
+      const int behind = min(DMA_NSTAGE - 1, nt - 1);
+      if (behind >= 2) wait_vmcnt<2 * PER_TILE>();
+      else if (behind == 1) wait_vmcnt<PER_TILE>();
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    Frag<T> fa0[WM], fb0[WN], fa1[WM], fb1[WN];
+#pragma unroll
+    for (int i = 0; i < WM; i++) fa0[i] = OA::frag(smem, (wr * WM + i) * 32, 0, lane);
+#pragma unroll
+    for (int j = 0; j < WN; j++) fb0[j] = OB::frag(smem + TILE_A_B, (wc * WN + j) * 32, 0, lane);
+    int stage = 0;
+    for (int t = 0; t < nt; t++) {
+      const char* at = smem + stage * DMA_STAGE_B;
+      const char* bt = at + TILE_A_B;
+#pragma unroll
+      for (int i = 0; i < WM; i++) fa1[i] = OA::frag(at, (wr * WM + i) * 32, 1, lane);
+#pragma unroll
+      for (int j = 0; j < WN; j++) fb1[j] = OB::frag(bt, (wc * WN + j) * 32, 1, lane);
+      if (do_asum) {
+#pragma unroll
+        for (int i = 0; i < WM; i++) asum[i] += frag_sum(fa0[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++) mma16(fa0[i], fb0[j], acc[i][j]);
+      const int nstage = stage == DMA_NSTAGE - 1 ? 0 : stage + 1;
+      if (t + 1 < nt) {
+        // this wave's reads of tile t are complete (its stage is about to be handed back to the DMA engine by any wave)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int behind = min(DMA_NSTAGE - 2, nt - 2 - t);   // tiles requested after tile t + 1
+        if (behind >= 1) wait_vmcnt<PER_TILE>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + DMA_NSTAGE < nt) {
+          const int tq = t + DMA_NSTAGE;
+          dma_issue<TILE_A_B, TILE_B_B, NIA, NIB>(da, db, g, smem, wave, kt0 + tq, CROG_KMEM(kt0 + tq), stage);
+        }
+        const char* an = smem + nstage * DMA_STAGE_B;
+#pragma unroll
+        for (int i = 0; i < WM; i++) fa0[i] = OA::frag(an, (wr * WM + i) * 32, 0, lane);
+#pragma unroll
+        for (int j = 0; j < WN; j++) fb0[j] = OB::frag(an + TILE_A_B, (wc * WN + j) * 32, 0, lane);
+      }
+      if (do_asum) {
+#pragma unroll
+        for (int i = 0; i < WM; i++) asum[i] += frag_sum(fa1[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++) mma16(fa1[i], fb1[j], acc[i][j]);
+      stage = nstage;
+    }
+  } else {
+#pragma unroll
+  for (int s = 0; s < DMA_NSTAGE - 1; s++)
+    if (s < nt) dma_issue<TILE_A_B, TILE_B_B, NIA, NIB>(da, db, g, smem, wave, kt0 + s, CROG_KMEM(kt0 + s), s);
   int stage = 0;
   for (int t = 0; t < nt; t++) {
     // k-tiles still allowed in flight behind tile t: min(depth - 2, tiles left); 4 DMA instructions per tile and wave
@@ -974,6 +1044,7 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 25
         for (int j = 0; j < WN; j++) mma16(fa[i], fb[j], acc[i][j]);
     }
     stage = stage == DMA_NSTAGE - 1 ? 0 : stage + 1;
+  }
   }
 #undef CROG_KMEM
   if (do_asum) flush_a_sum<WM>(asum, p.a_sum, m0 + wr * WM * 32, p.M, lane);
