@@ -259,8 +259,8 @@ def test_text_tower_hip_graph_replays_match_eager(monkeypatch):
     # model's 1x1 / 2x2 BatchNorm layers amplify their ordering noise to ~2e-4 on the logits and ~1 % on the stem gradients
     for (p0, l0, g0), (p1, l1, g1), (p2, l2, g2) in zip(eager, again, graphed):
         assert err(p0, p2) < max(1e-3, 4 * err(p0, p1)) and abs(l0 - l2) < 1e-4
-        noise = (g0 - g1).abs().max().item()
-        assert (g0 - g2).abs().max().item() <= 4 * noise + 1e-4 * g0.abs().max().item()
+        rel = lambda a, b: ((a - b).norm() / a.norm()).item()    # max-norm differences of the amplified noise are heavy-tailed
+        assert rel(g0, g2) <= max(4 * rel(g0, g1), 2e-2)
     assert err(graphed[0][0], g["pred_ins"]) < 1e-3
 
 
