@@ -335,6 +335,65 @@ __device__ inline void eval_bicubic4(const float* __restrict__ plane, int h, int
     out[e] = acc;
   }
 }
+// Tiled form for the usual 4x enlargement: a block produces 16 rows x 64 columns of one plane; the few input rows / columns those
+// outputs touch (8 x 20 for 104 -> 416) are staged in LDS once, with the sigmoid already applied (once per input value instead of
+// once per tap: 16x fewer exp / rcp), and every thread gathers its 4 x 16 taps from LDS instead of global memory.
+constexpr int EV_TR = 12, EV_TC = 28;   // LDS tile bounds (input rows x columns); the launcher checks that the scale fits
+__global__ void __launch_bounds__(NT) eval_maps_tiled_kernel(const float* __restrict__ x, int G, int h, int w, unsigned sigmoid_mask,
+                                                             float* __restrict__ y, int H, int W, float sy, float sx) {
+#pragma clang fp contract(off)   // source coordinates as ATen forms them (see eval_bicubic4)
+  __shared__ float tile[EV_TR][EV_TC + 1];
+  const int pl = blockIdx.z, oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 64;
+  const int oy1 = min(oy0 + 15, H - 1), ox1 = min(ox0 + 63, W - 1);
+  const int ylo = min(max((int)floorf(sy * (float)oy0) - 1, 0), h - 1), yhi = min(max((int)floorf(sy * (float)oy1) + 2, 0), h - 1);
+  const int xlo = min(max((int)floorf(sx * (float)ox0) - 1, 0), w - 1), xhi = min(max((int)floorf(sx * (float)ox1) + 2, 0), w - 1);
+  const int tr = yhi - ylo + 1, tc = xhi - xlo + 1;
+  const bool sig = (sigmoid_mask >> (pl % G)) & 1u;
+  const float* plane = x + (long)pl * h * w;
+  for (int i = threadIdx.x; i < tr * tc; i += NT) {
+    const int r = i / tc, c = i - r * tc;
+    const float v = plane[(long)(ylo + r) * w + xlo + c];
+    tile[r][c] = sig ? 1.f / (1.f + __expf(-v)) : v;
+  }
+  __syncthreads();
+  const int oy = oy0 + (int)(threadIdx.x >> 4), oxq = ox0 + (int)(threadIdx.x & 15) * 4;
+  if (oy >= H || oxq >= W) return;
+  const float fy = sy * (float)oy;
+  const int y0 = (int)floorf(fy);
+  float wy[4];
+  cubic_taps(fy - y0, wy);
+  int rr[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) rr[j] = min(max(y0 - 1 + j, 0), h - 1) - ylo;
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int ox = min(oxq + e, W - 1);
+    const float fx = sx * (float)ox;
+    const int x0 = (int)floorf(fx);
+    float wx[4];
+    cubic_taps(fx - x0, wx);
+    int cc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) cc[i] = min(max(x0 - 1 + i, 0), w - 1) - xlo;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float r = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) r += wx[i] * tile[rr[j]][cc[i]];
+      acc += wy[j] * r;
+    }
+    o[e] = acc;
+  }
+  float* dst = y + ((long)pl * H + oy) * W + oxq;
+  if (oxq + 4 <= W && (W & 3) == 0) {
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+    for (int e = 0; e < 4 && oxq + e < W; e++) dst[e] = o[e];
+  }
+}
+
 __global__ void __launch_bounds__(NT) eval_maps_kernel(const float* __restrict__ x, int planes, int G, int h, int w, unsigned sigmoid_mask,
                                                        float* __restrict__ y, int H, int W, float sy, float sx) {
   const int wq = (W + 3) / 4;
@@ -414,7 +473,14 @@ extern "C" int crog_eval_maps(const float* x, int B, int G, int h, int w, int si
   if (B == 0) return CROG_OK;
   // align_corners=True source scale (n_in - 1) / (n_out - 1), formed once on the host in fp32 as ATen does
   const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-  LAUNCH(eval_maps_kernel, (long)B * G * H * ((W + 3) / 4), s, x, B * G, G, h, w, (unsigned)sigmoid_mask, y, H, W, sy, sx);
+  // the LDS-tiled form needs the inputs of a 16 x 64 output tile to fit EV_TR x EV_TC (any enlargement >= ~2.7x does)
+  const bool tiled = (int)(sy * 15.f) + 5 <= EV_TR && (int)(sx * 63.f) + 5 <= EV_TC && (long)B * G <= 65535;
+  if (tiled) {
+    hipLaunchKernelGGL(eval_maps_tiled_kernel, dim3(cdiv(W, 64), cdiv(H, 16), B * G), dim3(NT), 0, (hipStream_t)s, x, G, h, w,
+                       (unsigned)sigmoid_mask, y, H, W, sy, sx);
+  } else {
+    LAUNCH(eval_maps_kernel, (long)B * G * H * ((W + 3) / 4), s, x, B * G, G, h, w, (unsigned)sigmoid_mask, y, H, W, sy, sx);
+  }
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
