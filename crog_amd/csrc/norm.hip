@@ -195,7 +195,7 @@ __device__ inline void ld_pairs(const float* __restrict__ p, float (&a)[VEC], fl
 template <typename T>
 __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ z, long ldz, const float* __restrict__ scale_shift,
                                                       const T* __restrict__ res, long ldr, int relu, T* __restrict__ y,
-                                                      long ldy, long M, int C) {
+                                                      long ldy, long M, int C, unsigned char* __restrict__ relu_mask) {
   constexpr int VEC = Elem<T>::VEC;
   const int cvec = C / VEC;
   const long total = M * cvec;
@@ -215,6 +215,12 @@ __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ z, l
       for (int e = 0; e < VEC; e++) f[e] += Elem<T>::to_f(rv.v[e]);
     }
     if (relu) {
+      if (relu_mask) {   // one byte per 16-byte vector: bit e = (pre-activation e > 0); backward reads this instead of y
+        unsigned bits = 0;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) bits |= (f[e] > 0.f ? 1u : 0u) << e;
+        relu_mask[i] = (unsigned char)bits;
+      }
 #pragma unroll
       for (int e = 0; e < VEC; e++) f[e] = fmaxf(f[e], 0.f);
     }
@@ -234,7 +240,7 @@ __global__ void __launch_bounds__(NT) bn_apply_stats_kernel(const T* __restrict_
                                                             float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                                                             float eps, float* __restrict__ scale_shift, float* __restrict__ mean_invstd,
                                                             const T* __restrict__ res, long ldr, int relu, T* __restrict__ y, long ldy, long M,
-                                                            int C) {
+                                                            int C, unsigned char* __restrict__ relu_mask) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) float ss[];   // [C][2]
   for (int c = threadIdx.x; c < C; c += NT) {
@@ -279,6 +285,12 @@ __global__ void __launch_bounds__(NT) bn_apply_stats_kernel(const T* __restrict_
       for (int e = 0; e < VEC; e++) f[e] += Elem<T>::to_f(rv.v[e]);
     }
     if (relu) {
+      if (relu_mask) {   // one byte per 16-byte vector: bit e = (pre-activation e > 0); backward reads this instead of y
+        unsigned bits = 0;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) bits |= (f[e] > 0.f ? 1u : 0u) << e;
+        relu_mask[i] = (unsigned char)bits;
+      }
 #pragma unroll
       for (int e = 0; e < VEC; e++) f[e] = fmaxf(f[e], 0.f);
     }
@@ -293,7 +305,7 @@ template <typename T>
 __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
                                                             const T* __restrict__ z, long ldz, const float* __restrict__ mean_invstd,
                                                             const float* __restrict__ relu_ss, long M, int C, int rows_per_block,
-                                                            float* __restrict__ partial, int replicas) {
+                                                            float* __restrict__ partial, int replicas, const unsigned char* __restrict__ relu_mask) {
   constexpr int VEC = Elem<T>::VEC;
   __shared__ float red[NT][2 * VEC + 1];
   const int cvec = C / VEC;
@@ -319,6 +331,11 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
       if (y) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) gf[e] = Elem<T>::to_f(yy.v[e]) > 0.f ? gf[e] : 0.f;
+      }
+      if (relu_mask) {   // residual layers: the forward's bit mask (1/16 of y's bytes)
+        const unsigned bits = relu_mask[r * cvec + cg + tx];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) gf[e] = ((bits >> e) & 1u) ? gf[e] : 0.f;
       }
       if (relu_ss) {   // ReLU mask recomputed from z (no residual): y is not read
 #pragma unroll
@@ -378,7 +395,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
                                                           const float* __restrict__ gamma, const float* __restrict__ sums, float count,
                                                           const float* __restrict__ relu_ss, T* __restrict__ dz, long lddz, T* __restrict__ dres,
                                                           long lddres, long M, int C, int sum_rows, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta) {
+                                                          float* __restrict__ dbeta, const unsigned char* __restrict__ relu_mask) {
   constexpr int VEC = Elem<T>::VEC;
   // sum_rows > 0: `sums` is [sum_rows][C][2] (atomic replicas of bn_bwd_partial, or the all-reduced totals): every block adds the
   // rows up into LDS once; block 0 also stores the parameter gradients (dbeta = sum g, dgamma = sum g*zhat) when asked to.
@@ -424,6 +441,11 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
     if (y) {
 #pragma unroll
       for (int e = 0; e < VEC; e++) gf[e] = Elem<T>::to_f(yy.v[e]) > 0.f ? gf[e] : 0.f;
+    }
+    if (relu_mask) {
+      const unsigned bits = relu_mask[i];
+#pragma unroll
+      for (int e = 0; e < VEC; e++) gf[e] = ((bits >> e) & 1u) ? gf[e] : 0.f;
     }
     if (relu_ss) {
       float rsc[VEC], rsh[VEC];
@@ -950,12 +972,12 @@ extern "C" int crog_bn_eval_scale(const float* gamma, const float* beta, const f
 }
 
 extern "C" int crog_bn_apply(int dtype, const void* z, int64_t ldz, const float* scale_shift, const void* res, int64_t ldr,
-                             int relu, void* y, int64_t ldy, int64_t M, int C, crog_stream_t stream) {
+                             int relu, void* y, int64_t ldy, int64_t M, int C, void* relu_mask, crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0 && ldz % vec == 0 && ldy % vec == 0 && (!res || ldr % vec == 0), "bn_apply: C/ld must be multiples of %d", vec);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(stream_grid(M * (C / vec))), dim3(NT), 0, (hipStream_t)stream,
                                        (const T*)z, (long)ldz, scale_shift, (const T*)res, (long)ldr, relu, (T*)y, (long)ldy,
-                                       (long)M, C));
+                                       (long)M, C, (unsigned char*)relu_mask));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
@@ -963,28 +985,28 @@ extern "C" int crog_bn_apply(int dtype, const void* z, int64_t ldz, const float*
 extern "C" int crog_bn_apply_stats(int dtype, const void* z, int64_t ldz, const float* sums, int replicas, float count, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                    float* scale_shift, float* mean_invstd, const void* res, int64_t ldr, int relu, void* y, int64_t ldy,
-                                   int64_t M, int C, crog_stream_t stream) {
+                                   int64_t M, int C, void* relu_mask, crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0 && ldz % vec == 0 && ldy % vec == 0 && (!res || ldr % vec == 0), "bn_apply_stats: C/ld must be multiples of %d", vec);
   CROG_CHECK_ARG(sums && replicas >= 1 && count > 0 && scale_shift && mean_invstd && C <= 8192, "bn_apply_stats: bad arguments");
   const int grid = std::min(stream_grid(M * (C / vec)), 1024);   // every block re-derives the C scale/shift pairs: keep the grid modest
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_stats_kernel<T>), dim3(grid), dim3(NT), (size_t)C * 2 * sizeof(float), (hipStream_t)stream,
                                        (const T*)z, (long)ldz, sums, replicas, count, gamma, beta, running_mean, running_var, momentum, eps,
-                                       scale_shift, mean_invstd, (const T*)res, (long)ldr, relu, (T*)y, (long)ldy, (long)M, C));
+                                       scale_shift, mean_invstd, (const T*)res, (long)ldr, relu, (T*)y, (long)ldy, (long)M, C, (unsigned char*)relu_mask));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
 
 extern "C" int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
                                    const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C, int rows_per_block,
-                                   float* partial, int replicas, crog_stream_t stream) {
+                                   float* partial, int replicas, const void* relu_mask, crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0 && pow2(C / vec), "bn_bwd_partial: C/vec must be a power of two (C=%d)", C);
   CROG_CHECK_ARG(replicas >= 0, "bn_bwd_partial: replicas must be >= 0");
   const int blocks = cdiv(M, rows_per_block);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dy,
                                        (long)lddy, (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, relu_scale_shift, (long)M, C,
-                                       rows_per_block, partial, replicas));
+                                       rows_per_block, partial, replicas, (const unsigned char*)relu_mask));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
@@ -992,7 +1014,7 @@ extern "C" int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, cons
 extern "C" int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
                                  const float* mean_invstd, const float* gamma, const float* sums, float count,
                                  const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres, int64_t M, int C,
-                                 int sum_rows, float* dgamma, float* dbeta, crog_stream_t stream) {
+                                 int sum_rows, float* dgamma, float* dbeta, const void* relu_mask, crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0, "bn_bwd_apply: C %% %d != 0", vec);
   CROG_CHECK_ARG(sum_rows >= 0 && C <= 8192 && (!dgamma || (dbeta && sum_rows > 0)), "bn_bwd_apply: bad sum_rows / parameter-gradient outputs");
@@ -1001,7 +1023,7 @@ extern "C" int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const 
   const size_t lds = sum_rows > 0 ? (size_t)C * 2 * sizeof(float) : 0;
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(NT), lds, (hipStream_t)stream, (const T*)dy, (long)lddy,
                                        (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, gamma, sums, count, relu_scale_shift,
-                                       (T*)dz, (long)lddz, (T*)dres, (long)lddres, (long)M, C, sum_rows, dgamma, dbeta));
+                                       (T*)dz, (long)lddz, (T*)dres, (long)lddres, (long)M, C, sum_rows, dgamma, dbeta, (const unsigned char*)relu_mask));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -44,6 +44,7 @@ FUSED_REDUCE_MAX_PARTS = int(_os.environ.get("CROG_FUSED_REDUCE_MAX_PARTS", "256
 FLASH_ATTN = _os.environ.get("CROG_FLASH_ATTN", "1") != "0"     # fused attention kernels (csrc/attn.hip) where they apply
 FLASH_MIN_KEYS = 64
 BN_ATOMIC_STATS = _os.environ.get("CROG_BN_ATOMIC_STATS", "1") != "0"   # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize
+RELU_BITMASK = _os.environ.get("CROG_RELU_BITMASK", "1") != "0"   # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
 BN_BWD_ATOMIC = _os.environ.get("CROG_BN_BWD_ATOMIC", "0") == "1"   # backward partial sums through atomics: measured slower
 DGRAD_T = _os.environ.get("CROG_DGRAD_T", "1") != "0"          # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
 FUSED_HEAD = _os.environ.get("CROG_FUSED_HEAD", "1") != "0"    # fold vis.4 into the dynamic head (no groups*C-channel map)
@@ -216,7 +217,9 @@ class ConvBnAct(Function):
             if training:
                 slabs = K.stat_tiles(M)
                 comm_on = RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force)
-                if BN_ATOMIC_STATS:
+                if BN_ATOMIC_STATS and dtype != torch.float32:
+                    # (fp32 is the parity mode: it keeps the per-tile slab + ordered reduction, so the forward is bit-reproducible
+                    # run to run; atomic accumulation order jitters the statistics by ~1e-7, which tiny BatchNorm layers amplify)
                     # statistics accumulate atomically into R pre-zeroed [C][2] rows in the GEMM epilogue and are finalised
                     # inside bn_apply: GEMM -> (all-reduce of all R rows) -> apply, no reduction / finalize launches in between
                     stat_R = stat_replicas(slabs, C)
@@ -237,13 +240,15 @@ class ConvBnAct(Function):
         count = float(M)
         y = _dest(out) if out is not None else torch.empty(lead + (C,), device=dev, dtype=dtype)
         applied = False
+        # residual + ReLU layers: backward needs sign(y); one bit per element is kept instead of re-reading y twice
+        rmask = K.relu_mask_like(y) if (RELU_BITMASK and training and relu and res is not None) else None
         if training and stat_R > 0:
             mi = torch.empty(C, 2, device=dev, dtype=torch.float32)
             if RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force):
                 RT.comm.all_reduce_sum(stats)
                 count = float(M * RT.comm.world_size)
             K.bn_apply_stats(z, stats, stat_R, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum,
-                             bn.eps, ss, mi, res, relu, y)
+                             bn.eps, ss, mi, res, relu, y, relu_mask=rmask)
             applied = True
         elif training:
             if stats is None:
@@ -268,7 +273,8 @@ class ConvBnAct(Function):
         else:
             K.bn_eval_scale(bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.eps, C, ss)
         if not applied:
-            K.bn_apply(z, ss, res, relu, y)
+            K.bn_apply(z, ss, res, relu, y, relu_mask=rmask)
+        ctx.rmask = rmask
         ctx.cfg = (ksize, relu, training, w, bn, wpad, count, cin, C, lead, dtype)
         ctx.has_res = res is not None
         ctx.relu_ss = ss if (relu and res is None and training) else None   # ReLU mask can be recomputed from z: y is not re-read in backward
@@ -293,7 +299,8 @@ class ConvBnAct(Function):
         rpb = K.bn_rows_per_block(M)
         nparts = (M + rpb - 1) // rpb
         relu_ss = ctx.relu_ss
-        ymask = y if (relu and relu_ss is None) else None
+        rmask = ctx.rmask
+        ymask = y if (relu and relu_ss is None and rmask is None) else None
         comm_on = RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force)
         dz = torch.empty(lead + (C,), device=dev, dtype=dtype)
         dres = torch.empty(lead + (C,), device=dev, dtype=dtype) if ctx.has_res else None
@@ -302,20 +309,20 @@ class ConvBnAct(Function):
             # Measured SLOWER (every block fires 2C atomics at the same few KB: 33 -> 115 us per launch), kept as a switch only.
             R = 1 if (comm_on or nparts <= 512) else 4
             sums = RT.zeros(R * 2 * C, dev)
-            K.bn_bwd_partial(dy, ymask, z, mi, rpb, sums, relu_ss, replicas=R)
+            K.bn_bwd_partial(dy, ymask, z, mi, rpb, sums, relu_ss, replicas=R, relu_mask=rmask)
             if comm_on:
                 K.split_pairs(sums, C, bn.beta.grad(), bn.gamma.grad())   # parameter gradients stay LOCAL sums (DDP averages them later)
                 RT.comm.all_reduce_sum(sums[:2 * C])
-                K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=1)
+                K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=1, relu_mask=rmask)
             else:
                 K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=R,
-                               dgamma=bn.gamma.grad(), dbeta=bn.beta.grad())
+                               dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=rmask)
             bn.beta.done()
             bn.gamma.done()
         elif BN_ATOMIC_STATS:
             # per-block slab -> one reduction launch -> apply kernel that stages the totals in LDS and (block 0) stores dbeta / dgamma
             partial = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
-            K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial, relu_ss)
+            K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial, relu_ss, relu_mask=rmask)
             fused = nparts <= FUSED_REDUCE_MAX_PARTS
             sums = torch.empty(2 * C, device=dev, dtype=torch.float32) if fused else RT.zeros(2 * C, dev)
             local_grads = fused or comm_on      # the parameter gradients are LOCAL sums: written before the all-reduce
@@ -328,12 +335,12 @@ class ConvBnAct(Function):
             if comm_on:
                 RT.comm.all_reduce_sum(sums)
             K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=1,
-                           dgamma=None if local_grads else bn.gamma.grad(), dbeta=None if local_grads else bn.beta.grad())
+                           dgamma=None if local_grads else bn.gamma.grad(), dbeta=None if local_grads else bn.beta.grad(), relu_mask=rmask)
             bn.beta.done()
             bn.gamma.done()
         else:
             partial = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
-            K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial, relu_ss)
+            K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial, relu_ss, relu_mask=rmask)
             sums = RT.zeros(2 * C, dev).view(C, 2) if nparts > FUSED_REDUCE_MAX_PARTS else torch.empty(C, 2, device=dev, dtype=torch.float32)
             # local sums: (sum g -> dbeta, sum g*xhat -> dgamma) and the pair vector for the second pass
             if nparts <= FUSED_REDUCE_MAX_PARTS:
@@ -345,7 +352,7 @@ class ConvBnAct(Function):
             bn.gamma.done()
             if comm_on:
                 RT.comm.all_reduce_sum(sums)
-            K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss)
+            K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, relu_mask=rmask)
         grad_slot, res_slot = ctx.slots
         if res_slot is not None and dres is not None:   # hand the identity's gradient to the block's first convolution
             res_slot.t = dres

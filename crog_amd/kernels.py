@@ -200,27 +200,34 @@ def bn_eval_scale(gamma, beta, running_mean, running_var, eps, C, scale_shift):
                                    ptr(scale_shift), stream()), "bn_eval_scale")
 
 
-def bn_apply(z, scale_shift, res, relu: bool, y):
+def relu_mask_like(y: torch.Tensor) -> torch.Tensor:
+    """uint8 [M, C / vec]: one byte of sign bits per 16-byte vector of y (vec = 8 for bf16, 4 for fp32)."""
+    M, C, _ = mat(y)
+    return torch.empty(M, C // (8 if y.dtype == torch.bfloat16 else 4), device=y.device, dtype=torch.uint8)
+
+
+def bn_apply(z, scale_shift, res, relu: bool, y, relu_mask=None):
     M, C, ldz = mat(z)
     _, _, ldy = mat(y)
     ldr = mat(res)[2] if res is not None else 0
-    check(lib().crog_bn_apply(dcode(z), ptr(z), ldz, ptr(scale_shift), ptr(res), ldr, int(relu), ptr(y), ldy, M, C, stream()),
-          "bn_apply")
+    check(lib().crog_bn_apply(dcode(z), ptr(z), ldz, ptr(scale_shift), ptr(res), ldr, int(relu), ptr(y), ldy, M, C, ptr(relu_mask),
+                              stream()), "bn_apply")
 
 
-def bn_apply_stats(z, sums, replicas, count, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, mean_invstd, res, relu, y):
+def bn_apply_stats(z, sums, replicas, count, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, mean_invstd, res, relu, y,
+                   relu_mask=None):
     M, C, ldz = mat(z)
     ldr = mat(res)[2] if res is not None else 0
     check(lib().crog_bn_apply_stats(dcode(z), ptr(z), ldz, ptr(sums), replicas, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
                                     ptr(running_var), float(momentum), float(eps), ptr(scale_shift), ptr(mean_invstd), ptr(res), ldr,
-                                    int(relu), ptr(y), mat(y)[2], M, C, stream()), "bn_apply_stats")
+                                    int(relu), ptr(y), mat(y)[2], M, C, ptr(relu_mask), stream()), "bn_apply_stats")
 
 
-def bn_bwd_partial(dy, y, z, mean_invstd, rows_per_block, partial, relu_ss=None, replicas=0):
+def bn_bwd_partial(dy, y, z, mean_invstd, rows_per_block, partial, relu_ss=None, replicas=0, relu_mask=None):
     M, C, lddy = mat(dy)
     ldy = mat(y)[2] if y is not None else 0
     check(lib().crog_bn_bwd_partial(dcode(dy), ptr(dy), lddy, ptr(y), ldy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(relu_ss), M, C,
-                                    rows_per_block, ptr(partial), replicas, stream()), "bn_bwd_partial")
+                                    rows_per_block, ptr(partial), replicas, ptr(relu_mask), stream()), "bn_bwd_partial")
 
 
 def bn_reduce_finalize(partial, nparts, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale_shift, mean_invstd):
@@ -232,13 +239,13 @@ def reduce_split(partial, nparts, C, sums, a, b):
     check(lib().crog_reduce_split(ptr(partial), nparts, C, ptr(sums), ptr(a), ptr(b), stream()), "reduce_split")
 
 
-def bn_bwd_apply(dy, y, z, mean_invstd, gamma, sums, count, dz, dres, relu_ss=None, sum_rows=0, dgamma=None, dbeta=None):
+def bn_bwd_apply(dy, y, z, mean_invstd, gamma, sums, count, dz, dres, relu_ss=None, sum_rows=0, dgamma=None, dbeta=None, relu_mask=None):
     M, C, lddy = mat(dy)
     ldy = mat(y)[2] if y is not None else 0
     lddres = mat(dres)[2] if dres is not None else 0
     check(lib().crog_bn_bwd_apply(dcode(dy), ptr(dy), lddy, ptr(y), ldy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(gamma),
                                   ptr(sums), float(count), ptr(relu_ss), ptr(dz), mat(dz)[2], ptr(dres), lddres, M, C, sum_rows,
-                                  ptr(dgamma), ptr(dbeta), stream()), "bn_bwd_apply")
+                                  ptr(dgamma), ptr(dbeta), ptr(relu_mask), stream()), "bn_bwd_apply")
 
 
 # --------------------------------------------------------------------------------------------

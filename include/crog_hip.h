@@ -126,7 +126,7 @@ int crog_bn_partial_stats(int dtype, const void* x, int64_t M, int C, int64_t ld
 int crog_bn_apply_stats(int dtype, const void* z, int64_t ldz, const float* sums, int replicas, float count,
                         const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                         float eps, float* scale_shift, float* mean_invstd, const void* res, int64_t ldr, int relu, void* y,
-                        int64_t ldy, int64_t M, int C, crog_stream_t stream);
+                        int64_t ldy, int64_t M, int C, void* relu_mask, crog_stream_t stream);
 int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, int sums_is_zero, crog_stream_t stream);
 int crog_split_pairs(const float* sums, int C, float* a, float* b, crog_stream_t stream);
 int crog_bn_finalize(const float* sums, float count, const float* gamma, const float* beta,
@@ -135,14 +135,17 @@ int crog_bn_finalize(const float* sums, float count, const float* gamma, const f
 int crog_bn_eval_scale(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, int C, float* scale_shift,
                        crog_stream_t stream);
-/* y = [relu](z*scale + shift [+ res])  — bn + residual add + ReLU of Bottleneck (clip.py:47-56) */
+/* y = [relu](z*scale + shift [+ res])  — bn + residual add + ReLU of Bottleneck (clip.py:47-56).
+ * relu_mask (optional, with relu): one byte per 16-byte vector of y, [M][C / (16 / sizeof(element))], bit e = element e > 0 —
+ * what `out = self.relu(out)` (clip.py:56) keeps for backward, at 1/16 of y's bytes; crog_bn_apply_stats takes the same. */
 int crog_bn_apply(int dtype, const void* z, int64_t ldz, const float* scale_shift, const void* res,
-                  int64_t ldr, int relu, void* y, int64_t ldy, int64_t M, int C, crog_stream_t stream);
-/* g = dy * mask;  mask = (y > 0) when y != NULL, or (z*scale+shift > 0) when relu_scale_shift != NULL (ReLU without a
- * residual: the output is not re-read), else 1;  partial[block][C][2] = (sum g, sum g*xhat) */
+                  int64_t ldr, int relu, void* y, int64_t ldy, int64_t M, int C, void* relu_mask, crog_stream_t stream);
+/* g = dy * mask;  mask = (y > 0) when y != NULL, the forward's bit mask when relu_mask != NULL, or (z*scale+shift > 0) when
+ * relu_scale_shift != NULL (ReLU without a residual: the output is not re-read), else 1;
+ * partial[block][C][2] = (sum g, sum g*xhat) */
 int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
                         int64_t ldz, const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C,
-                        int rows_per_block, float* partial, int replicas, crog_stream_t stream);
+                        int rows_per_block, float* partial, int replicas, const void* relu_mask, crog_stream_t stream);
 /* dz = gamma*invstd*(g - sums.g/count - xhat*sums.gx/count);  dres = g when dres != NULL.
  * replicas (partial) / sum_rows (apply) = 0: `partial` is the per-block slab [blocks][C][2] and `sums` the reduced [C][2].
  * replicas = R > 0: the partial kernel adds atomically into a PRE-ZEROED [R][C][2]; the apply kernel is handed the same buffer
@@ -150,7 +153,8 @@ int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, 
 int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
                       int64_t ldz, const float* mean_invstd, const float* gamma, const float* sums,
                       float count, const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres,
-                      int64_t M, int C, int sum_rows, float* dgamma, float* dbeta, crog_stream_t stream);
+                      int64_t M, int C, int sum_rows, float* dgamma, float* dbeta, const void* relu_mask,
+                      crog_stream_t stream);
 /* single-replica fast paths: slab [nparts][C][2] -> (reduce + finalize) / (reduce + split into two vectors) in one launch */
 int crog_bn_reduce_finalize(const float* partial, int nparts, float count, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int C,

@@ -224,6 +224,20 @@ def test_batchnorm_train_fwd_bwd(K, dt):
     assert torch.equal(dbeta, sums[:, 0]) and torch.equal(dgamma, sums[:, 1])
     dz, dres = torch.empty_like(z), torch.empty_like(z)
     K.bn_bwd_apply(dy, y, z, mi, gamma, sums, M, dz, dres)
+    # ReLU sign bits written by the forward instead of re-reading y: same partial sums, dz and dres, bit for bit
+    vec = 8 if dt == torch.bfloat16 else 4
+    bits = K.relu_mask_like(y)
+    y_b = torch.empty_like(z)
+    K.bn_apply(z, ss, res, True, y_b, relu_mask=bits)
+    assert torch.equal(y_b, y) and bits.shape == (M, C // vec)
+    want = ((y.float().view(M, C // vec, vec) > 0).to(torch.int32) << torch.arange(vec, device="cuda", dtype=torch.int32)).sum(-1)
+    assert torch.equal(bits.to(torch.int32), want)
+    part_b = torch.empty_like(partial)
+    K.bn_bwd_partial(dy, None, z, mi, rpb, part_b, relu_mask=bits)
+    assert torch.equal(part_b, partial)
+    dz_b, dres_b = torch.empty_like(z), torch.empty_like(z)
+    K.bn_bwd_apply(dy, None, z, mi, gamma, sums, M, dz_b, dres_b, relu_mask=bits)
+    assert torch.equal(dz_b, dz) and torch.equal(dres_b, dres)
     # atomic replicas + in-kernel totals (no reduction launch): same dz / dres, parameter gradients stored by the apply kernel
     for R in (1, 4):
         acc = torch.zeros(R, C, 2, device="cuda")
