@@ -65,6 +65,49 @@ __global__ void __launch_bounds__(NT) head_stencil_fwd_kernel(const float* __res
     out[i] = acc;
   }
 }
+// Same stencil, row-band form: a block owns HS_R output rows of one sample; the t rows it needs (HS_R + 2, taps 0..8 of every
+// head) are read ONCE as whole 48-byte runs and parked in LDS, and the nine taps of an output come from LDS.  The gather form
+// above pulls a different 64-byte sector for every 4 bytes it uses (measured 1.8 GB of traffic per launch for a 110 MB tensor).
+constexpr int HS_R = 2;
+__global__ void __launch_bounds__(NT) head_stencil_fwd_rows_kernel(const float* __restrict__ t, const float* __restrict__ word, long ldw, int bias_col,
+                                                                   const float* __restrict__ tbias, float* __restrict__ out, int heads, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float tl[];   // [(HS_R + 2)][W][heads * 9]
+  const int b = blockIdx.y, y0 = blockIdx.x * HS_R;
+  const long P = (long)H * W;
+  const int hp = heads * 9;
+  const int npair = (HS_R + 2) * W * heads;
+  for (int j = threadIdx.x; j < npair; j += NT) {
+    const int h = j % heads, px = (j / heads) % W, r = j / (heads * W);
+    const int sy = y0 - 1 + r;
+    if (sy < 0 || sy >= H) continue;
+    const float4* src = reinterpret_cast<const float4*>(t + ((b * P + (long)sy * W + px) * heads + h) * 16);
+    const float4 v0 = src[0], v1 = src[1];
+    const float v8 = reinterpret_cast<const float*>(src)[8];
+    float* dst = tl + ((long)r * W + px) * hp + h * 9;
+    dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w;
+    dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
+    dst[8] = v8;
+  }
+  __syncthreads();
+  const float bias = word[(long)b * ldw + bias_col];
+  const int nout = HS_R * W * heads;
+  for (int o = threadIdx.x; o < nout; o += NT) {
+    const int x = o % W, ry = (o / W) % HS_R, h = o / (W * HS_R);
+    const int y = y0 + ry;
+    if (y >= H) continue;
+    float acc = bias;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const int sy = y + dy, sx = x + dx;
+      if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+        acc += tl[((long)(ry + 1 + dy) * W + sx) * hp + h * 9 + tap];
+        if (tbias) acc += tbias[((long)b * heads + h) * 16 + tap];
+      }
+    }
+    out[(((long)b * heads + h) * H + y) * W + x] = acc;
+  }
+}
 // dt[((b*P + p)*heads + h)*16 + tap] = dout[b,h,p - off(tap)]
 template <typename T>
 __global__ void __launch_bounds__(NT) head_stencil_bwd_kernel(const float* __restrict__ dout, T* __restrict__ dt, int B, int heads, int H, int W) {
@@ -275,7 +318,21 @@ extern "C" int crog_head_cb_bwd(int dtype, const float* b5, const void* wpad, co
 }
 extern "C" int crog_head_stencil_fwd(const float* t, const float* word, int64_t ldw, int bias_col, const float* tbias, float* out, int B, int heads,
                                      int H, int W, crog_stream_t s) {
-  LAUNCH(head_stencil_fwd_kernel, (long)B * heads * H * W, s, t, word, (long)ldw, bias_col, tbias, out, B, heads, H, W);
+  const size_t lds = (size_t)(HS_R + 2) * W * heads * 9 * sizeof(float);
+  static int rows_form = -1;   // CROG_HEAD_STENCIL_ROWS=0: the gather form (A/B runs)
+  if (rows_form < 0) { const char* e = getenv("CROG_HEAD_STENCIL_ROWS"); rows_form = (e && e[0] == '0') ? 0 : 1; }
+  if (rows_form && lds <= 96 * 1024 && B <= 65535) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_stencil_fwd_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e != hipSuccess) { crog_set_error("head_stencil_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return CROG_ERR_LAUNCH; }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(head_stencil_fwd_rows_kernel, dim3(cdiv(H, HS_R), B), dim3(NT), lds, (hipStream_t)s, t, word, (long)ldw, bias_col, tbias, out,
+                       heads, H, W);
+  } else {
+    LAUNCH(head_stencil_fwd_kernel, (long)B * heads * H * W, s, t, word, (long)ldw, bias_col, tbias, out, B, heads, H, W);
+  }
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
