@@ -788,3 +788,26 @@ def test_eval_maps(K, shape, size, mask):
         ref[:, c] = torch.sigmoid(ref[:, c])
     ref = F.interpolate(ref, size=size, mode="bicubic", align_corners=True)
     assert (y - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_conv3_dgrad_weights(K, dt):
+    """crog_conv3_dgrad_weights: every [Cout][tap][Cin] block of the flat weight buffer -> [Cin][8 - tap][Cout], all entries in
+    one launch: tile-aligned, ragged (96 x 40), sub-vector (3 input channels: element-wise path) and untouched gaps."""
+    shapes = [(128, 64), (96, 40), (32, 3), (64, 256)]
+    offs, off = [], 8
+    for co, ci in shapes:
+        offs.append(off)
+        off += (co * 9 * ci + 7) // 8 * 8 + 16
+    total = off
+    src = rnd(total, dt=dt, seed=21)
+    dst = torch.full((total,), -7.0, device="cuda", dtype=dt)
+    table = torch.tensor([[o, co, ci] for o, (co, ci) in zip(offs, shapes)], dtype=torch.int64, device="cuda")
+    K.conv3_dgrad_weights(src, dst, table, len(shapes))
+    covered = torch.zeros(total, dtype=torch.bool, device="cuda")
+    for o, (co, ci) in zip(offs, shapes):
+        w = src[o:o + co * 9 * ci].view(co, 9, ci)
+        want = w.flip(1).permute(2, 1, 0).contiguous().view(-1)
+        assert torch.equal(dst[o:o + co * 9 * ci], want), (co, ci)
+        covered[o:o + co * 9 * ci] = True
+    assert torch.all(dst[~covered] == -7.0)
