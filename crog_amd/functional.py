@@ -95,6 +95,7 @@ class WRef:
         return self.store.G[self.off:self.off + self.rows * self.cols]
 
     def done(self):
+        self.store.g_clean = False
         if RT.reducer is not None:
             RT.reducer.mark_ready(self.param)
 

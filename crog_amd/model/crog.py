@@ -165,7 +165,7 @@ class CROG(nn.Module):
         self._ensure(dev)
         dtype = self.compute_dtype or (torch.bfloat16 if torch.is_autocast_enabled() else torch.float32)
         store = self._store
-        store.invalidate_shadow()          # parameters may have been stepped since the last forward
+        store.forward_begins()              # re-cast the bf16 shadow unless FusedAdam just wrote it
         if self.training and torch.is_grad_enabled():
             RT.join_streams()               # e.g. a previous backward's weight-gradient stream when no fused optimizer joined it
             store.relink_grads()

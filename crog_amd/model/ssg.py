@@ -249,7 +249,7 @@ class SSG(nn.Module):
             self.prepare(dev)
         dtype = dtype or self.compute_dtype or (torch.bfloat16 if torch.is_autocast_enabled() else torch.float32)
         st = self._store
-        st.invalidate_shadow()
+        st.forward_begins()
         if self.training and torch.is_grad_enabled():
             RT.join_streams()
             st.relink_grads()

@@ -73,11 +73,17 @@ class FusedAdam(torch.optim.Optimizer):
             self._build()
         self._step += 1
         store = self._store
+        shadow = store.S      # bf16 compute copy (None until a bf16 forward has run): refreshed by the same pass that updates P
         for group, segs in zip(self.param_groups, self._segments):
             b1, b2 = group["betas"]
             for o, n in segs:
-                K.adam_step(store.P, store.G, self.m, self.v, n, group["lr"], b1, b2, group["eps"], group["weight_decay"], self._step, off=o)
-        store.invalidate_shadow()
+                K.adam_step(store.P, store.G, self.m, self.v, n, group["lr"], b1, b2, group["eps"], group["weight_decay"], self._step,
+                            shadow=shadow, off=o)
+        if shadow is not None:
+            store.shadow_written()
+        else:
+            store.invalidate_shadow()
+        store.g_clean = False           # the gradients were consumed; the next zero_grad clears them
         return loss
 
     def zero_grad(self, set_to_none: bool = False):

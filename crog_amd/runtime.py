@@ -125,6 +125,9 @@ class Runtime:
 RT = Runtime()
 
 
+_LEGACY_SYNC = os.environ.get("CROG_LEGACY_SYNC") == "1"   # A/B: always memset G in zero_grad, always re-cast the shadow per forward
+
+
 class ParamStore:
     """Flat storage for a module's parameters."""
 
@@ -205,9 +208,30 @@ class ParamStore:
                 p.grad = g
 
     def zero_grad(self):
-        self.G.zero_()
+        """One memset of the flat gradient buffer — skipped while it is known to be clean (the training forward clears it and the
+        reference's `optimizer.zero_grad()` follows right after, crog_engine.py:77: that second 588 MB memset is redundant).  Every
+        kernel path that writes a gradient ends in WRef.done(), which marks the buffer dirty."""
+        if _LEGACY_SYNC or not getattr(self, "g_clean", False):
+            self.G.zero_()
+            self.g_clean = True
 
     def invalidate_shadow(self):
+        """The fp32 parameters changed behind the store's back (load_state_dict, a foreign optimizer, in-place edits)."""
         self.shadow_fresh = False
+        self.synced = False
         for k in self.t_fresh:
             self.t_fresh[k] = False
+
+    def forward_begins(self):
+        """Called by every forward.  FusedAdam writes the bf16 shadow itself while it updates the parameters (`shadow_written`), so
+        the first forward after its step needs no cast pass; anything else falls back to re-casting."""
+        if getattr(self, "synced", False) and not _LEGACY_SYNC:
+            self.synced = False            # consumed: a later forward without an optimizer step in between re-casts
+        else:
+            self.invalidate_shadow()
+
+    def shadow_written(self):
+        self.shadow_fresh = True
+        self.synced = True
+        for k in self.t_fresh:
+            self.t_fresh[k] = False        # the data-gradient weight layout is derived from the shadow

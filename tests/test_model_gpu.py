@@ -228,6 +228,38 @@ def test_checkpoint_wire_format_round_trips_with_torch_adam(tmp_path):
     lockstep(model2, opt2)
 
 
+def test_store_bookkeeping_across_fused_adam_steps():
+    """The flat store's two shortcuts stay sound over real steps: FusedAdam refreshes the bf16 shadow in the pass that updates the
+    fp32 parameters (no cast launch in the next forward), and zero_grad skips the memset only while the gradient buffer is clean."""
+    from crog_amd.optim import FusedAdam
+    g, meta = load_case("tiny_crog")
+    cfg = tiny_cfg()
+    model, groups = build(cfg, meta, dtype=torch.bfloat16)
+    model.train()
+    b = batch_for(cfg, meta)
+    opt = FusedAdam(groups, lr=1e-3, store=model.store)
+    st = model.store
+    for step in range(3):
+        _, _, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+        assert st.G.abs().max().item() == 0 and st.g_clean              # the forward handed backward a clean buffer
+        if step:
+            assert torch.equal(st.S, st.P.to(torch.bfloat16))          # the shadow this forward used == cast of the stepped parameters
+        opt.zero_grad()                                                 # crog_engine.py:77 — nothing to clear, nothing launched
+        assert st.g_clean
+        loss.backward()
+        torch.cuda.synchronize()
+        assert not st.g_clean and st.G.abs().max().item() > 0
+        before = st.P.clone()
+        opt.step()
+        torch.cuda.synchronize()
+        assert not torch.equal(before, st.P) and torch.equal(st.S, st.P.to(torch.bfloat16)) and st.shadow_fresh
+    # a foreign parameter edit must be announced: load_state_dict does it, and the next forward re-casts
+    model.load_state_dict(seeded_state({k: tuple(v) for k, v in meta["shapes"].items()}, seed=meta["seed"]))
+    assert not st.shadow_fresh
+    model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+    assert torch.equal(st.S, st.P.to(torch.bfloat16))
+
+
 def test_text_tower_hip_graph_replays_match_eager(monkeypatch):
     """CROG_TEXT_GRAPH=1: text tower forward/backward as hipGraph replays (crog_amd/graphs.py) == the eager launches,
     step after step (static buffers are overwritten in place), for outputs, loss and every parameter gradient."""
