@@ -45,7 +45,7 @@ FLASH_ATTN = _os.environ.get("CROG_FLASH_ATTN", "1") != "0"     # fused attentio
 FLASH_MIN_KEYS = 64
 BN_ATOMIC_STATS = _os.environ.get("CROG_BN_ATOMIC_STATS", "1") != "0"   # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize
 RELU_BITMASK = _os.environ.get("CROG_RELU_BITMASK", "1") != "0"   # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
-BN_BWD_ATOMIC = _os.environ.get("CROG_BN_BWD_ATOMIC", "0") == "1"   # backward partial sums through atomics: measured slower
+BN_BWD_ATOMIC = _os.environ.get("CROG_BN_BWD_ATOMIC", "1") != "0"   # backward partial sums through coalesced atomics (bf16, no SyncBN)
 DGRAD_T = _os.environ.get("CROG_DGRAD_T", "1") != "0"          # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
 FUSED_HEAD = _os.environ.get("CROG_FUSED_HEAD", "1") != "0"    # fold vis.4 into the dynamic head (no groups*C-channel map)
 
@@ -305,19 +305,16 @@ class ConvBnAct(Function):
         comm_on = RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force)
         dz = torch.empty(lead + (C,), device=dev, dtype=dtype)
         dres = torch.empty(lead + (C,), device=dev, dtype=dtype) if ctx.has_res else None
-        if BN_BWD_ATOMIC:
-            # (sum g, sum g*xhat) accumulate atomically into R pre-zeroed [C][2] rows and the apply kernel adds the rows up itself.
-            # Measured SLOWER (every block fires 2C atomics at the same few KB: 33 -> 115 us per launch), kept as a switch only.
-            R = 1 if (comm_on or nparts <= 512) else 4
+        if BN_BWD_ATOMIC and dtype != torch.float32 and not comm_on:
+            # (sum g, sum g*xhat) accumulate atomically into R pre-zeroed [C][2] rows - each block parks its sums in LDS and adds them
+            # as 256-byte runs - and the apply kernel adds the rows up itself and stores dbeta / dgamma: two launches, no slab, no
+            # reduction kernel.  Not in fp32 (the parity mode keeps the ordered slab reduction) and not under SyncBatchNorm (the
+            # all-reduce wants one row; the slab path below serves it).
+            R = stat_replicas(nparts, C)
             sums = RT.zeros(R * 2 * C, dev)
             K.bn_bwd_partial(dy, ymask, z, mi, rpb, sums, relu_ss, replicas=R, relu_mask=rmask)
-            if comm_on:
-                K.split_pairs(sums, C, bn.beta.grad(), bn.gamma.grad())   # parameter gradients stay LOCAL sums (DDP averages them later)
-                RT.comm.all_reduce_sum(sums[:2 * C])
-                K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=1, relu_mask=rmask)
-            else:
-                K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=R,
-                               dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=rmask)
+            K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=R,
+                           dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=rmask)
             bn.beta.done()
             bn.gamma.done()
         elif BN_ATOMIC_STATS:
