@@ -390,23 +390,18 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[S::WM][S::WN], const crog_gem
     }
     __syncthreads();
     constexpr int SLABS = (BM >= 128) ? BM / 128 : 1;
-    for (int idx = tid; idx < SLABS * BN; idx += NT) {
-      const int sl = idx / BN, c = idx % BN;
+    // one thread per float of the tile's [BN][2] statistics row: consecutive lanes store / add to consecutive addresses (a wave's
+    // atomics are 256 contiguous bytes, the shape the memory-side atomic units take at full rate)
+    for (int idx = tid; idx < SLABS * BN * 2; idx += NT) {
+      const int sl = idx / (BN * 2), k = idx % (BN * 2), c = k >> 1;
       if (n0 + c < p.N && m0 + sl * 128 < p.M) {
-        float a = 0.f, b = 0.f;
+        float v = 0.f;
 #pragma unroll
-        for (int q = 0; q < GPS; q++) {
-          a += red[((sl * GPS + q) * BN + c) * 2];
-          b += red[((sl * GPS + q) * BN + c) * 2 + 1];
-        }
+        for (int q = 0; q < GPS; q++) v += red[(sl * GPS + q) * BN * 2 + k];
         if (p.stat_replicas > 0) {   // accumulate into one of `stat_replicas` pre-zeroed [N][2] rows: no slab, no reduction kernel
-          float* dst = p.col_stats + ((int64_t)((m0 / 128 + sl) % p.stat_replicas) * p.N + n0 + c) * 2;
-          atomicAdd(dst, a);
-          atomicAdd(dst + 1, b);
+          atomicAdd(p.col_stats + ((int64_t)((m0 / 128 + sl) % p.stat_replicas) * p.N + n0) * 2 + k, v);
         } else {
-          float* dst = p.col_stats + ((int64_t)(m0 / 128 + sl) * p.N + n0 + c) * 2;
-          dst[0] = a;
-          dst[1] = b;
+          p.col_stats[((int64_t)(m0 / 128 + sl) * p.N + n0) * 2 + k] = v;
         }
       }
     }
