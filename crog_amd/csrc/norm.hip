@@ -360,30 +360,26 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
           s1[e] += red[j * cw + tx][e];
           s2[e] += red[j * cw + tx][VEC + e];
         }
-      if (replicas > 0) {   // park the block's sums in row tx of `red` (only this thread reads that row): issued coalesced below
+      // park the block's sums in row tx of `red` (only this thread reads that row); they leave the block coalesced below
 #pragma unroll
-        for (int e = 0; e < VEC; e++) {
-          red[tx][e] = s1[e];
-          red[tx][VEC + e] = s2[e];
-        }
-      } else {
-        float* dst = partial + ((long)blockIdx.x * C + c) * 2;
-#pragma unroll
-        for (int e = 0; e < VEC; e++) {
-          dst[2 * e] = s1[e];
-          dst[2 * e + 1] = s2[e];
-        }
+      for (int e = 0; e < VEC; e++) {
+        red[tx][e] = s1[e];
+        red[tx][VEC + e] = s2[e];
       }
     }
     __syncthreads();
-    if (replicas > 0) {
-      // accumulate into one of `replicas` pre-zeroed [C][2] rows (the consumer sums the rows in-kernel): consecutive lanes add to
-      // consecutive floats, i.e. 256 contiguous bytes per wave instruction - the shape the memory-side atomic units run at full rate
-      float* base = partial + ((long)(blockIdx.x % replicas) * C + (long)cg * VEC) * 2;
+    {
+      // consecutive lanes handle consecutive floats of the [C][2] row, i.e. 256 contiguous bytes per wave instruction: plain stores
+      // into this block's slab row, or (replicas > 0) atomic adds into one of `replicas` pre-zeroed rows that the consumer sums
+      // in-kernel - the shape the memory-side atomic units run at full rate
+      const long row = replicas > 0 ? (long)(blockIdx.x % replicas) : (long)blockIdx.x;
+      float* base = partial + (row * C + (long)cg * VEC) * 2;
       const int nf = min(cw, cvec - cg) * 2 * VEC;
       for (int k = threadIdx.x; k < nf; k += NT) {
         const int v = k / (2 * VEC), q = k % (2 * VEC);
-        atomicAdd(base + k, red[v][(q & 1) ? VEC + (q >> 1) : (q >> 1)]);
+        const float val = red[v][(q & 1) ? VEC + (q >> 1) : (q >> 1)];
+        if (replicas > 0) atomicAdd(base + k, val);
+        else base[k] = val;
       }
       __syncthreads();
     }
