@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
                                                           const float* __restrict__ gamma, const float* __restrict__ sums, float count,
                                                           const float* __restrict__ relu_ss, T* __restrict__ dz, long lddz, T* __restrict__ dres,
                                                           long lddres, long M, int C, int sum_rows, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, const unsigned char* __restrict__ relu_mask) {
+                                                          float* __restrict__ dbeta, const unsigned char* __restrict__ relu_mask, float pgrad_scale) {
   constexpr int VEC = Elem<T>::VEC;
   // sum_rows > 0: `sums` is [sum_rows][C][2] (atomic replicas of bn_bwd_partial, or the all-reduced totals): every block adds the
   // rows up into LDS once; block 0 also stores the parameter gradients (dbeta = sum g, dgamma = sum g*zhat) when asked to.
@@ -415,9 +415,9 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
       }
       tot[2 * c] = a;
       tot[2 * c + 1] = b;
-      if (blockIdx.x == 0 && dgamma) {
-        dbeta[c] = a;
-        dgamma[c] = b;
+      if (blockIdx.x == 0 && dgamma) {   // pgrad_scale = 1/world under SyncBatchNorm: the totals are global there (see header)
+        dbeta[c] = a * pgrad_scale;
+        dgamma[c] = b * pgrad_scale;
       }
     }
     __syncthreads();
@@ -1020,7 +1020,8 @@ extern "C" int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, cons
 extern "C" int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
                                  const float* mean_invstd, const float* gamma, const float* sums, float count,
                                  const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres, int64_t M, int C,
-                                 int sum_rows, float* dgamma, float* dbeta, const void* relu_mask, crog_stream_t stream) {
+                                 int sum_rows, float* dgamma, float* dbeta, float param_grad_scale, const void* relu_mask,
+                                 crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0, "bn_bwd_apply: C %% %d != 0", vec);
   CROG_CHECK_ARG(sum_rows >= 0 && C <= 8192 && (!dgamma || (dbeta && sum_rows > 0)), "bn_bwd_apply: bad sum_rows / parameter-gradient outputs");
@@ -1029,7 +1030,8 @@ extern "C" int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const 
   const size_t lds = sum_rows > 0 ? (size_t)C * 2 * sizeof(float) : 0;
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(NT), lds, (hipStream_t)stream, (const T*)dy, (long)lddy,
                                        (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, gamma, sums, count, relu_scale_shift,
-                                       (T*)dz, (long)lddz, (T*)dres, (long)lddres, (long)M, C, sum_rows, dgamma, dbeta, (const unsigned char*)relu_mask));
+                                       (T*)dz, (long)lddz, (T*)dres, (long)lddres, (long)M, C, sum_rows, dgamma, dbeta, (const unsigned char*)relu_mask,
+                                       param_grad_scale));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -305,16 +305,21 @@ class ConvBnAct(Function):
         comm_on = RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force)
         dz = torch.empty(lead + (C,), device=dev, dtype=dtype)
         dres = torch.empty(lead + (C,), device=dev, dtype=dtype) if ctx.has_res else None
-        if BN_BWD_ATOMIC and dtype != torch.float32 and not comm_on:
+        if BN_BWD_ATOMIC and dtype != torch.float32:
             # (sum g, sum g*xhat) accumulate atomically into R pre-zeroed [C][2] rows - each block parks its sums in LDS and adds them
             # as 256-byte runs - and the apply kernel adds the rows up itself and stores dbeta / dgamma: two launches, no slab, no
-            # reduction kernel.  Not in fp32 (the parity mode keeps the ordered slab reduction) and not under SyncBatchNorm (the
-            # all-reduce wants one row; the slab path below serves it).
+            # reduction kernel.  Under SyncBatchNorm the R rows are all-reduced in between; the totals are then global, and storing
+            # them divided by the world size equals what DDP's averaging makes of the local sums, so no local-sum pass is needed.
+            # Not in fp32: the parity mode keeps the ordered slab reduction below.
             R = stat_replicas(nparts, C)
             sums = RT.zeros(R * 2 * C, dev)
             K.bn_bwd_partial(dy, ymask, z, mi, rpb, sums, relu_ss, replicas=R, relu_mask=rmask)
+            scale = 1.0
+            if comm_on:
+                RT.comm.all_reduce_sum(sums)
+                scale = 1.0 / RT.comm.world_size
             K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=R,
-                           dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=rmask)
+                           dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=rmask, param_grad_scale=scale)
             bn.beta.done()
             bn.gamma.done()
         elif BN_ATOMIC_STATS:

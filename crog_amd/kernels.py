@@ -239,13 +239,14 @@ def reduce_split(partial, nparts, C, sums, a, b):
     check(lib().crog_reduce_split(ptr(partial), nparts, C, ptr(sums), ptr(a), ptr(b), stream()), "reduce_split")
 
 
-def bn_bwd_apply(dy, y, z, mean_invstd, gamma, sums, count, dz, dres, relu_ss=None, sum_rows=0, dgamma=None, dbeta=None, relu_mask=None):
+def bn_bwd_apply(dy, y, z, mean_invstd, gamma, sums, count, dz, dres, relu_ss=None, sum_rows=0, dgamma=None, dbeta=None, relu_mask=None,
+                 param_grad_scale=1.0):
     M, C, lddy = mat(dy)
     ldy = mat(y)[2] if y is not None else 0
     lddres = mat(dres)[2] if dres is not None else 0
     check(lib().crog_bn_bwd_apply(dcode(dy), ptr(dy), lddy, ptr(y), ldy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(gamma),
                                   ptr(sums), float(count), ptr(relu_ss), ptr(dz), mat(dz)[2], ptr(dres), lddres, M, C, sum_rows,
-                                  ptr(dgamma), ptr(dbeta), ptr(relu_mask), stream()), "bn_bwd_apply")
+                                  ptr(dgamma), ptr(dbeta), float(param_grad_scale), ptr(relu_mask), stream()), "bn_bwd_apply")
 
 
 # --------------------------------------------------------------------------------------------

@@ -149,12 +149,15 @@ int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, 
 /* dz = gamma*invstd*(g - sums.g/count - xhat*sums.gx/count);  dres = g when dres != NULL.
  * replicas (partial) / sum_rows (apply) = 0: `partial` is the per-block slab [blocks][C][2] and `sums` the reduced [C][2].
  * replicas = R > 0: the partial kernel adds atomically into a PRE-ZEROED [R][C][2]; the apply kernel is handed the same buffer
- * with sum_rows = R, adds the rows up itself and (dgamma/dbeta != NULL) stores the parameter gradients — no reduction launch. */
+ * with sum_rows = R, adds the rows up itself and (dgamma/dbeta != NULL) stores the parameter gradients times param_grad_scale —
+ * no reduction launch.  Under SyncBatchNorm the rows are all-reduced first, so the totals are GLOBAL sums: storing them with
+ * param_grad_scale = 1/world gives every rank the value DDP's gradient averaging would have produced from the local sums
+ * (mean over ranks of the local sums == global sum / world), and no separate local-sum pass is needed. */
 int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
                       int64_t ldz, const float* mean_invstd, const float* gamma, const float* sums,
                       float count, const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres,
-                      int64_t M, int C, int sum_rows, float* dgamma, float* dbeta, const void* relu_mask,
-                      crog_stream_t stream);
+                      int64_t M, int C, int sum_rows, float* dgamma, float* dbeta, float param_grad_scale,
+                      const void* relu_mask, crog_stream_t stream);
 /* single-replica fast paths: slab [nparts][C][2] -> (reduce + finalize) / (reduce + split into two vectors) in one launch */
 int crog_bn_reduce_finalize(const float* partial, int nparts, float count, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int C,

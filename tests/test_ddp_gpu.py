@@ -34,7 +34,9 @@ def rccl_world1():
 
 
 @pytest.mark.parametrize("text_graph", [False, True])
-def test_ddp_syncbn_world1_matches_plain_step(rccl_world1, monkeypatch, text_graph):
+def test_ddp_syncbn_world1_matches_plain_step(rccl_world1, monkeypatch, text_graph, dtype=torch.float32):
+    """fp32 (bit-reproducible forward): ordered slab reductions on both sides of the SyncBatchNorm exchange.  The bf16 form of the
+    exchange is checked on the non-chaotic part of the real network below."""
     import test_model_gpu as T
     import crog_amd.model.crog as crog_mod
     from crog_amd.optim import FusedAdam
@@ -45,7 +47,7 @@ def test_ddp_syncbn_world1_matches_plain_step(rccl_world1, monkeypatch, text_gra
     b = T.batch_for(cfg, meta)
 
     def step(wrap):
-        model, groups = T.build(cfg, meta)
+        model, groups = T.build(cfg, meta, dtype=dtype)
         model.train()
         net = model
         if wrap:
@@ -83,10 +85,63 @@ def test_ddp_syncbn_world1_matches_plain_step(rccl_world1, monkeypatch, text_gra
         print(f"step {i}: pred {T.err(p0, p1):.2e} / {T.err(p0, p2):.2e}  loss {abs(l0 - l1):.2e} / {abs(l0 - l2):.2e}  "
               f"grad rel-L2 {rel(g0, g1):.2e} / {rel(g0, g2):.2e}  (plain-vs-plain / plain-vs-ddp)")
         if i == 0:      # identical weights on both sides (measured: 2e-3 .. 4e-3 relative gradient noise, plain vs plain and plain vs DDP alike)
-            assert T.err(p0, p2) < max(1e-3, 4 * T.err(p0, p1)) and abs(l0 - l2) < 1e-3
+            assert T.err(p0, p2) < max(1e-3, 4 * T.err(p0, p1)) and abs(l0 - l2) < max(1e-3, 4 * abs(l0 - l1))
             assert rel(g0, g2) <= max(4 * rel(g0, g1), 2e-2)
         else:           # after an optimizer step the amplified noise reaches 1e-2 .. 1e-1 on gradients in BOTH comparisons: sanity bounds only
-            assert T.err(p0, p2) < 5e-2 and abs(l0 - l2) < 1e-2 and rel(g0, g2) < 0.5
-    assert (plain[1] - ddp[1]).abs().max().item() <= 4 * (plain[1] - again[1]).abs().max().item() + 1e-5
+            assert T.err(p0, p2) < max(5e-2, 4 * T.err(p0, p1)) and abs(l0 - l2) < max(1e-2, 4 * abs(l0 - l1))
+            assert rel(g0, g2) < max(0.5, 4 * rel(g0, g1))
+    assert (plain[1] - ddp[1]).abs().max().item() <= 4 * (plain[1] - again[1]).abs().max().item() + 1e-5   # parameters after two steps
+    tol = 1e-3 if dtype == torch.float32 else 2e-2
     for k, v in plain[2].items():
-        assert torch.allclose(v, ddp[2][k], rtol=1e-3, atol=1e-4), k
+        assert torch.allclose(v, ddp[2][k], rtol=tol, atol=tol * 0.1), k
+
+
+def test_syncbn_bf16_rows_allreduced_match_plain(rccl_world1):
+    """bf16 SyncBatchNorm path: the forward's statistic replicas and the backward's atomic (sum g, sum g*xhat) rows are all-reduced
+    as whole [R][C][2] buffers, and the BatchNorm parameter gradients are the GLOBAL totals / world.  At world size 1 that must
+    reproduce the plain path; run on stem + layer1 + layer2 of the real RN50 tower (2 x 416 x 416: BatchNorm over >= 5408 samples, no
+    chaotic amplification), compared in relative L2 per parameter."""
+    from crog_amd.model import build_crog
+    from crog_amd.parallel import convert_sync_batchnorm
+    from crog_amd.runtime import RT
+    from crog_amd.testing import make_cfg
+    torch.manual_seed(0)
+    model, _ = build_crog(make_cfg())
+    model = model.cuda().prepare()
+    model.train()
+    img = torch.randn(2, 3, 416, 416, generator=torch.Generator().manual_seed(3)).cuda()
+    st = model.store
+    for n, p, o, k, _ in st.entries:          # CLIP initialises every bottleneck's last BatchNorm scale to zero, which would zero the
+        if n.endswith("bn3.weight"):          # gradients of the whole residual branch: give them a non-trivial value
+            st.P[o:o + k].fill_(0.5)
+    st.invalidate_shadow()
+    names = [(n, o, k) for n, p, o, k, _ in st.entries
+             if n.startswith(("backbone.visual.conv", "backbone.visual.bn", "backbone.visual.layer1", "backbone.visual.layer2"))]
+
+    def run():
+        st.g_clean = False
+        st.zero_grad()
+        RT.begin_step(img.device)
+        st.forward_begins()
+        x2 = model.backbone.visual(img, torch.bfloat16)[0]
+        x2.float().pow(2).mean().backward()
+        torch.cuda.synchronize()
+        return x2.float().clone(), st.G.clone()
+
+    x_a, g_a = run()
+    x_b, g_b = run()
+    convert_sync_batchnorm(model, force=True)
+    assert RT.comm is not None
+    x_c, g_c = run()
+    RT.comm = None
+
+    def rel(a, b):
+        return ((a - b).norm() / a.norm().clamp_min(1e-12)).item()
+    assert rel(x_a, x_c) <= max(4 * rel(x_a, x_b), 1e-3)
+    worst = 0.0
+    for n, o, k in names:
+        a, b, c = g_a[o:o + k], g_b[o:o + k], g_c[o:o + k]
+        assert a.abs().max().item() > 0, n
+        worst = max(worst, rel(a, c))
+        assert rel(a, c) <= max(4 * rel(a, b), 2e-2), (n, rel(a, c), rel(a, b))
+    print("bf16 SyncBN vs plain: worst relative L2 over", len(names), "parameters:", worst)

@@ -247,6 +247,10 @@ def test_batchnorm_train_fwd_bwd(K, dt):
         dg2, db2 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
         K.bn_bwd_apply(dy, y, z, mi, gamma, acc, M, dz2, dres2, sum_rows=R, dgamma=dg2, dbeta=db2)
         assert torch.allclose(db2, dbeta, rtol=1e-4, atol=1e-3) and torch.allclose(dg2, dgamma, rtol=1e-4, atol=1e-3)
+        # SyncBatchNorm form: the rows hold GLOBAL totals, the parameter gradients are stored times 1 / world
+        dg4, db4 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        K.bn_bwd_apply(dy, y, z, mi, gamma, acc, M, dz2, dres2, sum_rows=R, dgamma=dg4, dbeta=db4, param_grad_scale=0.25)
+        assert torch.allclose(db4, 0.25 * db2, rtol=1e-6, atol=1e-6) and torch.allclose(dg4, 0.25 * dg2, rtol=1e-6, atol=1e-6)
         close(dz2, dz.float(), dt, scale=1)
         assert torch.equal(dres2, dres)
     # fused single-replica forward statistics == two-step path
