@@ -169,7 +169,7 @@ class CROG(nn.Module):
         if self.training and torch.is_grad_enabled():
             RT.join_streams()               # e.g. a previous backward's weight-gradient stream when no fused optimizer joined it
             store.relink_grads()
-            store.zero_grad()
+            store.zero_grad(trusted=True)
             RT.begin_step(dev)
         with torch.autocast("cuda", enabled=False):
             pad_mask = (word == 0).contiguous()

@@ -253,7 +253,7 @@ class SSG(nn.Module):
         if self.training and torch.is_grad_enabled():
             RT.join_streams()
             st.relink_grads()
-            st.zero_grad()
+            st.zero_grad(trusted=True)
             RT.begin_step(dev)
         with torch.autocast("cuda", enabled=False):
             RT.streams = [torch.cuda.current_stream()]

@@ -207,13 +207,15 @@ class ParamStore:
             if p.grad is not g:
                 p.grad = g
 
-    def zero_grad(self):
+    def zero_grad(self, trusted: bool = False):
         """One memset of the flat gradient buffer — skipped while it is known to be clean (the training forward clears it and the
-        reference's `optimizer.zero_grad()` follows right after, crog_engine.py:77: that second 588 MB memset is redundant).  Every
-        kernel path that writes a gradient ends in WRef.done(), which marks the buffer dirty."""
+        reference's `optimizer.zero_grad()` follows right after, crog_engine.py:77: that second 588 MB memset is redundant).
+        `trusted` is passed by the crog_amd models' own forward: every gradient THEY produce is written by a kernel path that ends in
+        WRef.done(), which marks the buffer dirty, so "clean" can be believed until then.  Any other caller (a generic module whose
+        gradients arrive through autograd's AccumulateGrad) gets the memset every time."""
         if _LEGACY_SYNC or not getattr(self, "g_clean", False):
             self.G.zero_()
-            self.g_clean = True
+            self.g_clean = trusted and not _LEGACY_SYNC
 
     def invalidate_shadow(self):
         """The fp32 parameters changed behind the store's back (load_state_dict, a foreign optimizer, in-place edits)."""
