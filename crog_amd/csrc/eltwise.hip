@@ -530,6 +530,16 @@ __global__ void __launch_bounds__(NT) cast_pad2d_kernel(const float* __restrict_
   }
 }
 
+// ---- dst[r][c] += src[r][c], c < cols: strips the zero padding of a ragged-Cin weight gradient back into the flat buffer ------
+__global__ void __launch_bounds__(NT) add_pad2d_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, int cols,
+                                                       long rows) {
+  GRID_STRIDE(i, rows * cols) {
+    const long r = i / cols;
+    const int c = (int)(i % cols);
+    dst[r * ldd + c] += src[r * lds_ + c];
+  }
+}
+
 // ---- flat casts ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NT) cast_f32_to_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long n) {
   const long nv = n / 8;
@@ -811,6 +821,13 @@ extern "C" int crog_conv3_dgrad_weights(int dtype, const void* src, void* dst, c
   static_assert(sizeof(long) == sizeof(int64_t), "table entries are 64-bit");
   DISPATCH_T(dtype, hipLaunchKernelGGL((conv3_dgrad_weights_kernel<T>), dim3(96, count), dim3(NT), 0, (hipStream_t)s, (const T*)src, (T*)dst,
                                        reinterpret_cast<const long*>(table)));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_add_pad2d(const float* src, int64_t lds_, float* dst, int64_t ldd, int cols, int64_t rows, crog_stream_t s) {
+  CROG_CHECK_ARG(src && dst && cols > 0 && rows >= 0, "add_pad2d: bad arguments");
+  if (rows == 0) return CROG_OK;
+  LAUNCH(add_pad2d_kernel, rows * cols, s, src, (long)lds_, dst, (long)ldd, cols, (long)rows);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -132,8 +132,10 @@ __global__ void __launch_bounds__(NT) reduce_split_kernel(const float* __restric
   if (t < 16 && col < 2 * C) {
     const float v = red[0][t];
     if (sums) sums[col] = v;
-    if (col & 1) { if (b) b[col >> 1] = v; }
-    else { if (a) a[col >> 1] = v; }
+    // a / b are gradient vectors of the flat buffer: ADD (torch accumulates gradients until zero_grad; a shared norm that is
+    // applied several times per forward sums its uses)
+    if (col & 1) { if (b) b[col >> 1] += v; }
+    else { if (a) a[col >> 1] += v; }
   }
 }
 
@@ -390,8 +392,8 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
 __global__ void bn_param_grads_kernel(const float* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  dbeta[c] = sums[2 * c];
-  dgamma[c] = sums[2 * c + 1];
+  dbeta[c] += sums[2 * c];
+  dgamma[c] += sums[2 * c + 1];
 }
 
 // Backward pass 2: dz = gamma*invstd * (g - sum_g/count - zhat * sum_gz/count);  dres = g (optional)
@@ -416,8 +418,8 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
       tot[2 * c] = a;
       tot[2 * c + 1] = b;
       if (blockIdx.x == 0 && dgamma) {   // pgrad_scale = 1/world under SyncBatchNorm: the totals are global there (see header)
-        dbeta[c] = a * pgrad_scale;
-        dgamma[c] = b * pgrad_scale;
+        dbeta[c] += a * pgrad_scale;     // gradient buffers accumulate (cleared by zero_grad)
+        dgamma[c] += b * pgrad_scale;
       }
     }
     __syncthreads();
@@ -754,12 +756,12 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
   }
 }
 
-// pairs [C][2] -> two separate fp32 vectors (dgamma, dbeta)
+// pairs [C][2] -> ADDED to two separate fp32 gradient vectors (dgamma, dbeta)
 __global__ void split_pairs_kernel(const float* __restrict__ sums, int C, float* __restrict__ a, float* __restrict__ b) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  a[c] = sums[2 * c];
-  b[c] = sums[2 * c + 1];
+  a[c] += sums[2 * c];
+  b[c] += sums[2 * c + 1];
 }
 
 // =============================================================================================

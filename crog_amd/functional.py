@@ -95,9 +95,14 @@ class WRef:
         return self.store.G[self.off:self.off + self.rows * self.cols]
 
     def done(self):
-        self.store.g_clean = False
+        """The kernels that write this parameter's gradient are enqueued."""
+        st, p = self.store, self.param
+        st.g_clean = False
+        st.touched.add(id(p))
+        if p.grad is None:      # dropped by a set_to_none zero_grad between forward and backward: G was cleared by BackwardBegin
+            p.grad = st.gview[id(p)]
         if RT.reducer is not None:
-            RT.reducer.mark_ready(self.param)
+            RT.reducer.mark_ready(p)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -388,7 +393,7 @@ class ConvBnAct(Function):
                     K.gemm(dt, K.A_MC, K.B_NC_IM2COL, dz, x, gt, C, 9 * cin, M, C, K.mat(x)[2], wcols, c_off=goff, conv=(lead[1], lead[2], cin),
                            splitk=sk, out_mode=K.OUT_F32_ATOMIC)
                 if wpad is not None:  # strip the zero padding back out into the real gradient
-                    K.cast_pad2d(gscratch, dst_cols, dst_cols, w.G, src_cols, src_cols, rows, dst_off=w.off)
+                    K.add_pad2d(gscratch, dst_cols, w.G, src_cols, src_cols, rows, dst_off=w.off)
             RT.on_wgrad_stream(wgrad, dz, x, gt if wpad is not None else None)
             if ksize == 1 and ctx.x_needs:
                 dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
@@ -702,13 +707,16 @@ class MhaFn(Function):
             def wgrad_proj(dbuf=dbuf, x_=x_, w_=w_, b_=b_, col=col, ld=ld):
                 lin_wgrad(dbuf, x_, w_, a_off=col, lda=ld, N=w_.rows, bias=b_)
             RT.on_wgrad_stream(wgrad_proj, dbuf, x_)
-            w_.done()
-            if b_ is not None:
-                b_.done()
             prev = grads.get(id(x_))
             dx = prev if prev is not None else torch.empty(x_.shape, device=dev, dtype=dtype)
             lin_dgrad(dbuf, w_, dx, accumulate_into=prev, a_off=col, lda=ld, N=w_.rows)
             grads[id(x_)] = dx
+        # a packed in_proj parameter is written by up to three row-block GEMMs: it is ready (DDP bucket bookkeeping) only once
+        # ALL of them are enqueued, so the marks come after the loop, one per parameter
+        for _, w_, b_, _ in merged:
+            w_.done()
+            if b_ is not None:
+                b_.done()
         dxq = grads.get(id(xq))
         dxk = None if same_qk else grads.get(id(xk))
         dxv = None if (same_kv or xv is xq) else grads.get(id(xv))
@@ -1333,6 +1341,27 @@ class FusedHeadFn(Function):
 
 def fused_head(x4, state, w5: WRef, b5: WRef, tw: WRef, tb: WRef, C, groups):
     return FusedHeadFn.apply(x4, state, w5.param, b5.param, tw.param, tb.param, w5, b5, tw, tb, C, groups)
+
+
+class BackwardBeginFn(Function):
+    """Identity on the model's differentiable outputs; its backward is the first node of the model's backward pass and gives
+    the flat store the chance to honour a `zero_grad(set_to_none=True)` issued between forward and backward
+    (crog_engine.py:77: forward -> optimizer.zero_grad() -> backward)."""
+
+    @staticmethod
+    def forward(ctx, store, *outs):
+        ctx.store = store
+        return tuple(o.view_as(o) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.store.fresh_grads_if_dropped()
+        return (None,) + tuple(grads)
+
+
+def backward_begin(store: ParamStore, *outs):
+    res = BackwardBeginFn.apply(store, *outs)
+    return res[0] if len(outs) == 1 else res
 
 
 class LossFn(Function):

@@ -462,6 +462,10 @@ def cast_pad2d(src, lds, cols_src, dst, ldd, cols_dst, rows, src_off=0, dst_off=
           "cast_pad2d")
 
 
+def add_pad2d(src, lds, dst, ldd, cols, rows, dst_off=0):
+    check(lib().crog_add_pad2d(ptr(src), lds, ptr(dst) + 4 * dst_off, ldd, cols, rows, stream()), "add_pad2d")
+
+
 def cast_f32_to_bf16(src, dst, n):
     check(lib().crog_cast_f32_to_bf16(ptr(src), ptr(dst), n, stream()), "cast_f32_to_bf16")
 

@@ -327,6 +327,48 @@ def build_model(arch: dict, txt_length: int) -> CLIP:
                 arch["transformer_layers"])
 
 
+CLIP_META_KEYS = ("input_resolution", "context_length", "vocab_size")     # clip.py:547-549
+
+
+def fp16_converted(name: str, dims: dict) -> bool:
+    """Does `convert_weights` (clip.py:477-500) cast this tensor to fp16?  It touches Conv/Linear weights and biases, the packed /
+    separate projection tensors of nn.MultiheadAttention, `text_projection` and `proj` — NOT BatchNorm / LayerNorm affine
+    parameters and statistics, embeddings, positional / class embeddings or `logit_scale`, which keep their fp32 values.
+    `dims`: tensor rank by state-dict key (tells a Linear bias from a norm bias through its sibling weight)."""
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf in ("in_proj_weight", "in_proj_bias", "q_proj_weight", "k_proj_weight", "v_proj_weight", "bias_k", "bias_v"):
+        return True
+    if leaf in ("text_projection", "proj"):
+        return True
+    if "token_embedding" in name:
+        return False
+    if leaf == "weight":
+        return dims.get(name, 0) >= 2
+    if leaf == "bias":
+        return dims.get(name[:-4] + "weight", 0) >= 2
+    return False
+
+
+def load_pretrained_clip(model: "CLIP", sd: dict):
+    """`convert_weights(model); model.load_state_dict(state_dict, False)` of clip.py:551-554 on fp32 storage: every tensor of a
+    converted class goes through an fp16 round trip — the checkpoint's values AND the random initialisation of modules the archive
+    does not carry (`visual.attnpool.connect.*`, a CRIS addition) — everything else is copied at full precision.  strict=False."""
+    own = model.state_dict()
+    dims = {k: v.dim() for k, v in own.items()}
+    with torch.no_grad():
+        for k, v in own.items():
+            if v.is_floating_point() and fp16_converted(k, dims):
+                v.copy_(v.half().float())
+    clean = {}
+    for k, v in sd.items():
+        if k in CLIP_META_KEYS:
+            continue
+        if torch.is_tensor(v) and v.is_floating_point():
+            v = v.half().float() if fp16_converted(k, dims) else v.float()
+        clean[k] = v
+    return model.load_state_dict(clean, strict=False)
+
+
 def arch_from_state_dict(sd: dict) -> dict:
     """Architecture inference from checkpoint tensor shapes, as clip.py:503-542 does."""
     vit = "visual.proj" in sd

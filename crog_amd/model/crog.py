@@ -15,7 +15,7 @@ import torch.nn as nn
 from .. import functional as Fn
 from ..runtime import RT, ParamStore
 from .blocks import BatchNorm, bind_all
-from .clip import arch_from_state_dict, build_model
+from .clip import arch_from_state_dict, build_model, load_pretrained_clip
 from .layers import FPN, MultiTaskProjector, Projector, TransformerDecoder
 
 # Text tower forward/backward as two hipGraph replays (crog_amd/graphs.py).  Opt-in: it removes ~650 launches (~8 ms of host
@@ -81,10 +81,7 @@ class CROG(nn.Module):
         arch, sd = self._clip_arch(cfg)
         self.backbone = build_model(arch, cfg.word_len)
         if sd is not None and self.use_pretrained_clip:
-            # clip.py:552-554: fp16 round trip of the checkpoint weights, strict=False (attnpool.connect.* stay random)
-            sd = {k: (v.half().float() if v.is_floating_point() else v) for k, v in sd.items()
-                  if k not in ("input_resolution", "context_length", "vocab_size")}
-            self.backbone.load_state_dict(sd, strict=False)
+            load_pretrained_clip(self.backbone, sd)      # clip.py:551-554
         self.neck = FPN(in_channels=cfg.fpn_in, out_channels=cfg.fpn_out)
         if self.use_contrastive:
             self.decoder = TransformerDecoder(num_layers=cfg.num_layers, d_model=cfg.vis_dim, nhead=cfg.num_head, dim_ffn=cfg.dim_ffn,
@@ -128,6 +125,7 @@ class CROG(nn.Module):
                     mod = getattr(mod, p)
                 mod._buffers[leaf] = buf.to(device)
         self._store = ParamStore(self, device)
+        self._store.explicit = True
         bind_all(self, self._store)
         self._bns = [m for m in self.modules() if isinstance(m, BatchNorm)]
         return self
@@ -168,8 +166,7 @@ class CROG(nn.Module):
         store.forward_begins()              # re-cast the bf16 shadow unless FusedAdam just wrote it
         if self.training and torch.is_grad_enabled():
             RT.join_streams()               # e.g. a previous backward's weight-gradient stream when no fused optimizer joined it
-            store.relink_grads()
-            store.zero_grad(trusted=True)
+            store.fresh_grads_if_dropped()   # gradients ACCUMULATE across forward/backward pairs until zero_grad(), as in torch
             RT.begin_step(dev)
         with torch.autocast("cuda", enabled=False):
             pad_mask = (word == 0).contiguous()
@@ -218,6 +215,10 @@ class CROG(nn.Module):
             fq = self.neck(vis, state)
             if self.use_contrastive:
                 fq = self.decoder(fq, wfeat, pad_mask)
+                if isinstance(fq, list):
+                    # cfg.intermediate=True: the reference's decoder returns a list and crog.py:69 then calls .reshape on it
+                    raise AttributeError("'list' object has no attribute 'reshape' (TransformerDecoder(return_intermediate=True) "
+                                         "returns per-layer outputs; CROG.forward consumes a single map, as in the reference)")
             pred = self.proj(fq, state)                      # fp32 logits [b, groups, H, W]
             if self.training and self._bns:
                 torch._foreach_add_([m.num_batches_tracked for m in self._bns], 1)
@@ -226,6 +227,7 @@ class CROG(nn.Module):
             targets = (mask, grasp_qua_mask, grasp_sin_mask, grasp_cos_mask, grasp_wid_mask)[:n]
             if self.training:
                 total, sums, small = Fn.head_loss(pred, [t.float() for t in targets], weighted=self.use_grasp_masks)
+                total = Fn.backward_begin(store, total)
                 loss_dict = LossDict(sums, n)
                 tgt = tuple(small[i] for i in range(n))
                 if self.use_grasp_masks:

@@ -166,8 +166,13 @@ class TransformerDecoder(Bound):
         x = vis.reshape(B * H * W, C)
         t = txt.reshape(B * L, D)
         t_k = Fn.add_rows(t, txt_pos)
+        intermediate = []
         for layer in self.layers:
             x = layer(x, t, t_k, vis_pos, pad_mask, B)
+            if self.return_intermediate:            # layers.py:262-274: the shared final norm applied to every layer's output
+                intermediate.append(self.norm(x).view(B, H, W, C))
+        if self.return_intermediate:
+            return intermediate                     # [output_1, ..., output_n]; the last entry is the plain return value
         return self.norm(x).view(B, H, W, C)
 
 

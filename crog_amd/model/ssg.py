@@ -221,6 +221,7 @@ class SSG(nn.Module):
                     mod = getattr(mod, p)
                 mod._buffers[leaf] = buf.to(device)
         self._store = ParamStore(self, device)
+        self._store.explicit = True
         bind_all(self, self._store)
         self._bns = [m for m in self.modules() if isinstance(m, BatchNorm)]
         return self
@@ -252,8 +253,7 @@ class SSG(nn.Module):
         st.forward_begins()
         if self.training and torch.is_grad_enabled():
             RT.join_streams()
-            st.relink_grads()
-            st.zero_grad(trusted=True)
+            st.fresh_grads_if_dropped()
             RT.begin_step(dev)
         with torch.autocast("cuda", enabled=False):
             RT.streams = [torch.cuda.current_stream()]
@@ -266,8 +266,10 @@ class SSG(nn.Module):
             seg = Fn.linear(levels[0], self.semantic_seg_conv.w, self.semantic_seg_conv.b)
             if self.training:
                 torch._foreach_add_([m.num_batches_tracked for m in self._bns], 1)
-        return dict(class_pred=conf, box_pred=box, ins_coef_pred=coef, grasp_coef_pred=gcoef, protos=protos.float(),
-                    seg_pred=seg.permute(0, 3, 1, 2).float())
+        outs = (conf, box, coef, gcoef, protos.float(), seg.permute(0, 3, 1, 2).float())
+        if self.training and torch.is_grad_enabled():
+            outs = Fn.backward_begin(st, *outs)     # first node of backward: honours a set_to_none zero_grad after the forward
+        return dict(zip(("class_pred", "box_pred", "ins_coef_pred", "grasp_coef_pred", "protos", "seg_pred"), outs))
 
     def forward(self, data_dict):
         """ssg.py:248-293.  Eval: the reference's output_dict.  Train with targets in `data_dict`: (output_dict, loss_dict);

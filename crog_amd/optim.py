@@ -56,6 +56,27 @@ class FusedAdam(torch.optim.Optimizer):
                     segs.append([o, n])
             self._segments.append(segs)
 
+    def _decay_segments(self, group, segs):
+        """torch.optim.Adam skips parameters whose gradient is None (CROG: `logit_scale`, never used by the forward): no decay,
+        no moment update.  Here such a parameter has a zero gradient in the flat buffer, which only differs from being skipped
+        when weight decay is on, so with decay the segments leave out every parameter no kernel has ever written a gradient for."""
+        store = self._store
+        idle = frozenset(id(p) for p in group["params"] if id(p) not in store.touched)
+        if not idle:
+            return segs
+        cache = self.__dict__.setdefault("_decay_cache", {})
+        key = (id(group), idle)
+        if key not in cache:
+            ext = sorted((store.off(p), (p.numel() + ALIGN - 1) // ALIGN * ALIGN) for p in group["params"] if id(p) not in idle)
+            out = []
+            for o, n in ext:
+                if out and out[-1][0] + out[-1][1] == o:
+                    out[-1][1] += n
+                else:
+                    out.append([o, n])
+            cache[key] = out
+        return cache[key]
+
     @staticmethod
     def _like(buf, p, o):
         co, ci, kh, kw = p.shape
@@ -76,6 +97,8 @@ class FusedAdam(torch.optim.Optimizer):
         shadow = store.S      # bf16 compute copy (None until a bf16 forward has run): refreshed by the same pass that updates P
         for group, segs in zip(self.param_groups, self._segments):
             b1, b2 = group["betas"]
+            if group["weight_decay"] != 0 and store.explicit:
+                segs = self._decay_segments(group, segs)
             for o, n in segs:
                 K.adam_step(store.P, store.G, self.m, self.v, n, group["lr"], b1, b2, group["eps"], group["weight_decay"], self._step,
                             shadow=shadow, off=o)

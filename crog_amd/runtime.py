@@ -165,6 +165,10 @@ class ParamStore:
             p.grad = g
             self.entries.append((name, p, o, n, g))
             self.by_param[id(p)] = o
+        self.explicit = False    # set by crog_amd models: all their gradients are announced through WRef.done()
+        self.g_clean = False
+        self.touched = set()     # ids of parameters whose gradient has been written at least once (FusedAdam weight decay)
+        self.gview = {id(p): g for _, p, _, _, g in self.entries}
         self.conv3_count = len(conv3) // 3
         self.conv3_table = torch.tensor(conv3, dtype=torch.int64, device=device) if conv3 else None
 
@@ -207,15 +211,30 @@ class ParamStore:
             if p.grad is not g:
                 p.grad = g
 
-    def zero_grad(self, trusted: bool = False):
-        """One memset of the flat gradient buffer — skipped while it is known to be clean (the training forward clears it and the
-        reference's `optimizer.zero_grad()` follows right after, crog_engine.py:77: that second 588 MB memset is redundant).
-        `trusted` is passed by the crog_amd models' own forward: every gradient THEY produce is written by a kernel path that ends in
-        WRef.done(), which marks the buffer dirty, so "clean" can be believed until then.  Any other caller (a generic module whose
-        gradients arrive through autograd's AccumulateGrad) gets the memset every time."""
-        if _LEGACY_SYNC or not getattr(self, "g_clean", False):
+    def grads_dropped(self) -> bool:
+        """True when somebody set a parameter's .grad to None (torch's default `zero_grad(set_to_none=True)`)."""
+        for name, p, o, n, g in self.entries:
+            if p.grad is None:
+                return True
+        return False
+
+    def zero_grad(self):
+        """One memset of the flat gradient buffer, skipped while the buffer is known to be all zeros.  "Known" needs the owner's
+        promise (`explicit`, set by the crog_amd models) that every gradient it produces is written by a kernel path ending in
+        WRef.done(), which marks the buffer dirty; a generic module whose gradients arrive through autograd's AccumulateGrad gets
+        the memset every time.  Also restores dropped .grad links."""
+        if _LEGACY_SYNC or not (getattr(self, "explicit", False) and getattr(self, "g_clean", False)):
             self.G.zero_()
-            self.g_clean = trusted and not _LEGACY_SYNC
+            self.g_clean = getattr(self, "explicit", False) and not _LEGACY_SYNC
+        self.relink_grads()
+
+    def fresh_grads_if_dropped(self):
+        """torch semantics of `p.grad = None` (model.zero_grad(), a stock optimizer's zero_grad()): the next backward REPLACES the
+        gradient.  The kernels always accumulate into G, so a dropped link means: clear G, link again.  Called at the start of a
+        training forward and again by the first node of backward (the reference zeroes between the two, crog_engine.py:77).
+        Gradients that are still linked are left alone: forward/backward twice without zero_grad accumulates, as in torch."""
+        if self.grads_dropped():
+            self.zero_grad()
 
     def invalidate_shadow(self):
         """The fp32 parameters changed behind the store's back (load_state_dict, a foreign optimizer, in-place edits)."""

@@ -183,3 +183,55 @@ def synthetic_ssg_targets(B: int, size: int, num_classes: int, seed: int = 1234,
     mv = lambda t: t.to(device)
     return dict(bboxes=[mv(t) for t in out["bboxes"]], labels=[mv(t) for t in out["labels"]], ins_masks=[mv(t) for t in out["ins_masks"]],
                 sem_mask=mv(out["sem_mask"]), grasp_masks={k: [mv(t) for t in v] for k, v in out["grasp_masks"].items()})
+
+
+# ---- CLIP ViT tower (BASELINE config 4) and the pretrained-CLIP load path -----------------------------------------
+def vit_seeded_state(shapes: Dict[str, Iterable[int]], seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Name-seeded weights of a VisionTransformer (keys as its own state_dict: `conv1.weight`, `class_embedding`, ...); the
+    recipe sees them under the `visual.` prefix they carry inside CLIP."""
+    st = seeded_state({"visual." + k: tuple(v) for k, v in shapes.items()}, seed=seed)
+    return {k[len("visual."):]: v for k, v in st.items()}
+
+
+def clip_load_arch():
+    """A small ModifiedResNet CLIP whose architecture is fully recoverable from tensor shapes (clip.py:503-542)."""
+    return dict(embed_dim=64, image_resolution=224, vision_layers=(1, 2, 1, 1), vision_width=16, vision_patch_size=None,
+                context_length=77, vocab_size=300, transformer_width=128, transformer_heads=2, transformer_layers=2)
+
+
+def synthetic_clip_checkpoint(arch: dict, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """State dict with the key names and shapes of an OpenAI CLIP archive for `arch` (no `visual.attnpool.connect.*`: that
+    module is a CRIS/CROG addition, clip.py:76-78), plus the three metadata entries real archives carry.  Values are not
+    fp16-representable on purpose, so a test can tell which tensors went through the fp16 round trip."""
+    from .model.clip import build_model
+    proto = build_model(arch, arch["context_length"])
+    sd = {}
+    for k, v in proto.state_dict().items():
+        if ".connect." in k:
+            continue
+        t = seeded_tensor("ckpt::" + k, tuple(v.shape), seed)
+        if t.is_floating_point():
+            t = t * (1.0 + 2.0 ** -15) + 2.0 ** -20
+        sd[k] = t
+    sd["input_resolution"] = torch.tensor(arch["image_resolution"])
+    sd["context_length"] = torch.tensor(arch["context_length"])
+    sd["vocab_size"] = torch.tensor(arch["vocab_size"])
+    return sd
+
+
+def save_clip_archive(sd: Dict[str, torch.Tensor], path: str):
+    """Write `sd` as a TorchScript archive (what cfg.clip_pretrain names, crog.py:20): a scripted module tree whose state_dict()
+    is exactly `sd` (floating tensors as parameters, the rest as buffers)."""
+    root = torch.nn.Module()
+    for key, val in sd.items():
+        mod = root
+        *parts, leaf = key.split(".")
+        for p in parts:
+            if not hasattr(mod, p):
+                mod.add_module(p, torch.nn.Module())
+            mod = getattr(mod, p)
+        if val.is_floating_point() and not leaf.startswith("running_"):
+            mod.register_parameter(leaf, torch.nn.Parameter(val.clone(), requires_grad=False))
+        else:
+            mod.register_buffer(leaf, val.clone())
+    torch.jit.save(torch.jit.script(root), path)

@@ -128,6 +128,7 @@ int crog_bn_apply_stats(int dtype, const void* z, int64_t ldz, const float* sums
                         float eps, float* scale_shift, float* mean_invstd, const void* res, int64_t ldr, int relu, void* y,
                         int64_t ldy, int64_t M, int C, void* relu_mask, crog_stream_t stream);
 int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, int sums_is_zero, crog_stream_t stream);
+/* a[c] += sums[c][0]; b[c] += sums[c][1]: a and b are parameter-gradient vectors, and gradients accumulate until zero_grad */
 int crog_split_pairs(const float* sums, int C, float* a, float* b, crog_stream_t stream);
 int crog_bn_finalize(const float* sums, float count, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps, int C,
@@ -149,8 +150,8 @@ int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, 
 /* dz = gamma*invstd*(g - sums.g/count - xhat*sums.gx/count);  dres = g when dres != NULL.
  * replicas (partial) / sum_rows (apply) = 0: `partial` is the per-block slab [blocks][C][2] and `sums` the reduced [C][2].
  * replicas = R > 0: the partial kernel adds atomically into a PRE-ZEROED [R][C][2]; the apply kernel is handed the same buffer
- * with sum_rows = R, adds the rows up itself and (dgamma/dbeta != NULL) stores the parameter gradients times param_grad_scale —
- * no reduction launch.  Under SyncBatchNorm the rows are all-reduced first, so the totals are GLOBAL sums: storing them with
+ * with sum_rows = R, adds the rows up itself and (dgamma/dbeta != NULL) ADDS the parameter gradients times param_grad_scale to
+ * dgamma/dbeta (gradient buffers accumulate until zero_grad, as torch's .grad does) — no reduction launch.  Under SyncBatchNorm the rows are all-reduced first, so the totals are GLOBAL sums: storing them with
  * param_grad_scale = 1/world gives every rank the value DDP's gradient averaging would have produced from the local sums
  * (mean over ranks of the local sums == global sum / world), and no separate local-sum pass is needed. */
 int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
@@ -158,7 +159,8 @@ int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, in
                       float count, const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres,
                       int64_t M, int C, int sum_rows, float* dgamma, float* dbeta, float param_grad_scale,
                       const void* relu_mask, crog_stream_t stream);
-/* single-replica fast paths: slab [nparts][C][2] -> (reduce + finalize) / (reduce + split into two vectors) in one launch */
+/* single-replica fast paths: slab [nparts][C][2] -> (reduce + finalize) / (reduce + split) in one launch; crog_reduce_split
+ * stores the reduced pairs to `sums` (optional) and ADDS the two halves to the gradient vectors a / b (optional) */
 int crog_bn_reduce_finalize(const float* partial, int nparts, float count, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int C,
                             float* scale_shift, float* mean_invstd, crog_stream_t stream);
@@ -295,6 +297,10 @@ int crog_conv3_dgrad_weights(int dtype, const void* src, void* dst, const int64_
 /* dst[r][c] = c < cols_src ? src[r][c] : 0 for c < cols_dst (fp32 source) */
 int crog_cast_pad2d(int dtype_dst, const float* src, int64_t lds, int cols_src, void* dst, int64_t ldd,
                     int cols_dst, int64_t rows, crog_stream_t stream);
+/* dst[r][c] += src[r][c] for c < cols (fp32): the gradient of a zero-padded compute copy of a ragged-Cin weight (stem 27 -> 32
+ * columns, CoordConv 514 -> 544 channels; clip.py:165, layers.py:38-41) added back into the parameter's gradient. */
+int crog_add_pad2d(const float* src, int64_t lds, float* dst, int64_t ldd, int cols, int64_t rows,
+                   crog_stream_t stream);
 int crog_cast_f32_to_bf16(const float* src, void* dst, int64_t n, crog_stream_t stream);
 int crog_cast_to_f32(int dtype, const void* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C,
                      crog_stream_t stream);

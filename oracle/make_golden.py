@@ -64,12 +64,12 @@ def build_reference(cfg, ref_model, ref_clip):
     return model, groups
 
 
-def run_case(name, cfg, B, seed, ref_model, ref_clip, store_intermediates):
+def run_case(name, cfg, B, seed, ref_model, ref_clip, store_intermediates, residual_gain=1.0):
     torch.manual_seed(0)
     torch.set_num_threads(8)
     model, groups = build_reference(cfg, ref_model, ref_clip)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    model.load_state_dict(seeded_state(shapes, seed=seed))
+    model.load_state_dict(seeded_state(shapes, seed=seed, residual_gain=residual_gain))
     batch = synthetic_batch(B, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + seed)
     out = {}
     inter = {}
@@ -86,7 +86,7 @@ def run_case(name, cfg, B, seed, ref_model, ref_clip, store_intermediates):
     if store_intermediates:
         out.update(x2=vis[0], x3=vis[1], x4=vis[2], word_feat=wfeat, state=state)
     # the encode_* calls above updated BN running stats once; reload so that the recorded step is step 1
-    model.load_state_dict(seeded_state(shapes, seed=seed))
+    model.load_state_dict(seeded_state(shapes, seed=seed, residual_gain=residual_gain))
     model.zero_grad()
     preds, tgts, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
     loss.backward()
@@ -123,7 +123,7 @@ def run_case(name, cfg, B, seed, ref_model, ref_clip, store_intermediates):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **{k: v.detach().numpy() for k, v in out.items()})
     meta = dict(param_names=names, shapes={k: list(v) for k, v in shapes.items()},
                 group_backbone=len(groups[0]["params"]), group_head=len(groups[1]["params"]),
-                group_lrs=[groups[0]["initial_lr"], groups[1]["initial_lr"]], seed=seed, B=B,
+                group_lrs=[groups[0]["initial_lr"], groups[1]["initial_lr"]], seed=seed, B=B, residual_gain=residual_gain,
                 bn_keys=sorted(bn_sum))
     json.dump(meta, open(os.path.join(GOLD, name + ".json"), "w"))
     print(name, "loss", float(loss.detach()), "items", out["loss_items"].tolist(), flush=True)
@@ -248,6 +248,103 @@ def ssg_fixture(name, cfg, B, seed):
     print(name, "loss", float(loss), "anchors", len(ev["anchors"]) // 4, flush=True)
 
 
+def sampled(t, stride):
+    """Fixed-stride sample of a large tensor + its sum / abs-sum (fixtures stay small; the test samples the same way)."""
+    f = t.detach().flatten()
+    return f[::stride].clone(), torch.stack([f.double().sum(), f.double().abs().sum()])
+
+
+def vit_full_fixture(ref_clip):
+    """BASELINE config 4 at full depth: the reference's VisionTransformer as CLIP ViT-B/16 builds it (clip.py:354-361:
+    input_resolution 224, patch 16, width 768, 12 layers, 12 heads, output_dim 512), B = 2.  Weights come from the name-seeded
+    recipe (86 M values are not committed).  Pinned: the full output, every parameter-gradient norm, the head of every gradient."""
+    torch.manual_seed(0)
+    m = ref_clip.VisionTransformer(224, 16, 768, 12, 12, 512).train()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    from crog_amd.testing import vit_seeded_state
+    m.load_state_dict(vit_seeded_state(shapes, seed=21))
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(2101))
+    o = m(img)
+    w = torch.linspace(-1, 1, o.numel()).view_as(o)
+    (o * w).sum().backward()
+    fx = {"out": o.detach()}
+    names = [n for n, _ in m.named_parameters()]
+    fx["grad_norms"] = torch.tensor([float(p.grad.norm()) for _, p in m.named_parameters()])
+    for n, p in m.named_parameters():
+        fx["grad::" + n] = p.grad.flatten()[:64].clone()
+    np.savez_compressed(os.path.join(GOLD, "vit_b16.npz"), **{k: v.detach().numpy() for k, v in fx.items()})
+    json.dump(dict(param_names=names, shapes={k: list(v) for k, v in shapes.items()}, seed=21, img_seed=2101, B=2),
+              open(os.path.join(GOLD, "vit_b16.json"), "w"))
+    print("vit_b16 fixture: out", tuple(o.shape), "absmax", float(o.abs().max()), flush=True)
+
+
+def ssg_full_fixture(name, cfg, B, seed, stride=29):
+    """BASELINE config 5 at full depth (ssg_r50.yaml: ResNet-50 [3,4,6,3], 544 x 544, RGB-D): same protocol as ssg_fixture, with
+    the large prediction tensors pinned through fixed-stride samples + (sum, abs-sum) instead of in full."""
+    import model.ssg as ref_ssg
+    torch.manual_seed(0)
+    m = ref_ssg.SSG(cfg)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(seeded_state(shapes, seed=seed))
+    batch = synthetic_ssg_batch(B, cfg.img_size, cfg.with_depth, seed=1234 + seed)
+    img = torch.cat([batch["rgb"], batch["depth"]], 1) if cfg.with_depth else batch["rgb"]
+    m.train()
+    x = m.backbone(img)
+    x = m.fpn(x[1:4])
+    protos = m.proto_net(x[0]).permute(0, 2, 3, 1).contiguous()
+    per = [m.prediction_layers(a) for a in x]
+    raw = {k: torch.cat([p[i] for p in per], dim=1) for i, k in enumerate(SSG_OUTPUTS[:4])}
+    raw["protos"] = protos
+    raw["seg_pred"] = m.semantic_seg_conv(x[0])
+    loss = ssg_surrogate_loss(raw, seed)
+    loss.backward()
+    out = {"loss": loss.detach()}
+    for k, v in raw.items():
+        out["sample::" + k], out["sums::" + k] = sampled(v, stride)
+        out["shape::" + k] = torch.tensor(v.shape)
+    names = [n for n, _ in m.named_parameters()]
+    out["grad_norms"] = torch.tensor([float(p.grad.norm()) for _, p in m.named_parameters()])
+    for n, p in m.named_parameters():
+        out["grad::" + n] = p.grad.flatten()[:64].clone()
+    bn = {k: float(v.double().sum()) for k, v in m.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    out["bn_running_checksum"] = torch.tensor([bn[k] for k in sorted(bn)])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **{k: v.detach().numpy() for k, v in out.items()})
+    json.dump(dict(param_names=names, shapes={k: list(v) for k, v in shapes.items()}, seed=seed, B=B, bn_keys=sorted(bn), stride=stride,
+                   cfg={k: v for k, v in vars(cfg).items()}), open(os.path.join(GOLD, name + ".json"), "w"))
+    print(name, "loss", float(loss), {k: tuple(v.shape) for k, v in raw.items()}, flush=True)
+
+
+def clip_load_fixture(ref_clip):
+    """Pretrained-CLIP load path (clip.py:477-556, crog.py:20-23): a synthetic checkpoint with CLIP key names (small RN
+    architecture, no `attnpool.connect.*` keys, as real CLIP archives) goes through the reference's build_model(load_weights=True)
+    and .float().  Recorded per key of the resulting module: 0 = the checkpoint value survived exactly, 1 = it equals the fp16
+    round trip of the checkpoint value, 2 = not in the checkpoint (kept its random init) + whether that init is fp16-representable;
+    plus the architecture the reference inferred."""
+    from crog_amd.testing import clip_load_arch, synthetic_clip_checkpoint
+    arch = clip_load_arch()
+    sd = synthetic_clip_checkpoint(arch, seed=31)
+    torch.manual_seed(5)
+    model = ref_clip.build_model(dict(sd), 20, True).float()
+    flags = {}
+    for k, v in model.state_dict().items():
+        if k not in sd:
+            flags[k] = [2, bool(torch.equal(v, v.half().float()))]
+        elif torch.equal(v, sd[k].float()) and not torch.equal(sd[k].float(), sd[k].half().float()):
+            flags[k] = [0, False]
+        elif torch.equal(v, sd[k].half().float()):
+            flags[k] = [1, True]
+        else:
+            raise AssertionError(("unexpected transformation", k))
+    v = model.visual
+    inferred = dict(embed_dim=model.text_projection.shape[1], image_resolution=v.input_resolution,
+                    vision_layers=[len(v.layer1), len(v.layer2), len(v.layer3), len(v.layer4)], vision_width=v.layer1[0].conv1.weight.shape[0],
+                    context_length=model.context_length, vocab_size=model.vocab_size, transformer_width=model.transformer.width,
+                    transformer_heads=model.transformer.resblocks[0].attn.num_heads, transformer_layers=model.transformer.layers,
+                    training=model.training)
+    json.dump(dict(flags=flags, arch=inferred, seed=31), open(os.path.join(GOLD, "clip_load.json"), "w"))
+    print("clip_load fixture:", {f: sum(1 for x in flags.values() if x[0] == f) for f in (0, 1, 2)}, inferred, flush=True)
+
+
 def shapes_only(ref_clip):
     """Parameter names/shapes of the real CLIP RN50 and ViT-B/16 towers + CROG heads (names are the checkpoint contract)."""
     vit = ref_clip.CLIP(512, 224, 12, 768, 16, 77, 20, 49408, 512, 8, 12)
@@ -257,7 +354,7 @@ def shapes_only(ref_clip):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_clip, ref_crog, ref_layers = import_reference()
-    which = sys.argv[1:] or ["tiny", "ops", "vit", "ssg", "shapes", "full"]
+    which = sys.argv[1:] or ["tiny", "ops", "vit", "ssg", "shapes", "full", "damped", "vitfull", "ssgfull", "clipload"]
     if "tiny" in which:
         run_case("tiny_crog", tiny_cfg(), B=4, seed=3, ref_model=ref_model, ref_clip=ref_clip, store_intermediates=True)
         run_case("tiny_crog_nomask", tiny_cfg(use_grasp_masks=False), B=4, seed=4, ref_model=ref_model, ref_clip=ref_clip,
@@ -269,6 +366,18 @@ def main():
     if "ssg" in which:
         ssg_fixture("ssg_tiny_rgbd", ssg_tiny_cfg(), B=2, seed=6)
         ssg_fixture("ssg_tiny_rgb", ssg_tiny_cfg(with_depth=False), B=2, seed=7)
+    if "vitfull" in which:
+        vit_full_fixture(ref_clip)
+    if "ssgfull" in which:
+        from crog_amd.testing import ssg_cfg
+        ssg_full_fixture("ssg_r50_rgbd", ssg_cfg(), B=2, seed=8)
+    if "clipload" in which:
+        clip_load_fixture(ref_clip)
+    if "damped" in which:
+        # BASELINE config 1 on reference-conditioned weights: every Bottleneck's last BatchNorm scale small (clip.py:402-408 zero-inits
+        # them; 0.25 keeps the residual branches alive) -> the trunk does not amplify rounding, 1e-3 ABSOLUTE is the test's bound
+        run_case("crog_r50_b2_damped", make_cfg(dropout=0.0), B=2, seed=9, ref_model=ref_model, ref_clip=ref_clip,
+                 store_intermediates=False, residual_gain=0.25)
     if "shapes" in which:
         shapes_only(ref_clip)
     if "full" in which:

@@ -1,0 +1,77 @@
+"""Child process of tests/test_ddp2_gpu.py: one rank of a world-size-`world` data-parallel run of the tiny CROG on cuda:0
+(every rank shares the one GPU of the test box; the collectives go through gloo on CUDA tensors), or the single-process run
+on the whole batch when world == 1.  Mirrors train_crog.py:113-121,154-156 + crog_engine.py:72-84: SyncBatchNorm conversion,
+DistributedDataParallel(find_unused_parameters=True), Adam, forward -> zero_grad -> backward -> step, twice."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, out_dir, dtype_name, gain = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], float(sys.argv[6])
+    from crog_amd.model import build_crog
+    from crog_amd.optim import FusedAdam
+    from crog_amd.parallel import DistributedDataParallel, convert_sync_batchnorm
+    from crog_amd.runtime import RT
+    from crog_amd.testing import seeded_state, synthetic_batch, tiny_cfg
+    torch.cuda.set_device(0)
+    dtype = torch.float32 if dtype_name == "f32" else torch.bfloat16
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "tiny_crog.json")))
+    cfg = tiny_cfg()
+    model, groups = build_crog(cfg)
+    shapes = {k: tuple(v) for k, v in meta["shapes"].items()}
+    # ranks > 0 start from DIFFERENT weights: DistributedDataParallel's constructor must hand them rank 0's (train_crog.py:154)
+    model.load_state_dict(seeded_state(shapes, seed=meta["seed"] + 100 * rank, residual_gain=gain))
+    model = model.cuda()
+    model.compute_dtype = dtype
+    model.prepare()
+    net = model
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        convert_sync_batchnorm(model)
+        assert RT.comm is not None and RT.comm.world_size == world
+        net = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True, bucket_cap_mb=0.25)
+    opt = FusedAdam(groups, lr=1e-4, store=model.store)
+    full = synthetic_batch(meta["B"], cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + meta["seed"])
+    per = meta["B"] // world
+    b = {k: v[rank * per:(rank + 1) * per].cuda() for k, v in full.items()}
+    net.train()
+    res = {}
+    names = meta["param_names"]
+    for step in range(2):
+        RT.manual_seed(11)
+        preds, tgts, loss, _ = net(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+        opt.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        if step == 0:
+            params = dict(model.named_parameters())
+            res["preds"] = torch.cat([p.float() for p in preds], 1).cpu().numpy()
+            res["loss"] = np.float64(float(loss.detach()))
+            res["grad_norms"] = np.array([float(params[n].grad.norm()) for n in names])
+            res["G"] = model.store.G.cpu().numpy()
+            sd = model.state_dict()
+            res["bn_checksum"] = np.array([float(sd[k].double().sum()) for k in meta["bn_keys"]])
+            if world > 1:
+                res["n_buckets"] = np.int64(len(net.reducer.buckets))
+        opt.step()
+    torch.cuda.synchronize()
+    res["P"] = model.store.P.cpu().numpy()
+    sd = model.state_dict()
+    res["bn_final"] = np.concatenate([sd[k].float().cpu().numpy().ravel() for k in meta["bn_keys"]])
+    np.savez(os.path.join(out_dir, f"rank{rank}_of{world}.npz"), **res)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

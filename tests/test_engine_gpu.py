@@ -1,0 +1,195 @@
+"""The step driver itself (engine/crog_engine.py:17-122 -> crog_amd/engine.py) and torch's gradient conventions on the flat store:
+GradScaler-enabled + clip_grad_norm_ branch of `train_with_grasp` against torch.optim.Adam + clip_grad_norm_ on the same
+gradients; the reference's statement order (forward -> optimizer.zero_grad() -> backward -> step) with a STOCK torch optimizer whose
+zero_grad() sets .grad to None; gradient accumulation over two forward/backward pairs."""
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from crog_amd.testing import seeded_state, synthetic_batch, tiny_cfg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _meta():
+    return json.load(open(os.path.join(GOLD, "tiny_crog.json")))
+
+
+def _build(cfg, meta, gain=0.25):
+    from crog_amd.model import build_crog
+    model, groups = build_crog(cfg)
+    model.load_state_dict(seeded_state({k: tuple(v) for k, v in meta["shapes"].items()}, seed=meta["seed"], residual_gain=gain))
+    model = model.cuda()
+    model.compute_dtype = torch.float32      # pinned: the comparison below is between two fp32 runs
+    model.prepare().train()
+    return model, groups
+
+
+def _loader(cfg, n):
+    """Batches in the collate format train_with_grasp unpacks (crog_engine.py:49-66): CPU tensors, masks [B, H, W]."""
+    out = []
+    for i in range(n):
+        b = synthetic_batch(4, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=500 + i)
+        out.append(dict(img=b["img"], word_vec=b["word"], mask=b["mask"][:, 0],
+                        grasp_masks={k: b[k][:, 0] for k in ("qua", "sin", "cos", "wid")}))
+    return out
+
+
+def test_train_with_grasp_gradscaler_and_clipping_match_torch_adam():
+    from torch.optim.lr_scheduler import MultiStepLR
+    from crog_amd.engine import train_with_grasp
+    from crog_amd.optim import FusedAdam
+    from crog_amd.runtime import RT
+    meta = _meta()
+    cfg = tiny_cfg()
+    args = SimpleNamespace(print_freq=2, epochs=1, max_norm=1.0)
+    loader = _loader(cfg, 3)
+
+    # ---- side A: the driver under test, GradScaler ENABLED, max_norm > 0 -----------------------------------------------
+    model, groups = _build(cfg, meta)
+    opt = FusedAdam(groups, lr=1e-3, store=model.store)
+    sched = MultiStepLR(opt, milestones=[35], gamma=0.1)
+    scaler = torch.amp.GradScaler("cuda", enabled=True)
+    lines = []
+    RT.manual_seed(5)
+    train_with_grasp(loader, model, opt, sched, scaler, 1, args, log=lines.append)
+    torch.cuda.synchronize()
+    assert len(lines) == 2 and "Loss" in lines[0] and "IoU" in lines[0] and "Prec@50" in lines[1]      # print_freq = 2, 3 batches
+    assert scaler.get_scale() == 65536.0 and opt._step == 3                                             # no overflow step was skipped
+    got = {k: v.detach().clone() for k, v in model.named_parameters()}
+    bn_a = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k}
+
+    # ---- side B: same gradients (HIP forward/backward, unscaled), torch's own clip_grad_norm_ + torch.optim.Adam -----------
+    model_b, _ = _build(cfg, meta)
+    names = [k for k, _ in model_b.named_parameters()]
+    ref_p = {k: torch.nn.Parameter(v.detach().clone()) for k, v in model_b.named_parameters()}
+    ref_groups = [{"params": [ref_p[k] for k in names if k.startswith("backbone") and "positional_embedding" not in k]},
+                  {"params": [ref_p[k] for k in names if not (k.startswith("backbone") and "positional_embedding" not in k)]}]
+    ref_opt = torch.optim.Adam(ref_groups, lr=1e-3)
+    norms = []
+    for data in loader:
+        gm = data["grasp_masks"]
+        _, _, loss, _ = model_b(data["img"].cuda(), data["word_vec"].cuda(), data["mask"].cuda().unsqueeze(1), gm["qua"].cuda().unsqueeze(1),
+                                gm["sin"].cuda().unsqueeze(1), gm["cos"].cuda().unsqueeze(1), gm["wid"].cuda().unsqueeze(1))
+        model_b.zero_grad()             # set_to_none between forward and backward (crog_engine.py:77 with a stock optimizer)
+        loss.backward()
+        torch.cuda.synchronize()
+        cur = dict(model_b.named_parameters())
+        for k in names:
+            ref_p[k].grad = cur[k].grad.detach().clone()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(list(ref_p.values()), args.max_norm)))
+        ref_opt.step()
+        sd = model_b.state_dict()
+        sd.update({k: ref_p[k].detach() for k in names})
+        model_b.load_state_dict(sd)
+    assert max(norms) > args.max_norm, norms            # the clipping branch really clipped
+    worst = max((got[k] - ref_p[k].detach()).abs().max().item() for k in names)
+    print(f"train_with_grasp (GradScaler on, max_norm 1.0) vs torch Adam + clip_grad_norm_: max parameter difference {worst:.2e}; "
+          f"gradient norms before clipping {['%.2f' % n for n in norms]}")
+    # Adam at lr 1e-3 moves every weight by ~1e-3 per step; the two sides differ only by fp32 summation order in the weight gradients
+    assert worst < 2e-5, worst
+    for k, v in bn_a.items():
+        assert torch.allclose(v, model_b.state_dict()[k], rtol=1e-4, atol=1e-5), k
+
+
+def test_reference_statement_order_with_stock_torch_adam():
+    """crog_engine.py:72-84 with torch.optim.Adam: forward -> optimizer.zero_grad() [sets .grad = None] -> backward -> step.
+    The flat store must hand the optimizer fresh, linked gradients; the result equals FusedAdam's."""
+    from crog_amd.optim import FusedAdam
+    meta = _meta()
+    cfg = tiny_cfg()
+    b = {k: v.cuda() for k, v in synthetic_batch(4, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=77).items()}
+
+    def steps(make_opt, n=2):
+        model, groups = _build(cfg, meta)
+        opt = make_opt(model, groups)
+        for _ in range(n):
+            _, _, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+            opt.zero_grad()
+            loss.backward()
+            live = [p.grad is not None for _, p in model.named_parameters()]
+            opt.step()
+        torch.cuda.synchronize()
+        return model, live
+
+    m_t, live = steps(lambda m, g: torch.optim.Adam(g, lr=1e-3))
+    names = [n for n, _ in m_t.named_parameters()]
+    # every parameter the forward uses has a gradient again after backward; `logit_scale` (never used, clip.py:385) stays None, as in torch
+    assert [n for n, ok in zip(names, live) if not ok] == ["backbone.logit_scale"]
+    init = seeded_state({k: tuple(v) for k, v in meta["shapes"].items()}, seed=meta["seed"], residual_gain=0.25)
+    moved = (m_t.state_dict()["neck.f1_v_proj.0.weight"].cpu() - init["neck.f1_v_proj.0.weight"]).abs().max().item()
+    assert moved > 1e-4, "torch.optim.Adam silently skipped the parameters"
+    m_f, _ = steps(lambda m, g: FusedAdam(g, lr=1e-3, store=m.store))
+    worst = max((p.detach() - q.detach()).abs().max().item() for (_, p), (_, q) in zip(m_t.named_parameters(), m_f.named_parameters()))
+    print(f"torch.optim.Adam (set_to_none zero_grad) vs FusedAdam after 2 steps: max parameter difference {worst:.2e}")
+    assert worst < 2e-5
+
+
+def test_gradients_accumulate_until_zero_grad():
+    meta = _meta()
+    cfg = tiny_cfg()
+    model, _ = _build(cfg, meta)
+    b = {k: v.cuda() for k, v in synthetic_batch(4, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=78).items()}
+
+    def fwd_bwd():
+        sd = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+        _, _, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+        loss.backward()
+        torch.cuda.synchronize()
+        model.load_state_dict({**model.state_dict(), **sd})   # same BatchNorm running statistics for the second pass (not that they matter in train mode)
+    model.store.zero_grad()
+    fwd_bwd()
+    g1 = model.store.G.clone()
+    fwd_bwd()
+    g2 = model.store.G.clone()
+    rel = ((g2 - 2 * g1).norm() / (2 * g1).norm()).item()
+    print(f"two forward/backward pairs without zero_grad: |G2 - 2 G1| / |2 G1| = {rel:.2e}")
+    assert rel < 1e-4
+    for n, p in model.named_parameters():       # every writer accumulates, including the norm layers' (sum, sum) vectors
+        if n.endswith(("bn1.weight", "ln_final.weight", "norm.weight", "txt.bias")) and float(p.grad.norm()) > 0:
+            o = model.store.off(p)
+            assert torch.allclose(g2[o:o + p.numel()], 2 * g1[o:o + p.numel()], rtol=2e-3, atol=1e-6), n
+    model.zero_grad()                           # set_to_none: the next backward REPLACES
+    fwd_bwd()
+    rel1 = ((model.store.G - g1).norm() / g1.norm()).item()
+    assert rel1 < 1e-4 and all(p.grad is not None for n, p in model.named_parameters() if n != "backbone.logit_scale")
+
+
+def test_decoder_return_intermediate_outputs():
+    """layers.py:259-274: with return_intermediate the decoder returns the final-norm'd output of EVERY layer; the last entry is what
+    the plain call returns.  CROG.forward fails on that list exactly as the reference does (crog.py:69)."""
+    from crog_amd.model import build_crog
+    meta = _meta()
+    cfg = tiny_cfg(num_layers=2, intermediate=True)
+    model, _ = build_crog(cfg)
+    model = model.cuda()
+    model.compute_dtype = torch.float32
+    model.prepare().train()
+    b = {k: v.cuda() for k, v in synthetic_batch(2, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=79).items()}
+    with pytest.raises(AttributeError):
+        model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+    vis = model.backbone.image_features(b["img"], torch.float32)
+    wfeat, state = model.backbone.text_features(b["word"], torch.float32)
+    fq = model.neck(vis, state)
+    pad = (b["word"] == 0).contiguous()
+    outs = model.decoder(fq, wfeat, pad)
+    assert isinstance(outs, list) and len(outs) == 2 and all(o.shape == fq.shape for o in outs)
+    model.decoder.return_intermediate = False
+    last = model.decoder(fq, wfeat, pad)
+    assert torch.allclose(outs[-1], last, atol=1e-6)
+    assert not torch.allclose(outs[0], last, atol=1e-3)
+    # the shared final LayerNorm was applied twice: its gradient is the SUM of both uses
+    model.decoder.return_intermediate = True
+    model.store.zero_grad()
+    o2 = model.decoder(fq.detach(), wfeat.detach(), pad)
+    (o2[0].float().sum() + 2.0 * o2[1].float().sum()).backward()
+    torch.cuda.synchronize()
+    assert float(model.decoder.norm.bias.grad.sum()) == pytest.approx(3.0 * o2[0].numel() / o2[0].shape[-1], rel=1e-4)

@@ -1,0 +1,235 @@
+"""Full-depth parity on the MI355X for the BASELINE configurations (BASELINE.json `configs`), against fixtures captured from the
+reference itself at full depth (oracle/make_golden.py: `damped`, `vitfull`, `ssgfull`):
+
+  config 1  CROG-R50, 2 x 416 x 416 + 20 tokens, fp32          -> 1e-3 ABSOLUTE on the five logit maps, loss 1e-4
+  config 2  CROG-R50 bf16, B = 32, 416 x 416, dropout 0.1        -> the benchmarked step itself: >= 3 optimizer steps, finite, and its
+                                                                    dropout-0 twin tracks the fp32 HIP path (loss 1 %, BN statistics 1e-2)
+  config 4  CLIP ViT-B/16 image tower, 224 x 224, 12 layers      -> output 1e-3, every parameter gradient
+  config 5  SSG-R50, 544 x 544 RGB-D, ResNet-50 [3, 4, 6, 3]     -> raw predictions 1e-3 (samples + sums), gradients, BN statistics
+(config 3 is config 2 on 8 GPUs: covered by the world-size-2 test in tests/test_ddp2_gpu.py and the driver's scaling run).
+"""
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from crog_amd.testing import (SSG_OUTPUTS, make_cfg, seeded_state, ssg_surrogate_loss, synthetic_batch, synthetic_ssg_batch,  # noqa: E402
+                              vit_seeded_state)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+NAMES = ["ins", "qua", "sin", "cos", "wid"]
+
+
+def load_case(name):
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    return {k: torch.from_numpy(d[k]) for k in d.files}, meta
+
+
+def err(a, b):
+    return (a.detach().float().cpu() - b.detach().float().cpu()).abs().max().item()
+
+
+def test_config1_crog_r50_fp32_absolute_1e3_on_reference_conditioned_weights():
+    """BASELINE config 1 with the weights conditioned as the reference conditions them: the last BatchNorm scale of every
+    Bottleneck small (clip.py:402-408 zero-initialises it; 0.25 here so the residual branches still carry signal).  With that the
+    trunk does not amplify rounding and north_star's bound applies as written: |logit error| < 1e-3 ABSOLUTE, loss within 1e-4."""
+    from crog_amd.model import build_crog
+    g, meta = load_case("crog_r50_b2_damped")
+    assert meta["residual_gain"] == 0.25
+    cfg = make_cfg(dropout=0.0)
+    model, _ = build_crog(cfg)
+    model.load_state_dict(seeded_state({k: tuple(v) for k, v in meta["shapes"].items()}, seed=meta["seed"], residual_gain=meta["residual_gain"]))
+    model = model.cuda()
+    model.compute_dtype = torch.float32
+    model.prepare().train()
+    b = {k: v.cuda() for k, v in synthetic_batch(meta["B"], cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + meta["seed"]).items()}
+    preds, tgts, loss, loss_dict = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+    loss.backward()
+    torch.cuda.synchronize()
+    errs = {nm: err(preds[i], g["pred_" + nm]) for i, nm in enumerate(NAMES)}
+    mags = {nm: float(g["pred_" + nm].abs().max()) for nm in NAMES}
+    dl = abs(float(loss.detach()) - float(g["loss_total"]))
+    print("config-1 (damped) max |dlogit|:", {k: f"{v:.2e}" for k, v in errs.items()}, "max |logit|:", {k: f"{v:.2f}" for k, v in mags.items()},
+          f"|dloss| {dl:.2e}")
+    for nm in NAMES:
+        assert errs[nm] < 1e-3, (nm, errs)
+        assert err(tgts[NAMES.index(nm)], g["tgt_" + nm]) == 0
+    assert dl < 1e-4, dl
+    items = [loss_dict[k] for k in ("m_ins", "m_qua", "m_sin", "m_cos", "m_wid")]
+    assert np.allclose(items, g["loss_items"].numpy(), atol=1e-4)
+    params = dict(model.named_parameters())
+    names = meta["param_names"]
+    gn = torch.tensor([float(params[n].grad.norm()) for n in names])
+    ref = torch.where(g["grad_norms"] < 0, torch.zeros_like(g["grad_norms"]), g["grad_norms"])
+    # B = 2: neck.txt_proj's BatchNorm1d normalises over two samples, its backward is ill-conditioned (see test_model_gpu.py) and
+    # everything upstream of it on the text side inherits that; image / neck / decoder / head gradients are held to 2 %
+    text_side = torch.tensor([("transformer" in n or "token_embedding" in n or "text_projection" in n or "ln_final" in n
+                               or n == "backbone.positional_embedding" or "txt_proj" in n) for n in names])
+    rel = (gn - ref).abs() / (ref + 1e-6)
+    print("config-1 (damped) gradient norms: worst relative error image side %.2e, text side %.2e" % (float(rel[~text_side].max()), float(rel[text_side].max())))
+    bad = ((gn - ref).abs() > 2e-2 * ref + 2e-5) & ~text_side
+    assert not bad.any(), [(names[i], float(gn[i]), float(ref[i])) for i in bad.nonzero().flatten()[:8]]
+    for k in g:
+        if k.startswith("grad::"):
+            r, a = g[k], params[k[6:]].grad.detach().cpu()
+            lim = 5e-3 if k[6:].startswith(("proj.", "decoder.")) else 3e-2
+            assert float((a - r).norm() / r.norm()) < lim, (k, float((a - r).norm() / r.norm()))
+    chk = torch.tensor([float(model.state_dict()[k].double().sum()) for k in meta["bn_keys"]])
+    assert torch.allclose(chk, g["bn_running_checksum"].float(), rtol=1e-4, atol=1e-3)
+    model.eval()
+    with torch.no_grad():
+        ev = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+    for i, nm in enumerate(NAMES):
+        assert err(ev[0][i], g["eval_pred_" + nm]) < 1e-3, (nm, err(ev[0][i], g["eval_pred_" + nm]))
+
+
+def _r50_b32(dtype, dropout, steps, seed=9):
+    """CROG-R50 at the benchmark shape (B = 32, 416 x 416, 20 tokens) on damped seeded weights: `steps` train_step calls.
+    Returns per-step (loss, iou, prec) lists, the BatchNorm running statistics and the parameters after the last step."""
+    from crog_amd.engine import train_step
+    from crog_amd.model import build_crog
+    from crog_amd.optim import FusedAdam
+    from crog_amd.runtime import RT
+    cfg = make_cfg(dropout=dropout)
+    model, groups = build_crog(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(seeded_state(shapes, seed=seed, residual_gain=0.25))
+    model = model.cuda().prepare()
+    model.train()
+    opt = FusedAdam(groups, lr=cfg.base_lr, weight_decay=cfg.weight_decay, store=model.store)
+    RT.manual_seed(77)
+    batch = synthetic_batch(32, 416, cfg.word_len, cfg.clip_arch["vocab_size"], seed=4321, device="cuda")
+    hist = []
+    for _ in range(steps):
+        stats, _ = train_step(model, opt, None, batch, cfg, autocast_dtype=torch.bfloat16 if dtype == torch.bfloat16 else None)
+        hist.append(stats.tolist())
+    torch.cuda.synchronize()
+    bn = {k: v.detach().float().clone() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+    finite = bool(torch.isfinite(model.store.P).all()) and bool(torch.isfinite(model.store.G).all())
+    del model, opt
+    torch.cuda.empty_cache()
+    return hist, bn, finite
+
+
+def test_config2_crog_r50_bf16_b32_as_benchmarked():
+    """BASELINE config 2 exactly as bench.py runs it (bf16 autocast, B = 32, 416 x 416, dropout 0.1, FusedAdam, train metric):
+    three optimizer steps stay finite and the loss follows the fp32 HIP path; the dropout-0 bf16 twin is held to the fp32 HIP
+    path (itself pinned against the reference above): loss within 1 %, BatchNorm running statistics within 1e-2."""
+    h32, bn32, ok32 = _r50_b32(torch.float32, 0.0, 1)
+    h16, bn16, ok16 = _r50_b32(torch.bfloat16, 0.0, 1)
+    assert ok32 and ok16
+    l32, l16 = h32[0][0], h16[0][0]
+    print(f"B=32 416^2 step-1 loss: fp32 {l32:.5f}  bf16 {l16:.5f}  (rel {abs(l16 - l32) / abs(l32):.2e})")
+    assert abs(l16 - l32) < 1e-2 * abs(l32)
+    worst = 0.0
+    for k in bn32:
+        d = (bn16[k] - bn32[k]).abs()
+        tol = 1e-2 * bn32[k].abs() + 1e-2 * bn32[k].abs().mean() + 1e-4      # relative to the value and to the layer's scale
+        worst = max(worst, float((d / tol).max()))
+        assert bool((d <= tol).all()), (k, float(d.max()), float(bn32[k].abs().mean()))
+    print(f"BatchNorm running statistics bf16 vs fp32: worst |diff| / tolerance = {worst:.3f} over {len(bn32)} tensors")
+    hb, _, okb = _r50_b32(torch.bfloat16, 0.1, 3)
+    assert okb
+    losses = [h[0] for h in hb]
+    print("bf16 B=32 dropout 0.1, three steps (loss, IoU, Prec@50):", hb)
+    assert all(np.isfinite(h).all() for h in hb)
+    assert abs(losses[0] - l32) < 5e-2 * abs(l32)                # dropout 0.1 perturbs the decoder only
+    assert losses[2] < losses[0]                                  # Adam at lr 1e-4 on one repeated batch must descend
+    assert all(0.0 <= h[1] <= 100.0 and 0.0 <= h[2] <= 100.0 for h in hb)
+
+
+def test_config4_vit_b16_full_depth_matches_reference():
+    """BASELINE config 4: the CLIP ViT-B/16 image tower (clip.py:286-332: 224 x 224, patch 16, width 768, 12 layers, 12 heads,
+    output 512) against the reference's own forward/backward on name-seeded weights.  fp32: output within 1e-3, every
+    parameter-gradient norm within 1e-3 relative, gradient heads within 1e-3 of the gradient's scale; bf16 follows (cosine)."""
+    from crog_amd.model.blocks import bind_all
+    from crog_amd.model.clip import VisionTransformer
+    from crog_amd.runtime import ParamStore
+    fx, meta = load_case("vit_b16")
+    vit = VisionTransformer(224, 16, 768, 12, 12, 512)
+    assert [n for n, _ in vit.named_parameters()] == meta["param_names"]
+    vit.load_state_dict(vit_seeded_state({k: tuple(v) for k, v in meta["shapes"].items()}, seed=meta["seed"]))
+    store = ParamStore(vit, torch.device("cuda"))
+    store.explicit = True
+    bind_all(vit, store)
+    vit.train()
+    store.zero_grad()
+    img = torch.randn(meta["B"], 3, 224, 224, generator=torch.Generator().manual_seed(meta["img_seed"])).cuda()
+    out = vit(img, torch.float32)
+    assert tuple(out.shape) == tuple(fx["out"].shape) == (2, 196, 512)
+    e = err(out, fx["out"])
+    print(f"ViT-B/16 output max err {e:.2e} (|out| max {float(fx['out'].abs().max()):.2f})")
+    assert e < 1e-3
+    w = torch.linspace(-1, 1, out.numel(), device="cuda").view_as(out)
+    (out * w).sum().backward()
+    torch.cuda.synchronize()
+    worst_n = worst_h = 0.0
+    for i, (n, p) in enumerate(vit.named_parameters()):
+        gref = float(fx["grad_norms"][i])
+        gn = float(p.grad.norm())
+        worst_n = max(worst_n, abs(gn - gref) / (gref + 1e-9))
+        assert abs(gn - gref) <= 1e-3 * gref + 1e-6, (n, gn, gref)
+        head = fx["grad::" + n]
+        scale = max(float(head.abs().max()), gref / max(1.0, p.numel() ** 0.5))
+        eh = err(p.grad.flatten()[:64], head) / (scale + 1e-12)
+        worst_h = max(worst_h, eh)
+        assert eh < 1e-3, (n, eh)
+    print(f"ViT-B/16 gradients: worst norm error {worst_n:.2e}, worst head error / scale {worst_h:.2e} over {len(meta['param_names'])} tensors")
+    store.invalidate_shadow()
+    ob = vit(img, torch.bfloat16).float().flatten()
+    cos = torch.nn.functional.cosine_similarity(ob, out.detach().flatten(), dim=0).item()
+    assert cos > 0.999, cos
+
+
+def test_config5_ssg_r50_full_depth_matches_reference():
+    """BASELINE config 5 at the yaml's own size (ssg_r50.yaml: ResNet-50 [3, 4, 6, 3], 544 x 544, with_depth): raw predictions
+    against fixed-stride samples and sums of the reference's, surrogate-loss gradients, BatchNorm statistics."""
+    from crog_amd.model.ssg import build_ssg
+    from crog_amd.runtime import RT
+    fx, meta = load_case("ssg_r50_rgbd")
+    cfg = SimpleNamespace(**meta["cfg"])
+    assert cfg.resnet_layers == [3, 4, 6, 3] and cfg.img_size == 544 and cfg.with_depth
+    model = build_ssg(cfg)
+    assert [n for n, _ in model.named_parameters()] == meta["param_names"]
+    model.load_state_dict(seeded_state({k: tuple(v) for k, v in meta["shapes"].items()}, seed=meta["seed"]))
+    model = model.cuda()
+    model.compute_dtype = torch.float32
+    model.prepare().train()
+    batch = synthetic_ssg_batch(meta["B"], cfg.img_size, cfg.with_depth, seed=1234 + meta["seed"], device="cuda")
+    out, raw = model(batch)
+    stride = meta["stride"]
+    for k in SSG_OUTPUTS:
+        assert list(raw[k].shape) == fx["shape::" + k].tolist(), (k, raw[k].shape)
+        f = raw[k].detach().flatten()
+        e = err(f[::stride], fx["sample::" + k])
+        sums = torch.stack([f.double().sum(), f.double().abs().sum()]).cpu()
+        rs = float(((sums - fx["sums::" + k]).abs() / (fx["sums::" + k].abs() + 1.0)).max())
+        print(f"ssg-r50 {k}: sample max err {e:.2e} over {f[::stride].numel()} values, sums rel err {rs:.2e}")
+        assert e < 1e-3, (k, e)
+        assert rs < 1e-3 * max(1.0, f.numel() ** 0.5 / 100), (k, rs)
+    loss = ssg_surrogate_loss(raw, meta["seed"])
+    assert abs(float(loss) - float(fx["loss"])) < 1e-4
+    loss.backward()
+    RT.join_streams()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for i, (n, p) in enumerate(model.named_parameters()):
+        ref_norm = float(fx["grad_norms"][i])
+        gq = p.grad.detach().float().cpu()
+        worst = max(worst, abs(float(gq.norm()) - ref_norm) / (ref_norm + 1e-9))
+        assert abs(float(gq.norm()) - ref_norm) <= 1e-2 * ref_norm + 1e-6, f"grad norm {n}: {float(gq.norm())} vs {ref_norm}"
+        head = fx["grad::" + n]
+        scale = max(float(head.abs().max()), ref_norm / max(1.0, gq.numel() ** 0.5))
+        assert err(gq.flatten()[:64], head) <= 2e-2 * scale + 1e-6, f"grad {n}: {err(gq.flatten()[:64], head)} scale {scale}"
+    print(f"ssg-r50 gradient norms: worst relative error {worst:.2e} over {len(meta['param_names'])} tensors")
+    sd = model.state_dict()
+    bn = torch.tensor([float(sd[k].double().sum()) for k in meta["bn_keys"]])
+    assert torch.allclose(bn, fx["bn_running_checksum"].float(), rtol=1e-4, atol=2e-3)

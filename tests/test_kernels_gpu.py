@@ -219,9 +219,12 @@ def test_batchnorm_train_fwd_bwd(K, dt):
     mask = (y.float() > 0).float()
     (ref2 * 0 + (F.batch_norm(zt, None, None, g_, b_, True, 0.1, 1e-5) + rt) * mask).backward(dy.float())
     K.bn_bwd_partial(dy, y, z, mi, rpb, partial)
-    dbeta, dgamma = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dbeta, dgamma = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")   # gradient vectors: the kernels ADD into them
     K.reduce_split(partial, nb, C, sums, dbeta, dgamma)
     assert torch.equal(dbeta, sums[:, 0]) and torch.equal(dgamma, sums[:, 1])
+    K.reduce_split(partial, nb, C, None, dbeta, dgamma)     # second use of a shared parameter accumulates
+    assert torch.equal(dbeta, 2 * sums[:, 0]) and torch.equal(dgamma, 2 * sums[:, 1])
+    dbeta, dgamma = sums[:, 0].clone(), sums[:, 1].clone()
     dz, dres = torch.empty_like(z), torch.empty_like(z)
     K.bn_bwd_apply(dy, y, z, mi, gamma, sums, M, dz, dres)
     # ReLU sign bits written by the forward instead of re-reading y: same partial sums, dz and dres, bit for bit
@@ -244,11 +247,11 @@ def test_batchnorm_train_fwd_bwd(K, dt):
         K.bn_bwd_partial(dy, y, z, mi, rpb, acc, replicas=R)
         assert torch.allclose(acc.sum(0), sums, rtol=1e-4, atol=1e-3)
         dz2, dres2 = torch.empty_like(z), torch.empty_like(z)
-        dg2, db2 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        dg2, db2 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
         K.bn_bwd_apply(dy, y, z, mi, gamma, acc, M, dz2, dres2, sum_rows=R, dgamma=dg2, dbeta=db2)
         assert torch.allclose(db2, dbeta, rtol=1e-4, atol=1e-3) and torch.allclose(dg2, dgamma, rtol=1e-4, atol=1e-3)
         # SyncBatchNorm form: the rows hold GLOBAL totals, the parameter gradients are stored times 1 / world
-        dg4, db4 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        dg4, db4 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
         K.bn_bwd_apply(dy, y, z, mi, gamma, acc, M, dz2, dres2, sum_rows=R, dgamma=dg4, dbeta=db4, param_grad_scale=0.25)
         assert torch.allclose(db4, 0.25 * db2, rtol=1e-6, atol=1e-6) and torch.allclose(dg4, 0.25 * dg2, rtol=1e-6, atol=1e-6)
         close(dz2, dz.float(), dt, scale=1)
@@ -815,3 +818,115 @@ def test_conv3_dgrad_weights(K, dt):
         assert torch.equal(dst[o:o + co * 9 * ci], want), (co, ci)
         covered[o:o + co * 9 * ci] = True
     assert torch.all(dst[~covered] == -7.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# Production shapes (CROG-R50 at B = 32, 416 x 416: M = B*H*W rows): what bench.py actually launches.
+# The checker is fp32/fp64 torch on the same (bf16-rounded) operands; errors are normalised by the accumulation length.
+# ------------------------------------------------------------------------------------------------
+def _rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,Cin,Cout", [(346112, 64, 64), (346112, 64, 256), (346112, 256, 64), (86528, 256, 512)])
+def test_production_1x1_conv_with_statistics_and_gradients(K, dt, M, Cin, Cout):
+    """Bottleneck 1x1 convolutions of layer1 / layer2 at B = 32 (clip.py:17-18,25-26): forward with BatchNorm statistics in the
+    epilogue (atomic replica rows, stat_replicas > 1), data gradient, weight gradient with the split-K the host picks."""
+    from crog_amd.functional import stat_replicas
+    x = rnd(M, Cin, dt=dt)
+    w = (rnd(Cout, Cin, dt=dt, seed=1) * (Cin ** -0.5)).to(dt)
+    y = torch.empty(M, Cout, device="cuda", dtype=dt)
+    R = stat_replicas(K.stat_tiles(M), Cout)
+    assert R > 1
+    stats = torch.zeros(R, Cout, 2, device="cuda")
+    K.gemm(K.dcode(dt), K.A_KC, K.B_KC, x, w, y, M, Cout, Cin, Cin, Cin, Cout, col_stats=stats, stat_replicas=R)
+    ref = x.float() @ w.float().t()
+    close(y, ref, dt, scale=math.sqrt(Cin) / 4)
+    s = stats.sum(0).double()
+    assert _rel_l2(s[:, 1], (ref.double() ** 2).sum(0)) < (1e-5 if dt == torch.float32 else 2e-3)
+    assert float((s[:, 0] - ref.double().sum(0)).abs().max()) < 2e-3 * math.sqrt(M)    # column sums are O(sqrt(M)); fp32 order noise only
+    # plain slab statistics (the fp32 parity mode's form) agree with the atomic rows
+    slab = torch.zeros(K.stat_tiles(M), Cout, 2, device="cuda")
+    y2 = torch.empty_like(y)
+    K.gemm(K.dcode(dt), K.A_KC, K.B_KC, x, w, y2, M, Cout, Cin, Cin, Cin, Cout, col_stats=slab)
+    assert torch.equal(y, y2) and _rel_l2(slab.sum(0)[:, 1], s[:, 1]) < 1e-5
+    dy = rnd(M, Cout, dt=dt, seed=5)
+    dx = torch.empty(M, Cin, device="cuda", dtype=dt)
+    K.gemm(K.dcode(dt), K.A_KC, K.B_NC, dy, w, dx, M, Cin, Cout, Cout, Cin, Cin)
+    close(dx, dy.float() @ w.float(), dt, scale=math.sqrt(Cout) / 4)
+    sk = K.pick_splitk(Cout, Cin, M, 32 if dt == torch.bfloat16 else 16)
+    assert sk > 1
+    dw = torch.zeros(Cout, Cin, device="cuda")
+    K.gemm(K.dcode(dt), K.A_MC, K.B_NC, dy, x, dw, Cout, Cin, M, Cout, Cin, Cin, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+    want = (dy.double().t() @ x.double()).float()
+    r = _rel_l2(dw, want)
+    print(f"1x1 wgrad {Cin}->{Cout} M={M} splitk={sk}: rel L2 {r:.2e}")
+    assert r < (2e-6 if dt == torch.float32 else 1e-5)       # operands are exact in both dtypes; only the fp32 summation order differs
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,Kd", [(21632, 512, 512), (21632, 2048, 512), (21632, 512, 2048), (5408, 2048, 2048)])
+def test_production_linear_weight_gradient_split_k(K, dt, M, N, Kd):
+    """Decoder / attention-pool linears (layers.py:291-301, clip.py:119-139): dW[N, Kd] = dy[M, N]^T x[M, Kd], reduction 21632
+    split across blocks, bias gradient folded into the same launch."""
+    x, dy = rnd(M, Kd, dt=dt), rnd(M, N, dt=dt, seed=3)
+    sk = K.pick_splitk(N, Kd, M, 32 if dt == torch.bfloat16 else 16)
+    dw = torch.zeros(N, Kd, device="cuda")
+    db = torch.zeros(N, device="cuda")
+    K.gemm(K.dcode(dt), K.A_MC, K.B_NC, dy, x, dw, N, Kd, M, N, Kd, Kd, splitk=sk, out_mode=K.OUT_F32_ATOMIC, a_sum=db)
+    want = (dy.double().t() @ x.double()).float()
+    r = _rel_l2(dw, want)
+    print(f"linear wgrad [{N} x {Kd}] over M={M} splitk={sk}: rel L2 {r:.2e}")
+    assert r < 1e-5
+    assert _rel_l2(db, dy.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,HW,Cin,Cout", [(32, 104, 64, 64), (32, 52, 128, 128), (8, 104, 512, 256), (32, 26, 512, 512)])
+def test_production_conv3x3_fwd_dgrad_wgrad(K, dt, B, HW, Cin, Cout):
+    """3x3 convolutions at bench resolution (layer1 conv2, layer2 conv2, the projector's 512 -> 256 at 104 x 104 on a quarter of the
+    batch, the neck's 512 -> 512 at 26 x 26): forward with statistics, data gradient on the transposed weight copy, weight gradient."""
+    if dt == torch.float32 and Cin * Cout >= 512 * 256:
+        pytest.skip("fp32 checker convolution of this size takes minutes; the bf16 case covers the shape")
+    H = W = HW
+    M = B * H * W
+    x = rnd(B, H, W, Cin, dt=dt)
+    w = (rnd(Cout, 3, 3, Cin, dt=dt, seed=1) * (9 * Cin) ** -0.5).to(dt)
+    y = torch.empty(B, H, W, Cout, device="cuda", dtype=dt)
+    K.gemm(K.dcode(dt), K.A_IM2COL, K.B_KC, x, w, y, M, Cout, 9 * Cin, Cin, 9 * Cin, Cout, conv=(H, W, Cin))
+    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wt = w.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.conv2d(xt, wt, padding=1)
+    close(y, ref.permute(0, 2, 3, 1), dt, scale=math.sqrt(9 * Cin) / 4)
+    dy = rnd(B, H, W, Cout, dt=dt, seed=5)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    # data gradient as the forward-shaped implicit GEMM on the [Cin][flipped tap][Cout] weight copy (crog_conv3_dgrad_weights)
+    wT = torch.empty(Cin * 9 * Cout, device="cuda", dtype=dt)
+    table = torch.tensor([0, Cout, Cin], dtype=torch.int64, device="cuda")
+    K.conv3_dgrad_weights(w.reshape(-1), wT, table, 1)
+    dx = torch.empty(B, H, W, Cin, device="cuda", dtype=dt)
+    K.gemm(K.dcode(dt), K.A_IM2COL, K.B_KC, dy, wT, dx, M, Cin, 9 * Cout, Cout, 9 * Cout, Cin, conv=(H, W, Cout))
+    close(dx, xt.grad.permute(0, 2, 3, 1), dt, scale=math.sqrt(9 * Cout) / 4)
+    sk = K.pick_splitk(Cout, 9 * Cin, M, 32 if dt == torch.bfloat16 else 16, conv=True)
+    dw = torch.zeros(Cout, 9 * Cin, device="cuda")
+    K.gemm(K.dcode(dt), K.A_MC, K.B_NC_IM2COL, dy, x, dw, Cout, 9 * Cin, M, Cout, Cin, 9 * Cin, conv=(H, W, Cin), splitk=sk,
+           out_mode=K.OUT_F32_ATOMIC)
+    r = _rel_l2(dw.view(Cout, 3, 3, Cin), wt.grad.permute(0, 2, 3, 1))
+    print(f"3x3 {Cin}->{Cout} @{HW} B={B} wgrad splitk={sk}: rel L2 {r:.2e}")
+    assert r < (1e-4 if dt == torch.float32 else 1e-4)
+
+
+def test_operands_beyond_32bit_buffer_extent_take_the_pointer_path(K):
+    """gemm.hip addresses an operand of the LDS-DMA kernel through a 32-bit byte offset; an operand of >= 2 GiB must fall back to
+    the 64-bit pointer kernel and still be right (last rows are the ones a wrapped offset would miss)."""
+    M, Kd, N = (1 << 20) + 128, 1024, 64
+    a = torch.zeros(M, Kd, device="cuda", dtype=torch.bfloat16)       # 2.0 GiB + 256 KiB
+    a[-300:] = rnd(300, Kd, dt=torch.bfloat16)
+    a[:200] = rnd(200, Kd, dt=torch.bfloat16, seed=2)
+    b = rnd(N, Kd, dt=torch.bfloat16, seed=1)
+    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    K.gemm(K.BF16, K.A_KC, K.B_KC, a, b, c, M, N, Kd, Kd, Kd, N)
+    for sl in (slice(0, 200), slice(M - 300, M), slice(M // 2, M // 2 + 64)):
+        close(c[sl], a[sl].float() @ b.float().t(), torch.bfloat16, scale=math.sqrt(Kd) / 4)

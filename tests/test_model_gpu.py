@@ -171,6 +171,7 @@ def test_checkpoint_wire_format_round_trips_with_torch_adam(tmp_path):
 
     def backward(model):
         _, _, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+        model.zero_grad()       # torch default set_to_none=True, BETWEEN forward and backward as crog_engine.py:77 does
         loss.backward()
         torch.cuda.synchronize()
 
@@ -241,10 +242,12 @@ def test_store_bookkeeping_across_fused_adam_steps():
     st = model.store
     for step in range(3):
         _, _, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
-        assert st.G.abs().max().item() == 0 and st.g_clean              # the forward handed backward a clean buffer
         if step:
+            assert not st.g_clean and st.G.abs().max().item() > 0       # the forward does NOT clear gradients (torch semantics)
             assert torch.equal(st.S, st.P.to(torch.bfloat16))          # the shadow this forward used == cast of the stepped parameters
-        opt.zero_grad()                                                 # crog_engine.py:77 — nothing to clear, nothing launched
+        opt.zero_grad()                                                 # crog_engine.py:77 — the one memset of the step
+        assert st.g_clean and st.G.abs().max().item() == 0
+        opt.zero_grad()                                                 # clean buffer: nothing launched
         assert st.g_clean
         loss.backward()
         torch.cuda.synchronize()
@@ -280,6 +283,7 @@ def test_text_tower_hip_graph_replays_match_eager(monkeypatch):
             # dropout seeds must line up between the two runs
             from crog_amd.runtime import RT
             RT.manual_seed(7)
+            model.store.zero_grad()
             preds, _, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
             loss.backward()
             torch.cuda.synchronize()
