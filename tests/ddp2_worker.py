@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, out_dir, dtype_name, gain = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], float(sys.argv[6])
+    size, B, tag = int(sys.argv[7]), int(sys.argv[8]), sys.argv[9]
     from crog_amd.model import build_crog
     from crog_amd.optim import FusedAdam
     from crog_amd.parallel import DistributedDataParallel, convert_sync_batchnorm
@@ -24,7 +25,7 @@ def main():
     torch.cuda.set_device(0)
     dtype = torch.float32 if dtype_name == "f32" else torch.bfloat16
     meta = json.load(open(os.path.join(ROOT, "tests", "golden", "tiny_crog.json")))
-    cfg = tiny_cfg()
+    cfg = tiny_cfg(input_size=size)
     model, groups = build_crog(cfg)
     shapes = {k: tuple(v) for k, v in meta["shapes"].items()}
     # ranks > 0 start from DIFFERENT weights: DistributedDataParallel's constructor must hand them rank 0's (train_crog.py:154)
@@ -40,8 +41,8 @@ def main():
         assert RT.comm is not None and RT.comm.world_size == world
         net = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True, bucket_cap_mb=0.25)
     opt = FusedAdam(groups, lr=1e-4, store=model.store)
-    full = synthetic_batch(meta["B"], cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + meta["seed"])
-    per = meta["B"] // world
+    full = synthetic_batch(B, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + meta["seed"])
+    per = B // world
     b = {k: v[rank * per:(rank + 1) * per].cuda() for k, v in full.items()}
     net.train()
     res = {}
@@ -67,7 +68,7 @@ def main():
     res["P"] = model.store.P.cpu().numpy()
     sd = model.state_dict()
     res["bn_final"] = np.concatenate([sd[k].float().cpu().numpy().ravel() for k in meta["bn_keys"]])
-    np.savez(os.path.join(out_dir, f"rank{rank}_of{world}.npz"), **res)
+    np.savez(os.path.join(out_dir, f"{tag}_rank{rank}_of{world}.npz"), **res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

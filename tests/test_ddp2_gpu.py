@@ -26,10 +26,10 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def _run(world, out_dir, dtype, gain):
+def _run(world, out_dir, dtype, gain, size=96, B=4, tag="a"):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, str(out_dir), dtype, str(gain)], env=env,
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, str(out_dir), dtype, str(gain), str(size), str(B), tag], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
     try:
@@ -42,7 +42,7 @@ def _run(world, out_dir, dtype, gain):
                 p.kill()
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} of {world} failed:\n{o[-3000:]}"
-    return [dict(np.load(os.path.join(out_dir, f"rank{r}_of{world}.npz"))) for r in range(world)]
+    return [dict(np.load(os.path.join(out_dir, f"{tag}_rank{r}_of{world}.npz"))) for r in range(world)]
 
 
 def test_two_rank_ddp_syncbn_fp32_equals_reference_on_concatenated_batch(tmp_path):
@@ -75,28 +75,38 @@ def test_two_rank_ddp_syncbn_fp32_equals_reference_on_concatenated_batch(tmp_pat
 
 def test_two_rank_ddp_syncbn_bf16_equals_single_process(tmp_path):
     """bf16 (the benchmark dtype): statistics travel as [R][C][2] atomic replica rows, BatchNorm parameter gradients are the
-    all-reduced totals / world.  2 ranks x 2 samples against 1 process x 4 samples, damped trunk (bf16 noise is not amplified)."""
+    all-reduced totals / world.  2 ranks x 4 samples against 1 process x 8 samples at 160 x 160 on a damped trunk.  Yardstick: the
+    single-process path's own run-to-run noise (its BatchNorm sums are fp32 atomics whose order changes, and every later bf16
+    rounding amplifies that) — the 2-rank run must sit within a small multiple of it."""
     meta = json.load(open(os.path.join(GOLD, "tiny_crog.json")))
-    (one,) = _run(1, tmp_path, "bf16", 0.25)
-    r0, r1 = _run(2, tmp_path, "bf16", 0.25)
+    kw = dict(size=160, B=8)
+    (one,) = _run(1, tmp_path, "bf16", 0.25, tag="one", **kw)
+    (two,) = _run(1, tmp_path, "bf16", 0.25, tag="again", **kw)
+    r0, r1 = _run(2, tmp_path, "bf16", 0.25, tag="ddp", **kw)
     assert np.array_equal(r0["G"], r1["G"]) and np.array_equal(r0["P"], r1["P"]) and np.array_equal(r0["bn_final"], r1["bn_final"])
     got = np.concatenate([r0["preds"], r1["preds"]], 0)
     scale = float(np.abs(one["preds"]).max())
-    e = float(np.abs(got - one["preds"]).max())
-    print(f"bf16 2-rank vs 1-process logits: max err {e:.3e} at logit scale {scale:.2f}")
-    assert e < 3e-2 * max(1.0, scale)
-    assert abs(0.5 * (float(r0["loss"]) + float(r1["loss"])) - float(one["loss"])) < 1e-2 * abs(float(one["loss"]))
+
+    def rms(a, b):
+        return float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    e, floor = rms(got, one["preds"]), rms(two["preds"], one["preds"])
+    print(f"bf16 logits, relative RMS: 2-rank vs 1-process {e:.3e}; 1-process run-to-run {floor:.3e}; logit scale {scale:.2f}")
+    assert e < max(4 * floor, 2e-2)
+    lm = 0.5 * (float(r0["loss"]) + float(r1["loss"]))
+    assert abs(lm - float(one["loss"])) < max(1e-2 * abs(float(one["loss"])), 4 * abs(float(two["loss"]) - float(one["loss"])))
     names = meta["param_names"]
-    a, b = r0["grad_norms"], one["grad_norms"]
-    rel = np.abs(a - b) / (np.abs(b) + 1e-6)
+    a, b, c = r0["grad_norms"], one["grad_norms"], two["grad_norms"]
+    rel, rel_floor = np.abs(a - b) / (np.abs(b) + 1e-6), np.abs(c - b) / (np.abs(b) + 1e-6)
     bn_params = np.array([(".bn" in n or "downsample.1" in n or "connect.1" in n or "norm_layer" in n or n.endswith(".1.weight") or n.endswith(".1.bias"))
                           for n in names])
     big = b > 1e-4
-    print(f"bf16 2-rank vs 1-process gradient norms: median rel {np.median(rel[big]):.2e}, worst {rel[big].max():.2e}; "
-          f"BatchNorm-parameter tensors worst {rel[big & bn_params].max():.2e}")
+    print(f"bf16 gradient norms vs 1-process: 2-rank median rel {np.median(rel[big]):.2e} worst {rel[big].max():.2e} "
+          f"(BatchNorm parameters worst {rel[big & bn_params].max():.2e}); run-to-run median {np.median(rel_floor[big]):.2e} worst {rel_floor[big].max():.2e}")
     # a wrong 1/world factor on the BatchNorm parameter gradients (or on `count`) would be a factor 2, not a few per cent
-    assert rel[big & bn_params].max() < 0.25 and np.median(rel[big]) < 3e-2
+    assert rel[big & bn_params].max() < max(0.25, 4 * rel_floor[big & bn_params].max())
+    assert np.median(rel[big]) < max(3e-2, 4 * np.median(rel_floor[big]))
     assert np.allclose(r0["bn_checksum"], one["bn_checksum"], rtol=2e-3, atol=2e-2)
-    ga, gb = r0["G"].astype(np.float64), one["G"].astype(np.float64)
-    cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
-    assert cos > 0.98, cos
+    ga, gb, gc = r0["G"].astype(np.float64), one["G"].astype(np.float64), two["G"].astype(np.float64)
+    cos = lambda x, y: float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y)))
+    print(f"flat gradient cosine: 2-rank vs 1-process {cos(ga, gb):.5f}; run-to-run {cos(gc, gb):.5f}")
+    assert cos(ga, gb) > min(0.98, 1 - 4 * (1 - cos(gc, gb)))
