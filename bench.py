@@ -26,8 +26,40 @@ PEAK_HBM_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 
 PEAK_MFMA_TF = 2500.0           # dense bf16 MFMA
 
 
+def _cpu_info():
+    """(physical cores usable by this process, logical CPUs, model string) from /proc/cpuinfo + the affinity mask."""
+    model, cores, logical = "unknown CPU", set(), 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+                cores.add((phys, core))
+    except OSError:
+        pass
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    n_phys = len(cores) or allowed
+    return max(1, min(n_phys, allowed)), logical or (os.cpu_count() or 1), model
+
+
+CPU_WARMUP, CPU_TIMED = 5, 5     # SURVEY.md §8(d): >= 5 warm-up steps (the first ones are 3-10x slower), then the mean of >= 5
+
+
 def cpu_baseline_worker(path, threads):
-    """Child process: time the CPU oracle's training step, appending each step's seconds to `path` as it goes."""
+    """Child process: the CPU oracle's training step under a gloo DistributedDataParallel wrapper at world size 1 (what the
+    reference's train_crog.py would be on CPU), appending each step's seconds to `path` as it goes."""
+    import socket
     from crog_amd.testing import make_cfg, seeded_state, synthetic_batch
     from crog_amd.model import build_crog
     from oracle import crog_oracle as O
@@ -38,28 +70,43 @@ def cpu_baseline_worker(path, threads):
     names = [n for n, _ in model.named_parameters()]
     del model
     P = seeded_state(shapes, seed=5, residual_gain=0.25)
-    params = [P[n].requires_grad_(True) for n in names]
-    opt = torch.optim.Adam(params, lr=1e-4)
     b = synthetic_batch(2, 416, 20, 49408, seed=1)
+
+    class Oracle(torch.nn.Module):       # the functional oracle behind an nn.Module so that DDP can wrap it
+        def __init__(self):
+            super().__init__()
+            self.params = torch.nn.ParameterList([torch.nn.Parameter(P[n]) for n in names])
+
+        def forward(self, img, word, *masks):
+            state = dict(P)
+            state.update({n: p for n, p in zip(names, self.params)})
+            return O.crog_forward(state, img, word, list(masks), num_head=cfg.num_head)["total"]
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    net = torch.nn.parallel.DistributedDataParallel(Oracle(), find_unused_parameters=True)     # train_crog.py:154-156
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     times = []
-    for i in range(6):
+    for i in range(CPU_WARMUP + CPU_TIMED):
         t0 = time.time()
-        out = O.crog_forward(P, b["img"], b["word"], [b[k] for k in ("mask", "qua", "sin", "cos", "wid")], num_head=cfg.num_head)
+        loss = net(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
         opt.zero_grad()
-        out["total"].backward()
+        loss.backward()
         opt.step()
         times.append(time.time() - t0)
         json.dump(times, open(path, "w"))
+    dist.destroy_process_group()
 
 
-def cpu_baseline(budget_s=75):
+def cpu_baseline(budget_s=150):
     """The CPU oracle (oracle/crog_oracle.py, a restatement of the reference's PyTorch-CPU path) doing the same training step
-    (fwd + losses + bwd + Adam) on BASELINE config 1: CROG-R50, B=2, 416x416, fp32, on this box's host cores, for a bounded
-    wall-clock budget (child process, killed at the budget; whatever steps completed are reported)."""
+    (fwd + losses + bwd + Adam, gloo DDP world size 1) on BASELINE config 1: CROG-R50, B=2, 416x416, fp32, on this box's host
+    cores: 5 warm-up + 5 timed steps in a child process (killed at the wall-clock budget; whatever completed is reported)."""
     import subprocess
     import tempfile
-    ncores = os.cpu_count() or 1
-    threads = max(1, min(ncores, 32))
+    threads, logical, model = _cpu_info()
     path = os.path.join(tempfile.mkdtemp(), "cpu_steps.json")
     p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path, "--cpu-threads", str(threads)],
                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -69,14 +116,47 @@ def cpu_baseline(budget_s=75):
         p.kill()
         p.wait()
     times = json.load(open(path)) if os.path.exists(path) else []
+    where = f"{model}; torch CPU threads = {threads} physical cores of {logical} logical CPUs"
     if not times:
-        return dict(value=None, unit="images/sec", cores=threads, kind="port", sample=f"no CPU step finished within {budget_s} s")
-    used = times[1:] if len(times) > 1 else times
+        return dict(value=None, unit="images/sec", cores=threads, kind="port", sample=f"no CPU step finished within {budget_s} s; {where}")
+    used = times[CPU_WARMUP:] if len(times) > CPU_WARMUP else times[-1:]
     t = sum(used) / len(used)
     return dict(value=round(2.0 / t, 4), unit="images/sec", cores=threads, kind="port",
-                sample=f"oracle training step (fwd+loss+bwd+Adam), CROG-R50 fp32, B=2, 416x416, 20 tokens; {len(times)} steps finished in the "
-                       f"{budget_s} s budget (first {times[0]:.1f} s), mean of {'steps 2..' + str(len(times)) if len(times) > 1 else 'the only step'}: "
-                       f"{t:.2f} s/step; torch CPU threads={threads} of {ncores} logical CPUs")
+                sample=f"oracle training step (fwd+loss+bwd+Adam, gloo DDP world size 1), CROG-R50 fp32, B=2, 416x416, 20 tokens; {len(times)} steps "
+                       f"in <= {budget_s} s (first {times[0]:.1f} s), mean of the last {len(used)} after {min(CPU_WARMUP, len(times) - len(used))} warm-ups: "
+                       f"{t:.2f} s/step; {where}")
+
+
+def measured_peaks(dev):
+    """The box's own stream-copy bandwidth and bf16 MFMA issue rate, next to the vendor peaks the fractions use."""
+    from crog_amd import kernels as K
+    lib = K.lib()
+    out = {}
+    n = 1 << 30
+    src = torch.empty(n, device=dev, dtype=torch.uint8).random_(0, 255)
+    dst = torch.empty_like(src)
+    s = torch.cuda.current_stream().cuda_stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for _ in range(2):
+        K.check(lib.crog_probe_copy(src.data_ptr(), dst.data_ptr(), n, s), "probe_copy")
+    ev[0].record()
+    for _ in range(10):
+        K.check(lib.crog_probe_copy(src.data_ptr(), dst.data_ptr(), n, s), "probe_copy")
+    ev[1].record()
+    torch.cuda.synchronize()
+    out["hbm_copy_GBps"] = round(10 * 2 * n / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, 1)
+    del src, dst
+    blocks, iters = 256 * 2, 4000
+    sink = torch.zeros(blocks * 256, device=dev)
+    K.check(lib.crog_probe_mfma_bf16(sink.data_ptr(), blocks, 200, s), "probe_mfma")
+    ev[0].record()
+    K.check(lib.crog_probe_mfma_bf16(sink.data_ptr(), blocks, iters, s), "probe_mfma")
+    ev[1].record()
+    torch.cuda.synchronize()
+    out["mfma_bf16_TFLOPs"] = round(blocks * 4 * iters * 8 * 32768 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12, 1)
+    out["note"] = ("crog_probe_copy: 1 GiB device-to-device copy, read + write bytes / time; crog_probe_mfma_bf16: 2 blocks x 4 waves per CU issuing "
+                   "independent v_mfma_f32_32x32x16_bf16 from registers (no memory traffic): what the chip sustains at the clock it holds")
+    return out
 
 
 def main():
@@ -193,6 +273,11 @@ def main():
             "roofline": roof,
             "last_step": {"loss": round(last[0], 4), "iou": round(last[1], 3), "prec50": round(last[2], 3)},
         }
+        if world == 1:
+            try:
+                out["measured_peaks"] = measured_peaks(dev)
+            except Exception as e:      # the probes are diagnostics: never lose the bench line over them
+                out["measured_peaks"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -110,14 +110,14 @@ struct ConvGeom { int H, W, C; };
 // 128-byte lines of a pixel (full-line use of L2), and the 9 taps of a chunk pair are 18 consecutive k-tiles (L2/L1 reuse
 // of the shifted pixels).  Falls back to chunk-major / tap-minor when the number of chunks is odd (Cin = 32).
 __device__ inline void conv_ktile(int kt, int nchunks, int& tap, int& chunk) {
-  if ((nchunks & 1) == 0) {
-    const int pair = kt / 18, r = kt - pair * 18;
-    tap = r >> 1;
-    chunk = pair * 2 + (r & 1);
-  } else {
-    tap = kt % 9;
-    chunk = kt / 9;
-  }
+  // both forms are a handful of scalar instructions: computed unconditionally and selected, so that the caller's loop body stays
+  // one basic block
+  const int pair = kt / 18, r = kt - pair * 18;
+  const int tap_e = r >> 1, chunk_e = pair * 2 + (r & 1);
+  const int chunk_o = kt / 9, tap_o = kt - chunk_o * 9;
+  const bool even = (nchunks & 1) == 0;
+  tap = even ? tap_e : tap_o;
+  chunk = even ? chunk_e : chunk_o;
 }
 
 // ---- K-contiguous loader: ROWS rows x BK, 4 16-byte chunks per row, thread -> rows {tid/4 + i*NT/4} ----
@@ -310,7 +310,7 @@ template <typename T, typename S> constexpr int lds_bytes() {
 // ------------------------------------------ epilogue ------------------------------------------
 // Shared by the register-staged and the LDS-DMA kernels.  `smem` may be reused: the caller has passed its last barrier.
 template <typename T, typename S>
-__device__ inline void gemm_epilogue(f32x16 (&acc)[S::WM][S::WN], const crog_gemm_desc& p, char* smem, int m0, int n0, int zs, int64_t coff) {
+__device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc)[S::WM][S::WN], const crog_gemm_desc& p, char* smem, int m0, int n0, int zs, int64_t coff) {
   constexpr int NT = S::NT, BM = S::BM, BN = S::BN, WM = S::WM, WN = S::WN, WVN = S::WVN, WVM = S::WVM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WVN, wc = wave % WVN;
@@ -663,45 +663,66 @@ template <typename T, int MODE, int NI>
 struct DmaKc {
   static constexpr int VEC = TileCfg<T>::VEC, BK = TileCfg<T>::BK;
   static constexpr bool TR = false;
-  __amdgpu_buffer_rsrc_t rsrc;
   unsigned base[NI];  // byte offset of (row, swizzled chunk) at k = 0; DMA_OOB when the row is out of range
-  unsigned cb[NI];    // byte position of the lane's logical chunk inside the k-tile
-  int py[NI], px[NI];
+  unsigned cb[NI];    // MODE 0: byte position of the lane's logical chunk inside the k-tile; MODE 1: 9-bit mask of the taps that land inside the image
   int ldb_;           // row stride in bytes
   unsigned kbytes;
 
-  __device__ void init(const T* ptr, int64_t ld, int rows_total, int K, int row0, int wave, int lane, const ConvGeom& g) {
+  // The buffer resource is NOT a member: it is rebuilt from the (kernel-scope, wave-uniform) base pointer and extent at the point
+  // of use, so that it is provably uniform and lives in SGPRs.  As a field of a loader that is modified inside the loop it came back
+  // from private memory, i.e. formally divergent, and every LDS-DMA request was wrapped in a waterfall loop.
+  __device__ __attribute__((always_inline)) static int extent(int64_t ld, int rows_total, int K, const ConvGeom&) {
     // num_records = the operand's true extent (rows_total rows of ld elements; the last row ends at K rounded up to a
     // chunk): anything past it reads as zero instead of touching a neighbouring allocation
-    const long extent = ((long)(rows_total - 1) * ld + ((K + VEC - 1) / VEC) * VEC) * (long)sizeof(T);
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr), 0, (int)extent, 0x00020000);
+    return (int)(((long)(rows_total - 1) * ld + ((K + VEC - 1) / VEC) * VEC) * (long)sizeof(T));
+  }
+  __device__ __attribute__((always_inline)) void init(const T* ptr, int64_t ld, int rows_total, int K, int row0, int wave, int lane, const ConvGeom& g) {
     ldb_ = (int)(ld * sizeof(T));
     kbytes = (unsigned)(K * sizeof(T));
 #pragma unroll
     for (int i = 0; i < NI; i++) {
       const int row = (wave * NI + i) * 16 + (lane >> 2);
-      cb[i] = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
+      const unsigned chunk = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
       const long m = (long)row0 + row;
-      base[i] = (m < rows_total) ? (unsigned)(m * ld * sizeof(T)) + cb[i] : DMA_OOB;
+      base[i] = (m < rows_total) ? (unsigned)(m * ld * sizeof(T)) + chunk : DMA_OOB;
       if constexpr (MODE == 1) {
+        // the pixel's position decides once which of the 9 taps exist; per k-tile the test is one shift + select instead of
+        // four compares under an exec mask (which also cut the loop body into basic blocks the scheduler cannot interleave)
         const long rem = m % ((long)g.H * g.W);
-        py[i] = (int)(rem / g.W);
-        px[i] = (int)(rem % g.W);
+        const int py = (int)(rem / g.W), px = (int)(rem % g.W);
+        unsigned mask = 0;
+        if (m < rows_total) {
+#pragma unroll
+          for (int tap = 0; tap < 9; tap++) {
+            const int sy = py + tap / 3 - 1, sx = px + tap % 3 - 1;
+            if (sy >= 0 && sy < g.H && sx >= 0 && sx < g.W) mask |= 1u << tap;
+          }
+        }
+        cb[i] = mask;
+      } else {
+        cb[i] = chunk;
       }
     }
   }
-  // kt: k-tile index; kmem: element offset of the k-tile inside the reduction (see kmem in the kernels)
-  __device__ unsigned off(int i, int kt, int kmem, const ConvGeom& g) const {
+  __device__ __attribute__((always_inline)) void start(int, const ConvGeom&) {}
+  __device__ __attribute__((always_inline)) void advance(const ConvGeom&) {}
+  // kt: k-tile index; kmem: element offset of the k-tile inside the reduction (see kmem in the kernels); live: the tile exists
+  // (block-uniform; a request past the end of the reduction range becomes an out-of-bounds offset = no traffic, zeros written)
+  __device__ __attribute__((always_inline)) unsigned off(int i, int kt, int kmem, const ConvGeom& g, bool live) const {
     if constexpr (MODE == 1) {
       int tap, chunk;
       conv_ktile(kt, g.C / BK, tap, chunk);
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-      const int sy = py[i] + dy, sx = px[i] + dx;
-      const bool ok = base[i] != DMA_OOB && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
-      return ok ? base[i] + (unsigned)((dy * g.W + dx) * ldb_) + (unsigned)(chunk * BK * sizeof(T)) : DMA_OOB;  // wrap-around = negative shift
+      const unsigned shift = (unsigned)((dy * g.W + dx) * ldb_ + chunk * BK * (int)sizeof(T));   // block-uniform; wrap-around = negative shift
+      // `live` enters as a mask, not as a condition: a block-uniform condition here is turned into a branch around the request,
+      // which splits the loop body
+      const unsigned lv = live ? ~0u : 0u;
+      const bool ok = ((cb[i] & lv) >> tap) & 1u;
+      return ok ? base[i] + shift : DMA_OOB;
     } else {
       const unsigned kb = (unsigned)(kmem * sizeof(T));
-      return (base[i] != DMA_OOB && kb + cb[i] < kbytes) ? base[i] + kb : DMA_OOB;
+      const unsigned lim = live ? kbytes : 0u;
+      return (base[i] != DMA_OOB && kb + cb[i] < lim) ? base[i] + kb : DMA_OOB;
     }
   }
   __device__ static Frag<T> frag(const char* tile, int rbase, int ks, int lane);
@@ -744,27 +765,33 @@ struct DmaTr {
   static constexpr int ROWB = COLS * (int)sizeof(T);
   static constexpr int RPI1024 = 1024 / ROWB;    // whole tile rows per 1 KiB wave-instruction (>= 1 for all shapes used)
   static_assert(RPI1024 >= 1, "a transposed tile row must fit one 1 KiB wave-instruction");
-  __amdgpu_buffer_rsrc_t rsrc;
   int rowin[NI];       // reduction row of this lane inside the k-tile
   unsigned colb[NI];   // byte offset of the lane's logical column chunk (DMA_OOB when the columns are out of range)
-  int tdy[NI], tdx[NI]; // MODE 2
+  int tdy[NI], tdx[NI]; // MODE 2: tap of the lane's column chunk
+  int px[NI], py[NI];   // MODE 2: image coordinates of the lane's reduction row (pixel), advanced k-tile by k-tile
+  unsigned cur[NI];     // MODE 0 / 2: byte offset of the lane's chunk in the current k-tile, advanced by BK rows per k-tile (no multiply in the loop)
   int ldb_, K;
+  int stepx, stepy;     // MODE 2: BK pixels = stepy rows (mod H) + stepx columns
 
   __device__ static int swz(int row) { return sizeof(T) == 2 ? tr_swz<COLS>(row) : 0; }
 
-  __device__ void init(const T* ptr, int64_t ld, int ncols, int K_, int col0, int wave, int lane, const ConvGeom& g) {
+  __device__ __attribute__((always_inline)) static int extent(int64_t ld, int ncols, int K_, const ConvGeom& g) {
     long rows = K_;                                    // rows of memory the tile can touch
     if (MODE == 1) rows = 9L * g.C;                    // KRSC weight rows (co*9 + tap)
     const long width = (MODE == 2) ? g.C : ((ncols + VEC - 1) / VEC) * VEC;   // im2col rows are one pixel's channels
-    const long extent = ((rows - 1) * ld + width) * (long)sizeof(T);
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr), 0, (int)extent, 0x00020000);
+    return (int)(((rows - 1) * ld + width) * (long)sizeof(T));
+  }
+  __device__ __attribute__((always_inline)) void init(const T* ptr, int64_t ld, int ncols, int K_, int col0, int wave, int lane, const ConvGeom& g) {
     ldb_ = (int)(ld * sizeof(T));
     K = K_;
+    stepx = stepy = 0;
 #pragma unroll
     for (int i = 0; i < NI; i++) {
       const int row = (wave * NI + i) * RPI1024 + lane / CPR;
       const int c = (lane % CPR) ^ swz(row);
       rowin[i] = row;
+      px[i] = py[i] = 0;
+      cur[i] = 0;
       const int col = col0 + c * VEC;
       if (col >= ncols) { colb[i] = DMA_OOB; tdy[i] = tdx[i] = 0; continue; }
       if constexpr (MODE == 2) {
@@ -777,19 +804,57 @@ struct DmaTr {
       }
     }
   }
-  __device__ unsigned off(int i, int kt, int kmem, const ConvGeom& g) const {
-    const int k = kmem + rowin[i];
-    if (colb[i] == DMA_OOB || k >= K) return DMA_OOB;
+  // MODE 2: position of the lane's pixels at the first k-tile of this block's reduction range (the only divisions), and the
+  // per-k-tile step; afterwards `advance` keeps (px, py) current with two adds and two selects per k-tile
+  __device__ __attribute__((always_inline)) void start(int kmem0, const ConvGeom& g) {
     if constexpr (MODE == 0) {
-      return (unsigned)k * (unsigned)ldb_ + colb[i];
+#pragma unroll
+      for (int i = 0; i < NI; i++) cur[i] = (unsigned)(kmem0 + rowin[i]) * (unsigned)ldb_ + colb[i];
+    }
+    if constexpr (MODE == 2) {
+      stepx = BK % g.W;
+      stepy = (BK / g.W) % g.H;
+#pragma unroll
+      for (int i = 0; i < NI; i++) {
+        const int k = kmem0 + rowin[i];
+        px[i] = k % g.W;
+        py[i] = (k / g.W) % g.H;
+        cur[i] = (unsigned)(k + tdy[i] * g.W + tdx[i]) * (unsigned)ldb_ + colb[i];   // wrap-around = negative shift
+      }
+    }
+  }
+  __device__ __attribute__((always_inline)) void advance(const ConvGeom& g) {
+    if constexpr (MODE == 0 || MODE == 2) {
+      const unsigned step = (unsigned)(BK * ldb_);
+#pragma unroll
+      for (int i = 0; i < NI; i++) cur[i] += step;
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < NI; i++) {
+        int x = px[i] + stepx, y = py[i] + stepy;
+        const bool wrap = x >= g.W;
+        x = wrap ? x - g.W : x;
+        y = wrap ? y + 1 : y;
+        y = y >= g.H ? y - g.H : y;      // stepy < H and at most one carry: y < 2 H
+        px[i] = x;
+        py[i] = y;
+      }
+    }
+  }
+  __device__ __attribute__((always_inline)) unsigned off(int i, int kt, int kmem, const ConvGeom& g, bool live) const {
+    const int k = kmem + rowin[i];
+    const int klim = live ? K : 0;      // (a mask, not a condition: see DmaKc::off)
+    if constexpr (MODE == 0) {
+      return (colb[i] != DMA_OOB && k < klim) ? cur[i] : DMA_OOB;
     } else if constexpr (MODE == 1) {
+      if (!live || colb[i] == DMA_OOB || k >= K) return DMA_OOB;
       const int tap = k / g.C, co = k - tap * g.C;
       return (unsigned)(co * 9 + (8 - tap)) * (unsigned)ldb_ + colb[i];
     } else {
-      const int x = k % g.W, y = (k / g.W) % g.H;
-      const int sy = y + tdy[i], sx = x + tdx[i];
-      if (sy < 0 || sy >= g.H || sx < 0 || sx >= g.W) return DMA_OOB;
-      return (unsigned)(k + tdy[i] * g.W + tdx[i]) * (unsigned)ldb_ + colb[i];
+      const int sy = py[i] + tdy[i], sx = px[i] + tdx[i];
+      const bool ok = colb[i] != DMA_OOB && k < klim && (unsigned)sy < (unsigned)g.H && (unsigned)sx < (unsigned)g.W;
+      return ok ? cur[i] : DMA_OOB;
     }
   }
   __device__ static Frag<T> frag(const char* tile, int cbase, int ks, int lane);
@@ -840,20 +905,34 @@ template <typename T, int E, int NI> struct DmaBSel<T, CROG_B_NC_DGRAD, E, NI> {
 template <typename T, int E, int NI> struct DmaBSel<T, CROG_B_NC_IM2COL, E, NI> { using type = DmaTr<T, 2, E, NI>; };
 
 // Issue the LDS-DMA loads of one k-tile into ring stage `stage`: every wave moves NIA 1-KiB slices of the A tile and NIB of
-// the B tile.  A plain __device__ function on purpose: a lambda here makes hipcc's HOST pass drop the kernel stub silently.
-template <int TILE_A_B, int TILE_B_B, int NIA, int NIB, typename OA, typename OB>
-__device__ inline void dma_issue(const OA& da, const OB& db, const ConvGeom& g, char* smem, int wave, int kt, int kmem, int stage) {
+// the B tile.  A macro on purpose: as a lambda it makes hipcc's HOST pass drop the kernel stub silently, and as a function template
+// the host pass rejects its second instantiation context ("substitution failure") while the device pass accepts it.
+// `live`: the tile exists (block-uniform); a request past the end of the reduction range is an out-of-bounds offset.
+// The buffer resources are rebuilt from the kernel-scope base pointers here, so they are provably wave-uniform (SGPRs).
+// One 1-KiB LDS-DMA request.  A plain (non-template) __device__ function: the AMDGCN builtins must not appear in the __global__ body
+// itself (the host pass then drops the kernel's stub without a diagnostic).
+__device__ __attribute__((always_inline)) inline void dma_piece(const void* base, int extent, char* dst, unsigned off) {
   typedef __attribute__((address_space(3))) void lds_void;
-  char* sa = smem + stage * (TILE_A_B + TILE_B_B) + wave * NIA * 1024;
-  char* sb = smem + stage * (TILE_A_B + TILE_B_B) + TILE_A_B + wave * NIB * 1024;
-#pragma unroll
-  for (int i = 0; i < NIA; i++) __builtin_amdgcn_raw_ptr_buffer_load_lds(da.rsrc, (lds_void*)(sa + i * 1024), 16, da.off(i, kt, kmem, g), 0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < NIB; i++) __builtin_amdgcn_raw_ptr_buffer_load_lds(db.rsrc, (lds_void*)(sb + i * 1024), 16, db.off(i, kt, kmem, g), 0, 0, 0);
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, extent, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, off, 0, 0, 0);
 }
+#define CROG_DMA_ISSUE(KT, KMEM, STAGE, LIVE)                                                                          \
+  do {                                                                                                                 \
+    const int kt_ = (KT), km_ = (KMEM);                                                                                \
+    const bool lv_ = (LIVE);                                                                                           \
+    char* sa_ = smem + (STAGE) * (TILE_A_B + TILE_B_B) + wave * NIA * 1024;                                            \
+    char* sb_ = smem + (STAGE) * (TILE_A_B + TILE_B_B) + TILE_A_B + wave * NIB * 1024;                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < NIA; i_++) dma_piece(A, exa, sa_ + i_ * 1024, da.off(i_, kt_, km_, g, lv_)); \
+    _Pragma("unroll") for (int i_ = 0; i_ < NIB; i_++) dma_piece(B, exb, sb_ + i_ * 1024, db.off(i_, kt_, km_, g, lv_)); \
+    da.advance(g); /* k-tiles are requested strictly in order, one call per tile */                                    \
+    db.advance(g);                                                                                                     \
+  } while (0)
 
 template <int N> __device__ inline void wait_vmcnt() {
-  static_assert((N >= 0 && N <= 10 && N != 1 && N != 7 && N != 9) || N == 12, "add the immediate");
+  static_assert((N >= 0 && N <= 10 && N != 1 && N != 7) || N == 12 || N == 15 || N == 18, "add the immediate");
+  if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
   if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -863,6 +942,16 @@ template <int N> __device__ inline void wait_vmcnt() {
   if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+}
+
+// Wait until at most `behind` of this wave's most recently requested k-tiles (P DMA instructions each) are still in flight.
+// MAXB = the deepest value `behind` can take (ring depth - 1): deeper cases are not instantiated.
+template <int P, int MAXB>
+__device__ __attribute__((always_inline)) inline void wait_tiles(int behind) {
+  if constexpr (MAXB >= 3) { if (behind >= 3) { wait_vmcnt<3 * P>(); return; } }
+  if constexpr (MAXB >= 2) { if (behind == 2) { wait_vmcnt<2 * P>(); return; } }
+  if (behind == 1) wait_vmcnt<P>();
+  else wait_vmcnt<0>();
 }
 
 // Tile shapes that were measured and lost (kept for A/B work, compiled only with -DCROG_GEMM_EXPERIMENTAL_TILES): 256 x 256 and
@@ -875,7 +964,13 @@ using ShapeTall = Shape<2, 2, 4, 1>;   // 256 x  64, 4 waves: layers with <= 64 
 using ShapeWide = Shape<2, 2, 1, 4>;   //  64 x 256, 4 waves: weight gradients of those layers (M = Cout = 32 / 64)
 using ShapeDma64 = Shape<1, 1, 2, 2>;  //  64 x  64, 4 waves: small GEMMs (text tower, attention pooling), no BN statistics
 
-template <typename T, int AL, int BL, typename S>
+#ifndef CROG_GEMM_INTERLEAVE
+#define CROG_GEMM_INTERLEAVE 1   // 0: leave the order of DMA requests / LDS reads / MFMAs inside a k-tile to the compiler (A/B builds)
+#endif
+
+// ASUM: the launch also accumulates a_sum[m] += sum_k A(m, k) (bias gradient inside a weight-gradient GEMM); a template flag so
+// that the main loop of every other launch is one basic block
+template <typename T, int AL, int BL, typename S, int ASUM>
 __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 256 ? 2 : (S::BM + S::BN <= 128 ? 4 : 3)))) gemm_dma_kernel(const crog_gemm_desc p) {
   constexpr int DMA_NSTAGE = dma_nstage<S>();
   constexpr int NW = S::NT / 64, NIA = S::BM / (16 * NW), NIB = S::BN / (16 * NW);   // 1-KiB DMA slices per wave and k-tile
@@ -914,6 +1009,7 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 25
   OB db;
   da.init(A, p.lda, p.M, p.K, m0, wave, lane, g);
   db.init(B, p.ldb, p.N, p.K, n0, wave, lane, g);
+  const int exa = OA::extent(p.lda, p.M, p.K, g), exb = OB::extent(p.ldb, p.N, p.K, g);
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -934,25 +1030,24 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 25
     }
   };
 #define CROG_KMEM(kt) kmem_of(kt)
-  const bool do_asum = p.a_sum != nullptr && tn == 0 && wc == 0;   // block- and wave-uniform
+  const bool do_asum = ASUM != 0 && p.a_sum != nullptr && tn == 0 && wc == 0;   // block- and wave-uniform
   float asum[WM];
 #pragma unroll
   for (int i = 0; i < WM; i++) asum[i] = 0.f;
   constexpr int PER_TILE = NIA + NIB;   // DMA instructions per k-tile and wave
+  da.start(kt0 * BK, g);
+  db.start(kt0 * BK, g);
   if constexpr (BK / 16 == 2 && CROG_GEMM_PIPELINED) {
-    // Software-pipelined form (two 16-deep MFMA steps per k-tile): the wait for the NEXT tile's DMA, the workgroup barrier, the
-    // address arithmetic of the next DMA issue and the first LDS reads of the next tile all sit between the two MFMA groups of
-    // the CURRENT tile, so they run while this wave's own MFMAs execute instead of in front of them.  All DEPTH stages are in
-    // flight: tile t + DEPTH is requested into tile t's stage as soon as every wave has its second-step fragments in registers.
+    // Software-pipelined, branch-free main loop (two 16-deep MFMA steps per k-tile).  Exactly DEPTH k-tiles are always requested
+    // ahead — a request past the end of this block's reduction range is an out-of-bounds offset (no traffic, zeros into a stage
+    // nobody reads) — so the vmcnt waits are compile-time constants and the loop body is ONE basic block: the DMA requests of tile
+    // t + DEPTH, the LDS reads of tile t + 1 and the second MFMA group of tile t can be interleaved instruction by instruction
+    // (an LDS-DMA request holds the wave's issue slot for 60-180 cycles; issued in a bunch by all waves right after the barrier, as
+    // before, the matrix pipe of every SIMD idled through that phase: the 256 x 256 tile ran at a third of its MFMA rate).
 #pragma unroll
     for (int s = 0; s < DMA_NSTAGE; s++)
-      if (s < nt) dma_issue<TILE_A_B, TILE_B_B, NIA, NIB>(da, db, g, smem, wave, kt0 + s, CROG_KMEM(kt0 + s), s);
-    {
-      const int behind = min(DMA_NSTAGE - 1, nt - 1);
-      if (behind >= 2) wait_vmcnt<2 * PER_TILE>();
-      else if (behind == 1) wait_vmcnt<PER_TILE>();
-      else wait_vmcnt<0>();
-    }
+      CROG_DMA_ISSUE(kt0 + s, CROG_KMEM(kt0 + s), s, s < nt);
+    wait_vmcnt<(DMA_NSTAGE - 1) * PER_TILE>();     // tile 0 has landed; depth - 1 tiles stay in flight
     __builtin_amdgcn_s_barrier();
     Frag<T> fa0[WM], fb0[WN], fa1[WM], fb1[WN];
 #pragma unroll
@@ -967,57 +1062,71 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 25
       for (int i = 0; i < WM; i++) fa1[i] = OA::frag(at, (wr * WM + i) * 32, 1, lane);
 #pragma unroll
       for (int j = 0; j < WN; j++) fb1[j] = OB::frag(bt, (wc * WN + j) * 32, 1, lane);
-      if (do_asum) {
+      if constexpr (ASUM) {
+        if (do_asum) {
 #pragma unroll
-        for (int i = 0; i < WM; i++) asum[i] += frag_sum(fa0[i]);
+          for (int i = 0; i < WM; i++) asum[i] += frag_sum(fa0[i]);
+        }
       }
 #pragma unroll
       for (int i = 0; i < WM; i++)
 #pragma unroll
         for (int j = 0; j < WN; j++) mma16(fa0[i], fb0[j], acc[i][j]);
       const int nstage = stage == DMA_NSTAGE - 1 ? 0 : stage + 1;
-      if (t + 1 < nt) {
-        // this wave's reads of tile t are complete (its stage is about to be handed back to the DMA engine by any wave)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int behind = min(DMA_NSTAGE - 2, nt - 2 - t);   // tiles requested after tile t + 1
-        if (behind >= 1) wait_vmcnt<PER_TILE>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (t + DMA_NSTAGE < nt) {
-          const int tq = t + DMA_NSTAGE;
-          dma_issue<TILE_A_B, TILE_B_B, NIA, NIB>(da, db, g, smem, wave, kt0 + tq, CROG_KMEM(kt0 + tq), stage);
-        }
-        const char* an = smem + nstage * DMA_STAGE_B;
-#pragma unroll
-        for (int i = 0; i < WM; i++) fa0[i] = OA::frag(an, (wr * WM + i) * 32, 0, lane);
-#pragma unroll
-        for (int j = 0; j < WN; j++) fb0[j] = OB::frag(an + TILE_A_B, (wc * WN + j) * 32, 0, lane);
+      // this wave's reads of tile t are complete (its stage is about to be handed back to the DMA engine by any wave), tile t + 1 has
+      // landed for this wave, and after the barrier for every wave; tiles t + 2 .. t + DEPTH - 1 stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_vmcnt<(DMA_NSTAGE - 2) * PER_TILE>();
+      __builtin_amdgcn_s_barrier();
+      {
+        const int tq = t + DMA_NSTAGE;
+        CROG_DMA_ISSUE(kt0 + tq, CROG_KMEM(kt0 + tq), stage, tq < nt);
       }
-      if (do_asum) {
+      const char* an = smem + nstage * DMA_STAGE_B;
 #pragma unroll
-        for (int i = 0; i < WM; i++) asum[i] += frag_sum(fa1[i]);
+      for (int i = 0; i < WM; i++) fa0[i] = OA::frag(an, (wr * WM + i) * 32, 0, lane);
+#pragma unroll
+      for (int j = 0; j < WN; j++) fb0[j] = OB::frag(an + TILE_A_B, (wc * WN + j) * 32, 0, lane);
+      if constexpr (ASUM) {
+        if (do_asum) {
+#pragma unroll
+          for (int i = 0; i < WM; i++) asum[i] += frag_sum(fa1[i]);
+        }
       }
 #pragma unroll
       for (int i = 0; i < WM; i++)
 #pragma unroll
         for (int j = 0; j < WN; j++) mma16(fa1[i], fb1[j], acc[i][j]);
+#if CROG_GEMM_INTERLEAVE
+      if constexpr (sizeof(T) == 2 && !ASUM) {
+        // order of the second half of the k-tile: the next tile's fragment reads first (they complete under the MFMAs), then the
+        // MFMAs with the DMA requests spread between them
+        constexpr int NMF = WM * WN, MPD = NMF / PER_TILE > 0 ? NMF / PER_TILE : 1;
+        constexpr int NDS = WM * (OA::TR ? 2 : 1) + WN * (OB::TR ? 2 : 1);     // a transposed fragment is two ds_read_b64_tr_b16
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+#pragma unroll
+        for (int q = 0; q < PER_TILE; q++) {
+          if (q * MPD < NMF) __builtin_amdgcn_sched_group_barrier(0x008, MPD, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+        if (PER_TILE * MPD < NMF) __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER_TILE * MPD, 0);
+      }
+#endif
       stage = nstage;
     }
+    wait_vmcnt<0>();     // the trailing out-of-range requests write zeros into the ring: they must land before the epilogue reuses it
   } else {
 #pragma unroll
   for (int s = 0; s < DMA_NSTAGE - 1; s++)
-    if (s < nt) dma_issue<TILE_A_B, TILE_B_B, NIA, NIB>(da, db, g, smem, wave, kt0 + s, CROG_KMEM(kt0 + s), s);
+    if (s < nt) CROG_DMA_ISSUE(kt0 + s, CROG_KMEM(kt0 + s), s, true);
   int stage = 0;
   for (int t = 0; t < nt; t++) {
     // k-tiles still allowed in flight behind tile t: min(depth - 2, tiles left); 4 DMA instructions per tile and wave
-    const int behind = min(DMA_NSTAGE - 2, nt - 1 - t);
-    if (behind >= 2) wait_vmcnt<2 * (NIA + NIB)>();
-    else if (behind == 1) wait_vmcnt<NIA + NIB>();
-    else wait_vmcnt<0>();
+    wait_tiles<NIA + NIB, DMA_NSTAGE - 2>(min(DMA_NSTAGE - 2, nt - 1 - t));
     __builtin_amdgcn_s_barrier();
     if (t + DMA_NSTAGE - 1 < nt && !(p.debug & 1)) {
       const int tn = t + DMA_NSTAGE - 1;
-      dma_issue<TILE_A_B, TILE_B_B, NIA, NIB>(da, db, g, smem, wave, kt0 + tn, CROG_KMEM(kt0 + tn), stage == 0 ? DMA_NSTAGE - 1 : stage - 1);
+      CROG_DMA_ISSUE(kt0 + tn, CROG_KMEM(kt0 + tn), stage == 0 ? DMA_NSTAGE - 1 : stage - 1, true);
     }
     const char* at = smem + stage * DMA_STAGE_B;
     const char* bt = at + TILE_A_B;
@@ -1047,23 +1156,38 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 25
   gemm_epilogue<T, S>(acc, p, smem, m0, n0, zs, coff);
 }
 
+#ifdef CROG_GEMM_PROBE
+// asm-inspection build (never linked): hipcc -DCROG_GEMM_PROBE -S instantiates only these kernels
+template __global__ void gemm_dma_kernel<bf16, CROG_A_IM2COL, CROG_B_KC, ShapeMid, 0>(const crog_gemm_desc);
+template __global__ void gemm_dma_kernel<bf16, CROG_A_MC, CROG_B_NC_IM2COL, ShapeMid, 0>(const crog_gemm_desc);
+template __global__ void gemm_dma_kernel<bf16, CROG_A_IM2COL, CROG_B_KC, ShapeDma8, 0>(const crog_gemm_desc);
+}  // namespace
+#else
 template <typename T, int AL, int BL, typename S>
 int launch_dma(const crog_gemm_desc& d, hipStream_t s) {
   constexpr int ring = dma_nstage<S>() * (S::BM + S::BN) * 64, epi = lds_bytes<T, S>();   // the epilogue reuses the ring
   constexpr int LDS = ring > epi ? ring : epi;
   static bool attr_set = false;
-  auto kern = gemm_dma_kernel<T, AL, BL, S>;
+  constexpr bool CAN_ASUM = AL == CROG_A_MC;     // a_sum is only requested by weight-gradient launches
+  auto kern = gemm_dma_kernel<T, AL, BL, S, 0>;
+  auto kern_asum = gemm_dma_kernel<T, AL, BL, S, CAN_ASUM ? 1 : 0>;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      crog_set_error("crog_gemm: hipFuncSetAttribute(%d bytes) failed: %s", LDS, hipGetErrorString(e));
-      return CROG_ERR_LAUNCH;
+    for (auto k : {kern, kern_asum}) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) {
+        crog_set_error("crog_gemm: hipFuncSetAttribute(%d bytes) failed: %s", LDS, hipGetErrorString(e));
+        return CROG_ERR_LAUNCH;
+      }
     }
     attr_set = true;
   }
+  if (d.a_sum && !CAN_ASUM) {
+    crog_set_error("crog_gemm: a_sum needs the A_MC layout");
+    return CROG_ERR_ARG;
+  }
   dim3 grid(cdiv(d.M, S::BM) * cdiv(d.N, S::BN), d.batch * d.splitk, 1);
   if (splitk_by_xcd(d)) grid = dim3(grid.x * d.splitk, 1, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(S::NT), LDS, s, d);
+  hipLaunchKernelGGL(d.a_sum ? kern_asum : kern, grid, dim3(S::NT), LDS, s, d);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
@@ -1331,3 +1455,4 @@ extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
   if (d.dtype == CROG_BF16) return hw ? dispatch_shape<bf16, true>(d, s) : dispatch_shape<bf16, false>(d, s);
   return dispatch_shape<float, true>(d, s);
 }
+#endif  // CROG_GEMM_PROBE

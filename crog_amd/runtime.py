@@ -230,11 +230,22 @@ class ParamStore:
 
     def fresh_grads_if_dropped(self):
         """torch semantics of `p.grad = None` (model.zero_grad(), a stock optimizer's zero_grad()): the next backward REPLACES the
-        gradient.  The kernels always accumulate into G, so a dropped link means: clear G, link again.  Called at the start of a
-        training forward and again by the first node of backward (the reference zeroes between the two, crog_engine.py:77).
-        Gradients that are still linked are left alone: forward/backward twice without zero_grad accumulates, as in torch."""
-        if self.grads_dropped():
-            self.zero_grad()
+        gradient.  The kernels always accumulate into G, so a dropped link means: clear that parameter's slice of G (one memset
+        when every link is gone); the link itself comes back in WRef.done() when a kernel writes the gradient, so a parameter the
+        forward never uses (`logit_scale`) keeps .grad = None, as in torch.  Called at the start of a training forward and again by
+        the first node of backward (the reference zeroes between the two, crog_engine.py:77).  Gradients that are still linked are
+        left alone: forward/backward twice without zero_grad accumulates, as in torch."""
+        dropped = [(o, n) for name, p, o, n, g in self.entries if p.grad is None]
+        if not dropped:
+            return
+        live = len(self.entries) - len(dropped)
+        if live <= len(self.entries) - len(self.touched) or live == 0:      # everything a kernel ever wrote was dropped
+            if _LEGACY_SYNC or not (self.explicit and self.g_clean):
+                self.G.zero_()
+                self.g_clean = self.explicit and not _LEGACY_SYNC
+        else:
+            for o, n in dropped:
+                self.G[o:o + n].zero_()
 
     def invalidate_shadow(self):
         """The fp32 parameters changed behind the store's back (load_state_dict, a foreign optimizer, in-place edits)."""

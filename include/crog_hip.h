@@ -33,6 +33,12 @@ enum crog_status { CROG_OK = 0, CROG_ERR_ARG = -1, CROG_ERR_LAUNCH = -2 };
 
 int crog_hip_version(void);
 const char* crog_last_error(void);
+/* Peak probes for the measurement harness (bench.py `measured_peaks`; SURVEY.md §8d asks for the box's own stream-copy and
+ * MFMA rates beside the vendor figures).  crog_probe_mfma_bf16: `blocks` x 4 waves each issue iters x 8 independent
+ * v_mfma_f32_32x32x16_bf16 on register operands (FLOP = blocks * 4 * iters * 8 * 32768); `sink` needs blocks * 256 floats and is
+ * never written.  crog_probe_copy: dst[0:bytes] = src[0:bytes], 16 bytes per lane (traffic = 2 * bytes).  Timing is the caller's. */
+int crog_probe_mfma_bf16(float* sink, int blocks, int iters, crog_stream_t stream);
+int crog_probe_copy(const void* src, void* dst, int64_t bytes, crog_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM / implicit-GEMM convolution family (MFMA 32x32x16 bf16, 32x32x2 f32).

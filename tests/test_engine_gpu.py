@@ -83,19 +83,25 @@ def test_train_with_grasp_gradscaler_and_clipping_match_torch_adam():
         loss.backward()
         torch.cuda.synchronize()
         cur = dict(model_b.named_parameters())
-        for k in names:
-            ref_p[k].grad = cur[k].grad.detach().clone()
-        norms.append(float(torch.nn.utils.clip_grad_norm_(list(ref_p.values()), args.max_norm)))
+        for k in names:      # (`logit_scale` is never used by the forward: its .grad stays None, as in torch)
+            ref_p[k].grad = None if cur[k].grad is None else cur[k].grad.detach().clone()
+        norms.append(float(torch.nn.utils.clip_grad_norm_([q for q in ref_p.values() if q.grad is not None], args.max_norm)))
         ref_opt.step()
         sd = model_b.state_dict()
         sd.update({k: ref_p[k].detach() for k in names})
         model_b.load_state_dict(sd)
     assert max(norms) > args.max_norm, norms            # the clipping branch really clipped
-    worst = max((got[k] - ref_p[k].detach()).abs().max().item() for k in names)
-    print(f"train_with_grasp (GradScaler on, max_norm 1.0) vs torch Adam + clip_grad_norm_: max parameter difference {worst:.2e}; "
-          f"gradient norms before clipping {['%.2f' % n for n in norms]}")
-    # Adam at lr 1e-3 moves every weight by ~1e-3 per step; the two sides differ only by fp32 summation order in the weight gradients
-    assert worst < 2e-5, worst
+    # Adam's update is scale-free (m / sqrt(v)): an element whose gradient is at the fp32 summation-noise level gets +-lr on either
+    # side with a coin flip, so the comparison is on the whole update vector (relative L2) and on the fraction of elements that
+    # moved differently, not on the worst element
+    init = seeded_state({k: tuple(v) for k, v in meta["shapes"].items()}, seed=meta["seed"], residual_gain=0.25)
+    da = torch.cat([(got[k].cpu() - init[k]).flatten() for k in names])
+    db = torch.cat([(ref_p[k].detach().cpu() - init[k]).flatten() for k in names])
+    rel = float((da - db).norm() / db.norm())
+    frac = float(((da - db).abs() > 2e-4).float().mean())
+    print(f"train_with_grasp (GradScaler on, max_norm 1.0) vs torch Adam + clip_grad_norm_: update vectors differ by {rel:.2e} (relative L2), "
+          f"{100 * frac:.3f} % of elements by more than 2e-4; |update| {float(db.norm()):.2f}; gradient norms before clipping {['%.2f' % n for n in norms]}")
+    assert rel < 2e-2 and frac < 2e-3, (rel, frac)
     for k, v in bn_a.items():
         assert torch.allclose(v, model_b.state_dict()[k], rtol=1e-4, atol=1e-5), k
 
@@ -128,9 +134,11 @@ def test_reference_statement_order_with_stock_torch_adam():
     moved = (m_t.state_dict()["neck.f1_v_proj.0.weight"].cpu() - init["neck.f1_v_proj.0.weight"]).abs().max().item()
     assert moved > 1e-4, "torch.optim.Adam silently skipped the parameters"
     m_f, _ = steps(lambda m, g: FusedAdam(g, lr=1e-3, store=m.store))
-    worst = max((p.detach() - q.detach()).abs().max().item() for (_, p), (_, q) in zip(m_t.named_parameters(), m_f.named_parameters()))
-    print(f"torch.optim.Adam (set_to_none zero_grad) vs FusedAdam after 2 steps: max parameter difference {worst:.2e}")
-    assert worst < 2e-5
+    da = torch.cat([(p.detach().cpu() - init[n]).flatten() for n, p in m_t.named_parameters()])
+    db = torch.cat([(p.detach().cpu() - init[n]).flatten() for n, p in m_f.named_parameters()])
+    rel = float((da - db).norm() / db.norm())
+    print(f"torch.optim.Adam (set_to_none zero_grad) vs FusedAdam after 2 steps: update vectors differ by {rel:.2e} (relative L2)")
+    assert rel < 2e-2
 
 
 def test_gradients_accumulate_until_zero_grad():
@@ -192,4 +200,4 @@ def test_decoder_return_intermediate_outputs():
     o2 = model.decoder(fq.detach(), wfeat.detach(), pad)
     (o2[0].float().sum() + 2.0 * o2[1].float().sum()).backward()
     torch.cuda.synchronize()
-    assert float(model.decoder.norm.bias.grad.sum()) == pytest.approx(3.0 * o2[0].numel() / o2[0].shape[-1], rel=1e-4)
+    assert float(model.decoder.norm.bias.grad.sum()) == pytest.approx(3.0 * o2[0].numel(), rel=1e-4)     # 1 x (first use) + 2 x (second use), per element
