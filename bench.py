@@ -228,6 +228,7 @@ def main():
            "lin_fwd": (K.A_KC, K.B_KC), "none": None}[args.roofline_kernel]
     if key is not None and rank == 0:
         K.PROF = dict(key=key, records=[])
+    coll0 = (RT.comm.calls if RT.comm is not None else 0, net.reducer.launches if (world > 1 or force_ddp) else 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats, _ = train_step(net, opt, None, batch, cfg, autocast_dtype=adt)
@@ -273,6 +274,10 @@ def main():
             "roofline": roof,
             "last_step": {"loss": round(last[0], 4), "iou": round(last[1], 3), "prec50": round(last[2], 3)},
         }
+        if world > 1 or force_ddp:
+            out["collectives_per_step"] = {"syncbn_allreduce": (RT.comm.calls - coll0[0]) // args.steps if RT.comm is not None else 0,
+                                           "gradient_buckets": (net.reducer.launches - coll0[1]) // args.steps,
+                                           "note": "BatchNorm statistics on a communicator of their own (crog_amd/parallel.py); metric all-reduce not counted"}
         if world == 1:
             try:
                 out["measured_peaks"] = measured_peaks(dev)

@@ -537,3 +537,21 @@ def head_loss(pred, targets, Hin, Win, weighted, tgt_small, loss_sums, dpred):
 def train_metric(pred, pred_bstride, tgt, B, P, threshold, pr_iou, counts, out2):
     check(lib().crog_train_metric(ptr(pred), pred_bstride, ptr(tgt), B, P, float(threshold), float(pr_iou), ptr(counts), ptr(out2),
                                   stream()), "train_metric")
+
+
+# --------------------------------------------------------------------------------------------
+# SSG target assignment (csrc/ssg.hip)
+# --------------------------------------------------------------------------------------------
+def ssg_match(anchors: torch.Tensor, gt: torch.Tensor, ng: torch.Tensor, pos_thr: float, neg_thr: float):
+    """anchors [A,4] fp32 (cx,cy,w,h); gt [B,Gmax,5] fp32; ng [B] int32 -> (offsets [B,A,4], labels [B,A] i64, matched box [B,A,4],
+    matched index [B,A] i64) for the whole batch in two launches."""
+    A, (B, Gmax) = anchors.shape[0], gt.shape[:2]
+    dev = gt.device
+    claim = torch.empty(B, Gmax, device=dev, dtype=torch.int32)
+    offsets = torch.empty(B, A, 4, device=dev, dtype=torch.float32)
+    labels = torch.empty(B, A, device=dev, dtype=torch.int64)
+    mbox = torch.empty(B, A, 4, device=dev, dtype=torch.float32)
+    midx = torch.empty(B, A, device=dev, dtype=torch.int64)
+    check(lib().crog_ssg_match(ptr(anchors), A, ptr(gt), ptr(ng), B, Gmax, float(pos_thr), float(neg_thr), ptr(claim), ptr(offsets), ptr(labels),
+                               ptr(mbox), ptr(midx), stream()), "ssg_match")
+    return offsets, labels, mbox, midx

@@ -26,20 +26,32 @@ _DRY = _os.environ.get("CROG_DDP_DRY") == "1"   # diagnostics: run the reducer's
 
 
 class SyncBNComm:
+    """Communicator of the cross-replica BatchNorm statistics (train_crog.py:113-114).  It owns a process group of ITS OWN
+    (a second RCCL communicator over the same ranks): collectives of one communicator execute in issue order, so on the default
+    group a 2 x C-float statistics all-reduce issued during backward queues behind whatever 64 MiB gradient bucket is in flight
+    (0.5-1 ms each, 71 times per step, on the critical path); on a separate communicator the two run side by side."""
+
     def __init__(self, group=None):
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.force = False
+        self.calls = 0          # collectives issued (bench.py reports the per-step count)
 
     def all_reduce_sum(self, t: torch.Tensor):
+        self.calls += 1
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
 
-def convert_sync_batchnorm(model, process_group=None, force=False):
+def convert_sync_batchnorm(model, process_group=None, force=False, dedicated_group=True):
     """nn.SyncBatchNorm.convert_sync_batchnorm equivalent: BatchNorm statistics of the HIP path become cross-replica.
-    `force` installs the communicator even at world_size 1 (single-GPU smoke test of the collective path)."""
+    `force` installs the communicator even at world_size 1 (single-GPU smoke test of the collective path).  Without an explicit
+    `process_group` a dedicated group over all ranks is created (a collective call: every rank converts its model, as with the
+    reference's conversion)."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force):
-        RT.comm = SyncBNComm(process_group)
+        group = process_group
+        if group is None and dedicated_group and dist.get_world_size() > 1:
+            group = dist.new_group()
+        RT.comm = SyncBNComm(group)
         RT.comm.force = force
     return model
 
@@ -69,6 +81,7 @@ class Reducer:
                 self.bucket_of[id(p)] = i
         self._armed = False
         self._use_avg = dist.get_backend(group) == "nccl"
+        self.launches = 0       # bucket all-reduces issued (bench.py reports the per-step count)
         self.reset()
 
     def reset(self):
@@ -84,6 +97,7 @@ class Reducer:
         if b["launched"]:
             return
         b["launched"] = True
+        self.launches += 1
         # a bucket can hold gradients written on different streams (image tower: main, text tower: side stream):
         # make the launching stream wait for the others before RCCL's stream takes its dependency on it
         view = self.G[b["start"]:b["start"] + b["numel"]]

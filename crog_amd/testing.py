@@ -235,3 +235,36 @@ def save_clip_archive(sd: Dict[str, torch.Tensor], path: str):
         else:
             mod.register_buffer(leaf, val.clone())
     torch.jit.save(torch.jit.script(root), path)
+
+
+def synthetic_ssg_predictions(B: int, A: int, cfg, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    """Seeded random stand-ins for the six raw SSG predictions at the configuration's sizes (class logits, box offsets, tanh-range
+    coefficients, ReLU-range prototypes, semantic logits): inputs for loss-only parity (the loss does not care where they came from)."""
+    hp, hs, P, C = cfg.img_size // 4, cfg.img_size // 8, cfg.num_protos, cfg.num_classes
+    g = lambda name: _gen("ssg-pred::" + name, seed)
+    out = dict(class_pred=torch.randn(B, A, C, generator=g("cls")),
+               box_pred=0.5 * torch.randn(B, A, 4, generator=g("box")),
+               ins_coef_pred=torch.tanh(torch.randn(B, A, P, generator=g("ins"))),
+               grasp_coef_pred=torch.tanh(torch.randn(B, A, 4, P, generator=g("grasp"))),
+               protos=torch.relu(torch.randn(B, hp, hp, P, generator=g("protos"))) * 0.5,
+               seg_pred=torch.randn(B, C, hs, hs, generator=g("seg")))
+    return {k: v.to(device) for k, v in out.items()}
+
+
+def synthetic_ssg_output(anchors: torch.Tensor, cfg, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    """Seeded eval-mode output_dict of SSG.forward for ONE image (ssg.py:283-293) with a few dozen confident, overlapping
+    detections: class probabilities peaked on clusters of neighbouring anchors, small box offsets, tanh-range coefficients."""
+    A = anchors.shape[0]
+    P, C, hp = cfg.num_protos, cfg.num_classes, cfg.img_size // 4
+    g = lambda name: _gen("ssg-out::" + name, seed)
+    logits = torch.randn(A, C, generator=g("cls"))
+    logits[:, 0] += 4.0                                              # background dominates ...
+    centres = torch.randint(0, A, (40,), generator=g("centres"))
+    for j, c in enumerate(centres.tolist()):                         # ... except around 40 anchor clusters
+        lo, hi = max(0, c - 4), min(A, c + 5)
+        logits[lo:hi, 1 + j % (C - 1)] += 7.0 + 0.1 * torch.arange(hi - lo)
+    out = dict(anchors=anchors.flatten().tolist(), protos=torch.relu(torch.randn(1, hp, hp, P, generator=g("protos"))) * 0.5,
+               cls_pred=torch.softmax(logits, -1)[None], box_pred=0.3 * torch.randn(1, A, 4, generator=g("box")),
+               ins_coef_pred=torch.tanh(torch.randn(1, A, P, generator=g("ins"))),
+               grasp_coef_pred=torch.tanh(torch.randn(1, A, 4, P, generator=g("grasp"))))
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in out.items()}

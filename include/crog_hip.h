@@ -351,6 +351,16 @@ int crog_head_loss(const float* pred, const float* const* targets, int B, int he
 int crog_train_metric(const float* pred, int64_t pred_bstride, const float* tgt, int B, int64_t P,
                       float threshold, float pr_iou, float* counts, float* out2, crog_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SSG target assignment for a whole batch (model/ssg.py:317-321 looping utils/box_utils.py:57-117 `match` + `encode` per
+ * image): anchors [A][4] (cx, cy, w, h), gt [B][Gmax][5] (corner box + class, rows >= ng[b] ignored), ng [B] >= 1.
+ * Outputs per (image, anchor): SSD-encoded offsets [B][A][4], labels [B][A] (class of the matched box; -1 neutral below
+ * pos_iou_thre; 0 background below neg_iou_thre), the matched box [B][A][4] and its index [B][A].  `claim` [B][Gmax] is
+ * scratch (each box's best anchor).  Every box keeps its best anchor; a later box wins a contested anchor. */
+int crog_ssg_match(const float* anchors, int A, const float* gt, const int* ng, int B, int Gmax, float pos_iou_thre,
+                   float neg_iou_thre, int* claim, float* offsets, int64_t* labels, float* matched_box,
+                   int64_t* matched_idx, crog_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -349,6 +349,71 @@ def clip_load_fixture(ref_clip):
     print("clip_load fixture:", {f: sum(1 for x in flags.values() if x[0] == f) for f in (0, 1, 2)}, inferred, flush=True)
 
 
+def ssg_loss_fixture(name, cfg, B, seed, stride=97):
+    """Row S2 / N4 at the yaml's anchor set: the reference's own SSG.compute_loss (ssg.py:297-530) on seeded random predictions
+    (the loss does not care where they came from) and ragged synthetic ground truth for B images -> eight losses + fixed-stride samples
+    and sums of d(sum of losses)/d(prediction).  `cfg.masks_to_train` below the positives per image exercises the randperm branch;
+    the CPU generator is seeded right before the call (the test does the same)."""
+    import model.ssg as ref_ssg
+    from crog_amd.testing import synthetic_ssg_predictions
+    torch.manual_seed(0)
+    m = ref_ssg.SSG(cfg)
+    anchors = torch.tensor(m.anchors).reshape(-1, 4)
+    preds = synthetic_ssg_predictions(B, anchors.shape[0], cfg, seed)
+    batch = synthetic_ssg_batch(B, cfg.img_size, cfg.with_depth, seed=1234 + seed)
+    tg = synthetic_ssg_targets(B, cfg.img_size, cfg.num_classes, seed=1234 + seed)
+    leaf = {k: preds[k].clone().requires_grad_(True) for k in SSG_OUTPUTS}
+    torch.manual_seed(4242 + seed)
+    losses = m.compute_loss(leaf["class_pred"], leaf["box_pred"], leaf["ins_coef_pred"], leaf["grasp_coef_pred"], leaf["protos"],
+                            leaf["seg_pred"], {**batch, **tg}, {})
+    sum(losses.values()).backward()
+    out = {"S2::" + k: v.detach() for k, v in losses.items()}
+    for k in SSG_OUTPUTS:
+        out["S2::d_" + k + "::sample"], out["S2::d_" + k + "::sums"] = sampled(leaf[k].grad, stride)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **{k: v.detach().numpy() for k, v in out.items()})
+    json.dump(dict(seed=seed, B=B, stride=stride, anchors=int(anchors.shape[0]), cfg={k: v for k, v in vars(cfg).items()}),
+              open(os.path.join(GOLD, name + ".json"), "w"))
+    print(name, {k: round(float(v), 5) for k, v in losses.items()}, flush=True)
+
+
+def ssg_detect_fixture(name, cfg, seed):
+    """Row N4, detection side: the reference's own `fast_nms` and `crop` (utils/grasp_eval.py:54-94, utils/box_utils.py:150-169) driven
+    as `ssg_post_processing` drives them (grasp_eval.py:99-150,168-186; batch size 1) on a seeded synthetic output_dict."""
+    for mod, attrs in (("skimage", ()), ("skimage.draw", ("polygon",)), ("skimage.filters", ("gaussian",)), ("skimage.feature", ("peak_local_max",))):
+        m_ = types.ModuleType(mod)
+        for a in attrs:
+            setattr(m_, a, None)
+        sys.modules.setdefault(mod, m_)
+    import utils.grasp_eval as ge
+    import model.ssg as ref_ssg
+    from crog_amd.testing import synthetic_ssg_output
+    torch.manual_seed(0)
+    anchors = torch.tensor(ref_ssg.SSG(cfg).anchors).reshape(-1, 4)
+    od = synthetic_ssg_output(anchors, cfg, seed)
+    protos, cls_pred, box_pred = od["protos"].squeeze(), od["cls_pred"].squeeze().transpose(1, 0).contiguous()[1:], od["box_pred"].squeeze()
+    ins_coef, grasp_coef = od["ins_coef_pred"].squeeze(), od["grasp_coef_pred"].squeeze()
+    keep = cls_pred.max(dim=0)[0] > cfg.nms_score_thre
+    a, b = anchors[keep], box_pred[keep]
+    dec = torch.cat((a[:, :2] + b[:, :2] * 0.1 * a[:, 2:], a[:, 2:] * torch.exp(b[:, 2:] * 0.2)), 1)
+    dec[:, :2] -= dec[:, 2:] / 2
+    dec[:, 2:] += dec[:, :2]
+    dec = torch.clip(dec, min=0., max=1.)
+    ids, sc, bx, ic, gc = ge.fast_nms(cfg, dec, cls_pred[:, keep], ins_coef[keep], grasp_coef[keep])
+    ok = sc > 0.3
+    assert bool(ok.any())
+    ids, sc, bx, ic, gc = ids[ok], sc[ok], bx[ok], ic[ok], gc[ok]
+    maps = dict(ins=torch.sigmoid(protos @ ic.t()), qua=torch.sigmoid(protos @ gc[:, 0].t()), sin=protos @ gc[:, 1].t(),
+                cos=protos @ gc[:, 2].t(), wid=torch.sigmoid(protos @ gc[:, 3].t()))
+    out = {"cls": ids + 1, "scores": sc, "bboxes": bx, "n_kept_before_nms": torch.tensor(int(keep.sum()))}
+    for k, v in maps.items():
+        v = ge.crop(v.contiguous(), bx).permute(2, 0, 1)
+        out["map_sums::" + k] = v.double().sum((1, 2))
+        out["map_sample::" + k] = v.flatten()[::211].clone()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **{k: v.detach().numpy() for k, v in out.items()})
+    json.dump(dict(seed=seed, cfg={k: v for k, v in vars(cfg).items()}), open(os.path.join(GOLD, name + ".json"), "w"))
+    print(name, "detections", int(ids.numel()), "of", int(keep.sum()), "score-filtered anchors", flush=True)
+
+
 def shapes_only(ref_clip):
     """Parameter names/shapes of the real CLIP RN50 and ViT-B/16 towers + CROG heads (names are the checkpoint contract)."""
     vit = ref_clip.CLIP(512, 224, 12, 768, 16, 77, 20, 49408, 512, 8, 12)
@@ -358,7 +423,7 @@ def shapes_only(ref_clip):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_clip, ref_crog, ref_layers = import_reference()
-    which = sys.argv[1:] or ["tiny", "ops", "vit", "ssg", "shapes", "full", "damped", "damped4", "vitfull", "ssgfull", "clipload"]
+    which = sys.argv[1:] or ["tiny", "ops", "vit", "ssg", "shapes", "full", "damped", "damped4", "vitfull", "ssgfull", "ssgloss", "ssgdet", "clipload"]
     if "tiny" in which:
         run_case("tiny_crog", tiny_cfg(), B=4, seed=3, ref_model=ref_model, ref_clip=ref_clip, store_intermediates=True)
         run_case("tiny_crog_nomask", tiny_cfg(use_grasp_masks=False), B=4, seed=4, ref_model=ref_model, ref_clip=ref_clip,
@@ -370,6 +435,13 @@ def main():
     if "ssg" in which:
         ssg_fixture("ssg_tiny_rgbd", ssg_tiny_cfg(), B=2, seed=6)
         ssg_fixture("ssg_tiny_rgb", ssg_tiny_cfg(with_depth=False), B=2, seed=7)
+    if "ssgloss" in which:
+        from crog_amd.testing import ssg_cfg
+        ssg_loss_fixture("ssg_loss_b8", ssg_cfg(), B=8, seed=12)
+        ssg_loss_fixture("ssg_loss_b8_limit", ssg_cfg(masks_to_train=12), B=8, seed=13)
+    if "ssgdet" in which:
+        from crog_amd.testing import ssg_cfg
+        ssg_detect_fixture("ssg_detect", ssg_cfg(nms_score_thre=0.05, nms_iou_thre=0.5, top_k=200, max_detections=100), seed=14)
     if "vitfull" in which:
         vit_full_fixture(ref_clip)
     if "ssgfull" in which:

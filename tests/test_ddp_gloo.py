@@ -40,7 +40,8 @@ class Net(torch.nn.Module):
 def _worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from crog_amd.parallel import DistributedDataParallel, SyncBNComm
+    from crog_amd.parallel import DistributedDataParallel, SyncBNComm, convert_sync_batchnorm
+    from crog_amd.runtime import RT
     torch.manual_seed(100 + rank)                      # different init per rank: DDP must broadcast rank 0's weights
     net = Net().prepare("cpu")
     ddp = DistributedDataParallel(net, bucket_cap_mb=0.001)   # tiny buckets -> several collectives in flight
@@ -54,10 +55,13 @@ def _worker(rank, world, port, tmp):
         ddp.reducer.wait()
     assert len(ddp.reducer.buckets) > 2
     # cross-replica BatchNorm statistics: all-reduce of (sum, sum^2) pairs
-    comm = SyncBNComm()
+    convert_sync_batchnorm(net)         # installs the statistics communicator on a process group of its own
+    comm = RT.comm
+    assert isinstance(comm, SyncBNComm) and comm.group is not None and comm.group is not dist.group.WORLD and comm.world_size == world
     z = I[rank * 4:(rank + 1) * 4]
     pairs = torch.stack([z.sum((0, 2, 3)), (z * z).sum((0, 2, 3))], 1).contiguous()
     comm.all_reduce_sum(pairs)
+    assert comm.calls == 1 and ddp.reducer.launches == 2 * len(ddp.reducer.buckets)
     torch.save(dict(G=net.store.G.clone(), P=net.store.P.clone(), pairs=pairs), os.path.join(tmp, f"r{rank}.pt"))
     dist.destroy_process_group()
 

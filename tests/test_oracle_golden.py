@@ -223,10 +223,11 @@ def test_oracle_ssg_trunk_matches_reference(case):
 
 @pytest.mark.parametrize("case", ["ssg_tiny_rgbd", "ssg_tiny_rgb"])
 def test_ssg_loss_matches_reference(case):
-    """SURVEY §8a row S2 (host logic): crog_amd.ssg_loss on the fixture's raw predictions + synthetic ground truth against the
-    reference's own SSG.compute_loss (ssg.py:297-530): eight losses and the gradient of their sum w.r.t. every prediction."""
+    """the loss oracle (oracle/ssg_loss_oracle.py) on the fixture's raw predictions + synthetic ground truth
+    against the reference's own SSG.compute_loss (ssg.py:297-530): eight losses and the gradient of their sum w.r.t. every
+    prediction.  (The product's batched device implementation is held to the same fixtures in tests/test_ssg_gpu.py.)"""
     from types import SimpleNamespace
-    from crog_amd.ssg_loss import ssg_loss
+    from oracle.ssg_loss_oracle import ssg_loss
     from crog_amd.testing import SSG_OUTPUTS, synthetic_ssg_targets
     from oracle import ssg_oracle as S
     fx, meta = load_case(case)
@@ -243,3 +244,31 @@ def test_ssg_loss_matches_reference(case):
     for k in SSG_OUTPUTS:
         check(raw[k].grad, fx["S2::d_" + k], atol=1e-7, rtol=1e-4, what=f"{case} d{k}")
     assert out["inter_mask_p"].shape == out["inter_mask_gt"].shape and out["inter_mask_p"].dim() == 3
+
+
+@pytest.mark.parametrize("case", ["ssg_loss_b8", "ssg_loss_b8_limit"])
+def test_ssg_loss_oracle_at_the_full_anchor_set(case):
+    """The loss oracle at ssg_r50.yaml's own sizes (18,525 anchors, 136 x 136 prototypes, B = 8 ragged images) against the reference's
+    compute_loss on seeded random predictions; `_limit` lowers masks_to_train so that the CPU-randperm subsampling branch runs
+    (same generator seed as the fixture script)."""
+    from types import SimpleNamespace
+    from crog_amd.testing import SSG_OUTPUTS, synthetic_ssg_batch, synthetic_ssg_predictions, synthetic_ssg_targets
+    from oracle import ssg_oracle as S
+    from oracle.ssg_loss_oracle import ssg_loss
+    fx, meta = load_case(case)
+    cfg = SimpleNamespace(**meta["cfg"])
+    anchors = torch.tensor(S.anchors(cfg.aspect_ratios, cfg.img_size, cfg.anchor_strides)).reshape(-1, 4)
+    assert anchors.shape[0] == meta["anchors"]
+    raw = {k: v.requires_grad_(True) for k, v in synthetic_ssg_predictions(meta["B"], anchors.shape[0], cfg, meta["seed"]).items()}
+    tg = synthetic_ssg_targets(meta["B"], cfg.img_size, cfg.num_classes, seed=1234 + meta["seed"])
+    torch.manual_seed(4242 + meta["seed"])
+    losses = ssg_loss(cfg, anchors, raw, tg, {})
+    for k, v in losses.items():
+        check(v, fx["S2::" + k], atol=1e-5, rtol=1e-5, what=f"{case} {k}")
+    sum(losses.values()).backward()
+    for k in SSG_OUTPUTS:
+        g = raw[k].grad.flatten()
+        check(g[::meta["stride"]], fx["S2::d_" + k + "::sample"], atol=1e-7, rtol=1e-4, what=f"{case} d{k} samples")
+        ref_sums = fx["S2::d_" + k + "::sums"]
+        got = torch.stack([g.double().sum(), g.double().abs().sum()])
+        assert float((got - ref_sums).abs().max()) <= 1e-4 * float(ref_sums[1]) + 1e-9, (case, k, got, ref_sums)

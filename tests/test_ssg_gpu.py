@@ -115,3 +115,100 @@ def test_ssg_training_forward_with_targets_returns_reference_losses(case):
     g = model.backbone.conv1.weight.grad
     assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
     assert "inter_mask_p" in out
+
+
+# ---- row N4: the batched device loss / target assignment / detection post-processing -------------------------------------------------
+def _anchors(cfg):
+    from oracle import ssg_oracle as S
+    return torch.tensor(S.anchors(cfg.aspect_ratios, cfg.img_size, cfg.anchor_strides)).reshape(-1, 4)
+
+
+def test_ssg_match_kernel_equals_the_reference_loop():
+    """csrc/ssg.hip against the per-image / per-box restatement of box_utils.py:57-117 (oracle), on ragged ground truth that includes
+    duplicated boxes (two boxes claiming the same best anchor: the later one must win), a box so small that only its forced claim makes
+    an anchor positive, and images with a single box.  Labels, matched indices and boxes bit-exact; offsets to 1e-6 (device logf)."""
+    from crog_amd import kernels as K
+    from crog_amd.ssg_loss import pad_ground_truth
+    from crog_amd.testing import ssg_cfg
+    from oracle.ssg_loss_oracle import match_anchors
+    cfg = ssg_cfg()
+    anchors = _anchors(cfg)
+    g = torch.Generator().manual_seed(5)
+    rows = []
+    for n in (3, 1, 5, 2, 4, 1, 6, 2):
+        c = 0.2 + 0.6 * torch.rand(n, 2, generator=g)
+        wh = 0.05 + 0.4 * torch.rand(n, 2, generator=g)
+        box = torch.cat([(c - wh / 2).clamp(0.01), (c + wh / 2).clamp(max=0.99)], 1)
+        rows.append(torch.cat([box, torch.randint(1, cfg.num_classes, (n, 1), generator=g).float()], 1))
+    rows[2][3, :4] = rows[2][1, :4]                           # duplicate: boxes 1 and 3 of image 2 claim the same anchor
+    rows[4][0, :4] = torch.tensor([0.5, 0.5, 0.5 + 0.012, 0.5 + 0.012])     # tiny box: no anchor reaches IoU 0.5 with it
+    gt, ng = pad_ground_truth(rows, "cuda")
+    off, lab, mbox, midx = K.ssg_match(anchors.cuda(), gt, ng, cfg.pos_iou_thre, cfg.neg_iou_thre)
+    for i, r in enumerate(rows):
+        o_ref, l_ref, b_ref, i_ref = match_anchors(cfg, r[:, :4], r[:, 4].long(), anchors)
+        assert torch.equal(lab[i].cpu(), l_ref) and torch.equal(midx[i].cpu(), i_ref) and torch.equal(mbox[i].cpu(), b_ref), i
+        assert err(off[i], o_ref) < 1e-5, (i, err(off[i], o_ref))
+    assert int((lab[4] > 0).sum()) >= 1 and int((lab > 0).sum()) > 50
+
+
+@pytest.mark.parametrize("case", ["ssg_loss_b8", "ssg_loss_b8_limit"])
+def test_batched_ssg_loss_matches_reference_at_full_anchor_set(case):
+    """crog_amd.ssg_loss (crog_ssg_match + batched GEMM mask assembly, no per-image loops) against the reference's compute_loss at
+    ssg_r50.yaml's sizes: eight losses within 1e-4 relative, gradients w.r.t. all six predictions (samples + sums)."""
+    from crog_amd.ssg_loss import ssg_loss
+    from crog_amd.testing import synthetic_ssg_predictions
+    fx, meta = load_case(case)
+    cfg = SimpleNamespace(**meta["cfg"])
+    anchors = _anchors(cfg).cuda()
+    raw = {k: v.requires_grad_(True) for k, v in synthetic_ssg_predictions(meta["B"], anchors.shape[0], cfg, meta["seed"], device="cuda").items()}
+    tg = synthetic_ssg_targets(meta["B"], cfg.img_size, cfg.num_classes, seed=1234 + meta["seed"], device="cuda")
+    torch.manual_seed(4242 + meta["seed"])
+    out = {}
+    losses = ssg_loss(cfg, anchors, raw, tg, out)
+    assert list(losses) == ["loss_cls", "loss_box", "loss_ins", "loss_sem", "loss_qua", "loss_sin", "loss_cos", "loss_wid"]
+    for k, v in losses.items():
+        ref = float(fx["S2::" + k])
+        assert abs(float(v) - ref) <= 1e-4 * max(1.0, abs(ref)), (k, float(v), ref)
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    for k in SSG_OUTPUTS:
+        gk = raw[k].grad.flatten()
+        ref_s = fx["S2::d_" + k + "::sample"]
+        scale = float(ref_s.abs().max()) + 1e-12
+        assert err(gk[::meta["stride"]], ref_s) <= 2e-4 * scale + 1e-9, (k, err(gk[::meta["stride"]], ref_s), scale)
+        sums = torch.stack([gk.double().sum(), gk.double().abs().sum()]).cpu()
+        ref_sums = fx["S2::d_" + k + "::sums"]          # (signed sum, sum of magnitudes): both errors relative to the magnitude sum
+        assert float((sums - ref_sums).abs().max()) <= 1e-4 * float(ref_sums[1]) + 1e-9, (k, sums, ref_sums)
+    assert out["inter_mask_p"].shape == out["inter_mask_gt"].shape and out["inter_mask_p"].dim() == 3
+
+
+@pytest.mark.parametrize("case", ["ssg_tiny_rgbd", "ssg_tiny_rgb"])
+def test_batched_ssg_loss_matches_reference_on_trunk_predictions(case):
+    from crog_amd.ssg_loss import ssg_loss
+    fx, meta = load_case(case)
+    cfg = SimpleNamespace(**meta["cfg"])
+    tg = synthetic_ssg_targets(meta["B"], cfg.img_size, cfg.num_classes, seed=1234 + meta["seed"], device="cuda")
+    raw = {k: fx[k].clone().cuda().requires_grad_(True) for k in SSG_OUTPUTS}
+    losses = ssg_loss(cfg, _anchors(cfg).cuda(), raw, tg, {})
+    for k, v in losses.items():
+        ref = float(fx["S2::" + k])
+        assert abs(float(v) - ref) <= 1e-5 * max(1.0, abs(ref)), (k, float(v), ref)
+    sum(losses.values()).backward()
+    for k in SSG_OUTPUTS:
+        scale = float(fx["S2::d_" + k].abs().max()) + 1e-12
+        assert err(raw[k].grad, fx["S2::d_" + k]) <= 1e-4 * scale + 1e-8, k
+
+
+def test_ssg_detections_match_reference_fast_nms():
+    """Tensor half of ssg_post_processing on the device (score filter, box decoding, fast NMS, score floor, cropped maps) against the
+    reference's own fast_nms / crop on a synthetic output_dict with 13k score-filtered anchors and 100 surviving detections."""
+    from crog_amd.ssg_loss import ssg_detections
+    from crog_amd.testing import synthetic_ssg_output
+    fx, meta = load_case("ssg_detect")
+    cfg = SimpleNamespace(**meta["cfg"])
+    od = synthetic_ssg_output(_anchors(cfg), cfg, meta["seed"], device="cuda")
+    det = ssg_detections(cfg, od)
+    assert torch.equal(det["cls"].cpu(), fx["cls"]) and err(det["scores"], fx["scores"]) < 1e-6 and err(det["bboxes"], fx["bboxes"]) < 1e-6
+    for k, m in det["maps"].items():
+        assert err(m.double().sum((1, 2)), fx["map_sums::" + k]) < 1e-2 * (1.0 + float(fx["map_sums::" + k].abs().max()) * 1e-3)
+        assert err(m.flatten()[::211], fx["map_sample::" + k]) < 1e-4, k
