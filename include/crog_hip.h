@@ -361,6 +361,18 @@ int crog_ssg_match(const float* anchors, int A, const float* gt, const int* ng, 
                    float neg_iou_thre, int* claim, float* offsets, int64_t* labels, float* matched_box,
                    int64_t* matched_idx, crog_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training-input preprocessing (OCIDVLGDataset.preprocess, utils/dataset.py:843-914) for B same-sized uint8 samples:
+ * img [B][H][W][3], masks [B][4][H][W] (instance, quality, angle in degrees, width) -> out_img [B][3][S][S] fp32 (letterbox
+ * warp with cv2.warpAffine's INTER_CUBIC arithmetic, border = the CLIP mean, then (v / 255 - mean) / std) and out_masks
+ * [B][5][S][S] fp32 (INTER_LINEAR warp, border 0: mask / 255, quality / 255, sin(2 theta), cos(2 theta), width / 255).
+ * Host-side constants (HOST pointers, read before the launch): minv[6] = the inverted 2 x 3 letterbox matrix in double, mean[3],
+ * stdv[3], border[3] (8-bit border value per channel).  tab_cubic [1024][16] / tab_linear [1024][4] are DEVICE int16 weight tables
+ * (15-bit fixed point, OpenCV's initInterTab2D). */
+int crog_preprocess_u8(const uint8_t* img, const uint8_t* masks, int B, int H, int W, const double* minv,
+                       const int16_t* tab_cubic, const int16_t* tab_linear, int S, const float* mean, const float* stdv,
+                       const int* border, float* out_img, float* out_masks, crog_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

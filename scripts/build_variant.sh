@@ -7,6 +7,6 @@ name=$1; shift
 mkdir -p crog_amd/csrc/build_$name
 hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-gpu-rdc "$@" -c crog_amd/csrc/gemm.hip -o crog_amd/csrc/build_$name/gemm.o
 objs=""
-for f in api norm eltwise head conv_aux attn ssg; do objs="$objs crog_amd/csrc/build/$f.o"; done
+for f in api norm eltwise head conv_aux attn ssg preprocess; do objs="$objs crog_amd/csrc/build/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o crog_amd/libcrog_hip_$name.so crog_amd/csrc/build_$name/gemm.o $objs
 echo built crog_amd/libcrog_hip_$name.so
