@@ -106,7 +106,10 @@ def cpu_baseline(budget_s=150):
     cores: 5 warm-up + 5 timed steps in a child process (killed at the wall-clock budget; whatever completed is reported)."""
     import subprocess
     import tempfile
-    threads, logical, model = _cpu_info()
+    n_phys, logical, model = _cpu_info()
+    # B = 2 convolutions scale NEGATIVELY past ~32 threads on the 128-core EPYC hosts of this pool (measured: 6.16 s/step at 128 threads,
+    # 1.2 s/step at 32), so the baseline gets the thread count that serves it best, capped by the physical cores present
+    threads = min(n_phys, 32)
     path = os.path.join(tempfile.mkdtemp(), "cpu_steps.json")
     p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path, "--cpu-threads", str(threads)],
                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -116,7 +119,7 @@ def cpu_baseline(budget_s=150):
         p.kill()
         p.wait()
     times = json.load(open(path)) if os.path.exists(path) else []
-    where = f"{model}; torch CPU threads = {threads} physical cores of {logical} logical CPUs"
+    where = f"{model}; torch CPU threads = {threads} of {n_phys} physical cores ({logical} logical CPUs)"
     if not times:
         return dict(value=None, unit="images/sec", cores=threads, kind="port", sample=f"no CPU step finished within {budget_s} s; {where}")
     used = times[CPU_WARMUP:] if len(times) > CPU_WARMUP else times[-1:]

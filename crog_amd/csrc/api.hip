@@ -46,7 +46,13 @@ __global__ void __launch_bounds__(256) mfma_probe_kernel(float* __restrict__ sin
 }
 // streaming copy, 16 bytes per lane, grid-stride: bytes moved = 2 * n16 * 16
 __global__ void __launch_bounds__(256) copy_probe_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n16) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) dst[i] = src[i];
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {      // four independent 16-byte loads in flight per lane
+    const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
 }
 }  // namespace
 

@@ -1356,7 +1356,33 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     const bool alt = alt_tiles_enabled();
 #ifdef CROG_GEMM_EXPERIMENTAL_TILES
     if (shape == 2 && dma_prefers_256(d)) return dispatch_dma<T, ShapeDma8>(d, s);
+    {
+      // A/B: wider tiles for the large 3x3 forward / data-gradient launches only (CROG_GEMM_CONV_TILE = f: 128 x 256 at two blocks
+      // per CU, 8: 256 x 256 at one), when the launch still has >= CROG_GEMM_CONV_MIN tiles of that shape
+      static int conv_tile = -1, conv_min = 512;
+      if (conv_tile < 0) {
+        const char* e = getenv("CROG_GEMM_CONV_TILE");
+        conv_tile = !e ? 0 : (e[0] == 'f' ? 1 : (e[0] == '8' ? 2 : 0));
+        const char* m = getenv("CROG_GEMM_CONV_MIN");
+        if (m) conv_min = atoi(m);
+      }
+      if (conv_tile && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0) {
+        if (conv_tile == 1 && (long)cdiv(d.M, 128) * (d.N / 256) >= conv_min) return dispatch_dma<T, ShapeFat>(d, s);
+        if (conv_tile == 2 && (long)cdiv(d.M, 256) * (d.N / 256) >= conv_min) return dispatch_dma<T, ShapeDma8>(d, s);
+      }
+    }
 #endif
+    // Large 3x3 forward / data-gradient launches (bf16, N a multiple of 256, >= 256 tiles of 256 x 256): the 8-wave 256 x 256 tile
+    // halves the L2 -> LDS bytes per FLOP, which is what bounds the 128 x 128 tile (ablation: DMA-only 831 us vs MFMA-only 603 us of a
+    // 1072 us launch).  Standalone +22-35 % on K = 4608 forwards (856 vs 691, 1031 vs 845 TFLOP/s), in the training step -1.5 %
+    // (37.5 vs 38.2 ms, two interleaved A/B pairs); smaller launches lose to tile quantisation at one block per CU and stay on 128 x 128.
+    static int conv256 = -1;
+    if (conv256 < 0) { const char* e = getenv("CROG_GEMM_NO_CONV256"); conv256 = (e && e[0] == '1') ? 0 : 1; }
+    if constexpr (sizeof(T) == 2) {
+      if (conv256 && alt && forced_shape() == 0 && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0 &&
+          (long)cdiv(d.M, 256) * (d.N / 256) >= 256)
+        return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, ShapeDma8>(d, s);
+    }
     static int force = -1;   // CROG_GEMM_DMA_TILE = mid | tall | wide | 64 : A/B runs only (never with BN statistics on 64-row tiles)
     if (force < 0) {
       const char* e = getenv("CROG_GEMM_DMA_TILE");

@@ -895,11 +895,19 @@ def test_production_conv3x3_fwd_dgrad_wgrad(K, dt, B, HW, Cin, Cout):
     x = rnd(B, H, W, Cin, dt=dt)
     w = (rnd(Cout, 3, 3, Cin, dt=dt, seed=1) * (9 * Cin) ** -0.5).to(dt)
     y = torch.empty(B, H, W, Cout, device="cuda", dtype=dt)
-    K.gemm(K.dcode(dt), K.A_IM2COL, K.B_KC, x, w, y, M, Cout, 9 * Cin, Cin, 9 * Cin, Cout, conv=(H, W, Cin))
+    # with BatchNorm statistics in the epilogue, as the training forward launches it (the (8, 104, 512, 256) case takes the 8-wave
+    # 256 x 256 tile: 338 tiles; the others stay on 128 x 128)
+    from crog_amd.functional import stat_replicas
+    R = stat_replicas(K.stat_tiles(M), Cout)
+    stats = torch.zeros(R, Cout, 2, device="cuda")
+    K.gemm(K.dcode(dt), K.A_IM2COL, K.B_KC, x, w, y, M, Cout, 9 * Cin, Cin, 9 * Cin, Cout, conv=(H, W, Cin), col_stats=stats, stat_replicas=R)
     xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
     wt = w.float().permute(0, 3, 1, 2).requires_grad_(True)
     ref = F.conv2d(xt, wt, padding=1)
     close(y, ref.permute(0, 2, 3, 1), dt, scale=math.sqrt(9 * Cin) / 4)
+    st = stats.sum(0).double()
+    assert _rel_l2(st[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < (1e-5 if dt == torch.float32 else 2e-3)
+    assert float((st[:, 0] - ref.double().sum((0, 2, 3))).abs().max()) < 2e-3 * math.sqrt(M)
     dy = rnd(B, H, W, Cout, dt=dt, seed=5)
     ref.backward(dy.float().permute(0, 3, 1, 2))
     # data gradient as the forward-shaped implicit GEMM on the [Cin][flipped tap][Cout] weight copy (crog_conv3_dgrad_weights)
