@@ -208,6 +208,9 @@ def main():
     model, groups = build_crog(cfg)            # random init of the RN50 architecture (no checkpoint / network here)
     model = model.to(dev)
     model.prepare(dev)
+    if os.environ.get("CROG_SINGLE_STREAM") == "1":      # profiling aid: one HIP stream, so that per-kernel durations are not inflated by overlap
+        RT.overlap_wgrad = False
+        model.overlap_text = False
     net = model
     if world > 1 or force_ddp:
         if os.environ.get("CROG_NO_SYNCBN") != "1":   # A/B switch: cost of the SyncBatchNorm exchange alone

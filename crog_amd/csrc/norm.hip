@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
                                                     const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                     const float* __restrict__ stats, long M, int C, T* __restrict__ dx, long lddx,
                                                     float* __restrict__ partial, int rows_per_block, float p_in, uint64_t seed_in,
-                                                    float p_out, uint64_t seed_out) {
+                                                    float p_out, uint64_t seed_out, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   constexpr int VEC = Elem<T>::VEC;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int cvec = C / VEC;
@@ -735,9 +735,11 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
       for (int j = 0; j < NV; j++) { cg[j] = ng[j % NP]; cg2[j] = ng2[j % NP]; cx[j] = nx[j % NP]; }
     }
   }
-  // combine the block's 4 waves through LDS, then one plain store per value into this block's partial row
+  // combine the block's 4 waves through LDS, then one plain store per value into this block's partial row — or, with dgamma / dbeta
+  // given, add the block's sums straight into the gradient vectors (a wave's 64 atomics are two runs of 32 consecutive floats: the
+  // full-rate shape), which saves the reduction launch that followed every LayerNorm backward
   __shared__ float red[NT / 64][2 * 2048 / 8 + 1];
-  float* dst = partial + (long)blockIdx.x * C * 2;
+  float* dst = partial ? partial + (long)blockIdx.x * C * 2 : nullptr;
   for (int cg_ = 0; cg_ < 2 * C; cg_ += 2 * 2048 / 8) {  // 512 floats (256 channels) per round keeps LDS at 8 KB
 #pragma unroll
     for (int j = 0; j < NV; j++) {
@@ -750,8 +752,20 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
         }
     }
     __syncthreads();
-    for (int f = threadIdx.x; f < 2 * 2048 / 8 && cg_ + f < 2 * C; f += NT)
-      dst[cg_ + f] = red[0][f] + red[1][f] + red[2][f] + red[3][f];
+    if (dgamma) {
+      // lanes 0..31 of a wave take the dgamma halves of 32 consecutive channels, lanes 32..63 the dbeta halves
+      for (int q = threadIdx.x; q < 2 * 2048 / 8; q += NT) {
+        const int half = (q >> 5) & 1, ch = ((q >> 6) << 5) | (q & 31);      // channel inside this round, 32-channel groups
+        const int f = 2 * ch + half;
+        if (cg_ + 2 * ch < 2 * C) {
+          const float v = red[0][f] + red[1][f] + red[2][f] + red[3][f];
+          atomicAdd((half ? dbeta : dgamma) + (cg_ >> 1) + ch, v);
+        }
+      }
+    } else {
+      for (int f = threadIdx.x; f < 2 * 2048 / 8 && cg_ + f < 2 * C; f += NT)
+        dst[cg_ + f] = red[0][f] + red[1][f] + red[2][f] + red[3][f];
+    }
     __syncthreads();
   }
 }
@@ -1064,15 +1078,18 @@ extern "C" int crog_ln_bwd_blocks(int64_t M, int rows_per_block) { return cdiv(M
 
 extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void* dout2, int64_t lddo2, const void* x, int64_t ldx,
                            const float* gamma, const float* stats, int64_t M, int C, void* dx, int64_t lddx, float* partial,
-                           int rows_per_block, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, crog_stream_t stream) {
+                           int rows_per_block, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float* dgamma, float* dbeta,
+                           crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0 && C <= 2048, "ln_bwd: C=%d must be a multiple of %d and <= 2048", C, vec);
+  CROG_CHECK_ARG((dgamma != nullptr) == (dbeta != nullptr) && (partial != nullptr) != (dgamma != nullptr),
+                 "ln_bwd: give either the partial slab or both gradient vectors");
   const int blocks = cdiv(M, rows_per_block);
   const int nv = cdiv(C / vec, 64);
 #define CROG_LN_BWD(NV)                                                                                                           \
   DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dout, (long)lddo, \
                                        (const T*)dout2, (long)lddo2, (const T*)x, (long)ldx, gamma, stats, (long)M, C, (T*)dx,       \
-                                       (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out))
+                                       (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out, dgamma, dbeta))
   if (nv <= 1) CROG_LN_BWD(1);
   else if (nv <= 2) CROG_LN_BWD(2);
   else if (nv <= 4) CROG_LN_BWD(4);

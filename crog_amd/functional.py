@@ -45,6 +45,7 @@ FLASH_ATTN = _os.environ.get("CROG_FLASH_ATTN", "1") != "0"     # fused attentio
 FLASH_MIN_KEYS = 64
 BN_ATOMIC_STATS = _os.environ.get("CROG_BN_ATOMIC_STATS", "1") != "0"   # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize
 RELU_BITMASK = _os.environ.get("CROG_RELU_BITMASK", "1") != "0"   # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
+LN_BWD_ATOMIC = _os.environ.get("CROG_LN_BWD_ATOMIC", "0") == "1"   # LayerNorm parameter gradients through atomics in ln_bwd itself: measured 0.5 % SLOWER (every block adds into the same 2 C floats), kept for A/B
 BN_BWD_ATOMIC = _os.environ.get("CROG_BN_BWD_ATOMIC", "1") != "0"   # backward partial sums through coalesced atomics (bf16, no SyncBN)
 DGRAD_T = _os.environ.get("CROG_DGRAD_T", "1") != "0"          # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
 FUSED_HEAD = _os.environ.get("CROG_FUSED_HEAD", "1") != "0"    # fold vis.4 into the dynamic head (no groups*C-channel map)
@@ -551,9 +552,15 @@ class LayerNormFn(Function):
         dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
         rpb = K.ln_bwd_rows_per_block(M)
         nb = (M + rpb - 1) // rpb
-        partial = torch.empty(nb, C, 2, device=x.device, dtype=torch.float32)
-        K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, partial, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out)
-        K.reduce_split(partial, nb, C, None, gamma.grad(), beta.grad())
+        if LN_BWD_ATOMIC and x.dtype != torch.float32:
+            # the blocks add their (dgamma, dbeta) sums straight into the gradient vectors: no slab, no reduction launch (85 launches
+            # per CROG step).  fp32, the parity mode, keeps the ordered reduction (bit-reproducible run to run)
+            K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, None, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out,
+                     dgamma=gamma.grad(), dbeta=beta.grad())
+        else:
+            partial = torch.empty(nb, C, 2, device=x.device, dtype=torch.float32)
+            K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, partial, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out)
+            K.reduce_split(partial, nb, C, None, gamma.grad(), beta.grad())
         gamma.done()
         beta.done()
         dres = None

@@ -19,8 +19,9 @@ def agg(d, counter):
     return acc
 f, w = agg(fetch_dir, "FETCH_SIZE"), agg(write_dir, "WRITE_SIZE")
 def clean(n): return re.sub(r"\(anonymous namespace\)::", "", n)
-L = [f"# rocprofv3 summary — {tag}", "",
-     f"Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {steps-2} --warmup 2 --no-cpu-baseline` (CROG-R50 bf16, B=32, 416x416, 1x MI355X).",
+NOTE = os.environ.get("PROFILE_NOTE", "")
+L = [f"# rocprofv3 summary — {tag}", ""] + ([NOTE, ""] if NOTE else []) + [
+     f"Command: `{os.environ.get('PROFILE_ENV', '')}rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {steps-2} --warmup 2 --no-cpu-baseline` (CROG-R50 bf16, B=32, 416x416, 1x MI355X).",
      f"PMC passes (separate runs): `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction, MI355X_MICROARCH.md §HBM).", "",
      f"Total kernel time: {tot/1e6/steps:.2f} ms per step ({steps} steps profiled).", "",
      "| ms/step | % | launches/step | avg us | HBM MB/launch (PMC) | kernel |", "|---|---|---|---|---|---|"]

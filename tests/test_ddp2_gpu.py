@@ -93,6 +93,7 @@ def test_two_rank_ddp_syncbn_bf16_equals_single_process(tmp_path):
     print(f"bf16 logits, relative RMS: 2-rank vs 1-process {e:.3e}; 1-process run-to-run {floor:.3e}; logit scale {scale:.2f}")
     assert e < max(4 * floor, 2e-2)
     lm = 0.5 * (float(r0["loss"]) + float(r1["loss"]))
+    print(f"loss: 2-rank mean {lm:.5f}, 1-process {float(one['loss']):.5f} / {float(two['loss']):.5f}")
     assert abs(lm - float(one["loss"])) < max(1e-2 * abs(float(one["loss"])), 4 * abs(float(two["loss"]) - float(one["loss"])))
     names = meta["param_names"]
     a, b, c = r0["grad_norms"], one["grad_norms"], two["grad_norms"]
@@ -105,7 +106,9 @@ def test_two_rank_ddp_syncbn_bf16_equals_single_process(tmp_path):
     # a wrong 1/world factor on the BatchNorm parameter gradients (or on `count`) would be a factor 2, not a few per cent
     assert rel[big & bn_params].max() < max(0.25, 4 * rel_floor[big & bn_params].max())
     assert np.median(rel[big]) < max(3e-2, 4 * np.median(rel_floor[big]))
-    assert np.allclose(r0["bn_checksum"], one["bn_checksum"], rtol=2e-3, atol=2e-2)
+    d_bn, f_bn = np.abs(r0["bn_checksum"] - one["bn_checksum"]), np.abs(two["bn_checksum"] - one["bn_checksum"])
+    print(f"BatchNorm running-statistic checksums: 2-rank vs 1-process worst {d_bn.max():.3e}; run-to-run worst {f_bn.max():.3e}")
+    assert (d_bn <= np.maximum(4 * f_bn.max(), 2e-2 + 2e-3 * np.abs(one["bn_checksum"]))).all()
     ga, gb, gc = r0["G"].astype(np.float64), one["G"].astype(np.float64), two["G"].astype(np.float64)
     cos = lambda x, y: float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y)))
     print(f"flat gradient cosine: 2-rank vs 1-process {cos(ga, gb):.5f}; run-to-run {cos(gc, gb):.5f}")

@@ -135,9 +135,11 @@ def test_gemm_batched_heads(K, dt):
     v = qkv[:, 2 * E:].float().view(B, L, H, dh).permute(0, 2, 1, 3)
     ref = 0.125 * q @ k.transpose(-1, -2)
     close(S.view(B, H, L, Lp)[..., :L], ref, dt, scale=2)
-    # O = P V with P = S (pad cols are zero), V n-contiguous
+    # O = P V with P = S (row stride Lp, pad cols are zero), V n-contiguous.  The reduction length is the true key count L, as
+    # MhaFn passes it: rows L .. Lp-1 of the last batch element's V lie past the end of the buffer (K = Lp multiplied whatever the
+    # allocator had left there by P's zero pad, which is NaN when that memory holds a NaN)
     O = torch.empty(B * L, E, device="cuda", dtype=dt)
-    K.gemm(K.dcode(dt), K.A_KC, K.B_NC, S, qkv, O, L, dh, Lp, Lp, 3 * E, E, batch=B * H, batch_inner=H,
+    K.gemm(K.dcode(dt), K.A_KC, K.B_NC, S, qkv, O, L, dh, L, Lp, 3 * E, E, batch=B * H, batch_inner=H,
            sA=(H * L * Lp, L * Lp), sB=(L * 3 * E, dh), sC=(L * E, dh), b_off=2 * E)
     refo = (S.view(B, H, L, Lp)[..., :L].float() @ v).permute(0, 2, 1, 3).reshape(B * L, E)
     close(O, refo, dt, scale=8)
@@ -293,6 +295,12 @@ def test_layernorm(K, dt, C):
     K.reduce_pairs(partial, nb, C, sums)
     close(sums[:, 0], gt.grad, dt, scale=40)
     close(sums[:, 1], bt.grad, dt, scale=40)
+    # atomic form: the blocks add their sums straight into (pre-existing) gradient vectors — same dx, same totals, accumulating
+    dg, db = torch.full((C,), 0.5, device="cuda"), torch.full((C,), -0.25, device="cuda")
+    dx2 = torch.empty_like(x)
+    K.ln_bwd(d1, d2, x, g, stats, dx2, None, rpb, dgamma=dg, dbeta=db)
+    assert torch.equal(dx2, dx)
+    assert torch.allclose(dg - 0.5, sums[:, 0], rtol=1e-4, atol=1e-3) and torch.allclose(db + 0.25, sums[:, 1], rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("dt", DT)
