@@ -26,32 +26,55 @@ _DRY = _os.environ.get("CROG_DDP_DRY") == "1"   # diagnostics: run the reducer's
 
 
 class SyncBNComm:
-    """Communicator of the cross-replica BatchNorm statistics (train_crog.py:113-114).  It owns a process group of ITS OWN
-    (a second RCCL communicator over the same ranks): collectives of one communicator execute in issue order, so on the default
-    group a 2 x C-float statistics all-reduce issued during backward queues behind whatever 64 MiB gradient bucket is in flight
-    (0.5-1 ms each, 71 times per step, on the critical path); on a separate communicator the two run side by side."""
+    """Communicator of the cross-replica BatchNorm statistics (train_crog.py:113-114).  The exchanges are on the critical path (142
+    per CROG step, 2·C floats each), so they avoid both the gradient buckets' communicator — collectives of one communicator execute in
+    issue order, and a statistics exchange would queue behind whatever 64 MiB bucket is in flight — and, on RCCL, torch.distributed's
+    stream/event fencing: `direct` = an RCCL communicator of our own whose all-reduce is enqueued on the compute stream itself
+    (crog_amd/rccl.py).  OPT-IN (CROG_SYNCBN_DIRECT=1 or direct=True): at world size 1 — the only size this build could measure — the
+    direct form costs MORE than torch's (forced-DDP step 41.1-41.6 ms vs 39.7-40.0 ms, plain step 37.5 ms): RCCL's enqueue puts its own
+    host callbacks / fences on the user stream.  Default: a torch process group of its own (also the gloo path)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, direct=None):
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.force = False
         self.calls = 0          # collectives issued (bench.py reports the per-step count)
+        self.direct = None
+        self.kind = "torch.distributed"
+        if direct is None:
+            direct = _os.environ.get("CROG_SYNCBN_DIRECT", "0") == "1"
+        if direct and torch.cuda.is_available() and dist.get_backend(group) == "nccl":
+            try:
+                from .rccl import RcclComm
+                self.direct = RcclComm(group)
+                self.kind = "rccl-direct"
+            except Exception as e:      # any set-up problem: keep training on the torch path
+                import warnings
+                warnings.warn(f"crog_amd: direct RCCL communicator unavailable ({e!r}); SyncBatchNorm uses torch.distributed")
+                self.direct = None
 
     def all_reduce_sum(self, t: torch.Tensor):
         self.calls += 1
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if self.direct is not None and t.is_cuda:
+            self.direct.all_reduce_sum(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
 
-def convert_sync_batchnorm(model, process_group=None, force=False, dedicated_group=True):
+def convert_sync_batchnorm(model, process_group=None, force=False, dedicated_group=True, direct=None):
     """nn.SyncBatchNorm.convert_sync_batchnorm equivalent: BatchNorm statistics of the HIP path become cross-replica.
-    `force` installs the communicator even at world_size 1 (single-GPU smoke test of the collective path).  Without an explicit
-    `process_group` a dedicated group over all ranks is created (a collective call: every rank converts its model, as with the
-    reference's conversion)."""
+    `force` installs the communicator even at world_size 1 (single-GPU smoke test of the collective path).  A collective call:
+    every rank converts its model (as with the reference's conversion), because the statistics get a communicator of their own —
+    a direct RCCL one on the nccl backend, otherwise (or with direct=False) a dedicated torch process group."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force):
+        use_direct = (_os.environ.get("CROG_SYNCBN_DIRECT", "0") == "1") if direct is None else direct
+        use_direct = use_direct and torch.cuda.is_available() and dist.get_backend(process_group) == "nccl"
         group = process_group
-        if group is None and dedicated_group and dist.get_world_size() > 1:
+        if group is None and dedicated_group and not use_direct and dist.get_world_size() > 1:
             group = dist.new_group()
-        RT.comm = SyncBNComm(group)
+        RT.comm = SyncBNComm(group, direct=use_direct)
+        if RT.comm.direct is None and use_direct and group is None and dedicated_group and dist.get_world_size() > 1:
+            RT.comm.group = dist.new_group()     # direct set-up failed on every rank alike: fall back to a dedicated torch group
         RT.comm.force = force
     return model
 

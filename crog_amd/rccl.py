@@ -1,0 +1,89 @@
+"""A direct RCCL communicator for the SyncBatchNorm statistics exchange (`crog_comm_init` / `crog_syncbn_stats`).
+
+Why not `torch.distributed.all_reduce` for this one: ProcessGroupNCCL runs every collective on a stream of its own and fences it
+with two event hops (compute stream -> communicator stream -> compute stream) plus ~25 us of host work.  The CROG step issues 142
+statistics exchanges of 2·C floats each, ALL on the critical path (BatchNorm cannot apply before the global sums exist): measured at
+world size 1, where the collective itself is a no-op, that machinery alone costs 2.2 ms of a 37 ms step.  Here the exchange is one
+`ncclAllReduce` enqueued IN ORDER on the stream the BatchNorm kernels run on — no events, one ctypes call.
+
+STATUS: opt-in (`CROG_SYNCBN_DIRECT=1`).  Measured at world size 1 (the only size this build has hardware for) the direct form is
+SLOWER than torch's path (forced-DDP step 41.1-41.6 vs 39.7-40.0 ms): RCCL's own enqueue work lands on the compute stream.  Whether
+that reverses with real peers (where torch's two event hops sit next to a 20-30 us collective) needs an 8-GPU node.
+
+RCCL is the library PyTorch-ROCm already has resident (`torch/lib/librccl.so`); the unique id is created on rank 0 and handed to the
+other ranks through the existing `torch.distributed` group, which is also what the gradient buckets keep using (they are large,
+asynchronous and belong on a side stream).  If anything in the set-up fails, `crog_amd.parallel` falls back to a torch process group.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+
+NCCL_FLOAT32, NCCL_SUM = 7, 0          # ncclDataType_t / ncclRedOp_t (nccl.h; RCCL keeps NCCL's values)
+
+
+class _UniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_byte * 128)]
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        lib = ctypes.CDLL(path)
+        lib.ncclGetErrorString.restype = ctypes.c_char_p
+        lib.ncclGetErrorString.argtypes = [ctypes.c_int]
+        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
+        lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        for fn in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce, lib.ncclCommDestroy):
+            fn.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"RCCL {what} failed: {_load().ncclGetErrorString(rc).decode()} ({rc})")
+
+
+class RcclComm:
+    """ncclComm over the ranks of a torch.distributed group (default: all ranks).  Construction is a collective call."""
+
+    def __init__(self, group=None, device=None):
+        lib = _load()
+        self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        uid = _UniqueId()
+        if self.rank == 0:
+            _check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        wire = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
+        if dist.get_backend(group) == "nccl":
+            wire = wire.to(dev)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(wire, src=src, group=group)
+        ctypes.memmove(ctypes.byref(uid), bytes(wire.cpu().tolist()), 128)
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world_size, uid, self.rank), "ncclCommInitRank")
+        self._lib = lib
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        """In-place fp32 sum over the ranks, enqueued on the stream the caller's kernels run on."""
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise TypeError("RcclComm.all_reduce_sum expects a contiguous fp32 GPU tensor")
+        _check(self._lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), NCCL_FLOAT32, NCCL_SUM, self._comm, K.stream()), "ncclAllReduce")
+
+    def close(self):
+        if self._comm:
+            self._lib.ncclCommDestroy(self._comm)
+            self._comm = ctypes.c_void_p()
