@@ -16,6 +16,7 @@
 //   are copied row-major into LDS as [BK][cols+pad] with full 16-byte coalesced loads and are
 //   transposed on the READ side: ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <algorithm>
 
@@ -283,11 +284,17 @@ __device__ inline void flush_a_sum(const float (&asum)[WM], float* dst, int mbas
   }
 }
 
-__device__ inline float apply_act(float v, int act) {
-  if (act == CROG_ACT_RELU) return fmaxf(v, 0.f);
-  if (act == CROG_ACT_QUICKGELU) return v / (1.f + expf(-1.702f * v));
-  if (act == CROG_ACT_TANH) return tanhf(v);
-  return v;
+// Branch-free activations: a per-lane branch inside the register loops (ocml's tanhf has one at |x| = 0.625) makes the compiler
+// carry the f32x16 accumulators through divergent control flow as whole vectors and spill them.
+__device__ inline float act_quickgelu(float v) { return v / (1.f + expf(-1.702f * v)); }
+__device__ inline float act_tanh(float v) {      // (1 - t) / (1 + t), t = e^(-2|v|) in (0, 1]: absolute error <= 1 ulp of 1
+  const float t = expf(-2.f * fabsf(v));
+  return copysignf((1.f - t) / (1.f + t), v);
+}
+
+// value of lane ^ 1 (quad_perm [1, 0, 3, 2]): a DPP move, no LDS
+__device__ inline float dpp_swap1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
 
 template <int WM_, int WN_, int WVM_, int WVN_>
@@ -358,19 +365,27 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
           }
     }
   }
-  if (p.act != CROG_ACT_NONE) {
+  if (p.act == CROG_ACT_RELU) {
 #pragma unroll
     for (int i = 0; i < WM; i++)
 #pragma unroll
-      for (int j = 0; j < WN; j++) {
-        if (p.act == CROG_ACT_RELU) {
+      for (int j = 0; j < WN; j++)
 #pragma unroll
-          for (int e = 0; e < 16; e++) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
-        } else {
+        for (int e = 0; e < 16; e++) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+  } else if (p.act == CROG_ACT_QUICKGELU) {
 #pragma unroll
-          for (int e = 0; e < 16; e++) acc[i][j][e] = apply_act(acc[i][j][e], p.act);
-        }
-      }
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+      for (int j = 0; j < WN; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[i][j][e] = act_quickgelu(acc[i][j][e]);
+  } else if (p.act == CROG_ACT_TANH) {
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+      for (int j = 0; j < WN; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[i][j][e] = act_tanh(acc[i][j][e]);
   }
 
   if (p.col_stats) {  // block-uniform branch; slab rows are 128 matrix rows each
@@ -463,6 +478,39 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
       constexpr int CW = 32 * WN, CROW = CW + 8, VPR = CW / 8, RPP = 64 / VPR;  // vectors per row, rows per pass
       T* Cs = reinterpret_cast<T*>(smem) + wave * 32 * CROW;
       T* C = reinterpret_cast<T*>(p.C) + coff;
+      if (!R && (p.N & 1) == 0 && !(p.debug & 4)) {      // (debug bit 2: A/B switch back to the staged path)
+        // No residual: skip the LDS transpose.  Neighbouring lanes hold neighbouring columns of the same rows, so one DPP swap per
+        // register gives every lane two adjacent columns: even lanes store the pair of row(e), odd lanes the pair of row(e + 1) —
+        // 32 four-byte stores per 32 x 32 block and lane instead of 64 ds_write_b16 + barriers + ds_read_b128 + 16-byte stores.
+        // (The fp32-output path, which stores straight from the accumulators, moves TWICE the bytes of the staged bf16 path in
+        // 1.2x its time on the large-M 1x1 layers: the staging, not HBM, bounded them.)
+        const bool odd = lane & 1;
+        const int64_t ldc = p.ldc;
+        auto store_pairs = [&](auto guarded) {
+#pragma unroll
+          for (int i = 0; i < WM; i++)
+#pragma unroll
+            for (int j = 0; j < WN; j++) {
+              const int col = n0 + (wc * WN + j) * 32 + (r & ~1);
+              const int mrow = m0 + (wr * WM + i) * 32 + 4 * h + (odd ? 1 : 0);     // row of register 0 (even lanes) / 1 (odd lanes)
+              T* base = C + (int64_t)mrow * ldc + col;
+#pragma unroll
+              for (int q = 0; q < 8; q++) {
+                const float a0 = acc[i][j][2 * q], a1 = acc[i][j][2 * q + 1];
+                const float b0 = dpp_swap1(a0), b1 = dpp_swap1(a1);     // the neighbour lane's values (lane ^ 1)
+                bf16x2 v;
+                v[0] = (bf16)(odd ? b1 : a0);
+                v[1] = (bf16)(odd ? a1 : b0);
+                const int ro = (2 * q & 3) + 8 * (2 * q >> 2);          // row offset of register 2q: 0, 2, 8, 10, 16, 18, 24, 26
+                if (!decltype(guarded)::value || (mrow + ro < p.M && col < p.N)) *reinterpret_cast<bf16x2*>(base + ro * ldc) = v;
+              }
+              __builtin_amdgcn_sched_barrier(0);      // keep one 32 x 32 block's temporaries live at a time
+            }
+        };
+        if (m0 + BM <= p.M && n0 + BN <= p.N) store_pairs(std::false_type{});     // block-uniform: no guards inside the matrix
+        else store_pairs(std::true_type{});
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < WM; i++) {
         __syncthreads();

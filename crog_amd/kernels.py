@@ -24,7 +24,7 @@ OUT_T, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 
 # Optional per-launch timing of ONE GEMM variant (bench.py's roofline leg): {"key": (a_layout, b_layout), "records": []}
 PROF = None
-DEBUG_FLAGS = 0  # timing-only ablation bits of crog_gemm_desc.debug (scripts/ablate_gemm.py); 0 in production
+DEBUG_FLAGS = int(os.environ.get("CROG_GEMM_DEBUG", "0"))  # ablation / A-B bits of crog_gemm_desc.debug (scripts/ablate_gemm.py); 0 in production
 GEMM_SYMBOL = {
     (A_KC, B_KC): "gemm_dma_kernel<T, A_KC, B_KC>  (1x1 conv / linear forward, Q.K^T)",
     (A_IM2COL, B_KC): "gemm_dma_kernel<T, A_IM2COL, B_KC>  (3x3 conv forward and data gradient, implicit GEMM)",
