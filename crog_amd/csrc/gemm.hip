@@ -478,37 +478,59 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
       constexpr int CW = 32 * WN, CROW = CW + 8, VPR = CW / 8, RPP = 64 / VPR;  // vectors per row, rows per pass
       T* Cs = reinterpret_cast<T*>(smem) + wave * 32 * CROW;
       T* C = reinterpret_cast<T*>(p.C) + coff;
-      if (!R && (p.N & 1) == 0 && !(p.debug & 4)) {      // (debug bit 2: A/B switch back to the staged path)
-        // No residual: skip the LDS transpose.  Neighbouring lanes hold neighbouring columns of the same rows, so one DPP swap per
-        // register gives every lane two adjacent columns: even lanes store the pair of row(e), odd lanes the pair of row(e + 1) —
-        // 32 four-byte stores per 32 x 32 block and lane instead of 64 ds_write_b16 + barriers + ds_read_b128 + 16-byte stores.
+      // (crog_gemm has checked C, R, ldc, ldr for 16-byte alignment: an even N is all the 4-byte pairs need)
+      if ((p.N & 1) == 0 && !(p.debug & 4) && !(R && (p.debug & 8))) {      // debug bits 2 / 3: staged path for all / for residual launches      // (debug bit 2: A/B switch back to the staged path)
+        // Skip the LDS transpose.  Neighbouring lanes hold neighbouring columns of the same rows, so one DPP swap per register
+        // gives every lane two adjacent columns: even lanes store the pair of row(e), odd lanes the pair of row(e + 1) — 32
+        // four-byte stores per 32 x 32 block and lane instead of 64 ds_write_b16 + barriers + ds_read_b128 + 16-byte stores.
         // (The fp32-output path, which stores straight from the accumulators, moves TWICE the bytes of the staged bf16 path in
-        // 1.2x its time on the large-M 1x1 layers: the staging, not HBM, bounded them.)
+        // 1.2x its time on the large-M 1x1 layers: the staging, not HBM, bounded them.)  The residual, when there is one, is
+        // fetched in the same pair layout, a wave-row's 8 * WN loads in flight before the first is used, and added in fp32
+        // (one rounding; the staged path rounds the product first, as a separate bf16 add would).
         const bool odd = lane & 1;
-        const int64_t ldc = p.ldc;
-        auto store_pairs = [&](auto guarded) {
+        const int64_t ldc = p.ldc, ldr = p.ldr;
+        auto store_pairs = [&](auto guarded, auto with_res) {
+          constexpr bool G = decltype(guarded)::value, WR = decltype(with_res)::value;
 #pragma unroll
-          for (int i = 0; i < WM; i++)
+          for (int i = 0; i < WM; i++) {
+            const int mrow = m0 + (wr * WM + i) * 32 + 4 * h + (odd ? 1 : 0);     // row of register 0 (even lanes) / 1 (odd lanes)
+            bf16x2 rv[WR ? WN : 1][8];
+            if constexpr (WR) {
+#pragma unroll
+              for (int j = 0; j < WN; j++) {
+                const int col = n0 + (wc * WN + j) * 32 + (r & ~1);
+                const T* rbase = R + (int64_t)mrow * ldr + col;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                  const int ro = (2 * q & 3) + 8 * (2 * q >> 2);
+                  if (!G || (mrow + ro < p.M && col < p.N)) rv[j][q] = *reinterpret_cast<const bf16x2*>(rbase + ro * ldr);
+                  else rv[j][q] = bf16x2{(bf16)0.f, (bf16)0.f};
+                }
+              }
+            }
 #pragma unroll
             for (int j = 0; j < WN; j++) {
               const int col = n0 + (wc * WN + j) * 32 + (r & ~1);
-              const int mrow = m0 + (wr * WM + i) * 32 + 4 * h + (odd ? 1 : 0);     // row of register 0 (even lanes) / 1 (odd lanes)
               T* base = C + (int64_t)mrow * ldc + col;
 #pragma unroll
               for (int q = 0; q < 8; q++) {
                 const float a0 = acc[i][j][2 * q], a1 = acc[i][j][2 * q + 1];
                 const float b0 = dpp_swap1(a0), b1 = dpp_swap1(a1);     // the neighbour lane's values (lane ^ 1)
+                float lo = odd ? b1 : a0, hi = odd ? a1 : b0;
+                if constexpr (WR) { lo += (float)rv[j][q][0]; hi += (float)rv[j][q][1]; }
                 bf16x2 v;
-                v[0] = (bf16)(odd ? b1 : a0);
-                v[1] = (bf16)(odd ? a1 : b0);
+                v[0] = (bf16)lo;
+                v[1] = (bf16)hi;
                 const int ro = (2 * q & 3) + 8 * (2 * q >> 2);          // row offset of register 2q: 0, 2, 8, 10, 16, 18, 24, 26
-                if (!decltype(guarded)::value || (mrow + ro < p.M && col < p.N)) *reinterpret_cast<bf16x2*>(base + ro * ldc) = v;
+                if (!G || (mrow + ro < p.M && col < p.N)) *reinterpret_cast<bf16x2*>(base + ro * ldc) = v;
               }
               __builtin_amdgcn_sched_barrier(0);      // keep one 32 x 32 block's temporaries live at a time
             }
+          }
         };
-        if (m0 + BM <= p.M && n0 + BN <= p.N) store_pairs(std::false_type{});     // block-uniform: no guards inside the matrix
-        else store_pairs(std::true_type{});
+        const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;     // block-uniform: no guards inside the matrix
+        if (R) { if (interior) store_pairs(std::false_type{}, std::true_type{}); else store_pairs(std::true_type{}, std::true_type{}); }
+        else   { if (interior) store_pairs(std::false_type{}, std::false_type{}); else store_pairs(std::true_type{}, std::false_type{}); }
         return;
       }
 #pragma unroll

@@ -81,6 +81,33 @@ def test_gemm_epilogue(K, dt):
     close(s[:, 1], (ref * ref).sum(0), dt, scale=300)
 
 
+@pytest.mark.parametrize("M,N,K_", [(300, 136, 96), (1000, 64, 64), (4097, 258, 32), (256, 256, 64)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_bf16_pair_store_epilogue_equals_the_staged_one(K, monkeypatch, M, N, K_, with_res):
+    """The bf16 epilogue stores DPP-paired columns straight from the accumulators; debug bit 2 brings the LDS-staged form back.
+    Without a residual both round the same fp32 value once (bit-equal); with one the pair form adds in fp32 (one rounding
+    instead of two): apart by no more than those roundings, and never further from the fp32 result."""
+    dt = torch.bfloat16
+    a, b = rnd(M, K_, dt=dt), rnd(N, K_, dt=dt, seed=1)
+    ld = (N + 7) // 8 * 8 + 8                                                  # rows 16-byte aligned, canary columns behind N
+    r = rnd(M, ld, dt=dt, seed=3) if with_res else None
+    ref = a.float() @ b.float().t() + (r[:, :N].float() if with_res else 0)
+    out = {}
+    for flag in (0, 4):
+        monkeypatch.setattr(K, "DEBUG_FLAGS", flag)
+        c = torch.full((M + 1, ld), 7.0, device="cuda", dtype=dt)              # canary row and columns
+        K.gemm(K.dcode(dt), K.A_KC, K.B_KC, a, b, c, M, N, K_, K_, K_, ld, R=r, ldr=ld)
+        assert (c[M] == 7).all() and (c[:, N:] == 7).all(), "epilogue wrote outside the M x N block"
+        out[flag] = c[:M, :N].float()
+    if not with_res:
+        assert torch.equal(out[0], out[4])
+    else:
+        prod = a.float() @ b.float().t()          # the staged path rounds the product (<= 2^-8 |prod|), then both round the sum
+        assert ((out[0] - out[4]).abs() <= 2.0 ** -7 * (prod.abs() + out[4].abs()) * 1.001).all()
+        assert (out[0] - ref).abs().max() <= (out[4] - ref).abs().max() * 1.001 + 1e-6
+    close(out[0], ref, dt, scale=math.sqrt(K_) / 4)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (250, 72, 44), (676, 64, 676), (64, 2048, 49)])
 def test_gemm_nn(K, dt, M, N, K_):
