@@ -68,3 +68,36 @@ extern "C" int crog_probe_copy(const void* src, void* dst, int64_t bytes, crog_s
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
+
+// ---- timing-only events (see include/crog_hip.h) ------------------------------------------------------------------------------
+#define CROG_HIP_CALL(expr, what)                                                   \
+  do {                                                                              \
+    hipError_t e__ = (expr);                                                        \
+    if (e__ != hipSuccess) {                                                        \
+      crog_set_error("%s failed: %s", what, hipGetErrorString(e__));                \
+      return CROG_ERR_LAUNCH;                                                       \
+    }                                                                               \
+  } while (0)
+
+extern "C" int crog_timer_create(void** timer) {
+  CROG_CHECK_ARG(timer != nullptr, "timer_create: null handle pointer");
+  hipEvent_t ev;
+  CROG_HIP_CALL(hipEventCreateWithFlags(&ev, hipEventDisableSystemFence), "hipEventCreateWithFlags");
+  *timer = (void*)ev;
+  return CROG_OK;
+}
+extern "C" int crog_timer_record(void* timer, crog_stream_t stream) {
+  CROG_CHECK_ARG(timer != nullptr, "timer_record: null timer");
+  CROG_HIP_CALL(hipEventRecord((hipEvent_t)timer, (hipStream_t)stream), "hipEventRecord");
+  return CROG_OK;
+}
+extern "C" int crog_timer_elapsed_ms(void* start, void* stop, float* ms) {
+  CROG_CHECK_ARG(start && stop && ms, "timer_elapsed_ms: null argument");
+  CROG_HIP_CALL(hipEventSynchronize((hipEvent_t)stop), "hipEventSynchronize");
+  CROG_HIP_CALL(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop), "hipEventElapsedTime");
+  return CROG_OK;
+}
+extern "C" int crog_timer_destroy(void* timer) {
+  if (timer) CROG_HIP_CALL(hipEventDestroy((hipEvent_t)timer), "hipEventDestroy");
+  return CROG_OK;
+}

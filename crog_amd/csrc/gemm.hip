@@ -286,10 +286,11 @@ __device__ inline void flush_a_sum(const float (&asum)[WM], float* dst, int mbas
 
 // Branch-free activations: a per-lane branch inside the register loops (ocml's tanhf has one at |x| = 0.625) makes the compiler
 // carry the f32x16 accumulators through divergent control flow as whole vectors and spill them.
-__device__ inline float act_quickgelu(float v) { return v / (1.f + expf(-1.702f * v)); }
-__device__ inline float act_tanh(float v) {      // (1 - t) / (1 + t), t = e^(-2|v|) in (0, 1]: absolute error <= 1 ulp of 1
+// (v_rcp_f32 is within 1 ulp; an IEEE division would add a dozen temporaries per element to loops that hold 64-128 accumulators)
+__device__ inline float act_quickgelu(float v) { return v * __builtin_amdgcn_rcpf(1.f + expf(-1.702f * v)); }
+__device__ inline float act_tanh(float v) {      // (1 - t) / (1 + t), t = e^(-2|v|) in (0, 1]: absolute error ~1 ulp of 1
   const float t = expf(-2.f * fabsf(v));
-  return copysignf((1.f - t) / (1.f + t), v);
+  return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), v);
 }
 
 // value of lane ^ 1 (quad_perm [1, 0, 3, 2]): a DPP move, no LDS
@@ -297,12 +298,15 @@ __device__ inline float dpp_swap1(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
 
-template <int WM_, int WN_, int WVM_, int WVN_>
+// LEAN: the tile is only ever launched with the plain bf16 epilogue (alpha 1, no bias / activation / residual, dtype output, even N;
+// column statistics optional) and the other epilogue paths are not compiled into it (lean_epilogue_ok() is the dispatch-side check)
+template <int WM_, int WN_, int WVM_, int WVN_, bool LEAN_ = false>
 struct Shape {
   static constexpr int WM = WM_, WN = WN_, WVM = WVM_, WVN = WVN_;
+  static constexpr bool LEAN = LEAN_;
   static constexpr int NT = 64 * WVM * WVN, BM = 32 * WM * WVM, BN = 32 * WN * WVN;
 };
-using ShapeBig = Shape<4, 2, 2, 2>;    // 256 x 128, 256 threads, 128 accumulator registers per lane
+// (a 256 x 128 register-staged variant was measured slower than 128 x 128 -- occupancy-bound staging -- and spilled at 256 VGPRs: removed)
 using ShapeMid = Shape<2, 2, 2, 2>;    // 128 x 128, 256 threads
 using ShapeSmall = Shape<1, 1, 2, 2>;  //  64 x  64, 256 threads
 
@@ -334,58 +338,59 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
   float s1[WN], s2[WN];
 #pragma unroll
   for (int j = 0; j < WN; j++) s1[j] = s2[j] = 0.f;
-  // every flag below is block-uniform: test it once around the register loops, never per element
-  if (alpha != 1.f || bias) {
+  // every flag below is block-uniform: test it once around the register loops, never per element.  The loops go one 32 x 32 block
+  // at a time with a scheduling barrier between blocks: left to itself the scheduler interleaves all WM * WN * 16 elements of a pass
+  // (division sequences of the activations, 64-bit store addresses) and spills the accumulators to make room.
+  auto per_block = [&](auto&& body) {
 #pragma unroll
     for (int i = 0; i < WM; i++)
 #pragma unroll
-      for (int j = 0; j < WN; j++)
+      for (int j = 0; j < WN; j++) {
+        body(i, j);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+  constexpr bool LEAN = S::LEAN;
+  if (!LEAN && (alpha != 1.f || bias)) {
+    per_block([&](int i, int j) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[i][j][e] = alpha * acc[i][j][e] + bcol[j];
+      for (int e = 0; e < 16; e++) acc[i][j][e] = alpha * acc[i][j][e] + bcol[j];
+    });
   }
   if (p.col_stats) {
     if (m0 + BM <= p.M) {   // interior tile: no row guard
+      per_block([&](int i, int j) {
 #pragma unroll
-      for (int i = 0; i < WM; i++)
-#pragma unroll
-        for (int j = 0; j < WN; j++)
-#pragma unroll
-          for (int e = 0; e < 16; e++) { const float v = acc[i][j][e]; s1[j] += v; s2[j] += v * v; }
+        for (int e = 0; e < 16; e++) { const float v = acc[i][j][e]; s1[j] += v; s2[j] += v * v; }
+      });
     } else {
+      per_block([&](int i, int j) {
 #pragma unroll
-      for (int i = 0; i < WM; i++)
-#pragma unroll
-        for (int j = 0; j < WN; j++)
-#pragma unroll
-          for (int e = 0; e < 16; e++) {
-            const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float v = m < p.M ? acc[i][j][e] : 0.f;
-            s1[j] += v;
-            s2[j] += v * v;
-          }
+        for (int e = 0; e < 16; e++) {
+          const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float v = m < p.M ? acc[i][j][e] : 0.f;
+          s1[j] += v;
+          s2[j] += v * v;
+        }
+      });
     }
   }
-  if (p.act == CROG_ACT_RELU) {
+  if (LEAN) {
+  } else if (p.act == CROG_ACT_RELU) {
+    per_block([&](int i, int j) {
 #pragma unroll
-    for (int i = 0; i < WM; i++)
-#pragma unroll
-      for (int j = 0; j < WN; j++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+      for (int e = 0; e < 16; e++) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+    });
   } else if (p.act == CROG_ACT_QUICKGELU) {
+    per_block([&](int i, int j) {
 #pragma unroll
-    for (int i = 0; i < WM; i++)
-#pragma unroll
-      for (int j = 0; j < WN; j++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[i][j][e] = act_quickgelu(acc[i][j][e]);
+      for (int e = 0; e < 16; e++) acc[i][j][e] = act_quickgelu(acc[i][j][e]);
+    });
   } else if (p.act == CROG_ACT_TANH) {
+    per_block([&](int i, int j) {
 #pragma unroll
-    for (int i = 0; i < WM; i++)
-#pragma unroll
-      for (int j = 0; j < WN; j++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[i][j][e] = act_tanh(acc[i][j][e]);
+      for (int e = 0; e < 16; e++) acc[i][j][e] = act_tanh(acc[i][j][e]);
+    });
   }
 
   if (p.col_stats) {  // block-uniform branch; slab rows are 128 matrix rows each
@@ -423,53 +428,39 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
     __syncthreads();
   }
 
-  const T* R = reinterpret_cast<const T*>(p.R);
-  if (p.out_mode != CROG_OUT_T || sizeof(T) == 4) {
-    // direct stores from the accumulator layout: a register covers 2 rows x 32 consecutive columns
-    if (R) {
+  const T* R = LEAN ? nullptr : reinterpret_cast<const T*>(p.R);
+  if (!LEAN && (p.out_mode != CROG_OUT_T || sizeof(T) == 4)) {
+    // direct stores from the accumulator layout: a register covers 2 rows x 32 consecutive columns.  One 32 x 32 block at a time
+    // (scheduling barrier between blocks) with one base pointer per block: the compiler otherwise forms all WM * WN * 16 64-bit
+    // addresses first and spills the accumulators to make room.
+    const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;     // block-uniform: no guards inside the matrix
+    auto row_of = [](int e) { return (e & 3) + 8 * (e >> 2); };
+    // acc element = body(acc element, base + row offset) for every element of the tile, one 32 x 32 block at a time
+    auto for_each_elem = [&](auto guarded, auto* base0, int64_t ld, auto&& body) {
 #pragma unroll
       for (int i = 0; i < WM; i++)
 #pragma unroll
-        for (int j = 0; j < WN; j++)
+        for (int j = 0; j < WN; j++) {
+          const int mb = m0 + (wr * WM + i) * 32 + 4 * h;
+          auto* cb = base0 + (int64_t)mb * ld + ncol[j];
 #pragma unroll
-          for (int e = 0; e < 16; e++) {
-            const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m < p.M && ncol[j] < p.N) acc[i][j][e] += Elem<T>::to_f(R[(int64_t)m * p.ldr + ncol[j]]);
-          }
-    }
+          for (int e = 0; e < 16; e++)
+            if (!decltype(guarded)::value || (mb + row_of(e) < p.M && ncol[j] < p.N)) acc[i][j][e] = body(acc[i][j][e], cb + (int64_t)row_of(e) * ld);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto all_elems = [&](auto* base0, int64_t ld, auto&& body) {
+      if (interior) for_each_elem(std::false_type{}, base0, ld, body);
+      else for_each_elem(std::true_type{}, base0, ld, body);
+    };
+    if (R) all_elems(R, p.ldr, [](float a, const T* r) { return a + Elem<T>::to_f(*r); });
     if (p.out_mode == CROG_OUT_F32_ATOMIC) {
-      float* Cf = reinterpret_cast<float*>(p.C) + coff;
-#pragma unroll
-      for (int i = 0; i < WM; i++)
-#pragma unroll
-        for (int j = 0; j < WN; j++)
-#pragma unroll
-          for (int e = 0; e < 16; e++) {
-            const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m < p.M && ncol[j] < p.N) atomicAdd(Cf + (int64_t)m * p.ldc + ncol[j], acc[i][j][e]);
-          }
+      if (p.debug & 32) return;          // timing-only ablation: what the atomic adds cost
+      all_elems(reinterpret_cast<float*>(p.C) + coff, p.ldc, [](float a, float* c) { atomicAdd(c, a); return a; });
     } else if (p.out_mode == CROG_OUT_F32) {
-      float* Cf = reinterpret_cast<float*>(p.C) + coff;
-#pragma unroll
-      for (int i = 0; i < WM; i++)
-#pragma unroll
-        for (int j = 0; j < WN; j++)
-#pragma unroll
-          for (int e = 0; e < 16; e++) {
-            const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m < p.M && ncol[j] < p.N) Cf[(int64_t)m * p.ldc + ncol[j]] = acc[i][j][e];
-          }
+      all_elems(reinterpret_cast<float*>(p.C) + coff, p.ldc, [](float a, float* c) { *c = a; return a; });
     } else {
-      T* Ct = reinterpret_cast<T*>(p.C) + coff;
-#pragma unroll
-      for (int i = 0; i < WM; i++)
-#pragma unroll
-        for (int j = 0; j < WN; j++)
-#pragma unroll
-          for (int e = 0; e < 16; e++) {
-            const int m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m < p.M && ncol[j] < p.N) Ct[(int64_t)m * p.ldc + ncol[j]] = Elem<T>::from_f(acc[i][j][e]);
-          }
+      all_elems(reinterpret_cast<T*>(p.C) + coff, p.ldc, [](float a, T* c) { *c = Elem<T>::from_f(a); return a; });
     }
   } else {
     // 2-byte output: each wave stages 32 x (32*WN) of its tile in a private LDS region, then adds the residual
@@ -479,7 +470,7 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
       T* Cs = reinterpret_cast<T*>(smem) + wave * 32 * CROW;
       T* C = reinterpret_cast<T*>(p.C) + coff;
       // (crog_gemm has checked C, R, ldc, ldr for 16-byte alignment: an even N is all the 4-byte pairs need)
-      if ((p.N & 1) == 0 && !(p.debug & 4) && !(R && (p.debug & 8))) {      // debug bits 2 / 3: staged path for all / for residual launches      // (debug bit 2: A/B switch back to the staged path)
+      if (LEAN || ((p.N & 1) == 0 && !(p.debug & 4) && !(R && (p.debug & 8)))) {      // debug bits 2 / 3: staged path for all / for residual launches
         // Skip the LDS transpose.  Neighbouring lanes hold neighbouring columns of the same rows, so one DPP swap per register
         // gives every lane two adjacent columns: even lanes store the pair of row(e), odd lanes the pair of row(e + 1) — 32
         // four-byte stores per 32 x 32 block and lane instead of 64 ds_write_b16 + barriers + ds_read_b128 + 16-byte stores.
@@ -555,11 +546,13 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
               }
               stg16(C + (int64_t)m * p.ldc + n, o);
             } else {
-              for (int e = 0; e < 8 && n + e < p.N; e++) {
-                float f = (float)o.v[e];
-                if (R) f += (float)R[(int64_t)m * p.ldr + n + e];
-                C[(int64_t)m * p.ldc + n + e] = (T)f;
-              }
+#pragma unroll
+              for (int e = 0; e < 8; e++)      // constant trip count: a data-dependent bound would put `o` in scratch memory
+                if (n + e < p.N) {
+                  float f = (float)o.v[e];
+                  if (R) f += (float)R[(int64_t)m * p.ldr + n + e];
+                  C[(int64_t)m * p.ldc + n + e] = (T)f;
+                }
             }
           }
         }
@@ -863,14 +856,15 @@ struct DmaTr {
       px[i] = py[i] = 0;
       cur[i] = 0;
       const int col = col0 + c * VEC;
-      if (col >= ncols) { colb[i] = DMA_OOB; tdy[i] = tdx[i] = 0; continue; }
+      const bool oob = col >= ncols;      // selects, not an early `continue`: with divergent control flow here the compiler keeps the arrays in scratch memory
       if constexpr (MODE == 2) {
         const int tap = col / g.C;
-        colb[i] = (unsigned)((col - tap * g.C) * sizeof(T));
-        tdy[i] = tap / 3 - 1;
-        tdx[i] = tap % 3 - 1;
+        colb[i] = oob ? DMA_OOB : (unsigned)((col - tap * g.C) * sizeof(T));
+        tdy[i] = oob ? 0 : tap / 3 - 1;
+        tdx[i] = oob ? 0 : tap % 3 - 1;
       } else {
-        colb[i] = (unsigned)(col * sizeof(T));
+        colb[i] = oob ? DMA_OOB : (unsigned)(col * sizeof(T));
+        tdy[i] = tdx[i] = 0;
       }
     }
   }
@@ -1027,7 +1021,7 @@ __device__ __attribute__((always_inline)) inline void wait_tiles(int behind) {
 // Tile shapes that were measured and lost (kept for A/B work, compiled only with -DCROG_GEMM_EXPERIMENTAL_TILES): 256 x 256 and
 // 256 x 128 with 8 waves at one block per CU (barrier stalls are not hidden by a second block: 5-30 % slower than 128 x 128 at
 // three blocks per CU), 64 x 256 for Cout <= 64 weight gradients (two blocks per CU, 20 KiB per k-tile: 14 % slower).
-using ShapeDma8 = Shape<4, 2, 2, 4>;   // 256 x 256, 8 waves, 128 accumulator registers per lane
+using ShapeDma8 = Shape<4, 2, 2, 4, true>;   // 256 x 256, 8 waves, 128 accumulator registers per lane (lean epilogue: at the 256-VGPR limit the full one spills)
 using ShapeDma8x = Shape<2, 2, 4, 2>;  // 256 x 128, 8 waves of 64 x 64 (64 accumulator registers, as the 128^2 tile): A/B experiments
 using ShapeFat = Shape<2, 4, 2, 2>;    // 128 x 256, 4 waves of 64 x 128 (128 accumulator registers, 2 blocks per CU): 20-45 % slower (experimental)
 using ShapeTall = Shape<2, 2, 4, 1>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
@@ -1059,7 +1053,7 @@ __global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 25
   const int nwg = tilesM * tilesN;
   int id = blockIdx.x, z = blockIdx.y;
   xcd_map(nwg, p.splitk, id, z);
-  const int tm = id / tilesN, tn = id % tilesN;
+  const int tm = id / tilesN, tn = id % tilesN;     // (row tiles fastest instead: measured equal on the 3x3 shapes, scripts/bench_conv_n.py)
   const int m0 = tm * BM, n0 = tn * BN;
   const int zb = z / p.splitk, zs = z % p.splitk;
   const int zo = zb / p.batch_inner, zi = zb % p.batch_inner;
@@ -1371,7 +1365,7 @@ bool hwtr_enabled() {
   return v == 1;
 }
 
-// 0 = auto, 1 = small, 2 = mid, 3 = big (CROG_GEMM_SHAPE, for tests and A/B runs)
+// 0 = auto, 1 = small, 2 = mid (CROG_GEMM_SHAPE, for tests and A/B runs)
 int forced_shape() {
   static int v = -1;
   if (v < 0) {
@@ -1380,7 +1374,6 @@ int forced_shape() {
     if (e) {
       if (e[0] == 's') v = 1;
       else if (e[0] == 'm') v = 2;
-      else if (e[0] == 'b') v = 3;
     }
   }
   return v;
@@ -1389,7 +1382,7 @@ int forced_shape() {
 int pick_shape(const crog_gemm_desc& d) {
   const int f = forced_shape();
   const long zb = (long)d.batch * d.splitk;
-  if (f == 3 || f == 2) return f;
+  if (f == 2) return f;
   if (f == 1) return d.col_stats ? 2 : 1;
   const long mid = (long)cdiv(d.M, 128) * cdiv(d.N, 128) * zb;
   const long big = (long)cdiv(d.M, 256) * cdiv(d.N, 128) * zb;
@@ -1409,13 +1402,22 @@ inline bool alt_tiles_enabled() {
   if (alt < 0) { const char* e = getenv("CROG_GEMM_NO_ALT_TILES"); alt = (e && e[0] == '1') ? 0 : 1; }
   return alt == 1;
 }
+// EXPERIMENT knobs: CROG_WGRAD_TILE = 128 sends the 1x1 / linear weight gradients to 128 x 128 tiles, CROG_WGRAD_TARGET = blocks per launch
+inline int wgrad_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 inline bool small_wgrad(int a_layout, int b_layout, int out_mode, long M, long N) {
-  static int off = -1;
-  if (off < 0) { const char* e = getenv("CROG_GEMM_NO_SMALL_WGRAD"); off = (e && e[0] == '1') ? 1 : 0; }
+  static int off = -1, tile = 0;
+  if (off < 0) { const char* e = getenv("CROG_GEMM_NO_SMALL_WGRAD"); off = (e && e[0] == '1') ? 1 : 0; tile = wgrad_env("CROG_WGRAD_TILE", 64); }
   if (off || !alt_tiles_enabled() || out_mode != CROG_OUT_F32_ATOMIC || a_layout != CROG_A_MC) return false;
-  if (b_layout == CROG_B_NC) return M * N <= (1L << 20);
+  if (b_layout == CROG_B_NC) return tile == 64 && M * N <= (1L << 20);
   if (b_layout == CROG_B_NC_IM2COL) return M * N <= 160L * 1024;
   return false;
+}
+
+inline bool lean_epilogue_ok(const crog_gemm_desc& d) {
+  return d.alpha == 1.f && !d.bias && d.act == CROG_ACT_NONE && !d.R && d.out_mode == CROG_OUT_T && d.dtype == CROG_BF16 && (d.N & 1) == 0;
 }
 
 template <typename T, bool HWTR>
@@ -1425,7 +1427,7 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     // tile shape of the LDS-DMA kernel by padding waste: 64-wide sides for <= 64 columns / rows, 64 x 64 for small problems
     const bool alt = alt_tiles_enabled();
 #ifdef CROG_GEMM_EXPERIMENTAL_TILES
-    if (shape == 2 && dma_prefers_256(d)) return dispatch_dma<T, ShapeDma8>(d, s);
+    if (shape == 2 && dma_prefers_256(d) && lean_epilogue_ok(d)) return dispatch_dma<T, ShapeDma8>(d, s);
     {
       // A/B: wider tiles for the large 3x3 forward / data-gradient launches only (CROG_GEMM_CONV_TILE = f: 128 x 256 at two blocks
       // per CU, 8: 256 x 256 at one), when the launch still has >= CROG_GEMM_CONV_MIN tiles of that shape
@@ -1438,7 +1440,7 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
       }
       if (conv_tile && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0) {
         if (conv_tile == 1 && (long)cdiv(d.M, 128) * (d.N / 256) >= conv_min) return dispatch_dma<T, ShapeFat>(d, s);
-        if (conv_tile == 2 && (long)cdiv(d.M, 256) * (d.N / 256) >= conv_min) return dispatch_dma<T, ShapeDma8>(d, s);
+        if (conv_tile == 2 && lean_epilogue_ok(d) && (long)cdiv(d.M, 256) * (d.N / 256) >= conv_min) return dispatch_dma<T, ShapeDma8>(d, s);
       }
     }
 #endif
@@ -1449,7 +1451,7 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     static int conv256 = -1;
     if (conv256 < 0) { const char* e = getenv("CROG_GEMM_NO_CONV256"); conv256 = (e && e[0] == '1') ? 0 : 1; }
     if constexpr (sizeof(T) == 2) {
-      if (conv256 && alt && forced_shape() == 0 && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0 &&
+      if (conv256 && alt && forced_shape() == 0 && lean_epilogue_ok(d) && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0 &&
           (long)cdiv(d.M, 256) * (d.N / 256) >= 256)
         return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, ShapeDma8>(d, s);
     }
@@ -1484,7 +1486,6 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     if (shape == 2) return dispatch_dma<T, ShapeMid>(d, s);
   }
   switch (shape) {
-    case 3: return dispatch_layout<T, HWTR, ShapeBig>(d, s);
     case 1: return dispatch_layout<T, HWTR, ShapeSmall>(d, s);
     default: return dispatch_layout<T, HWTR, ShapeMid>(d, s);
   }
@@ -1502,11 +1503,13 @@ extern "C" int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int 
   long s;
   if (small_wgrad(a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N)) {
     const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
-    const long target = b_layout == CROG_B_NC_IM2COL ? 2048 : 1024;
+    static const long t1 = wgrad_env("CROG_WGRAD_TARGET", 1024);
+    const long target = b_layout == CROG_B_NC_IM2COL ? 2048 : t1;
     s = std::min(std::max(1L, target / tiles), std::max(1L, ktiles / 16));
   } else {
+    static const long t2 = wgrad_env("CROG_WGRAD_TARGET128", 768), t3 = wgrad_env("CROG_WGRAD_TARGET_CONV", 768);
     const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-    s = std::min(std::max(1L, 768 / tiles), std::max(1L, ktiles / 24));
+    s = std::min(std::max(1L, (b_layout == CROG_B_NC_IM2COL ? t3 : t2) / tiles), std::max(1L, ktiles / 24));
   }
   return (int)std::max(1L, std::min(s, 1024L));
 }

@@ -40,6 +40,32 @@ def lib():
     return _lib.load()
 
 
+class Timer:
+    """Timing-only HIP event without the system-scope fence of a default event (crog_timer_*, include/crog_hip.h): a pair around
+    one launch inside a running step measures that launch, not the cache write-back a fencing event puts between kernels."""
+    __slots__ = ("h",)
+
+    def __init__(self):
+        self.h = ctypes.c_void_p()
+        check(lib().crog_timer_create(ctypes.byref(self.h)), "timer_create")
+
+    def record(self, raw_stream=None):
+        check(lib().crog_timer_record(self.h, stream() if raw_stream is None else raw_stream), "timer_record")
+
+    def elapsed_time(self, stop: "Timer") -> float:
+        """Milliseconds from this timer to `stop` (waits for `stop`), same call shape as torch.cuda.Event.elapsed_time."""
+        ms = ctypes.c_float()
+        check(lib().crog_timer_elapsed_ms(self.h, stop.h, ctypes.byref(ms)), "timer_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().crog_timer_destroy(self.h)
+        except Exception:
+            pass
+
+
 def dcode(t_or_dtype) -> int:
     dt = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
     if dt == torch.float32:
@@ -51,7 +77,6 @@ def dcode(t_or_dtype) -> int:
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _DEV_INDEX = None
-_EXT_STREAMS = {}
 _STREAM_OVERRIDE = None   # raw handle set by Runtime.on_wgrad_stream while it enqueues weight-gradient kernels on the side stream
 
 
@@ -143,18 +168,15 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
                  None if col_stats is None else col_stats.data_ptr(), stat_replicas,
                  None if a_sum is None else a_sum.data_ptr() + 4 * a_sum_off)
     if PROF is not None and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
-        # events go on the stream the kernel is actually launched on (the weight-gradient side stream while it is overridden)
+        # timers go on the stream the kernel is actually launched on (the weight-gradient side stream while it is overridden)
         raw = stream()
-        st = None   # torch's current stream unless the launch is redirected to the side stream
-        if _STREAM_OVERRIDE is not None:
-            st = _EXT_STREAMS.get(raw)
-            if st is None:
-                st = _EXT_STREAMS[raw] = torch.cuda.ExternalStream(raw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
+        e0, e1 = Timer(), Timer()
+        e0.record(raw)
         check(lib().crog_gemm(ctypes.byref(d), raw), "crog_gemm")
-        e1.record(st)
+        e1.record(raw)
         PROF["records"].append((e0, e1, 2.0 * M * N * K * batch, (a_layout, b_layout, M, N, K, batch, splitk)))
+        if "descs" in PROF:      # scripts/profile_gemms.py replays the launch on the same memory after the step
+            PROF["descs"].append(d)
         return
     check(lib().crog_gemm(ctypes.byref(d), stream()), "crog_gemm")
 

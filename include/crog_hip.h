@@ -40,6 +40,16 @@ const char* crog_last_error(void);
 int crog_probe_mfma_bf16(float* sink, int blocks, int iters, crog_stream_t stream);
 int crog_probe_copy(const void* src, void* dst, int64_t bytes, crog_stream_t stream);
 
+/* Timing-only HIP events for per-launch measurements inside a running step (bench.py `roofline`, scripts/profile_gemms.py).
+ * They are created with hipEventDisableSystemFence: a default event performs a system-scope release when it completes (L2
+ * write-back between every pair of kernels), which made the kernels BETWEEN two events measure 1.5-2.6x their rocprofv3
+ * kernel-trace duration.  crog_timer_create writes an opaque handle; record enqueues it on `stream`; elapsed waits for `stop`
+ * and writes the milliseconds between the two. */
+int crog_timer_create(void** timer);
+int crog_timer_record(void* timer, crog_stream_t stream);
+int crog_timer_elapsed_ms(void* start, void* stop, float* ms);
+int crog_timer_destroy(void* timer);
+
 /* ------------------------------------------------------------------------------------------
  * GEMM / implicit-GEMM convolution family (MFMA 32x32x16 bf16, 32x32x2 f32).
  *   C[z][m][n] = epilogue( alpha * sum_k Aop(z,m,k) * Bop(z,n,k) )

@@ -973,3 +973,20 @@ def test_operands_beyond_32bit_buffer_extent_take_the_pointer_path(K):
     K.gemm(K.BF16, K.A_KC, K.B_KC, a, b, c, M, N, Kd, Kd, Kd, N)
     for sl in (slice(0, 200), slice(M - 300, M), slice(M // 2, M // 2 + 64)):
         close(c[sl], a[sl].float() @ b.float().t(), torch.bfloat16, scale=math.sqrt(Kd) / 4)
+
+
+def test_timing_only_events_measure_a_launch(K):
+    """crog_timer_* (fence-free HIP events): elapsed time between two timers around a known-length launch is positive, of the
+    right order, and consistent with torch's own events around the same launch."""
+    src = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+    dst = torch.empty_like(src)
+    def copy():
+        K.check(K.lib().crog_probe_copy(K.ptr(src), K.ptr(dst), src.numel(), K.stream()), "probe_copy")
+    copy(); torch.cuda.synchronize()
+    t0, t1 = K.Timer(), K.Timer()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); t0.record(); copy(); t1.record(); e1.record()
+    torch.cuda.synchronize()
+    ms, ms_torch = t0.elapsed_time(t1), e0.elapsed_time(e1)
+    assert 0.005 < ms < 5.0                      # 128 MB of traffic: ~30 us at 4.5 TB/s, never milliseconds
+    assert ms <= ms_torch * 1.05 + 0.01          # bracketed by the torch pair
