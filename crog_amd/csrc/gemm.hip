@@ -137,7 +137,7 @@ struct KcLoader {
   ConvGeom g;
   Vec16<T> reg[NV];
 
-  __device__ void init(const T* b, int64_t ld_, int rows_total, int K_, int row0, ConvGeom g_, int tid) {
+  __device__ __attribute__((always_inline)) void init(const T* b, int64_t ld_, int rows_total, int K_, int row0, ConvGeom g_, int tid) {
     base = b; ld = ld_; K = K_; g = g_;
     kv = (tid & 3) * VEC;
 #pragma unroll
@@ -152,7 +152,7 @@ struct KcLoader {
       }
     }
   }
-  __device__ void load(int k0) {
+  __device__ __attribute__((always_inline)) void load(int k0) {
     const int k = k0 + kv;
     if constexpr (IM2COL) {
       const int tap = k0 / g.C;  // k-tile never straddles a tap (convC % BK == 0)
@@ -180,7 +180,7 @@ struct KcLoader {
       }
     }
   }
-  __device__ void store(T* tile) const {
+  __device__ __attribute__((always_inline)) void store(T* tile) const {
 #pragma unroll
     for (int i = 0; i < NV; i++) stg16(tile + lrow[i] * ROW + kv, reg[i]);
   }
@@ -206,7 +206,7 @@ struct TrLoader {
   int tdy, tdx, tc;  // MODE 2: tap offset and channel of this thread's chunk
   Vec16<T> reg[NV];
 
-  __device__ void init(const T* b, int64_t ld_, int ncols_, int K_, int col0, ConvGeom g_, int tid) {
+  __device__ __attribute__((always_inline)) void init(const T* b, int64_t ld_, int ncols_, int K_, int col0, ConvGeom g_, int tid) {
     base = b; ld = ld_; K = K_; ncols = ncols_; g = g_;
     lcol = (tid % CPR) * VEC;
     lrow0 = tid / CPR;
@@ -218,7 +218,7 @@ struct TrLoader {
       tdx = tap % 3 - 1;
     }
   }
-  __device__ Vec16<T> guarded(const T* src) const {
+  __device__ __attribute__((always_inline)) Vec16<T> guarded(const T* src) const {
     if (col + VEC <= ncols) return ldg16(src);
     Vec16<T> v = zero16<T>();
 #pragma unroll
@@ -226,7 +226,7 @@ struct TrLoader {
       if (col + e < ncols) v.v[e] = src[e];
     return v;
   }
-  __device__ void load(int k0) {
+  __device__ __attribute__((always_inline)) void load(int k0) {
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const long k = (long)k0 + lrow0 + i * RSTEP;
@@ -245,7 +245,7 @@ struct TrLoader {
       }
     }
   }
-  __device__ void store(T* tile) const {
+  __device__ __attribute__((always_inline)) void store(T* tile) const {
 #pragma unroll
     for (int i = 0; i < NV; i++) stg16(tile + (lrow0 + i * RSTEP) * ROW + lcol, reg[i]);
   }
