@@ -300,9 +300,10 @@ __device__ inline float dpp_swap1(float v) {
 
 // LEAN: the tile is only ever launched with the plain bf16 epilogue (alpha 1, no bias / activation / residual, dtype output, even N;
 // column statistics optional) and the other epilogue paths are not compiled into it (lean_epilogue_ok() is the dispatch-side check)
-template <int WM_, int WN_, int WVM_, int WVN_, bool LEAN_ = false>
+// NSTAGE: depth of the LDS-DMA ring (0 = the default of the tile size, dma_nstage()).
+template <int WM_, int WN_, int WVM_, int WVN_, bool LEAN_ = false, int NSTAGE_ = 0>
 struct Shape {
-  static constexpr int WM = WM_, WN = WN_, WVM = WVM_, WVN = WVN_;
+  static constexpr int WM = WM_, WN = WN_, WVM = WVM_, WVN = WVN_, NSTAGE = NSTAGE_;
   static constexpr bool LEAN = LEAN_;
   static constexpr int NT = 64 * WVM * WVN, BM = 32 * WM * WVM, BN = 32 * WN * WVN;
 };
@@ -719,7 +720,12 @@ constexpr unsigned DMA_OOB = 0x80000000u;
 // operand tile = edge * 64 bytes.  128^2: 3 stages x 16 KiB, 3 blocks per CU (a 4-stage ring at 2 blocks per CU measured 10 %
 // slower: occupancy beats depth).  256^2: one 8-wave block per CU owns all 256 VGPRs per lane (128 of them accumulators), so
 // the ring is 4 x 32 KiB deep instead.
-template <typename S> constexpr int dma_nstage() { return S::NT == 512 ? 4 : 3; }
+template <typename S> constexpr int dma_nstage() { return S::NSTAGE ? S::NSTAGE : (S::NT == 512 ? 4 : 3); }
+// blocks per CU the kernel is compiled for (register budget): by tile size, or what a deep ring leaves room for in 160 KiB of LDS
+template <typename S> constexpr int dma_blocks_per_cu() {
+  if constexpr (S::NSTAGE != 0) { constexpr int fit = 160 * 1024 / (S::NSTAGE * (S::BM + S::BN) * 64); return fit < 1 ? 1 : (fit > 4 ? 4 : fit); }
+  return S::NT == 512 ? 1 : (S::BM + S::BN > 256 ? 2 : (S::BM + S::BN <= 128 ? 4 : 3));
+}
 
 // K-contiguous operand (MODE 0 dense rows, MODE 1 im2col patches of an NHWC map)
 template <typename T, int MODE, int NI>
@@ -993,19 +999,8 @@ __device__ __attribute__((always_inline)) inline void dma_piece(const void* base
   } while (0)
 
 template <int N> __device__ inline void wait_vmcnt() {
-  static_assert((N >= 0 && N <= 10 && N != 1 && N != 7) || N == 12 || N == 15 || N == 18, "add the immediate");
-  if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-  if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // Wait until at most `behind` of this wave's most recently requested k-tiles (P DMA instructions each) are still in flight.
@@ -1027,6 +1022,8 @@ using ShapeFat = Shape<2, 4, 2, 2>;    // 128 x 256, 4 waves of 64 x 128 (128 ac
 using ShapeTall = Shape<2, 2, 4, 1>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
 using ShapeWide = Shape<2, 2, 1, 4>;   //  64 x 256, 4 waves: weight gradients of those layers (M = Cout = 32 / 64)
 using ShapeDma64 = Shape<1, 1, 2, 2>;  //  64 x  64, 4 waves: small GEMMs (text tower, attention pooling), no BN statistics
+// (8-deep rings for launches of <= 1-2 blocks per CU were tried: no gain standalone -- those launches are not bound by request
+// latency -- and 3 % slower in the step, where a 128 KiB block keeps the other streams' blocks off the CU.)
 
 #ifndef CROG_GEMM_INTERLEAVE
 #define CROG_GEMM_INTERLEAVE 1   // 0: leave the order of DMA requests / LDS reads / MFMAs inside a k-tile to the compiler (A/B builds)
@@ -1035,7 +1032,7 @@ using ShapeDma64 = Shape<1, 1, 2, 2>;  //  64 x  64, 4 waves: small GEMMs (text 
 // ASUM: the launch also accumulates a_sum[m] += sum_k A(m, k) (bias gradient inside a weight-gradient GEMM); a template flag so
 // that the main loop of every other launch is one basic block
 template <typename T, int AL, int BL, typename S, int ASUM>
-__global__ void __launch_bounds__(S::NT, (S::NT == 512 ? 1 : (S::BM + S::BN > 256 ? 2 : (S::BM + S::BN <= 128 ? 4 : 3)))) gemm_dma_kernel(const crog_gemm_desc p) {
+__global__ void __launch_bounds__(S::NT, dma_blocks_per_cu<S>()) gemm_dma_kernel(const crog_gemm_desc p) {
   constexpr int DMA_NSTAGE = dma_nstage<S>();
   constexpr int NW = S::NT / 64, NIA = S::BM / (16 * NW), NIB = S::BN / (16 * NW);   // 1-KiB DMA slices per wave and k-tile
   static_assert(NIA >= 1 && NIB >= 1 && NIA * 16 * NW == S::BM && NIB * 16 * NW == S::BN, "every wave must move whole 1 KiB slices of both tiles");
@@ -1394,22 +1391,26 @@ int pick_shape(const crog_gemm_desc& d) {
   return 2;
 }
 
-// Small-output weight gradients (M x N up to 512 x 2048 for 1x1 / linear layers, up to 128 x 1152 for 3x3) are bound by the
-// fp32-atomic epilogue and by how many blocks stream the huge reduction dimension, not by MFMA: 64 x 64 tiles quarter the
-// atomic bytes per split and give 4x the blocks (measured 8-36 % faster, scripts/bench_wgrad2.py).
+// Small-output weight gradients are bound by L2 -> LDS bytes and by the fp32-atomic epilogue, not by MFMA (scripts/ablate_wgrad.py,
+// HBM-cold operands: 512 x 512 over K = 21632 with 64 x 64 tiles and 16 splits = 44 us, 33 us of it without the atomics, 354 MB
+// through L2 for 44 MB of operands).  Launched ALONE, 64 x 64 tiles win (4x the blocks of 128 x 128 at the same atomic bytes:
+// 8-36 % faster, scripts/bench_wgrad2.py) -- but inside the training step the weight gradients run on a side stream next to the
+// main stream's kernels, the chip is full anyway, and what counts is the work per launch: 128 x 128 tiles at ~256 blocks (half
+// the L2 bytes, a third of the splits) make the step 2 % faster (33.97 vs 34.65 ms, two interleaved A/B pairs).  The 3x3 form keeps
+// 64 x 64 for outputs up to 128 x 1152 (Cout <= 128: 128-wide tiles would be mostly padding) and targets 512 blocks otherwise.
+// CROG_WGRAD_TILE / CROG_WGRAD_TARGET / CROG_WGRAD_TARGET128 / CROG_WGRAD_TARGET_CONV override the policy for A/B runs.
 inline bool alt_tiles_enabled() {
   static int alt = -1;
   if (alt < 0) { const char* e = getenv("CROG_GEMM_NO_ALT_TILES"); alt = (e && e[0] == '1') ? 0 : 1; }
   return alt == 1;
 }
-// EXPERIMENT knobs: CROG_WGRAD_TILE = 128 sends the 1x1 / linear weight gradients to 128 x 128 tiles, CROG_WGRAD_TARGET = blocks per launch
 inline int wgrad_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
 inline bool small_wgrad(int a_layout, int b_layout, int out_mode, long M, long N) {
   static int off = -1, tile = 0;
-  if (off < 0) { const char* e = getenv("CROG_GEMM_NO_SMALL_WGRAD"); off = (e && e[0] == '1') ? 1 : 0; tile = wgrad_env("CROG_WGRAD_TILE", 64); }
+  if (off < 0) { const char* e = getenv("CROG_GEMM_NO_SMALL_WGRAD"); off = (e && e[0] == '1') ? 1 : 0; tile = wgrad_env("CROG_WGRAD_TILE", 128); }
   if (off || !alt_tiles_enabled() || out_mode != CROG_OUT_F32_ATOMIC || a_layout != CROG_A_MC) return false;
   if (b_layout == CROG_B_NC) return tile == 64 && M * N <= (1L << 20);
   if (b_layout == CROG_B_NC_IM2COL) return M * N <= 160L * 1024;
@@ -1496,7 +1497,8 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
 extern "C" int crog_gemm_stat_tiles(int M) { return cdiv(M, 128); }
 
 // Split count for a weight-gradient GEMM C[M,N] += A^T B over K (out_mode CROG_OUT_F32_ATOMIC), matched to the tile shape
-// crog_gemm will pick: enough blocks to fill 256 CUs, but at least 16-24 k-tiles per block (every split pays an atomic epilogue).
+// crog_gemm will pick: about one block per CU (the side stream shares the chip with the main stream), at least 16-24 k-tiles per
+// block (every split pays an atomic epilogue).
 extern "C" int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int M, int N, int K) {
   const int bk = dtype == CROG_BF16 ? 32 : 16;
   const long ktiles = cdiv(K, bk);
@@ -1507,7 +1509,7 @@ extern "C" int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int 
     const long target = b_layout == CROG_B_NC_IM2COL ? 2048 : t1;
     s = std::min(std::max(1L, target / tiles), std::max(1L, ktiles / 16));
   } else {
-    static const long t2 = wgrad_env("CROG_WGRAD_TARGET128", 768), t3 = wgrad_env("CROG_WGRAD_TARGET_CONV", 768);
+    static const long t2 = wgrad_env("CROG_WGRAD_TARGET128", 256), t3 = wgrad_env("CROG_WGRAD_TARGET_CONV", 512);
     const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
     s = std::min(std::max(1L, (b_layout == CROG_B_NC_IM2COL ? t3 : t2) / tiles), std::max(1L, ktiles / 24));
   }
