@@ -82,9 +82,14 @@ def convert_sync_batchnorm(model, process_group=None, force=False, dedicated_gro
 class Reducer:
     """Bucketed, overlapped mean all-reduce of a flat gradient buffer."""
 
-    def __init__(self, flat_grad: torch.Tensor, entries, group=None, bucket_cap_mb: float = 64.0):
-        """entries: iterable of (param, offset, numel) in registration order."""
+    def __init__(self, flat_grad: torch.Tensor, entries, group=None, bucket_cap_mb: float = 64.0, payload_dtype=None):
+        """entries: iterable of (param, offset, numel) in registration order.
+        payload_dtype: None = exchange the fp32 gradients as they are (the reference's DDP, bit-compatible); torch.bfloat16 = each
+        bucket is rounded to bf16 for the wire (294 instead of 588 MB per step for CROG-R50), averaged, and widened back — an opt-in
+        that changes the numerics (`DistributedDataParallel(..., gradient_payload=torch.bfloat16)` or CROG_GRAD_PAYLOAD=bf16)."""
         self.G = flat_grad
+        self.payload_dtype = payload_dtype
+        self._wire = {}           # bucket index -> bf16 staging buffer
         self.group = group
         self.world = dist.get_world_size(group)
         cap = int(bucket_cap_mb * (1 << 20) / 4)
@@ -128,6 +133,12 @@ class Reducer:
         if _DRY:
             b["work"] = None
             return
+        b["wire"] = None
+        if self.payload_dtype is not None and self.payload_dtype != view.dtype:
+            i = self.buckets.index(b)
+            if i not in self._wire:
+                self._wire[i] = torch.empty(b["numel"], device=view.device, dtype=self.payload_dtype)
+            b["wire"] = self._wire[i]
         if self.G.is_cuda:
             cur = torch.cuda.current_stream()
             side = [s for s in RT.streams if s != cur]
@@ -140,9 +151,19 @@ class Reducer:
                 for s in side[:-1]:
                     carrier.wait_stream(s)
                 with torch.cuda.stream(carrier):
-                    b["work"] = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+                    b["work"] = dist.all_reduce(self._to_wire(b, view), op=op, group=self.group, async_op=True)
+                b["carrier"] = carrier
                 return
-        b["work"] = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+        b["carrier"] = None
+        b["work"] = dist.all_reduce(self._to_wire(b, view), op=op, group=self.group, async_op=True)
+
+    @staticmethod
+    def _to_wire(b, view):
+        """The tensor that goes on the wire: the gradient slice itself, or its rounded copy (made on the launching stream)."""
+        if b["wire"] is None:
+            return view
+        b["wire"].copy_(view)
+        return b["wire"]
 
     def mark_ready(self, param):
         i = self.bucket_of.get(id(param))
@@ -169,8 +190,11 @@ class Reducer:
         for b in self.buckets:
             if b["work"] is not None:
                 b["work"].wait()
+            view = self.G[b["start"]:b["start"] + b["numel"]]
+            if b.get("wire") is not None and b["work"] is not None:
+                view.copy_(b["wire"])          # widen the averaged payload back into the fp32 gradient buffer
             if not self._use_avg:
-                self.G[b["start"]:b["start"] + b["numel"]].div_(self.world)
+                view.div_(self.world)
         self.reset()
 
 
@@ -179,9 +203,12 @@ class DistributedDataParallel(torch.nn.Module):
     as used at train_crog.py:154-156, for crog_amd models (or any module whose parameters live in a ParamStore)."""
 
     def __init__(self, module, device_ids=None, find_unused_parameters=False, process_group=None, bucket_cap_mb: float = 64.0,
-                 broadcast_buffers: bool = True, force: bool = False):
+                 broadcast_buffers: bool = True, force: bool = False, gradient_payload=None):
         super().__init__()
         self.module = module
+        if gradient_payload is None and _os.environ.get("CROG_GRAD_PAYLOAD", "").lower() in ("bf16", "bfloat16"):
+            gradient_payload = torch.bfloat16
+        self.gradient_payload = gradient_payload
         self.force = force
         self.process_group = process_group
         self.bucket_cap_mb = bucket_cap_mb
@@ -208,7 +235,8 @@ class DistributedDataParallel(torch.nn.Module):
     def _ensure_reducer(self):
         store = self.module.store
         if self.reducer is None or self.reducer.G is not store.G:
-            self.reducer = Reducer(store.G, [(p, o, n) for _, p, o, n, _ in store.entries], self.process_group, self.bucket_cap_mb)
+            self.reducer = Reducer(store.G, [(p, o, n) for _, p, o, n, _ in store.entries], self.process_group, self.bucket_cap_mb,
+                                   payload_dtype=self.gradient_payload)
             for h in self._hooks:
                 h.remove()
             self._hooks = []

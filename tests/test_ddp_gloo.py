@@ -62,7 +62,14 @@ def _worker(rank, world, port, tmp):
     pairs = torch.stack([z.sum((0, 2, 3)), (z * z).sum((0, 2, 3))], 1).contiguous()
     comm.all_reduce_sum(pairs)
     assert comm.calls == 1 and ddp.reducer.launches == 2 * len(ddp.reducer.buckets)
-    torch.save(dict(G=net.store.G.clone(), P=net.store.P.clone(), pairs=pairs), os.path.join(tmp, f"r{rank}.pt"))
+    G32 = net.store.G.clone()
+    # opt-in bf16 gradient payload: the same step with every bucket rounded for the wire
+    ddp16 = DistributedDataParallel(net, bucket_cap_mb=0.001, gradient_payload=torch.bfloat16)
+    net.store.zero_grad()
+    ddp16(xs, im).backward()
+    ddp16.reducer.wait()
+    assert ddp16.reducer.payload_dtype is torch.bfloat16 and net.store.G.dtype == torch.float32
+    torch.save(dict(G=G32, G16=net.store.G.clone(), P=net.store.P.clone(), pairs=pairs), os.path.join(tmp, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -83,5 +90,10 @@ def test_reducer_matches_single_process(tmp_path):
     (0.5 * (net(X[:4], I[:4]) + net(X[4:], I[4:]))).backward()
     assert torch.allclose(st.G, r0["G"], atol=1e-6, rtol=1e-5)
     assert st.G[st.off(net.unused):st.off(net.unused) + 7].abs().sum() == 0
+    # bf16 payload: identical on both ranks, equal to the fp32 mean up to the rounding of each rank's contribution (2^-8 of ITS size:
+    # measured on the whole vector, the two contributions of an element may cancel)
+    assert torch.equal(r0["G16"], r1["G16"])
+    rel = float((r0["G16"] - r0["G"]).norm() / r0["G"].norm())
+    assert 0 < rel < 2 ** -7, rel
     ref = torch.stack([I.sum((0, 2, 3)), (I * I).sum((0, 2, 3))], 1)
     assert torch.allclose(r0["pairs"], ref, atol=1e-4)
