@@ -107,7 +107,8 @@ typedef struct crog_gemm_desc {
   int debug;         /* 0 in production.  Timing-only ablations of the LDS-DMA kernel (results are wrong): bit 0 skips the
                         global->LDS loads of the main loop, bit 1 skips the fragment reads + MFMAs (non-pipelined build only); bit 2
                         (results stay right) sends bf16 outputs through the LDS-staged epilogue instead of the direct pair stores, bit 3
-                        the same for launches with a residual only */
+                        the same for launches with a residual only; bit 5 (timing only, results wrong) skips the fp32 atomic adds of a
+                        split-K launch (scripts/ablate_wgrad.py) */
   float* col_stats;  /* NULL, or [ceil(M/128)][N][2] fp32 partial (sum, sum of squares) over the
                         rows of each 128-row tile of v = alpha*acc + bias (BatchNorm statistics,
                         clip.py:18,21,26; layers.py:11).  batch must be 1, splitk 1. */
