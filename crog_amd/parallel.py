@@ -30,9 +30,12 @@ class SyncBNComm:
     per CROG step, 2·C floats each), so they avoid both the gradient buckets' communicator — collectives of one communicator execute in
     issue order, and a statistics exchange would queue behind whatever 64 MiB bucket is in flight — and, on RCCL, torch.distributed's
     stream/event fencing: `direct` = an RCCL communicator of our own whose all-reduce is enqueued on the compute stream itself
-    (crog_amd/rccl.py).  OPT-IN (CROG_SYNCBN_DIRECT=1 or direct=True): at world size 1 — the only size this build could measure — the
-    direct form costs MORE than torch's (forced-DDP step 41.1-41.6 ms vs 39.7-40.0 ms, plain step 37.5 ms): RCCL's enqueue puts its own
-    host callbacks / fences on the user stream.  Default: a torch process group of its own (also the gloo path)."""
+    (crog_amd/rccl.py).  OPT-IN (CROG_SYNCBN_DIRECT=1 or direct=True).  Measured at world size 1, the only size this build could
+    measure: the direct CALLS are the cheaper ones (1.2 us of host time and no GPU work per call against 7.7 us + a 9.5 us stream
+    round trip for torch's; the gap between the two BatchNorm-backward kernels drops from 12.8 us to 0), but a communicator created
+    through ncclCommInitRank from here costs the step 2.9 ms by merely EXISTING (forced-DDP step: torch group 35.6 ms, direct 37.4 ms,
+    direct communicator created but torch calls used 38.5 ms; plain step 33.9 ms) — cause not found without RCCL's sources.
+    Default: a torch process group of its own (also the gloo path)."""
 
     def __init__(self, group=None, direct=None):
         self.group = group
