@@ -68,12 +68,17 @@ def convert_sync_batchnorm(model, process_group=None, force=False, dedicated_gro
     """nn.SyncBatchNorm.convert_sync_batchnorm equivalent: BatchNorm statistics of the HIP path become cross-replica.
     `force` installs the communicator even at world_size 1 (single-GPU smoke test of the collective path).  A collective call:
     every rank converts its model (as with the reference's conversion), because the statistics get a communicator of their own —
-    a direct RCCL one on the nccl backend, otherwise (or with direct=False) a dedicated torch process group."""
+    a direct RCCL one on the nccl backend when asked for, otherwise a dedicated torch process group (world size > 1; at world size 1
+    `CROG_SYNCBN_OWN_GROUP=1` forces it for A/B runs).  Measured at world size 1: a second communicator is not free — the forced-DDP
+    step is 37.1 ms with the statistics on a group of their own against 35.6 ms on the default group (1.5 ms; 2.9 ms for a communicator
+    made with ncclCommInitRank).  It stays the default for real multi-GPU runs because the alternative is worse by construction:
+    collectives of one communicator run in issue order, so every statistics exchange issued while a 64 MiB gradient bucket is in
+    flight (nine per step, ~0.4 ms each at 8 GPUs) would wait for it on the critical path."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force):
         use_direct = (_os.environ.get("CROG_SYNCBN_DIRECT", "0") == "1") if direct is None else direct
         use_direct = use_direct and torch.cuda.is_available() and dist.get_backend(process_group) == "nccl"
         group = process_group
-        if group is None and dedicated_group and not use_direct and dist.get_world_size() > 1:
+        if group is None and dedicated_group and not use_direct and (dist.get_world_size() > 1 or _os.environ.get("CROG_SYNCBN_OWN_GROUP") == "1"):
             group = dist.new_group()
         RT.comm = SyncBNComm(group, direct=use_direct)
         if RT.comm.direct is None and use_direct and group is None and dedicated_group and dist.get_world_size() > 1:
