@@ -124,6 +124,7 @@ class CROG(nn.Module):
                 for p in path:
                     mod = getattr(mod, p)
                 mod._buffers[leaf] = buf.to(device)
+        RT.ensure_streams(device)        # before any communicator creates streams of its own (crog_amd/runtime.py)
         self._store = ParamStore(self, device)
         self._store.explicit = True
         bind_all(self, self._store)
@@ -177,7 +178,8 @@ class CROG(nn.Module):
             store.weights(dtype)               # refresh the bf16 shadow on the main stream BEFORE the streams fork
             if self.overlap_text:
                 if self._side is None:
-                    self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CROG_SIDE_PRIORITY", "0")))
+                    RT.ensure_streams(dev)      # creation ORDER of the side streams decides which hardware queues they share
+                    self._side = RT.text_stream if RT.text_stream is not None else torch.cuda.Stream(device=dev)
                 RT.streams = [main, self._side]
                 self._side.wait_stream(main)
                 graphed = self._text_graph(word, dtype) if (TEXT_GRAPH and self.training and torch.is_grad_enabled()) else None

@@ -31,10 +31,12 @@ class SyncBNComm:
     issue order, and a statistics exchange would queue behind whatever 64 MiB bucket is in flight — and, on RCCL, torch.distributed's
     stream/event fencing: `direct` = an RCCL communicator of our own whose all-reduce is enqueued on the compute stream itself
     (crog_amd/rccl.py).  OPT-IN (CROG_SYNCBN_DIRECT=1 or direct=True).  Measured at world size 1, the only size this build could
-    measure: the direct CALLS are the cheaper ones (1.2 us of host time and no GPU work per call against 7.7 us + a 9.5 us stream
-    round trip for torch's; the gap between the two BatchNorm-backward kernels drops from 12.8 us to 0), but a communicator created
-    through ncclCommInitRank from here costs the step 2.9 ms by merely EXISTING (forced-DDP step: torch group 35.6 ms, direct 37.4 ms,
-    direct communicator created but torch calls used 38.5 ms; plain step 33.9 ms) — cause not found without RCCL's sources.
+    measure: the direct calls are the cheaper ones (1.2 us of host time and no GPU work per call against 7.7 us + a 9.5 us stream
+    round trip for torch's; the gap between the two BatchNorm-backward kernels drops from 12.8 us to 0) and the forced-DDP step is
+    35.1-35.6 ms with them against 35.8-36.2 ms on torch's groups (plain step 33.9 ms, 34.8 ms with the gradient buckets alone).
+    (An earlier measurement had the direct form 1.7 ms SLOWER: a communicator's stream created before the weight-gradient stream
+    pushed the latter onto the main stream's hardware queue — Runtime.ensure_streams now fixes the creation order.)  It stays opt-in
+    because it has never run with real peers.
     Default: a torch process group of its own (also the gloo path)."""
 
     def __init__(self, group=None, direct=None):
@@ -69,12 +71,11 @@ def convert_sync_batchnorm(model, process_group=None, force=False, dedicated_gro
     `force` installs the communicator even at world_size 1 (single-GPU smoke test of the collective path).  A collective call:
     every rank converts its model (as with the reference's conversion), because the statistics get a communicator of their own —
     a direct RCCL one on the nccl backend when asked for, otherwise a dedicated torch process group (world size > 1; at world size 1
-    `CROG_SYNCBN_OWN_GROUP=1` forces it for A/B runs).  Measured at world size 1: a second communicator is not free — the forced-DDP
-    step is 37.1 ms with the statistics on a group of their own against 35.6 ms on the default group (1.5 ms; 2.9 ms for a communicator
-    made with ncclCommInitRank).  It stays the default for real multi-GPU runs because the alternative is worse by construction:
-    collectives of one communicator run in issue order, so every statistics exchange issued while a 64 MiB gradient bucket is in
-    flight (nine per step, ~0.4 ms each at 8 GPUs) would wait for it on the critical path."""
+    `CROG_SYNCBN_OWN_GROUP=1` forces it for A/B runs: 36.0 vs 35.8-36.2 ms on the default group, i.e. free once the stream creation
+    order is fixed).  Collectives of one communicator run in issue order, so on the default group every statistics exchange issued
+    while a 64 MiB gradient bucket is in flight (nine per step, ~0.4 ms each at 8 GPUs) would wait for it on the critical path."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force):
+        RT.ensure_streams()       # the side streams take their hardware queues before the communicator's streams exist
         use_direct = (_os.environ.get("CROG_SYNCBN_DIRECT", "0") == "1") if direct is None else direct
         use_direct = use_direct and torch.cuda.is_available() and dist.get_backend(process_group) == "nccl"
         group = process_group
@@ -224,6 +225,8 @@ class DistributedDataParallel(torch.nn.Module):
         self._hooks = []
         if hasattr(module, "prepare"):
             dev = torch.device("cuda", device_ids[0]) if device_ids else next(module.parameters()).device
+            if dev.type == "cuda":
+                RT.ensure_streams(dev)
             module.prepare(dev)
         self._sync_initial_state()
 

@@ -8,10 +8,9 @@ world size 1, where the collective itself is a no-op, that machinery alone costs
 
 STATUS: opt-in (`CROG_SYNCBN_DIRECT=1`).  Measured at world size 1 (the only size this build has hardware for): the direct call costs
 1.2 us of host time and nothing on the GPU (an in-place single-rank all-reduce is a no-op) where torch's costs 7.7 us + a 9.5 us stream
-round trip (`scripts/probe_allreduce_host.py`), and the BatchNorm-backward partial -> apply gap shrinks from 12.8 us to 0
-(`scripts/_ddp_gaps.sh`) — yet the forced-DDP step is SLOWER with it (37.4 vs 35.6 ms), because a communicator created from here
-costs ~2.9 ms per step by existing (38.5 ms when it is created and torch's calls are used anyway).  Until that is understood — or
-measured away with real peers on an 8-GPU node — the default stays torch's process group.
+round trip (`scripts/probe_allreduce_host.py`), the BatchNorm-backward partial -> apply gap shrinks from 12.8 us to 0
+(`scripts/_ddp_gaps.sh`), and the forced-DDP step is 35.1-35.6 ms against 35.8-36.2 ms with torch's process groups.  Opt-in only
+because it has never run with real peers (a set-up problem falls back to torch; a hang would not).
 
 RCCL is the library PyTorch-ROCm already has resident (`torch/lib/librccl.so`); the unique id is created on rank 0 and handed to the
 other ranks through the existing `torch.distributed` group, which is also what the gradient buckets keep using (they are large,

@@ -27,6 +27,8 @@ class Runtime:
         self.streams = []      # HIP streams the model's kernels run on (main + text-tower side stream + wgrad stream)
         self.overlap_wgrad = os.environ.get("CROG_OVERLAP_WGRAD", "1") != "0"
         self._wgrad_stream = None
+        self.text_stream = None
+        self._streams_ready = False
         self._join_armed = False
         self.seed_base = 0x5EED
         self._seed_ctr = 0
@@ -35,11 +37,46 @@ class Runtime:
     # Weight gradients are only consumed by the optimizer (or the gradient all-reduce), never by the rest of backward,
     # so their GEMMs run on a second stream and fill the CUs that the skinny data-gradient / BatchNorm kernels of the
     # dependency chain leave idle.
+    # ---- stream creation order ---------------------------------------------------------------------------
+    # HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in the order the streams are first
+    # used, and streams that land on the SAME hardware queue execute strictly in order.  Measured at world size 1 with
+    # DistributedDataParallel + SyncBatchNorm forced on: when a communicator's internal stream is created between the main stream and
+    # the weight-gradient stream, the latter wraps around onto the main stream's queue and the overlap is gone (+1.5 ms per step for
+    # one extra communicator, +2.9 ms for two; 2 queues instead of 4 costs the plain step the same 1.5 ms; 8 queues make the
+    # cross-queue waits of torch's collectives so slow that the step takes 54 ms).  So the side streams of the dependency chain are
+    # created AND touched before anything else can create a stream: main -> queue 0, weight gradients -> 1, text tower -> 2.
+    def ensure_streams(self, device=None):
+        if not torch.cuda.is_available() or getattr(self, "_streams_ready", False):
+            return
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            return
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream()
+            order = []
+            if self.overlap_wgrad:
+                n = max(1, int(os.environ.get("CROG_WGRAD_STREAMS", "1")))
+                prio = int(os.environ.get("CROG_SIDE_PRIORITY", "0"))
+                self._wgrad_stream = [torch.cuda.Stream(priority=prio) for _ in range(n)]
+                self._wgrad_next = 0
+                order += self._wgrad_stream
+            self.text_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CROG_SIDE_PRIORITY", "0")))
+            order.append(self.text_stream)
+            touch = torch.zeros(8, device=dev)
+            for s in order:                     # first USE binds the stream to its hardware queue
+                s.wait_stream(main)
+                with torch.cuda.stream(s):
+                    touch.add_(1.0)
+                main.wait_stream(s)
+        self._streams_ready = True
+
     def wgrad_stream(self):
         """Weight-gradient side stream (CROG_WGRAD_STREAMS > 1 round-robins over several: measured 1 % slower with 2-3, the small
         atomic-bound weight gradients contend with each other)."""
         if not self.overlap_wgrad or not torch.cuda.is_available():
             return None
+        if self._wgrad_stream is None:
+            self.ensure_streams()
         if self._wgrad_stream is None:
             n = max(1, int(os.environ.get("CROG_WGRAD_STREAMS", "1")))
             prio = int(os.environ.get("CROG_SIDE_PRIORITY", "0"))
