@@ -358,7 +358,49 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
       for (int e = 0; e < 16; e++) acc[i][j][e] = alpha * acc[i][j][e] + bcol[j];
     });
   }
-  if (p.col_stats) {
+  if (p.col_stats && p.bwd_z) {
+    // BatchNorm-backward statistics (crog_hip.h: bwd_z): the accumulators are a gradient dy; gate it with the ReLU mask recomputed
+    // from z, keep the gated value (it is what gets stored) and accumulate (sum g, sum g * z).  z is fetched in the pair layout of
+    // the bf16 store path — even lanes read row(2q), odd lanes row(2q + 1), two adjacent columns each — and one DPP swap hands
+    // every lane the value of its own column in the other row.
+    if constexpr (sizeof(T) == 2) {
+      const T* Z = reinterpret_cast<const T*>(p.bwd_z);
+      const bool odd = lane & 1;
+      const bool inner = m0 + BM <= p.M && n0 + BN <= p.N;
+      float gsc[WN], gsh[WN];
+#pragma unroll
+      for (int j = 0; j < WN; j++) {
+        const bool okc = p.bwd_ss && ncol[j] < p.N;
+        gsc[j] = okc ? p.bwd_ss[2 * ncol[j]] : 0.f;
+        gsh[j] = okc ? p.bwd_ss[2 * ncol[j] + 1] : 1.f;      // no ReLU: gate = 0 * z + 1 > 0
+      }
+      per_block([&](int i, int j) {
+        const int colp = n0 + (wc * WN + j) * 32 + (r & ~1);
+        const int mrow = m0 + (wr * WM + i) * 32 + 4 * h + (odd ? 1 : 0);
+        const T* zb = Z + (int64_t)mrow * p.ldz + colp;
+        unsigned P[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int ro = (2 * q & 3) + 8 * (2 * q >> 2);
+          P[q] = (inner || (mrow + ro < p.M && colp < p.N)) ? *reinterpret_cast<const unsigned*>(zb + (int64_t)ro * p.ldz) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const unsigned O = (unsigned)__builtin_amdgcn_update_dpp(0, (int)P[q], 0xB1, 0xF, 0xF, false);   // lane ^ 1
+          // bf16 -> f32 is a 16-bit shift: low half = first column of the pair, high half = second
+          const float z0 = __builtin_bit_cast(float, odd ? (O & 0xffff0000u) : (P[q] << 16));
+          const float z1 = __builtin_bit_cast(float, odd ? (P[q] & 0xffff0000u) : (O << 16));
+          float a0 = acc[i][j][2 * q], a1 = acc[i][j][2 * q + 1];
+          a0 = (z0 * gsc[j] + gsh[j] > 0.f) ? a0 : 0.f;
+          a1 = (z1 * gsc[j] + gsh[j] > 0.f) ? a1 : 0.f;
+          acc[i][j][2 * q] = a0;
+          acc[i][j][2 * q + 1] = a1;
+          s1[j] += a0 + a1;
+          s2[j] += a0 * z0 + a1 * z1;
+        }
+      });
+    }
+  } else if (p.col_stats) {
     if (m0 + BM <= p.M) {   // interior tile: no row guard
       per_block([&](int i, int j) {
 #pragma unroll
@@ -1549,6 +1591,10 @@ extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
                  "crog_gemm: splitk > 1 needs atomic fp32 output, no activation, no residual");
   CROG_CHECK_ARG(!d.R || d.batch == 1, "crog_gemm: residual only for unbatched GEMM");
   CROG_CHECK_ARG(!d.col_stats || (d.batch == 1 && d.splitk == 1), "crog_gemm: col_stats needs batch == 1 and splitk == 1");
+  if (d.bwd_z)
+    CROG_CHECK_ARG(d.col_stats && d.stat_replicas > 0 && d.dtype == CROG_BF16 && d.out_mode == CROG_OUT_T && !d.R && (d.N & 1) == 0 &&
+                       d.ldz % vec == 0 && ((uintptr_t)d.bwd_z % 16) == 0 && d.act == CROG_ACT_NONE,
+                   "crog_gemm: bwd_z needs bf16 dtype output, col_stats with stat_replicas > 0, no residual / activation, even N, aligned z");
   CROG_CHECK_ARG(!d.a_sum || d.batch == 1, "crog_gemm: a_sum needs batch == 1");
   CROG_CHECK_ARG((long)d.batch * d.splitk <= 65535, "crog_gemm: batch*splitk too large");
   hipStream_t s = (hipStream_t)stream;

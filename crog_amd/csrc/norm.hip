@@ -407,7 +407,11 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
   constexpr int VEC = Elem<T>::VEC;
   // sum_rows > 0: `sums` is [sum_rows][C][2] (atomic replicas of bn_bwd_partial, or the all-reduced totals): every block adds the
   // rows up into LDS once; block 0 also stores the parameter gradients (dbeta = sum g, dgamma = sum g*zhat) when asked to.
+  // sum_rows < 0: |sum_rows| rows of RAW z-moments (sum g, sum g*z) from a data-gradient GEMM's epilogue (crog_gemm bwd_z):
+  // sum g*zhat = invstd * (sum g*z - mean * sum g).
   extern __shared__ __attribute__((aligned(16))) float tot[];
+  const bool raw = sum_rows < 0;
+  if (raw) sum_rows = -sum_rows;
   if (sum_rows > 0) {
     for (int c = threadIdx.x; c < C; c += NT) {
       float a = 0.f, b = 0.f;
@@ -415,6 +419,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
         a += sums[((long)r * C + c) * 2];
         b += sums[((long)r * C + c) * 2 + 1];
       }
+      if (raw) b = mean_invstd[2 * c + 1] * (b - mean_invstd[2 * c] * a);
       tot[2 * c] = a;
       tot[2 * c + 1] = b;
       if (blockIdx.x == 0 && dgamma) {   // pgrad_scale = 1/world under SyncBatchNorm: the totals are global there (see header)
@@ -1040,10 +1045,10 @@ extern "C" int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const 
                                  crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(C % vec == 0, "bn_bwd_apply: C %% %d != 0", vec);
-  CROG_CHECK_ARG(sum_rows >= 0 && C <= 8192 && (!dgamma || (dbeta && sum_rows > 0)), "bn_bwd_apply: bad sum_rows / parameter-gradient outputs");
+  CROG_CHECK_ARG(C <= 8192 && (!dgamma || (dbeta && sum_rows != 0)), "bn_bwd_apply: bad sum_rows / parameter-gradient outputs");
   int grid = stream_grid(M * (C / vec));
-  if (sum_rows > 0) grid = std::min(grid, 1024);   // every block adds up the sum_rows x 2C partials once
-  const size_t lds = sum_rows > 0 ? (size_t)C * 2 * sizeof(float) : 0;
+  if (sum_rows != 0) grid = std::min(grid, 1024);   // every block adds up the |sum_rows| x 2C partials once
+  const size_t lds = sum_rows != 0 ? (size_t)C * 2 * sizeof(float) : 0;
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(NT), lds, (hipStream_t)stream, (const T*)dy, (long)lddy,
                                        (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, gamma, sums, count, relu_scale_shift,
                                        (T*)dz, (long)lddz, (T*)dres, (long)lddres, (long)M, C, sum_rows, dgamma, dbeta, (const unsigned char*)relu_mask,

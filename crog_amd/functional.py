@@ -171,6 +171,28 @@ class GradSlot:
         self.t = None
 
 
+class BnLink:
+    """Side channel between two consecutive ConvBnAct layers whose only connection is y_L -> x_{L+1} (bn1 -> conv2, bn2 -> conv3 of
+    a Bottleneck, the stem convolutions): layer L publishes its pre-normalisation activation and ReLU gate in the forward
+    (`stat_out`); in backward layer L+1, whose data gradient IS layer L's dy, lets the GEMM epilogue gate that gradient and
+    accumulate (sum g, sum g*z) (`stat_in`, crog_gemm bwd_z) — layer L then skips the first pass of BatchNorm backward, which
+    would have re-read dy and z from HBM.  Only valid when NOTHING else consumes y_L: the model code that wires it vouches."""
+
+    __slots__ = ("z", "ss", "C", "M", "sums", "R")
+
+    def __init__(self):
+        self.z = self.ss = self.sums = None
+        self.C = self.M = self.R = 0
+
+
+BN_BWD_FUSED = _os.environ.get("CROG_BN_BWD_FUSED", "1") != "0"   # BnLink fusion on (bf16, atomic statistics path)
+# ... for layers of at most this many rows.  Measured per layer, HBM-cold (scripts/bench_bwd_fused.py): the gated-statistics epilogue
+# adds 5-7 us to a 21632- / 86528-row data gradient and saves a 16-23 us first pass; on the 346112-row layers of layer1 it costs what it
+# saves (+17 us vs 19-21 us: bn_bwd_partial streams at 4.2 TB/s, the epilogue gathers z in 4-byte pieces and its atomics collide on 64
+# columns), and on the 1.38 M-row stem it LOSES 13-19 us.
+BN_BWD_FUSED_MAX_ROWS = int(_os.environ.get("CROG_BN_BWD_FUSED_MAX_ROWS", "131072"))
+
+
 def stat_replicas(slabs: int, C: int) -> int:
     """Replica rows for the atomic BatchNorm statistics: at most ~256 adds land on one address (every tile of a layer adds to the
     same 2C floats: with ONE row the 346112 x 64 layer1 convolution takes 159 us instead of 68, the 1.4 M-row stem 540 instead of
@@ -190,9 +212,10 @@ class ConvBnAct(Function):
 
     @staticmethod
     def forward(ctx, x, res, _wp, _gp, _bp, w: Optional[WRef], bn: BnBuffers, ksize, relu: bool, training: bool, out, wpad, dtype,
-                grad_slot=None, res_slot=None):
+                grad_slot=None, res_slot=None, stat_out=None, stat_in=None):
         dev = x.device
         ctx.slots = (grad_slot, res_slot)
+        ctx.links = (stat_out, stat_in)
         if ksize == "s":
             B, _, Hi, Wi = x.shape
             H, W = Hi // 2, Wi // 2
@@ -286,6 +309,11 @@ class ConvBnAct(Function):
         ctx.has_res = res is not None
         ctx.relu_ss = ss if (relu and res is None and training) else None   # ReLU mask can be recomputed from z: y is not re-read in backward
         ctx.x_needs = ksize != "s" and x.requires_grad
+        if stat_out is not None:
+            # publish what the NEXT layer's data-gradient epilogue needs to do this layer's first backward pass (BnLink)
+            ok = (BN_BWD_FUSED and BN_BWD_ATOMIC and training and dtype == torch.bfloat16 and res is None and ksize != 0 and torch.is_grad_enabled()
+                  and M <= BN_BWD_FUSED_MAX_ROWS)
+            stat_out.z, stat_out.ss, stat_out.C, stat_out.M, stat_out.sums = (z if ok else None), (ss if relu else None), C, M, None
         ctx.wt = (wt, wbuf_off) if wpad is not None else None
         if ksize == "s":
             ctx.save_for_backward(patches, z, y, mi)
@@ -311,7 +339,21 @@ class ConvBnAct(Function):
         comm_on = RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force)
         dz = torch.empty(lead + (C,), device=dev, dtype=dtype)
         dres = torch.empty(lead + (C,), device=dev, dtype=dtype) if ctx.has_res else None
-        if BN_BWD_ATOMIC and dtype != torch.float32:
+        stat_out, stat_in = ctx.links
+        fused = stat_out is not None and stat_out.sums is not None
+        if fused:
+            # the layer that consumed y already gated dy and left (sum g, sum g*z) in R replica rows (BnLink): no first pass
+            sums, R = stat_out.sums, stat_out.R
+            stat_out.sums = stat_out.z = None
+            scale = 1.0
+            if comm_on:
+                RT.comm.all_reduce_sum(sums)
+                scale = 1.0 / RT.comm.world_size
+            K.bn_bwd_apply(dy, None, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=-R,
+                           dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=None, param_grad_scale=scale)
+            bn.beta.done()
+            bn.gamma.done()
+        elif BN_BWD_ATOMIC and dtype != torch.float32:
             # (sum g, sum g*xhat) accumulate atomically into R pre-zeroed [C][2] rows - each block parks its sums in LDS and adds them
             # as 256-byte runs - and the apply kernel adds the rows up itself and stores dbeta / dgamma: two launches, no slab, no
             # reduction kernel.  Under SyncBatchNorm the R rows are all-reduced in between; the totals are then global, and storing
@@ -396,26 +438,38 @@ class ConvBnAct(Function):
                 if wpad is not None:  # strip the zero padding back out into the real gradient
                     K.add_pad2d(gscratch, dst_cols, w.G, src_cols, src_cols, rows, dst_off=w.off)
             RT.on_wgrad_stream(wgrad, dz, x, gt if wpad is not None else None)
+            # BnLink: this data gradient is the previous layer's dy -> its epilogue does that layer's first BatchNorm-backward pass
+            bwd = {}
+            if (stat_in is not None and stat_in.z is not None and ctx.x_needs and extra is None and dtype == torch.bfloat16
+                    and stat_in.C == cin and stat_in.M == M and cin % 8 == 0):
+                stat_in.R = stat_replicas(K.stat_tiles(M), cin)
+                stat_in.sums = RT.zeros(stat_in.R * 2 * cin, dev)
+                bwd = dict(col_stats=stat_in.sums, stat_replicas=stat_in.R, bwd_z=stat_in.z, bwd_ss=stat_in.ss)
             if ksize == 1 and ctx.x_needs:
                 dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
-                K.gemm(dt, K.A_KC, K.B_NC, dz, wt, dx, M, cin, C, C, wcols, cin, b_off=woff, R=extra, ldr=K.mat(extra)[2] if extra is not None else 0)
+                K.gemm(dt, K.A_KC, K.B_NC, dz, wt, dx, M, cin, C, C, wcols, cin, b_off=woff, R=extra, ldr=K.mat(extra)[2] if extra is not None else 0,
+                       **bwd)
             elif ksize == 3 and ctx.x_needs:
                 B, H, W = lead
                 dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
                 if DGRAD_T and wpad is None and cin % 8 == 0:
                     # data gradient as a forward-shaped implicit GEMM on the [Cin][flipped tap][Cout] copy of the weight
-                    K.gemm(dt, K.A_IM2COL, K.B_KC, dz, w.store.weights_t(dtype), dx, M, cin, 9 * C, C, 9 * C, cin, b_off=woff, conv=(H, W, C))
+                    K.gemm(dt, K.A_IM2COL, K.B_KC, dz, w.store.weights_t(dtype), dx, M, cin, 9 * C, C, 9 * C, cin, b_off=woff, conv=(H, W, C), **bwd)
                 else:
-                    K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, dz, wt, dx, M, cin, 9 * C, C, cin, cin, b_off=woff, conv=(H, W, C))
+                    K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, dz, wt, dx, M, cin, 9 * C, C, cin, cin, b_off=woff, conv=(H, W, C), **bwd)
+            elif stat_in is not None:
+                stat_in.sums = None
             w.done()
-        return (dx, dres) + (None,) * 13
+        return (dx, dres) + (None,) * 15
 
 
 def conv_bn_act(x, w: Optional[WRef], bn: BnBuffers, *, ksize, relu=True, res=None, training=True, out=None, wpad=None, dtype=None,
-                grad_slot=None, res_slot=None):
+                grad_slot=None, res_slot=None, stat_out=None, stat_in=None):
+    """stat_out / stat_in: a BnLink shared by two layers with y_L -> x_{L+1} and no other consumer of y_L (see BnLink)."""
     dtype = dtype if dtype is not None else x.dtype
     wp = w.param if w is not None else None
-    return ConvBnAct.apply(x, res, wp, bn.gamma.param, bn.beta.param, w, bn, ksize, relu, training, out, wpad, dtype, grad_slot, res_slot)
+    return ConvBnAct.apply(x, res, wp, bn.gamma.param, bn.beta.param, w, bn, ksize, relu, training, out, wpad, dtype, grad_slot, res_slot,
+                           stat_out, stat_in)
 
 
 # ------------------------------------------------------------------------------------------------

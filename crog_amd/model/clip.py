@@ -40,8 +40,12 @@ class Bottleneck(Bound):
         tr = self.training
         # identity blocks: the residual's gradient rides a slot into conv1's dgrad epilogue (no separate accumulation pass)
         slot = Fn.GradSlot() if (self.downsample is None and tr and x.requires_grad) else None
-        out = Fn.conv_bn_act(x, self.conv1.w, self.bn1.buffers_ref(), ksize=1, relu=True, training=tr, grad_slot=slot)
-        out = Fn.conv_bn_act(out, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr)
+        # bn1's output feeds conv2 and nothing else, bn2's feeds conv3 directly when no AvgPool sits between them: the data gradient
+        # of the consuming convolution does the first pass of that BatchNorm's backward in its epilogue (Fn.BnLink)
+        l1 = Fn.BnLink() if tr else None
+        l2 = Fn.BnLink() if (tr and self.stride == 1) else None
+        out = Fn.conv_bn_act(x, self.conv1.w, self.bn1.buffers_ref(), ksize=1, relu=True, training=tr, grad_slot=slot, stat_out=l1)
+        out = Fn.conv_bn_act(out, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=l1, stat_out=l2)
         if self.stride > 1:
             out = Fn.avgpool2(out)
         identity = x
@@ -49,7 +53,8 @@ class Bottleneck(Bound):
             if self.stride > 1:
                 identity = Fn.avgpool2(x)
             identity = Fn.conv_bn_act(identity, self.downsample["0"].w, self.downsample["1"].buffers_ref(), ksize=1, relu=False, training=tr)
-        return Fn.conv_bn_act(out, self.conv3.w, self.bn3.buffers_ref(), ksize=1, relu=True, res=identity, training=tr, res_slot=slot)
+        return Fn.conv_bn_act(out, self.conv3.w, self.bn3.buffers_ref(), ksize=1, relu=True, res=identity, training=tr, res_slot=slot,
+                              stat_in=l2)
 
 
 _BICUBIC_CACHE = {}
@@ -130,9 +135,11 @@ class ModifiedResNet(Bound):
         c1 = self.conv1.weight.shape[0]
         if c1 != 32:
             raise NotImplementedError("stem kernel is specialised for CLIP ResNets of width 64 (conv1: 3 -> 32)")
-        x = Fn.conv_bn_act(img, self.conv1.w, self.bn1.buffers_ref(), ksize="s", relu=True, training=tr, wpad=(27, 32, c1), dtype=dtype)
-        x = Fn.conv_bn_act(x, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr)
-        x = Fn.conv_bn_act(x, self.conv3.w, self.bn3.buffers_ref(), ksize=3, relu=True, training=tr)
+        s1, s2 = (Fn.BnLink(), Fn.BnLink()) if tr else (None, None)       # stem: conv1 -> conv2 -> conv3 is a plain chain
+        x = Fn.conv_bn_act(img, self.conv1.w, self.bn1.buffers_ref(), ksize="s", relu=True, training=tr, wpad=(27, 32, c1), dtype=dtype,
+                           stat_out=s1)
+        x = Fn.conv_bn_act(x, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=s1, stat_out=s2)
+        x = Fn.conv_bn_act(x, self.conv3.w, self.bn3.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=s2)
         x = Fn.avgpool2(x)
         x = self.layer1(x)
         if after_layer1 is not None:

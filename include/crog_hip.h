@@ -119,6 +119,15 @@ typedef struct crog_gemm_desc {
                         N-tile (every split adds its share).  With A = dy^T (CROG_A_MC) this is the bias gradient of the
                         nn.Linear / bias-conv whose weight gradient the GEMM computes (clip.py:249-251, layers.py:58,
                         298-301, ssg.py:123-133): no separate column-sum pass over dy.  batch must be 1. */
+  const void* bwd_z; /* NULL, or [M][N] (dtype, row stride ldz): BatchNorm-BACKWARD statistics mode of col_stats, for a data-gradient
+                        GEMM whose output is the gradient dy of a BatchNorm(+ReLU) layer with pre-normalisation activation z
+                        (clip.py:44-57: conv1 -> bn1 -> relu -> conv2: conv2's data gradient IS bn1's dy).  The epilogue masks the
+                        gradient, g = relu_gate(z) ? v : 0 with relu_gate(z) = z * bwd_ss[n][0] + bwd_ss[n][1] > 0 (all ones when
+                        bwd_ss is NULL), STORES g instead of v, and accumulates (sum g, sum g * z) per column into col_stats —
+                        the first pass of BatchNorm backward without re-reading dy (crog_bn_bwd_apply takes the raw z-moments
+                        with a negative sum_rows).  Needs dtype output, no residual, stat_replicas > 0, even N. */
+  int64_t ldz;
+  const float* bwd_ss; /* NULL, or fp32 [N][2]: (scale, shift) of the layer's normalisation, to recompute the ReLU gate from z */
 } crog_gemm_desc;
 
 int crog_gemm(const crog_gemm_desc* d, crog_stream_t stream);
@@ -172,7 +181,9 @@ int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, 
  * with sum_rows = R, adds the rows up itself and (dgamma/dbeta != NULL) ADDS the parameter gradients times param_grad_scale to
  * dgamma/dbeta (gradient buffers accumulate until zero_grad, as torch's .grad does) — no reduction launch.  Under SyncBatchNorm the rows are all-reduced first, so the totals are GLOBAL sums: storing them with
  * param_grad_scale = 1/world gives every rank the value DDP's gradient averaging would have produced from the local sums
- * (mean over ranks of the local sums == global sum / world), and no separate local-sum pass is needed. */
+ * (mean over ranks of the local sums == global sum / world), and no separate local-sum pass is needed.
+ * sum_rows < 0: |sum_rows| rows of RAW z-moments (sum g, sum g*z), as a data-gradient GEMM's epilogue accumulates them
+ * (crog_gemm_desc.bwd_z); the kernel forms sum g*zhat = invstd * (sum g*z - mean * sum g) itself. */
 int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
                       int64_t ldz, const float* mean_invstd, const float* gamma, const float* sums,
                       float count, const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres,

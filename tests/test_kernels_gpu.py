@@ -990,3 +990,42 @@ def test_timing_only_events_measure_a_launch(K):
     ms, ms_torch = t0.elapsed_time(t1), e0.elapsed_time(e1)
     assert 0.005 < ms < 5.0                      # 128 MB of traffic: ~30 us at 4.5 TB/s, never milliseconds
     assert ms <= ms_torch * 1.05 + 0.01          # bracketed by the torch pair
+
+
+@pytest.mark.parametrize("M,N,K_,relu", [(4096, 64, 64, True), (1000, 72, 96, True), (21632, 256, 2304 // 9, False), (2500, 512, 128, True)])
+def test_dgrad_epilogue_does_the_first_batchnorm_backward_pass(K, M, N, K_, relu):
+    """crog_gemm bwd_z: a data-gradient GEMM whose output is a BatchNorm(+ReLU) layer's dy gates it with the ReLU mask recomputed
+    from z, stores the gated gradient and accumulates (sum g, sum g*z) into replica rows; crog_bn_bwd_apply with a negative
+    sum_rows turns the raw z-moments into the totals the two-launch path computes.  Checked against torch on the same operands."""
+    dt = torch.bfloat16
+    from crog_amd.functional import stat_replicas
+    a, b = rnd(M, K_, dt=dt), (rnd(K_, N, dt=dt, seed=1) * 0.1).to(dt)            # dy_next [M, K_] @ W [K_, N] (B_NC layout)
+    z = (rnd(M, N, dt=dt, seed=2) * 1.5 + 0.3).to(dt)
+    ss = torch.stack([torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda") * 0.3], 1).contiguous()
+    R = stat_replicas(K.stat_tiles(M), N)
+    sums = torch.zeros(R, N, 2, device="cuda")
+    dx = torch.full((M + 1, N), 7.0, device="cuda", dtype=dt)
+    K.gemm(K.dcode(dt), K.A_KC, K.B_NC, a, b, dx, M, N, K_, K_, N, N, col_stats=sums, stat_replicas=R, bwd_z=z, bwd_ss=ss if relu else None)
+    assert (dx[M] == 7).all()
+    v = a.float() @ b.float()
+    gate = (z.float() * ss[:, 0] + ss[:, 1] > 0) if relu else torch.ones_like(v, dtype=torch.bool)
+    g = torch.where(gate, v, torch.zeros_like(v))
+    close(dx[:M], g, dt, scale=math.sqrt(K_) / 4)
+    tot = sums.sum(0)
+    assert torch.allclose(tot[:, 0], g.sum(0), rtol=2e-3, atol=2e-2 * g.abs().sum(0).max().item() / 100)
+    assert torch.allclose(tot[:, 1], (g * z.float()).sum(0), rtol=2e-3, atol=2e-2 * (g * z.float()).abs().sum(0).max().item() / 100)
+    # second pass from the raw moments == second pass from (sum g, sum g*zhat) of the stored gradient
+    mean = z.float().mean(0); var = z.float().var(0, unbiased=False); invstd = (var + 1e-5).rsqrt()
+    mi = torch.stack([mean, invstd], 1).contiguous()
+    gamma = torch.rand(N, device="cuda") + 0.5
+    dg = [torch.zeros(N, device="cuda") for _ in range(4)]
+    dz_raw, dz_ref = torch.empty(M, N, device="cuda", dtype=dt), torch.empty(M, N, device="cuda", dtype=dt)
+    K.bn_bwd_apply(dx[:M], None, z, mi, gamma, sums, float(M), dz_raw, None, ss if relu else None, sum_rows=-R, dgamma=dg[0], dbeta=dg[1])
+    gs = dx[:M].float()                       # the gradient as stored (bf16-rounded): what a separate first pass would have read
+    zh = (z.float() - mean) * invstd
+    ref_sums = torch.stack([gs.sum(0), (gs * zh).sum(0)], 1).contiguous().view(1, N, 2)
+    K.bn_bwd_apply(dx[:M], None, z, mi, gamma, ref_sums, float(M), dz_ref, None, ss if relu else None, sum_rows=1, dgamma=dg[2], dbeta=dg[3])
+    scale = max(dz_ref.float().abs().max().item(), 1e-3)
+    assert (dz_raw.float() - dz_ref.float()).abs().max().item() <= 2e-2 * scale
+    assert torch.allclose(dg[1], dg[3], rtol=5e-3, atol=5e-3 * dg[3].abs().max().item())
+    assert torch.allclose(dg[0], dg[2], rtol=5e-3, atol=5e-3 * dg[2].abs().max().item() + 1e-3)
