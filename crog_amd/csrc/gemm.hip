@@ -301,10 +301,13 @@ __device__ inline float dpp_swap1(float v) {
 // LEAN: the tile is only ever launched with the plain bf16 epilogue (alpha 1, no bias / activation / residual, dtype output, even N;
 // column statistics optional) and the other epilogue paths are not compiled into it (lean_epilogue_ok() is the dispatch-side check)
 // NSTAGE: depth of the LDS-DMA ring (0 = the default of the tile size, dma_nstage()).
-template <int WM_, int WN_, int WVM_, int WVN_, bool LEAN_ = false, int NSTAGE_ = 0>
+// BWD: a LEAN tile whose statistics are the BatchNorm-BACKWARD ones (crog_gemm_desc.bwd_z); a kernel of its own so that the
+// gather of z does not cost the other instantiations registers.
+template <int WM_, int WN_, int WVM_, int WVN_, bool LEAN_ = false, int NSTAGE_ = 0, bool BWD_ = false>
 struct Shape {
   static constexpr int WM = WM_, WN = WN_, WVM = WVM_, WVN = WVN_, NSTAGE = NSTAGE_;
-  static constexpr bool LEAN = LEAN_;
+  static constexpr bool LEAN = LEAN_, BWD = BWD_;
+  static_assert(!BWD_ || LEAN_, "the backward-statistics epilogue is a lean one");
   static constexpr int NT = 64 * WVM * WVN, BM = 32 * WM * WVM, BN = 32 * WN * WVN;
 };
 // (a 256 x 128 register-staged variant was measured slower than 128 x 128 -- occupancy-bound staging -- and spilled at 256 VGPRs: removed)
@@ -358,47 +361,48 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
       for (int e = 0; e < 16; e++) acc[i][j][e] = alpha * acc[i][j][e] + bcol[j];
     });
   }
-  if (p.col_stats && p.bwd_z) {
+  if (S::BWD && p.col_stats && p.bwd_z) {
     // BatchNorm-backward statistics (crog_hip.h: bwd_z): the accumulators are a gradient dy; gate it with the ReLU mask recomputed
     // from z, keep the gated value (it is what gets stored) and accumulate (sum g, sum g * z).  z is fetched in the pair layout of
     // the bf16 store path — even lanes read row(2q), odd lanes row(2q + 1), two adjacent columns each — and one DPP swap hands
-    // every lane the value of its own column in the other row.
-    if constexpr (sizeof(T) == 2) {
+    // every lane the value of its own column in the other row.  Compiled only into the BWD tile (Shape<..., BWD>).
+    if constexpr (sizeof(T) == 2 && S::BWD) {
       const T* Z = reinterpret_cast<const T*>(p.bwd_z);
       const bool odd = lane & 1;
-      const bool inner = m0 + BM <= p.M && n0 + BN <= p.N;
-      float gsc[WN], gsh[WN];
+      auto gated_stats = [&](auto guarded) {
+        constexpr bool G = decltype(guarded)::value;
+        per_block([&](int i, int j) {
+          const bool okc = p.bwd_ss && ncol[j] < p.N;
+          const float gsc = okc ? p.bwd_ss[2 * ncol[j]] : 0.f;
+          const float gsh = okc ? p.bwd_ss[2 * ncol[j] + 1] : 1.f;      // no ReLU: gate = 0 * z + 1 > 0
+          const int colp = n0 + (wc * WN + j) * 32 + (r & ~1);
+          const int mrow = m0 + (wr * WM + i) * 32 + 4 * h + (odd ? 1 : 0);
+          const T* zb = Z + (int64_t)mrow * p.ldz + colp;
+          unsigned P[8];
 #pragma unroll
-      for (int j = 0; j < WN; j++) {
-        const bool okc = p.bwd_ss && ncol[j] < p.N;
-        gsc[j] = okc ? p.bwd_ss[2 * ncol[j]] : 0.f;
-        gsh[j] = okc ? p.bwd_ss[2 * ncol[j] + 1] : 1.f;      // no ReLU: gate = 0 * z + 1 > 0
-      }
-      per_block([&](int i, int j) {
-        const int colp = n0 + (wc * WN + j) * 32 + (r & ~1);
-        const int mrow = m0 + (wr * WM + i) * 32 + 4 * h + (odd ? 1 : 0);
-        const T* zb = Z + (int64_t)mrow * p.ldz + colp;
-        unsigned P[8];
+          for (int q = 0; q < 8; q++) {
+            const int ro = (2 * q & 3) + 8 * (2 * q >> 2);
+            if (!G || (mrow + ro < p.M && colp < p.N)) P[q] = *reinterpret_cast<const unsigned*>(zb + (int64_t)ro * p.ldz);
+            else P[q] = 0u;
+          }
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const int ro = (2 * q & 3) + 8 * (2 * q >> 2);
-          P[q] = (inner || (mrow + ro < p.M && colp < p.N)) ? *reinterpret_cast<const unsigned*>(zb + (int64_t)ro * p.ldz) : 0u;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const unsigned O = (unsigned)__builtin_amdgcn_update_dpp(0, (int)P[q], 0xB1, 0xF, 0xF, false);   // lane ^ 1
-          // bf16 -> f32 is a 16-bit shift: low half = first column of the pair, high half = second
-          const float z0 = __builtin_bit_cast(float, odd ? (O & 0xffff0000u) : (P[q] << 16));
-          const float z1 = __builtin_bit_cast(float, odd ? (P[q] & 0xffff0000u) : (O << 16));
-          float a0 = acc[i][j][2 * q], a1 = acc[i][j][2 * q + 1];
-          a0 = (z0 * gsc[j] + gsh[j] > 0.f) ? a0 : 0.f;
-          a1 = (z1 * gsc[j] + gsh[j] > 0.f) ? a1 : 0.f;
-          acc[i][j][2 * q] = a0;
-          acc[i][j][2 * q + 1] = a1;
-          s1[j] += a0 + a1;
-          s2[j] += a0 * z0 + a1 * z1;
-        }
-      });
+          for (int q = 0; q < 8; q++) {
+            const unsigned O = (unsigned)__builtin_amdgcn_update_dpp(0, (int)P[q], 0xB1, 0xF, 0xF, false);   // lane ^ 1
+            // bf16 -> f32 is a 16-bit shift: low half = first column of the pair, high half = second
+            const float z0 = __builtin_bit_cast(float, odd ? (O & 0xffff0000u) : (P[q] << 16));
+            const float z1 = __builtin_bit_cast(float, odd ? (P[q] & 0xffff0000u) : (O << 16));
+            float a0 = acc[i][j][2 * q], a1 = acc[i][j][2 * q + 1];
+            a0 = (z0 * gsc + gsh > 0.f) ? a0 : 0.f;
+            a1 = (z1 * gsc + gsh > 0.f) ? a1 : 0.f;
+            acc[i][j][2 * q] = a0;
+            acc[i][j][2 * q + 1] = a1;
+            s1[j] += a0 + a1;
+            s2[j] += a0 * z0 + a1 * z1;
+          }
+        });
+      };
+      if (m0 + BM <= p.M && n0 + BN <= p.N) gated_stats(std::false_type{});
+      else gated_stats(std::true_type{});
     }
   } else if (p.col_stats) {
     if (m0 + BM <= p.M) {   // interior tile: no row guard
@@ -766,6 +770,7 @@ template <typename S> constexpr int dma_nstage() { return S::NSTAGE ? S::NSTAGE 
 // blocks per CU the kernel is compiled for (register budget): by tile size, or what a deep ring leaves room for in 160 KiB of LDS
 template <typename S> constexpr int dma_blocks_per_cu() {
   if constexpr (S::NSTAGE != 0) { constexpr int fit = 160 * 1024 / (S::NSTAGE * (S::BM + S::BN) * 64); return fit < 1 ? 1 : (fit > 4 ? 4 : fit); }
+  if constexpr (S::BWD) return 2;     // the gated-statistics epilogue needs a few registers more than 3 blocks per CU leave
   return S::NT == 512 ? 1 : (S::BM + S::BN > 256 ? 2 : (S::BM + S::BN <= 128 ? 4 : 3));
 }
 
@@ -1064,6 +1069,7 @@ using ShapeFat = Shape<2, 4, 2, 2>;    // 128 x 256, 4 waves of 64 x 128 (128 ac
 using ShapeTall = Shape<2, 2, 4, 1>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
 using ShapeWide = Shape<2, 2, 1, 4>;   //  64 x 256, 4 waves: weight gradients of those layers (M = Cout = 32 / 64)
 using ShapeDma64 = Shape<1, 1, 2, 2>;  //  64 x  64, 4 waves: small GEMMs (text tower, attention pooling), no BN statistics
+using ShapeMidBwd = Shape<2, 2, 2, 2, true, 0, true>;   // 128 x 128 data gradient that does the consumer BatchNorm's first backward pass
 // (8-deep rings for launches of <= 1-2 blocks per CU were tried: no gain standalone -- those launches are not bound by request
 // latency -- and 3 % slower in the step, where a 128 KiB block keeps the other streams' blocks off the CU.)
 
@@ -1465,6 +1471,18 @@ inline bool lean_epilogue_ok(const crog_gemm_desc& d) {
 
 template <typename T, bool HWTR>
 int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
+  if (d.bwd_z) {      // BatchNorm-backward statistics: one dedicated tile, the three data-gradient layouts
+    if constexpr (sizeof(T) == 2) {
+      if (dma_eligible(d) && lean_epilogue_ok(d)) {
+        if (d.a_layout == CROG_A_KC && d.b_layout == CROG_B_NC) return launch_dma<T, CROG_A_KC, CROG_B_NC, ShapeMidBwd>(d, s);
+        if (d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC) return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, ShapeMidBwd>(d, s);
+        if (d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_NC_DGRAD) return launch_dma<T, CROG_A_IM2COL, CROG_B_NC_DGRAD, ShapeMidBwd>(d, s);
+      }
+    }
+    crog_set_error("crog_gemm: bwd_z is implemented for bf16 data gradients (A_KC x B_NC, A_IM2COL x B_KC / B_NC_DGRAD) with a plain epilogue "
+                   "and operands the LDS-DMA path can address");
+    return CROG_ERR_ARG;
+  }
   const int shape = pick_shape(d);
   if (dma_eligible(d)) {
     // tile shape of the LDS-DMA kernel by padding waste: 64-wide sides for <= 64 columns / rows, 64 x 64 for small problems

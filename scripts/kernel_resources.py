@@ -22,10 +22,10 @@ for src in SOURCES:
         rows.append((src, name, g("vgpr_count"), m.group(1) if m else "?", g("sgpr_count"), g("group_segment_fixed_size"), g("private_segment_fixed_size"),
                      g("vgpr_spill_count"), g("sgpr_spill_count")))
 def short(n):
-    m = re.search(r"gemm_(dma_)?kernelI(DF16b|f)Li(\d)ELi(\d)E(Lb(\d)E)?NS_5ShapeILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)EEE(Li(\d)E)?", n)
+    m = re.search(r"gemm_(dma_)?kernelI(DF16b|f)Li(\d)ELi(\d)E(Lb(\d)E)?NS_5ShapeILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)E(?:Li(\d+)E)?EE(Li(\d)E)?", n)
     if m:
         return "gemm_%skernel<%s, A%s, B%s, %sShape<%s,%s,%s,%s%s>%s>" % (m.group(1) or "", "bf16" if m.group(2) == "DF16b" else "f32", m.group(3), m.group(4),
-            ("hwtr%s, " % m.group(6)) if m.group(6) else "", m.group(7), m.group(8), m.group(9), m.group(10), ",lean" if m.group(11) == "1" else "", (", asum%s" % m.group(13)) if m.group(13) else "")
+            ("hwtr%s, " % m.group(6)) if m.group(6) else "", m.group(7), m.group(8), m.group(9), m.group(10), ",lean" if m.group(11) == "1" else "", (", asum%s" % m.group(14)) if m.group(14) else "")
     m = re.search(r"_ZN12_GLOBAL__N_1\d+([a-zA-Z0-9_]+?)I", n)
     return m.group(1) if m else n[:80]
 out = ["| source | kernel | VGPR | AGPR | SGPR | static LDS B | scratch B | VGPR spills | SGPR spills |", "|---|---|---|---|---|---|---|---|---|"]
