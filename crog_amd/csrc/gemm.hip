@@ -1505,15 +1505,21 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
       }
     }
 #endif
-    // Large 3x3 forward / data-gradient launches (bf16, N a multiple of 256, >= 256 tiles of 256 x 256): the 8-wave 256 x 256 tile
+    // Large 3x3 forward / data-gradient launches (bf16, N a multiple of 256, >= 160 tiles of 256 x 256 — with 170 tiles the
+    // 21632 x 512 launches of the neck gain 25 % standalone, 135 -> 108 us, and the step 0.5 %; at 85 tiles the tile loses): the 8-wave 256 x 256 tile
     // halves the L2 -> LDS bytes per FLOP, which is what bounds the 128 x 128 tile (ablation: DMA-only 831 us vs MFMA-only 603 us of a
     // 1072 us launch).  Standalone +22-35 % on K = 4608 forwards (856 vs 691, 1031 vs 845 TFLOP/s), in the training step -1.5 %
     // (37.5 vs 38.2 ms, two interleaved A/B pairs); smaller launches lose to tile quantisation at one block per CU and stay on 128 x 128.
-    static int conv256 = -1;
-    if (conv256 < 0) { const char* e = getenv("CROG_GEMM_NO_CONV256"); conv256 = (e && e[0] == '1') ? 0 : 1; }
+    static int conv256 = -1, conv256_min = 160;
+    if (conv256 < 0) {
+      const char* e = getenv("CROG_GEMM_NO_CONV256");
+      const char* m = getenv("CROG_GEMM_CONV256_MIN");      // A/B: least number of 256 x 256 tiles for the wide tile
+      if (m) conv256_min = atoi(m);
+      conv256 = (e && e[0] == '1') ? 0 : 1;
+    }
     if constexpr (sizeof(T) == 2) {
       if (conv256 && alt && forced_shape() == 0 && lean_epilogue_ok(d) && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0 &&
-          (long)cdiv(d.M, 256) * (d.N / 256) >= 256)
+          (long)cdiv(d.M, 256) * (d.N / 256) >= conv256_min)
         return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, ShapeDma8>(d, s);
     }
     static int force = -1;   // CROG_GEMM_DMA_TILE = mid | tall | wide | 64 : A/B runs only (never with BN statistics on 64-row tiles)
