@@ -1522,7 +1522,7 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
           (long)cdiv(d.M, 256) * (d.N / 256) >= conv256_min)
         return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, ShapeDma8>(d, s);
       // (the same tile for 1x1 / linear forwards and data gradients, K = 128 ... 2048: no gain standalone — their reductions are too
-      // short to amortise the 128 KiB ring's fill — and +0.4 ms in the step; scripts/bench_lin256.py)
+      // short to amortise the 128 KiB ring's fill — and +0.4 ms in the step)
     }
     static int force = -1;   // CROG_GEMM_DMA_TILE = mid | tall | wide | 64 : A/B runs only (never with BN statistics on 64-row tiles)
     if (force < 0) {
