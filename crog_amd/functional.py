@@ -46,6 +46,7 @@ FLASH_MIN_KEYS = 64
 BN_ATOMIC_STATS = _os.environ.get("CROG_BN_ATOMIC_STATS", "1") != "0"   # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize
 RELU_BITMASK = _os.environ.get("CROG_RELU_BITMASK", "1") != "0"   # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
 LN_BWD_ATOMIC = _os.environ.get("CROG_LN_BWD_ATOMIC", "0") == "1"   # LayerNorm parameter gradients through atomics in ln_bwd itself: measured 0.5 % SLOWER (every block adds into the same 2 C floats), kept for A/B
+LN_REDUCE_SIDE = _os.environ.get("CROG_LN_REDUCE_SIDE", "1") != "0"   # LayerNorm parameter-gradient reduction on the weight-gradient stream
 BN_BWD_ATOMIC = _os.environ.get("CROG_BN_BWD_ATOMIC", "1") != "0"   # backward partial sums through coalesced atomics (bf16, no SyncBN)
 DGRAD_T = _os.environ.get("CROG_DGRAD_T", "1") != "0"          # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
 FUSED_HEAD = _os.environ.get("CROG_FUSED_HEAD", "1") != "0"    # fold vis.4 into the dynamic head (no groups*C-channel map)
@@ -614,7 +615,12 @@ class LayerNormFn(Function):
         else:
             partial = torch.empty(nb, C, 2, device=x.device, dtype=torch.float32)
             K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, partial, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out)
-            K.reduce_split(partial, nb, C, None, gamma.grad(), beta.grad())
+            # the parameter gradients are consumed by the optimizer only: their reduction leaves the dependency chain for the
+            # weight-gradient stream (41 small launches per CROG step that sat between dependent kernels of the main stream)
+            if LN_REDUCE_SIDE:
+                RT.on_wgrad_stream(lambda: K.reduce_split(partial, nb, C, None, gamma.grad(), beta.grad()), partial)
+            else:
+                K.reduce_split(partial, nb, C, None, gamma.grad(), beta.grad())
         gamma.done()
         beta.done()
         dres = None
