@@ -169,7 +169,7 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
                  None if col_stats is None else col_stats.data_ptr(), stat_replicas,
                  None if a_sum is None else a_sum.data_ptr() + 4 * a_sum_off,
                  None if bwd_z is None else bwd_z.data_ptr(), 0 if bwd_z is None else mat(bwd_z)[2], None if bwd_ss is None else bwd_ss.data_ptr())
-    if PROF is not None and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
+    if PROF is not None and PROF.get("on", True) and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
         # timers go on the stream the kernel is actually launched on (the weight-gradient side stream while it is overridden)
         raw = stream()
         e0, e1 = Timer(), Timer()
