@@ -1223,7 +1223,12 @@ __global__ void __launch_bounds__(S::NT, dma_blocks_per_cu<S>()) gemm_dma_kernel
 #endif
       stage = nstage;
     }
-    wait_vmcnt<0>();     // the trailing out-of-range requests write zeros into the ring: they must land before the epilogue reuses it
+    // The trailing out-of-range requests write zeros into the ring, and the epilogue reuses the ring (statistics exchange, staged
+    // stores): EVERY wave's requests must have landed before ANY wave writes there — its own wait is not enough (a slower wave's
+    // zeros landed on a faster wave's column sums: BatchNorm statistics, and with them the whole forward, differed from run to run
+    // by ~2 % of the layer-2 output until this barrier was added).
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
   } else {
 #pragma unroll
   for (int s = 0; s < DMA_NSTAGE - 1; s++)

@@ -312,7 +312,8 @@ class ConvBnAct(Function):
         ctx.x_needs = ksize != "s" and x.requires_grad
         if stat_out is not None:
             # publish what the NEXT layer's data-gradient epilogue needs to do this layer's first backward pass (BnLink)
-            ok = (BN_BWD_FUSED and BN_BWD_ATOMIC and training and dtype == torch.bfloat16 and res is None and ksize != 0 and torch.is_grad_enabled()
+            # (no torch.is_grad_enabled() here: it is always False inside Function.forward)
+            ok = (BN_BWD_FUSED and BN_BWD_ATOMIC and training and dtype == torch.bfloat16 and res is None and ksize != 0
                   and M <= BN_BWD_FUSED_MAX_ROWS)
             stat_out.z, stat_out.ss, stat_out.C, stat_out.M, stat_out.sums = (z if ok else None), (ss if relu else None), C, M, None
         ctx.wt = (wt, wbuf_off) if wpad is not None else None
