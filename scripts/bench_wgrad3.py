@@ -1,4 +1,4 @@
-"""The step's large 3x3 weight gradients, HBM-cold (operand sets rotated past the Infinity Cache).  Env: CROG_WGRAD_CONV256, CROG_WGRAD_TARGET256."""
+"""The step's large 3x3 weight gradients, HBM-cold (operand sets rotated past the Infinity Cache).  Env: CROG_WGRAD_TARGET_CONV (blocks per launch the split count aims at)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
