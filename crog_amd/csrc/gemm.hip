@@ -1449,9 +1449,11 @@ int pick_shape(const crog_gemm_desc& d) {
 // through L2 for 44 MB of operands).  Launched ALONE, 64 x 64 tiles win (4x the blocks of 128 x 128 at the same atomic bytes:
 // 8-36 % faster, scripts/bench_wgrad2.py) -- but inside the training step the weight gradients run on a side stream next to the
 // main stream's kernels, the chip is full anyway, and what counts is the work per launch: 128 x 128 tiles at ~256 blocks (half
-// the L2 bytes, a third of the splits) make the step 2 % faster (33.97 vs 34.65 ms, two interleaved A/B pairs).  The 3x3 form keeps
+// the L2 bytes, a third of the splits) make the step 2 % faster (33.97 vs 34.65 ms, two interleaved A/B pairs).  Outputs above 1 M
+// elements (transformer FFN / ViT weights: many tiles already) aim at 512 blocks: CROG-R50 does not care, the ViT-B/16 tower, whose
+// main stream leaves more of the chip free, loses 12 % with 256 (17.3 vs 15.4 ms per forward + backward).  The 3x3 form keeps
 // 64 x 64 for outputs up to 128 x 1152 (Cout <= 128: 128-wide tiles would be mostly padding) and targets 512 blocks otherwise.
-// CROG_WGRAD_TILE / CROG_WGRAD_TARGET / CROG_WGRAD_TARGET128 / CROG_WGRAD_TARGET_CONV override the policy for A/B runs.
+// CROG_WGRAD_TILE / CROG_WGRAD_TARGET / CROG_WGRAD_TARGET128 / CROG_WGRAD_TARGET_BIG / CROG_WGRAD_TARGET_CONV override the policy for A/B runs.
 inline bool alt_tiles_enabled() {
   static int alt = -1;
   if (alt < 0) { const char* e = getenv("CROG_GEMM_NO_ALT_TILES"); alt = (e && e[0] == '1') ? 0 : 1; }
@@ -1582,9 +1584,11 @@ extern "C" int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int 
     const long target = b_layout == CROG_B_NC_IM2COL ? 2048 : t1;
     s = std::min(std::max(1L, target / tiles), std::max(1L, ktiles / 16));
   } else {
-    static const long t2 = wgrad_env("CROG_WGRAD_TARGET128", 256), t3 = wgrad_env("CROG_WGRAD_TARGET_CONV", 512);
+    static const long t2 = wgrad_env("CROG_WGRAD_TARGET128", 256), t3 = wgrad_env("CROG_WGRAD_TARGET_CONV", 512),
+                      t4 = wgrad_env("CROG_WGRAD_TARGET_BIG", 512);
     const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-    s = std::min(std::max(1L, (b_layout == CROG_B_NC_IM2COL ? t3 : t2) / tiles), std::max(1L, ktiles / 24));
+    const long target = b_layout == CROG_B_NC_IM2COL ? t3 : ((long)M * N <= (1L << 20) ? t2 : t4);      // BIG: outputs above 1 M elements
+    s = std::min(std::max(1L, target / tiles), std::max(1L, ktiles / 24));
   }
   return (int)std::max(1L, std::min(s, 1024L));
 }
