@@ -52,16 +52,21 @@ class Bottleneck(Bound):
 
     def forward(self, x):
         tr = self.training
-        out = Fn.conv_bn_act(x, self.conv1.w, self.bn1.buffers_ref(), ksize=1, relu=True, training=tr)
+        # bn1 -> conv2 (when conv2 reads bn1's output itself, i.e. stride 1) and bn2 -> conv3: the consuming convolution's data
+        # gradient does the first pass of the BatchNorm backward in its epilogue (Fn.BnLink)
+        l1 = Fn.BnLink() if (tr and self.stride == 1) else None
+        l2 = Fn.BnLink() if tr else None
+        out = Fn.conv_bn_act(x, self.conv1.w, self.bn1.buffers_ref(), ksize=1, relu=True, training=tr, stat_out=l1)
         if self.stride == 1:
-            out = Fn.conv_bn_act(out, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr)
+            out = Fn.conv_bn_act(out, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=l1, stat_out=l2)
         else:
-            out = Fn.conv_bn_act(Fn.im2col(out, 3, 3, self.stride, 1), self.conv2.w, self.bn2.buffers_ref(), ksize=1, relu=True, training=tr)
+            out = Fn.conv_bn_act(Fn.im2col(out, 3, 3, self.stride, 1), self.conv2.w, self.bn2.buffers_ref(), ksize=1, relu=True, training=tr,
+                                 stat_out=l2)
         identity = x
         if self.downsample is not None:
             xin = x if self.stride == 1 else Fn.im2col(x, 1, 1, self.stride, 0)
             identity = Fn.conv_bn_act(xin, self.downsample["0"].w, self.downsample["1"].buffers_ref(), ksize=1, relu=False, training=tr)
-        return Fn.conv_bn_act(out, self.conv3.w, self.bn3.buffers_ref(), ksize=1, relu=True, res=identity, training=tr)
+        return Fn.conv_bn_act(out, self.conv3.w, self.bn3.buffers_ref(), ksize=1, relu=True, res=identity, training=tr, stat_in=l2)
 
 
 class ResNet(Bound):
