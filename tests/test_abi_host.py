@@ -40,14 +40,24 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_gemm_desc_layout_matches_c_struct(tmp_path):
+    """Every field of crog_gemm_desc: same order, same offset, same total size in the C header and in the ctypes mirror."""
+    D = _lib.GemmDesc
+    names = [f[0] for f in D._fields_]
+    header = open(os.path.join(ROOT, "include", "crog_hip.h")).read()
+    body = re.search(r"typedef struct crog_gemm_desc \{(.*?)\} crog_gemm_desc;", header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", " ", body, flags=re.S)
+    c_names = []
+    for decl in body.split(";"):          # "int M, N, K" declares three fields
+        if decl.strip():
+            c_names += [re.split(r"[\s\*]+", part.strip())[-1] for part in decl.split(",")]
+    assert c_names == names, (c_names, names)
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "crog_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(crog_gemm_desc),'
-                   ' offsetof(crog_gemm_desc, lda), offsetof(crog_gemm_desc, splitk), offsetof(crog_gemm_desc, bias), offsetof(crog_gemm_desc, col_stats));return 0;}')
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "crog_hip.h"\nint main(){printf("%zu", sizeof(crog_gemm_desc));'
+                   + "".join('printf(" %%zu", offsetof(crog_gemm_desc, %s));' % n for n in names) + 'printf("\\n");return 0;}')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
-    out = subprocess.check_output([str(exe)]).split()
-    D = _lib.GemmDesc
-    assert [int(x) for x in out] == [ctypes.sizeof(D), D.lda.offset, D.splitk.offset, D.bias.offset, D.col_stats.offset]
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out == [ctypes.sizeof(D)] + [getattr(D, n).offset for n in names]
 
 
 def test_argument_validation_needs_no_device(lib):
