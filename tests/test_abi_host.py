@@ -68,6 +68,14 @@ def test_argument_validation_needs_no_device(lib):
     assert b"crog_gemm" in lib.crog_last_error()
     d.dtype = 7
     assert lib.crog_gemm(ctypes.byref(d), None) == -1 and b"dtype" in lib.crog_last_error()
+    # BatchNorm-backward statistics mode: needs the atomic replica form of col_stats (checked before any launch)
+    buf = (ctypes.c_char * 4096)()
+    addr = (ctypes.addressof(buf) + 15) // 16 * 16
+    e = _lib.GemmDesc(dtype=1, a_layout=0, b_layout=1, A=addr, B=addr, C=addr, M=8, N=8, K=8, lda=8, ldb=8, ldc=8, batch=1, batch_inner=1,
+                      splitk=1, alpha=1.0, bwd_z=addr, ldz=8)
+    assert lib.crog_gemm(ctypes.byref(e), None) == -1 and b"bwd_z" in lib.crog_last_error()
+    t = ctypes.c_void_p()
+    assert lib.crog_timer_record(None, None) == -1 and lib.crog_timer_elapsed_ms(None, None, None) == -1 and lib.crog_timer_create(None) == -1
     assert lib.crog_gemm_stat_tiles(129) == 2
     assert lib.crog_adam_step(None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 0.0, 0, None, None) == -1  # step must be >= 1
 
