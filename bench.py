@@ -162,6 +162,71 @@ def measured_peaks(dev):
     return out
 
 
+def _spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes, one per GPU (train_crog.py:67-78 spawns its
+    per-GPU workers the same way), BEFORE this process has made any GPU call - a process that initialised the GPU must never be
+    replaced or forked.  Rank 0's JSON line goes straight to our stdout; the exit code is the worst child's."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.dry:
+        have = torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is None:
+                    continue
+                pending.remove(p)
+                if r != 0:
+                    rc = rc or r
+                    for q in pending:            # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def _dry_rank(args, world, rank):
+    """--dry: the launcher / rendezvous / timing protocol only (gloo, CPU tensors, no model, no GPU): what `tests/test_bench_launch.py`
+    runs in the build container."""
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    x = torch.ones(4)
+    for _ in range(args.steps):
+        dist.all_reduce(x)
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ranks = torch.zeros(world, dtype=torch.int64)
+    ranks[rank] = 1
+    dist.all_reduce(ranks)
+    if rank == 0:
+        print(json.dumps({"metric": "training images/sec CROG-R50 416x416 bs32/GPU", "value": None, "unit": "images/sec", "dry": True,
+                          "n_gpus": world, "ranks_seen": int(ranks.sum()), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(tmax) / max(args.steps, 1) * 1e3, 3), "scaling": "weak",
+                          "config": {"workload": "launcher dry run (gloo, no model)", "global_batch": args.batch * world,
+                                     "parallelism": f"dp{world}"}}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,14 +239,29 @@ def main():
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--roofline-kernel", default="conv3x3_fwd", choices=["conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "lin_fwd", "none"])
+    ap.add_argument("--dry", action="store_true", help="launcher / rendezvous check only: gloo on CPU tensors, no model, no GPU")
+    ap.add_argument("--eager", action="store_true", help="issue every step from Python instead of replaying the captured whole-step hipGraph")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.cpu_baseline_worker, args.cpu_threads)
-        return
+        return 0
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return _spawn_ranks(args)            # no launcher: become one (the children come back here with WORLD_SIZE set)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    if args.dry:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        _dry_rank(args, world, rank)
+        return 0
+    if torch.cuda.device_count() < (world if world > 1 else 1):
+        print(f"bench.py: {world} rank(s) but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        return 2
     force_ddp = os.environ.get("CROG_FORCE_DDP") == "1"   # exercise the RCCL path on a single GPU (smoke test of the N > 1 code)
     if world > 1 or force_ddp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -305,4 +385,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
