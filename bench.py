@@ -140,14 +140,19 @@ def measured_peaks(dev):
     dst = torch.empty_like(src)
     s = torch.cuda.current_stream().cuda_stream
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    for _ in range(2):
-        K.check(lib.crog_probe_copy(src.data_ptr(), dst.data_ptr(), n, s), "probe_copy")
-    ev[0].record()
-    for _ in range(10):
-        K.check(lib.crog_probe_copy(src.data_ptr(), dst.data_ptr(), n, s), "probe_copy")
-    ev[1].record()
-    torch.cuda.synchronize()
-    out["hbm_copy_GBps"] = round(10 * 2 * n / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, 1)
+    rates = {}
+    for mode in range(6):          # V = 1/2/4 vectors per lane, non-temporal (0-2) or plain (3-5) loads/stores: report the best shape
+        for _ in range(2):
+            K.check(lib.crog_probe_copy(src.data_ptr(), dst.data_ptr(), n, mode, s), "probe_copy")
+        ev[0].record()
+        for _ in range(10):
+            K.check(lib.crog_probe_copy(src.data_ptr(), dst.data_ptr(), n, mode, s), "probe_copy")
+        ev[1].record()
+        torch.cuda.synchronize()
+        rates[mode] = round(10 * 2 * n / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, 1)
+    best = max(rates, key=rates.get)
+    out["hbm_copy_GBps"] = rates[best]
+    out["hbm_copy_modes_GBps"] = rates
     del src, dst
     blocks, iters = 256 * 2, 4000
     sink = torch.zeros(blocks * 256, device=dev)
@@ -157,7 +162,7 @@ def measured_peaks(dev):
     ev[1].record()
     torch.cuda.synchronize()
     out["mfma_bf16_TFLOPs"] = round(blocks * 4 * iters * 8 * 32768 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12, 1)
-    out["note"] = ("crog_probe_copy: 1 GiB device-to-device copy, read + write bytes / time; crog_probe_mfma_bf16: 2 blocks x 4 waves per CU issuing "
+    out["note"] = ("crog_probe_copy: 1 GiB device-to-device copy, one block per 256*V consecutive 16-byte vectors (no grid-stride loop), read + write bytes / time, best of six shapes; crog_probe_mfma_bf16: 2 blocks x 4 waves per CU issuing "
                    "independent v_mfma_f32_32x32x16_bf16 from registers (no memory traffic): what the chip sustains at the clock it holds")
     return out
 
@@ -307,24 +312,43 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
+    # Default: the step is captured once into a hipGraph (crog_amd/graphs.py) after 3 eager steps and replayed - one host call per step
+    # instead of ~1300 launches through Python.  --eager (or CROG_STEP_GRAPH=0) issues every step from Python as rounds 1-2 did.
+    graphed = None
+    if not args.eager and os.environ.get("CROG_STEP_GRAPH", "1") != "0":
+        from crog_amd.graphs import GraphedTrainStep
+        graphed = GraphedTrainStep(net, opt, cfg, adt, warmup=3)
+
+    def step(eager=False):
+        if graphed is not None:
+            return graphed(batch, eager=eager)
+        return train_step(net, opt, None, batch, cfg, autocast_dtype=adt)
+
     for _ in range(args.warmup):
-        stats, _ = train_step(net, opt, None, batch, cfg, autocast_dtype=adt)
+        stats, _ = step()
+    while graphed is not None and graphed.graph is None and graphed.failed is None:
+        stats, _ = step()          # --warmup < 4: the capture still happens before the timed region
     sync()
     key = {"conv3x3_fwd": (K.A_IM2COL, K.B_KC), "conv3x3_dgrad": (K.A_IM2COL, K.B_NC_DGRAD), "conv3x3_wgrad": (K.A_MC, K.B_NC_IM2COL),
            "lin_fwd": (K.A_KC, K.B_KC), "none": None}[args.roofline_kernel]
     if key is not None and rank == 0:
-        K.PROF = dict(key=key, records=[])
+        K.PROF = dict(key=key, records=[], on=False)
+    replaying = graphed is not None and graphed.graph is not None
     coll0 = (RT.comm.calls if RT.comm is not None else 0, net.reducer.launches if (world > 1 or force_ddp) else 0)
     t0 = time.perf_counter()
-    # the per-launch timers of the roofline leg bracket every PROF_EVERY-th timed step (106 event records per bracketed step cost
-    # the step ~0.3 ms: sampling keeps the measurement inside the timed region without taxing `value`)
+    # The per-launch timers of the roofline leg need real launches (an event cannot be read back out of a graph replay): every
+    # PROF_EVERY-th timed step is issued eagerly with a timer pair around each launch of the roofline kernel (same kernels, same
+    # streams, same seeds as a replay; 106 event records).  Eager mode: every 5th step is bracketed (~0.3 ms each).  Graph mode: an
+    # eager step costs a few ms more than a replay, so only steps K/3 and 2K/3 are - the measurement stays inside the timed region.
     PROF_EVERY = 5
+    prof_steps = {i for i in range(args.steps) if i % PROF_EVERY == 0} if not replaying else {args.steps // 3, (2 * args.steps) // 3}
     sampled = 0
     for i in range(args.steps):
+        prof = K.PROF is not None and i in prof_steps
         if K.PROF is not None:
-            K.PROF["on"] = (i % PROF_EVERY == 0)
-            sampled += i % PROF_EVERY == 0
-        stats, _ = train_step(net, opt, None, batch, cfg, autocast_dtype=adt)
+            K.PROF["on"] = prof
+            sampled += prof
+        stats, _ = step(eager=prof and replaying)
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -367,9 +391,16 @@ def main():
             "roofline": roof,
             "last_step": {"loss": round(last[0], 4), "iou": round(last[1], 3), "prec50": round(last[2], 3)},
         }
+        out["step_issue"] = ({"mode": "hipgraph", "replays": graphed.replays, "eager_steps_in_timed_region": sampled}
+                             if replaying else {"mode": "eager", "graph_capture_failed": getattr(graphed, "failed", None)})
         if world > 1 or force_ddp:
-            out["collectives_per_step"] = {"syncbn_allreduce": (RT.comm.calls - coll0[0]) // args.steps if RT.comm is not None else 0,
-                                           "gradient_buckets": (net.reducer.launches - coll0[1]) // args.steps,
+            per_step = (lambda now, then: (now - then) // args.steps)
+            sb = per_step(RT.comm.calls, coll0[0]) if RT.comm is not None else 0
+            gb = per_step(net.reducer.launches, coll0[1])
+            if replaying:      # the Python counters only move in eager steps: a replay re-issues what the capture recorded
+                sb, gb = graphed.collectives["syncbn"], graphed.collectives["buckets"]
+            out["collectives_per_step"] = {"syncbn_allreduce": sb,
+                                           "gradient_buckets": gb,
                                            "note": "BatchNorm statistics on a communicator of their own (crog_amd/parallel.py); metric all-reduce not counted"}
         if world == 1:
             try:

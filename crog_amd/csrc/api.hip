@@ -44,15 +44,30 @@ __global__ void __launch_bounds__(256) mfma_probe_kernel(float* __restrict__ sin
     for (int e = 0; e < 16; e++) s += acc[q][e];
   if (s == 12345.678f) sink[blockIdx.x * 256 + threadIdx.x] = s;   // never true for these operands; keeps the chain alive
 }
-// streaming copy, 16 bytes per lane, grid-stride: bytes moved = 2 * n16 * 16
+// streaming copy, 16 bytes per lane.  V vectors per lane, a block owns 256 * V consecutive vectors (lane-contiguous within each of
+// its V sub-rows), no grid-stride loop: the whole copy is in flight as independent wave-wide 1-KiB requests and the workgroup
+// dispatcher, not a loop, walks the buffer (MI355X_MICROARCH.md: 6.29 TB/s for this shape; the 4096-block grid-stride form it
+// replaces read 4.2-4.6 TB/s).  NT: non-temporal stores (the destination is not re-read: keep it out of L2 / Infinity Cache).
+template <int V, bool NT>
 __global__ void __launch_bounds__(256) copy_probe_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n16) {
-  const long stride = (long)gridDim.x * 256;
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {      // four independent 16-byte loads in flight per lane
-    const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  const long base = (long)blockIdx.x * (256 * V) + threadIdx.x;
+  f32x4 r[V];
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    const long i = base + k * 256;
+    if (i < n16) r[k] = NT ? __builtin_nontemporal_load(src + i) : src[i];
   }
-  for (; i < n16; i += stride) dst[i] = src[i];
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    const long i = base + k * 256;
+    if (i < n16) {
+      if (NT) __builtin_nontemporal_store(r[k], dst + i);
+      else dst[i] = r[k];
+    }
+  }
+}
+__global__ void counter_add_kernel(uint64_t* __restrict__ c, uint64_t inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc;
 }
 }  // namespace
 
@@ -62,9 +77,36 @@ extern "C" int crog_probe_mfma_bf16(float* sink, int blocks, int iters, crog_str
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
-extern "C" int crog_probe_copy(const void* src, void* dst, int64_t bytes, crog_stream_t stream) {
+extern "C" int crog_probe_copy(const void* src, void* dst, int64_t bytes, int mode, crog_stream_t stream) {
   CROG_CHECK_ARG(src && dst && bytes > 0 && bytes % 16 == 0, "probe_copy: bytes must be a positive multiple of 16");
-  hipLaunchKernelGGL(copy_probe_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, (long)(bytes / 16));
+  CROG_CHECK_ARG(mode >= 0 && mode <= 5, "probe_copy: mode 0..5");
+  const long n16 = bytes / 16;
+#define CROG_COPY(V, NT) hipLaunchKernelGGL((copy_probe_kernel<V, NT>), dim3(cdiv(n16, 256 * V)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, n16)
+  switch (mode) {
+    case 0: CROG_COPY(1, true); break;
+    case 1: CROG_COPY(2, true); break;
+    case 2: CROG_COPY(4, true); break;
+    case 3: CROG_COPY(1, false); break;
+    case 4: CROG_COPY(2, false); break;
+    default: CROG_COPY(4, false); break;
+  }
+#undef CROG_COPY
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+// ---- per-step launch state that lives in DEVICE memory, so that a captured hipGraph of the whole training step replays with fresh
+// values (crog_amd/graphs.py): the dropout seed offset and (eltwise.hip) Adam's step count / learning rates -----------------------
+static const uint64_t* g_seed_epoch = nullptr;
+const uint64_t* crog_seed_epoch() { return g_seed_epoch; }
+
+extern "C" int crog_set_seed_epoch(const uint64_t* epoch_dev) {
+  g_seed_epoch = epoch_dev;
+  return CROG_OK;
+}
+extern "C" int crog_counter_add(uint64_t* counter_dev, uint64_t inc, crog_stream_t stream) {
+  CROG_CHECK_ARG(counter_dev != nullptr, "counter_add: null counter");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter_dev, inc);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -31,6 +31,7 @@ struct AttnArgs {
   int Lq, Lk, heads, ldp;
   float scale, p_drop;
   uint64_t seed;
+  const uint64_t* epoch;   // crog_set_seed_epoch: per-step seed offset in device memory (null = none)
 };
 
 // ---- LDS images of a [32][64] bf16 tile (128-byte rows) -------------------------------------------------------------
@@ -71,6 +72,7 @@ __device__ inline float xor32(float v) { return __shfl_xor(v, 32, 64); }
 // forward: O = softmax(scale Q K^T) [dropout] V, lse = row log-sum-exp.  grid (ceil(Lq / 128), B * heads)
 // =====================================================================================================================
 __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
+  const uint64_t seed = a.seed + (a.epoch ? *a.epoch : 0ull);
   __shared__ __attribute__((aligned(16))) bf16 sK[2][TILE];
   __shared__ __attribute__((aligned(16))) bf16 sV[2][TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ln = lane & 31;
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
     for (int e = 0; e < 16; e++) { o[0][e] *= alpha; o[1][e] *= alpha; }
     if (a.p_drop > 0.f) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) s[r] = dropout_keep(a.seed, rowbase + kb + acc_row(r, h), thr) ? s[r] * sc : 0.f;
+      for (int r = 0; r < 16; r++) s[r] = dropout_keep(seed, rowbase + kb + acc_row(r, h), thr) ? s[r] * sc : 0.f;
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -171,6 +173,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
 // backward 1: D = rowsum(dO * O);  dQ = scale * dS K  with dS = P * (dropout'(dO V^T) - D).  Same blocking as the forward.
 // =====================================================================================================================
 __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a) {
+  const uint64_t seed = a.seed + (a.epoch ? *a.epoch : 0ull);
   __shared__ __attribute__((aligned(16))) bf16 sKc[2][TILE];
   __shared__ __attribute__((aligned(16))) bf16 sKt[2][TILE];
   __shared__ __attribute__((aligned(16))) bf16 sVc[2][TILE];
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
     }
     if (a.p_drop > 0.f) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) dp[r] = dropout_keep(a.seed, rowbase + kb + acc_row(r, h), thr) ? dp[r] * sc : 0.f;
+      for (int r = 0; r < 16; r++) dp[r] = dropout_keep(seed, rowbase + kb + acc_row(r, h), thr) ? dp[r] * sc : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) s[r] = s[r] * (dp[r] - Dq) * a.scale;
@@ -275,6 +278,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
 // grid (ceil(Lk / 128), B * heads).  Needs lse (forward) and D (flash_bwd_dq_kernel).
 // =====================================================================================================================
 __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs a) {
+  const uint64_t seed = a.seed + (a.epoch ? *a.epoch : 0ull);
   __shared__ __attribute__((aligned(16))) bf16 sQc[2][TILE];
   __shared__ __attribute__((aligned(16))) bf16 sQt[2][TILE];
   __shared__ __attribute__((aligned(16))) bf16 sOc[2][TILE];
@@ -348,7 +352,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
       const float p = (qb + qr < a.Lq) ? __expf(s[r] * a.scale - sL[buf][qr]) : 0.f;
       float g = dp[r], pk = p;
       if (a.p_drop > 0.f) {
-        const bool keep = dropout_keep(a.seed, ((uint64_t)bh * a.Lq + qb + qr) * a.ldp + key, thr);
+        const bool keep = dropout_keep(seed, ((uint64_t)bh * a.Lq + qb + qr) * a.ldp + key, thr);
         g = keep ? g * sc : 0.f;
         pk = keep ? p * sc : 0.f;
       }
@@ -402,7 +406,7 @@ extern "C" int crog_flash_attn_fwd(const void* Q, int64_t ldq, const void* K, in
   AttnArgs a{};
   a.Q = (const bf16*)Q; a.K = (const bf16*)K; a.V = (const bf16*)V; a.Out = (bf16*)O; a.lse = lse;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
-  a.Lq = Lq; a.Lk = Lk; a.heads = heads; a.ldp = ldp; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+  a.Lq = Lq; a.Lk = Lk; a.heads = heads; a.ldp = ldp; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.epoch = crog_seed_epoch();
   hipLaunchKernelGGL(flash_fwd_kernel, dim3(cdiv(Lq, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
@@ -421,7 +425,7 @@ extern "C" int crog_flash_attn_bwd(const void* Q, int64_t ldq, const void* K, in
   a.Q = (const bf16*)Q; a.K = (const bf16*)K; a.V = (const bf16*)V; a.O = (const bf16*)O; a.dO = (const bf16*)dO;
   a.dQ = (bf16*)dQ; a.dK = (bf16*)dK; a.dV = (bf16*)dV; a.lse = const_cast<float*>(lse); a.D = D;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-  a.Lq = Lq; a.Lk = Lk; a.heads = heads; a.ldp = ldp; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+  a.Lq = Lq; a.Lk = Lk; a.heads = heads; a.ldp = ldp; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.epoch = crog_seed_epoch();
   hipLaunchKernelGGL(flash_bwd_dq_kernel, dim3(cdiv(Lq, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
   hipLaunchKernelGGL(flash_bwd_dkdv_kernel, dim3(cdiv(Lk, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);

@@ -33,6 +33,9 @@ void crog_set_error(const char* fmt, ...);
     }                                                                   \
   } while (0)
 
+// per-step dropout seed offset in device memory (crog_set_seed_epoch, api.hip); null when none is installed
+const uint64_t* crog_seed_epoch();
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- element traits ----------------------------------------------------------------------

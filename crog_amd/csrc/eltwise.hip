@@ -301,8 +301,9 @@ __global__ void __launch_bounds__(NT) sum_over_batch_kernel(const T* __restrict_
 // ---- out = a + dropout(b)  /  db = dropout_bwd(dout)   (layers.py:326,334,338) ------------------------
 template <typename T>
 __global__ void __launch_bounds__(NT) add_dropout_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, T* __restrict__ out,
-                                                         long ldo, long M, int C, float p, uint64_t seed) {
+                                                         long ldo, long M, int C, float p, uint64_t seed, const uint64_t* __restrict__ epoch) {
   constexpr int VEC = Elem<T>::VEC;
+  if (epoch) seed += *epoch;                 // crog_set_seed_epoch: per-step offset from device memory
   const int cvec = C / VEC;
   const uint32_t thr = (uint32_t)(p * 4294967296.0);
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
@@ -578,7 +579,12 @@ __global__ void __launch_bounds__(NT) coord_fill_kernel(T* __restrict__ buf, lon
 // ---- fused Adam (torch.optim.Adam semantics, train_crog.py:119-121) + optional bf16 shadow copy ---------------
 __global__ void __launch_bounds__(NT) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                   long n, float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
-                                                  float bc2_sqrt, bf16* __restrict__ shadow) {
+                                                  float bc2_sqrt, bf16* __restrict__ shadow, const float* __restrict__ hyper) {
+  if (hyper) {           // crog_adam_step_dev: learning rate and bias corrections of THIS step from device memory (graph replays)
+    lr = hyper[0];
+    bc1 = hyper[1];
+    bc2_sqrt = hyper[2];
+  }
   const float step_size = lr / bc1;
   GRID_STRIDE(i, (n + 3) / 4) {
     const long o = i * 4;
@@ -765,7 +771,7 @@ extern "C" int crog_add_dropout(int dtype, const void* a, int64_t lda, const voi
                                 uint64_t seed, crog_stream_t s) {
   const int vec = VECOF(dtype);
   CROG_CHECK_ARG(C % vec == 0 && ldb % vec == 0 && ldo % vec == 0 && p >= 0.f && p < 1.f, "add_dropout: bad args");
-  DISPATCH_T(dtype, LAUNCH((add_dropout_kernel<T>), M * (C / vec), s, (const T*)a, (long)lda, (const T*)b, (long)ldb, (T*)out, (long)ldo, (long)M, C, p, seed));
+  DISPATCH_T(dtype, LAUNCH((add_dropout_kernel<T>), M * (C / vec), s, (const T*)a, (long)lda, (const T*)b, (long)ldb, (T*)out, (long)ldo, (long)M, C, p, seed, crog_seed_epoch()));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
@@ -860,9 +866,40 @@ extern "C" int crog_adam_step(float* p, const float* g, float* m, float* v, int6
   CROG_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
                  "adam: buffers must be 16-byte aligned");
   if (n == 0) return CROG_OK;
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-  LAUNCH(adam_kernel, (n + 3) / 4, s, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, (bf16*)bf16_shadow);
+  // bias corrections in double, rounded once: the device-side form (adam_advance_kernel) computes the same expression
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  LAUNCH(adam_kernel, (n + 3) / 4, s, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, (bf16*)bf16_shadow,
+         (const float*)nullptr);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+namespace {
+// hyper = {lr, 1 - beta1^t, sqrt(1 - beta2^t), t}: t += 1 and the corrections of the new t
+__global__ void adam_advance_kernel(float* __restrict__ hyper, float beta1, float beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double t = (double)hyper[3] + 1.0;
+  hyper[3] = (float)t;
+  hyper[1] = (float)(1.0 - pow((double)beta1, t));
+  hyper[2] = (float)sqrt(1.0 - pow((double)beta2, t));
+}
+}  // namespace
+
+extern "C" int crog_adam_advance(float* hyper_dev, float beta1, float beta2, crog_stream_t s) {
+  CROG_CHECK_ARG(hyper_dev != nullptr && ((uintptr_t)hyper_dev % 16) == 0, "adam_advance: hyper must be a 16-byte aligned device float[4]");
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, hyper_dev, beta1, beta2);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, float beta1, float beta2,
+                                  float eps, float weight_decay, void* bf16_shadow, crog_stream_t s) {
+  CROG_CHECK_ARG(hyper_dev != nullptr && n >= 0, "adam_step_dev: hyper (device float[4]: lr, bc1, bc2_sqrt, t) is required");
+  CROG_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+                 "adam: buffers must be 16-byte aligned");
+  if (n == 0) return CROG_OK;
+  LAUNCH(adam_kernel, (n + 3) / 4, s, p, g, m, v, (long)n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, (bf16*)bf16_shadow, hyper_dev);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -494,8 +494,10 @@ __global__ void __launch_bounds__(NT) ln_fwd_kernel(const T* __restrict__ x, lon
                                                     const float* __restrict__ beta, float eps, long M, int C, T* __restrict__ out,
                                                     long ldo, float* __restrict__ stats, const T* __restrict__ res, long ldr,
                                                     T* __restrict__ out2, long ldo2, const T* __restrict__ pos, int pos_rows, long ldp,
-                                                    float p_in, uint64_t seed_in, float p_out, uint64_t seed_out) {
+                                                    float p_in, uint64_t seed_in, float p_out, uint64_t seed_out,
+                                                    const uint64_t* __restrict__ epoch) {
   constexpr int VEC = Elem<T>::VEC;
+  if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }     // crog_set_seed_epoch: per-step offset from device memory
   const int lane = threadIdx.x & 63;
   const long stride = (long)gridDim.x * (NT / 64);
   long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -617,8 +619,10 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
                                                     const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                     const float* __restrict__ stats, long M, int C, T* __restrict__ dx, long lddx,
                                                     float* __restrict__ partial, int rows_per_block, float p_in, uint64_t seed_in,
-                                                    float p_out, uint64_t seed_out, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                    float p_out, uint64_t seed_out, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                    const uint64_t* __restrict__ epoch) {
   constexpr int VEC = Elem<T>::VEC;
+  if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int cvec = C / VEC;
   const uint32_t thr_in = (uint32_t)(p_in * 4294967296.0), thr_out = (uint32_t)(p_out * 4294967296.0);
@@ -808,8 +812,9 @@ __device__ inline float group_max(float v) {
 template <typename T, int LPR, int NJ>
 __global__ void __launch_bounds__(NT) softmax_fwd_kernel(T* __restrict__ S, long rows, int Lq, int Lk, int ldp, int heads,
                                                          int causal, const uint8_t* __restrict__ kpm, T* __restrict__ Pd,
-                                                         float p_drop, uint64_t seed) {
+                                                         float p_drop, uint64_t seed, const uint64_t* __restrict__ epoch) {
   constexpr int VEC = Elem<T>::VEC, RPW = 64 / LPR;
+  if (epoch) seed += *epoch;
   const int lane = threadIdx.x & 63, sub = lane % LPR;
   const long row = ((long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
   const bool live = row < rows;
@@ -885,8 +890,9 @@ __global__ void __launch_bounds__(NT) softmax_fwd_kernel(T* __restrict__ S, long
 // dS = P * (dP - sum_k dP*P) with dP = dropout_bwd(dPd); written in place over dPd.
 template <typename T, int LPR, int NJ>
 __global__ void __launch_bounds__(NT) softmax_bwd_kernel(const T* __restrict__ P, T* __restrict__ dPd, long rows, int Lk, int ldp,
-                                                         float p_drop, uint64_t seed) {
+                                                         float p_drop, uint64_t seed, const uint64_t* __restrict__ epoch) {
   constexpr int VEC = Elem<T>::VEC, RPW = 64 / LPR;
+  if (epoch) seed += *epoch;
   const int lane = threadIdx.x & 63, sub = lane % LPR;
   const long row = ((long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
   const bool live = row < rows;
@@ -1069,7 +1075,7 @@ extern "C" int crog_ln_fwd(int dtype, const void* x, int64_t ldx, const float* g
 #define CROG_LN_FWD(NV)                                                                                                          \
   DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)x,     \
                                        (long)ldx, gamma, beta, eps, (long)M, C, (T*)out, (long)ldo, stats, (const T*)res, (long)ldr, \
-                                       (T*)out2, (long)ldo2, (const T*)pos, pos_rows, (long)ldp, p_in, seed_in, p_out, seed_out))
+                                       (T*)out2, (long)ldo2, (const T*)pos, pos_rows, (long)ldp, p_in, seed_in, p_out, seed_out, crog_seed_epoch()))
   if (nv <= 1) CROG_LN_FWD(1);
   else if (nv <= 2) CROG_LN_FWD(2);
   else if (nv <= 4) CROG_LN_FWD(4);
@@ -1094,7 +1100,7 @@ extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void
 #define CROG_LN_BWD(NV)                                                                                                           \
   DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dout, (long)lddo, \
                                        (const T*)dout2, (long)lddo2, (const T*)x, (long)ldx, gamma, stats, (long)M, C, (T*)dx,       \
-                                       (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out, dgamma, dbeta))
+                                       (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out, dgamma, dbeta, crog_seed_epoch()))
   if (nv <= 1) CROG_LN_BWD(1);
   else if (nv <= 2) CROG_LN_BWD(2);
   else if (nv <= 4) CROG_LN_BWD(4);
@@ -1113,7 +1119,7 @@ extern "C" int crog_softmax_fwd(int dtype, void* S, int64_t rows, int Lq, int Lk
 #define CROG_SM_FWD(LPR, NJ)                                                                                                       \
   DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_fwd_kernel<T, LPR, NJ>), dim3(cdiv(rows, (NT / 64) * (64 / LPR))), dim3(NT), 0,    \
                                        (hipStream_t)stream, (T*)S, (long)rows, Lq, Lk, ldp, heads, causal, key_padding_mask, (T*)Pd, \
-                                       p_drop, seed))
+                                       p_drop, seed, crog_seed_epoch()))
   if (nvec <= 4) CROG_SM_FWD(4, 1);
   else if (nvec <= 16) CROG_SM_FWD(16, 1);
   else if (nvec <= 64) CROG_SM_FWD(64, 1);
@@ -1132,7 +1138,7 @@ extern "C" int crog_softmax_bwd(int dtype, const void* P, void* dPd, int64_t row
   const int nvec = ldp / vec;
 #define CROG_SM_BWD(LPR, NJ)                                                                                                       \
   DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_bwd_kernel<T, LPR, NJ>), dim3(cdiv(rows, (NT / 64) * (64 / LPR))), dim3(NT), 0,    \
-                                       (hipStream_t)stream, (const T*)P, (T*)dPd, (long)rows, Lk, ldp, p_drop, seed))
+                                       (hipStream_t)stream, (const T*)P, (T*)dPd, (long)rows, Lk, ldp, p_drop, seed, crog_seed_epoch()))
   if (nvec <= 4) CROG_SM_BWD(4, 1);
   else if (nvec <= 16) CROG_SM_BWD(16, 1);
   else if (nvec <= 64) CROG_SM_BWD(64, 1);

@@ -7,6 +7,7 @@ host reads of device scalars happen once per `print_freq` steps instead of ~8 ti
 """
 from __future__ import annotations
 
+import os
 import time
 
 import torch
@@ -102,8 +103,29 @@ def mask_iou(pred_map, target, thr=0.35):
     return inter / (union + 1e-6)
 
 
+STEP_GRAPH = os.environ.get("CROG_STEP_GRAPH", "1") != "0"    # whole-step hipGraph replay (crog_amd/graphs.py); 0 = issue every step from Python
+_GRAPHED = {}
+
+
+def graphed_step_for(model, optimizer, scaler, args, autocast_dtype=torch.bfloat16):
+    """The GraphedTrainStep of this (model, optimizer) pair, or None when the step cannot be one graph: a live GradScaler (its
+    inf check steers the host), a stock torch optimizer (host-side step count), or CROG_STEP_GRAPH=0."""
+    from .optim import FusedAdam
+    if not STEP_GRAPH or not torch.cuda.is_available() or not isinstance(optimizer, FusedAdam):
+        return None
+    if scaler is not None and scaler.is_enabled():
+        return None
+    key = (id(model), id(optimizer))
+    g = _GRAPHED.get(key)
+    if g is None or g.model is not model or g.optimizer is not optimizer:
+        from .graphs import GraphedTrainStep
+        g = _GRAPHED[key] = GraphedTrainStep(model, optimizer, args, autocast_dtype)
+    return g
+
+
 def train_with_grasp(train_loader, model, optimizer, scheduler, scaler, epoch, args, log=print):
-    """Epoch loop with the reference's meters (crog_engine.py:17-122)."""
+    """Epoch loop with the reference's meters (crog_engine.py:17-122).  With crog_amd's FusedAdam and no live GradScaler (bf16
+    autocast needs none) the step is captured once and replayed as a hipGraph; otherwise it is issued eagerly."""
     batch_time, data_time = AverageMeter("Batch", ":2.2f"), AverageMeter("Data", ":2.2f")
     lr, loss_meter = AverageMeter("Lr", ":1.6f"), AverageMeter("Loss", ":2.4f")
     iou_meter, pr_meter = AverageMeter("IoU", ":2.2f"), AverageMeter("Prec@50", ":2.2f")
@@ -117,7 +139,11 @@ def train_with_grasp(train_loader, model, optimizer, scheduler, scaler, epoch, a
                      mask=data["mask"].cuda(non_blocking=True).unsqueeze(1), qua=gm["qua"].cuda(non_blocking=True).unsqueeze(1),
                      sin=gm["sin"].cuda(non_blocking=True).unsqueeze(1), cos=gm["cos"].cuda(non_blocking=True).unsqueeze(1),
                      wid=gm["wid"].cuda(non_blocking=True).unsqueeze(1))
-        stats, _ = train_step(model, optimizer, scaler, batch, args)
+        graphed = graphed_step_for(model, optimizer, scaler, args)
+        if graphed is not None:
+            stats, _ = graphed(batch)
+        else:
+            stats, _ = train_step(model, optimizer, scaler, batch, args)
         pending.append((stats, batch["img"].size(0)))
         lr.update(scheduler.get_last_lr()[-1])
         if (i + 1) % args.print_freq == 0 or i + 1 == len(train_loader):

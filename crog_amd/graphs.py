@@ -1,4 +1,5 @@
-"""HIP-graph capture of a fixed-shape, launch-bound sub-network (forward AND backward).
+"""HIP-graph capture: the whole training step (GraphedTrainStep, the default of bench.py and train_with_grasp), and a fixed-shape,
+launch-bound sub-network with its backward (GraphedTower, the CLIP text tower; kept for eager steps).
 
 The CLIP text tower of CROG (reference model/clip.py:334-500, called from model/crog.py:60) works on B x 20 token rows:
 about 250 forward and 400 backward launches of a few microseconds each.  Issued eagerly they cost the host ~8 ms per
@@ -88,3 +89,143 @@ class _Replay(Function):
             for p in tower.params:
                 RT.reducer.mark_ready(p)
         return None, None, None
+
+
+class GraphedTrainStep:
+    """engine.train_step (crog_engine.py:60-90: autocast forward, zero_grad, backward, optimizer step, train metric, rank-averaged
+    scalars) as ONE hipGraph launch per step.
+
+    Why: an eager step is ~1300 kernel launches issued through Python and ctypes, ~30 ms of host time at any batch size, so the
+    step could never be shorter than that however fast the kernels are (B = 8: 24 ms for 10 ms of GPU work).  A replay costs the host
+    one call.
+
+    What makes the capture legal (and keeps a replay equal to the eager step it replaces):
+      * shapes are static (the loader drops the ragged last batch, train_crog.py:192); inputs are copied into the captured step's
+        own input tensors (a loader's H2D copy can target them directly: `static_batch()`),
+      * no entry point of the C ABI allocates or synchronises; parameters, gradients, bf16 shadow and Adam moments live at fixed
+        addresses in the ParamStore; activations come from the graph's private pool,
+      * per-step scalars live in device memory: dropout seeds = captured seed + a device epoch that the step itself advances
+        (crog_set_seed_epoch), Adam's step count / bias corrections / learning rates (FusedAdam(capturable=True)),
+      * the side streams (text tower, weight gradients) fork from and re-join the capture stream inside the step, so their
+        overlap is part of the graph; DDP's bucket all-reduces and the SyncBatchNorm exchanges are RCCL launches on captured streams
+        and replay with it (the reducer's Python bookkeeping ran once, at capture).
+    The first `warmup` calls run eagerly (lazy initialisation, RCCL communicator set-up, the store's steady-state flags); if the
+    capture raises, every later call stays eager and `self.failed` says why.  Eager and replayed steps draw the same seed sequence,
+    so they can be mixed (bench.py brackets kernels with timers in an occasional eager step)."""
+
+    def __init__(self, model, optimizer, args=None, autocast_dtype=torch.bfloat16, warmup: int = 3, enabled: bool = True):
+        self.model, self.optimizer, self.args, self.autocast_dtype = model, optimizer, args, autocast_dtype
+        self.warmup = max(2, warmup)      # >= 2: the first step casts the bf16 shadow and builds the optimizer state
+        self.enabled = enabled and torch.cuda.is_available()
+        self.calls = 0
+        self.graph = None
+        self.failed = None
+        self.static = None
+        self.replays = 0
+        self._seed0 = None
+        self._seeds_per_step = None
+        if self.enabled and not getattr(optimizer, "capturable", False):
+            if not hasattr(optimizer, "sync_lr"):
+                raise TypeError("GraphedTrainStep needs crog_amd.optim.FusedAdam (device-resident step state); pass enabled=False for other optimizers")
+            optimizer.capturable = True
+
+    # ---- the step itself (what engine.train_step does, minus GradScaler: bf16 needs none) ------------------------------------
+    def _body(self, batch):
+        from . import functional as Fn
+        import torch.distributed as dist
+        model, opt = self.model, self.optimizer
+        adt = self.autocast_dtype
+        with torch.autocast("cuda", dtype=adt or torch.bfloat16, enabled=adt is not None):
+            pred, target, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
+        opt.zero_grad()
+        loss.backward()
+        max_norm = getattr(self.args, "max_norm", 0.0) if self.args is not None else 0.0
+        if max_norm:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        opt.step()
+        m = Fn.train_metric(pred[0], target[0], 0.35, 0.5)
+        stats = torch.stack([loss.detach().float(), m[0], m[1]])
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(stats)
+            stats = stats / dist.get_world_size()
+        return stats, loss_dict
+
+    def _eager(self, batch):
+        """One eager step inside the seed protocol: seeds restart at the same host counter every step and the device epoch moves on by
+        the number of seeds a step draws - exactly what a replay does."""
+        from . import kernels as K
+        if self._seed0 is None:
+            self._seed0 = RT._seed_ctr
+            RT.enable_seed_epoch(batch["img"].device)
+        RT._seed_ctr = self._seed0
+        out = self._body(batch)
+        n = RT._seed_ctr - self._seed0
+        if self._seeds_per_step is None:
+            self._seeds_per_step = n
+        elif n != self._seeds_per_step:
+            raise RuntimeError(f"training step drew {n} dropout seeds, {self._seeds_per_step} before: not a static step")
+        if n:
+            K.counter_add(RT.seed_epoch, n)
+        return out
+
+    def _capture(self, batch):
+        from . import kernels as K
+        from .model import crog as crog_mod
+        self.static = dict(batch)           # the captured kernels read THESE tensors; later batches are copied into them
+        torch.cuda.synchronize()
+        saved_text_graph, saved_prof = crog_mod.TEXT_GRAPH, K.PROF
+        crog_mod.TEXT_GRAPH, K.PROF = False, None      # no graph replay and no timing events inside a capture
+        g = torch.cuda.CUDAGraph()
+        try:
+            RT._seed_ctr = self._seed0
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                stats, loss_dict = self._body(self.static)
+                if self._seeds_per_step:
+                    K.counter_add(RT.seed_epoch, self._seeds_per_step)
+            if RT._seed_ctr - self._seed0 != self._seeds_per_step:
+                raise RuntimeError("seed count changed during capture")
+        finally:
+            crog_mod.TEXT_GRAPH, K.PROF = saved_text_graph, saved_prof
+        self.graph, self._stats, self._loss_dict = g, stats, loss_dict
+        self._loss_sums = getattr(loss_dict, "_sums", None)
+        self.collectives = dict(syncbn=(RT.comm.calls if RT.comm is not None else 0), buckets=(RT.reducer.launches if RT.reducer is not None else 0))
+
+    def static_batch(self):
+        """The captured step's input tensors (None before capture): write the next batch straight into them to skip the copy."""
+        return self.static
+
+    def __call__(self, batch, eager: bool = False):
+        """-> (stats [loss, 100*IoU, 100*Prec@50] as a fresh 3-element device tensor, loss_dict).  eager=True issues this step
+        from Python even when a graph exists (same results; bench.py's per-launch timers need real launches)."""
+        self.calls += 1
+        if not self.enabled or self.failed is not None:
+            return self._eager(batch)
+        if self.graph is None:
+            if self.calls <= self.warmup:
+                return self._eager(batch)
+            try:
+                n0 = (RT.comm.calls if RT.comm is not None else 0, RT.reducer.launches if RT.reducer is not None else 0)
+                self._capture(batch)
+                self.collectives = dict(syncbn=self.collectives["syncbn"] - n0[0], buckets=self.collectives["buckets"] - n0[1])
+            except Exception as e:          # stay correct: an uncapturable configuration trains eagerly
+                import warnings
+                self.failed = repr(e)
+                self.graph = None
+                torch.cuda.synchronize()
+                warnings.warn(f"crog_amd: whole-step hipGraph capture failed ({e!r}); steps stay eager")
+                return self._eager(batch)
+        if eager or any(batch[k].shape != t.shape or batch[k].dtype != t.dtype for k, t in self.static.items()):
+            return self._eager(batch)       # asked for, or a batch of another shape (a ragged last batch): issue it from Python
+        for k, dst in self.static.items():
+            src = batch[k]
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.optimizer.sync_lr()
+        self.graph.replay()
+        self.optimizer.replayed()
+        self.replays += 1
+        from .model.crog import LossDict
+        ld = self._loss_dict
+        if self._loss_sums is not None:
+            ld = LossDict(self._loss_sums.clone(), ld._heads)
+        return self._stats.clone(), ld

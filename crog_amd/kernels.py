@@ -518,6 +518,28 @@ def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, shadow=None, off=0
                                float(beta2), float(eps), float(wd), int(step), sh, stream()), "adam_step")
 
 
+def adam_advance(hyper, beta1, beta2):
+    """hyper: device float[4] {lr, 1 - beta1^t, sqrt(1 - beta2^t), t} -> t += 1 and its two corrections."""
+    check(lib().crog_adam_advance(ptr(hyper), float(beta1), float(beta2), stream()), "adam_advance")
+
+
+def adam_step_dev(p, g, m, v, n, hyper, beta1, beta2, eps, wd, shadow=None, off=0):
+    sh = None if shadow is None else ptr(shadow) + 2 * off
+    check(lib().crog_adam_step_dev(ptr(p) + 4 * off, ptr(g) + 4 * off, ptr(m) + 4 * off, ptr(v) + 4 * off, n, ptr(hyper), float(beta1),
+                                   float(beta2), float(eps), float(wd), sh, stream()), "adam_step_dev")
+
+
+def set_seed_epoch(epoch: Optional[torch.Tensor]):
+    """Install (None: remove) the device uint64 every dropout kernel adds to its seeds (include/crog_hip.h)."""
+    if epoch is not None and (epoch.dtype != torch.int64 or epoch.numel() != 1 or not epoch.is_cuda):
+        raise TypeError("seed epoch must be a one-element int64 GPU tensor")
+    check(lib().crog_set_seed_epoch(None if epoch is None else epoch.data_ptr()), "set_seed_epoch")
+
+
+def counter_add(counter: torch.Tensor, inc: int):
+    check(lib().crog_counter_add(ptr(counter), int(inc), stream()), "counter_add")
+
+
 # --------------------------------------------------------------------------------------------
 # head
 # --------------------------------------------------------------------------------------------

@@ -16,13 +16,19 @@ from .runtime import ALIGN, RT, ParamStore
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, store: ParamStore = None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, store: ParamStore = None, capturable: bool = False):
+        """capturable: the step count, its bias corrections and the learning rates live in device memory (one float[4] per
+        parameter group, advanced by a one-thread kernel), so `step()` has no per-step scalar in a kernel argument and can be
+        captured into a hipGraph and replayed (crog_amd.graphs.GraphedTrainStep switches it on).  Same arithmetic either way."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self._store = store
         self._segments = None
         self._step = 0
         self.m = self.v = None
+        self.capturable = capturable
+        self._hyper = None          # [groups, 4] device floats {lr, 1 - beta1^t, sqrt(1 - beta2^t), t}
+        self._hyper_lr = None       # the learning rates last written into it
 
     def attach(self, store: ParamStore):
         self._store = store
@@ -77,6 +83,29 @@ class FusedAdam(torch.optim.Optimizer):
             cache[key] = out
         return cache[key]
 
+    # ---- device-resident step state (capturable mode) ---------------------------------------------------------------
+    def _ensure_hyper(self):
+        if self._hyper is None:
+            self._hyper = torch.zeros(len(self.param_groups), 4, device=self._store.device, dtype=torch.float32)
+            self._hyper[:, 3] = float(self._step)
+            self._hyper_lr = [None] * len(self.param_groups)
+        return self._hyper
+
+    def sync_lr(self):
+        """Write the groups' learning rates into the device state when a scheduler changed them (MultiStepLR: a few times per
+        run).  Launches fill kernels, so it runs OUTSIDE a captured step: GraphedTrainStep calls it before every replay."""
+        if not self.capturable or self._store is None:
+            return
+        hyper = self._ensure_hyper()
+        for i, group in enumerate(self.param_groups):
+            if self._hyper_lr[i] != group["lr"]:
+                hyper[i, 0:1].fill_(float(group["lr"]))
+                self._hyper_lr[i] = group["lr"]
+
+    def replayed(self, steps: int = 1):
+        """A captured step() was replayed `steps` times: the device count advanced by itself, the host mirror follows."""
+        self._step += steps
+
     @staticmethod
     def _like(buf, p, o):
         co, ci, kh, kw = p.shape
@@ -95,10 +124,19 @@ class FusedAdam(torch.optim.Optimizer):
         self._step += 1
         store = self._store
         shadow = store.S      # bf16 compute copy (None until a bf16 forward has run): refreshed by the same pass that updates P
-        for group, segs in zip(self.param_groups, self._segments):
+        if self.capturable:
+            self.sync_lr()
+        for gi, (group, segs) in enumerate(zip(self.param_groups, self._segments)):
             b1, b2 = group["betas"]
             if group["weight_decay"] != 0 and store.explicit:
                 segs = self._decay_segments(group, segs)
+            if self.capturable:
+                hyper = self._hyper[gi]
+                K.adam_advance(hyper, b1, b2)
+                for o, n in segs:
+                    K.adam_step_dev(store.P, store.G, self.m, self.v, n, hyper, b1, b2, group["eps"], group["weight_decay"],
+                                    shadow=shadow, off=o)
+                continue
             for o, n in segs:
                 K.adam_step(store.P, store.G, self.m, self.v, n, group["lr"], b1, b2, group["eps"], group["weight_decay"], self._step,
                             shadow=shadow, off=o)
@@ -128,6 +166,9 @@ class FusedAdam(torch.optim.Optimizer):
         loaded = {p: dict(st) for p, st in self.state.items()}
         steps = [int(st["step"]) for st in loaded.values() if "step" in st]
         self._step = max(steps) if steps else 0
+        if self._hyper is not None:           # keep the tensor (a captured graph holds its address); rewrite its contents
+            self._hyper[:, 3] = float(self._step)
+            self._hyper_lr = [None] * len(self.param_groups)
         self.state.clear()
         self._segments = None
         if self._store is not None:

@@ -20,6 +20,20 @@ from . import kernels as K
 ALIGN = 8  # elements; keeps every parameter 16-byte aligned in the bf16 shadow too
 
 
+def _cu_masked_stream(cus: int, dev):
+    """A/B aid (CROG_WGRAD_CUS=N, eager steps only - a hipGraph replay does not keep stream attributes): a stream whose kernels may only
+    use N of the 256 CUs (hipExtStreamCreateWithCUMask; mask bits are dealt round-robin over the 8 XCDs, so the low N bits are N/8 CUs
+    of every XCD), wrapped for torch.  Measured in round 3 as the weight-gradient stream: see DESIGN.md section 4."""
+    import ctypes
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    words = (ctypes.c_uint32 * 8)(*[(((1 << cus) - 1) >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+    h = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(8), words)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 class Runtime:
     def __init__(self):
         self.comm = None       # object with .world_size and .all_reduce_sum(tensor) for SyncBatchNorm
@@ -32,6 +46,7 @@ class Runtime:
         self._join_armed = False
         self.seed_base = 0x5EED
         self._seed_ctr = 0
+        self.seed_epoch = None   # device int64 added to every dropout seed inside the kernels (enable_seed_epoch)
 
     # ---- weight-gradient side stream -----------------------------------------------------------------
     # Weight gradients are only consumed by the optimizer (or the gradient all-reduce), never by the rest of backward,
@@ -57,7 +72,11 @@ class Runtime:
             if self.overlap_wgrad:
                 n = max(1, int(os.environ.get("CROG_WGRAD_STREAMS", "1")))
                 prio = int(os.environ.get("CROG_SIDE_PRIORITY", "0"))
-                self._wgrad_stream = [torch.cuda.Stream(priority=prio) for _ in range(n)]
+                cus = int(os.environ.get("CROG_WGRAD_CUS", "0"))
+                if cus > 0:
+                    self._wgrad_stream = [_cu_masked_stream(cus, dev)]
+                else:
+                    self._wgrad_stream = [torch.cuda.Stream(priority=prio) for _ in range(n)]
                 self._wgrad_next = 0
                 order += self._wgrad_stream
             self.text_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CROG_SIDE_PRIORITY", "0")))
@@ -150,6 +169,14 @@ class Runtime:
         self._zptr += n8
         return t
 
+    def enable_seed_epoch(self, device):
+        """Dropout seeds = host seed + a device-resident epoch (crog_set_seed_epoch): a captured step advances the epoch itself, so
+        every replay drops different elements (crog_amd.graphs.GraphedTrainStep)."""
+        if getattr(self, "seed_epoch", None) is None or self.seed_epoch.device != torch.device(device):
+            self.seed_epoch = torch.zeros(1, device=device, dtype=torch.int64)
+            K.set_seed_epoch(self.seed_epoch)
+        return self.seed_epoch
+
     def next_seed(self) -> int:
         self._seed_ctr += 1
         return ((self.seed_base & 0xFFFFFFFF) << 32) | (self._seed_ctr & 0xFFFFFFFF)
@@ -157,6 +184,8 @@ class Runtime:
     def manual_seed(self, seed: int):
         self.seed_base = int(seed)
         self._seed_ctr = 0
+        if getattr(self, "seed_epoch", None) is not None:
+            self.seed_epoch.zero_()
 
 
 RT = Runtime()

@@ -36,9 +36,20 @@ const char* crog_last_error(void);
 /* Peak probes for the measurement harness (bench.py `measured_peaks`; SURVEY.md §8d asks for the box's own stream-copy and
  * MFMA rates beside the vendor figures).  crog_probe_mfma_bf16: `blocks` x 4 waves each issue iters x 8 independent
  * v_mfma_f32_32x32x16_bf16 on register operands (FLOP = blocks * 4 * iters * 8 * 32768); `sink` needs blocks * 256 floats and is
- * never written.  crog_probe_copy: dst[0:bytes] = src[0:bytes], 16 bytes per lane (traffic = 2 * bytes).  Timing is the caller's. */
+ * never written.  crog_probe_copy: dst[0:bytes] = src[0:bytes], 16 bytes per lane, one block per 256 * V consecutive vectors, no
+ * grid-stride loop (traffic = 2 * bytes); mode 0/1/2 = V 1/2/4 with non-temporal loads and stores, 3/4/5 = the same with plain ones.
+ * Timing is the caller's. */
 int crog_probe_mfma_bf16(float* sink, int blocks, int iters, crog_stream_t stream);
-int crog_probe_copy(const void* src, void* dst, int64_t bytes, crog_stream_t stream);
+int crog_probe_copy(const void* src, void* dst, int64_t bytes, int mode, crog_stream_t stream);
+
+/* Per-step launch state in DEVICE memory, so that a hipGraph captured over a whole training step (crog_engine.py:60-90 as one
+ * graph launch; crog_amd/graphs.py) replays with fresh values instead of the scalars baked into its kernel arguments.
+ * crog_set_seed_epoch installs (NULL: removes) a device uint64 that every dropout-carrying entry point below ADDS to its `seed`
+ * arguments inside the kernel (crog_ln_fwd/bwd, crog_softmax_fwd/bwd, crog_add_dropout, crog_flash_attn_fwd/bwd); it is process-wide
+ * launch state like the current device: set once, before the first launch that should see it.  crog_counter_add: *counter += inc
+ * on `stream` (the captured step advances the epoch by the number of seeds one step draws). */
+int crog_set_seed_epoch(const uint64_t* epoch_dev);
+int crog_counter_add(uint64_t* counter_dev, uint64_t inc, crog_stream_t stream);
 
 /* Timing-only HIP events for per-launch measurements inside a running step (bench.py `roofline`, scripts/profile_gemms.py).
  * They are created with hipEventDisableSystemFence: a default event performs a system-scope release when it completes (L2
@@ -346,6 +357,12 @@ int crog_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, int row
 /* torch.optim.Adam step over one flat fp32 segment (train_crog.py:119-121, crog_engine.py:83) */
 int crog_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, void* bf16_shadow, crog_stream_t stream);
+/* The same step with its per-step scalars in device memory: hyper_dev = float[4] {lr, 1 - beta1^t, sqrt(1 - beta2^t), t}.
+ * crog_adam_advance: t += 1 and the two corrections of the new t (one launch per parameter group, before its segments);
+ * the host writes lr (MultiStepLR, train_crog.py:122,270) and, on load_state_dict, t. */
+int crog_adam_advance(float* hyper_dev, float beta1, float beta2, crog_stream_t stream);
+int crog_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, float beta1,
+                       float beta2, float eps, float weight_decay, void* bf16_shadow, crog_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Text-conditioned dynamic conv head, losses, metric

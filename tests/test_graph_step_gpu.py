@@ -1,0 +1,204 @@
+"""Whole-step hipGraph (crog_amd/graphs.py::GraphedTrainStep): a replayed step must be the eager step it replaces
+(crog_engine.py:60-90) - same forward, same dropout masks, same Adam update, fresh inputs every step - and the device-resident
+per-step state it relies on (dropout seed epoch, Adam step count / learning rate) must match the host-scalar form."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from crog_amd.testing import seeded_state, synthetic_batch, tiny_cfg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh(cfg, dtype, seed=11):
+    from crog_amd.model import build_crog
+    from crog_amd.optim import FusedAdam
+    model, groups = build_crog(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(seeded_state(shapes, seed=seed, residual_gain=0.25))
+    model = model.cuda()
+    model.compute_dtype = dtype
+    model.prepare()
+    model.train()
+    opt = FusedAdam(groups, lr=cfg.base_lr, weight_decay=1e-4, store=model.store)
+    return model, opt
+
+
+def _batches(cfg, n, B=4):
+    return [{k: v.cuda() for k, v in synthetic_batch(B, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=50 + i).items()}
+            for i in range(n)]
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / (a.float().norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_replayed_steps_equal_eager_steps(dtype):
+    """7 optimizer steps with dropout 0.1 and a different batch every step: (a) engine.train_step eagerly, (b) again (the eager
+    path's own run-to-run noise: split-K / statistics atomics), (c) GraphedTrainStep = 3 eager + capture + replays, with one
+    eager step mixed in after the capture.  Per-step loss / metric and the final parameters of (c) sit within that noise of (a),
+    and an lr change between replays reaches the captured Adam kernels."""
+    from crog_amd.engine import train_step
+    from crog_amd.graphs import GraphedTrainStep
+    from crog_amd.runtime import RT
+    cfg = tiny_cfg(dropout=0.1)
+    batches = _batches(cfg, 7)
+    adt = torch.bfloat16 if dtype == torch.bfloat16 else None
+
+    def run(mode):
+        model, opt = _fresh(cfg, dtype)
+        RT.manual_seed(21)
+        graphed = GraphedTrainStep(model, opt, cfg, adt, warmup=3) if mode == "graph" else None
+        stats = []
+        for i, b in enumerate(batches):
+            if i == 5:
+                for g in opt.param_groups:          # MultiStepLR milestone (train_crog.py:122,270)
+                    g["lr"] = g["lr"] * 0.1
+            if graphed is not None:
+                st, _ = graphed(b, eager=(i == 5))
+            else:
+                st, _ = train_step(model, opt, None, b, cfg, autocast_dtype=adt)
+            stats.append(st.clone())
+        torch.cuda.synchronize()
+        if graphed is not None:
+            assert graphed.failed is None and graphed.graph is not None, graphed.failed
+            assert graphed.replays == 3 and opt._step == 7
+            assert float(opt._hyper[0, 3]) == 7.0
+        return torch.stack(stats).cpu(), model.store.P.clone(), (opt.m.clone(), opt.v.clone())
+
+    s0, p0, mv0 = run("eager")
+    s1, p1, mv1 = run("eager")
+    s2, p2, mv2 = run("graph")
+    noise_s = (s0 - s1).abs().max().item()
+    assert (s0 - s2).abs().max().item() <= max(4 * noise_s, 2e-3 if dtype == torch.float32 else 5e-2), (s0, s2)
+    noise_p = _rel(p0, p1)
+    assert _rel(p0, p2) <= max(4 * noise_p, 1e-6 if dtype == torch.float32 else 1e-4), (noise_p, _rel(p0, p2))
+    assert _rel(mv0[0], mv2[0]) <= max(4 * _rel(mv0[0], mv1[0]), 1e-3 if dtype == torch.float32 else 5e-2)
+
+
+def test_replays_draw_fresh_dropout_masks_and_fresh_inputs():
+    """Two replays on the SAME batch differ (the seed epoch advances inside the graph); two replays on different batches follow the
+    batch (inputs are copied into the captured step's tensors)."""
+    from crog_amd.graphs import GraphedTrainStep
+    from crog_amd.runtime import RT
+    cfg = tiny_cfg(dropout=0.3)
+    model, opt = _fresh(cfg, torch.float32)
+    for g in opt.param_groups:
+        g["lr"] = 0.0            # freeze the weights: what changes between steps is only the masks / the batch
+    RT.manual_seed(5)
+    b = _batches(cfg, 2)
+    graphed = GraphedTrainStep(model, opt, cfg, None, warmup=2)
+    for _ in range(3):
+        graphed(b[0])
+    assert graphed.graph is not None, graphed.failed
+    e0 = int(RT.seed_epoch)
+    l1 = float(graphed(b[0])[0][0])
+    l2 = float(graphed(b[0])[0][0])
+    l3 = float(graphed(b[1])[0][0])
+    assert int(RT.seed_epoch) == e0 + 3 * graphed._seeds_per_step and graphed._seeds_per_step > 0
+    assert l1 != l2 and abs(l3 - l2) > 1e-4
+    # same step eagerly at the same epoch == the replay (up to atomics noise)
+    RT.seed_epoch.fill_(e0)
+    l1e = float(graphed(b[0], eager=True)[0][0])
+    assert abs(l1e - l1) < 2e-4, (l1e, l1)
+
+
+def test_capturable_adam_matches_host_scalar_adam():
+    """crog_adam_step_dev + crog_adam_advance (step count / bias corrections / lr in device memory) == crog_adam_step with host
+    scalars == torch.optim.Adam, over several steps and an lr change."""
+    from crog_amd import kernels as K
+    n = 4096 + 24
+    torch.manual_seed(0)
+    p0 = torch.randn(n, device="cuda")
+    ref = torch.nn.Parameter(p0.clone())
+    topt = torch.optim.Adam([ref], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    ph, pd = p0.clone(), p0.clone()
+    mh, vh, md, vd = (torch.zeros(n, device="cuda") for _ in range(4))
+    hyper = torch.zeros(4, device="cuda")
+    lr = 1e-2
+    for step in range(1, 8):
+        g = torch.randn(n, device="cuda") * (1 + step)
+        if step == 5:
+            lr = 1e-3
+            topt.param_groups[0]["lr"] = lr
+        ref.grad = g.clone()
+        topt.step()
+        K.adam_step(ph, g, mh, vh, n, lr, 0.9, 0.999, 1e-8, 1e-2, step)
+        hyper[0:1].fill_(lr)
+        K.adam_advance(hyper, 0.9, 0.999)
+        K.adam_step_dev(pd, g, md, vd, n, hyper, 0.9, 0.999, 1e-8, 1e-2)
+    torch.cuda.synchronize()
+    assert float(hyper[3]) == 7.0
+    assert torch.equal(ph, pd) and torch.equal(mh, md) and torch.equal(vh, vd)       # same arithmetic, bit for bit
+    assert (ph - ref.detach()).abs().max().item() < 2e-6
+
+
+def test_seed_epoch_shifts_every_dropout_kernel_like_a_host_seed():
+    """seed s + epoch e (device) drops exactly the elements that seed s + e (host argument) drops."""
+    from crog_amd import kernels as K
+    from crog_amd.runtime import RT
+    x = torch.randn(512, 256, device="cuda", dtype=torch.bfloat16)
+    out_a, out_b = torch.empty_like(x), torch.empty_like(x)
+    ep = RT.enable_seed_epoch(x.device)
+    try:
+        ep.fill_(0)
+        K.add_dropout(None, x, out_a, 0.25, (7 << 32) | 1234 + 99)
+        ep.fill_(99)
+        K.add_dropout(None, x, out_b, 0.25, (7 << 32) | 1234)
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, out_b)
+        K.add_dropout(None, x, out_b, 0.25, (7 << 32) | 1235)
+        torch.cuda.synchronize()
+        assert not torch.equal(out_a, out_b)
+    finally:
+        ep.fill_(0)
+
+
+def test_graphed_step_under_forced_ddp_and_syncbn():
+    """DistributedDataParallel + SyncBatchNorm forced on at world size 1 over RCCL (every statistics exchange and gradient bucket
+    really issued): the captured step carries the collectives and replays match the eager DDP steps."""
+    import socket
+    import torch.distributed as dist
+    from crog_amd.engine import train_step
+    from crog_amd.graphs import GraphedTrainStep
+    from crog_amd.parallel import DistributedDataParallel, convert_sync_batchnorm
+    from crog_amd.runtime import RT
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    cfg = tiny_cfg(dropout=0.1)
+    batches = _batches(cfg, 6)
+    try:
+        def run(graph):
+            model, opt = _fresh(cfg, torch.bfloat16)
+            convert_sync_batchnorm(model, force=True)
+            net = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True, force=True, bucket_cap_mb=0.25)
+            RT.manual_seed(3)
+            graphed = GraphedTrainStep(net, opt, cfg, torch.bfloat16, warmup=3) if graph else None
+            out = []
+            for b in batches:
+                st, _ = graphed(b) if graph else train_step(net, opt, None, b, cfg, autocast_dtype=torch.bfloat16)
+                out.append(st.clone())
+            torch.cuda.synchronize()
+            if graph:
+                assert graphed.failed is None and graphed.replays == 3, graphed.failed
+                assert graphed.collectives["syncbn"] > 0 and graphed.collectives["buckets"] > 1
+            return torch.stack(out).cpu(), model.store.P.clone()
+        s0, p0 = run(False)
+        s1, p1 = run(False)
+        s2, p2 = run(True)
+        assert (s0 - s2).abs().max().item() <= max(4 * (s0 - s1).abs().max().item(), 5e-2)
+        assert _rel(p0, p2) <= max(4 * _rel(p0, p1), 1e-4)
+    finally:
+        RT.comm = None
+        RT.reducer = None
+        dist.destroy_process_group()

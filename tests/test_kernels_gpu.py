@@ -981,7 +981,7 @@ def test_timing_only_events_measure_a_launch(K):
     src = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
     dst = torch.empty_like(src)
     def copy():
-        K.check(K.lib().crog_probe_copy(K.ptr(src), K.ptr(dst), src.numel(), K.stream()), "probe_copy")
+        K.check(K.lib().crog_probe_copy(K.ptr(src), K.ptr(dst), src.numel(), 0, K.stream()), "probe_copy")
     copy(); torch.cuda.synchronize()
     t0, t1 = K.Timer(), K.Timer()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -990,6 +990,12 @@ def test_timing_only_events_measure_a_launch(K):
     ms, ms_torch = t0.elapsed_time(t1), e0.elapsed_time(e1)
     assert 0.005 < ms < 5.0                      # 128 MB of traffic: ~30 us at 4.5 TB/s, never milliseconds
     assert ms <= ms_torch * 1.05 + 0.01          # bracketed by the torch pair
+    for mode in range(6):                        # every copy shape of the probe moves the bytes (ragged tail included)
+        dst.zero_()
+        src.random_(0, 255)
+        n = src.numel() - 16 * 37
+        K.check(K.lib().crog_probe_copy(K.ptr(src), K.ptr(dst), n, mode, K.stream()), "probe_copy")
+        assert torch.equal(dst[:n], src[:n]) and int(dst[n:].sum()) == 0, mode
 
 
 @pytest.mark.parametrize("M,N,K_,relu", [(4096, 64, 64, True), (1000, 72, 96, True), (21632, 256, 2304 // 9, False), (2500, 512, 128, True)])
