@@ -312,16 +312,22 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    # Default: the step is captured once into a hipGraph (crog_amd/graphs.py) after 3 eager steps and replayed - one host call per step
-    # instead of ~1300 launches through Python.  --eager (or CROG_STEP_GRAPH=0) issues every step from Python as rounds 1-2 did.
+    # Default: the step is captured once (ordinary stream capture) after 3 eager steps and then re-issued per step by ONE C call
+    # (crog_amd/graphs.py, csrc/replay.hip: same kernels, arguments, streams and cross-stream edges as the eager step) instead of ~1300
+    # launches through Python.  --eager (or CROG_STEP_GRAPH=0) issues every step from Python as rounds 1-2 did;
+    # CROG_STEP_GRAPH=hipgraph replays with hipGraphLaunch instead.  Multi-GPU runs stay eager unless CROG_STEP_GRAPH asks for replay:
+    # a captured RCCL collective has never run with real peers on this build.
+    key = {"conv3x3_fwd": (K.A_IM2COL, K.B_KC), "conv3x3_dgrad": (K.A_IM2COL, K.B_NC_DGRAD), "conv3x3_wgrad": (K.A_MC, K.B_NC_IM2COL),
+           "lin_fwd": (K.A_KC, K.B_KC), "none": None}[args.roofline_kernel]
     graphed = None
-    if not args.eager and os.environ.get("CROG_STEP_GRAPH", "1") != "0":
+    want = os.environ.get("CROG_STEP_GRAPH", "1" if world == 1 else "0")
+    if not args.eager and want != "0":
         from crog_amd.graphs import GraphedTrainStep
-        graphed = GraphedTrainStep(net, opt, cfg, adt, warmup=3)
+        graphed = GraphedTrainStep(net, opt, cfg, adt, warmup=3, profile_key=key if rank == 0 else None)
 
-    def step(eager=False):
+    def step(eager=False, profile=False):
         if graphed is not None:
-            return graphed(batch, eager=eager)
+            return graphed(batch, eager=eager, profile=profile)
         return train_step(net, opt, None, batch, cfg, autocast_dtype=adt)
 
     for _ in range(args.warmup):
@@ -329,26 +335,27 @@ def main():
     while graphed is not None and graphed.graph is None and graphed.failed is None:
         stats, _ = step()          # --warmup < 4: the capture still happens before the timed region
     sync()
-    key = {"conv3x3_fwd": (K.A_IM2COL, K.B_KC), "conv3x3_dgrad": (K.A_IM2COL, K.B_NC_DGRAD), "conv3x3_wgrad": (K.A_MC, K.B_NC_IM2COL),
-           "lin_fwd": (K.A_KC, K.B_KC), "none": None}[args.roofline_kernel]
-    if key is not None and rank == 0:
-        K.PROF = dict(key=key, records=[], on=False)
     replaying = graphed is not None and graphed.graph is not None
+    timers_in_replay = replaying and bool(graphed.prof_nodes)      # the replay brackets the roofline kernel's launches itself
+    if key is not None and rank == 0 and not timers_in_replay:
+        K.PROF = dict(key=key, records=[], on=False)
     coll0 = (RT.comm.calls if RT.comm is not None else 0, net.reducer.launches if (world > 1 or force_ddp) else 0)
     t0 = time.perf_counter()
-    # The per-launch timers of the roofline leg need real launches (an event cannot be read back out of a graph replay): every
-    # PROF_EVERY-th timed step is issued eagerly with a timer pair around each launch of the roofline kernel (same kernels, same
-    # streams, same seeds as a replay; 106 event records).  Eager mode: every 5th step is bracketed (~0.3 ms each).  Graph mode: an
-    # eager step costs a few ms more than a replay, so only steps K/3 and 2K/3 are - the measurement stays inside the timed region.
+    # Roofline leg, measured inside the timed region: a timing-only HIP event pair (no system fence) around every launch of the roofline
+    # kernel, on the stream it is launched on, in every PROF_EVERY-th timed step (106 event records per bracketed step cost ~0.3 ms:
+    # sampling keeps `value` untaxed).  Replayed steps carry the pairs inside the replay (crog_replay_profile_*); eager steps take them
+    # in K.gemm; with hipGraphLaunch (no way to read an event out of a graph) steps K/3 and 2K/3 are issued eagerly instead.
     PROF_EVERY = 5
-    prof_steps = {i for i in range(args.steps) if i % PROF_EVERY == 0} if not replaying else {args.steps // 3, (2 * args.steps) // 3}
+    want_prof = key is not None and rank == 0
+    prof_steps = ({i for i in range(args.steps) if i % PROF_EVERY == 0} if (not replaying or timers_in_replay)
+                  else {args.steps // 3, (2 * args.steps) // 3})
     sampled = 0
     for i in range(args.steps):
-        prof = K.PROF is not None and i in prof_steps
+        prof = want_prof and i in prof_steps
+        sampled += prof
         if K.PROF is not None:
             K.PROF["on"] = prof
-            sampled += prof
-        stats, _ = step(eager=prof and replaying)
+        stats, _ = step(eager=prof and replaying and not timers_in_replay, profile=prof and timers_in_replay)
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -361,11 +368,17 @@ def main():
         ms = dt / args.steps * 1e3
         ips = args.batch * world * args.steps / dt
         roof = None
-        if K.PROF is not None and K.PROF["records"]:
+        recs = None
+        if timers_in_replay:
+            recs = graphed.profile_records()
+            durs = [ms * 1e-3 for ms, _, _ in recs]
+            flops = [f for _, f, _ in recs]
+        elif K.PROF is not None and K.PROF["records"]:
             recs = K.PROF["records"]
             K.PROF = None
             durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _, _ in recs]
             flops = [f for _, _, f, _ in recs]
+        if recs:
             avg_d, avg_f = sum(durs) / len(durs), sum(flops) / len(flops)
             traffic = None   # HBM bytes per launch of this kernel from the committed PMC passes (profiles/pmc_traffic.json)
             try:
@@ -391,7 +404,8 @@ def main():
             "roofline": roof,
             "last_step": {"loss": round(last[0], 4), "iou": round(last[1], 3), "prec50": round(last[2], 3)},
         }
-        out["step_issue"] = ({"mode": "hipgraph", "replays": graphed.replays, "eager_steps_in_timed_region": sampled}
+        out["step_issue"] = ({"mode": "replay:" + graphed.executor, "replays": graphed.replays, "captured": graphed.replay_info,
+                              "eager_steps_in_timed_region": 0 if timers_in_replay else sampled}
                              if replaying else {"mode": "eager", "graph_capture_failed": getattr(graphed, "failed", None)})
         if world > 1 or force_ddp:
             per_step = (lambda now, then: (now - then) // args.steps)

@@ -103,7 +103,9 @@ def mask_iou(pred_map, target, thr=0.35):
     return inter / (union + 1e-6)
 
 
-STEP_GRAPH = os.environ.get("CROG_STEP_GRAPH", "1") != "0"    # whole-step hipGraph replay (crog_amd/graphs.py); 0 = issue every step from Python
+# Captured-step replay (crog_amd/graphs.py): "0" = issue every step from Python, "streams" / "1" = csrc/replay.hip on our own streams,
+# "hipgraph" = hipGraphLaunch.  Default: on with one rank, off with several (a captured RCCL collective never ran with real peers here).
+STEP_GRAPH = os.environ.get("CROG_STEP_GRAPH")
 _GRAPHED = {}
 
 
@@ -111,7 +113,9 @@ def graphed_step_for(model, optimizer, scaler, args, autocast_dtype=torch.bfloat
     """The GraphedTrainStep of this (model, optimizer) pair, or None when the step cannot be one graph: a live GradScaler (its
     inf check steers the host), a stock torch optimizer (host-side step count), or CROG_STEP_GRAPH=0."""
     from .optim import FusedAdam
-    if not STEP_GRAPH or not torch.cuda.is_available() or not isinstance(optimizer, FusedAdam):
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    want = STEP_GRAPH if STEP_GRAPH is not None else ("0" if multi else "1")
+    if want == "0" or not torch.cuda.is_available() or not isinstance(optimizer, FusedAdam):
         return None
     if scaler is not None and scaler.is_enabled():
         return None

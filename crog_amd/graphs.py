@@ -113,7 +113,20 @@ class GraphedTrainStep:
     capture raises, every later call stays eager and `self.failed` says why.  Eager and replayed steps draw the same seed sequence,
     so they can be mixed (bench.py brackets kernels with timers in an occasional eager step)."""
 
-    def __init__(self, model, optimizer, args=None, autocast_dtype=torch.bfloat16, warmup: int = 3, enabled: bool = True):
+    def __init__(self, model, optimizer, args=None, autocast_dtype=torch.bfloat16, warmup: int = 3, enabled: bool = True,
+                 executor: str = None, profile_key=None):
+        """executor: "streams" (default) = csrc/replay.hip re-issues the captured nodes on this process's own three streams, so the
+        weight-gradient / text-tower overlap is the eager step's; "hipgraph" = hipGraphLaunch (ROCm 7.0 re-partitions the branches
+        over its own queues: 38.6 instead of 33 ms per CROG-R50 step, kept for A/B).  CROG_STEP_GRAPH=streams|hipgraph overrides.
+        profile_key: (a_layout, b_layout) of the GEMM variant whose launches get timer pairs in profiled replays (bench.py)."""
+        import os
+        self.executor = executor or {"hip": "hipgraph", "hipgraph": "hipgraph"}.get(os.environ.get("CROG_STEP_GRAPH", ""), "streams")
+        self.profile_key = profile_key
+        self.prof_nodes = []            # (node handle, flops, meta) of the profiled launches, capture order
+        self.prof_ms = []               # per profiled replay: list of milliseconds, same order
+        self._prof_pending = False
+        self.replay_handle = None
+        self.replay_info = None
         self.model, self.optimizer, self.args, self.autocast_dtype = model, optimizer, args, autocast_dtype
         self.warmup = max(2, warmup)      # >= 2: the first step casts the bf16 shadow and builds the optimizer state
         self.enabled = enabled and torch.cuda.is_available()
@@ -175,7 +188,11 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         saved_text_graph, saved_prof = crog_mod.TEXT_GRAPH, K.PROF
         crog_mod.TEXT_GRAPH, K.PROF = False, None      # no graph replay and no timing events inside a capture
-        g = torch.cuda.CUDAGraph()
+        own = self.executor == "streams"
+        g = torch.cuda.CUDAGraph(keep_graph=True) if own else torch.cuda.CUDAGraph()
+        if own and self.profile_key is not None:
+            K.CAPTURE_NODES = dict(key=tuple(self.profile_key), nodes=[])
+        host_step = getattr(self.optimizer, "_step", None)
         try:
             RT._seed_ctr = self._seed0
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
@@ -186,17 +203,80 @@ class GraphedTrainStep:
                 raise RuntimeError("seed count changed during capture")
         finally:
             crog_mod.TEXT_GRAPH, K.PROF = saved_text_graph, saved_prof
+            captured, K.CAPTURE_NODES = K.CAPTURE_NODES, None
+            if host_step is not None:
+                self.optimizer._step = host_step      # the capture ran step()'s Python once without executing anything
+        if own:
+            self._build_replay(g, captured)
         self.graph, self._stats, self._loss_dict = g, stats, loss_dict
         self._loss_sums = getattr(loss_dict, "_sums", None)
         self.collectives = dict(syncbn=(RT.comm.calls if RT.comm is not None else 0), buckets=(RT.reducer.launches if RT.reducer is not None else 0))
+
+    def _build_replay(self, g, captured):
+        import ctypes
+        from . import kernels as K
+        lib = K.lib()
+        h = ctypes.c_void_p()
+        K.check(lib.crog_replay_build(ctypes.c_void_p(g.raw_cuda_graph()), 8, ctypes.byref(h)), "replay_build")
+        n = [ctypes.c_int() for _ in range(5)]
+        sizes = (ctypes.c_int * 8)()
+        K.check(lib.crog_replay_info(h, *[ctypes.byref(x) for x in n], sizes, 8), "replay_info")
+        self.replay_handle = h
+        self.replay_info = dict(nodes=n[0].value, kernels=n[1].value, chains=n[2].value, events=n[3].value, waits=n[4].value,
+                                chain_sizes=list(sizes)[:n[2].value])
+        # one stream per chain: the caller's current stream, then the runtime's weight-gradient and text streams, then fresh ones
+        pool = [s for s in ((RT._wgrad_stream or []) + [RT.text_stream]) if s is not None]
+        while len(pool) < n[2].value - 1:
+            pool.append(torch.cuda.Stream())
+        self._replay_side = pool[:n[2].value - 1]
+        if captured is not None and captured["nodes"]:
+            self.prof_nodes = captured["nodes"]
+            arr = (ctypes.c_void_p * len(self.prof_nodes))(*[nd for nd, _, _ in self.prof_nodes])
+            K.check(lib.crog_replay_profile_nodes(h, arr, len(self.prof_nodes)), "replay_profile_nodes")
+
+    def _replay_launch(self, profile: bool):
+        import ctypes
+        from . import kernels as K
+        lib = K.lib()
+        if self._prof_pending:
+            self._read_profile()
+        if self.prof_nodes:
+            K.check(lib.crog_replay_profile_enable(self.replay_handle, 1 if profile else 0), "replay_profile_enable")
+            self._prof_pending = bool(profile)
+        raws = [K.stream()] + [s.cuda_stream for s in self._replay_side]
+        arr = (ctypes.c_void_p * len(raws))(*raws)
+        K.check(lib.crog_replay_launch(self.replay_handle, arr, len(raws)), "replay_launch")
+
+    def _read_profile(self):
+        import ctypes
+        from . import kernels as K
+        out = (ctypes.c_float * len(self.prof_nodes))()
+        K.check(K.lib().crog_replay_profile_read(self.replay_handle, out, len(self.prof_nodes)), "replay_profile_read")
+        self.prof_ms.append(list(out))
+        self._prof_pending = False
+
+    def profile_records(self):
+        """[(milliseconds, flops, meta)] of every profiled launch so far (waits for the last profiled replay)."""
+        if self._prof_pending:
+            self._read_profile()
+        return [(ms, f, meta) for step in self.prof_ms for ms, (_, f, meta) in zip(step, self.prof_nodes)]
+
+    def __del__(self):
+        try:
+            if self.replay_handle is not None:
+                from . import kernels as K
+                K.lib().crog_replay_destroy(self.replay_handle)
+        except Exception:
+            pass
 
     def static_batch(self):
         """The captured step's input tensors (None before capture): write the next batch straight into them to skip the copy."""
         return self.static
 
-    def __call__(self, batch, eager: bool = False):
+    def __call__(self, batch, eager: bool = False, profile: bool = False):
         """-> (stats [loss, 100*IoU, 100*Prec@50] as a fresh 3-element device tensor, loss_dict).  eager=True issues this step
-        from Python even when a graph exists (same results; bench.py's per-launch timers need real launches)."""
+        from Python even when a graph exists (same results); profile=True puts timer pairs around the `profile_key` launches of
+        this replay (executor "streams" only; read them with profile_records())."""
         self.calls += 1
         if not self.enabled or self.failed is not None:
             return self._eager(batch)
@@ -221,7 +301,10 @@ class GraphedTrainStep:
             if src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.optimizer.sync_lr()
-        self.graph.replay()
+        if self.replay_handle is not None:
+            self._replay_launch(profile)
+        else:
+            self.graph.replay()
         self.optimizer.replayed()
         self.replays += 1
         from .model.crog import LossDict

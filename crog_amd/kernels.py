@@ -24,6 +24,9 @@ OUT_T, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 
 # Optional per-launch timing of ONE GEMM variant (bench.py's roofline leg): {"key": (a_layout, b_layout), "records": []}
 PROF = None
+# While a training step is being captured for replay (crog_amd/graphs.py): {"key": (a_layout, b_layout), "nodes": []} collects the
+# graph node of every launch of that variant, so that the replay can put a timer pair around exactly those launches
+CAPTURE_NODES = None
 DEBUG_FLAGS = int(os.environ.get("CROG_GEMM_DEBUG", "0"))  # ablation / A-B bits of crog_gemm_desc.debug (scripts/ablate_gemm.py); 0 in production
 GEMM_SYMBOL = {
     (A_KC, B_KC): "gemm_dma_kernel<T, A_KC, B_KC>  (1x1 conv / linear forward, Q.K^T)",
@@ -179,6 +182,14 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
         PROF["records"].append((e0, e1, 2.0 * M * N * K * batch, (a_layout, b_layout, M, N, K, batch, splitk)))
         if "descs" in PROF:      # scripts/profile_gemms.py replays the launch on the same memory after the step
             PROF["descs"].append(d)
+        return
+    if CAPTURE_NODES is not None and CAPTURE_NODES["key"] == (a_layout, b_layout):
+        raw = stream()
+        check(lib().crog_gemm(ctypes.byref(d), raw), "crog_gemm")
+        node = ctypes.c_void_p()
+        check(lib().crog_capture_last_node(raw, ctypes.byref(node)), "capture_last_node")
+        if node.value:
+            CAPTURE_NODES["nodes"].append((node.value, 2.0 * M * N * K * batch, (a_layout, b_layout, M, N, K, batch, splitk)))
         return
     check(lib().crog_gemm(ctypes.byref(d), stream()), "crog_gemm")
 

@@ -121,11 +121,11 @@ class FusedAdam(torch.optim.Optimizer):
             RT.reducer.wait()
         if self._segments is None or not self._store.valid():
             self._build()
+        if self.capturable:
+            self.sync_lr()        # (creates the device state from the host step count: before that count moves on)
         self._step += 1
         store = self._store
         shadow = store.S      # bf16 compute copy (None until a bf16 forward has run): refreshed by the same pass that updates P
-        if self.capturable:
-            self.sync_lr()
         for gi, (group, segs) in enumerate(zip(self.param_groups, self._segments)):
             b1, b2 = group["betas"]
             if group["weight_decay"] != 0 and store.explicit:

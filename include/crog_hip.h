@@ -51,6 +51,26 @@ int crog_probe_copy(const void* src, void* dst, int64_t bytes, int mode, crog_st
 int crog_set_seed_epoch(const uint64_t* epoch_dev);
 int crog_counter_add(uint64_t* counter_dev, uint64_t inc, crog_stream_t stream);
 
+/* Stream-faithful replay of a captured training step (csrc/replay.hip; replaces the ~1300 Python -> ctypes launches per step of
+ * the loop at crog_engine.py:45-104 by one call).  crog_replay_build walks a hipGraph_t produced by ordinary stream capture
+ * (kernel / memset / 1-D device memcpy / empty nodes; anything else -> CROG_ERR_ARG and the caller keeps issuing eagerly), recovers
+ * the stream-ordered chains of the capture (at most max_chains) and the edges between them; crog_replay_launch re-issues every node in
+ * capture order on streams[chain] (streams[0] = the stream the caller orders against: every other stream first waits for it and is
+ * joined back into it at the end), with an event record / stream wait per cross-chain edge.  The graph must outlive the replay
+ * object (kernel arguments are the node-owned copies).  crog_replay_info: node / kernel / chain / event / wait counts and chain sizes.
+ * Per-launch timing inside a replay: crog_capture_last_node (during capture: the node the last launch on `stream` created) gives
+ * handles; crog_replay_profile_nodes selects them, _enable switches the timer pairs (timing-only events, no system fence) on for the
+ * following launches, _read waits and returns the milliseconds of the LAST profiled launch, in the order the handles were given. */
+int crog_capture_last_node(crog_stream_t stream, void** node_out);
+int crog_replay_build(void* hip_graph, int max_chains, void** replay_out);
+int crog_replay_info(void* replay, int* n_nodes, int* n_kernels, int* n_chains, int* n_events, int* n_waits, int* chain_sizes,
+                     int chain_sizes_cap);
+int crog_replay_launch(void* replay, const crog_stream_t* streams, int n_streams);
+int crog_replay_profile_nodes(void* replay, void* const* nodes, int n);
+int crog_replay_profile_enable(void* replay, int on);
+int crog_replay_profile_read(void* replay, float* ms_out, int cap);
+int crog_replay_destroy(void* replay);
+
 /* Timing-only HIP events for per-launch measurements inside a running step (bench.py `roofline`, scripts/profile_gemms.py).
  * They are created with hipEventDisableSystemFence: a default event performs a system-scope release when it completes (L2
  * write-back between every pair of kernels), which made the kernels BETWEEN two events measure 1.5-2.6x their rocprofv3

@@ -37,8 +37,9 @@ def _rel(a, b):
     return ((a.float() - b.float()).norm() / (a.float().norm() + 1e-30)).item()
 
 
+@pytest.mark.parametrize("executor", ["streams", "hipgraph"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_replayed_steps_equal_eager_steps(dtype):
+def test_replayed_steps_equal_eager_steps(dtype, executor):
     """7 optimizer steps with dropout 0.1 and a different batch every step: (a) engine.train_step eagerly, (b) again (the eager
     path's own run-to-run noise: split-K / statistics atomics), (c) GraphedTrainStep = 3 eager + capture + replays, with one
     eager step mixed in after the capture.  Per-step loss / metric and the final parameters of (c) sit within that noise of (a),
@@ -53,7 +54,7 @@ def test_replayed_steps_equal_eager_steps(dtype):
     def run(mode):
         model, opt = _fresh(cfg, dtype)
         RT.manual_seed(21)
-        graphed = GraphedTrainStep(model, opt, cfg, adt, warmup=3) if mode == "graph" else None
+        graphed = GraphedTrainStep(model, opt, cfg, adt, warmup=3, executor=executor) if mode == "graph" else None
         stats = []
         for i, b in enumerate(batches):
             if i == 5:
@@ -69,6 +70,9 @@ def test_replayed_steps_equal_eager_steps(dtype):
             assert graphed.failed is None and graphed.graph is not None, graphed.failed
             assert graphed.replays == 3 and opt._step == 7
             assert float(opt._hyper[0, 3]) == 7.0
+            if executor == "streams":     # the capture's three stream-ordered chains were recovered: main, weight gradients, text tower
+                info = graphed.replay_info
+                assert info["chains"] == 3 and info["kernels"] > 300 and 0 < info["waits"] < info["nodes"], info
         return torch.stack(stats).cpu(), model.store.P.clone(), (opt.m.clone(), opt.v.clone())
 
     s0, p0, mv0 = run("eager")
@@ -106,6 +110,25 @@ def test_replays_draw_fresh_dropout_masks_and_fresh_inputs():
     RT.seed_epoch.fill_(e0)
     l1e = float(graphed(b[0], eager=True)[0][0])
     assert abs(l1e - l1) < 2e-4, (l1e, l1)
+
+
+def test_replay_times_the_selected_launches():
+    """profile_key: the replay puts a timing-only event pair around every launch of one GEMM variant (bench.py's roofline leg)."""
+    from crog_amd import kernels as K
+    from crog_amd.graphs import GraphedTrainStep
+    cfg = tiny_cfg(dropout=0.1)
+    model, opt = _fresh(cfg, torch.bfloat16)
+    b = _batches(cfg, 1)[0]
+    graphed = GraphedTrainStep(model, opt, cfg, torch.bfloat16, warmup=2, profile_key=(K.A_IM2COL, K.B_KC))
+    for i in range(6):
+        graphed(b, profile=(i >= 4))
+    assert graphed.failed is None and graphed.replay_handle is not None, graphed.failed
+    n = len(graphed.prof_nodes)
+    assert n >= 10          # 3x3 forward + data-gradient launches of the tiny model
+    recs = graphed.profile_records()
+    assert len(recs) == 2 * n
+    assert all(0.0005 < ms < 5.0 for ms, _, _ in recs), [ms for ms, _, _ in recs]
+    assert all(f > 0 and meta[0] == K.A_IM2COL for _, f, meta in recs)
 
 
 def test_capturable_adam_matches_host_scalar_adam():
