@@ -106,6 +106,33 @@ __device__ inline Frag<float> frag_tr(const float* tile, int cbase, int ks, int 
 
 struct ConvGeom { int H, W, C; };
 
+// fp32 (the parity mode) accumulates k-blocked: every KBLOCK_F32 k-tiles (128 reduction indices) the running MFMA accumulators are
+// folded into a second set and restarted.  One long sequential-k chain is the noisier summation - on BASELINE config 1 it put the
+// HIP logits 2.5x as far from the float64 result as the reference's blocked CPU GEMM (tests/test_fulldepth_gpu.py); partial sums
+// of 128 bound the chain length the way a blocked GEMM does.  bf16 keeps one chain (its operands carry 8 bits; and no registers to spare).
+constexpr int KBLOCK_F32 = 8;
+template <int WM, int WN>
+__device__ __attribute__((always_inline)) inline void kblock_fold(f32x16 (&acc)[WM][WN], f32x16 (&tot)[WM][WN]) {
+#pragma unroll
+  for (int i = 0; i < WM; i++)
+#pragma unroll
+    for (int j = 0; j < WN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        tot[i][j][e] += acc[i][j][e];
+        acc[i][j][e] = 0.f;
+      }
+}
+template <int WM, int WN>
+__device__ __attribute__((always_inline)) inline void kblock_finish(f32x16 (&acc)[WM][WN], const f32x16 (&tot)[WM][WN]) {
+#pragma unroll
+  for (int i = 0; i < WM; i++)
+#pragma unroll
+    for (int j = 0; j < WN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] += tot[i][j][e];
+}
+
 // Reduction order of the 3x3 forward / data-gradient forms: k-tile index -> (tap, 32-channel chunk).
 // Chunk-PAIR major, tap, then the two chunks of the pair: consecutive k-tiles read the two 64-byte halves of the same
 // 128-byte lines of a pixel (full-line use of L2), and the 9 taps of a chunk pair are 18 consecutive k-tiles (L2/L1 reuse
@@ -634,7 +661,7 @@ inline bool splitk_by_xcd(const crog_gemm_desc& d) {
 }
 
 template <typename T, int AL, int BL, bool HWTR, typename S>
-__global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))) gemm_kernel(const crog_gemm_desc p) {
+__global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? (sizeof(T) == 4 ? 2 : 3) : (sizeof(T) == 4 ? 3 : 4)))) gemm_kernel(const crog_gemm_desc p) {
   using Cfg = TileCfg<T>;
   constexpr int BK = Cfg::BK, NT = S::NT, BM = S::BM, BN = S::BN, WM = S::WM, WN = S::WN, WVN = S::WVN, WVM = S::WVM;
   using ALd = typename ALoaderSel<T, AL, BM, NT>::type;
@@ -682,6 +709,16 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))
     for (int j = 0; j < WN; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  constexpr bool KBLOCK = sizeof(T) == 4;
+  f32x16 tot[KBLOCK ? WM : 1][KBLOCK ? WN : 1];
+  if constexpr (KBLOCK) {
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+      for (int j = 0; j < WN; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) tot[i][j][e] = 0.f;
+  }
 
   // Reduction order.  For the 3x3 forward / data-gradient kernels the k-tiles are visited channel-chunk-major, tap-minor
   // (the 9 taps of one 32-channel chunk back to back): the 9 shifted reads of the same pixels then hit L1/L2 instead of
@@ -742,9 +779,13 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? 3 : 4))
       la.store(reinterpret_cast<T*>(smem + (cur ^ 1) * OPA));
       lb.store(reinterpret_cast<T*>(smem + 2 * OPA + (cur ^ 1) * OPB));
     }
+    if constexpr (KBLOCK) {
+      if (((kt - kt0 + 1) % KBLOCK_F32) == 0) kblock_fold<WM, WN>(acc, tot);
+    }
     __syncthreads();
     cur ^= 1;
   }
+  if constexpr (KBLOCK) kblock_finish<WM, WN>(acc, tot);
   if (do_asum) flush_a_sum<WM>(asum, p.a_sum, m0 + wr * WM * 32, p.M, lane);
 
   gemm_epilogue<T, S>(acc, p, smem, m0, n0, zs, coff);
@@ -1080,7 +1121,8 @@ using ShapeMidBwd = Shape<2, 2, 2, 2, true, 0, true>;   // 128 x 128 data gradie
 // ASUM: the launch also accumulates a_sum[m] += sum_k A(m, k) (bias gradient inside a weight-gradient GEMM); a template flag so
 // that the main loop of every other launch is one basic block
 template <typename T, int AL, int BL, typename S, int ASUM>
-__global__ void __launch_bounds__(S::NT, dma_blocks_per_cu<S>()) gemm_dma_kernel(const crog_gemm_desc p) {
+__global__ void __launch_bounds__(S::NT, (sizeof(T) == 4 && dma_blocks_per_cu<S>() > 2 ? dma_blocks_per_cu<S>() - 1 : dma_blocks_per_cu<S>()))
+gemm_dma_kernel(const crog_gemm_desc p) {   // (fp32 carries a second accumulator set, KBLOCK_F32: one block per CU less)
   constexpr int DMA_NSTAGE = dma_nstage<S>();
   constexpr int NW = S::NT / 64, NIA = S::BM / (16 * NW), NIB = S::BN / (16 * NW);   // 1-KiB DMA slices per wave and k-tile
   static_assert(NIA >= 1 && NIB >= 1 && NIA * 16 * NW == S::BM && NIB * 16 * NW == S::BN, "every wave must move whole 1 KiB slices of both tiles");
@@ -1127,6 +1169,16 @@ __global__ void __launch_bounds__(S::NT, dma_blocks_per_cu<S>()) gemm_dma_kernel
     for (int j = 0; j < WN; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  constexpr bool KBLOCK = sizeof(T) == 4;     // fp32: k-blocked accumulation (KBLOCK_F32)
+  f32x16 tot[KBLOCK ? WM : 1][KBLOCK ? WN : 1];
+  if constexpr (KBLOCK) {
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+      for (int j = 0; j < WN; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) tot[i][j][e] = 0.f;
+  }
 
   // channel-chunk-major, tap-minor reduction order for the 3x3 forward / data-gradient forms (see gemm_kernel)
   auto kmem_of = [&](int kt) -> int {   // no builtins inside: safe for the host pass (see dma_issue)
@@ -1261,8 +1313,12 @@ __global__ void __launch_bounds__(S::NT, dma_blocks_per_cu<S>()) gemm_dma_kernel
 #pragma unroll
         for (int j = 0; j < WN; j++) mma16(fa[i], fb[j], acc[i][j]);
     }
+    if constexpr (KBLOCK) {
+      if (((t + 1) % KBLOCK_F32) == 0) kblock_fold<WM, WN>(acc, tot);
+    }
     stage = stage == DMA_NSTAGE - 1 ? 0 : stage + 1;
   }
+  if constexpr (KBLOCK) kblock_finish<WM, WN>(acc, tot);
   }
 #undef CROG_KMEM
   if (do_asum) flush_a_sum<WM>(asum, p.a_sum, m0 + wr * WM * 32, p.M, lane);

@@ -49,14 +49,16 @@ class SyncBNComm:
         if direct is None:
             direct = _os.environ.get("CROG_SYNCBN_DIRECT", "0") == "1"
         if direct and torch.cuda.is_available() and dist.get_backend(group) == "nccl":
-            try:
-                from .rccl import RcclComm
-                self.direct = RcclComm(group)
+            # RcclComm.create is collective and its verdict is the same on every rank (a MIN all-reduce after each step that can fail
+            # one-sidedly): either all ranks get the direct communicator or all of them fall back, so the ranks can never disagree
+            # about the collectives that follow (the dedicated torch group below is created by all of them or by none)
+            from .rccl import RcclComm
+            self.direct, err = RcclComm.create(group)
+            if self.direct is not None:
                 self.kind = "rccl-direct"
-            except Exception as e:      # any set-up problem: keep training on the torch path
+            else:
                 import warnings
-                warnings.warn(f"crog_amd: direct RCCL communicator unavailable ({e!r}); SyncBatchNorm uses torch.distributed")
-                self.direct = None
+                warnings.warn(f"crog_amd: direct RCCL communicator unavailable ({err!r}); SyncBatchNorm uses torch.distributed on every rank")
 
     def all_reduce_sum(self, t: torch.Tensor):
         self.calls += 1
@@ -83,7 +85,7 @@ def convert_sync_batchnorm(model, process_group=None, force=False, dedicated_gro
             group = dist.new_group()
         RT.comm = SyncBNComm(group, direct=use_direct)
         if RT.comm.direct is None and use_direct and group is None and dedicated_group and dist.get_world_size() > 1:
-            RT.comm.group = dist.new_group()     # direct set-up failed on every rank alike: fall back to a dedicated torch group
+            RT.comm.group = dist.new_group()     # the direct set-up failed, on every rank alike (RcclComm.create): a dedicated torch group
         RT.comm.force = force
     return model
 

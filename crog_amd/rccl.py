@@ -14,7 +14,8 @@ because it has never run with real peers (a set-up problem falls back to torch; 
 
 RCCL is the library PyTorch-ROCm already has resident (`torch/lib/librccl.so`); the unique id is created on rank 0 and handed to the
 other ranks through the existing `torch.distributed` group, which is also what the gradient buckets keep using (they are large,
-asynchronous and belong on a side stream).  If anything in the set-up fails, `crog_amd.parallel` falls back to a torch process group.
+asynchronous and belong on a side stream).  If anything in the set-up fails ON ANY RANK, every rank learns it (RcclComm.create) and
+`crog_amd.parallel` falls back to a torch process group on all ranks alike.
 """
 from __future__ import annotations
 
@@ -58,26 +59,62 @@ def _check(rc: int, what: str):
         raise RuntimeError(f"RCCL {what} failed: {_load().ncclGetErrorString(rc).decode()} ({rc})")
 
 
-class RcclComm:
-    """ncclComm over the ranks of a torch.distributed group (default: all ranks).  Construction is a collective call."""
+def _all_agree(ok: bool, group, dev) -> bool:
+    """True only when EVERY rank of the group reports ok (a MIN all-reduce over the torch group that carries the set-up)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        flag = flag.to(dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
 
-    def __init__(self, group=None, device=None):
-        lib = _load()
-        self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
+
+class RcclComm:
+    """ncclComm over the ranks of a torch.distributed group (default: all ranks).  Construction is a collective call; use
+    `RcclComm.create`, whose outcome is the SAME on every rank: a communicator everywhere, or None everywhere."""
+
+    @classmethod
+    def create(cls, group=None, device=None):
+        """Set-up with a collective verdict.  Every step that can fail on a subset of the ranks (loading librccl, ncclGetUniqueId
+        on rank 0, ncclCommInitRank) is followed by a MIN all-reduce of an ok flag over the torch group, and no rank enters the next
+        collective step unless all ranks passed the previous one - so a one-sided failure can neither leave some ranks waiting in a
+        broadcast / ncclCommInitRank the others never enter, nor make the ranks disagree on which communicator BatchNorm uses."""
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self = cls.__new__(cls)
+        self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
+        self._comm = ctypes.c_void_p()
+        self._lib = None
+        err = None
         uid = _UniqueId()
-        if self.rank == 0:
-            _check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        try:
+            self._lib = _load()
+            if self.rank == 0:
+                _check(self._lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        except Exception as e:
+            err = e
+        if not _all_agree(err is None, group, dev):
+            return None, err or RuntimeError("direct RCCL set-up failed on another rank")
+        # every rank has the library and rank 0 an id: hand the id out over the existing group (always entered by all ranks)
         wire = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
         if dist.get_backend(group) == "nccl":
             wire = wire.to(dev)
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast(wire, src=src, group=group)
         ctypes.memmove(ctypes.byref(uid), bytes(wire.cpu().tolist()), 128)
-        self._comm = ctypes.c_void_p()
-        with torch.cuda.device(dev):
-            _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world_size, uid, self.rank), "ncclCommInitRank")
-        self._lib = lib
+        try:
+            with torch.cuda.device(dev):
+                _check(self._lib.ncclCommInitRank(ctypes.byref(self._comm), self.world_size, uid, self.rank), "ncclCommInitRank")
+        except Exception as e:
+            err = e
+        if not _all_agree(err is None, group, dev):
+            self.close()
+            return None, err or RuntimeError("ncclCommInitRank failed on another rank")
+        return self, None
+
+    def __init__(self, group=None, device=None):
+        comm, err = RcclComm.create(group, device)
+        if comm is None:
+            raise err
+        self.__dict__.update(comm.__dict__)
 
     def all_reduce_sum(self, t: torch.Tensor):
         """In-place fp32 sum over the ranks, enqueued on the stream the caller's kernels run on."""
@@ -86,6 +123,6 @@ class RcclComm:
         _check(self._lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), NCCL_FLOAT32, NCCL_SUM, self._comm, K.stream()), "ncclAllReduce")
 
     def close(self):
-        if self._comm:
+        if self._comm and self._lib is not None:
             self._lib.ncclCommDestroy(self._comm)
             self._comm = ctypes.c_void_p()

@@ -130,6 +130,39 @@ def run_case(name, cfg, B, seed, ref_model, ref_clip, store_intermediates, resid
     return model
 
 
+PINNED_GRADS = ("bn1.weight", "ln_final", "norm.weight", "txt.bias", "vis.4.bias", "attnpool.c_proj.bias", "norm_layer.0.bias")
+
+
+def run_case_bf16(name, cfg, B, seed, ref_model, ref_clip, residual_gain=1.0):
+    """The yardstick for the benchmarked dtype: the REFERENCE's own training step under bf16 autocast (crog_engine.py:72-73 runs the
+    forward under amp.autocast(); here torch.autocast("cpu", dtype=torch.bfloat16), the only autocast this container can execute) on
+    the weights / inputs of the fp32 fixture `name`.  Stored next to it as `name`_bf16ref: logits, losses, gradient norms and the
+    pinned small gradients - what a correct bf16 implementation's distance to the fp32 result looks like."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    model, groups = build_reference(cfg, ref_model, ref_clip)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(seeded_state(shapes, seed=seed, residual_gain=residual_gain))
+    batch = synthetic_batch(B, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + seed)
+    model.train()
+    model.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        preds, tgts, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
+    loss.backward()
+    out = {}
+    for i, nm in enumerate(["ins", "qua", "sin", "cos", "wid"]):
+        if preds[i] is not None:
+            out["pred_" + nm] = preds[i].float()
+    out["loss_total"] = loss.detach().float()
+    out["loss_items"] = torch.tensor([loss_dict[k] for k in ("m_ins", "m_qua", "m_sin", "m_cos", "m_wid")])
+    out["grad_norms"] = torch.tensor([float(p.grad.float().norm()) if p.grad is not None else -1.0 for _, p in model.named_parameters()])
+    for n, p in model.named_parameters():
+        if p.grad is not None and p.numel() <= 4096 and any(t in n for t in PINNED_GRADS):
+            out["grad::" + n] = p.grad.float()
+    np.savez_compressed(os.path.join(GOLD, name + "_bf16ref.npz"), **{k: v.detach().numpy() for k, v in out.items()})
+    print(name + "_bf16ref", "loss", float(loss.detach()), "pred dtype", preds[0].dtype, flush=True)
+
+
 def op_fixtures(ref_clip, ref_layers):
     """Per-op pins from the reference classes at small shapes (weights + input + output + input grad)."""
     torch.manual_seed(7)
@@ -460,6 +493,10 @@ def main():
         # oracle/make_fp64.py); with four samples the reference is 1.7e-4 from exact and 1e-3 absolute is a meaningful bound
         run_case("crog_r50_b4_damped", make_cfg(dropout=0.0), B=4, seed=10, ref_model=ref_model, ref_clip=ref_clip,
                  store_intermediates=False, residual_gain=0.25)
+    if "bf16ref" in which:
+        # (not in the default list: ~10 minutes of emulated bf16 on the build container's CPU)
+        run_case_bf16("tiny_crog", tiny_cfg(), B=4, seed=3, ref_model=ref_model, ref_clip=ref_clip)
+        run_case_bf16("crog_r50_b4_damped", make_cfg(dropout=0.0), B=4, seed=10, ref_model=ref_model, ref_clip=ref_clip, residual_gain=0.25)
     if "shapes" in which:
         shapes_only(ref_clip)
     if "full" in which:

@@ -97,3 +97,62 @@ def test_reducer_matches_single_process(tmp_path):
     assert 0 < rel < 2 ** -7, rel
     ref = torch.stack([I.sum((0, 2, 3)), (I * I).sum((0, 2, 3))], 1)
     assert torch.allclose(r0["pairs"], ref, atol=1e-4)
+
+
+class _FakeRccl:
+    """Stands in for librccl in the set-up protocol test: every call succeeds unless told to fail on this rank."""
+
+    def __init__(self, fail_uid=False, fail_init=False):
+        self.fail_uid, self.fail_init = fail_uid, fail_init
+        self.destroyed = 0
+
+    def ncclGetUniqueId(self, _p):
+        return 1 if self.fail_uid else 0
+
+    def ncclCommInitRank(self, comm_p, world, uid, rank):
+        if self.fail_init:
+            return 5
+        comm_p._obj.value = 0x1234          # ctypes.byref(c_void_p): the handle the real library would write
+        return 0
+
+    def ncclCommDestroy(self, _c):
+        self.destroyed += 1
+        return 0
+
+    def ncclGetErrorString(self, rc):
+        return b"fake failure"
+
+
+def _setup_worker(rank, world, port, tmp):
+    """The direct-RCCL set-up verdict is collective (advisor, round 2): whatever fails, on whichever single rank, BOTH ranks return
+    None and nobody is left waiting in a collective the other never enters."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from crog_amd import rccl
+    outcomes = []
+    scenarios = [("load fails on rank 1", dict(load_fail=1)), ("unique id fails on rank 0", dict(uid_fail=0)),
+                 ("comm init fails on rank 0", dict(init_fail=0)), ("comm init fails on rank 1", dict(init_fail=1)), ("all fine", dict())]
+    for name, sc in scenarios:
+        fake = _FakeRccl(fail_uid=sc.get("uid_fail") == rank, fail_init=sc.get("init_fail") == rank)
+
+        def load(fake=fake, sc=sc):
+            if sc.get("load_fail") == rank:
+                raise OSError("librccl.so: cannot open shared object file")
+            return fake
+        rccl._load = load
+        comm, err = rccl.RcclComm.create(None, device="cpu")
+        outcomes.append((name, comm is not None, repr(err)[:60]))
+        if name != "all fine":
+            assert comm is None and err is not None, (rank, name)
+        else:
+            assert comm is not None and err is None and comm._comm.value == 0x1234
+        dist.barrier()          # both ranks are still in step: no rank is stuck in a collective of the previous scenario
+    torch.save(outcomes, os.path.join(tmp, f"setup{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_direct_rccl_setup_verdict_is_collective(tmp_path):
+    world, port = 2, 31000 + os.getpid() % 2000
+    mp.start_processes(_setup_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    o0, o1 = torch.load(tmp_path / "setup0.pt"), torch.load(tmp_path / "setup1.pt")
+    assert [(n, ok) for n, ok, _ in o0] == [(n, ok) for n, ok, _ in o1]

@@ -111,6 +111,72 @@ def test_config1_crog_r50_fp32_on_reference_conditioned_weights(case):
         assert err(ev[0][i], g["eval_pred_" + nm]) < 1e-3, (nm, err(ev[0][i], g["eval_pred_" + nm]))
 
 
+GROUPS = (("backbone.visual", lambda n: n.startswith("backbone.visual")),
+          ("text tower", lambda n: n.startswith("backbone.") and not n.startswith("backbone.visual")),
+          ("neck", lambda n: n.startswith("neck.")), ("decoder", lambda n: n.startswith("decoder.")), ("proj", lambda n: n.startswith("proj.")))
+
+
+def bf16_distances(preds, loss, grads_by_name, g32, names):
+    """Distances of a bf16 result to the reference's fp32 fixture `g32`: logits RMS, |loss difference|, per parameter group the median
+    and 90th percentile of |norm / norm_fp32 - 1| over its parameter gradients, and 1 - cosine of the pinned small gradients."""
+    out = {}
+    d = torch.cat([(preds[i].float().cpu() - g32["pred_" + nm]).flatten() for i, nm in enumerate(NAMES)])
+    out["logit_rms"] = float(d.pow(2).mean().sqrt())
+    out["loss"] = abs(float(loss) - float(g32["loss_total"]))
+    ref = g32["grad_norms"]
+    gn = torch.tensor([float(grads_by_name[n]) if n in grads_by_name else -1.0 for n in names])
+    ok = (ref > 1e-12) & (gn >= 0)
+    dev = (gn / ref.clamp_min(1e-30) - 1).abs()
+    for gname, pred in GROUPS:
+        sel = torch.tensor([pred(n) for n in names]) & ok
+        if sel.any():
+            out["gnorm_med:" + gname] = float(dev[sel].median())
+            out["gnorm_p90:" + gname] = float(dev[sel].quantile(0.9))
+    return out
+
+
+def test_bf16_training_step_against_the_reference_under_bf16_autocast():
+    """The benchmarked dtype, pinned against the reference: `crog_r50_b4_damped_bf16ref` is the reference's own forward + backward
+    under torch.autocast(bfloat16) (crog_engine.py:72-73 runs the training forward under amp.autocast; CPU autocast is the form this
+    container can execute - oracle/make_golden.py bf16ref) on the weights and inputs of the fp32 fixture `crog_r50_b4_damped`.
+    Its distance to the fp32 fixture is what a CORRECT bf16 implementation costs; the HIP bf16 path (dropout 0, same weights, same
+    batch) must be no further from the fp32 fixture than 1.5x that, metric by metric: logits RMS, loss, gradient-norm deviation per
+    parameter group (median and 90th percentile), cosine of the pinned small gradients."""
+    from crog_amd.model import build_crog
+    case = "crog_r50_b4_damped"
+    g32, meta = load_case(case)
+    gbf = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, case + "_bf16ref.npz")).items()}
+    names = meta["param_names"]
+    cfg = make_cfg(dropout=0.0)
+    model, _ = build_crog(cfg)
+    model.load_state_dict(seeded_state({k: tuple(v) for k, v in meta["shapes"].items()}, seed=meta["seed"], residual_gain=meta["residual_gain"]))
+    model = model.cuda()
+    model.compute_dtype = torch.bfloat16
+    model.prepare().train()
+    b = {k: v.cuda() for k, v in synthetic_batch(meta["B"], cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + meta["seed"]).items()}
+    preds, tgts, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    hip = bf16_distances(preds, loss.detach(), {n: params[n].grad.float().norm() for n in names if params[n].grad is not None}, g32, names)
+    refd = bf16_distances([gbf["pred_" + nm] for nm in NAMES], gbf["loss_total"],
+                          {n: gbf["grad_norms"][i] for i, n in enumerate(names) if gbf["grad_norms"][i] >= 0}, g32, names)
+    for k in g32:
+        if k.startswith("grad::") and k in gbf:
+            r = g32[k].flatten()
+            cos = lambda a: float(1 - torch.dot(a.flatten().float(), r) / (a.float().norm() * r.norm() + 1e-30))
+            hip["1-cos:" + k[6:]] = cos(params[k[6:]].grad.detach().cpu())
+            refd["1-cos:" + k[6:]] = cos(gbf[k])
+    worst = {}
+    for k in sorted(hip):
+        floor = {"logit_rms": 1e-4, "loss": 2e-3}.get(k, 2e-3 if k.startswith("gnorm") else 2e-4)
+        lim = 1.5 * refd[k] + floor
+        print(f"  {k:45s} HIP bf16 {hip[k]:.3e}   reference bf16 {refd[k]:.3e}   bound {lim:.3e}")
+        if hip[k] > lim:
+            worst[k] = (hip[k], refd[k])
+    assert not worst, worst
+
+
 def _r50_b32(dtype, dropout, steps, seed=9):
     """CROG-R50 at the benchmark shape (B = 32, 416 x 416, 20 tokens) on damped seeded weights: `steps` train_step calls.
     Returns per-step (loss, iou, prec) lists, the BatchNorm running statistics and the parameters after the last step."""
