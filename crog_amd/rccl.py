@@ -101,7 +101,8 @@ class RcclComm:
         dist.broadcast(wire, src=src, group=group)
         ctypes.memmove(ctypes.byref(uid), bytes(wire.cpu().tolist()), 128)
         try:
-            with torch.cuda.device(dev):
+            import contextlib
+            with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
                 _check(self._lib.ncclCommInitRank(ctypes.byref(self._comm), self.world_size, uid, self.rank), "ncclCommInitRank")
         except Exception as e:
             err = e
