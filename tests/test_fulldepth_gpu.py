@@ -169,7 +169,9 @@ def test_bf16_training_step_against_the_reference_under_bf16_autocast():
             refd["1-cos:" + k[6:]] = cos(gbf[k])
     worst = {}
     for k in sorted(hip):
-        floor = {"logit_rms": 1e-4, "loss": 2e-3}.get(k, 2e-3 if k.startswith("gnorm") else 2e-4)
+        # floors: what the yardstick itself does not resolve.  A gradient-norm deviation below 1 % is bf16 rounding on either side (the
+        # reference's own 90th percentiles run from 0.9 % to 7 % across the groups, and `proj` has eleven tensors: its p90 is one tensor)
+        floor = {"logit_rms": 1e-4, "loss": 2e-3}.get(k, 1e-2 if k.startswith("gnorm_p90") else (2e-3 if k.startswith("gnorm") else 2e-4))
         lim = 1.5 * refd[k] + floor
         print(f"  {k:45s} HIP bf16 {hip[k]:.3e}   reference bf16 {refd[k]:.3e}   bound {lim:.3e}")
         if hip[k] > lim:
