@@ -47,9 +47,9 @@ def test_config1_crog_r50_fp32_on_reference_conditioned_weights(case):
     * B = 2 (the configuration's own batch): neck.txt_proj is a BatchNorm1d over TWO samples (layers.py:14-16), which amplifies
       rounding ~60x on its own; the reference's fp32 logits sit 1.0-1.3e-3 (max) from the float64 value on this very input
       (tests/golden/crog_r50_b2_damped_fp64.npz, oracle/make_fp64.py), so two correct fp32 implementations differ by more than
-      1e-3 here.  Bound: the HIP path is no further from the exact result than three times the reference's own distance
-      (measured 2.5x: the amplified quantity is the summation order of the trunk's fp32 accumulations, which differs between a
-      blocked CPU GEMM and sequential-k MFMA), and within 1e-3 of the reference RELATIVE to the logit scale; loss within 1e-4."""
+      1e-3 here in general.  Bound: the HIP path is no further from the exact result than 1.5x the reference's own distance
+      (measured 0.65x since the fp32 GEMMs accumulate k-blocked - partial sums of 128, as a blocked CPU GEMM does; one sequential-k
+      MFMA chain measured 2.5x), and - measured 4.9e-4 - within 1e-3 ABSOLUTE of the reference here too; loss within 1e-4."""
     from crog_amd.model import build_crog
     g, meta = load_case(case)
     assert meta["residual_gain"] == 0.25
@@ -78,8 +78,8 @@ def test_config1_crog_r50_fp32_on_reference_conditioned_weights(case):
             e_hip = float((preds[i].double().cpu() - truth).abs().max())
             e_ref = float((g["pred_" + nm].double() - truth).abs().max())
             print(f"  {nm}: distance to the float64 result: HIP {e_hip:.2e}, reference fp32 {e_ref:.2e}")
-            assert e_hip < 3.0 * e_ref, (nm, e_hip, e_ref)
-            assert errs[nm] < 1e-3 * max(1.0, mags[nm]), (nm, errs[nm], mags[nm])
+            assert e_hip < 1.5 * e_ref, (nm, e_hip, e_ref)      # measured 0.65x with k-blocked fp32 accumulation (2.5x with one sequential-k chain)
+            assert errs[nm] < 1e-3, (nm, errs[nm], mags[nm])     # north_star's bound as written, at the configuration's own batch size
     for nm in NAMES:
         assert err(tgts[NAMES.index(nm)], g["tgt_" + nm]) == 0
     assert dl < 1e-4, dl

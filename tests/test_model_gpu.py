@@ -376,7 +376,8 @@ def test_config1_crog_r50_fp32_matches_reference():
     # The reference's own fp32 CPU logits sit 3.1e-3..3.8e-3 (max abs) from the exact (fp64) value on this input
     # (tests/golden/crog_r50_b2_fp64.npz, oracle in float64): logits reach +-12 and the random gain-1 trunk amplifies
     # rounding ~5000x.  1e-3 is therefore applied relative to the logit scale, and the HIP path must stay within
-    # 3x of the reference's own distance to the exact result.
+    # 1.5x of the reference's own distance to the exact result (3x until round 3: the fp32 GEMMs now accumulate k-blocked, partial sums
+    # of 128 as a blocked CPU GEMM forms them, instead of one sequential-k chain).
     for e, m in zip(errs, mags):
         assert e < 1e-3 * max(1.0, m), (errs, mags)
     t64 = np.load(os.path.join(GOLD, "crog_r50_b2_fp64.npz"))
@@ -384,7 +385,8 @@ def test_config1_crog_r50_fp32_matches_reference():
         truth = torch.from_numpy(t64["pred_" + nm])
         e_hip = float((preds[i].double().cpu() - truth).abs().max())
         e_ref = float((g["pred_" + nm].double() - truth).abs().max())
-        assert e_hip < 3.0 * e_ref, (nm, e_hip, e_ref)
+        print(f"  {nm}: distance to the float64 result: HIP {e_hip:.2e}, reference fp32 {e_ref:.2e}")
+        assert e_hip < 1.5 * e_ref, (nm, e_hip, e_ref)
     assert abs(float(loss.detach()) - float(g["loss_total"])) < 1e-3   # logits carry ~6e-3 of amplified fp32 noise (see above)
     params = dict(model.named_parameters())
     gn = torch.tensor([float(params[n].grad.norm()) for n in meta["param_names"]])
@@ -394,7 +396,9 @@ def test_config1_crog_r50_fp32_matches_reference():
     names = meta["param_names"]
     text_side = torch.tensor([("transformer" in n or "token_embedding" in n or "text_projection" in n or "ln_final" in n
                                or n == "backbone.positional_embedding" or "txt_proj" in n) for n in names])
-    tight = ((gn - ref).abs() > 8e-2 * ref + 2e-5) & ~text_side  # ReLU knife-edge flips move trunk gradients by a few % (see tiny test)
+    rel = ((gn - ref).abs() / (ref + 1e-6))[~text_side]
+    print("config-1 worst relative gradient-norm error, image / neck / decoder / head side: %.2e" % float(rel.max()))
+    tight = ((gn - ref).abs() > 3e-2 * ref + 2e-5) & ~text_side  # ReLU knife-edge flips move trunk gradients by a few % (see tiny test)
     assert not tight.any(), [(names[i], float(gn[i]), float(ref[i])) for i in tight.nonzero().flatten()[:8]]
 
 
