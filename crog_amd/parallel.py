@@ -25,18 +25,31 @@ import os as _os
 _DRY = _os.environ.get("CROG_DDP_DRY") == "1"   # diagnostics: run the reducer's bookkeeping without issuing collectives
 
 
+def _direct_mode(direct):
+    """direct / CROG_SYNCBN_DIRECT -> (rccl, peer): which transports of the C-ABI communicator (crog_amd/rccl.py) to build.
+    "peer": the one-shot hipIpc mailbox exchange only (any torch backend carries the set-up: two test ranks on one GPU use gloo);
+    "rccl" / "1" / True: ncclAllReduce on the compute stream; "both": mailbox for what fits a slot, RCCL for the rest."""
+    if direct is None:
+        direct = _os.environ.get("CROG_SYNCBN_DIRECT", "0")
+    if direct in (False, "0", "", "off"):
+        return False, False
+    if direct == "peer":
+        return False, True
+    if direct == "both":
+        return True, True
+    return True, False
+
+
 class SyncBNComm:
     """Communicator of the cross-replica BatchNorm statistics (train_crog.py:113-114).  The exchanges are on the critical path (142
     per CROG step, 2·C floats each), so they avoid both the gradient buckets' communicator — collectives of one communicator execute in
-    issue order, and a statistics exchange would queue behind whatever 64 MiB bucket is in flight — and, on RCCL, torch.distributed's
-    stream/event fencing: `direct` = an RCCL communicator of our own whose all-reduce is enqueued on the compute stream itself
-    (crog_amd/rccl.py).  OPT-IN (CROG_SYNCBN_DIRECT=1 or direct=True).  Measured at world size 1, the only size this build could
-    measure: the direct calls are the cheaper ones (1.2 us of host time and no GPU work per call against 7.7 us + a 9.5 us stream
-    round trip for torch's; the gap between the two BatchNorm-backward kernels drops from 12.8 us to 0) and the forced-DDP step is
-    35.1-35.6 ms with them against 35.8-36.2 ms on torch's groups (plain step 33.9 ms, 34.8 ms with the gradient buckets alone).
-    (An earlier measurement had the direct form 1.7 ms SLOWER: a communicator's stream created before the weight-gradient stream
-    pushed the latter onto the main stream's hardware queue — Runtime.ensure_streams now fixes the creation order.)  It stays opt-in
-    because it has never run with real peers.
+    issue order, and a statistics exchange would queue behind whatever 64 MiB bucket is in flight — and, with `direct`, torch.distributed's
+    stream/event fencing: `direct` = the C-ABI communicator (include/crog_hip.h crog_comm_*, crog_amd/rccl.py) whose exchange is
+    enqueued on the compute stream itself, either as ONE single-block kernel per rank (peer writes into hipIpc mailboxes: one hop
+    instead of a ring) or as an ncclAllReduce.  OPT-IN (CROG_SYNCBN_DIRECT=peer | rccl | both, or direct=...).  Measured at world size
+    1, the only size a box of this pool has: the direct RCCL calls cost 1.2 us of host time and no GPU work per call against 7.7 us + a
+    9.5 us stream round trip for torch's, and the forced-DDP step is 35.1-35.6 ms with them against 35.8-36.2 ms on torch's groups.  The
+    mailbox exchange is validated with two processes sharing one GPU (tests/test_ddp2_gpu.py); neither has run across xGMI.
     Default: a torch process group of its own (also the gloo path)."""
 
     def __init__(self, group=None, direct=None):
@@ -46,46 +59,53 @@ class SyncBNComm:
         self.calls = 0          # collectives issued (bench.py reports the per-step count)
         self.direct = None
         self.kind = "torch.distributed"
-        if direct is None:
-            direct = _os.environ.get("CROG_SYNCBN_DIRECT", "0") == "1"
-        if direct and torch.cuda.is_available() and dist.get_backend(group) == "nccl":
-            # RcclComm.create is collective and its verdict is the same on every rank (a MIN all-reduce after each step that can fail
+        rccl, peer = _direct_mode(direct)
+        rccl = rccl and dist.get_backend(group) == "nccl"
+        if (rccl or peer) and torch.cuda.is_available():
+            # DirectComm.create is collective and its verdict is the same on every rank (a MIN all-reduce after each step that can fail
             # one-sidedly): either all ranks get the direct communicator or all of them fall back, so the ranks can never disagree
             # about the collectives that follow (the dedicated torch group below is created by all of them or by none)
-            from .rccl import RcclComm
-            self.direct, err = RcclComm.create(group)
+            from .rccl import DirectComm
+            self.direct, err = DirectComm.create(group, rccl=rccl, peer=peer)
             if self.direct is not None:
-                self.kind = "rccl-direct"
+                self.kind = "crog_comm:" + "+".join(k for k, on in (("rccl", rccl), ("peer", peer)) if on)
             else:
                 import warnings
-                warnings.warn(f"crog_amd: direct RCCL communicator unavailable ({err!r}); SyncBatchNorm uses torch.distributed on every rank")
+                warnings.warn(f"crog_amd: direct communicator unavailable ({err!r}); SyncBatchNorm uses torch.distributed on every rank")
 
     def all_reduce_sum(self, t: torch.Tensor):
         self.calls += 1
-        if self.direct is not None and t.is_cuda:
+        if self.direct is not None and t.is_cuda and (self.direct.has_rccl or t.numel() <= self._slot()):
             self.direct.all_reduce_sum(t)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    @staticmethod
+    def _slot():
+        from .rccl import SLOT_FLOATS
+        return SLOT_FLOATS
 
 
 def convert_sync_batchnorm(model, process_group=None, force=False, dedicated_group=True, direct=None):
     """nn.SyncBatchNorm.convert_sync_batchnorm equivalent: BatchNorm statistics of the HIP path become cross-replica.
     `force` installs the communicator even at world_size 1 (single-GPU smoke test of the collective path).  A collective call:
     every rank converts its model (as with the reference's conversion), because the statistics get a communicator of their own —
-    a direct RCCL one on the nccl backend when asked for, otherwise a dedicated torch process group (world size > 1; at world size 1
-    `CROG_SYNCBN_OWN_GROUP=1` forces it for A/B runs: 36.0 vs 35.8-36.2 ms on the default group, i.e. free once the stream creation
-    order is fixed).  Collectives of one communicator run in issue order, so on the default group every statistics exchange issued
-    while a 64 MiB gradient bucket is in flight (nine per step, ~0.4 ms each at 8 GPUs) would wait for it on the critical path."""
+    the C-ABI one when asked for (`direct`, CROG_SYNCBN_DIRECT), otherwise a dedicated torch process group (world size > 1; at world
+    size 1 `CROG_SYNCBN_OWN_GROUP=1` forces it for A/B runs: 36.0 vs 35.8-36.2 ms on the default group, i.e. free once the stream
+    creation order is fixed).  Collectives of one communicator run in issue order, so on the default group every statistics exchange
+    issued while a 64 MiB gradient bucket is in flight (nine per step, ~0.4 ms each at 8 GPUs) would wait for it on the critical path."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force):
         RT.ensure_streams()       # the side streams take their hardware queues before the communicator's streams exist
-        use_direct = (_os.environ.get("CROG_SYNCBN_DIRECT", "0") == "1") if direct is None else direct
-        use_direct = use_direct and torch.cuda.is_available() and dist.get_backend(process_group) == "nccl"
+        rccl, peer = _direct_mode(direct)
+        use_direct = ((rccl and dist.get_backend(process_group) == "nccl") or peer) and torch.cuda.is_available()
         group = process_group
-        if group is None and dedicated_group and not use_direct and (dist.get_world_size() > 1 or _os.environ.get("CROG_SYNCBN_OWN_GROUP") == "1"):
+        need_group = dedicated_group and (dist.get_world_size() > 1 or _os.environ.get("CROG_SYNCBN_OWN_GROUP") == "1")
+        if group is None and need_group and not (use_direct and rccl):
+            # (a peer-only communicator still needs a torch group for exchanges larger than a mailbox slot)
             group = dist.new_group()
-        RT.comm = SyncBNComm(group, direct=use_direct)
-        if RT.comm.direct is None and use_direct and group is None and dedicated_group and dist.get_world_size() > 1:
-            RT.comm.group = dist.new_group()     # the direct set-up failed, on every rank alike (RcclComm.create): a dedicated torch group
+        RT.comm = SyncBNComm(group, direct=direct if use_direct else False)
+        if RT.comm.direct is None and use_direct and rccl and group is None and need_group:
+            RT.comm.group = dist.new_group()     # the direct set-up failed, on every rank alike (DirectComm.create): a dedicated torch group
         RT.comm.force = force
     return model
 

@@ -1,62 +1,31 @@
-"""A direct RCCL communicator for the SyncBatchNorm statistics exchange (`crog_comm_init` / `crog_syncbn_stats`).
+"""The C-ABI communicator of the data-parallel step (include/crog_hip.h: crog_comm_*, csrc/comm.hip) as a Python
+object: RCCL for gradient buckets, a one-shot peer-write all-reduce (hipIpc mailboxes) for the SyncBatchNorm statistics.
 
-Why not `torch.distributed.all_reduce` for this one: ProcessGroupNCCL runs every collective on a stream of its own and fences it
-with two event hops (compute stream -> communicator stream -> compute stream) plus ~25 us of host work.  The CROG step issues 142
-statistics exchanges of 2·C floats each, ALL on the critical path (BatchNorm cannot apply before the global sums exist): measured at
-world size 1, where the collective itself is a no-op, that machinery alone costs 2.2 ms of a 37 ms step.  Here the exchange is one
-`ncclAllReduce` enqueued IN ORDER on the stream the BatchNorm kernels run on — no events, one ctypes call.
+Why not `torch.distributed.all_reduce` for the statistics: ProcessGroupNCCL runs every collective on a stream of its own and fences
+it with two event hops (compute stream -> communicator stream -> compute stream) plus ~25 us of host work, and the collective itself
+is a ring: 20-40 us of latency for 2·C floats.  The CROG step issues 142 such exchanges, ALL on the critical path (BatchNorm cannot
+apply before the global sums exist).  `crog_syncbn_stats` is one single-block kernel on the stream the BatchNorm kernels run on:
+peer writes into every rank's mailbox, a flag, a poll, a sum in rank order (bit-identical on all ranks).
 
-STATUS: opt-in (`CROG_SYNCBN_DIRECT=1`).  Measured at world size 1 (the only size this build has hardware for): the direct call costs
-1.2 us of host time and nothing on the GPU (an in-place single-rank all-reduce is a no-op) where torch's costs 7.7 us + a 9.5 us stream
-round trip (`scripts/probe_allreduce_host.py`), the BatchNorm-backward partial -> apply gap shrinks from 12.8 us to 0
-(`scripts/_ddp_gaps.sh`), and the forced-DDP step is 35.1-35.6 ms against 35.8-36.2 ms with torch's process groups.  Opt-in only
-because it has never run with real peers (a set-up problem falls back to torch; a hang would not).
+Set-up is collective and so is its VERDICT: after every step that can fail on a subset of the ranks (binding librccl, the unique id on
+rank 0, ncclCommInitRank, allocating / opening the hipIpc mailboxes) the ranks MIN-all-reduce an ok flag over the torch group that
+carries the set-up, and nobody enters the next collective step unless everybody passed the previous one.  `DirectComm.create` returns
+the same thing on every rank: a communicator, or None plus the reason (crog_amd.parallel then uses a torch process group everywhere).
 
-RCCL is the library PyTorch-ROCm already has resident (`torch/lib/librccl.so`); the unique id is created on rank 0 and handed to the
-other ranks through the existing `torch.distributed` group, which is also what the gradient buckets keep using (they are large,
-asynchronous and belong on a side stream).  If anything in the set-up fails ON ANY RANK, every rank learns it (RcclComm.create) and
-`crog_amd.parallel` falls back to a torch process group on all ranks alike.
+STATUS.  The peer-write exchange is validated with two processes sharing one GPU (tests/test_ddp2_gpu.py: bit-identical to the
+gloo exchange); RCCL with more than one rank has not run on this build's hardware (one GPU per box).  Both stay opt-in
+(CROG_SYNCBN_DIRECT=peer | rccl | 1): the default SyncBatchNorm exchange is a dedicated torch process group.
 """
 from __future__ import annotations
 
 import ctypes
-import os
 
 import torch
 import torch.distributed as dist
 
 from . import kernels as K
 
-NCCL_FLOAT32, NCCL_SUM = 7, 0          # ncclDataType_t / ncclRedOp_t (nccl.h; RCCL keeps NCCL's values)
-
-
-class _UniqueId(ctypes.Structure):
-    _fields_ = [("internal", ctypes.c_byte * 128)]
-
-
-_lib = None
-
-
-def _load():
-    global _lib
-    if _lib is None:
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        lib = ctypes.CDLL(path)
-        lib.ncclGetErrorString.restype = ctypes.c_char_p
-        lib.ncclGetErrorString.argtypes = [ctypes.c_int]
-        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
-        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
-        lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
-        for fn in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce, lib.ncclCommDestroy):
-            fn.restype = ctypes.c_int
-        _lib = lib
-    return _lib
-
-
-def _check(rc: int, what: str):
-    if rc != 0:
-        raise RuntimeError(f"RCCL {what} failed: {_load().ncclGetErrorString(rc).decode()} ({rc})")
+SLOT_FLOATS = 8192      # largest exchange that takes the mailbox path: 2·C floats x statistic replicas (C <= 2048)
 
 
 def _all_agree(ok: bool, group, dev) -> bool:
@@ -68,62 +37,97 @@ def _all_agree(ok: bool, group, dev) -> bool:
     return bool(int(flag.item()))
 
 
-class RcclComm:
-    """ncclComm over the ranks of a torch.distributed group (default: all ranks).  Construction is a collective call; use
-    `RcclComm.create`, whose outcome is the SAME on every rank: a communicator everywhere, or None everywhere."""
+def _wire(t: torch.Tensor, group, dev):
+    return t.to(dev) if dist.get_backend(group) == "nccl" else t
+
+
+class DirectComm:
+    """crog_comm over the ranks of a torch.distributed group (default: all ranks)."""
+
+    def __init__(self):
+        self._h = ctypes.c_void_p()
+        self.rank = self.world_size = 0
+        self.has_rccl = self.has_peer = False
+        self._lib = None
 
     @classmethod
-    def create(cls, group=None, device=None):
-        """Set-up with a collective verdict.  Every step that can fail on a subset of the ranks (loading librccl, ncclGetUniqueId
-        on rank 0, ncclCommInitRank) is followed by a MIN all-reduce of an ok flag over the torch group, and no rank enters the next
-        collective step unless all ranks passed the previous one - so a one-sided failure can neither leave some ranks waiting in a
-        broadcast / ncclCommInitRank the others never enter, nor make the ranks disagree on which communicator BatchNorm uses."""
-        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self = cls.__new__(cls)
+    def create(cls, group=None, device=None, rccl: bool = True, peer: bool = True, lib=None):
+        """-> (comm, None) on every rank, or (None, reason) on every rank.  rccl: build the RCCL communicator (needs one GPU per
+        rank); peer: build the hipIpc mailboxes of the one-shot statistics exchange.  `lib` replaces the C ABI (protocol tests)."""
+        if device is None:
+            dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        else:
+            dev = torch.device(device)
+        self = cls()
         self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
-        self._comm = ctypes.c_void_p()
-        self._lib = None
         err = None
-        uid = _UniqueId()
+        uid = (ctypes.c_char * 128)()
         try:
-            self._lib = _load()
-            if self.rank == 0:
-                _check(self._lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+            self._lib = lib if lib is not None else K.lib()
+            if rccl and self.rank == 0:
+                K.check(self._lib.crog_comm_unique_id(uid), "comm_unique_id")
         except Exception as e:
             err = e
         if not _all_agree(err is None, group, dev):
-            return None, err or RuntimeError("direct RCCL set-up failed on another rank")
-        # every rank has the library and rank 0 an id: hand the id out over the existing group (always entered by all ranks)
-        wire = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
-        if dist.get_backend(group) == "nccl":
-            wire = wire.to(dev)
+            return None, err or RuntimeError("communicator set-up failed on another rank")
         src = dist.get_global_rank(group, 0) if group is not None else 0
-        dist.broadcast(wire, src=src, group=group)
-        ctypes.memmove(ctypes.byref(uid), bytes(wire.cpu().tolist()), 128)
+        if rccl:        # every rank has the library and rank 0 an id: hand the id out over the existing group (entered by all ranks)
+            wire = _wire(torch.tensor(list(bytes(uid)), dtype=torch.uint8), group, dev)
+            dist.broadcast(wire, src=src, group=group)
+            ctypes.memmove(uid, bytes(wire.cpu().tolist()), 128)
         try:
             import contextlib
             with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
-                _check(self._lib.ncclCommInitRank(ctypes.byref(self._comm), self.world_size, uid, self.rank), "ncclCommInitRank")
+                K.check(self._lib.crog_comm_init(self.rank, self.world_size, uid if rccl else None, ctypes.byref(self._h)), "comm_init")
+            self.has_rccl = bool(rccl)
         except Exception as e:
             err = e
         if not _all_agree(err is None, group, dev):
             self.close()
-            return None, err or RuntimeError("ncclCommInitRank failed on another rank")
+            return None, err or RuntimeError("crog_comm_init failed on another rank")
+        if peer:
+            handle = (ctypes.c_char * 64)()
+            try:
+                K.check(self._lib.crog_comm_peer_handle(self._h, SLOT_FLOATS, handle), "comm_peer_handle")
+            except Exception as e:
+                err = e
+            if not _all_agree(err is None, group, dev):
+                self.close()
+                return None, err or RuntimeError("mailbox allocation failed on another rank")
+            mine = _wire(torch.tensor(list(bytes(handle)), dtype=torch.uint8), group, dev)
+            gathered = [torch.empty_like(mine) for _ in range(self.world_size)]
+            dist.all_gather(gathered, mine, group=group)
+            blob = b"".join(bytes(g.cpu().tolist()) for g in gathered)
+            try:
+                K.check(self._lib.crog_comm_peer_connect(self._h, blob), "comm_peer_connect")
+                self.has_peer = True
+            except Exception as e:
+                err = e
+            if not _all_agree(err is None, group, dev):
+                self.close()
+                return None, err or RuntimeError("opening a peer mailbox failed on another rank")
         return self, None
 
-    def __init__(self, group=None, device=None):
-        comm, err = RcclComm.create(group, device)
-        if comm is None:
-            raise err
-        self.__dict__.update(comm.__dict__)
-
     def all_reduce_sum(self, t: torch.Tensor):
-        """In-place fp32 sum over the ranks, enqueued on the stream the caller's kernels run on."""
+        """In-place fp32 sum over the ranks, enqueued on the stream the caller's kernels run on (crog_syncbn_stats)."""
         if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
-            raise TypeError("RcclComm.all_reduce_sum expects a contiguous fp32 GPU tensor")
-        _check(self._lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), NCCL_FLOAT32, NCCL_SUM, self._comm, K.stream()), "ncclAllReduce")
+            raise TypeError("DirectComm.all_reduce_sum expects a contiguous fp32 GPU tensor")
+        K.check(self._lib.crog_syncbn_stats(self._h, t.data_ptr(), t.numel(), K.stream()), "syncbn_stats")
+
+    def all_reduce_bucket(self, t: torch.Tensor, average: bool = True):
+        """In-place RCCL all-reduce of a gradient bucket (crog_allreduce_bucket) on the current stream."""
+        K.check(self._lib.crog_allreduce_bucket(self._h, t.data_ptr(), t.numel(), K.dcode(t), 1 if average else 0, K.stream()), "allreduce_bucket")
+
+    def timed_out(self) -> int:
+        """Sequence number of an exchange that gave up waiting for a peer (0 = none).  Synchronises the device."""
+        n = ctypes.c_int()
+        K.check(self._lib.crog_comm_status(self._h, ctypes.byref(n)), "comm_status")
+        return n.value
 
     def close(self):
-        if self._comm and self._lib is not None:
-            self._lib.ncclCommDestroy(self._comm)
-            self._comm = ctypes.c_void_p()
+        if self._h and self._lib is not None:
+            self._lib.crog_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+
+RcclComm = DirectComm      # the name rounds 1-2 used

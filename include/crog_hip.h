@@ -385,6 +385,32 @@ int crog_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, 
                        float beta2, float eps, float weight_decay, void* bf16_shadow, crog_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Collectives of the data-parallel step (csrc/comm.hip).  Replace torch.distributed / NCCL at
+ * train_crog.py:96-99 (init_process_group), :113-114 (SyncBatchNorm statistics), :154-156 (DDP gradient all-reduce) and
+ * crog_engine.py:88-90 (metric all-reduce).  One process per GPU; every call below is issued by all ranks in the same order.
+ *   crog_comm_unique_id  rank 0: 128 opaque bytes (ncclGetUniqueId) to hand to the other ranks by any side channel
+ *   crog_comm_init       RCCL communicator over `world` ranks on the current device; id128 == NULL creates a communicator without
+ *                        RCCL (peer mailbox only)
+ *   crog_comm_peer_handle / _connect   the one-shot peer-write all-reduce for BatchNorm statistics: each rank allocates a mailbox
+ *                        (uncached device memory, 2 x world slots of slot_floats floats) and gets a 64-byte hipIpc handle; after the
+ *                        handles of all ranks (world x 64 bytes, rank order) were exchanged, _connect maps the peers' mailboxes
+ *   crog_syncbn_stats    in-place fp32 SUM of ptr[0:count] over the ranks, asynchronous on `stream`: one single-block kernel per rank
+ *                        (peer writes + flag poll, sums formed in rank order: bit-identical on all ranks) when count fits a mailbox
+ *                        slot, ncclAllReduce otherwise.  Capture-safe (the exchange counter lives in the mailbox)
+ *   crog_allreduce_bucket  in-place ncclAllReduce (SUM, or AVG when `average`) of a gradient bucket, fp32 or bf16, on `stream`
+ *   crog_comm_status     *timed_out_seq != 0: an exchange gave up waiting for a peer (~2 s) - the training state is invalid
+ * RCCL is bound at run time (dlopen of the librccl.so already resident in the process; CROG_RCCL_LIB overrides): the library has no
+ * link-time dependency on it. */
+int crog_comm_unique_id(void* id128);
+int crog_comm_init(int rank, int world, const void* id128, void** comm_out);
+int crog_comm_peer_handle(void* comm, int slot_floats, void* handle64);
+int crog_comm_peer_connect(void* comm, const void* handles);
+int crog_comm_status(void* comm, int* timed_out_seq);
+int crog_syncbn_stats(void* comm, float* ptr, int64_t count, crog_stream_t stream);
+int crog_allreduce_bucket(void* comm, void* ptr, int64_t count, int dtype, int average, crog_stream_t stream);
+int crog_comm_destroy(void* comm);
+
+/* ------------------------------------------------------------------------------------------
  * Text-conditioned dynamic conv head, losses, metric
  * (layers.py:64-132,152-173; crog.py:76-111,119-131; utils/misc.py:115-131)
  * ---------------------------------------------------------------------------------------- */

@@ -39,6 +39,8 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
         convert_sync_batchnorm(model)
         assert RT.comm is not None and RT.comm.world_size == world
+        if os.environ.get("CROG_SYNCBN_DIRECT") == "peer":      # the statistics really travel through the hipIpc mailboxes
+            assert RT.comm.direct is not None and RT.comm.direct.has_peer and RT.comm.kind == "crog_comm:peer", RT.comm.kind
         net = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True, bucket_cap_mb=0.25)
     opt = FusedAdam(groups, lr=1e-4, store=model.store)
     full = synthetic_batch(B, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + meta["seed"])
@@ -68,6 +70,8 @@ def main():
     res["P"] = model.store.P.cpu().numpy()
     sd = model.state_dict()
     res["bn_final"] = np.concatenate([sd[k].float().cpu().numpy().ravel() for k in meta["bn_keys"]])
+    if world > 1 and RT.comm.direct is not None:
+        assert RT.comm.direct.timed_out() == 0
     np.savez(os.path.join(out_dir, f"{tag}_rank{rank}_of{world}.npz"), **res)
     if world > 1:
         dist.barrier()

@@ -26,9 +26,9 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def _run(world, out_dir, dtype, gain, size=96, B=4, tag="a"):
+def _run(world, out_dir, dtype, gain, size=96, B=4, tag="a", extra_env=None):
     port = _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, str(out_dir), dtype, str(gain), str(size), str(B), tag], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
@@ -113,3 +113,44 @@ def test_two_rank_ddp_syncbn_bf16_equals_single_process(tmp_path):
     cos = lambda x, y: float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y)))
     print(f"flat gradient cosine: 2-rank vs 1-process {cos(ga, gb):.5f}; run-to-run {cos(gc, gb):.5f}")
     assert cos(ga, gb) > min(0.98, 1 - 4 * (1 - cos(gc, gb)))
+
+
+def test_peer_mailbox_allreduce_two_processes_one_gpu(tmp_path):
+    """crog_syncbn_stats through the hipIpc mailboxes (csrc/comm.hip): two processes sharing cuda:0 exchange 60 vectors of 2 ... 8192
+    floats; every result equals gloo's all-reduce of the same data bit for bit, both ranks hold identical bits, nothing timed out."""
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(ROOT, "tests", "peer_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=300)
+            outs.append(o.decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+    res = [json.load(open(tmp_path / f"peer_rank{r}.json")) for r in range(2)]
+    print("peer mailbox exchange:", res)
+    for r in res:
+        assert r["created"], r["err"]
+        assert "timed_out_at" not in r and r["timed_out"] == 0
+        assert r["mismatches"] == 0 and r["identical_across_ranks"] and r["chain_value_ok"]
+
+
+def test_two_rank_ddp_syncbn_over_the_peer_mailboxes_equals_the_gloo_exchange(tmp_path):
+    """The whole 2-rank fp32 step with the BatchNorm statistics exchanged by crog_syncbn_stats (CROG_SYNCBN_DIRECT=peer) instead of
+    gloo: a two-rank sum is a + b either way, the fp32 forward is bit-reproducible, so logits and loss are IDENTICAL to the gloo run;
+    the gradient buffers (split-K atomics) agree to run-to-run noise."""
+    a0, a1 = _run(2, tmp_path, "f32", 1.0, tag="gloo")
+    b0, b1 = _run(2, tmp_path, "f32", 1.0, tag="peer", extra_env={"CROG_SYNCBN_DIRECT": "peer"})
+    for a, b in ((a0, b0), (a1, b1)):
+        assert np.array_equal(a["preds"], b["preds"]) and float(a["loss"]) == float(b["loss"])
+        rel = np.linalg.norm(a["G"] - b["G"]) / np.linalg.norm(a["G"])
+        assert rel < 2e-2, rel
+        assert np.allclose(a["bn_checksum"], b["bn_checksum"], rtol=1e-6)
+    assert np.array_equal(b0["P"], b1["P"])            # both ranks end on identical parameters

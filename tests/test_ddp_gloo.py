@@ -99,60 +99,69 @@ def test_reducer_matches_single_process(tmp_path):
     assert torch.allclose(r0["pairs"], ref, atol=1e-4)
 
 
-class _FakeRccl:
-    """Stands in for librccl in the set-up protocol test: every call succeeds unless told to fail on this rank."""
+class _FakeLib:
+    """Stands in for the C ABI (crog_comm_*) in the set-up protocol test: every call succeeds unless told to fail on this rank."""
 
-    def __init__(self, fail_uid=False, fail_init=False):
-        self.fail_uid, self.fail_init = fail_uid, fail_init
+    def __init__(self, fail_uid=False, fail_init=False, fail_handle=False, fail_connect=False):
+        self.fail = dict(uid=fail_uid, init=fail_init, handle=fail_handle, connect=fail_connect)
         self.destroyed = 0
 
-    def ncclGetUniqueId(self, _p):
-        return 1 if self.fail_uid else 0
+    def crog_last_error(self):
+        return b"fake failure"
 
-    def ncclCommInitRank(self, comm_p, world, uid, rank):
-        if self.fail_init:
-            return 5
+    def crog_comm_unique_id(self, _buf):
+        return -2 if self.fail["uid"] else 0
+
+    def crog_comm_init(self, rank, world, uid, comm_p):
+        if self.fail["init"]:
+            return -2
         comm_p._obj.value = 0x1234          # ctypes.byref(c_void_p): the handle the real library would write
         return 0
 
-    def ncclCommDestroy(self, _c):
+    def crog_comm_peer_handle(self, comm, slot, buf):
+        return -2 if self.fail["handle"] else 0
+
+    def crog_comm_peer_connect(self, comm, blob):
+        assert len(blob) == 2 * 64
+        return -2 if self.fail["connect"] else 0
+
+    def crog_comm_destroy(self, _c):
         self.destroyed += 1
         return 0
 
-    def ncclGetErrorString(self, rc):
-        return b"fake failure"
-
 
 def _setup_worker(rank, world, port, tmp):
-    """The direct-RCCL set-up verdict is collective (advisor, round 2): whatever fails, on whichever single rank, BOTH ranks return
-    None and nobody is left waiting in a collective the other never enters."""
+    """The direct communicator's set-up verdict is collective (advisor, round 2): whatever fails, on whichever single rank, BOTH ranks
+    return None and nobody is left waiting in a collective the other never enters."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from crog_amd import rccl
+    from crog_amd import _lib, rccl
     outcomes = []
-    scenarios = [("load fails on rank 1", dict(load_fail=1)), ("unique id fails on rank 0", dict(uid_fail=0)),
-                 ("comm init fails on rank 0", dict(init_fail=0)), ("comm init fails on rank 1", dict(init_fail=1)), ("all fine", dict())]
+    scenarios = [("library missing on rank 1", dict(load_fail=1)), ("unique id fails on rank 0", dict(uid=0)), ("comm init fails on rank 0", dict(init=0)),
+                 ("comm init fails on rank 1", dict(init=1)), ("mailbox allocation fails on rank 1", dict(handle=1)),
+                 ("opening a peer mailbox fails on rank 0", dict(connect=0)), ("all fine", dict())]
     for name, sc in scenarios:
-        fake = _FakeRccl(fail_uid=sc.get("uid_fail") == rank, fail_init=sc.get("init_fail") == rank)
-
-        def load(fake=fake, sc=sc):
-            if sc.get("load_fail") == rank:
-                raise OSError("librccl.so: cannot open shared object file")
-            return fake
-        rccl._load = load
-        comm, err = rccl.RcclComm.create(None, device="cpu")
+        fake = _FakeLib(**{"fail_" + k: v == rank for k, v in sc.items() if k != "load_fail"})
+        _lib._lib = fake                      # what K.lib() / check() return from now on
+        lib = None
+        if sc.get("load_fail") == rank:
+            class Missing:
+                def __getattr__(self, k):
+                    raise OSError("libcrog_hip.so: cannot open shared object file")
+            lib = Missing()
+        comm, err = rccl.DirectComm.create(None, device="cpu", rccl=True, peer=True, lib=lib or fake)
         outcomes.append((name, comm is not None, repr(err)[:60]))
         if name != "all fine":
             assert comm is None and err is not None, (rank, name)
         else:
-            assert comm is not None and err is None and comm._comm.value == 0x1234
+            assert comm is not None and err is None and comm._h.value == 0x1234 and comm.has_rccl and comm.has_peer
         dist.barrier()          # both ranks are still in step: no rank is stuck in a collective of the previous scenario
     torch.save(outcomes, os.path.join(tmp, f"setup{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_direct_rccl_setup_verdict_is_collective(tmp_path):
+def test_direct_comm_setup_verdict_is_collective(tmp_path):
     world, port = 2, 31000 + os.getpid() % 2000
     mp.start_processes(_setup_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     o0, o1 = torch.load(tmp_path / "setup0.pt"), torch.load(tmp_path / "setup1.pt")
-    assert [(n, ok) for n, ok, _ in o0] == [(n, ok) for n, ok, _ in o1]
+    assert [(n, ok) for n, ok, _ in o0] == [(n, ok) for n, ok, _ in o1] and len(o0) == 7
