@@ -336,6 +336,8 @@ def main():
         stats, _ = step()          # --warmup < 4: the capture still happens before the timed region
     sync()
     replaying = graphed is not None and graphed.graph is not None
+    if replaying:
+        batch = graphed.static_batch()     # the synthetic batch is resident in the captured step's own input tensors (no per-step copy, as in the eager loop)
     timers_in_replay = replaying and bool(graphed.prof_nodes)      # the replay brackets the roofline kernel's launches itself
     if key is not None and rank == 0 and not timers_in_replay:
         K.PROF = dict(key=key, records=[], on=False)

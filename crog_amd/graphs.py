@@ -184,7 +184,8 @@ class GraphedTrainStep:
     def _capture(self, batch):
         from . import kernels as K
         from .model import crog as crog_mod
-        self.static = dict(batch)           # the captured kernels read THESE tensors; later batches are copied into them
+        # the captured kernels read THESE tensors; later batches are copied into them (clones: the caller's batch is never written)
+        self.static = {k: v.clone() for k, v in batch.items()}
         torch.cuda.synchronize()
         saved_text_graph, saved_prof = crog_mod.TEXT_GRAPH, K.PROF
         crog_mod.TEXT_GRAPH, K.PROF = False, None      # no graph replay and no timing events inside a capture
