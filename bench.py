@@ -298,8 +298,7 @@ def main():
         model.overlap_text = False
     net = model
     if world > 1 or force_ddp:
-        if os.environ.get("CROG_NO_SYNCBN") != "1":   # A/B switch: cost of the SyncBatchNorm exchange alone
-            convert_sync_batchnorm(model, force=force_ddp)
+        convert_sync_batchnorm(model, force=force_ddp)
         net = DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True, force=force_ddp)
     opt = FusedAdam(groups, lr=cfg.base_lr, weight_decay=cfg.weight_decay, store=model.store)
     RT.manual_seed(1234 + rank)

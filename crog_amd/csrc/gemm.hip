@@ -20,10 +20,6 @@
 #include <stdlib.h>
 #include <algorithm>
 
-#ifndef CROG_GEMM_PIPELINED
-#define CROG_GEMM_PIPELINED 1   // 0: the plain wait -> barrier -> issue -> compute loop (A/B builds)
-#endif
-
 namespace {
 
 template <typename T> struct TileCfg;
@@ -654,11 +650,7 @@ __device__ inline void xcd_map(int nwg, int splitk, int& id, int& z) {
     id = w;
   }
 }
-inline bool splitk_by_xcd(const crog_gemm_desc& d) {
-  static int off = -1;
-  if (off < 0) { const char* e = getenv("CROG_GEMM_NO_XCD_SPLITK"); off = (e && e[0] == '1') ? 1 : 0; }
-  return !off && d.batch == 1 && d.splitk > 1;
-}
+inline bool splitk_by_xcd(const crog_gemm_desc& d) { return d.batch == 1 && d.splitk > 1; }
 
 template <typename T, int AL, int BL, bool HWTR, typename S>
 __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? (sizeof(T) == 4 ? 2 : 3) : (sizeof(T) == 4 ? 3 : 4)))) gemm_kernel(const crog_gemm_desc p) {
@@ -1101,22 +1093,15 @@ __device__ __attribute__((always_inline)) inline void wait_tiles(int behind) {
   else wait_vmcnt<0>();
 }
 
-// Tile shapes that were measured and lost (kept for A/B work, compiled only with -DCROG_GEMM_EXPERIMENTAL_TILES): 256 x 256 and
-// 256 x 128 with 8 waves at one block per CU (barrier stalls are not hidden by a second block: 5-30 % slower than 128 x 128 at
-// three blocks per CU), 64 x 256 for Cout <= 64 weight gradients (two blocks per CU, 20 KiB per k-tile: 14 % slower).
+// Tile shapes of the LDS-DMA kernel.  Measured and dropped (rounds 1-2): 256 x 128 with 8 waves of 64 x 64 at one block per CU
+// (barrier stalls are not hidden by a second block: 5-30 % slower than 128 x 128 at three blocks per CU), 128 x 256 with 4 waves of
+// 64 x 128 (20-45 % slower), 64 x 256 for Cout <= 64 weight gradients (two blocks per CU, 20 KiB per k-tile: 14 % slower).
 using ShapeDma8 = Shape<4, 2, 2, 4, true>;   // 256 x 256, 8 waves, 128 accumulator registers per lane (lean epilogue: at the 256-VGPR limit the full one spills)
-using ShapeDma8x = Shape<2, 2, 4, 2>;  // 256 x 128, 8 waves of 64 x 64 (64 accumulator registers, as the 128^2 tile): A/B experiments
-using ShapeFat = Shape<2, 4, 2, 2>;    // 128 x 256, 4 waves of 64 x 128 (128 accumulator registers, 2 blocks per CU): 20-45 % slower (experimental)
 using ShapeTall = Shape<2, 2, 4, 1>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
-using ShapeWide = Shape<2, 2, 1, 4>;   //  64 x 256, 4 waves: weight gradients of those layers (M = Cout = 32 / 64)
 using ShapeDma64 = Shape<1, 1, 2, 2>;  //  64 x  64, 4 waves: small GEMMs (text tower, attention pooling), no BN statistics
 using ShapeMidBwd = Shape<2, 2, 2, 2, true, 0, true>;   // 128 x 128 data gradient that does the consumer BatchNorm's first backward pass
 // (8-deep rings for launches of <= 1-2 blocks per CU were tried: no gain standalone -- those launches are not bound by request
 // latency -- and 3 % slower in the step, where a 128 KiB block keeps the other streams' blocks off the CU.)
-
-#ifndef CROG_GEMM_INTERLEAVE
-#define CROG_GEMM_INTERLEAVE 1   // 0: leave the order of DMA requests / LDS reads / MFMAs inside a k-tile to the compiler (A/B builds)
-#endif
 
 // ASUM: the launch also accumulates a_sum[m] += sum_k A(m, k) (bias gradient inside a weight-gradient GEMM); a template flag so
 // that the main loop of every other launch is one basic block
@@ -1198,7 +1183,7 @@ gemm_dma_kernel(const crog_gemm_desc p) {   // (fp32 carries a second accumulato
   constexpr int PER_TILE = NIA + NIB;   // DMA instructions per k-tile and wave
   da.start(kt0 * BK, g);
   db.start(kt0 * BK, g);
-  if constexpr (BK / 16 == 2 && CROG_GEMM_PIPELINED) {
+  if constexpr (BK / 16 == 2) {
     // Software-pipelined, branch-free main loop (two 16-deep MFMA steps per k-tile).  Exactly DEPTH k-tiles are always requested
     // ahead — a request past the end of this block's reduction range is an out-of-bounds offset (no traffic, zeros into a stage
     // nobody reads) — so the vmcnt waits are compile-time constants and the loop body is ONE basic block: the DMA requests of tile
@@ -1258,7 +1243,6 @@ gemm_dma_kernel(const crog_gemm_desc p) {   // (fp32 carries a second accumulato
       for (int i = 0; i < WM; i++)
 #pragma unroll
         for (int j = 0; j < WN; j++) mma16(fa1[i], fb1[j], acc[i][j]);
-#if CROG_GEMM_INTERLEAVE
       if constexpr (sizeof(T) == 2 && !ASUM) {
         // order of the second half of the k-tile: the next tile's fragment reads first (they complete under the MFMAs), then the
         // MFMAs with the DMA requests spread between them
@@ -1272,7 +1256,6 @@ gemm_dma_kernel(const crog_gemm_desc p) {   // (fp32 carries a second accumulato
         }
         if (PER_TILE * MPD < NMF) __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER_TILE * MPD, 0);
       }
-#endif
       stage = nstage;
     }
     // The trailing out-of-range requests write zeros into the ring, and the epilogue reuses the ring (statistics exchange, staged
@@ -1376,36 +1359,11 @@ int dispatch_dma(const crog_gemm_desc& d, hipStream_t s) {
   return CROG_ERR_ARG;
 }
 
-// 256x256 DMA tile when the problem still fills the chip and wastes no more of the tile on padding than 128x128 does
-bool dma_prefers_256(const crog_gemm_desc& d) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("CROG_GEMM_DMA256");
-    forced = e ? (e[0] == '1' ? 1 : (e[0] == 'a' ? 2 : 0)) : 0;   // default off: measured no gain on CROG's conv shapes (N = 256/512)
-  }
-  if (forced != 2) return forced == 1;
-  const long zb = (long)d.batch * d.splitk;
-  const long big = (long)cdiv(d.M, 256) * cdiv(d.N, 256) * zb;
-  const double eff_big = (double)d.M * d.N / ((double)cdiv(d.M, 256) * 256 * cdiv(d.N, 256) * 256);
-  const double eff_mid = (double)d.M * d.N / ((double)cdiv(d.M, 128) * 128 * cdiv(d.N, 128) * 128);
-  return big >= 224 && eff_big >= 0.9 * eff_mid;
-}
-
-bool dma_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CROG_GEMM_NO_DMA");
-    v = (e && e[0] == '1') ? 0 : 1;
-  }
-  return v == 1;
-}
-
 // The DMA kernel addresses each operand through a 32-bit byte offset from its (batch-adjusted) base pointer and moves whole
 // 16-byte chunks.  A ragged last chunk (K or a transposed operand's column count not a multiple of the chunk) is read in full:
 // that is memory-safe when the row stride covers the rounded-up length, and value-safe because the partner operand's rows
 // beyond K are zero-filled (transposed partner, exact row guard) or the extra columns only feed outputs that are never stored.
 bool dma_eligible(const crog_gemm_desc& d) {
-  if (!dma_enabled()) return false;
   const long esz = d.dtype == CROG_BF16 ? 2 : 4, vec = 16 / esz;
   const bool a_tr = d.a_layout == CROG_A_MC, b_tr = d.b_layout != CROG_B_KC;
   auto up = [&](long v) { return (v + vec - 1) / vec * vec; };
@@ -1462,42 +1420,10 @@ int dispatch_layout(const crog_gemm_desc& d, hipStream_t s) {
   return CROG_ERR_ARG;
 }
 
-bool hwtr_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CROG_GEMM_NO_HWTR");
-    v = (e && e[0] == '1') ? 0 : 1;
-  }
-  return v == 1;
-}
-
-// 0 = auto, 1 = small, 2 = mid (CROG_GEMM_SHAPE, for tests and A/B runs)
-int forced_shape() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CROG_GEMM_SHAPE");
-    v = 0;
-    if (e) {
-      if (e[0] == 's') v = 1;
-      else if (e[0] == 'm') v = 2;
-    }
-  }
-  return v;
-}
-
+// 1 = 64 x 64 tiles (latency-bound small problems without BatchNorm statistics), 2 = 128 x 128
 int pick_shape(const crog_gemm_desc& d) {
-  const int f = forced_shape();
-  const long zb = (long)d.batch * d.splitk;
-  if (f == 2) return f;
-  if (f == 1) return d.col_stats ? 2 : 1;
-  const long mid = (long)cdiv(d.M, 128) * cdiv(d.N, 128) * zb;
-  const long big = (long)cdiv(d.M, 256) * cdiv(d.N, 128) * zb;
-  // BIG when it still fills the chip and does not waste more of the tile on padding than MID does
-  const double eff_big = (double)d.M * d.N / ((double)cdiv(d.M, 256) * 256 * cdiv(d.N, 128) * 128);
-  const double eff_mid = (double)d.M * d.N / ((double)cdiv(d.M, 128) * 128 * cdiv(d.N, 128) * 128);
-  (void)big; (void)eff_big; (void)eff_mid;  // BIG is kept for A/B runs only: measured slower than MID/SMALL (occupancy-bound staging)
-  if (mid < 192 && !d.col_stats) return 1;
-  return 2;
+  const long mid = (long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.batch * d.splitk;
+  return (mid < 192 && !d.col_stats) ? 1 : 2;
 }
 
 // Small-output weight gradients are bound by L2 -> LDS bytes and by the fp32-atomic epilogue, not by MFMA (scripts/ablate_wgrad.py,
@@ -1509,23 +1435,9 @@ int pick_shape(const crog_gemm_desc& d) {
 // elements (transformer FFN / ViT weights: many tiles already) aim at 512 blocks: CROG-R50 does not care, the ViT-B/16 tower, whose
 // main stream leaves more of the chip free, loses 12 % with 256 (17.3 vs 15.4 ms per forward + backward).  The 3x3 form keeps
 // 64 x 64 for outputs up to 128 x 1152 (Cout <= 128: 128-wide tiles would be mostly padding) and targets 512 blocks otherwise.
-// CROG_WGRAD_TILE / CROG_WGRAD_TARGET / CROG_WGRAD_TARGET128 / CROG_WGRAD_TARGET_BIG / CROG_WGRAD_TARGET_CONV override the policy for A/B runs.
-inline bool alt_tiles_enabled() {
-  static int alt = -1;
-  if (alt < 0) { const char* e = getenv("CROG_GEMM_NO_ALT_TILES"); alt = (e && e[0] == '1') ? 0 : 1; }
-  return alt == 1;
-}
-inline int wgrad_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 inline bool small_wgrad(int a_layout, int b_layout, int out_mode, long M, long N) {
-  static int off = -1, tile = 0;
-  if (off < 0) { const char* e = getenv("CROG_GEMM_NO_SMALL_WGRAD"); off = (e && e[0] == '1') ? 1 : 0; tile = wgrad_env("CROG_WGRAD_TILE", 128); }
-  if (off || !alt_tiles_enabled() || out_mode != CROG_OUT_F32_ATOMIC || a_layout != CROG_A_MC) return false;
-  if (b_layout == CROG_B_NC) return tile == 64 && M * N <= (1L << 20);
-  if (b_layout == CROG_B_NC_IM2COL) return M * N <= 160L * 1024;
-  return false;
+  if (out_mode != CROG_OUT_F32_ATOMIC || a_layout != CROG_A_MC) return false;
+  return b_layout == CROG_B_NC_IM2COL && M * N <= 160L * 1024;      // 3x3 weight gradients with Cout <= 128: 64 x 64 tiles
 }
 
 inline bool lean_epilogue_ok(const crog_gemm_desc& d) {
@@ -1543,79 +1455,33 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
       }
     }
     crog_set_error("crog_gemm: bwd_z is implemented for bf16 data gradients (A_KC x B_NC, A_IM2COL x B_KC / B_NC_DGRAD) with a plain epilogue "
-                   "and operands the LDS-DMA path can address");
+                   "and operands the LDS-DMA path can address (crog_gemm_supports_bwd_z)");
     return CROG_ERR_ARG;
   }
   const int shape = pick_shape(d);
   if (dma_eligible(d)) {
-    // tile shape of the LDS-DMA kernel by padding waste: 64-wide sides for <= 64 columns / rows, 64 x 64 for small problems
-    const bool alt = alt_tiles_enabled();
-#ifdef CROG_GEMM_EXPERIMENTAL_TILES
-    if (shape == 2 && dma_prefers_256(d) && lean_epilogue_ok(d)) return dispatch_dma<T, ShapeDma8>(d, s);
-    {
-      // A/B: wider tiles for the large 3x3 forward / data-gradient launches only (CROG_GEMM_CONV_TILE = f: 128 x 256 at two blocks
-      // per CU, 8: 256 x 256 at one), when the launch still has >= CROG_GEMM_CONV_MIN tiles of that shape
-      static int conv_tile = -1, conv_min = 512;
-      if (conv_tile < 0) {
-        const char* e = getenv("CROG_GEMM_CONV_TILE");
-        conv_tile = !e ? 0 : (e[0] == 'f' ? 1 : (e[0] == '8' ? 2 : 0));
-        const char* m = getenv("CROG_GEMM_CONV_MIN");
-        if (m) conv_min = atoi(m);
-      }
-      if (conv_tile && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0) {
-        if (conv_tile == 1 && (long)cdiv(d.M, 128) * (d.N / 256) >= conv_min) return dispatch_dma<T, ShapeFat>(d, s);
-        if (conv_tile == 2 && lean_epilogue_ok(d) && (long)cdiv(d.M, 256) * (d.N / 256) >= conv_min) return dispatch_dma<T, ShapeDma8>(d, s);
-      }
-    }
-#endif
-    // Large 3x3 forward / data-gradient launches (bf16, N a multiple of 256, >= 160 tiles of 256 x 256 — with 170 tiles the
-    // 21632 x 512 launches of the neck gain 25 % standalone, 135 -> 108 us, and the step 0.5 %; at 85 tiles the tile loses): the 8-wave 256 x 256 tile
-    // halves the L2 -> LDS bytes per FLOP, which is what bounds the 128 x 128 tile (ablation: DMA-only 831 us vs MFMA-only 603 us of a
-    // 1072 us launch).  Standalone +22-35 % on K = 4608 forwards (856 vs 691, 1031 vs 845 TFLOP/s), in the training step -1.5 %
-    // (37.5 vs 38.2 ms, two interleaved A/B pairs); smaller launches lose to tile quantisation at one block per CU and stay on 128 x 128.
-    static int conv256 = -1, conv256_min = 160;
-    if (conv256 < 0) {
-      const char* e = getenv("CROG_GEMM_NO_CONV256");
-      const char* m = getenv("CROG_GEMM_CONV256_MIN");      // A/B: least number of 256 x 256 tiles for the wide tile
-      if (m) conv256_min = atoi(m);
-      conv256 = (e && e[0] == '1') ? 0 : 1;
-    }
+    // Tile shape of the LDS-DMA kernel.
+    // Large 3x3 forward / data-gradient launches (bf16, N a multiple of 256, >= 160 tiles of 256 x 256 - with 170 tiles the
+    // 21632 x 512 launches of the neck gain 25 % standalone, 135 -> 108 us, and the step 0.5 %; at 85 tiles the tile loses): the 8-wave
+    // 256 x 256 tile halves the L2 -> LDS bytes per FLOP, which is what bounds the 128 x 128 tile (ablation: DMA-only 831 us vs
+    // MFMA-only 603 us of a 1072 us launch).  Standalone +22-35 % on K = 4608 forwards (856 vs 691, 1031 vs 845 TFLOP/s), in the
+    // training step -1.5 % (37.5 vs 38.2 ms, two interleaved A/B pairs); smaller launches lose to tile quantisation at one block per
+    // CU and stay on 128 x 128.  (The same tile for 1x1 / linear forwards and data gradients, K = 128 ... 2048: no gain standalone -
+    // their reductions are too short to amortise the 128 KiB ring's fill - and +0.4 ms in the step.)
     if constexpr (sizeof(T) == 2) {
-      if (conv256 && alt && forced_shape() == 0 && lean_epilogue_ok(d) && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0 &&
-          (long)cdiv(d.M, 256) * (d.N / 256) >= conv256_min)
+      if (lean_epilogue_ok(d) && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0 && (long)cdiv(d.M, 256) * (d.N / 256) >= 160)
         return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, ShapeDma8>(d, s);
-      // (the same tile for 1x1 / linear forwards and data gradients, K = 128 ... 2048: no gain standalone — their reductions are too
-      // short to amortise the 128 KiB ring's fill — and +0.4 ms in the step)
     }
-    static int force = -1;   // CROG_GEMM_DMA_TILE = mid | tall | wide | 64 : A/B runs only (never with BN statistics on 64-row tiles)
-    if (force < 0) {
-      const char* e = getenv("CROG_GEMM_DMA_TILE");
-      force = !e ? 0 : (e[0] == 'm' ? 1 : (e[0] == 't' ? 2 : (e[0] == 'w' ? 3 : (e[0] == '6' ? 4 : (e[0] == 'x' ? 5 : (e[0] == 'f' ? 6 : 0))))));
+    // Otherwise by padding waste: 64-wide sides for <= 64 columns, 64 x 64 for small problems and small 3x3 weight gradients
+    if (d.col_stats) {
+      if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
+    } else {
+      if (d.M <= 64 && d.N <= 64) return dispatch_dma<T, ShapeDma64>(d, s);
+      if (small_wgrad(d.a_layout, d.b_layout, d.out_mode, d.M, d.N)) return dispatch_dma<T, ShapeDma64>(d, s);
+      if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
+      if (shape == 1) return dispatch_dma<T, ShapeDma64>(d, s);
     }
-    if (force == 1) return dispatch_dma<T, ShapeMid>(d, s);
-    if (force == 2) return dispatch_dma<T, ShapeTall>(d, s);
-    if (force == 4 && !d.col_stats) return dispatch_dma<T, ShapeDma64>(d, s);
-#ifdef CROG_GEMM_EXPERIMENTAL_TILES
-    if (force == 6) return dispatch_dma<T, ShapeFat>(d, s);
-    if (force == 3 && !d.col_stats) return dispatch_dma<T, ShapeWide>(d, s);
-    if (force == 5) return dispatch_dma<T, ShapeDma8x>(d, s);
-#endif
-    if (alt && forced_shape() == 0) {
-      if (d.col_stats) {
-        if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
-      } else {
-        if (d.M <= 64 && d.N <= 64) return dispatch_dma<T, ShapeDma64>(d, s);
-        if (small_wgrad(d.a_layout, d.b_layout, d.out_mode, d.M, d.N)) return dispatch_dma<T, ShapeDma64>(d, s);
-        if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
-#ifdef CROG_GEMM_EXPERIMENTAL_TILES
-        static int wide = -1;   // 64 x 256: measured slower than 128 x 128 on the Cout = 64 weight gradients (2 blocks/CU, 20 KiB per k-tile)
-        if (wide < 0) { const char* e = getenv("CROG_GEMM_WIDE"); wide = (e && e[0] == '1') ? 1 : 0; }
-        if (wide && d.M <= 64) return dispatch_dma<T, ShapeWide>(d, s);
-#endif
-        if (shape == 1) return dispatch_dma<T, ShapeDma64>(d, s);
-      }
-    }
-    if (shape == 2) return dispatch_dma<T, ShapeMid>(d, s);
+    return dispatch_dma<T, ShapeMid>(d, s);
   }
   switch (shape) {
     case 1: return dispatch_layout<T, HWTR, ShapeSmall>(d, s);
@@ -1634,19 +1500,24 @@ extern "C" int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int 
   const int bk = dtype == CROG_BF16 ? 32 : 16;
   const long ktiles = cdiv(K, bk);
   long s;
-  if (small_wgrad(a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N)) {
+  if (small_wgrad(a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N)) {      // 64 x 64 tiles, ~2048 blocks, >= 16 k-tiles per block
     const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
-    static const long t1 = wgrad_env("CROG_WGRAD_TARGET", 1024);
-    const long target = b_layout == CROG_B_NC_IM2COL ? 2048 : t1;
-    s = std::min(std::max(1L, target / tiles), std::max(1L, ktiles / 16));
-  } else {
-    static const long t2 = wgrad_env("CROG_WGRAD_TARGET128", 256), t3 = wgrad_env("CROG_WGRAD_TARGET_CONV", 512),
-                      t4 = wgrad_env("CROG_WGRAD_TARGET_BIG", 512);
+    s = std::min(std::max(1L, 2048 / tiles), std::max(1L, ktiles / 16));
+  } else {      // 128 x 128 tiles: ~256 blocks (512 for the 3x3 form and for outputs above 1 M elements), >= 24 k-tiles per block
     const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-    const long target = b_layout == CROG_B_NC_IM2COL ? t3 : ((long)M * N <= (1L << 20) ? t2 : t4);      // BIG: outputs above 1 M elements
+    const long target = b_layout == CROG_B_NC_IM2COL ? 512 : ((long)M * N <= (1L << 20) ? 256 : 512);
     s = std::min(std::max(1L, target / tiles), std::max(1L, ktiles / 24));
   }
   return (int)std::max(1L, std::min(s, 1024L));
+}
+
+// Can crog_gemm do the BatchNorm-backward statistics (bwd_z) for this descriptor?  The caller decides BEFORE the producer layer commits
+// to skipping its own first pass (crog_amd/functional.py BnLink).
+extern "C" int crog_gemm_supports_bwd_z(const crog_gemm_desc* dp) {
+  if (!dp) return 0;
+  const crog_gemm_desc& d = *dp;
+  if (d.dtype != CROG_BF16 || !dma_eligible(d) || !lean_epilogue_ok(d)) return 0;
+  return (d.a_layout == CROG_A_KC && d.b_layout == CROG_B_NC) || (d.a_layout == CROG_A_IM2COL && (d.b_layout == CROG_B_KC || d.b_layout == CROG_B_NC_DGRAD));
 }
 
 extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
@@ -1689,8 +1560,7 @@ extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
   CROG_CHECK_ARG(!d.a_sum || d.batch == 1, "crog_gemm: a_sum needs batch == 1");
   CROG_CHECK_ARG((long)d.batch * d.splitk <= 65535, "crog_gemm: batch*splitk too large");
   hipStream_t s = (hipStream_t)stream;
-  const bool hw = hwtr_enabled();
-  if (d.dtype == CROG_BF16) return hw ? dispatch_shape<bf16, true>(d, s) : dispatch_shape<bf16, false>(d, s);
+  if (d.dtype == CROG_BF16) return dispatch_shape<bf16, true>(d, s);
   return dispatch_shape<float, true>(d, s);
 }
 #endif  // CROG_GEMM_PROBE

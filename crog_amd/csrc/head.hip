@@ -319,9 +319,7 @@ extern "C" int crog_head_cb_bwd(int dtype, const float* b5, const void* wpad, co
 extern "C" int crog_head_stencil_fwd(const float* t, const float* word, int64_t ldw, int bias_col, const float* tbias, float* out, int B, int heads,
                                      int H, int W, crog_stream_t s) {
   const size_t lds = (size_t)(HS_R + 2) * W * heads * 9 * sizeof(float);
-  static int rows_form = -1;   // CROG_HEAD_STENCIL_ROWS=0: the gather form (A/B runs)
-  if (rows_form < 0) { const char* e = getenv("CROG_HEAD_STENCIL_ROWS"); rows_form = (e && e[0] == '0') ? 0 : 1; }
-  if (rows_form && lds <= 96 * 1024 && B <= 65535) {
+  if (lds <= 96 * 1024 && B <= 65535) {      // LDS row-band form; the gather form below serves maps too wide for it
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_stencil_fwd_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

@@ -39,17 +39,18 @@ def _pad(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
-import os as _os
-FUSED_REDUCE_MAX_PARTS = int(_os.environ.get("CROG_FUSED_REDUCE_MAX_PARTS", "256"))
-FLASH_ATTN = _os.environ.get("CROG_FLASH_ATTN", "1") != "0"     # fused attention kernels (csrc/attn.hip) where they apply
+# Policy constants of the operator layer.  They were environment switches while rounds 1-2 measured them (DESIGN.md section 4 has the
+# numbers); the measured winners are now fixed, and tests that compare two forms set the module attribute.
+FUSED_REDUCE_MAX_PARTS = 256     # BatchNorm slab reductions up to this many partial rows are folded into the finalize launch
+FLASH_ATTN = True                # fused attention kernels (csrc/attn.hip) where they apply; tests compare with the unfused path
 FLASH_MIN_KEYS = 64
-BN_ATOMIC_STATS = _os.environ.get("CROG_BN_ATOMIC_STATS", "1") != "0"   # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize
-RELU_BITMASK = _os.environ.get("CROG_RELU_BITMASK", "1") != "0"   # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
-LN_BWD_ATOMIC = _os.environ.get("CROG_LN_BWD_ATOMIC", "0") == "1"   # LayerNorm parameter gradients through atomics in ln_bwd itself: measured 0.5 % SLOWER (every block adds into the same 2 C floats), kept for A/B
-LN_REDUCE_SIDE = _os.environ.get("CROG_LN_REDUCE_SIDE", "1") != "0"   # LayerNorm parameter-gradient reduction on the weight-gradient stream
-BN_BWD_ATOMIC = _os.environ.get("CROG_BN_BWD_ATOMIC", "1") != "0"   # backward partial sums through coalesced atomics (bf16, no SyncBN)
-DGRAD_T = _os.environ.get("CROG_DGRAD_T", "1") != "0"          # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
-FUSED_HEAD = _os.environ.get("CROG_FUSED_HEAD", "1") != "0"    # fold vis.4 into the dynamic head (no groups*C-channel map)
+BN_ATOMIC_STATS = True           # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize (bf16)
+RELU_BITMASK = True              # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
+LN_BWD_ATOMIC = False            # LayerNorm parameter gradients through atomics in ln_bwd itself: measured 0.5 % SLOWER (every block adds into the same 2 C floats)
+LN_REDUCE_SIDE = True            # LayerNorm parameter-gradient reduction on the weight-gradient stream
+BN_BWD_ATOMIC = True             # backward partial sums through coalesced atomics (bf16)
+DGRAD_T = True                   # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
+FUSED_HEAD = True                # fold vis.4 into the dynamic head (no groups*C-channel map)
 
 
 class OutRef:
@@ -97,7 +98,14 @@ class WRef:
         return self.store.G[self.off:self.off + self.rows * self.cols]
 
     def done(self):
-        """The kernels that write this parameter's gradient are enqueued."""
+        """The kernels that write this parameter's gradient are enqueued (or parked: Runtime.defer_wgrad - then the announcement waits
+        for the flush that really enqueues them, so a DDP bucket can never be launched ahead of its last gradient)."""
+        if RT._pending_wgrad:
+            RT._pending_done.append(self._done_now)
+            return
+        self._done_now()
+
+    def _done_now(self):
         st, p = self.store, self.param
         st.g_clean = False
         st.touched.add(id(p))
@@ -186,12 +194,12 @@ class BnLink:
         self.C = self.M = self.R = 0
 
 
-BN_BWD_FUSED = _os.environ.get("CROG_BN_BWD_FUSED", "1") != "0"   # BnLink fusion on (bf16, atomic statistics path)
+BN_BWD_FUSED = True   # BnLink fusion on (bf16, atomic statistics path); tests compare with the two-launch form
 # ... for layers of at most this many rows.  Measured per layer, HBM-cold (scripts/bench_bwd_fused.py): the gated-statistics epilogue
 # adds 5-7 us to a 21632- / 86528-row data gradient and saves a 16-23 us first pass; on the 346112-row layers of layer1 it costs what it
 # saves (+17 us vs 19-21 us: bn_bwd_partial streams at 4.2 TB/s, the epilogue gathers z in 4-byte pieces and its atomics collide on 64
 # columns), and on the 1.38 M-row stem it LOSES 13-19 us.
-BN_BWD_FUSED_MAX_ROWS = int(_os.environ.get("CROG_BN_BWD_FUSED_MAX_ROWS", "131072"))
+BN_BWD_FUSED_MAX_ROWS = 131072
 
 
 def stat_replicas(slabs: int, C: int) -> int:
@@ -442,8 +450,12 @@ class ConvBnAct(Function):
             RT.on_wgrad_stream(wgrad, dz, x, gt if wpad is not None else None)
             # BnLink: this data gradient is the previous layer's dy -> its epilogue does that layer's first BatchNorm-backward pass
             bwd = {}
+            # (the last two terms mirror crog_gemm's own eligibility test for bwd_z - operands the LDS-DMA path can address with 32-bit
+            # byte offsets, C-ABI crog_gemm_supports_bwd_z - so that a launch that would be refused is never armed: the producer layer
+            # has not committed to anything yet, `sums` stays None and it runs its own first pass)
             if (stat_in is not None and stat_in.z is not None and ctx.x_needs and extra is None and dtype == torch.bfloat16
-                    and stat_in.C == cin and stat_in.M == M and cin % 8 == 0):
+                    and stat_in.C == cin and stat_in.M == M and cin % 8 == 0 and C % 8 == 0
+                    and 2 * M * max(C, cin) < 2 ** 31):
                 stat_in.R = stat_replicas(K.stat_tiles(M), cin)
                 stat_in.sums = RT.zeros(stat_in.R * 2 * cin, dev)
                 bwd = dict(col_stats=stat_in.sums, stat_replicas=stat_in.R, bwd_z=stat_in.z, bwd_ss=stat_in.ss)
@@ -461,6 +473,7 @@ class ConvBnAct(Function):
                     K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, dz, wt, dx, M, cin, 9 * C, C, cin, cin, b_off=woff, conv=(H, W, C), **bwd)
             elif stat_in is not None:
                 stat_in.sums = None
+            RT.flush_wgrad()       # (defer_wgrad: the weight gradient parked above forks here, behind the data gradient just enqueued)
             w.done()
         return (dx, dres) + (None,) * 15
 

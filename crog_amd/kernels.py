@@ -27,7 +27,7 @@ PROF = None
 # While a training step is being captured for replay (crog_amd/graphs.py): {"key": (a_layout, b_layout), "nodes": []} collects the
 # graph node of every launch of that variant, so that the replay can put a timer pair around exactly those launches
 CAPTURE_NODES = None
-DEBUG_FLAGS = int(os.environ.get("CROG_GEMM_DEBUG", "0"))  # ablation / A-B bits of crog_gemm_desc.debug (scripts/ablate_gemm.py); 0 in production
+DEBUG_FLAGS = 0  # ablation / A-B bits of crog_gemm_desc.debug (set by tests and scripts/ablate_gemm.py); 0 in production
 GEMM_SYMBOL = {
     (A_KC, B_KC): "gemm_dma_kernel<T, A_KC, B_KC>  (1x1 conv / linear forward, Q.K^T)",
     (A_IM2COL, B_KC): "gemm_dma_kernel<T, A_IM2COL, B_KC>  (3x3 conv forward and data gradient, implicit GEMM)",

@@ -110,6 +110,7 @@ class ModifiedResNet(Bound):
 
     def __init__(self, layers, output_dim, heads, input_resolution=224, width=64):
         super().__init__()
+        self.width = width
         self.output_dim, self.input_resolution = output_dim, input_resolution
         self.conv1, self.bn1 = Conv2d(3, width // 2, 3), BatchNorm(width // 2)
         self.conv2, self.bn2 = Conv2d(width // 2, width // 2, 3), BatchNorm(width // 2)
@@ -120,6 +121,15 @@ class ModifiedResNet(Bound):
         self.layer3 = self._make_layer(width * 4, layers[2], stride=2)
         self.layer4 = self._make_layer(width * 8, layers[3], stride=2)
         self.attnpool = AttentionPool2d(input_resolution // 32, width * 32, heads, output_dim)
+
+    def check_supported(self, source: str = ""):
+        """clip.py:165-185 is width-generic (RN50x4 = 80, RN50x16 = 96, RN50x64 = 128).  The 3x3 implicit-GEMM kernels need
+        Cin % 32 == 0; widths 80 / 96 give 40- / 48- / 80-channel maps that would need zero-padded channel strides through the stem and
+        layer1 (the mechanism CoordConv's 514 -> 544 uses) - not built and not fixture-tested.  Called by CROG.prepare(), i.e. when
+        the model is bound to the GPU, so an unsupported archive is refused by name before the first forward."""
+        if self.width != 64:
+            raise NotImplementedError(f"crog_amd: CLIP ModifiedResNet of width {self.width}{' (' + source + ')' if source else ''} is not supported: the HIP "
+                                      "path implements width 64 (RN50, RN101 archives); RN50x4 / x16 / x64 need padded channel strides")
 
     def _make_layer(self, planes, blocks, stride=1):
         mods = [Bottleneck(self._inplanes, planes, stride)]
@@ -133,8 +143,7 @@ class ModifiedResNet(Bound):
         queued while the host works through the ~250 small text launches."""
         tr = self.training
         c1 = self.conv1.weight.shape[0]
-        if c1 != 32:
-            raise NotImplementedError("stem kernel is specialised for CLIP ResNets of width 64 (conv1: 3 -> 32)")
+        self.check_supported()
         s1, s2 = (Fn.BnLink(), Fn.BnLink()) if tr else (None, None)       # stem: conv1 -> conv2 -> conv3 is a plain chain
         x = Fn.conv_bn_act(img, self.conv1.w, self.bn1.buffers_ref(), ksize="s", relu=True, training=tr, wpad=(27, 32, c1), dtype=dtype,
                            stat_out=s1)

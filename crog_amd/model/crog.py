@@ -79,6 +79,7 @@ class CROG(nn.Module):
         self.use_pretrained_clip = cfg.use_pretrained_clip
         self.use_grasp_masks = cfg.use_grasp_masks
         arch, sd = self._clip_arch(cfg)
+        self._clip_source = str(getattr(cfg, "clip_pretrain", "")) if sd is not None else "cfg.clip_arch"
         self.backbone = build_model(arch, cfg.word_len)
         if sd is not None and self.use_pretrained_clip:
             load_pretrained_clip(self.backbone, sd)      # clip.py:551-554
@@ -117,6 +118,8 @@ class CROG(nn.Module):
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("crog_amd.CROG runs on an MI355X only: there is no CPU path (move the module with .cuda())")
+        if hasattr(self.backbone.visual, "check_supported"):
+            self.backbone.visual.check_supported(getattr(self, "_clip_source", ""))
         for b_name, buf in list(self.named_buffers()):
             if buf.device != device:
                 mod = self
@@ -192,7 +195,7 @@ class CROG(nn.Module):
                 main.wait_stream(self._side)
             elif self.overlap_text:
                 txt = []
-                steps = self.backbone.text_features_steps(word, dtype, parts=int(os.environ.get("CROG_TEXT_PARTS", "3")))
+                steps = self.backbone.text_features_steps(word, dtype, parts=3)
 
                 def issue_text():   # called by the image tower after layer1 / layer2 / layer3 are enqueued (host issue order only)
                     with torch.cuda.stream(self._side):

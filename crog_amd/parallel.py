@@ -22,7 +22,7 @@ from .runtime import ALIGN, RT
 
 
 import os as _os
-_DRY = _os.environ.get("CROG_DDP_DRY") == "1"   # diagnostics: run the reducer's bookkeeping without issuing collectives
+_DRY = False   # diagnostics (set by scripts): run the reducer's bookkeeping without issuing collectives
 
 
 def _direct_mode(direct):
@@ -90,16 +90,15 @@ def convert_sync_batchnorm(model, process_group=None, force=False, dedicated_gro
     """nn.SyncBatchNorm.convert_sync_batchnorm equivalent: BatchNorm statistics of the HIP path become cross-replica.
     `force` installs the communicator even at world_size 1 (single-GPU smoke test of the collective path).  A collective call:
     every rank converts its model (as with the reference's conversion), because the statistics get a communicator of their own —
-    the C-ABI one when asked for (`direct`, CROG_SYNCBN_DIRECT), otherwise a dedicated torch process group (world size > 1; at world
-    size 1 `CROG_SYNCBN_OWN_GROUP=1` forces it for A/B runs: 36.0 vs 35.8-36.2 ms on the default group, i.e. free once the stream
-    creation order is fixed).  Collectives of one communicator run in issue order, so on the default group every statistics exchange
+    the C-ABI one when asked for (`direct`, CROG_SYNCBN_DIRECT), otherwise a dedicated torch process group (world size > 1; measured
+    at world size 1: 36.0 vs 35.8-36.2 ms on the default group, i.e. free once the stream creation order is fixed).  Collectives of one communicator run in issue order, so on the default group every statistics exchange
     issued while a 64 MiB gradient bucket is in flight (nine per step, ~0.4 ms each at 8 GPUs) would wait for it on the critical path."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force):
         RT.ensure_streams()       # the side streams take their hardware queues before the communicator's streams exist
         rccl, peer = _direct_mode(direct)
         use_direct = ((rccl and dist.get_backend(process_group) == "nccl") or peer) and torch.cuda.is_available()
         group = process_group
-        need_group = dedicated_group and (dist.get_world_size() > 1 or _os.environ.get("CROG_SYNCBN_OWN_GROUP") == "1")
+        need_group = dedicated_group and dist.get_world_size() > 1
         if group is None and need_group and not (use_direct and rccl):
             # (a peer-only communicator still needs a torch group for exchanges larger than a mailbox slot)
             group = dist.new_group()

@@ -20,26 +20,15 @@ from . import kernels as K
 ALIGN = 8  # elements; keeps every parameter 16-byte aligned in the bf16 shadow too
 
 
-def _cu_masked_stream(cus: int, dev):
-    """A/B aid (CROG_WGRAD_CUS=N, eager steps only - a hipGraph replay does not keep stream attributes): a stream whose kernels may only
-    use N of the 256 CUs (hipExtStreamCreateWithCUMask; mask bits are dealt round-robin over the 8 XCDs, so the low N bits are N/8 CUs
-    of every XCD), wrapped for torch.  Measured in round 3 as the weight-gradient stream: see DESIGN.md section 4."""
-    import ctypes
-    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
-    words = (ctypes.c_uint32 * 8)(*[(((1 << cus) - 1) >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
-    h = ctypes.c_void_p()
-    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(8), words)
-    if rc != 0:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
-    return torch.cuda.ExternalStream(h.value, device=dev)
-
-
 class Runtime:
     def __init__(self):
         self.comm = None       # object with .world_size and .all_reduce_sum(tensor) for SyncBatchNorm
         self.reducer = None    # gradient reducer (crog_amd.parallel); .mark_ready(param)
         self.streams = []      # HIP streams the model's kernels run on (main + text-tower side stream + wgrad stream)
-        self.overlap_wgrad = os.environ.get("CROG_OVERLAP_WGRAD", "1") != "0"
+        self.overlap_wgrad = True     # weight gradients on a side stream (bench.py's CROG_SINGLE_STREAM profile mode switches it off)
+        self.defer_wgrad = os.environ.get("CROG_DEFER_WGRAD", "0") == "1"     # A/B (round 3): weight gradients start after the layer's data gradient
+        self._pending_wgrad = []
+        self._pending_done = []
         self._wgrad_stream = None
         self.text_stream = None
         self._streams_ready = False
@@ -70,16 +59,13 @@ class Runtime:
             main = torch.cuda.current_stream()
             order = []
             if self.overlap_wgrad:
-                n = max(1, int(os.environ.get("CROG_WGRAD_STREAMS", "1")))
-                prio = int(os.environ.get("CROG_SIDE_PRIORITY", "0"))
-                cus = int(os.environ.get("CROG_WGRAD_CUS", "0"))
-                if cus > 0:
-                    self._wgrad_stream = [_cu_masked_stream(cus, dev)]
-                else:
-                    self._wgrad_stream = [torch.cuda.Stream(priority=prio) for _ in range(n)]
-                self._wgrad_next = 0
+                # ONE weight-gradient stream at default priority.  Measured alternatives: two or three streams
+                # round-robin (1 % slower: the small atomic-bound launches contend with each other), stream priorities either way (no
+                # change), a CU-masked stream of 64 / 96 / 128 / 192 CUs (64.2 / 57.5 / 56.9 / 53.9 ms per step against 33.4: the weight
+                # gradients need half of the chip-time of a step and cannot finish on a slice of it).
+                self._wgrad_stream = [torch.cuda.Stream()]
                 order += self._wgrad_stream
-            self.text_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CROG_SIDE_PRIORITY", "0")))
+            self.text_stream = torch.cuda.Stream(device=dev)
             order.append(self.text_stream)
             touch = torch.zeros(8, device=dev)
             for s in order:                     # first USE binds the stream to its hardware queue
@@ -90,26 +76,46 @@ class Runtime:
         self._streams_ready = True
 
     def wgrad_stream(self):
-        """Weight-gradient side stream (CROG_WGRAD_STREAMS > 1 round-robins over several: measured 1 % slower with 2-3, the small
-        atomic-bound weight gradients contend with each other)."""
+        """The weight-gradient side stream (one: every reduction into a parameter gradient is ordered on it)."""
         if not self.overlap_wgrad or not torch.cuda.is_available():
             return None
         if self._wgrad_stream is None:
             self.ensure_streams()
         if self._wgrad_stream is None:
-            n = max(1, int(os.environ.get("CROG_WGRAD_STREAMS", "1")))
-            prio = int(os.environ.get("CROG_SIDE_PRIORITY", "0"))
-            self._wgrad_stream = [torch.cuda.Stream(priority=prio) for _ in range(n)]
-            self._wgrad_next = 0
-        s = self._wgrad_stream[self._wgrad_next % len(self._wgrad_stream)]
-        self._wgrad_next += 1
+            self._wgrad_stream = [torch.cuda.Stream()]
+        s = self._wgrad_stream[0]
         if s not in self.streams:
             self.streams.append(s)
         return s
 
     def on_wgrad_stream(self, fn, *tensors):
         """Run fn() (kernel launches only) on the weight-gradient stream, after everything enqueued so far on the current
-        stream; `tensors` are the operands it reads (kept alive for that stream)."""
+        stream; `tensors` are the operands it reads (kept alive for that stream).
+        With `defer_wgrad` the fork is taken one launch LATER: the request is parked and issued by the next `flush_wgrad()` - which
+        ConvBnAct.backward calls right after it has enqueued the layer's data-gradient GEMM - so a weight gradient starts when that
+        data gradient has finished instead of next to it (both are MFMA-bound: side by side the one on the critical path takes up
+        to 2.5x its own time)."""
+        if self.defer_wgrad and self.overlap_wgrad and torch.cuda.is_available():
+            self.flush_wgrad()
+            self._pending_wgrad.append((fn, tensors))
+            if not self._join_armed:
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+                    self._join_armed = True
+                except RuntimeError:
+                    self.flush_wgrad()
+            return
+        self._issue_wgrad(fn, tensors)
+
+    def flush_wgrad(self):
+        pend, self._pending_wgrad = self._pending_wgrad, []
+        for fn, tensors in pend:
+            self._issue_wgrad(fn, tensors)
+        done, self._pending_done = self._pending_done, []
+        for d in done:
+            d()
+
+    def _issue_wgrad(self, fn, tensors):
         s = self.wgrad_stream()
         if s is None:
             fn()
@@ -137,12 +143,14 @@ class Runtime:
 
     def _end_of_backward(self):
         self._join_armed = False
+        self.flush_wgrad()
         self.join_streams()
 
     def join_streams(self):
         """Make the current stream wait for every side stream (before the optimizer step / gradient zeroing)."""
         if not torch.cuda.is_available():
             return
+        self.flush_wgrad()
         cur = torch.cuda.current_stream()
         for s in self.streams:
             if s != cur:
@@ -191,7 +199,7 @@ class Runtime:
 RT = Runtime()
 
 
-_LEGACY_SYNC = os.environ.get("CROG_LEGACY_SYNC") == "1"   # A/B: always memset G in zero_grad, always re-cast the shadow per forward
+_LEGACY_SYNC = False   # (round-1 A/B: always memset G in zero_grad, always re-cast the shadow per forward)
 
 
 class ParamStore:

@@ -1,4 +1,4 @@
-"""3x3 forward-shaped implicit GEMMs by output width N: tile order / tile size A-B (GPU box).  CROG_GEMM_DEBUG=16: row tiles fastest."""
+"""3x3 forward-shaped implicit GEMMs by output width N: tile order / tile size A-B (GPU box).  K.DEBUG_FLAGS = 16: row tiles fastest."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

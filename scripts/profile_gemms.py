@@ -13,7 +13,7 @@ cfg = make_cfg(); torch.manual_seed(0)
 model, groups = build_crog(cfg); model = model.cuda().prepare()
 if os.environ.get("CROG_NO_TEXT_OVERLAP") == "1": model.overlap_text = False
 if os.environ.get("CROG_SINGLE_STREAM") == "1":
-    from crog_amd import runtime as RT
+    from crog_amd.runtime import RT
     RT.overlap_wgrad = False; model.overlap_text = False
 opt = FusedAdam(groups, lr=1e-4, store=model.store)
 batch = synthetic_batch(B, 416, 20, 49408, seed=1, device="cuda"); model.train()

@@ -90,3 +90,15 @@ def test_decoder_return_intermediate_flag():
     from crog_amd.model.layers import TransformerDecoder
     dec = TransformerDecoder(num_layers=3, d_model=64, nhead=2, dim_ffn=128, dropout=0.0, return_intermediate=True)
     assert dec.return_intermediate and len(dec.layers) == 3
+
+
+def test_unsupported_resnet_width_is_refused_by_name_before_any_forward():
+    """clip.py:165-185 is width-generic; the HIP path implements width 64 (RN50 / RN101).  An RN50x4-shaped tower (width 80) is
+    refused by `check_supported` - which CROG.prepare() calls when the model is bound to the GPU - with the width and the archive
+    in the message, not by a kernel argument check deep inside the first forward."""
+    import pytest
+    from crog_amd.model.clip import ModifiedResNet
+    tower = ModifiedResNet((1, 1, 1, 1), 640, 40, 288, width=80)
+    with pytest.raises(NotImplementedError, match=r"width 80 \(RN50x4.pt\)"):
+        tower.check_supported("RN50x4.pt")
+    ModifiedResNet((1, 1, 1, 1), 1024, 32, 224, width=64).check_supported("RN50.pt")

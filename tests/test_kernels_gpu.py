@@ -197,26 +197,6 @@ def test_conv3x3_fwd_dgrad_wgrad(K, dt, B, H, W, Cin, Cout):
     close(dw.view(Cout, 3, 3, Cin), wt.grad.permute(0, 2, 3, 1), dt, scale=math.sqrt(M) / 2)
 
 
-def test_gemm_hwtr_matches_fallback(K):
-    """ds_read_b64_tr_b16 fragment path == scalar LDS read path (run in a subprocess with the env switch)."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import torch, sys; sys.path.insert(0, %r); from crog_amd import kernels as K;"
-        "g=torch.Generator().manual_seed(1); a=torch.randn(300,72,generator=g).cuda().bfloat16(); b=torch.randn(300,200,generator=g).cuda().bfloat16();"
-        "c=torch.zeros(72,200,device='cuda'); K.gemm(1,K.A_MC,K.B_NC,a,b,c,72,200,300,72,200,200,out_mode=K.OUT_F32);"
-        "torch.cuda.synchronize(); ref=a.float().t()@b.float(); print(float((c-ref).abs().max()))"
-    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for flag in ("0", "1"):
-        env = dict(os.environ, CROG_GEMM_NO_HWTR=flag)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr
-        outs.append(float(r.stdout.strip().splitlines()[-1]))
-    assert outs[0] < 0.5 and outs[1] < 0.5, outs
-
-
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DT)
 def test_batchnorm_train_fwd_bwd(K, dt):
