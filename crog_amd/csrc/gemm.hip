@@ -326,11 +326,14 @@ __device__ inline float dpp_swap1(float v) {
 // NSTAGE: depth of the LDS-DMA ring (0 = the default of the tile size, dma_nstage()).
 // BWD: a LEAN tile whose statistics are the BatchNorm-BACKWARD ones (crog_gemm_desc.bwd_z); a kernel of its own so that the
 // gather of z does not cost the other instantiations registers.
-template <int WM_, int WN_, int WVM_, int WVN_, bool LEAN_ = false, int NSTAGE_ = 0, bool BWD_ = false>
+// ATOM: a LEAN tile whose ONLY epilogue is the fp32 atomic add of a split-K weight gradient (out_mode CROG_OUT_F32_ATOMIC, alpha 1, no
+// a_sum): the 256 x 256 tile for the large 3x3 weight gradients.
+template <int WM_, int WN_, int WVM_, int WVN_, bool LEAN_ = false, int NSTAGE_ = 0, bool BWD_ = false, bool ATOM_ = false>
 struct Shape {
   static constexpr int WM = WM_, WN = WN_, WVM = WVM_, WVN = WVN_, NSTAGE = NSTAGE_;
-  static constexpr bool LEAN = LEAN_, BWD = BWD_;
+  static constexpr bool LEAN = LEAN_, BWD = BWD_, ATOM = ATOM_;
   static_assert(!BWD_ || LEAN_, "the backward-statistics epilogue is a lean one");
+  static_assert(!ATOM_ || (LEAN_ && !BWD_), "the atomic-only epilogue is a lean one");
   static constexpr int NT = 64 * WVM * WVN, BM = 32 * WM * WVM, BN = 32 * WN * WVN;
 };
 // (a 256 x 128 register-staged variant was measured slower than 128 x 128 -- occupancy-bound staging -- and spilled at 256 VGPRs: removed)
@@ -378,6 +381,31 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
       }
   };
   constexpr bool LEAN = S::LEAN;
+  if constexpr (S::ATOM) {
+    // split-K weight gradient: accumulators -> fp32 atomic adds, one 32 x 32 block at a time (a register covers 2 rows x 32
+    // consecutive columns: a wave-instruction is two 128-byte runs).  Nothing else is compiled into this tile.
+    float* Cf = reinterpret_cast<float*>(p.C) + coff;
+    const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;
+    auto add_all = [&](auto guarded) {
+      constexpr bool G = decltype(guarded)::value;
+#pragma unroll
+      for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++) {
+          const int mb = m0 + (wr * WM + i) * 32 + 4 * h;
+          float* cb = Cf + (int64_t)mb * p.ldc + ncol[j];
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            const int ro = (e & 3) + 8 * (e >> 2);
+            if (!G || (mb + ro < p.M && ncol[j] < p.N)) atomicAdd(cb + (int64_t)ro * p.ldc, acc[i][j][e]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (interior) add_all(std::false_type{});
+    else add_all(std::true_type{});
+    return;
+  }
   if (!LEAN && (alpha != 1.f || bias)) {
     per_block([&](int i, int j) {
 #pragma unroll
@@ -1097,6 +1125,7 @@ __device__ __attribute__((always_inline)) inline void wait_tiles(int behind) {
 // (barrier stalls are not hidden by a second block: 5-30 % slower than 128 x 128 at three blocks per CU), 128 x 256 with 4 waves of
 // 64 x 128 (20-45 % slower), 64 x 256 for Cout <= 64 weight gradients (two blocks per CU, 20 KiB per k-tile: 14 % slower).
 using ShapeDma8 = Shape<4, 2, 2, 4, true>;   // 256 x 256, 8 waves, 128 accumulator registers per lane (lean epilogue: at the 256-VGPR limit the full one spills)
+using ShapeDma8A = Shape<4, 2, 2, 4, true, 0, false, true>;   // the same tile with the atomic-only epilogue: large 3x3 weight gradients
 using ShapeTall = Shape<2, 2, 4, 1>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
 using ShapeDma64 = Shape<1, 1, 2, 2>;  //  64 x  64, 4 waves: small GEMMs (text tower, attention pooling), no BN statistics
 using ShapeMidBwd = Shape<2, 2, 2, 2, true, 0, true>;   // 128 x 128 data gradient that does the consumer BatchNorm's first backward pass
@@ -1321,7 +1350,7 @@ int launch_dma(const crog_gemm_desc& d, hipStream_t s) {
   constexpr int ring = dma_nstage<S>() * (S::BM + S::BN) * 64, epi = lds_bytes<T, S>();   // the epilogue reuses the ring
   constexpr int LDS = ring > epi ? ring : epi;
   static bool attr_set = false;
-  constexpr bool CAN_ASUM = AL == CROG_A_MC;     // a_sum is only requested by weight-gradient launches
+  constexpr bool CAN_ASUM = AL == CROG_A_MC && !S::ATOM;     // a_sum is only requested by weight-gradient launches (not on the atomic-only tile)
   auto kern = gemm_dma_kernel<T, AL, BL, S, 0>;
   auto kern_asum = gemm_dma_kernel<T, AL, BL, S, CAN_ASUM ? 1 : 0>;
   if (!attr_set) {
@@ -1440,6 +1469,23 @@ inline bool small_wgrad(int a_layout, int b_layout, int out_mode, long M, long N
   return b_layout == CROG_B_NC_IM2COL && M * N <= 160L * 1024;      // 3x3 weight gradients with Cout <= 128: 64 x 64 tiles
 }
 
+// Large weight gradients (both output sides multiples of 256, a reduction of >= 8192) on the 256 x 256 tile with the atomic-only
+// epilogue (round 3): half the L2 -> LDS bytes and half the LDS fragment reads per MFMA of the 128 x 128 tile, which is what bounds a
+// weight gradient (both operands are read transposed out of LDS).  One 8-wave block owns a CU, so a launch is kept to ~144 blocks: the
+// side stream works a little over half of the chip at the better per-CU rate and leaves the rest to the main stream.  Measured in the
+// step, interleaved pairs of 60 steps, three boxes: 3x3 forms only (>= 512 K outputs) 32.6-32.8 ms against 33.2-33.6 on 128 x 128; plus
+// the 1x1 / linear forms from 256 K outputs (512 x 512 over 21632 pixels: 12 launches per step) **31.8-32.2 ms (-3.3 ... -3.6 %)**, and
+// the roofline kernel next to them 596-603 instead of 528-537 TFLOP/s.  Targets of 80 / 96 / 112 blocks help the neighbour more
+// (617-629 TFLOP/s) and the step less (31.9-33.2 ms), 176-208 lose (32.2-32.7): 144.  Lower thresholds (128 K / 64 K outputs, 3x3 from
+// 256 K) change nothing.
+constexpr long WGRAD256_BLOCKS = 144;
+inline bool big_wgrad(int dtype, int a_layout, int b_layout, int out_mode, long M, long N, long K) {
+  if (dtype != CROG_BF16 || out_mode != CROG_OUT_F32_ATOMIC || a_layout != CROG_A_MC) return false;
+  if (M % 256 != 0 || N % 256 != 0 || K < 8192) return false;
+  if (b_layout == CROG_B_NC_IM2COL) return M * N >= (1L << 19);
+  return b_layout == CROG_B_NC && M * N >= (1L << 18);
+}
+
 inline bool lean_epilogue_ok(const crog_gemm_desc& d) {
   return d.alpha == 1.f && !d.bias && d.act == CROG_ACT_NONE && !d.R && d.out_mode == CROG_OUT_T && d.dtype == CROG_BF16 && (d.N & 1) == 0;
 }
@@ -1472,6 +1518,12 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
       if (lean_epilogue_ok(d) && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0 && (long)cdiv(d.M, 256) * (d.N / 256) >= 160)
         return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, ShapeDma8>(d, s);
     }
+    if constexpr (sizeof(T) == 2) {
+      if (big_wgrad(d.dtype, d.a_layout, d.b_layout, d.out_mode, d.M, d.N, d.K) && d.alpha == 1.f && !d.a_sum && !d.bias && !d.R && d.batch == 1) {
+        if (d.b_layout == CROG_B_NC_IM2COL) return launch_dma<T, CROG_A_MC, CROG_B_NC_IM2COL, ShapeDma8A>(d, s);
+        return launch_dma<T, CROG_A_MC, CROG_B_NC, ShapeDma8A>(d, s);
+      }
+    }
     // Otherwise by padding waste: 64-wide sides for <= 64 columns, 64 x 64 for small problems and small 3x3 weight gradients
     if (d.col_stats) {
       if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
@@ -1500,7 +1552,10 @@ extern "C" int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int 
   const int bk = dtype == CROG_BF16 ? 32 : 16;
   const long ktiles = cdiv(K, bk);
   long s;
-  if (small_wgrad(a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N)) {      // 64 x 64 tiles, ~2048 blocks, >= 16 k-tiles per block
+  if (big_wgrad(dtype, a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N, K)) {      // 256 x 256 tiles, >= 32 k-tiles per block
+    const long tiles = (long)(M / 256) * (N / 256);
+    s = std::min(std::max(1L, WGRAD256_BLOCKS / tiles), std::max(1L, ktiles / 32));
+  } else if (small_wgrad(a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N)) {      // 64 x 64 tiles, ~2048 blocks, >= 16 k-tiles per block
     const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
     s = std::min(std::max(1L, 2048 / tiles), std::max(1L, ktiles / 16));
   } else {      // 128 x 128 tiles: ~256 blocks (512 for the 3x3 form and for outputs above 1 M elements), >= 24 k-tiles per block
@@ -1509,6 +1564,13 @@ extern "C" int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int 
     s = std::min(std::max(1L, target / tiles), std::max(1L, ktiles / 24));
   }
   return (int)std::max(1L, std::min(s, 1024L));
+}
+
+// Edge of the tile crog_gemm takes for a weight-gradient GEMM (256: the atomic-only 256 x 256 tile, which cannot also form a_sum - the caller
+// then sums the bias gradient separately, crog_colsum).
+extern "C" int crog_gemm_wgrad_tile(int dtype, int a_layout, int b_layout, int M, int N, int K) {
+  if (big_wgrad(dtype, a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N, K)) return 256;
+  return small_wgrad(a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N) ? 64 : 128;
 }
 
 // Can crog_gemm do the BatchNorm-backward statistics (bwd_z) for this descriptor?  The caller decides BEFORE the producer layer commits

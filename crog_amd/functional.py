@@ -147,6 +147,9 @@ def lin_wgrad(dy, x, w: WRef, *, a_off=0, lda=None, N=None, bias: Optional[WRef]
     _, Kd, ldx = K.mat(x)
     dt = _cdt(x)
     sk = K.pick_splitk(n, Kd, M, _bk(dt))
+    if bias is not None and a_off == 0 and K.lib().crog_gemm_wgrad_tile(dt, K.A_MC, K.B_NC, n, Kd, M) == 256:
+        bias_grad(dy, bias, 0, n)      # the 256 x 256 weight-gradient tile has no a_sum path: the bias gradient is its own column sum
+        bias = None
     K.gemm(dt, K.A_MC, K.B_NC, dy, x, w.G, n, Kd, M, lda if lda is not None else ld, ldx, w.cols, a_off=a_off, c_off=w.off,
            splitk=sk, out_mode=K.OUT_F32_ATOMIC, a_sum=bias.G if bias is not None else None, a_sum_off=bias.off if bias is not None else 0)
 
@@ -447,7 +450,9 @@ class ConvBnAct(Function):
                            splitk=sk, out_mode=K.OUT_F32_ATOMIC)
                 if wpad is not None:  # strip the zero padding back out into the real gradient
                     K.add_pad2d(gscratch, dst_cols, w.G, src_cols, src_cols, rows, dst_off=w.off)
-            RT.on_wgrad_stream(wgrad, dz, x, gt if wpad is not None else None)
+            # (a data gradient that will take the one-block-per-CU 256 x 256 tile: csrc/gemm.hip dispatch_shape)
+            big = ksize == 3 and ctx.x_needs and wpad is None and dtype == torch.bfloat16 and cin % 256 == 0 and ((M + 255) // 256) * (cin // 256) >= 160
+            RT.on_wgrad_stream(wgrad, dz, x, gt if wpad is not None else None, defer=big)
             # BnLink: this data gradient is the previous layer's dy -> its epilogue does that layer's first BatchNorm-backward pass
             bwd = {}
             # (the last two terms mirror crog_gemm's own eligibility test for bwd_z - operands the LDS-DMA path can address with 32-bit

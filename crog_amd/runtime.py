@@ -26,7 +26,9 @@ class Runtime:
         self.reducer = None    # gradient reducer (crog_amd.parallel); .mark_ready(param)
         self.streams = []      # HIP streams the model's kernels run on (main + text-tower side stream + wgrad stream)
         self.overlap_wgrad = True     # weight gradients on a side stream (bench.py's CROG_SINGLE_STREAM profile mode switches it off)
-        self.defer_wgrad = os.environ.get("CROG_DEFER_WGRAD", "0") == "1"     # A/B (round 3): weight gradients start after the layer's data gradient
+        # A/B (round 3): weight gradients start after the layer's data gradient: "all" layers, or only the "big" ones whose data gradient
+        # runs on the 256 x 256 tile (one block per CU: it needs CUs free of weight-gradient blocks)
+        self.defer_wgrad = {"1": "all", "all": "all", "big": "big"}.get(os.environ.get("CROG_DEFER_WGRAD", "0"), "")
         self._pending_wgrad = []
         self._pending_done = []
         self._wgrad_stream = None
@@ -88,14 +90,15 @@ class Runtime:
             self.streams.append(s)
         return s
 
-    def on_wgrad_stream(self, fn, *tensors):
+    def on_wgrad_stream(self, fn, *tensors, defer=None):
         """Run fn() (kernel launches only) on the weight-gradient stream, after everything enqueued so far on the current
         stream; `tensors` are the operands it reads (kept alive for that stream).
         With `defer_wgrad` the fork is taken one launch LATER: the request is parked and issued by the next `flush_wgrad()` - which
         ConvBnAct.backward calls right after it has enqueued the layer's data-gradient GEMM - so a weight gradient starts when that
         data gradient has finished instead of next to it (both are MFMA-bound: side by side the one on the critical path takes up
         to 2.5x its own time)."""
-        if self.defer_wgrad and self.overlap_wgrad and torch.cuda.is_available():
+        want = self.defer_wgrad == "all" or (self.defer_wgrad == "big" and defer)
+        if want and self.overlap_wgrad and torch.cuda.is_available():
             self.flush_wgrad()
             self._pending_wgrad.append((fn, tensors))
             if not self._join_armed:

@@ -167,6 +167,9 @@ int crog_gemm_stat_tiles(int M);
 /* Split count for a weight-gradient GEMM (out_mode CROG_OUT_F32_ATOMIC) of logical size M x N over K, matched to the tile
  * shape crog_gemm selects for it (wgrad call sites: every conv / linear backward, e.g. clip.py:44-57, layers.py:298-301). */
 int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int M, int N, int K);
+/* Tile edge (64 / 128 / 256) crog_gemm takes for that weight gradient.  The 256 x 256 tile has an atomic-only epilogue: a launch that
+ * also asks for a_sum stays on 128 x 128, so a caller that wants the wide tile sums the bias gradient with crog_colsum instead. */
+int crog_gemm_wgrad_tile(int dtype, int a_layout, int b_layout, int M, int N, int K);
 /* 1 when crog_gemm can run this descriptor with the BatchNorm-backward statistics epilogue (bwd_z): bf16, one of the three
  * data-gradient layouts, plain epilogue, operands addressable by the LDS-DMA path (32-bit byte offsets).  For callers that must
  * decide before the producing layer skips its own first pass. */

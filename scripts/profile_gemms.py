@@ -69,3 +69,14 @@ for key, (n, dsum, fl) in sorted(agg.items(), key=lambda kv: -(kv[1][1] - kv[1][
     al, bl, M, N, Kd, bt, sk = key
     print(f"  in-step {dsum:7.3f}  replay {n*rep[key]:7.3f}  n={n:3d} {names[(al,bl)]:12s} M={M:7d} N={N:5d} K={Kd:7d} batch={bt:4d} sk={sk:4d}  each {dsum/n*1e3:7.1f} vs {rep[key]*1e3:7.1f} us")
 print(f"in-step total {tot:.2f} ms, replay total {sum(a[0]*rep[k] for k, a in agg.items()):.2f} ms")
+print("standalone (replay) time minus ideal, all shapes, by gap:")
+rows = sorted(((n * (rep[k] - ideal_ms(k, fl)), n, rep[k], ideal_ms(k, fl), fl, k) for k, (n, d, fl) in agg.items()), reverse=True)
+acc = 0.0
+for gap_, n, r, idl, fl, key in rows[:80]:
+    al, bl, M, N, Kd, bt, sk = key
+    acc += gap_
+    print(f"  gap {gap_:6.3f} (cum {acc:6.2f})  n={n:3d} {names[(al,bl)]:12s} M={M:7d} N={N:5d} K={Kd:7d} batch={bt:4d} sk={sk:4d}  alone {r*1e3:7.1f} us ideal {idl*1e3:6.1f}  {fl/r/1e9:7.1f} TF/s")
+cat = collections.defaultdict(lambda: [0.0, 0.0])
+for gap_, n, r, idl, fl, key in rows:
+    c = cat[names[(key[0], key[1])]]; c[0] += n * r; c[1] += n * idl
+print({k: (round(v[0], 2), round(v[1], 2)) for k, v in cat.items()})

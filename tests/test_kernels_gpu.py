@@ -898,6 +898,35 @@ def test_production_linear_weight_gradient_split_k(K, dt, M, N, Kd):
     assert _rel_l2(db, dy.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,Kd", [(21632, 512, 512), (21632, 1024, 256), (86528, 512, 256), (21600, 256, 1024)])
+def test_wide_tile_weight_gradient_256x256(K, M, N, Kd):
+    """Weight gradients whose two output sides are multiples of 256 (>= 256 K outputs, reduction >= 8192) take the 8-wave 256 x 256 tile
+    with the atomic-only epilogue (csrc/gemm.hip big_wgrad / ShapeDma8A): against float64, incl. a reduction that is no multiple of the
+    k-tile, accumulation on top of existing gradients, and the bias gradient the operator layer sums separately for this tile."""
+    dt = torch.bfloat16
+    assert K.lib().crog_gemm_wgrad_tile(K.BF16, K.A_MC, K.B_NC, N, Kd, M) == 256
+    x, dy = rnd(M, Kd, dt=dt), rnd(M, N, dt=dt, seed=3)
+    sk = K.pick_splitk(N, Kd, M, 32)
+    base = rnd(N, Kd, seed=9)
+    dw = base.clone()
+    K.gemm(K.BF16, K.A_MC, K.B_NC, dy, x, dw, N, Kd, M, N, Kd, Kd, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+    want = (dy.double().t() @ x.double()).float()
+    r = _rel_l2(dw - base, want)
+    print(f"wide-tile wgrad [{N} x {Kd}] over M={M} splitk={sk}: rel L2 {r:.2e}")
+    assert r < 1e-5
+    # through the operator layer: weight + bias gradient of a Linear (the bias sum becomes its own launch for this tile)
+    from crog_amd import functional as Fn
+    from crog_amd.runtime import ParamStore
+    lin = torch.nn.Linear(Kd, N).cuda()
+    store = ParamStore(lin, torch.device("cuda"))
+    w, b = Fn.WRef(store, lin.weight), Fn.WRef(store, lin.bias, cols=1)
+    store.G.zero_()
+    Fn.lin_wgrad(dy, x, w, bias=b)
+    torch.cuda.synchronize()
+    assert _rel_l2(w.grad().view(N, Kd), want) < 1e-5
+    assert _rel_l2(b.grad(), dy.double().sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("B,HW,Cin,Cout", [(32, 104, 64, 64), (32, 52, 128, 128), (8, 104, 512, 256), (32, 26, 512, 512)])
 def test_production_conv3x3_fwd_dgrad_wgrad(K, dt, B, HW, Cin, Cout):
