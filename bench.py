@@ -364,6 +364,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     last = stats.tolist()
+    if not all(v == v and abs(v) != float("inf") for v in last):
+        # a number measured on a step that produces NaN / inf is not a measurement of the training step
+        print(f"bench.py: non-finite training statistics after the timed region (loss, IoU, Prec@50 = {last}): refusing to report a throughput", file=sys.stderr)
+        return 3
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -381,14 +385,19 @@ def main():
             flops = [f for _, _, f, _ in recs]
         if recs:
             avg_d, avg_f = sum(durs) / len(durs), sum(flops) / len(flops)
-            traffic = None   # HBM bytes per launch of this kernel from the committed PMC passes (profiles/pmc_traffic.json)
+            # HBM bytes per launch of this kernel: NOT measured in this run (PMC counters need rocprofv3 around the process) but read from
+            # the committed PMC passes of the same workload, and labelled as such - it goes stale when the kernels change and the
+            # round's profile is not re-taken
+            traffic = traffic_source = None
             try:
                 pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
-                traffic = pm[args.roofline_kernel]["bytes_per_launch"] if args.dtype == "bf16" and args.batch == 32 else None
+                if args.dtype == "bf16" and args.batch == 32:
+                    traffic = pm[args.roofline_kernel]["bytes_per_launch"]
+                    traffic_source = "committed profile, not this run: profiles/pmc_traffic.json (" + pm[args.roofline_kernel].get("source", "?") + ")"
             except (OSError, KeyError, ValueError):
                 pass
             roof = dict(bound="mfma", achieved=round(avg_f / avg_d / 1e12, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
-                        frac=round(avg_f / avg_d / 1e12 / PEAK_MFMA_TF, 4), traffic=traffic,
+                        frac=round(avg_f / avg_d / 1e12 / PEAK_MFMA_TF, 4), traffic=traffic, traffic_source=traffic_source,
                         kernel=K.GEMM_SYMBOL[key], launches_per_step=len(recs) // max(sampled, 1), timed_steps_bracketed=sampled,
                         avg_launch_us=round(avg_d * 1e6, 1), avg_gflop_per_launch=round(avg_f / 1e9, 2),
                         share_of_step=round(sum(durs) / max(sampled, 1) / (dt / args.steps), 4))

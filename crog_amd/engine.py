@@ -94,6 +94,80 @@ def eval_maps(model, batch, autocast_dtype=None):
     return [maps[:, g] for g in range(maps.shape[1])], target
 
 
+def _reference_host_half():
+    """The host post-processing of validate_with_grasp is the reference's own code (out of scope here): cv2's
+    inverse warp and utils/grasp_eval.py's detect_grasps / calculate_jacquard_index.  In a deployment they are importable - the
+    reference's `utils` package is on sys.path next to train_crog.py, cv2 and skimage are its dependencies; this image has neither."""
+    try:
+        import cv2
+        from utils.grasp_eval import calculate_jacquard_index, detect_grasps
+    except ImportError as e:
+        raise ImportError("crog_amd.engine.validate_with_grasp: the host half (cv2.warpAffine, utils.grasp_eval.detect_grasps / "
+                          "calculate_jacquard_index of the reference) is not importable here; pass inverse= / detect= / jacquard= callables") from e
+
+    def inverse(img, mat, w, h):          # crog_engine.py:127-131
+        return cv2.warpAffine(img, mat, (w, h), flags=cv2.INTER_CUBIC, borderValue=0.)
+    return inverse, detect_grasps, calculate_jacquard_index
+
+
+@torch.no_grad()
+def validate_with_grasp(val_loader, model, epoch, args, inverse=None, detect=None, jacquard=None, log=print, autocast_dtype=None):
+    """Drop-in for engine/crog_engine.py:125-285 (same arguments, same return `(iou, prec, J_index)`, same log line).
+    Device half on the HIP path: eval forward + sigmoid + bicubic align_corners resize of all five maps in one kernel (`eval_maps`,
+    crog_engine.py:163-211).  Host half, per sample as in the reference (:214-261): inverse warp to the original size, IoU of the
+    thresholded instance mask, grasp detection and Jacquard index for 1 and 5 grasps - `inverse(img, mat, w, h)`,
+    `detect(qua, sin, cos, wid, n) -> (grasps, _)`, `jacquard(grasps, targets) -> 0/1` default to the reference's own cv2 /
+    utils.grasp_eval functions.  The per-sample IoUs are gathered over the ranks (utils/misc.py:46-59) before Pr@50..90."""
+    import numpy as np
+    if inverse is None or detect is None or jacquard is None:
+        r_inv, r_det, r_jac = _reference_host_half()
+        inverse, detect, jacquard = inverse or r_inv, detect or r_det, jacquard or r_jac
+    model.eval()
+    num_grasps = [1, 5]
+    correct, total = [0, 0], [0, 0]
+    iou_list = []
+    dev = None
+    for data in val_loader:
+        gm = data["grasp_masks"]
+        batch = dict(img=data["img"].cuda(non_blocking=True), word=data["word_vec"].cuda(non_blocking=True),
+                     mask=data["mask"].cuda(non_blocking=True).unsqueeze(1), qua=gm["qua"].cuda(non_blocking=True).unsqueeze(1),
+                     sin=gm["sin"].cuda(non_blocking=True).unsqueeze(1), cos=gm["cos"].cuda(non_blocking=True).unsqueeze(1),
+                     wid=gm["wid"].cuda(non_blocking=True).unsqueeze(1))
+        dev = batch["img"].device
+        maps, targets = eval_maps(model, batch, autocast_dtype=autocast_dtype)
+        preds_np = [m.cpu().numpy() for m in maps]                             # one device -> host copy per map, not per sample
+        tgts_np = [t.squeeze(1).float().cpu().numpy() for t in targets]
+        for idx in range(preds_np[0].shape[0]):
+            inv_mat = data["inverse"][idx]
+            h, w = data["ori_size"][idx]
+            h, w = int(h), int(w)
+            p = [inverse(np.ascontiguousarray(m[idx]), inv_mat, w, h) for m in preds_np]
+            t_ins = inverse(np.ascontiguousarray(tgts_np[0][idx]), inv_mat, w, h)
+            ins = p[0] > 0.35
+            inter, union = np.logical_and(ins, t_ins), np.logical_or(ins, t_ins)
+            iou_list.append(np.sum(inter) / (np.sum(union) + 1e-6))
+            for i, n in enumerate(num_grasps):
+                grasps, _ = detect(p[1], p[2], p[3], p[4], n)
+                correct[i] += jacquard(grasps, data["grasps"][idx])
+                total[i] += 1
+    J_index = [correct[i] / max(total[i], 1) for i in range(2)]
+    ious = torch.from_numpy(np.stack(iou_list)).to(dev)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:       # concat_all_gather, utils/misc.py:46-59
+        parts = [torch.ones_like(ious) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, ious, async_op=False)
+        ious = torch.cat(parts, 0)
+    prec = {}
+    temp = "  "
+    for i, thres in enumerate(torch.arange(0.5, 1.0, 0.1)):          # the reference's thresholds, float32 as it forms them (:271)
+        value = (ious > thres).float().mean().item()
+        prec["Pr@{}".format((5 + i) * 10)] = value
+        temp += "{}: {:.2f}  ".format("Pr@{}".format((5 + i) * 10), 100. * value)
+    iou = ious.mean().item()
+    log("Evaluation: Epoch=[{}/{}]  IoU={:.2f}  J_index@1: {:.2f}  J_index@5: {:.2f}".format(
+        epoch, args.epochs, 100. * iou, 100. * J_index[0], 100. * J_index[1]) + temp)
+    return iou, prec, J_index
+
+
 def mask_iou(pred_map, target, thr=0.35):
     """Per-image IoU of (pred > thr) against a {0,1} target, on the device (crog_engine.py:251-255 without the inverse warp)."""
     p = pred_map > thr

@@ -109,6 +109,7 @@ class WRef:
         st, p = self.store, self.param
         st.g_clean = False
         st.touched.add(id(p))
+        st.written.add(id(p))
         if p.grad is None:      # dropped by a set_to_none zero_grad between forward and backward: G was cleared by BackwardBegin
             p.grad = st.gview[id(p)]
         if RT.reducer is not None:
@@ -148,16 +149,19 @@ def lin_wgrad(dy, x, w: WRef, *, a_off=0, lda=None, N=None, bias: Optional[WRef]
     dt = _cdt(x)
     sk = K.pick_splitk(n, Kd, M, _bk(dt))
     if bias is not None and a_off == 0 and K.lib().crog_gemm_wgrad_tile(dt, K.A_MC, K.B_NC, n, Kd, M) == 256:
-        bias_grad(dy, bias, 0, n)      # the 256 x 256 weight-gradient tile has no a_sum path: the bias gradient is its own column sum
+        bias_grad(dy, bias, 0, n, pooled=True)      # the 256 x 256 weight-gradient tile has no a_sum path: the bias gradient is its own column sum
         bias = None
     K.gemm(dt, K.A_MC, K.B_NC, dy, x, w.G, n, Kd, M, lda if lda is not None else ld, ldx, w.cols, a_off=a_off, c_off=w.off,
            splitk=sk, out_mode=K.OUT_F32_ATOMIC, a_sum=bias.G if bias is not None else None, a_sum_off=bias.off if bias is not None else 0)
 
 
-def bias_grad(dy, b: WRef, col0=0, n=None):
+def bias_grad(dy, b: WRef, col0=0, n=None, pooled=False):
+    """pooled: take the reduction workspace from the step's pre-zeroed pool (valid until the next step, never handed out twice):
+    needed when the launch goes to the weight-gradient stream, where a fresh torch allocation would not be ordered."""
     M, C, ld = K.mat(dy)
     view = dy if (col0 == 0 and (n is None or n == C)) else dy[..., col0:col0 + n]
-    K.colsum(view, b.G, b.off)
+    ws = RT.zeros(K.colsum_workspace(M, K.mat(view)[1]), dy.device) if pooled else None
+    K.colsum(view, b.G, b.off, ws=ws)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -516,10 +516,21 @@ def coord_fill(buf, c0, cend):
     check(lib().crog_coord_fill(dcode(buf), ptr(buf), ld, B, H, W, c0, cend, stream()), "coord_fill")
 
 
-def colsum(x, out, out_off=0):
+def colsum_workspace(M: int, C: int) -> int:
+    rpb = max(8, (M + 127) // 128)
+    return ((M + rpb - 1) // rpb) * C
+
+
+def colsum(x, out, out_off=0, ws=None):
+    """ws: fp32 workspace of colsum_workspace(M, C) floats.  REQUIRED when the launch goes to another stream than torch's current one
+    (Runtime.on_wgrad_stream overrides the launch stream): a torch.empty here would belong to the current stream and could be handed
+    out again while the side stream still reads it."""
     M, C, ldx = mat(x)
     rpb = max(8, (M + 127) // 128)
-    ws = torch.empty(((M + rpb - 1) // rpb) * C, device=x.device, dtype=torch.float32)
+    if ws is None:
+        if _STREAM_OVERRIDE is not None:
+            raise RuntimeError("colsum on an overridden stream needs a caller-owned workspace")
+        ws = torch.empty(((M + rpb - 1) // rpb) * C, device=x.device, dtype=torch.float32)
     check(lib().crog_colsum(dcode(x), ptr(x), ldx, M, C, rpb, ptr(ws), ptr(out) + 4 * out_off, stream()), "colsum")
 
 

@@ -65,9 +65,12 @@ class FusedAdam(torch.optim.Optimizer):
     def _decay_segments(self, group, segs):
         """torch.optim.Adam skips parameters whose gradient is None (CROG: `logit_scale`, never used by the forward): no decay,
         no moment update.  Here such a parameter has a zero gradient in the flat buffer, which only differs from being skipped
-        when weight decay is on, so with decay the segments leave out every parameter no kernel has ever written a gradient for."""
+        when weight decay is on, so with decay the segments leave out every parameter no kernel has written a gradient for SINCE
+        THE LAST zero_grad (`store.written`; advisor, round 2: "ever written" also decayed a parameter that is used in some steps only).
+        Known deviation: all parameters share one step count for the bias correction; a parameter first used at step k is corrected
+        as at step k, torch would start it at 1 (CROG has no such parameter)."""
         store = self._store
-        idle = frozenset(id(p) for p in group["params"] if id(p) not in store.touched)
+        idle = frozenset(id(p) for p in group["params"] if id(p) not in store.written)
         if not idle:
             return segs
         cache = self.__dict__.setdefault("_decay_cache", {})

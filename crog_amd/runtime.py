@@ -160,7 +160,7 @@ class Runtime:
                 cur.wait_stream(s)
 
     # ---- pre-zeroed fp32 scratch: one memset per step instead of one per BatchNorm reduction ---------------------------
-    ZERO_POOL = 1 << 22   # floats (16 MiB): BatchNorm statistic replicas and reduction targets of one step
+    ZERO_POOL = 1 << 23   # floats (32 MiB): BatchNorm statistic replicas, reduction targets and column-sum workspaces of one step
 
     def begin_step(self, device):
         """Called once per training forward: clears the zero pool and rewinds its bump pointer."""
@@ -175,7 +175,14 @@ class Runtime:
         pool = getattr(self, "_zpool", None)
         n8 = (n + 7) // 8 * 8
         if pool is None or pool.device != device or self._zptr + n8 > pool.numel():
-            return torch.zeros(n, device=device, dtype=torch.float32)
+            t = torch.zeros(n, device=device, dtype=torch.float32)
+            if K._STREAM_OVERRIDE is not None and self._wgrad_stream:
+                # the caller launches on the weight-gradient stream (on_wgrad_stream): order that stream behind the fill above and keep
+                # the block from being handed out again while it is still read there
+                s = self._wgrad_stream[0]
+                s.wait_stream(torch.cuda.current_stream())
+                t.record_stream(s)
+            return t
         t = pool[self._zptr:self._zptr + n]
         self._zptr += n8
         return t
@@ -244,7 +251,8 @@ class ParamStore:
             self.by_param[id(p)] = o
         self.explicit = False    # set by crog_amd models: all their gradients are announced through WRef.done()
         self.g_clean = False
-        self.touched = set()     # ids of parameters whose gradient has been written at least once (FusedAdam weight decay)
+        self.touched = set()     # ids of parameters whose gradient has been written at least once
+        self.written = set()     # ... since the last zero_grad (FusedAdam: weight decay skips the others, as torch skips grad-None parameters)
         self.gview = {id(p): g for _, p, _, _, g in self.entries}
         self.conv3_count = len(conv3) // 3
         self.conv3_table = torch.tensor(conv3, dtype=torch.int64, device=device) if conv3 else None
@@ -303,6 +311,7 @@ class ParamStore:
         if _LEGACY_SYNC or not (getattr(self, "explicit", False) and getattr(self, "g_clean", False)):
             self.G.zero_()
             self.g_clean = getattr(self, "explicit", False) and not _LEGACY_SYNC
+        self.written = set()
         self.relink_grads()
 
     def fresh_grads_if_dropped(self):
@@ -312,11 +321,15 @@ class ParamStore:
         forward never uses (`logit_scale`) keeps .grad = None, as in torch.  Called at the start of a training forward and again by
         the first node of backward (the reference zeroes between the two, crog_engine.py:77).  Gradients that are still linked are
         left alone: forward/backward twice without zero_grad accumulates, as in torch."""
-        dropped = [(o, n) for name, p, o, n, g in self.entries if p.grad is None]
+        # decided by IDENTITY (advisor, round 2): only parameters a kernel has written (`touched`) can hold anything in G, so
+        #  * all of those dropped -> one memset of G (the usual case: a stock optimizer's zero_grad drops every link);
+        #  * some of them dropped -> clear exactly their slices; gradients that are still linked keep accumulating;
+        #  * a dropped parameter no kernel ever wrote (`logit_scale`) has a zero slice already: nothing to launch for it.
+        touched = [(p, o, n) for name, p, o, n, g in self.entries if (not self.explicit) or id(p) in self.touched]
+        dropped = [(o, n) for p, o, n in touched if p.grad is None]
         if not dropped:
             return
-        live = len(self.entries) - len(dropped)
-        if live <= len(self.entries) - len(self.touched) or live == 0:      # everything a kernel ever wrote was dropped
+        if len(dropped) == len(touched):
             if _LEGACY_SYNC or not (self.explicit and self.g_clean):
                 self.G.zero_()
                 self.g_clean = self.explicit and not _LEGACY_SYNC

@@ -202,3 +202,53 @@ def test_decoder_return_intermediate_outputs():
     (o2[0].float().sum() + 2.0 * o2[1].float().sum()).backward()
     torch.cuda.synchronize()
     assert float(model.decoder.norm.bias.grad.sum()) == pytest.approx(3.0 * o2[0].numel(), rel=1e-4)     # 1 x (first use) + 2 x (second use), per element
+
+
+def test_validate_with_grasp_is_a_callable_drop_in():
+    """engine.validate_with_grasp (crog_engine.py:125-285): same arguments and return triple.  The device half (eval forward, sigmoid,
+    bicubic align_corners resize) is checked against ATen on the model's own eval logits; the host half is injected (this image has no
+    cv2 / skimage: in a deployment the reference's own functions are picked up) and the aggregation - per-sample IoU at 0.35,
+    Pr@50..90, J@1 / J@5 counting - against a plain numpy restatement of the reference's loop."""
+    import numpy as np
+    import torch.nn.functional as F
+    from types import SimpleNamespace
+    from crog_amd.engine import validate_with_grasp
+    from crog_amd.model import build_crog
+    cfg = tiny_cfg()
+    model, _ = build_crog(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(seeded_state(shapes, seed=21, residual_gain=0.25))
+    model = model.cuda().prepare()
+    model.compute_dtype = torch.float32
+    S = cfg.input_size
+    batches = []
+    for i in range(2):
+        b = synthetic_batch(3, S, cfg.word_len, cfg.clip_arch["vocab_size"], seed=300 + i)
+        batches.append({"img": b["img"], "word_vec": b["word"], "mask": b["mask"].squeeze(1),
+                        "grasp_masks": {k: b[k].squeeze(1) for k in ("qua", "sin", "cos", "wid")},
+                        "inverse": [np.eye(2, 3, dtype=np.float32)] * 3, "ori_size": [(S, S)] * 3, "grasps": [[[1.0, 2.0, 30.0, 20.0, 0.0, 0]]] * 3})
+    inverse = lambda img, mat, w, h: img                                  # identity warp: ori_size == input size
+    detect = lambda q, s_, c, w_, n: ([[float(np.argmax(q) % q.shape[1]), float(np.argmax(q) // q.shape[1]), float(w_.max()) * 100, 20, 0.0]] * n, None)
+    jacquard = lambda grasps, targets: int(len(grasps) == 5 or grasps[0][2] > 40.0)      # depends on n and on the width map
+    lines = []
+    iou, prec, J = validate_with_grasp(batches, model, 3, SimpleNamespace(epochs=50), inverse=inverse, detect=detect, jacquard=jacquard, log=lines.append)
+    # restatement with ATen on the model's eval outputs
+    model.eval()
+    ious, j1 = [], []
+    with torch.no_grad():
+        for d in batches:
+            pred, _ = model(d["img"].cuda(), d["word_vec"].cuda(), d["mask"].cuda().unsqueeze(1), *[d["grasp_masks"][k].cuda().unsqueeze(1) for k in ("qua", "sin", "cos", "wid")])
+            ins = F.interpolate(torch.sigmoid(pred[0]), size=(S, S), mode="bicubic", align_corners=True).squeeze(1).cpu().numpy()
+            wid = F.interpolate(torch.sigmoid(pred[4]), size=(S, S), mode="bicubic", align_corners=True).squeeze(1).cpu().numpy()
+            for k in range(3):
+                m, t = ins[k] > 0.35, d["mask"][k].numpy()
+                ious.append(np.logical_and(m, t).sum() / (np.logical_or(m, t).sum() + 1e-6))
+                j1.append(int(float(wid[k].max()) * 100 > 40.0))
+    ious = np.array(ious)
+    assert abs(iou - ious.mean()) < 1e-4
+    for i, th in enumerate((0.5, 0.6, 0.7, 0.8, 0.9)):
+        assert abs(prec[f"Pr@{(5 + i) * 10}"] - float((ious > th).mean())) < 1e-6
+    assert J == [sum(j1) / 6, 1.0] and set(prec) == {"Pr@50", "Pr@60", "Pr@70", "Pr@80", "Pr@90"}
+    assert lines and lines[0].startswith("Evaluation: Epoch=[3/50]  IoU=") and "J_index@5: 100.00" in lines[0]
+    with pytest.raises(ImportError):                                            # no cv2 / reference utils in this image: the defaults say so
+        validate_with_grasp(batches, model, 3, SimpleNamespace(epochs=50))
