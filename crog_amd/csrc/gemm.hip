@@ -1473,17 +1473,18 @@ inline bool small_wgrad(int a_layout, int b_layout, int out_mode, long M, long N
 // epilogue (round 3): half the L2 -> LDS bytes and half the LDS fragment reads per MFMA of the 128 x 128 tile, which is what bounds a
 // weight gradient (both operands are read transposed out of LDS).  One 8-wave block owns a CU, so a launch is kept to ~144 blocks: the
 // side stream works a little over half of the chip at the better per-CU rate and leaves the rest to the main stream.  Measured in the
-// step, interleaved pairs of 60 steps, three boxes: 3x3 forms only (>= 512 K outputs) 32.6-32.8 ms against 33.2-33.6 on 128 x 128; plus
-// the 1x1 / linear forms from 256 K outputs (512 x 512 over 21632 pixels: 12 launches per step) **31.8-32.2 ms (-3.3 ... -3.6 %)**, and
-// the roofline kernel next to them 596-603 instead of 528-537 TFLOP/s.  Targets of 80 / 96 / 112 blocks help the neighbour more
-// (617-629 TFLOP/s) and the step less (31.9-33.2 ms), 176-208 lose (32.2-32.7): 144.  Lower thresholds (128 K / 64 K outputs, 3x3 from
-// 256 K) change nothing.
+// step (interleaved runs of 60 steps, finite losses checked): 3x3 forms from 512 K outputs 32.55-33.03 ms against 33.2-33.6 on
+// 128 x 128 tiles, and the roofline kernel next to them 573-580 instead of 528-537 TFLOP/s; adding the 1x1 / linear forms from 1 M
+// outputs (the decoder's 2048 x 512 FFN weights) 32.36-32.73, from 256 K outputs 32.65-33.15 (no gain: twelve 512 x 512 launches
+// whose four tiles need 21 splits).  Block targets of 80 / 96 / 112 help the neighbour more (617-629 TFLOP/s) and the step less,
+// 176-208 lose: 144.  (A first measurement of 31.8-32.2 ms for the 256 K variant was of a step whose text tower had gone NaN - an
+// unordered workspace, fixed - and NaN operands let the chip hold a higher clock: bench.py now refuses non-finite statistics.)
 constexpr long WGRAD256_BLOCKS = 144;
 inline bool big_wgrad(int dtype, int a_layout, int b_layout, int out_mode, long M, long N, long K) {
   if (dtype != CROG_BF16 || out_mode != CROG_OUT_F32_ATOMIC || a_layout != CROG_A_MC) return false;
   if (M % 256 != 0 || N % 256 != 0 || K < 8192) return false;
   if (b_layout == CROG_B_NC_IM2COL) return M * N >= (1L << 19);
-  return b_layout == CROG_B_NC && M * N >= (1L << 18);
+  return b_layout == CROG_B_NC && M * N >= (1L << 20);
 }
 
 inline bool lean_epilogue_ok(const crog_gemm_desc& d) {

@@ -898,9 +898,9 @@ def test_production_linear_weight_gradient_split_k(K, dt, M, N, Kd):
     assert _rel_l2(db, dy.double().sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,Kd", [(21632, 512, 512), (21632, 1024, 256), (86528, 512, 512), (21600, 256, 1024)])
+@pytest.mark.parametrize("M,N,Kd", [(21632, 2048, 512), (21632, 512, 2048), (86528, 1024, 1024), (21600, 2048, 512)])
 def test_wide_tile_weight_gradient_256x256(K, M, N, Kd):
-    """Weight gradients whose two output sides are multiples of 256 (>= 256 K outputs, reduction >= 8192) take the 8-wave 256 x 256 tile
+    """Weight gradients whose two output sides are multiples of 256 (1x1 / linear: >= 1 M outputs, reduction >= 8192) take the 8-wave 256 x 256 tile
     with the atomic-only epilogue (csrc/gemm.hip big_wgrad / ShapeDma8A): against float64, incl. a reduction that is no multiple of the
     k-tile, accumulation on top of existing gradients, and the bias gradient the operator layer sums separately for this tile."""
     dt = torch.bfloat16
