@@ -210,6 +210,7 @@ class GraphedTrainStep:
         if own:
             self._build_replay(g, captured)
         self.graph, self._stats, self._loss_dict = g, stats, loss_dict
+        self._captured_store = self._store()
         self._loss_sums = getattr(loss_dict, "_sums", None)
         self.collectives = dict(syncbn=(RT.comm.calls if RT.comm is not None else 0), buckets=(RT.reducer.launches if RT.reducer is not None else 0))
 
@@ -270,6 +271,10 @@ class GraphedTrainStep:
         except Exception:
             pass
 
+    def _store(self):
+        m = self.model.module if hasattr(self.model, "module") and not hasattr(self.model, "store") else self.model
+        return getattr(m, "store", None)
+
     def static_batch(self):
         """The captured step's input tensors (None before capture): write the next batch straight into them to skip the copy."""
         return self.static
@@ -297,6 +302,15 @@ class GraphedTrainStep:
                 return self._eager(batch)
         if eager or any(batch[k].shape != t.shape or batch[k].dtype != t.dtype for k, t in self.static.items()):
             return self._eager(batch)       # asked for, or a batch of another shape (a ragged last batch): issue it from Python
+        store = self._store()
+        if store is not self._captured_store or not store.valid():
+            # the parameters were re-materialised (.cuda() / .to() / .float()): the captured addresses are gone - capture again
+            self.graph, self.replay_handle, self.calls = None, None, self.warmup
+            return self._eager(batch)
+        if store.S is not None and not getattr(store, "synced", False):
+            # the fp32 parameters changed behind the captured step's back (load_state_dict, an in-place edit): the replay assumes
+            # the bf16 shadow FusedAdam wrote last step; one eager step re-casts it and leaves the state a replay expects
+            return self._eager(batch)
         for k, dst in self.static.items():
             src = batch[k]
             if src.data_ptr() != dst.data_ptr():

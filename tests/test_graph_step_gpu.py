@@ -135,6 +135,37 @@ def test_replay_times_the_selected_launches():
     assert all(f > 0 and meta[0] == K.A_IM2COL for _, f, meta in recs)
 
 
+def test_replay_notices_parameters_changed_behind_its_back():
+    """load_state_dict between replays: the captured step reads the bf16 shadow FusedAdam wrote in the previous step, so after an
+    external change of the fp32 parameters one step must run eagerly (re-casting the shadow) before replays resume - the result is
+    the eager loop's."""
+    from crog_amd.engine import train_step
+    from crog_amd.graphs import GraphedTrainStep
+    from crog_amd.runtime import RT
+    cfg = tiny_cfg(dropout=0.0)
+    batches = _batches(cfg, 7)
+
+    def run(graph):
+        model, opt = _fresh(cfg, torch.bfloat16)
+        RT.manual_seed(4)
+        g = GraphedTrainStep(model, opt, cfg, torch.bfloat16, warmup=2) if graph else None
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        out = []
+        for i, b in enumerate(batches):
+            if i == 5:
+                model.load_state_dict(sd0)           # back to the initial weights (checkpoint resume)
+            st, _ = g(b) if graph else train_step(model, opt, None, b, cfg, autocast_dtype=torch.bfloat16)
+            out.append(float(st[0]))
+        torch.cuda.synchronize()
+        if graph:
+            assert g.replays == 4 and g.graph is not None        # calls 3, 4, 5 and 7 replayed; call 6 (after the load) went eager
+        return out
+    e, e2, r = run(False), run(False), run(True)
+    noise = max(abs(a - b) for a, b in zip(e, e2))
+    assert max(abs(a - b) for a, b in zip(e, r)) <= max(4 * noise, 5e-2), (e, r)
+    assert abs(r[5] - r[0]) < abs(r[4] - r[0]) + 5e-2 or abs(r[5] - e[5]) <= max(4 * noise, 5e-2)     # step 6 saw the restored weights
+
+
 def test_capturable_adam_matches_host_scalar_adam():
     """crog_adam_step_dev + crog_adam_advance (step count / bias corrections / lr in device memory) == crog_adam_step with host
     scalars == torch.optim.Adam, over several steps and an lr change."""
