@@ -477,32 +477,36 @@ __global__ void __launch_bounds__(NT) vit_tokens_bwd_kernel(const T* __restrict_
 // along Cin) and the writes (runs along Cout) are 16-byte vectors (the element-wise form read one 64-byte sector per 2 bytes used:
 // 465 us and 1 GB of traffic per step for 80 MB of weights).  Layers whose channel counts are not multiples of the vector (the
 // 3-channel stem) take the element-wise loop.
-template <typename T>
+// TSTRIDE: longs per table entry: 3 = (offset, Cout, Cin) of a 3x3 convolution; 4 = (offset, rows, cols, taps) with taps 9 or 1 - a
+// plain [rows][cols] -> [cols][rows] transpose for the 1x1 / linear weights, whose data gradients then read a K-contiguous operand too
+// (crog_dgrad_weights).
+template <typename T, int TSTRIDE>
 __global__ void __launch_bounds__(NT) conv3_dgrad_weights_kernel(const T* __restrict__ src, T* __restrict__ dst, const long* __restrict__ table) {
   constexpr int VEC = Elem<T>::VEC, TS = 64, VPR = TS / VEC;
   __shared__ __attribute__((aligned(16))) T tile[TS][TS + VEC];
-  const long off = table[3 * blockIdx.y], co_n = table[3 * blockIdx.y + 1], ci_n = table[3 * blockIdx.y + 2];
+  const long off = table[TSTRIDE * blockIdx.y], co_n = table[TSTRIDE * blockIdx.y + 1], ci_n = table[TSTRIDE * blockIdx.y + 2];
+  const int TAPS = TSTRIDE == 4 ? (int)table[TSTRIDE * blockIdx.y + 3] : 9;
   if (co_n % VEC != 0 || ci_n % VEC != 0) {
-    const long total = co_n * 9 * ci_n;
+    const long total = co_n * TAPS * ci_n;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-      const long co = i % co_n;              // destination index i = (ci * 9 + t) * Cout + co
-      const long t = (i / co_n) % 9;
-      const long ci = i / (co_n * 9);
-      dst[off + i] = src[off + (co * 9 + (8 - t)) * ci_n + ci];
+      const long co = i % co_n;              // destination index i = (ci * TAPS + t) * Cout + co
+      const long t = (i / co_n) % TAPS;
+      const long ci = i / (co_n * TAPS);
+      dst[off + i] = src[off + (co * TAPS + (TAPS - 1 - t)) * ci_n + ci];
     }
     return;
   }
   const int tco = (int)((co_n + TS - 1) / TS), tci = (int)((ci_n + TS - 1) / TS);
-  const int ntiles = 9 * tco * tci;
+  const int ntiles = TAPS * tco * tci;
   for (int id = blockIdx.x; id < ntiles; id += gridDim.x) {
-    const int t = id % 9, rest = id / 9;
+    const int t = id % TAPS, rest = id / TAPS;
     const long ci0 = (long)(rest % tci) * TS, co0 = (long)(rest / tci) * TS;
     for (int v = threadIdx.x; v < TS * VPR; v += NT) {
       const int r = v / VPR, c = (v % VPR) * VEC;
       Vec16<T> x;
 #pragma unroll
       for (int e = 0; e < VEC; e++) x.v[e] = Elem<T>::from_f(0.f);
-      if (co0 + r < co_n && ci0 + c < ci_n) x = ldg16(src + off + ((co0 + r) * 9 + t) * ci_n + ci0 + c);
+      if (co0 + r < co_n && ci0 + c < ci_n) x = ldg16(src + off + ((co0 + r) * TAPS + t) * ci_n + ci0 + c);
       *reinterpret_cast<Vec16<T>*>(&tile[r][c]) = x;
     }
     __syncthreads();
@@ -512,7 +516,7 @@ __global__ void __launch_bounds__(NT) conv3_dgrad_weights_kernel(const T* __rest
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < VEC; e++) o.v[e] = tile[c + e][r];
-        stg16(dst + off + ((ci0 + r) * 9 + (8 - t)) * co_n + co0 + c, o);
+        stg16(dst + off + ((ci0 + r) * TAPS + (TAPS - 1 - t)) * co_n + co0 + c, o);
       }
     }
     __syncthreads();
@@ -825,7 +829,15 @@ extern "C" int crog_conv3_dgrad_weights(int dtype, const void* src, void* dst, c
   if (count <= 0) return CROG_OK;
   CROG_CHECK_ARG(src && dst && table, "conv3_dgrad_weights: null pointer");
   static_assert(sizeof(long) == sizeof(int64_t), "table entries are 64-bit");
-  DISPATCH_T(dtype, hipLaunchKernelGGL((conv3_dgrad_weights_kernel<T>), dim3(96, count), dim3(NT), 0, (hipStream_t)s, (const T*)src, (T*)dst,
+  DISPATCH_T(dtype, hipLaunchKernelGGL((conv3_dgrad_weights_kernel<T, 3>), dim3(96, count), dim3(NT), 0, (hipStream_t)s, (const T*)src, (T*)dst,
+                                       reinterpret_cast<const long*>(table)));
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+extern "C" int crog_dgrad_weights(int dtype, const void* src, void* dst, const int64_t* table, int count, crog_stream_t s) {
+  if (count <= 0) return CROG_OK;
+  CROG_CHECK_ARG(src && dst && table && count <= 65535, "dgrad_weights: null pointer or more than 65535 entries");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((conv3_dgrad_weights_kernel<T, 4>), dim3(24, count), dim3(NT), 0, (hipStream_t)s, (const T*)src, (T*)dst,
                                        reinterpret_cast<const long*>(table)));
   CROG_LAUNCH_CHECK();
   return CROG_OK;

@@ -1497,11 +1497,12 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
       if (dma_eligible(d) && lean_epilogue_ok(d)) {
         if (d.a_layout == CROG_A_KC && d.b_layout == CROG_B_NC) return launch_dma<T, CROG_A_KC, CROG_B_NC, ShapeMidBwd>(d, s);
+        if (d.a_layout == CROG_A_KC && d.b_layout == CROG_B_KC) return launch_dma<T, CROG_A_KC, CROG_B_KC, ShapeMidBwd>(d, s);
         if (d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC) return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, ShapeMidBwd>(d, s);
         if (d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_NC_DGRAD) return launch_dma<T, CROG_A_IM2COL, CROG_B_NC_DGRAD, ShapeMidBwd>(d, s);
       }
     }
-    crog_set_error("crog_gemm: bwd_z is implemented for bf16 data gradients (A_KC x B_NC, A_IM2COL x B_KC / B_NC_DGRAD) with a plain epilogue "
+    crog_set_error("crog_gemm: bwd_z is implemented for bf16 data gradients (A_KC x B_NC / B_KC, A_IM2COL x B_KC / B_NC_DGRAD) with a plain epilogue "
                    "and operands the LDS-DMA path can address (crog_gemm_supports_bwd_z)");
     return CROG_ERR_ARG;
   }
@@ -1580,7 +1581,8 @@ extern "C" int crog_gemm_supports_bwd_z(const crog_gemm_desc* dp) {
   if (!dp) return 0;
   const crog_gemm_desc& d = *dp;
   if (d.dtype != CROG_BF16 || !dma_eligible(d) || !lean_epilogue_ok(d)) return 0;
-  return (d.a_layout == CROG_A_KC && d.b_layout == CROG_B_NC) || (d.a_layout == CROG_A_IM2COL && (d.b_layout == CROG_B_KC || d.b_layout == CROG_B_NC_DGRAD));
+  return (d.a_layout == CROG_A_KC && (d.b_layout == CROG_B_NC || d.b_layout == CROG_B_KC)) ||
+         (d.a_layout == CROG_A_IM2COL && (d.b_layout == CROG_B_KC || d.b_layout == CROG_B_NC_DGRAD));
 }
 
 extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {

@@ -50,6 +50,7 @@ LN_BWD_ATOMIC = False            # LayerNorm parameter gradients through atomics
 LN_REDUCE_SIDE = True            # LayerNorm parameter-gradient reduction on the weight-gradient stream
 BN_BWD_ATOMIC = True             # backward partial sums through coalesced atomics (bf16)
 DGRAD_T = True                   # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
+LIN_DGRAD_T = True               # ... and the 1x1 / linear ones (round 3); tests compare with the transposed-read form
 FUSED_HEAD = True                # fold vis.4 into the dynamic head (no groups*C-channel map)
 
 
@@ -136,8 +137,16 @@ def lin_dgrad(dy, w: WRef, dx, *, accumulate_into: Optional[torch.Tensor] = None
     if N is not None:
         n = N
     dt = _cdt(dx)
+    R, ldr = accumulate_into, K.mat(accumulate_into)[2] if accumulate_into is not None else 0
+    if LIN_DGRAD_T and id(w.param) in w.store.lin_t and n % _vec(dt) == 0:
+        # forward-shaped GEMM on the transposed copy of the weight ([K][total rows]: this block's rows are its columns row0 .. row0 + N)
+        poff = w.store.off(w.param)
+        total_rows = w.param.numel() // w.cols
+        K.gemm(dt, K.A_KC, K.B_KC, dy, w.store.weights_t(dx.dtype), dx, M, w.cols, n, lda if lda is not None else ld, total_rows, K.mat(dx)[2],
+               a_off=a_off, b_off=poff + (w.off - poff) // w.cols, R=R, ldr=ldr)
+        return
     K.gemm(dt, K.A_KC, K.B_NC, dy, w.w(dx.dtype), dx, M, w.cols, n, lda if lda is not None else ld, w.cols, K.mat(dx)[2],
-           a_off=a_off, b_off=w.off, R=accumulate_into, ldr=K.mat(accumulate_into)[2] if accumulate_into is not None else 0)
+           a_off=a_off, b_off=w.off, R=R, ldr=ldr)
 
 
 def lin_wgrad(dy, x, w: WRef, *, a_off=0, lda=None, N=None, bias: Optional[WRef] = None):
@@ -470,8 +479,13 @@ class ConvBnAct(Function):
                 bwd = dict(col_stats=stat_in.sums, stat_replicas=stat_in.R, bwd_z=stat_in.z, bwd_ss=stat_in.ss)
             if ksize == 1 and ctx.x_needs:
                 dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
-                K.gemm(dt, K.A_KC, K.B_NC, dz, wt, dx, M, cin, C, C, wcols, cin, b_off=woff, R=extra, ldr=K.mat(extra)[2] if extra is not None else 0,
-                       **bwd)
+                if LIN_DGRAD_T and wpad is None and id(w.param) in w.store.lin_t:
+                    # forward-shaped GEMM on the [Cin][Cout] copy of the weight: both operands K-contiguous
+                    K.gemm(dt, K.A_KC, K.B_KC, dz, w.store.weights_t(dtype), dx, M, cin, C, C, C, cin, b_off=woff, R=extra,
+                           ldr=K.mat(extra)[2] if extra is not None else 0, **bwd)
+                else:
+                    K.gemm(dt, K.A_KC, K.B_NC, dz, wt, dx, M, cin, C, C, wcols, cin, b_off=woff, R=extra,
+                           ldr=K.mat(extra)[2] if extra is not None else 0, **bwd)
             elif ksize == 3 and ctx.x_needs:
                 B, H, W = lead
                 dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)

@@ -491,6 +491,10 @@ def conv3_dgrad_weights(src, dst, table, count):
     check(lib().crog_conv3_dgrad_weights(dcode(src), ptr(src), ptr(dst), ptr(table), count, stream()), "conv3_dgrad_weights")
 
 
+def dgrad_weights(src, dst, table, count):
+    check(lib().crog_dgrad_weights(dcode(src), ptr(src), ptr(dst), ptr(table), count, stream()), "dgrad_weights")
+
+
 def cast_pad2d(src, lds, cols_src, dst, ldd, cols_dst, rows, src_off=0, dst_off=0):
     dt = dcode(dst)
     sz = 2 if dt == BF16 else 4

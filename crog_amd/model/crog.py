@@ -179,6 +179,8 @@ class CROG(nn.Module):
             # node on its forward stream, which overlaps the two backward passes the same way.
             main = torch.cuda.current_stream()
             store.weights(dtype)               # refresh the bf16 shadow on the main stream BEFORE the streams fork
+            if self.training and torch.is_grad_enabled():
+                store.weights_t(dtype)         # ... and the data-gradient copies of the weights: backward reads them on both streams
             if self.overlap_text:
                 if self._side is None:
                     RT.ensure_streams(dev)      # creation ORDER of the side streams decides which hardware queues they share

@@ -231,13 +231,19 @@ class ParamStore:
         self.T: Dict[torch.dtype, torch.Tensor] = {}   # data-gradient layout of the 3x3 conv weights, per compute dtype
         self.t_fresh: Dict[torch.dtype, bool] = {}
         self.by_param: Dict[int, int] = {}
-        conv3 = []
+        conv3, tr = [], []
+        self.lin_t = set()       # ids of 2-D / 1x1 parameters that have a transposed copy in `weights_t` (K-contiguous data gradients)
         for name, p, o in plan:
             n = p.numel()
+            if (p.dim() == 2 or (p.dim() == 4 and p.shape[2] * p.shape[3] == 1)) and p.shape[0] % 8 == 0 and p.shape[1] % 8 == 0 and n <= (1 << 23):
+                # ([rows, cols] with both sides whole 16-byte vectors; embedding tables - 25 M elements, no data gradient - stay out)
+                tr += [o, p.shape[0], p.shape[1], 1]
+                self.lin_t.add(id(p))
             if p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
                 co, ci, kh, kw = p.shape
                 if kh == 3 and kw == 3:
                     conv3 += [o, co, ci]
+                    tr += [o, co, ci, 9]
                 v = self.P[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
                 g = self.G[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
             else:
@@ -256,6 +262,8 @@ class ParamStore:
         self.gview = {id(p): g for _, p, _, _, g in self.entries}
         self.conv3_count = len(conv3) // 3
         self.conv3_table = torch.tensor(conv3, dtype=torch.int64, device=device) if conv3 else None
+        self.tr_count = len(tr) // 4
+        self.tr_table = torch.tensor(tr, dtype=torch.int64, device=device) if (tr and device.type == "cuda") else None
 
     # -- lookups ---------------------------------------------------------------------------------
     def off(self, p) -> int:
@@ -274,15 +282,17 @@ class ParamStore:
         return self.S
 
     def weights_t(self, dtype: torch.dtype) -> torch.Tensor:
-        """Flat buffer (same offsets as `weights`) whose 3x3 convolution entries hold the data-gradient layout
-        [Cin][8 - tap][Cout]; refreshed by one launch per step, on first use after the weights changed."""
+        """Flat buffer (same offsets as `weights`) holding the data-gradient layout of the weights: 3x3 convolutions as
+        [Cin][8 - tap][Cout], 1x1 convolutions / linears (`lin_t`) as [cols][rows]; refreshed by one launch per step, on first use after
+        the weights changed.  Models whose backward runs on several streams refresh it at the start of the forward, before the
+        streams fork (CROG.forward), so that every later reader is ordered behind the launch."""
         src = self.weights(dtype)
         if dtype not in self.T:
             self.T[dtype] = torch.zeros(self.total, device=self.device, dtype=dtype)
             self.t_fresh[dtype] = False
         if not self.t_fresh[dtype]:
-            if self.conv3_count:
-                K.conv3_dgrad_weights(src, self.T[dtype], self.conv3_table, self.conv3_count)
+            if self.tr_table is not None:
+                K.dgrad_weights(src, self.T[dtype], self.tr_table, self.tr_count)
             self.t_fresh[dtype] = True
         return self.T[dtype]
 

@@ -364,6 +364,11 @@ int crog_eval_maps(const float* x, int B, int G, int h, int w, int sigmoid_mask,
  * F.conv2d(k=3, s=1, p=1) (clip.py:21,166-170; layers.py:8-11) is then crog_gemm(CROG_A_IM2COL, CROG_B_KC) on dy and this copy. */
 int crog_conv3_dgrad_weights(int dtype, const void* src, void* dst, const int64_t* table, int count,
                              crog_stream_t stream);
+/* The same for every weight of a model, 3x3 and 1x1 / linear alike: table entries (element offset, rows, cols, taps), taps = 9
+ * (as above) or 1 - a plain transpose dst[off + c*rows + r] = src[off + r*cols + c], so that the data gradient of a Linear /
+ * 1x1 convolution (dx = dy W) is a forward-shaped crog_gemm(CROG_A_KC, CROG_B_KC) on dy and the copy: both operands K-contiguous
+ * (20-46 % faster on the text tower's 640-row launches, 0-12 % elsewhere, than reading W transposed out of LDS). */
+int crog_dgrad_weights(int dtype, const void* src, void* dst, const int64_t* table, int count, crog_stream_t stream);
 /* dst[r][c] = c < cols_src ? src[r][c] : 0 for c < cols_dst (fp32 source) */
 int crog_cast_pad2d(int dtype_dst, const float* src, int64_t lds, int cols_src, void* dst, int64_t ldd,
                     int cols_dst, int64_t rows, crog_stream_t stream);

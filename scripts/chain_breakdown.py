@@ -1,0 +1,27 @@
+"""Per-queue kernel-time breakdown of the last full step in a rocprofv3 --kernel-trace CSV of a replayed run, split at the start of backward.
+usage: chain_breakdown.py <kernel_trace.csv>"""
+import csv, collections, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in rows))
+ends = [i for i, e in enumerate(ev) if "adam_kernel" in e[3] and (i + 1 == len(ev) or "adam_kernel" not in ev[i + 1][3])]
+lo, hi = ends[-3] + 1, ends[-1] + 1          # one full step = two adam runs (two parameter groups)
+seg = ev[lo:hi]
+t0 = seg[0][0]
+def short(n):
+    n = n.replace('(anonymous namespace)::', '')
+    mm = re.search(r'gemm_dma_kernelI(DF16b|f)Li(\d)ELi(\d)ENS_5ShapeILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELi\dELb(\d)ELb(\d)', n)
+    if mm: return f"gemm A{mm.group(2)}B{mm.group(3)} {32*int(mm.group(4))*int(mm.group(6))}x{32*int(mm.group(5))*int(mm.group(7))}{' bwdz' if mm.group(9)=='1' else ''}{' atom' if mm.group(10)=='1' else ''}"
+    mm = re.search(r'gemm_dma_kernel<.*?(\d), Shape<(\d), (\d), (\d), (\d), (\w+), \d, (\w+), (\w+)>', n)
+    if mm: return f"gemm(?) {32*int(mm.group(2))*int(mm.group(4))}x{32*int(mm.group(3))*int(mm.group(5))}{' bwdz' if mm.group(7)=='true' else ''}{' atom' if mm.group(8)=='true' else ''}"
+    m = re.search(r'_ZN12_GLOBAL__N_1\d+([a-z0-9_]+?)I', n)
+    if m: return m.group(1)
+    return n.split('(')[0].replace('void ', '')[:44]
+bwd0 = min(e[0] for e in seg if "bn_bwd" in e[3] or "flash_bwd" in e[3] or "stencil_bwd" in e[3])
+print(f"step wall {(seg[-1][1]-t0)/1e6:.2f} ms; backward starts at {(bwd0-t0)/1e6:.2f} ms")
+for q in sorted({e[2] for e in seg}):
+    for name, L in (("fwd", [e for e in seg if e[2] == q and e[0] < bwd0]), ("bwd", [e for e in seg if e[2] == q and e[0] >= bwd0])):
+        if not L: continue
+        agg, cnt = collections.Counter(), collections.Counter()
+        for s, e, _, n in L: agg[short(n)] += e - s; cnt[short(n)] += 1
+        print(f"--- queue {q} {name}: {len(L)} launches, busy {sum(agg.values())/1e6:.2f} ms, span {(L[0][0]-t0)/1e6:.2f}..{(max(e[1] for e in L)-t0)/1e6:.2f} ms")
+        for k, v in agg.most_common(11): print(f"   {v/1e6:6.2f} ms {cnt[k]:4d}x  {k}")

@@ -144,12 +144,13 @@ def test_peer_mailbox_allreduce_two_processes_one_gpu(tmp_path):
 
 def test_two_rank_ddp_syncbn_over_the_peer_mailboxes_equals_the_gloo_exchange(tmp_path):
     """The whole 2-rank fp32 step with the BatchNorm statistics exchanged by crog_syncbn_stats (CROG_SYNCBN_DIRECT=peer) instead of
-    gloo: a two-rank sum is a + b either way, the fp32 forward is bit-reproducible, so logits and loss are IDENTICAL to the gloo run;
+    gloo: a two-rank sum is a + b either way, the fp32 forward is bit-reproducible, so the logits are IDENTICAL to the gloo run (the loss to the last bits);
     the gradient buffers (split-K atomics) agree to run-to-run noise."""
     a0, a1 = _run(2, tmp_path, "f32", 1.0, tag="gloo")
     b0, b1 = _run(2, tmp_path, "f32", 1.0, tag="peer", extra_env={"CROG_SYNCBN_DIRECT": "peer"})
     for a, b in ((a0, b0), (a1, b1)):
-        assert np.array_equal(a["preds"], b["preds"]) and float(a["loss"]) == float(b["loss"])
+        assert np.array_equal(a["preds"], b["preds"])
+        assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5        # (the loss kernel adds its partial sums atomically: last-bit noise)
         rel = np.linalg.norm(a["G"] - b["G"]) / np.linalg.norm(a["G"])
         assert rel < 2e-2, rel
         assert np.allclose(a["bn_checksum"], b["bn_checksum"], rtol=1e-6)

@@ -898,6 +898,47 @@ def test_production_linear_weight_gradient_split_k(K, dt, M, N, Kd):
     assert _rel_l2(db, dy.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_linear_data_gradient_on_the_transposed_weight_copy(K, dt):
+    """crog_dgrad_weights (taps = 1: a plain transpose per table entry, next to a 3x3 entry in the same launch) and the forward-shaped
+    data gradient that reads it: lin_dgrad on the copy == lin_dgrad reading W transposed out of LDS == dy @ W, for a whole parameter and
+    for a row block of a packed one (nn.MultiheadAttention's in_proj_weight)."""
+    from crog_amd import functional as Fn
+    from crog_amd.runtime import ParamStore
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(96, 200, bias=False)                  # [200, 96]
+            self.packed = torch.nn.Parameter(torch.randn(3 * 64, 64) * 0.1)     # three row blocks of 64
+            self.conv = torch.nn.Conv2d(32, 16, 3, bias=False)
+            self.ragged = torch.nn.Linear(64, 12, bias=False)                # 12 rows: no 16-byte rows in the copy -> stays on the NN form
+    net = Net().cuda()
+    store = ParamStore(net, torch.device("cuda"))
+    assert id(net.lin.weight) in store.lin_t and id(net.packed) in store.lin_t and id(net.ragged.weight) not in store.lin_t
+    T = store.weights_t(dt)
+    W = store.weights(dt)
+    o = store.off(net.lin.weight)
+    assert torch.equal(T[o:o + 200 * 96].view(96, 200), W[o:o + 200 * 96].view(200, 96).t())
+    oc = store.off(net.conv.weight)
+    wc = W[oc:oc + 16 * 9 * 32].view(16, 9, 32)
+    assert torch.equal(T[oc:oc + 16 * 9 * 32].view(32, 9, 16), wc.flip(1).permute(2, 1, 0))
+    M = 1000
+    for w, ref_w in ((Fn.WRef(store, net.lin.weight), net.lin.weight), (Fn.WRef(store, net.packed, 64, 64), net.packed[64:128]),
+                     (Fn.WRef(store, net.ragged.weight), net.ragged.weight)):
+        dy = rnd(M, w.rows, dt=dt, seed=4)
+        want = dy.float() @ ref_w.detach().to(dt).float()
+        outs = []
+        for flag in (True, False):
+            Fn.LIN_DGRAD_T = flag
+            dx = torch.empty(M, w.cols, device="cuda", dtype=dt)
+            Fn.lin_dgrad(dy, w, dx)
+            outs.append(dx.float())
+        Fn.LIN_DGRAD_T = True
+        close(outs[0], want, dt, scale=math.sqrt(w.rows) / 4)
+        assert (outs[0] - outs[1]).abs().max().item() <= (1e-5 if dt == torch.float32 else 2e-2) * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("M,N,Kd", [(21632, 2048, 512), (21632, 512, 2048), (86528, 1024, 1024), (21600, 2048, 512)])
 def test_wide_tile_weight_gradient_256x256(K, M, N, Kd):
     """Weight gradients whose two output sides are multiples of 256 (1x1 / linear: >= 1 M outputs, reduction >= 8192) take the 8-wave 256 x 256 tile
