@@ -122,7 +122,12 @@ class FusedAdam(torch.optim.Optimizer):
         RT.join_streams()                       # weight-gradient / text-tower side streams must have landed in G
         if RT.reducer is not None:
             RT.reducer.wait()
-        if self._segments is None or not self._store.valid():
+        if self._store is not None and not self._store.valid():
+            # .cuda() / .to() / prepare() after the optimizer was built moved the parameters into ANOTHER flat store: updating this one
+            # would train nothing, silently
+            raise RuntimeError("FusedAdam is attached to a ParamStore its parameters no longer live in (the model was moved or prepared again "
+                               "after the optimizer was built): call optimizer.attach(model.store)")
+        if self._segments is None:
             self._build()
         if self.capturable:
             self.sync_lr()        # (creates the device state from the host step count: before that count moves on)

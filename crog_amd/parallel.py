@@ -248,7 +248,10 @@ class DistributedDataParallel(torch.nn.Module):
             dev = torch.device("cuda", device_ids[0]) if device_ids else next(module.parameters()).device
             if dev.type == "cuda":
                 RT.ensure_streams(dev)
-            module.prepare(dev)
+            if hasattr(module, "_ensure"):
+                module._ensure(dev)       # keep a flat store that is already in place: an optimizer may be attached to it
+            else:
+                module.prepare(dev)
         self._sync_initial_state()
 
     def _sync_initial_state(self):

@@ -240,6 +240,7 @@ def test_graphed_step_under_forced_ddp_and_syncbn():
             model, opt = _fresh(cfg, torch.bfloat16)
             convert_sync_batchnorm(model, force=True)
             net = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True, force=True, bucket_cap_mb=0.25)
+            opt.attach(model.store)        # the wrapper re-homed the parameters (prepare): the optimizer follows, as in bench.py
             RT.manual_seed(3)
             graphed = GraphedTrainStep(net, opt, cfg, torch.bfloat16, warmup=3) if graph else None
             out = []

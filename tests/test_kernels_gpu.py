@@ -924,8 +924,10 @@ def test_linear_data_gradient_on_the_transposed_weight_copy(K, dt):
     wc = W[oc:oc + 16 * 9 * 32].view(16, 9, 32)
     assert torch.equal(T[oc:oc + 16 * 9 * 32].view(32, 9, 16), wc.flip(1).permute(2, 1, 0))
     M = 1000
-    for w, ref_w in ((Fn.WRef(store, net.lin.weight), net.lin.weight), (Fn.WRef(store, net.packed, 64, 64), net.packed[64:128]),
-                     (Fn.WRef(store, net.ragged.weight), net.ragged.weight)):
+    cases = [(Fn.WRef(store, net.lin.weight), net.lin.weight), (Fn.WRef(store, net.packed, 64, 64), net.packed[64:128])]
+    if dt == torch.float32:      # 12 gradient columns are whole 16-byte vectors only in fp32 (the operator layer pads bf16 rows)
+        cases.append((Fn.WRef(store, net.ragged.weight), net.ragged.weight))
+    for w, ref_w in cases:
         dy = rnd(M, w.rows, dt=dt, seed=4)
         want = dy.float() @ ref_w.detach().to(dt).float()
         outs = []
