@@ -196,7 +196,11 @@ class GraphedTrainStep:
         host_step = getattr(self.optimizer, "_step", None)
         try:
             RT._seed_ctr = self._seed0
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            # with a process group alive, its watchdog thread polls events of earlier collectives while this thread captures: "relaxed"
+            # keeps such calls from other threads legal (an order-dependent abort inside the capture was seen with "thread_local")
+            import torch.distributed as dist
+            mode = "relaxed" if (dist.is_available() and dist.is_initialized()) else "thread_local"
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 stats, loss_dict = self._body(self.static)
                 if self._seeds_per_step:
                     K.counter_add(RT.seed_epoch, self._seeds_per_step)

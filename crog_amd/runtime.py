@@ -287,14 +287,20 @@ class ParamStore:
         the weights changed.  Models whose backward runs on several streams refresh it at the start of the forward, before the
         streams fork (CROG.forward), so that every later reader is ordered behind the launch."""
         src = self.weights(dtype)
-        if dtype not in self.T:
-            self.T[dtype] = torch.zeros(self.total, device=self.device, dtype=dtype)
-            self.t_fresh[dtype] = False
+        self.ensure_t(dtype)
         if not self.t_fresh[dtype]:
             if self.tr_table is not None:
                 K.dgrad_weights(src, self.T[dtype], self.tr_table, self.tr_count)
             self.t_fresh[dtype] = True
         return self.T[dtype]
+
+    def ensure_t(self, dtype: torch.dtype):
+        """Allocate (and zero) the data-gradient weight buffer on torch's CURRENT stream.  Callers that launch the refresh on another
+        stream call this first, on the stream the other one then waits for: a buffer first created inside the side-stream launch would
+        be zero-filled by the current stream, unordered against the refresh."""
+        if dtype not in self.T:
+            self.T[dtype] = torch.zeros(self.total, device=self.device, dtype=dtype)
+            self.t_fresh[dtype] = False
 
     def valid(self) -> bool:
         name, p, o, n, g = self.entries[0]

@@ -8,6 +8,8 @@ os.makedirs(out, exist_ok=True)
 sf = max(glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(stats_dir, "*_kernel_stats.csv")), key=os.path.getmtime)
 shutil.copy(sf, os.path.join(out, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(sf)))
+probes_ns = sum(float(r["TotalDurationNs"]) for r in rows if "probe_kernel" in r["Name"])
+rows = [r for r in rows if "probe_kernel" not in r["Name"]]      # bench.py's peak probes run once per process: not part of a step
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 def agg(d, counter):
     acc = collections.defaultdict(lambda: [0, 0.0])
@@ -21,9 +23,9 @@ f, w = agg(fetch_dir, "FETCH_SIZE"), agg(write_dir, "WRITE_SIZE")
 def clean(n): return re.sub(r"\(anonymous namespace\)::", "", n)
 NOTE = os.environ.get("PROFILE_NOTE", "")
 L = [f"# rocprofv3 summary — {tag}", ""] + ([NOTE, ""] if NOTE else []) + [
-     f"Command: `{os.environ.get('PROFILE_ENV', '')}rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {steps-2} --warmup 2 --no-cpu-baseline` (CROG-R50 bf16, B=32, 416x416, 1x MI355X).",
+     f"Command: `{os.environ.get('PROFILE_ENV', '')}rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline` (CROG-R50 bf16, B=32, 416x416, 1x MI355X; {steps} steps executed: warm-ups, the eager steps before the capture, the replays).",
      f"PMC passes (separate runs): `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction, MI355X_MICROARCH.md §HBM).", "",
-     f"Total kernel time: {tot/1e6/steps:.2f} ms per step ({steps} steps profiled).", "",
+     f"Total kernel time: {tot/1e6/steps:.2f} ms per step ({steps} steps profiled; the peak probes of bench.py, {probes_ns/1e6:.1f} ms once per process, are left out).", "",
      "| ms/step | % | launches/step | avg us | HBM MB/launch (PMC) | kernel |", "|---|---|---|---|---|---|"]
 for r in rows[:40]:
     k = r["Name"]
@@ -31,8 +33,11 @@ for r in rows[:40]:
     if k in f and f[k][0]:
         hb = f"{(2*f[k][1]/f[k][0] + (w[k][1]/w[k][0] if k in w and w[k][0] else 0))*1024/1e6:.0f}"
     L.append(f"| {float(r['TotalDurationNs'])/1e6/steps:.3f} | {float(r['Percentage']):.2f} | {int(r['Calls'])/steps:.1f} | {float(r['AverageNs'])/1e3:.1f} | {hb} | `{clean(k)[:110]}` |")
-tb = sum(2*f[k][1] + w.get(k, [0, 0.0])[1] for k in f) * 1024
-if tb: L += ["", f"Measured HBM traffic (all kernels): {tb/1e9/ (f[next(iter(f))][0] and 1):.1f} GB over the PMC run = {tb/1e9/PMC_STEPS:.1f} GB/step ({PMC_STEPS} steps in the PMC runs); algorithmic 56.2 GB/step (1.58 GB/img x 32 + 5.6 GB)."]
+probe = lambda k: "probe_kernel" in k          # bench.py's peak probes (1-GiB copies, MFMA loop) run once per process: not part of a step
+tb = sum(2*f[k][1] + w.get(k, [0, 0.0])[1] for k in f if not probe(k)) * 1024
+tp = sum(2*f[k][1] + w.get(k, [0, 0.0])[1] for k in f if probe(k)) * 1024
+if tb: L += ["", f"Measured HBM traffic of the training steps: {tb/1e9:.1f} GB over the PMC run = {tb/1e9/PMC_STEPS:.1f} GB/step ({PMC_STEPS} steps executed in the PMC runs; "
+                 f"the peak probes of bench.py moved another {tp/1e9:.1f} GB and are left out); algorithmic 56.2 GB/step (1.58 GB/img x 32 + 5.6 GB)."]
 # per-launch HBM traffic of the GEMM kernels whose (A layout, B layout) can be read off the mangled name; bench.py reports it as roofline.traffic
 import json
 names = {(1, 0): "conv3x3_fwd", (1, 2): "conv3x3_dgrad", (2, 3): "conv3x3_wgrad", (0, 0): "lin_fwd"}
