@@ -91,6 +91,9 @@ class _Replay(Function):
         return None, None, None
 
 
+_FAILED_CAPTURES = []
+
+
 class GraphedTrainStep:
     """engine.train_step (crog_engine.py:60-90: autocast forward, zero_grad, backward, optimizer step, train metric, rank-averaged
     scalars) as ONE hipGraph launch per step.
@@ -206,6 +209,14 @@ class GraphedTrainStep:
                     K.counter_add(RT.seed_epoch, self._seeds_per_step)
             if RT._seed_ctr - self._seed0 != self._seeds_per_step:
                 raise RuntimeError("seed count changed during capture")
+        except BaseException:
+            # a CUDAGraph whose capture failed half-way aborts the PROCESS when it is destroyed ("The graph should be registered to the
+            # state", seen on torch 2.10 / ROCm 7.0) - also at interpreter exit, after a bench line has been printed.  The caller falls
+            # back to eager steps; the broken object is parked where no destructor ever runs.
+            _FAILED_CAPTURES.append(g)
+            import ctypes
+            ctypes.pythonapi.Py_IncRef(ctypes.py_object(g))
+            raise
         finally:
             crog_mod.TEXT_GRAPH, K.PROF = saved_text_graph, saved_prof
             captured, K.CAPTURE_NODES = K.CAPTURE_NODES, None
