@@ -137,35 +137,37 @@ def test_replay_times_the_selected_launches():
 
 def test_replay_notices_parameters_changed_behind_its_back():
     """load_state_dict between replays: the captured step reads the bf16 shadow FusedAdam wrote in the previous step, so after an
-    external change of the fp32 parameters one step must run eagerly (re-casting the shadow) before replays resume - the result is
-    the eager loop's."""
-    from crog_amd.engine import train_step
+    external change of the fp32 parameters one step must run eagerly (re-casting the shadow) before replays resume.  Checked on the
+    loss of the step right after the load: it must be the loss of the RESTORED weights on that batch (computed by a fresh model), not
+    the one the stale shadow - five large Adam steps away - would give."""
     from crog_amd.graphs import GraphedTrainStep
     from crog_amd.runtime import RT
     cfg = tiny_cfg(dropout=0.0)
     batches = _batches(cfg, 7)
-
-    def run(graph):
-        model, opt = _fresh(cfg, torch.bfloat16)
-        RT.manual_seed(4)
-        g = GraphedTrainStep(model, opt, cfg, torch.bfloat16, warmup=2) if graph else None
-        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
-        out = []
-        for i, b in enumerate(batches):
-            if i == 5:
-                model.load_state_dict(sd0)           # back to the initial weights (checkpoint resume)
-            st, _ = g(b) if graph else train_step(model, opt, None, b, cfg, autocast_dtype=torch.bfloat16)
-            out.append(float(st[0]))
-        torch.cuda.synchronize()
-        if graph:
-            assert g.replays == 4 and g.graph is not None        # calls 3, 4, 5 and 7 replayed; call 6 (after the load) went eager
-        return out
-    e, e2, r = run(False), run(False), run(True)
-    noise = max(abs(a - b) for a, b in zip(e, e2))
-    assert max(abs(a - b) for a, b in zip(e, r)) <= max(6 * noise, 0.1), (e, e2, r)
-    # had the step after the load replayed with the stale bf16 shadow, its loss would continue the OLD weights' trajectory (r[4])
-    # instead of restarting near the first step's (same restored weights, another batch)
-    assert abs(r[5] - e[5]) <= max(6 * noise, 0.1)
+    model, opt = _fresh(cfg, torch.bfloat16)
+    for g_ in opt.param_groups:
+        g_["lr"], g_["weight_decay"] = 3e-3, 0.0           # large steps: a stale shadow is far from the restored weights
+    RT.manual_seed(4)
+    g = GraphedTrainStep(model, opt, cfg, torch.bfloat16, warmup=2)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    losses = []
+    for i, b in enumerate(batches):
+        if i == 5:
+            model.load_state_dict(sd0)           # back to the initial weights (checkpoint resume)
+        st, _ = g(b)
+        losses.append(float(st[0]))
+    torch.cuda.synchronize()
+    assert g.replays == 4 and g.graph is not None        # calls 3, 4, 5 and 7 replayed; call 6 (after the load) went eager
+    # what the restored weights give on batch 5, from a fresh model (training-mode forward: batch statistics, no dropout)
+    ref, _ = _fresh(cfg, torch.bfloat16)
+    ref.load_state_dict(sd0)
+    b = batches[5]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        _, _, loss_ref, _ = ref(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+    loss_ref = float(loss_ref.detach())
+    # what the weights BEFORE the load (five steps of lr 3e-3 away) give on the same batch: the stale-shadow outcome
+    assert abs(losses[5] - loss_ref) < 0.02 * max(1.0, abs(loss_ref)), (losses, loss_ref)
+    assert abs(losses[4] - loss_ref) > 5 * abs(losses[5] - loss_ref) or abs(losses[5] - loss_ref) < 1e-3, (losses, loss_ref)
 
 
 def test_capturable_adam_matches_host_scalar_adam():
