@@ -17,7 +17,7 @@
 //    Two slot sets (sequence parity): a rank can only run ahead of a peer by one exchange - it needs that peer's contribution to finish
 //    the next one - so exchange e + 2 can never overwrite data a slower peer is still reading from exchange e.
 //    The sequence number lives in device memory and is advanced by the kernel, so the launch carries no per-step scalar and can be
-//    captured / replayed (crog_amd/graphs.py).  Every wait is bounded (~2 s of wall clock): a missing peer raises the mailbox's error word
+//    captured / replayed (crog_amd/graphs.py).  Every wait is bounded (120 s of wall clock by default, CROG_COMM_TIMEOUT_S): a missing peer raises the mailbox's error word
 //    instead of hanging the GPU.
 #include "common.h"
 
@@ -114,10 +114,23 @@ struct Comm {
   std::vector<void*> opened;     // hipIpcOpenMemHandle mappings to close
 };
 
+// How long a rank waits for its peers inside one exchange before it gives up and raises the mailbox's error word.  Ranks of one job
+// are NOT in lock step at the first exchange (code-object loading, a slow data loader; two test processes time-slicing one GPU were
+// seen > 2 s apart), so the default is generous - 120 s, RCCL's own watchdog is minutes - and CROG_COMM_TIMEOUT_S overrides it.
+inline unsigned long long peer_wait_ticks() {
+  static const unsigned long long t = [] {
+    const char* e = getenv("CROG_COMM_TIMEOUT_S");
+    double sec = e ? atof(e) : 120.0;
+    if (!(sec > 0.0)) sec = 120.0;
+    return (unsigned long long)(sec * 1e8);
+  }();
+  return t;
+}
+
 __device__ inline unsigned ld_sys(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ inline void st_sys(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-__global__ void __launch_bounds__(256) peer_allreduce_kernel(float* __restrict__ x, int n, PeerPtrs peers, int rank, int world, int S) {
+__global__ void __launch_bounds__(256) peer_allreduce_kernel(float* __restrict__ x, int n, PeerPtrs peers, int rank, int world, int S, unsigned long long wait_ticks) {
   float* mine = peers.box[rank];
   unsigned* tail = reinterpret_cast<unsigned*>(mine + (size_t)2 * world * S + 2 * world);   // [seq, err]
   __shared__ unsigned s_seq, s_bad;
@@ -141,12 +154,12 @@ __global__ void __launch_bounds__(256) peer_allreduce_kernel(float* __restrict__
     unsigned* f = reinterpret_cast<unsigned*>(peers.box[threadIdx.x] + (size_t)2 * world * S) + par * world + rank;
     st_sys(f, seq);
   }
-  // 3. wait for every rank's flag in MY mailbox (bounded: ~2 s at the 100 MHz wall clock)
+  // 3. wait for every rank's flag in MY mailbox (bounded: wait_ticks of the 100 MHz wall clock, peer_wait_ticks())
   if (threadIdx.x < world) {
     const unsigned* f = reinterpret_cast<const unsigned*>(mine + (size_t)2 * world * S) + par * world + threadIdx.x;
     const unsigned long long t0 = wall_clock64();
     while (ld_sys(f) != seq) {
-      if (wall_clock64() - t0 > 200000000ull) {
+      if (wall_clock64() - t0 > wait_ticks) {
         atomicOr(&s_bad, 1u);
         break;
       }
@@ -259,7 +272,7 @@ extern "C" int crog_syncbn_stats(void* comm, float* ptr, int64_t count, crog_str
   CROG_CHECK_ARG(comm && ptr && count > 0, "syncbn_stats: null argument");
   auto* c = (Comm*)comm;
   if (c->connected && count <= c->slot) {
-    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ptr, (int)count, c->peers, c->rank, c->world, c->slot);
+    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ptr, (int)count, c->peers, c->rank, c->world, c->slot, peer_wait_ticks());
     CROG_LAUNCH_CHECK();
     return CROG_OK;
   }

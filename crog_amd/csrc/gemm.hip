@@ -835,8 +835,25 @@ template <typename S> constexpr int dma_blocks_per_cu() {
   return S::NT == 512 ? 1 : (S::BM + S::BN > 256 ? 2 : (S::BM + S::BN <= 128 ? 4 : 3));
 }
 
+// XOR applied to the 16-byte chunk index of a K-contiguous tile row (64-byte rows: four rows per 256-byte bank row).
+// VAR 0: fragments are read by v_mfma_f32_32x32x16 lanes (row = lane & 31, chunk = 2 ks + (lane >> 5)): chunk ^= (row >> 2) & 3.
+// VAR 1 / 2: fragments are read by v_mfma_f32_16x16x32 lanes (row = lane & 15, chunk = lane >> 4).  ds_read_b128 is served in the
+// lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): a group holds the row quads Q = (row >> 2) & 3 of {0, 3} at one
+// chunk and {1, 2} at the next, so the four quads need distinct f(Q0), f(Q3), f(Q1) ^ 1, f(Q2) ^ 1: f = {0, 2, 3, 1}.
+template <int VAR>
+__device__ inline int kc_swz(int row) {
+  const int q = (row >> 2) & 3;
+  return VAR == 0 ? q : ((0x78 >> (2 * q)) & 3);
+}
+// VAR 2: the tile's rows are stored de-interleaved by 4 inside every group of 64: LDS row 16 b + c holds tile row 4 c + b.  A wave's
+// four 16-column MFMA blocks then hold columns 4 c + {0, 1, 2, 3} in lane c: four adjacent output columns per lane, 8-byte stores.
+template <int VAR>
+__device__ inline int kc_tile_row(int lds_row) {
+  return VAR == 2 ? ((lds_row & ~63) | ((lds_row & 15) << 2) | ((lds_row >> 4) & 3)) : lds_row;
+}
+
 // K-contiguous operand (MODE 0 dense rows, MODE 1 im2col patches of an NHWC map)
-template <typename T, int MODE, int NI>
+template <typename T, int MODE, int NI, int VAR = 0>
 struct DmaKc {
   static constexpr int VEC = TileCfg<T>::VEC, BK = TileCfg<T>::BK;
   static constexpr bool TR = false;
@@ -858,9 +875,9 @@ struct DmaKc {
     kbytes = (unsigned)(K * sizeof(T));
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-      const int row = (wave * NI + i) * 16 + (lane >> 2);
-      const unsigned chunk = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
-      const long m = (long)row0 + row;
+      const int row = (wave * NI + i) * 16 + (lane >> 2);       // row of the LDS image
+      const unsigned chunk = (unsigned)(((lane & 3) ^ kc_swz<VAR>(row)) * 16);
+      const long m = (long)row0 + kc_tile_row<VAR>(row);
       base[i] = (m < rows_total) ? (unsigned)(m * ld * sizeof(T)) + chunk : DMA_OOB;
       if constexpr (MODE == 1) {
         // the pixel's position decides once which of the 9 taps exist; per k-tile the test is one shift + select instead of
@@ -899,7 +916,8 @@ struct DmaKc {
     } else {
       const unsigned kb = (unsigned)(kmem * sizeof(T));
       const unsigned lim = live ? kbytes : 0u;
-      return (base[i] != DMA_OOB && kb + cb[i] < lim) ? base[i] + kb : DMA_OOB;
+      const bool ok = (base[i] != DMA_OOB) & (kb + cb[i] < lim);     // '&': a short-circuit '&&' became an exec-masked branch that cut the loop body in two
+      return ok ? base[i] + kb : DMA_OOB;
     }
   }
   __device__ static Frag<T> frag(const char* tile, int rbase, int ks, int lane);
@@ -924,8 +942,14 @@ template <> struct DmaKcFrag<float> {
     return f;
   }
 };
-template <typename T, int MODE, int NI>
-__device__ inline Frag<T> DmaKc<T, MODE, NI>::frag(const char* tile, int rbase, int ks, int lane) { return DmaKcFrag<T>::get(tile, rbase, ks, lane); }
+template <typename T, int MODE, int NI, int VAR>
+__device__ inline Frag<T> DmaKc<T, MODE, NI, VAR>::frag(const char* tile, int rbase, int ks, int lane) { return DmaKcFrag<T>::get(tile, rbase, ks, lane); }
+// fragment of v_mfma_f32_16x16x32_bf16: lane (c = lane & 15, g = lane >> 4) supplies row rbase + c, reduction indices 8 g .. 8 g + 7
+__device__ inline bf16x8 frag16_kc(const char* tile, int rbase, int lane) {
+  const int row = rbase + (lane & 15), c = (lane >> 4) ^ kc_swz<1>(row);
+  return *reinterpret_cast<const bf16x8*>(tile + row * 64 + c * 16);
+}
+__device__ inline void mma32(const bf16x8& a, const bf16x8& b, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 // Transposed operand: the tile is [BK reduction rows][128 columns] of memory (MODE as TrLoader: 0 dense, 1 dgrad weights, 2 wgrad im2col)
 // XOR applied to the 16-byte chunk index of a transposed bf16 tile row (the four reduction rows a ds_read_b64_tr_b16 group
@@ -1024,14 +1048,15 @@ struct DmaTr {
     const int k = kmem + rowin[i];
     const int klim = live ? K : 0;      // (a mask, not a condition: see DmaKc::off)
     if constexpr (MODE == 0) {
-      return (colb[i] != DMA_OOB && k < klim) ? cur[i] : DMA_OOB;
+      const bool ok = (colb[i] != DMA_OOB) & (k < klim);
+      return ok ? cur[i] : DMA_OOB;
     } else if constexpr (MODE == 1) {
       if (!live || colb[i] == DMA_OOB || k >= K) return DMA_OOB;
       const int tap = k / g.C, co = k - tap * g.C;
       return (unsigned)(co * 9 + (8 - tap)) * (unsigned)ldb_ + colb[i];
     } else {
       const int sy = py[i] + tdy[i], sx = px[i] + tdx[i];
-      const bool ok = colb[i] != DMA_OOB && k < klim && (unsigned)sy < (unsigned)g.H && (unsigned)sx < (unsigned)g.W;
+      const bool ok = (colb[i] != DMA_OOB) & (k < klim) & ((unsigned)sy < (unsigned)g.H) & ((unsigned)sx < (unsigned)g.W);
       return ok ? cur[i] : DMA_OOB;
     }
   }
@@ -1338,11 +1363,198 @@ gemm_dma_kernel(const crog_gemm_desc p) {   // (fp32 carries a second accumulato
   gemm_epilogue<T, S>(acc, p, smem, m0, n0, zs, coff);
 }
 
+
+// =================================================================================================
+// v_mfma_f32_16x16x32_bf16 variant of the LDS-DMA kernel: bf16, both operands K-contiguous (1x1 / linear / 3x3 implicit-GEMM forward
+// and the data gradients on transposed weight copies), lean epilogue (BatchNorm statistics + bf16 stores).
+// Why a second MFMA shape: the large launches are power-bound, not issue-bound (the GEMM loop holds ~1.97 GHz at the
+// package limit), and at equal cycles per FLOP the chip holds a higher clock on the 16x16x32 shape than on 32x32x16
+// (MI355X_MICROARCH.md, DVFS give-back item 7: x1.12-1.14 with operands re-read from LDS).
+// One k-tile (BK = 32) is ONE reduction step of the 16x16x32 shape, so the two halves of the pipelined loop body are the two ROW
+// halves of the wave tile: half 1 = rows 0 .. 16 HALF - 1 with the B fragments of tile t while the A fragments of the second row
+// half are read; barrier + LDS-DMA requests; half 2 = second row half while tile t + 1's first-half A and its B fragments are read
+// (B is double-buffered in registers: the loop is unrolled by two, and an odd reduction range runs one extra all-zero tile).
+// Accumulators: lane (c = lane & 15, g = lane >> 4), block (bi, bj), register e = C[16 bi + 4 g + e][4 c + bj] - the B tile is
+// stored de-interleaved (kc_tile_row<2>) so that a lane owns four ADJACENT output columns: one 8-byte store per row.
+// =================================================================================================
+template <int AL, typename S>
+__global__ void __launch_bounds__(S::NT, S::NT == 512 ? 1 : 2) gemm_dma16_kernel(const crog_gemm_desc p) {
+  using T = bf16;
+  constexpr int DMA_NSTAGE = dma_nstage<S>();
+  constexpr int NW = S::NT / 64, NIA = S::BM / (16 * NW), NIB = S::BN / (16 * NW);
+  static_assert(NIA >= 1 && NIB >= 1 && NIA * 16 * NW == S::BM && NIB * 16 * NW == S::BN, "every wave must move whole 1 KiB slices of both tiles");
+  using OA = DmaKc<T, AL == CROG_A_IM2COL ? 1 : 0, NIA, 1>;
+  using OB = DmaKc<T, 0, NIB, 2>;
+  constexpr int BK = 32, BM = S::BM, BN = S::BN, RB = 2 * S::WM, CB = 2 * S::WN, HALF = RB / 2;
+  static_assert(CB == 4 && RB % 2 == 0, "a wave tile is 64 columns wide (four interleaved 16-column blocks)");
+  constexpr int TILE_A_B = BM * 64, TILE_B_B = BN * 64, DMA_STAGE_B = TILE_A_B + TILE_B_B;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / S::WVN, wc = wave % S::WVN;
+  const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
+  const int nwg = tilesM * tilesN;
+  int id = blockIdx.x, z = blockIdx.y;
+  xcd_map(nwg, 1, id, z);
+  const int tm = id / tilesN, tn = id % tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int zo = z / p.batch_inner, zi = z % p.batch_inner;
+  const T* A = reinterpret_cast<const T*>(p.A) + zo * p.sAo + zi * p.sAi;
+  const T* B = reinterpret_cast<const T*>(p.B) + zo * p.sBo + zi * p.sBi;
+  const int64_t coff = zo * p.sCo + zi * p.sCi;
+  const int kt0 = 0;
+  const int nt = (p.K + BK - 1) / BK;
+  const int nt2 = (nt + 1) & ~1;
+
+  const ConvGeom g{p.convH, p.convW, p.convC};
+  OA da;
+  OB db;
+  da.init(A, p.lda, p.M, p.K, m0, wave, lane, g);
+  db.init(B, p.ldb, p.N, p.K, n0, wave, lane, g);
+  const int exa = OA::extent(p.lda, p.M, p.K, g), exb = OB::extent(p.ldb, p.N, p.K, g);
+
+  f32x4 acc[RB][CB];
+#pragma unroll
+  for (int i = 0; i < RB; i++)
+#pragma unroll
+    for (int j = 0; j < CB; j++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc[i][j][e] = 0.f;
+
+  auto kmem_of = [&](int kt) -> int {
+    if constexpr (AL == CROG_A_IM2COL) {
+      int tap, chunk;
+      conv_ktile(kt, p.convC / BK, tap, chunk);
+      return tap * p.convC + chunk * BK;
+    } else {
+      return kt * BK;
+    }
+  };
+  constexpr int PER_TILE = NIA + NIB;
+  da.start(0, g);
+  db.start(0, g);
+#pragma unroll
+  for (int s = 0; s < DMA_NSTAGE; s++)
+    CROG_DMA_ISSUE(kt0 + s, kmem_of(kt0 + s), s, s < nt);
+  wait_vmcnt<(DMA_NSTAGE - 1) * PER_TILE>();
+  __builtin_amdgcn_s_barrier();
+  const int arow = wr * RB * 16, brow = wc * CB * 16;      // the wave's first row of the A / B LDS image
+  bf16x8 alo[HALF], ahi[HALF], b0[CB], b1[CB];
+#pragma unroll
+  for (int i = 0; i < HALF; i++) alo[i] = frag16_kc(smem, arow + i * 16, lane);
+#pragma unroll
+  for (int j = 0; j < CB; j++) b0[j] = frag16_kc(smem + TILE_A_B, brow + j * 16, lane);
+  int stage = 0;
+  // one k-tile: BC = the B fragments of this tile (in registers), BN_ = where the next tile's go
+#define CROG_MF16_TILE(T_, BC, BN_)                                                                                    \
+  do {                                                                                                                 \
+    const char* at_ = smem + stage * DMA_STAGE_B;                                                                      \
+    _Pragma("unroll") for (int i = 0; i < HALF; i++) ahi[i] = frag16_kc(at_, arow + (HALF + i) * 16, lane);            \
+    _Pragma("unroll") for (int i = 0; i < HALF; i++)                                                                   \
+      _Pragma("unroll") for (int j = 0; j < CB; j++) mma32(alo[i], BC[j], acc[i][j]);                                  \
+    const int nstage_ = stage == DMA_NSTAGE - 1 ? 0 : stage + 1;                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+    wait_vmcnt<(DMA_NSTAGE - 2) * PER_TILE>();                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    {                                                                                                                  \
+      const int tq_ = (T_) + DMA_NSTAGE;                                                                               \
+      CROG_DMA_ISSUE(kt0 + tq_, kmem_of(kt0 + tq_), stage, tq_ < nt);                                                  \
+    }                                                                                                                  \
+    const char* an_ = smem + nstage_ * DMA_STAGE_B;                                                                    \
+    _Pragma("unroll") for (int i = 0; i < HALF; i++) alo[i] = frag16_kc(an_, arow + i * 16, lane);                     \
+    _Pragma("unroll") for (int j = 0; j < CB; j++) BN_[j] = frag16_kc(an_ + TILE_A_B, brow + j * 16, lane);            \
+    _Pragma("unroll") for (int i = 0; i < HALF; i++)                                                                   \
+      _Pragma("unroll") for (int j = 0; j < CB; j++) mma32(ahi[i], BC[j], acc[HALF + i][j]);                           \
+    {                                                                                                                  \
+      constexpr int NMF = HALF * CB, MPD = NMF / PER_TILE > 0 ? NMF / PER_TILE : 1;                                    \
+      __builtin_amdgcn_sched_group_barrier(0x100, HALF + CB, 0);                                                       \
+      _Pragma("unroll") for (int q = 0; q < PER_TILE; q++) {                                                           \
+        if (q * MPD < NMF) __builtin_amdgcn_sched_group_barrier(0x008, MPD, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                                                             \
+      }                                                                                                                \
+      if (PER_TILE * MPD < NMF) __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER_TILE * MPD, 0);                  \
+    }                                                                                                                  \
+    stage = nstage_;                                                                                                   \
+  } while (0)
+  for (int t = 0; t < nt2; t += 2) {
+    CROG_MF16_TILE(t, b0, b1);
+    CROG_MF16_TILE(t + 1, b1, b0);
+  }
+#undef CROG_MF16_TILE
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();     // every wave's trailing (zero-writing) requests have landed before the ring is reused
+
+  // ---- lean epilogue: column statistics, bf16 stores --------------------------------------------
+  const int c = lane & 15, gq = lane >> 4;
+  const bool rows_in = m0 + BM <= p.M;
+  if (p.col_stats) {
+    float s1[CB], s2[CB];
+#pragma unroll
+    for (int j = 0; j < CB; j++) s1[j] = s2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const bool ok = rows_in || m0 + arow + i * 16 + 4 * gq + e < p.M;
+#pragma unroll
+        for (int j = 0; j < CB; j++) { const float v = ok ? acc[i][j][e] : 0.f; s1[j] += v; s2[j] += v * v; }
+      }
+    }
+    constexpr int WVM = S::WVM, NT = S::NT;
+    constexpr int RG = 16 * RB, GPS = 128 / RG;
+    static_assert(RG <= 128 && 128 % RG == 0 && BM % 128 == 0, "stats slab granularity");
+    float* red = reinterpret_cast<float*>(smem);      // [WVM][BN][2]
+#pragma unroll
+    for (int j = 0; j < CB; j++) {
+      s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
+      s2[j] += __shfl_xor(s2[j], 16, 64); s2[j] += __shfl_xor(s2[j], 32, 64);
+    }
+    if (gq == 0) {
+#pragma unroll
+      for (int j = 0; j < CB; j++) {
+        const int col = brow + 4 * c + j;
+        red[(wr * BN + col) * 2 + 0] = s1[j];
+        red[(wr * BN + col) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    constexpr int SLABS = BM / 128;
+    for (int idx = tid; idx < SLABS * BN * 2; idx += NT) {
+      const int sl = idx / (BN * 2), k = idx % (BN * 2), cc = k >> 1;
+      if (n0 + cc < p.N && m0 + sl * 128 < p.M) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < GPS; q++) v += red[(sl * GPS + q) * BN * 2 + k];
+        if (p.stat_replicas > 0) atomicAdd(p.col_stats + ((int64_t)((m0 / 128 + sl) % p.stat_replicas) * p.N + n0) * 2 + k, v);
+        else p.col_stats[((int64_t)(m0 / 128 + sl) * p.N + n0) * 2 + k] = v;
+      }
+    }
+  }
+  T* C = reinterpret_cast<T*>(p.C) + coff;
+  const int col = n0 + brow + 4 * c;
+  const bool interior = rows_in && n0 + BN <= p.N;
+#pragma unroll
+  for (int i = 0; i < RB; i++) {
+    const int row0 = m0 + arow + i * 16 + 4 * gq;
+    T* cb = C + (int64_t)row0 * p.ldc + col;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      bf16x4 v;
+      v[0] = (bf16)acc[i][0][e]; v[1] = (bf16)acc[i][1][e]; v[2] = (bf16)acc[i][2][e]; v[3] = (bf16)acc[i][3][e];
+      if (interior || (row0 + e < p.M && col < p.N)) *reinterpret_cast<bf16x4*>(cb + (int64_t)e * p.ldc) = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 #ifdef CROG_GEMM_PROBE
 // asm-inspection build (never linked): hipcc -DCROG_GEMM_PROBE -S instantiates only these kernels
 template __global__ void gemm_dma_kernel<bf16, CROG_A_IM2COL, CROG_B_KC, ShapeMid, 0>(const crog_gemm_desc);
 template __global__ void gemm_dma_kernel<bf16, CROG_A_MC, CROG_B_NC_IM2COL, ShapeMid, 0>(const crog_gemm_desc);
 template __global__ void gemm_dma_kernel<bf16, CROG_A_IM2COL, CROG_B_KC, ShapeDma8, 0>(const crog_gemm_desc);
+template __global__ void gemm_dma16_kernel<CROG_A_IM2COL, ShapeDma8>(const crog_gemm_desc);
+template __global__ void gemm_dma16_kernel<CROG_A_KC, ShapeMid>(const crog_gemm_desc);
 }  // namespace
 #else
 template <typename T, int AL, int BL, typename S>
@@ -1370,6 +1582,28 @@ int launch_dma(const crog_gemm_desc& d, hipStream_t s) {
   dim3 grid(cdiv(d.M, S::BM) * cdiv(d.N, S::BN), d.batch * d.splitk, 1);
   if (splitk_by_xcd(d)) grid = dim3(grid.x * d.splitk, 1, 1);
   hipLaunchKernelGGL(d.a_sum ? kern_asum : kern, grid, dim3(S::NT), LDS, s, d);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+
+// v_mfma_f32_16x16x32 variant (gemm_dma16_kernel): bf16, A_KC / A_IM2COL x B_KC, lean epilogue, no split-K
+template <int AL, typename S>
+int launch_dma16(const crog_gemm_desc& d, hipStream_t s) {
+  constexpr int ring = dma_nstage<S>() * (S::BM + S::BN) * 64, epi = S::WVM * S::BN * 2 * 4;
+  constexpr int LDS = ring > epi ? ring : epi;
+  static bool attr_set = false;
+  auto kern = gemm_dma16_kernel<AL, S>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      crog_set_error("crog_gemm: hipFuncSetAttribute(%d bytes) failed: %s", LDS, hipGetErrorString(e));
+      return CROG_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(d.M, S::BM) * cdiv(d.N, S::BN), d.batch, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(S::NT), LDS, s, d);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
@@ -1487,6 +1721,19 @@ inline bool big_wgrad(int dtype, int a_layout, int b_layout, int out_mode, long 
   return b_layout == CROG_B_NC && M * N >= (1L << 20);
 }
 
+// Which launches take the v_mfma_f32_16x16x32 kernel (gemm_dma16_kernel): 1 (default) = the 256 x 256 tile of the large 3x3 forward /
+// data-gradient launches, 2 = also lean 128 x 128 launches, 0 = none.  CROG_MFMA16 in the environment overrides the default; debug
+// bits 6 / 7 / 8 of a descriptor force 1 / 2 / 0 for that launch (tests, scripts/ab_mfma16.py).  Same bits in, same bits out: both
+// shapes accumulate a k-tile's 32 products in fp32 in the same order (the A/B outputs are bit-identical).  Measured: back to
+// back (the chip at its power limit) 1068 -> 1160, 1054 -> 1127, 1083 -> 1154 TFLOP/s on the 346112 x 512 x 2304, 346112 x 256 x 4608
+// and 86528 x 512 x 4608 forwards (+6.5-8.7 %), 128 x 128 tile -1 ... +9 %; inside the training step, where BatchNorm passes between
+// the GEMMs keep the chip off its power limit, +-0.1 ms either way (32.38-32.58 against 32.42-32.44 ms).
+inline int mf16_mode(const crog_gemm_desc& d) {
+  static const int env = [] { const char* e = getenv("CROG_MFMA16"); return e ? atoi(e) : 1; }();
+  if (d.debug & 256) return 0;
+  if (d.debug & 64) return (d.debug & 128) ? 2 : 1;
+  return env;
+}
 inline bool lean_epilogue_ok(const crog_gemm_desc& d) {
   return d.alpha == 1.f && !d.bias && d.act == CROG_ACT_NONE && !d.R && d.out_mode == CROG_OUT_T && d.dtype == CROG_BF16 && (d.N & 1) == 0;
 }
@@ -1517,8 +1764,10 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     // CU and stay on 128 x 128.  (The same tile for 1x1 / linear forwards and data gradients, K = 128 ... 2048: no gain standalone -
     // their reductions are too short to amortise the 128 KiB ring's fill - and +0.4 ms in the step.)
     if constexpr (sizeof(T) == 2) {
-      if (lean_epilogue_ok(d) && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0 && (long)cdiv(d.M, 256) * (d.N / 256) >= 160)
+      if (lean_epilogue_ok(d) && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0 && (long)cdiv(d.M, 256) * (d.N / 256) >= 160) {
+        if (mf16_mode(d) >= 1) return launch_dma16<CROG_A_IM2COL, ShapeDma8>(d, s);
         return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, ShapeDma8>(d, s);
+      }
     }
     if constexpr (sizeof(T) == 2) {
       if (big_wgrad(d.dtype, d.a_layout, d.b_layout, d.out_mode, d.M, d.N, d.K) && d.alpha == 1.f && !d.a_sum && !d.bias && !d.R && d.batch == 1) {
@@ -1534,6 +1783,12 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
       if (small_wgrad(d.a_layout, d.b_layout, d.out_mode, d.M, d.N)) return dispatch_dma<T, ShapeDma64>(d, s);
       if (d.N <= 64) return dispatch_dma<T, ShapeTall>(d, s);
       if (shape == 1) return dispatch_dma<T, ShapeDma64>(d, s);
+    }
+    if constexpr (sizeof(T) == 2) {     // (opt-in: the 128 x 128 tile on the 16x16x32 shape, lean launches with whole tiles)
+      if (mf16_mode(d) >= 2 && lean_epilogue_ok(d) && d.b_layout == CROG_B_KC && d.N % 128 == 0 && d.splitk == 1 && d.M % 128 == 0) {
+        if (d.a_layout == CROG_A_IM2COL) return launch_dma16<CROG_A_IM2COL, ShapeMid>(d, s);
+        if (d.a_layout == CROG_A_KC) return launch_dma16<CROG_A_KC, ShapeMid>(d, s);
+      }
     }
     return dispatch_dma<T, ShapeMid>(d, s);
   }

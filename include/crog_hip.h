@@ -410,7 +410,7 @@ int crog_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, 
  *                        (peer writes + flag poll, sums formed in rank order: bit-identical on all ranks) when count fits a mailbox
  *                        slot, ncclAllReduce otherwise.  Capture-safe (the exchange counter lives in the mailbox)
  *   crog_allreduce_bucket  in-place ncclAllReduce (SUM, or AVG when `average`) of a gradient bucket, fp32 or bf16, on `stream`
- *   crog_comm_status     *timed_out_seq != 0: an exchange gave up waiting for a peer (~2 s) - the training state is invalid
+ *   crog_comm_status     *timed_out_seq != 0: an exchange gave up waiting for a peer (120 s by default, CROG_COMM_TIMEOUT_S) - the training state is invalid
  * RCCL is bound at run time (dlopen of the librccl.so already resident in the process; CROG_RCCL_LIB overrides): the library has no
  * link-time dependency on it. */
 int crog_comm_unique_id(void* id128);

