@@ -552,6 +552,12 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
       else for_each_elem(std::true_type{}, base0, ld, body);
     };
     if (R) all_elems(R, p.ldr, [](float a, const T* r) { return a + Elem<T>::to_f(*r); });
+    if (p.act == CROG_ACT_RELU_POST) {
+      per_block([&](int i, int j) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+      });
+    }
     if (p.out_mode == CROG_OUT_F32_ATOMIC) {
       if (p.debug & 32) return;          // timing-only ablation: what the atomic adds cost
       all_elems(reinterpret_cast<float*>(p.C) + coff, p.ldc, [](float a, float* c) { atomicAdd(c, a); return a; });
@@ -578,8 +584,8 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
         // (one rounding; the staged path rounds the product first, as a separate bf16 add would).
         const bool odd = lane & 1;
         const int64_t ldc = p.ldc, ldr = p.ldr;
-        auto store_pairs = [&](auto guarded, auto with_res) {
-          constexpr bool G = decltype(guarded)::value, WR = decltype(with_res)::value;
+        auto store_pairs = [&](auto guarded, auto with_res, auto relu_post) {
+          constexpr bool G = decltype(guarded)::value, WR = decltype(with_res)::value, POST = decltype(relu_post)::value;
 #pragma unroll
           for (int i = 0; i < WM; i++) {
             const int mrow = m0 + (wr * WM + i) * 32 + 4 * h + (odd ? 1 : 0);     // row of register 0 (even lanes) / 1 (odd lanes)
@@ -607,6 +613,7 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
                 const float b0 = dpp_swap1(a0), b1 = dpp_swap1(a1);     // the neighbour lane's values (lane ^ 1)
                 float lo = odd ? b1 : a0, hi = odd ? a1 : b0;
                 if constexpr (WR) { lo += (float)rv[j][q][0]; hi += (float)rv[j][q][1]; }
+                if constexpr (POST) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }      // CROG_ACT_RELU_POST: the ReLU after the residual
                 bf16x2 v;
                 v[0] = (bf16)lo;
                 v[1] = (bf16)hi;
@@ -618,8 +625,15 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
           }
         };
         const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;     // block-uniform: no guards inside the matrix
-        if (R) { if (interior) store_pairs(std::false_type{}, std::true_type{}); else store_pairs(std::true_type{}, std::true_type{}); }
-        else   { if (interior) store_pairs(std::false_type{}, std::false_type{}); else store_pairs(std::true_type{}, std::false_type{}); }
+        if constexpr (!LEAN) {
+          if (p.act == CROG_ACT_RELU_POST) {      // block-uniform; its own instantiations so that the common stores carry no extra max
+            if (R) { if (interior) store_pairs(std::false_type{}, std::true_type{}, std::true_type{}); else store_pairs(std::true_type{}, std::true_type{}, std::true_type{}); }
+            else   { if (interior) store_pairs(std::false_type{}, std::false_type{}, std::true_type{}); else store_pairs(std::true_type{}, std::false_type{}, std::true_type{}); }
+            return;
+          }
+        }
+        if (R) { if (interior) store_pairs(std::false_type{}, std::true_type{}, std::false_type{}); else store_pairs(std::true_type{}, std::true_type{}, std::false_type{}); }
+        else   { if (interior) store_pairs(std::false_type{}, std::false_type{}, std::false_type{}); else store_pairs(std::true_type{}, std::false_type{}, std::false_type{}); }
         return;
       }
 #pragma unroll
@@ -642,6 +656,10 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
 #pragma unroll
                 for (int e = 0; e < 8; e++) o.v[e] = (T)((float)o.v[e] + (float)rv.v[e]);
               }
+              if (p.act == CROG_ACT_RELU_POST) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) o.v[e] = (T)fmaxf((float)o.v[e], 0.f);
+              }
               stg16(C + (int64_t)m * p.ldc + n, o);
             } else {
 #pragma unroll
@@ -649,6 +667,7 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
                 if (n + e < p.N) {
                   float f = (float)o.v[e];
                   if (R) f += (float)R[(int64_t)m * p.ldr + n + e];
+                  if (p.act == CROG_ACT_RELU_POST) f = fmaxf(f, 0.f);
                   C[(int64_t)m * p.ldc + n + e] = (T)f;
                 }
             }

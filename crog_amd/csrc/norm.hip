@@ -174,6 +174,25 @@ __global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const floa
   scale_shift[2 * c + 1] = beta[c] - running_mean[c] * sc;
 }
 
+// Eval-mode BN folded into the convolution weights (crog_bn_fold_weights): one thread per destination element
+template <typename TD>
+__global__ void __launch_bounds__(NT) bn_fold_weights_kernel(const float* __restrict__ src, long lds_, int cols_src, int rpc,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                                             float eps, TD* __restrict__ dst, long ldd, int cols_dst, long rows,
+                                                             float* __restrict__ bias_dst) {
+  const long total = rows * cols_dst;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const long r = i / cols_dst;
+    const int c = (int)(i - r * cols_dst);
+    const int ch = (int)(r / rpc);
+    const float sc = gamma[ch] * rsqrtf(running_var[ch] + eps);
+    const float v = c < cols_src ? src[r * lds_ + c] * sc : 0.f;
+    dst[r * ldd + c] = Elem<TD>::from_f(v);
+    if (c == 0 && r == (long)ch * rpc) bias_dst[ch] = beta[ch] - running_mean[ch] * sc;
+  }
+}
+
 template <int VEC>
 __device__ inline void ld_f32v(const float* __restrict__ p, float (&o)[VEC]) {   // p is 16-byte aligned (parameter blocks are)
 #pragma unroll
@@ -1056,6 +1075,19 @@ extern "C" int crog_bn_eval_scale(const float* gamma, const float* beta, const f
                                   float eps, int C, float* scale_shift, crog_stream_t stream) {
   hipLaunchKernelGGL(bn_eval_scale_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean,
                      running_var, eps, C, scale_shift);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+extern "C" int crog_bn_fold_weights(int dtype_dst, const float* w_src, int64_t lds_, int cols_src, int rows_per_channel, const float* gamma,
+                                    const float* beta, const float* running_mean, const float* running_var, float eps, void* w_dst,
+                                    int64_t ldd, int cols_dst, int64_t rows, float* bias_dst, crog_stream_t stream) {
+  CROG_CHECK_ARG(w_src && w_dst && bias_dst && gamma && beta && running_mean && running_var, "bn_fold_weights: null pointer");
+  CROG_CHECK_ARG(rows > 0 && cols_dst > 0 && cols_src > 0 && cols_src <= cols_dst && rows_per_channel >= 1 && rows % rows_per_channel == 0,
+                 "bn_fold_weights: bad sizes rows=%ld cols %d -> %d rows_per_channel=%d", (long)rows, cols_src, cols_dst, rows_per_channel);
+  DISPATCH_T(dtype_dst, hipLaunchKernelGGL((bn_fold_weights_kernel<T>), dim3(stream_grid(rows * cols_dst)), dim3(NT), 0, (hipStream_t)stream,
+                                           w_src, (long)lds_, cols_src, rows_per_channel, gamma, beta, running_mean, running_var, eps, (T*)w_dst,
+                                           (long)ldd, cols_dst, (long)rows, bias_dst));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -501,11 +501,58 @@ class ConvBnAct(Function):
         return (dx, dres) + (None,) * 15
 
 
+EVAL_BN_FOLD = True
+
+
+def _conv_bn_act_eval(x, w: WRef, bn: BnBuffers, ksize, relu, res, out, wpad, dtype):
+    """Inference form of conv -> BatchNorm (-> + identity) (-> ReLU) (validate_with_grasp runs under model.eval() + torch.no_grad(),
+    crog_engine.py:133-135): with running statistics BatchNorm is an affine map per output channel, so it is folded into the weights
+    (crog_bn_fold_weights: fp32 master weights x scale -> compute dtype, one tiny launch per layer) and the shift, the residual and
+    the ReLU go into the GEMM epilogue - the pre-normalisation map z is never written or read (training needs z for the batch
+    statistics and the backward pass; inference does not)."""
+    dev = x.device
+    dt = K.dcode(dtype)
+    C = bn.gamma.rows * bn.gamma.cols
+    if ksize == "s":
+        B, _, Hi, Wi = x.shape
+        H, W = Hi // 2, Wi // 2
+        lead, M, cin = (B, H, W), B * (Hi // 2) * (Wi // 2), 27
+    else:
+        lead = tuple(x.shape[:-1])
+        M, cin, _ = K.mat(x)
+        if ksize == 3:
+            H, W = x.shape[1], x.shape[2]
+    if wpad is not None:
+        src_cols, dst_cols, rows = wpad
+    else:
+        rows, src_cols, dst_cols = w.rows, w.cols, w.cols
+    wf = torch.empty(rows * dst_cols, device=dev, dtype=dtype)
+    shift = torch.empty(C, device=dev, dtype=torch.float32)
+    K.bn_fold_weights(w.P, w.off, src_cols, rows // C, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.eps, wf,
+                      dst_cols, rows, shift)
+    wcols = dst_cols * (rows // C)
+    y = _dest(out) if out is not None else torch.empty(lead + (C,), device=dev, dtype=dtype)
+    ldy = K.mat(y)[2]
+    act = (K.ACT_RELU_POST if res is not None else K.ACT_RELU) if relu else K.ACT_NONE
+    ldr = K.mat(res)[2] if res is not None else 0
+    if ksize == "s":
+        patches = torch.empty(M, 32, device=dev, dtype=dtype)
+        K.stem_im2col(x, patches)
+        K.gemm(dt, K.A_KC, K.B_KC, patches, wf, y, M, C, 32, 32, 32, ldy, bias=shift, act=act, R=res, ldr=ldr)
+    elif ksize == 1:
+        K.gemm(dt, K.A_KC, K.B_KC, x, wf, y, M, C, cin, K.mat(x)[2], wcols, ldy, bias=shift, act=act, R=res, ldr=ldr)
+    else:
+        K.gemm(dt, K.A_IM2COL, K.B_KC, x, wf, y, M, C, 9 * cin, K.mat(x)[2], wcols, ldy, conv=(H, W, cin), bias=shift, act=act, R=res, ldr=ldr)
+    return y
+
+
 def conv_bn_act(x, w: Optional[WRef], bn: BnBuffers, *, ksize, relu=True, res=None, training=True, out=None, wpad=None, dtype=None,
                 grad_slot=None, res_slot=None, stat_out=None, stat_in=None):
     """stat_out / stat_in: a BnLink shared by two layers with y_L -> x_{L+1} and no other consumer of y_L (see BnLink)."""
     dtype = dtype if dtype is not None else x.dtype
     wp = w.param if w is not None else None
+    if EVAL_BN_FOLD and not training and ksize != 0 and not torch.is_grad_enabled():
+        return _conv_bn_act_eval(x, w, bn, ksize, relu, res, out, wpad, dtype)
     return ConvBnAct.apply(x, res, wp, bn.gamma.param, bn.beta.param, w, bn, ksize, relu, training, out, wpad, dtype, grad_slot, res_slot,
                            stat_out, stat_in)
 

@@ -18,7 +18,7 @@ from ._lib import GemmDesc, check
 F32, BF16 = 0, 1
 A_KC, A_IM2COL, A_MC = 0, 1, 2
 B_KC, B_NC, B_NC_DGRAD, B_NC_IM2COL = 0, 1, 2, 3
-ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_QUICKGELU, ACT_TANH, ACT_RELU_POST = 0, 1, 2, 3, 4
 OUT_T, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 
 
@@ -233,6 +233,13 @@ def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, e
 def bn_eval_scale(gamma, beta, running_mean, running_var, eps, C, scale_shift):
     check(lib().crog_bn_eval_scale(ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), C,
                                    ptr(scale_shift), stream()), "bn_eval_scale")
+
+
+def bn_fold_weights(w_master, w_off, cols_src, rows_per_channel, gamma, beta, running_mean, running_var, eps, w_dst, cols_dst, rows, bias_dst):
+    """Eval-mode BatchNorm folded into the convolution weights (crog_bn_fold_weights): fp32 master rows -> scaled compute-dtype rows + bias."""
+    check(lib().crog_bn_fold_weights(dcode(w_dst), ptr(w_master) + 4 * w_off, cols_src, cols_src, rows_per_channel, ptr(gamma), ptr(beta),
+                                     ptr(running_mean), ptr(running_var), float(eps), ptr(w_dst), cols_dst, cols_dst, rows, ptr(bias_dst),
+                                     stream()), "bn_fold_weights")
 
 
 def relu_mask_like(y: torch.Tensor) -> torch.Tensor:

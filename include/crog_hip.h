@@ -104,7 +104,8 @@ enum crog_b_layout {
   CROG_B_NC_IM2COL = 3  /* wgrad of conv3x3: B_mem[k = pixel][n = tap*convC + c] gathered from an
                            NHWC map [B,H,W,convC] (row stride ldb); K = B*H*W                    */
 };
-enum crog_act { CROG_ACT_NONE = 0, CROG_ACT_RELU = 1, CROG_ACT_QUICKGELU = 2, CROG_ACT_TANH = 3 };
+enum crog_act { CROG_ACT_NONE = 0, CROG_ACT_RELU = 1, CROG_ACT_QUICKGELU = 2, CROG_ACT_TANH = 3,
+                CROG_ACT_RELU_POST = 4 /* relu(alpha*acc + bias + R): the ReLU AFTER the residual (eval-mode bn3 + identity of a Bottleneck, clip.py:55-56, with BatchNorm folded into the weights) */ };
 enum crog_out_mode {
   CROG_OUT_T = 0,         /* store as dtype                                                      */
   CROG_OUT_F32 = 1,       /* store fp32                                                          */
@@ -132,7 +133,7 @@ typedef struct crog_gemm_desc {
   float alpha;
   const float* bias; /* [N] fp32 or NULL, added before act */
   int act;           /* crog_act */
-  const void* R;     /* residual [M][N] (dtype), added after act, or NULL (unbatched only) */
+  const void* R;     /* residual [M][N] (dtype), added after act (before the ReLU of CROG_ACT_RELU_POST), or NULL (unbatched only) */
   int64_t ldr;
   int out_mode;      /* crog_out_mode */
   int debug;         /* 0 in production.  Timing-only ablations of the LDS-DMA kernel (results are wrong): bit 0 skips the
@@ -369,6 +370,15 @@ int crog_conv3_dgrad_weights(int dtype, const void* src, void* dst, const int64_
  * 1x1 convolution (dx = dy W) is a forward-shaped crog_gemm(CROG_A_KC, CROG_B_KC) on dy and the copy: both operands K-contiguous
  * (20-46 % faster on the text tower's 640-row launches, 0-12 % elsewhere, than reading W transposed out of LDS). */
 int crog_dgrad_weights(int dtype, const void* src, void* dst, const int64_t* table, int count, crog_stream_t stream);
+/* Eval-mode BatchNorm folded into the preceding convolution (validate_with_grasp runs model.eval(), crog_engine.py:133: BatchNorm
+ * is the affine map y = z * sc + sh with sc = gamma / sqrt(running_var + eps), sh = beta - running_mean * sc, clip.py:18-26):
+ *   w_dst[r][c] = (c < cols_src ? w_src[r][c] : 0) * sc[r / rows_per_channel]   for c < cols_dst   (fp32 master weights in, compute dtype out)
+ *   bias_dst[ch] = sh[ch]
+ * so that conv + BatchNorm (+ ReLU, + residual) is ONE crog_gemm with bias / act / R and the pre-normalisation map is never written.
+ * rows_per_channel = 9 for a 3x3 weight stored [Cout][3][3][Cin] whose Cin is being zero-padded (rows = 9 * Cout), 1 otherwise. */
+int crog_bn_fold_weights(int dtype_dst, const float* w_src, int64_t lds, int cols_src, int rows_per_channel, const float* gamma,
+                         const float* beta, const float* running_mean, const float* running_var, float eps, void* w_dst, int64_t ldd,
+                         int cols_dst, int64_t rows, float* bias_dst, crog_stream_t stream);
 /* dst[r][c] = c < cols_src ? src[r][c] : 0 for c < cols_dst (fp32 source) */
 int crog_cast_pad2d(int dtype_dst, const float* src, int64_t lds, int cols_src, void* dst, int64_t ldd,
                     int cols_dst, int64_t rows, crog_stream_t stream);

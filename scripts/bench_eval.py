@@ -8,6 +8,8 @@ from crog_amd.engine import eval_maps
 from crog_amd.model import build_crog
 from crog_amd.testing import make_cfg, synthetic_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+from crog_amd import functional as Fn
+if len(sys.argv) > 2 and sys.argv[2] == "nofold": Fn.EVAL_BN_FOLD = False      # A/B: BatchNorm as a separate scale / shift pass
 cfg = make_cfg(); torch.manual_seed(0)
 model, _ = build_crog(cfg); model = model.cuda().prepare(); model.eval()
 batch = synthetic_batch(B, 416, 20, 49408, seed=1, device="cuda")
@@ -25,4 +27,4 @@ for name, dt in (("fp32", None), ("bf16", torch.bfloat16)):
     e1.record(); torch.cuda.synchronize()
     tk = e0.elapsed_time(e1) / 20 * 1e-3
     by = B * 5 * (104 * 104 + 416 * 416) * 4
-    print(f"eval {name}: {t*1e3:.2f} ms / {B} images = {B/t:.0f} img/s; crog_eval_maps alone {tk*1e6:.1f} us = {by/tk/1e9:.0f} GB/s algorithmic")
+    print(f"eval {name} (BatchNorm {'folded' if Fn.EVAL_BN_FOLD else 'as a pass'}): {t*1e3:.2f} ms / {B} images = {B/t:.0f} img/s; crog_eval_maps alone {tk*1e6:.1f} us = {by/tk/1e9:.0f} GB/s algorithmic")

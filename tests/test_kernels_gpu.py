@@ -152,6 +152,44 @@ def test_mfma_16x16x32_variant_equals_the_32x32x16_kernel(K, monkeypatch, case):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("shape", [(2, 13, 64, 72, 3, 64, True), (3, 10, 32, 40, 1, 32, True), (2, 9, 27, 64, 3, 32, False), (2, 12, 64, 64, 1, 64, False)])
+def test_eval_batchnorm_folded_into_the_convolution(K, dt, shape):
+    """crog_bn_fold_weights + the bias / ReLU / residual epilogue (CROG_ACT_RELU_POST: the ReLU after the residual) against
+    conv -> BatchNorm(running statistics) -> (+ identity) -> ReLU in float64 (clip.py:44-57 under model.eval()), incl. a 3x3 weight
+    whose ragged Cin is zero-padded while it is folded."""
+    B, HW, Cin, Cout, k, Cpad, with_res = shape
+    M = B * HW * HW
+    x = torch.zeros(B, HW, HW, Cpad, device="cuda", dtype=dt)
+    x[..., :Cin] = rnd(B, HW, HW, Cin, dt=dt)
+    w = rnd(Cout, k, k, Cin, seed=1) * (k * k * Cin) ** -0.5                                   # fp32 master, [Cout][ky][kx][Cin]
+    gamma, beta = rnd(Cout, seed=2).abs() + 0.5, rnd(Cout, seed=3) * 0.3
+    mean, var = rnd(Cout, seed=4) * 0.2, rnd(Cout, seed=5).abs() + 0.3
+    res = rnd(M, Cout, dt=dt, seed=6) if with_res else None
+    rows, rpc = (Cout * k * k, k * k) if Cpad != Cin else (Cout, 1)
+    src_cols = Cin if Cpad != Cin else k * k * Cin
+    dst_cols = Cpad if Cpad != Cin else k * k * Cin
+    wf = torch.empty(rows * dst_cols, device="cuda", dtype=dt)
+    shift = torch.empty(Cout, device="cuda")
+    K.bn_fold_weights(w.contiguous().view(-1), 0, src_cols, rpc, gamma, beta, mean, var, 1e-5, wf, dst_cols, rows, shift)
+    y = torch.empty(M, Cout, device="cuda", dtype=dt)
+    act = K.ACT_RELU_POST if with_res else K.ACT_RELU
+    Kd = k * k * Cpad
+    if k == 3:
+        K.gemm(K.dcode(dt), K.A_IM2COL, K.B_KC, x, wf, y, M, Cout, Kd, Cpad, Kd, Cout, conv=(HW, HW, Cpad), bias=shift, act=act, R=res, ldr=Cout)
+    else:
+        K.gemm(K.dcode(dt), K.A_KC, K.B_KC, x, wf, y, M, Cout, Kd, Cpad, Kd, Cout, bias=shift, act=act, R=res, ldr=Cout)
+    xi = x[..., :Cin].double().permute(0, 3, 1, 2)
+    wi = w.double().permute(0, 3, 1, 2)
+    z = torch.nn.functional.conv2d(xi, wi, padding=k // 2)
+    sc = gamma.double() / (var.double() + 1e-5).sqrt()
+    ref = (z * sc.view(1, -1, 1, 1) + (beta.double() - mean.double() * sc).view(1, -1, 1, 1)).permute(0, 2, 3, 1).reshape(M, Cout)
+    if with_res:
+        ref = ref + res.double()
+    close(y, ref.relu().float(), dt, scale=2.0)
+    assert float(y.float().min()) >= 0.0
+
+
+@pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (250, 72, 44), (676, 64, 676), (64, 2048, 49)])
 def test_gemm_nn(K, dt, M, N, K_):
     # A[m][k] k-contig (K padded to a multiple of 8 with zeros), B_mem[k][n] n-contig

@@ -108,6 +108,23 @@ def test_tiny_fp32_matches_reference_fixture():
     for i, nm in enumerate(NAMES):
         assert err(ev[0][i], g["eval_pred_" + nm]) < 1e-3, nm
         assert ev[1][i] is b[["mask", "qua", "sin", "cos", "wid"][i]]
+    # the eval forward above folds BatchNorm into the convolution weights (functional._conv_bn_act_eval); the unfolded form (conv -> z ->
+    # scale / shift pass) must give the same logits up to fp32 rounding, in fp32 and (looser) in bf16
+    from crog_amd import functional as Fn
+    for dtype, lim in ((torch.float32, 2e-5), (torch.bfloat16, 0.15)):
+        model.compute_dtype = dtype
+        outs = []
+        for fold in (True, False):
+            Fn.EVAL_BN_FOLD = fold
+            try:
+                with torch.no_grad():
+                    outs.append(torch.cat([o.float() for o in model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])[0]], 1))
+            finally:
+                Fn.EVAL_BN_FOLD = True
+        d = float((outs[0] - outs[1]).abs().max())
+        print(f"eval forward, BatchNorm folded vs unfolded ({dtype}): max |dlogit| = {d:.2e} (logit scale {float(outs[1].abs().max()):.1f})")
+        assert d < lim * max(1.0, float(outs[1].abs().max())), (dtype, d)
+    model.compute_dtype = None
 
 
 def test_tiny_nomask_variant():
