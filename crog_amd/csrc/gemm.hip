@@ -1397,7 +1397,7 @@ gemm_dma_kernel(const crog_gemm_desc p) {   // (fp32 carries a second accumulato
 // stored de-interleaved (kc_tile_row<2>) so that a lane owns four ADJACENT output columns: one 8-byte store per row.
 // =================================================================================================
 template <int AL, typename S>
-__global__ void __launch_bounds__(S::NT, S::NT == 512 ? 1 : 2) gemm_dma16_kernel(const crog_gemm_desc p) {
+__global__ void __launch_bounds__(S::NT, S::NT == 512 ? 1 : 3) gemm_dma16_kernel(const crog_gemm_desc p) {
   using T = bf16;
   constexpr int DMA_NSTAGE = dma_nstage<S>();
   constexpr int NW = S::NT / 64, NIA = S::BM / (16 * NW), NIB = S::BN / (16 * NW);
@@ -1740,15 +1740,17 @@ inline bool big_wgrad(int dtype, int a_layout, int b_layout, int out_mode, long 
   return b_layout == CROG_B_NC && M * N >= (1L << 20);
 }
 
-// Which launches take the v_mfma_f32_16x16x32 kernel (gemm_dma16_kernel): 1 (default) = the 256 x 256 tile of the large 3x3 forward /
-// data-gradient launches, 2 = also lean 128 x 128 launches, 0 = none.  CROG_MFMA16 in the environment overrides the default; debug
+// Which launches take the v_mfma_f32_16x16x32 kernel (gemm_dma16_kernel): 2 (default) = the 256 x 256 tile of the large 3x3 forward /
+// data-gradient launches and every lean 128 x 128 launch with K-contiguous operands and whole tiles (the BatchNorm'd convolutions and
+// their plain data gradients), 1 = the 256 x 256 tile only, 0 = none.  CROG_MFMA16 in the environment overrides the default; debug
 // bits 6 / 7 / 8 of a descriptor force 1 / 2 / 0 for that launch (tests, scripts/ab_mfma16.py).  Same bits in, same bits out: both
 // shapes accumulate a k-tile's 32 products in fp32 in the same order (the A/B outputs are bit-identical).  Measured: back to
 // back (the chip at its power limit) 1068 -> 1160, 1054 -> 1127, 1083 -> 1154 TFLOP/s on the 346112 x 512 x 2304, 346112 x 256 x 4608
 // and 86528 x 512 x 4608 forwards (+6.5-8.7 %), 128 x 128 tile -1 ... +9 %; inside the training step, where BatchNorm passes between
-// the GEMMs keep the chip off its power limit, +-0.1 ms either way (32.38-32.58 against 32.42-32.44 ms).
+// the GEMMs keep the chip off its power limit, less: 32.05-32.12 ms (0) / 31.93-31.97 (1) / 31.81-31.85 (2), three interleaved runs
+// each; the 128 x 128 kernel at two or three blocks per CU: 31.80 either way.
 inline int mf16_mode(const crog_gemm_desc& d) {
-  static const int env = [] { const char* e = getenv("CROG_MFMA16"); return e ? atoi(e) : 1; }();
+  static const int env = [] { const char* e = getenv("CROG_MFMA16"); return e ? atoi(e) : 2; }();
   if (d.debug & 256) return 0;
   if (d.debug & 64) return (d.debug & 128) ? 2 : 1;
   return env;
