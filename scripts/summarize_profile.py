@@ -51,6 +51,9 @@ for k in f:   # one roofline key can cover several tile-shape instantiations of 
             lay = (1, int(m2.group(1)))
         elif "gemm_dma_kernel<bool _Accum, int, EL, int, E," in k:
             lay = (2, 1)
+    m3 = re.search(r"gemm_dma16_kernel(?:<|ILi)(\d)", k)      # the 16x16x32 kernel: <AL, Shape>, B is K-contiguous
+    if m3:
+        lay = (int(m3.group(1)), 0)
     if lay in names and f[k][0]:
         key = names[lay]
         e = pm.setdefault(key, dict(kernels=[], launches=0, _bytes=0.0,
