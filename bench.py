@@ -319,7 +319,9 @@ def main():
     key = {"conv3x3_fwd": (K.A_IM2COL, K.B_KC), "conv3x3_dgrad": (K.A_IM2COL, K.B_NC_DGRAD), "conv3x3_wgrad": (K.A_MC, K.B_NC_IM2COL),
            "lin_fwd": (K.A_KC, K.B_KC), "none": None}[args.roofline_kernel]
     graphed = None
-    want = os.environ.get("CROG_STEP_GRAPH", "1" if world == 1 else "0")
+    # (also eager by default with CROG_FORCE_DDP: torch's process-group watchdog thread was seen to poll an event recorded inside the
+    # capture - hipErrorCapturedEvent, std::terminate - once in a few runs; tests/test_graph_step_gpu.py covers that combination in a child process)
+    want = os.environ.get("CROG_STEP_GRAPH", "1" if (world == 1 and not force_ddp) else "0")
     if not args.eager and want != "0":
         from crog_amd.graphs import GraphedTrainStep
         graphed = GraphedTrainStep(net, opt, cfg, adt, warmup=3, profile_key=key if rank == 0 else None)
@@ -433,10 +435,26 @@ def main():
                 out["measured_peaks"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+    # The JSON line must be the LAST thing on stdout.  RCCL prints a version banner through C stdio when a communicator is created; with
+    # stdout redirected that sits in a buffer until the process exits - i.e. AFTER a line printed from Python (seen: five banner lines
+    # behind the JSON of a forced-DDP run), and with N ranks sharing one stdout in whatever order they exit.  So every rank flushes C
+    # stdio before the final barrier, the process group goes away, and only then rank 0 prints.
+    import ctypes
+
+    def flush_c_stdio():
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+
+    flush_c_stdio()
     if world > 1 or force_ddp:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
+        flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

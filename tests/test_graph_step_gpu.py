@@ -221,17 +221,14 @@ def test_seed_epoch_shifts_every_dropout_kernel_like_a_host_seed():
         ep.fill_(0)
 
 
-def test_graphed_step_under_forced_ddp_and_syncbn():
-    """DistributedDataParallel + SyncBatchNorm forced on at world size 1 over RCCL (every statistics exchange and gradient bucket
-    really issued): the captured step carries the collectives and replays match the eager DDP steps."""
+def _forced_ddp_graph_case():
+    """Body of test_graphed_step_under_forced_ddp_and_syncbn (runs in a child process, see there)."""
     import socket
     import torch.distributed as dist
     from crog_amd.engine import train_step
     from crog_amd.graphs import GraphedTrainStep
     from crog_amd.parallel import DistributedDataParallel, convert_sync_batchnorm
     from crog_amd.runtime import RT
-    if dist.is_initialized():
-        pytest.skip("a process group already exists in this process")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -265,3 +262,27 @@ def test_graphed_step_under_forced_ddp_and_syncbn():
         RT.comm = None
         RT.reducer = None
         dist.destroy_process_group()
+    print("FORCED_DDP_GRAPH_OK")
+
+
+def test_graphed_step_under_forced_ddp_and_syncbn():
+    """DistributedDataParallel + SyncBatchNorm forced on at world size 1 over RCCL (every statistics exchange and gradient bucket
+    really issued): the captured step carries the collectives and replays match the eager DDP steps.
+    In a child process: torch's ProcessGroupNCCL watchdog THREAD polls the completion events of collectives, and on this stack
+    (torch 2.10 / ROCm 7.0) it was seen - once in a few runs - to query an event that was last recorded inside the stream capture,
+    which HIP refuses (hipErrorCapturedEvent) and torch turns into std::terminate of the whole process.  That race is torch's and only
+    exists while a capture is open next to a live process group (replay with collectives is opt-in for multi-rank runs, DESIGN.md
+    section 6); a run that dies of it is repeated, any other failure fails the test."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_graph_step_gpu as t; t._forced_ddp_graph_case()"
+            % (ROOT, os.path.join(ROOT, "tests")))
+    last = ""
+    for attempt in range(4):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+        last = (r.stdout + r.stderr)[-4000:]
+        if r.returncode == 0 and "FORCED_DDP_GRAPH_OK" in r.stdout:
+            return
+        if "hipErrorCapturedEvent" not in last and "captured" not in last.lower():
+            break
+        print(f"attempt {attempt}: the process group watchdog hit the capture (hipErrorCapturedEvent); repeating")
+    raise AssertionError(last)
