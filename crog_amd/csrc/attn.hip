@@ -10,7 +10,7 @@
 //   dK, dV       :  S   = Q K^T  [queries x keys]   lane = key:   registers are the operand of  dV += P^T dO,  dK += dS^T Q
 // with the reduction index permuted consistently on both operands (slot (h, j) of k-step t <-> row 16t + 8(j>>2) + 4h + (j&3));
 // the other operand comes out of LDS through ds_read_b64_tr_b16 with the same permutation.  No shuffles, no LDS round trip
-// for P.  Attention dropout uses the same counter hash and index (row * ldp + key) as crog_softmax_fwd, so the fused and the
+// for P.  Attention dropout uses the same pair hash and index (attn_hash, common.h: one hash per two neighbouring keys) as crog_softmax_fwd, so the fused and the
 // unfused paths drop identical elements for a given seed.
 #include "common.h"
 
@@ -92,9 +92,9 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
   const bf16* kg = a.K + (long)b * a.Lk * a.ldk + hd * DH + lch * 8;
   const bf16* vg = a.V + (long)b * a.Lk * a.ldv + hd * DH + lch * 8;
   const int nkt = (a.Lk + TT - 1) / TT;
-  const uint32_t thr = (uint32_t)(a.p_drop * 4294967296.0);
+  const uint32_t thr = attn_thr16(a.p_drop);
   const float sc = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-  const uint64_t rowbase = ((uint64_t)bh * a.Lq + q) * a.ldp;
+  const uint64_t rowbase2 = ((uint64_t)bh * a.Lq + q) * (uint64_t)((a.ldp + 1) >> 1);      // first key pair of the lane's score row
 
   bf16x8 rk, rv;
   {
@@ -137,8 +137,13 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; e++) { o[0][e] *= alpha; o[1][e] *= alpha; }
     if (a.p_drop > 0.f) {
+      // registers 4 g .. 4 g + 3 hold keys kb + 8 g + 4 h + {0, 1, 2, 3}: two pairs, one hash each (attn_hash, common.h)
 #pragma unroll
-      for (int r = 0; r < 16; r++) s[r] = dropout_keep(seed, rowbase + kb + acc_row(r, h), thr) ? s[r] * sc : 0.f;
+      for (int r = 0; r < 16; r += 2) {
+        const uint32_t hh = attn_hash(seed, rowbase2 + (uint64_t)((kb + acc_row(r, h)) >> 1));
+        s[r] = attn_keep_lo(hh, thr) ? s[r] * sc : 0.f;
+        s[r + 1] = attn_keep_hi(hh, thr) ? s[r + 1] * sc : 0.f;
+      }
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -209,9 +214,9 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
   const bf16* kg = a.K + (long)b * a.Lk * a.ldk + hd * DH + lch * 8;
   const bf16* vg = a.V + (long)b * a.Lk * a.ldv + hd * DH + lch * 8;
   const int nkt = (a.Lk + TT - 1) / TT;
-  const uint32_t thr = (uint32_t)(a.p_drop * 4294967296.0);
+  const uint32_t thr = attn_thr16(a.p_drop);
   const float sc = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-  const uint64_t rowbase = ((uint64_t)bh * a.Lq + q) * a.ldp;
+  const uint64_t rowbase2 = ((uint64_t)bh * a.Lq + q) * (uint64_t)((a.ldp + 1) >> 1);      // first key pair of the lane's score row
 
   bf16x8 rk, rv;
   {
@@ -246,7 +251,11 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
     }
     if (a.p_drop > 0.f) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) dp[r] = dropout_keep(seed, rowbase + kb + acc_row(r, h), thr) ? dp[r] * sc : 0.f;
+      for (int r = 0; r < 16; r += 2) {
+        const uint32_t hh = attn_hash(seed, rowbase2 + (uint64_t)((kb + acc_row(r, h)) >> 1));
+        dp[r] = attn_keep_lo(hh, thr) ? dp[r] * sc : 0.f;
+        dp[r + 1] = attn_keep_hi(hh, thr) ? dp[r + 1] * sc : 0.f;
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) s[r] = s[r] * (dp[r] - Dq) * a.scale;
@@ -310,7 +319,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
   const float* lg = a.lse + (long)bh * a.Lq;
   const float* dg = a.D + (long)bh * a.Lq;
   const int nqt = (a.Lq + TT - 1) / TT;
-  const uint32_t thr = (uint32_t)(a.p_drop * 4294967296.0);
+  const uint32_t thr = attn_thr16(a.p_drop);
   const float sc = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
 
   bf16x8 rq, ro;
@@ -346,17 +355,31 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
     }
     const int qb = qt * TT;
     f32x16 pd;
+    // dropout decisions: a hash covers the key pair (2 j, 2 j + 1) of one score row = lanes (2 j, 2 j + 1) of one register, so of
+    // every two rows the even lane hashes the first and the odd lane the second, and a DPP swap hands each its partner's value
+    unsigned keepbits = 0xffffu;
+    if (a.p_drop > 0.f) {
+      const bool odd = lane & 1;
+      keepbits = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int qmine = qb + acc_row(r, h) + (odd ? 1 : 0);
+        const uint32_t hm = attn_hash(seed, ((uint64_t)bh * a.Lq + qmine) * (uint64_t)((a.ldp + 1) >> 1) + (uint64_t)(key >> 1));
+        const uint32_t ho = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm, 0xB1, 0xF, 0xF, false);      // lane ^ 1
+        const uint32_t h0 = odd ? ho : hm, h1 = odd ? hm : ho;      // rows r, r + 1
+        const bool k0 = odd ? attn_keep_hi(h0, thr) : attn_keep_lo(h0, thr);
+        const bool k1 = odd ? attn_keep_hi(h1, thr) : attn_keep_lo(h1, thr);
+        keepbits |= (k0 ? 1u : 0u) << r;
+        keepbits |= (k1 ? 1u : 0u) << (r + 1);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int qr = acc_row(r, h);
       const float p = (qb + qr < a.Lq) ? __expf(s[r] * a.scale - sL[buf][qr]) : 0.f;
-      float g = dp[r], pk = p;
-      if (a.p_drop > 0.f) {
-        const bool keep = dropout_keep(seed, ((uint64_t)bh * a.Lq + qb + qr) * a.ldp + key, thr);
-        g = keep ? g * sc : 0.f;
-        pk = keep ? p * sc : 0.f;
-      }
-      pd[r] = pk;
+      const bool keep = (keepbits >> r) & 1u;
+      const float g = keep ? dp[r] * sc : 0.f;
+      pd[r] = keep ? p * sc : 0.f;
       s[r] = p * (g - sD[buf][qr]) * a.scale;
     }
 #pragma unroll

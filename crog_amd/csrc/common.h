@@ -103,3 +103,26 @@ __device__ inline uint32_t hash_u32(uint64_t seed, uint64_t idx) {
 __device__ inline bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thr) {
   return hash_u32(seed, idx) >= thr;
 }
+
+// Attention dropout (softmax probabilities: crog_softmax_fwd / bwd and the fused attention kernels): ONE hash decides the TWO
+// neighbouring keys (2j, 2j + 1) of a score row, 16 bits each (threshold = p * 2^16: 0.1 -> 6554 / 65536), and the hash is
+// murmur3's 32-bit finaliser - two multiplies instead of hash_u32's three.  v_mul_lo_u32 runs at a quarter of the VALU rate, and
+// with one three-multiply hash per score the fused forward was VALU-bound on its dropout (141 us with p = 0.1 against 72 us with
+// p = 0 at the decoder's shape): a multiply per score instead of three.  Index of a pair: row * ceil(ldp / 2) + (key >> 1).
+__device__ inline uint32_t attn_hash(uint64_t seed, uint64_t pair_idx) {
+  const uint32_t y = (uint32_t)(pair_idx >> 32) ^ (uint32_t)(seed >> 32);
+  uint32_t x = ((uint32_t)pair_idx + (uint32_t)seed) ^ ((y << 16) | (y >> 16));
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+__device__ inline uint32_t attn_thr16(float p) { return (uint32_t)(p * 65536.0f); }
+__device__ inline bool attn_keep_lo(uint32_t h, uint32_t thr16) { return (h & 0xffffu) >= thr16; }   // key 2j
+__device__ inline bool attn_keep_hi(uint32_t h, uint32_t thr16) { return (h >> 16) >= thr16; }       // key 2j + 1
+__device__ inline bool attn_keep(uint64_t seed, uint64_t row, int key, int ldp2, uint32_t thr16) {
+  const uint32_t h = attn_hash(seed, row * (uint64_t)ldp2 + (uint64_t)(key >> 1));
+  return (key & 1) ? attn_keep_hi(h, thr16) : attn_keep_lo(h, thr16);
+}

@@ -936,7 +936,7 @@ __global__ void __launch_bounds__(NT) softmax_fwd_kernel(T* __restrict__ S, long
     }
   sum = group_sum<LPR>(sum);
   const float inv = 1.f / sum;  // a fully masked row gives NaN exactly as torch does
-  const uint32_t thr = (uint32_t)(p_drop * 4294967296.0);
+  const uint32_t thr16 = attn_thr16(p_drop);
   const float sc = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   if (!live) return;
 #pragma unroll
@@ -954,7 +954,11 @@ __global__ void __launch_bounds__(NT) softmax_fwd_kernel(T* __restrict__ S, long
       if (Pd) {
         if (p_drop > 0.f) {
 #pragma unroll
-          for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(dropout_keep(seed, (uint64_t)row * ldp + k0 + e, thr) ? pv[e] * sc : 0.f);
+          for (int e = 0; e < VEC; e += 2) {      // one hash per pair of keys (attn_hash, common.h); k0 is even
+            const uint32_t hh = attn_hash(seed, (uint64_t)row * (uint64_t)((ldp + 1) >> 1) + (uint64_t)((k0 + e) >> 1));
+            o.v[e] = Elem<T>::from_f(attn_keep_lo(hh, thr16) ? pv[e] * sc : 0.f);
+            o.v[e + 1] = Elem<T>::from_f(attn_keep_hi(hh, thr16) ? pv[e + 1] * sc : 0.f);
+          }
         }
         stg16(Pd + row * ldp + k0, o);
       }
@@ -972,7 +976,7 @@ __global__ void __launch_bounds__(NT) softmax_bwd_kernel(const T* __restrict__ P
   const long row = ((long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
   const bool live = row < rows;
   const long rr = live ? row : rows - 1;
-  const uint32_t thr = (uint32_t)(p_drop * 4294967296.0);
+  const uint32_t thr16 = attn_thr16(p_drop);
   const float sc = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   const int nvec = ldp / VEC;
   float pv[NJ][VEC], dp[NJ][VEC];
@@ -989,7 +993,11 @@ __global__ void __launch_bounds__(NT) softmax_bwd_kernel(const T* __restrict__ P
         if (k0 + e < Lk) { pv[j][e] = Elem<T>::to_f(a.v[e]); dp[j][e] = Elem<T>::to_f(g.v[e]); }
       if (p_drop > 0.f) {
 #pragma unroll
-        for (int e = 0; e < VEC; e++) dp[j][e] = dropout_keep(seed, (uint64_t)rr * ldp + k0 + e, thr) ? dp[j][e] * sc : 0.f;
+        for (int e = 0; e < VEC; e += 2) {
+          const uint32_t hh = attn_hash(seed, (uint64_t)rr * (uint64_t)((ldp + 1) >> 1) + (uint64_t)((k0 + e) >> 1));
+          dp[j][e] = attn_keep_lo(hh, thr16) ? dp[j][e] * sc : 0.f;
+          dp[j][e + 1] = attn_keep_hi(hh, thr16) ? dp[j][e + 1] * sc : 0.f;
+        }
       }
 #pragma unroll
       for (int e = 0; e < VEC; e++) dot += dp[j][e] * pv[j][e];
