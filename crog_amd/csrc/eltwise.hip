@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(NT) add_dropout_kernel(const T* __restrict__ a
   constexpr int VEC = Elem<T>::VEC;
   if (epoch) seed += *epoch;                 // crog_set_seed_epoch: per-step offset from device memory
   const int cvec = C / VEC;
-  const uint32_t thr = (uint32_t)(p * 4294967296.0);
+  const uint32_t thr = attn_thr16(p);      // 16-bit threshold of the pair hash (dropout_apply, common.h)
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
   GRID_STRIDE(i, M * cvec) {
     const long r = i / cvec;
@@ -316,8 +316,7 @@ __global__ void __launch_bounds__(NT) add_dropout_kernel(const T* __restrict__ a
 #pragma unroll
     for (int e = 0; e < VEC; e++) f[e] = Elem<T>::to_f(y.v[e]);
     if (p > 0.f) {   // launch-uniform flags: tested once per vector
-#pragma unroll
-      for (int e = 0; e < VEC; e++) f[e] = dropout_keep(seed, (uint64_t)r * C + c + e, thr) ? f[e] * sc : 0.f;
+      dropout_apply<VEC>(f, seed, (uint64_t)r * C + c, thr, sc);
     }
     if (a) {
 #pragma unroll

@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(NT) ln_fwd_kernel(const T* __restrict__ x, lon
   long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
   if (row >= M) return;
   const int cvec = C / VEC;
-  const uint32_t thr_in = (uint32_t)(p_in * 4294967296.0), thr_out = (uint32_t)(p_out * 4294967296.0);
+  const uint32_t thr_in = attn_thr16(p_in), thr_out = attn_thr16(p_out);      // 16-bit thresholds of the pair hash (dropout_apply, common.h)
   const float sc_in = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, sc_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
   const float invC = 1.f / C;
   constexpr bool PF = NV <= 2;   // wide rows already keep >= 4 loads per lane in flight; prefetching them only costs registers
@@ -625,9 +625,7 @@ __global__ void __launch_bounds__(NT) ln_fwd_kernel(const T* __restrict__ x, lon
 #pragma unroll
         for (int e = 0; e < VEC; e++) vals[j][e] = Elem<T>::to_f(cur[j].v[e]);
         if (p_in > 0.f) {   // wave-uniform: hoisted around the whole vector so the common p = 0 path stays branch-free
-#pragma unroll
-          for (int e = 0; e < VEC; e++)
-            vals[j][e] = dropout_keep(seed_in, (uint64_t)row * C + cv * VEC + e, thr_in) ? vals[j][e] * sc_in : 0.f;
+          dropout_apply<VEC>(vals[j], seed_in, (uint64_t)row * C + cv * VEC, thr_in, sc_in);
         }
 #pragma unroll
         for (int e = 0; e < VEC; e++) s += vals[j][e];
@@ -662,8 +660,7 @@ __global__ void __launch_bounds__(NT) ln_fwd_kernel(const T* __restrict__ x, lon
 #pragma unroll
         for (int e = 0; e < VEC; e++) f[e] = (vals[j][e] - mean) * rstd * gv[e] + bv[e];
         if (p_out > 0.f) {
-#pragma unroll
-          for (int e = 0; e < VEC; e++) f[e] = dropout_keep(seed_out, (uint64_t)row * C + c + e, thr_out) ? f[e] * sc_out : 0.f;
+          dropout_apply<VEC>(f, seed_out, (uint64_t)row * C + c, thr_out, sc_out);
         }
         if (res) {
 #pragma unroll
@@ -700,7 +697,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
   if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int cvec = C / VEC;
-  const uint32_t thr_in = (uint32_t)(p_in * 4294967296.0), thr_out = (uint32_t)(p_out * 4294967296.0);
+  const uint32_t thr_in = attn_thr16(p_in), thr_out = attn_thr16(p_out);      // 16-bit thresholds of the pair hash (dropout_apply, common.h)
   const float sc_in = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, sc_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
   const float invC = 1.f / C;
   constexpr bool PF = NV <= 2;   // see ln_fwd_kernel
@@ -768,12 +765,10 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
           for (int e = 0; e < VEC; e++) gf[e] += Elem<T>::to_f(cg2[j].v[e]);
         }
         if (p_out > 0.f) {
-#pragma unroll
-          for (int e = 0; e < VEC; e++) gf[e] = dropout_keep(seed_out, (uint64_t)row * C + c + e, thr_out) ? gf[e] * sc_out : 0.f;
+          dropout_apply<VEC>(gf, seed_out, (uint64_t)row * C + c, thr_out, sc_out);
         }
         if (p_in > 0.f) {
-#pragma unroll
-          for (int e = 0; e < VEC; e++) xf[e] = dropout_keep(seed_in, (uint64_t)row * C + c + e, thr_in) ? xf[e] * sc_in : 0.f;
+          dropout_apply<VEC>(xf, seed_in, (uint64_t)row * C + c, thr_in, sc_in);
         }
         if (PF) {
 #pragma unroll
@@ -806,8 +801,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
 #pragma unroll
         for (int e = 0; e < VEC; e++) d[e] = rstd * (gy[j][e] - a - xh[j][e] * b);
         if (p_in > 0.f) {
-#pragma unroll
-          for (int e = 0; e < VEC; e++) d[e] = dropout_keep(seed_in, (uint64_t)row * C + c + e, thr_in) ? d[e] * sc_in : 0.f;
+          dropout_apply<VEC>(d, seed_in, (uint64_t)row * C + c, thr_in, sc_in);
         }
 #pragma unroll
         for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(d[e]);
