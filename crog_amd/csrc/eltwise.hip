@@ -589,11 +589,16 @@ __global__ void __launch_bounds__(NT) adam_kernel(float* __restrict__ p, const f
     bc2_sqrt = hyper[2];
   }
   const float step_size = lr / bc1;
-  GRID_STRIDE(i, (n + 3) / 4) {
+  // One 16-byte vector of each stream per thread, no grid-stride loop, non-temporal accesses for everything that is not read again
+  // before the next optimizer step (g, m, v, the fp32 parameters): the launch shape of the copy probe (api.hip), which streams at
+  // 6.5 TB/s where a 4096-block grid-stride loop reached 4.3-4.6.  The bf16 shadow is stored normally: the next forward reads it.
+  {
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= (n + 3) / 4) return;
     const long o = i * 4;
     if (o + 4 <= n) {
-      f32x4 pv = *reinterpret_cast<f32x4*>(p + o), gv = *reinterpret_cast<const f32x4*>(g + o);
-      f32x4 mv = *reinterpret_cast<f32x4*>(m + o), vv = *reinterpret_cast<f32x4*>(v + o);
+      f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + o)), gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + o));
+      f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + o)), vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + o));
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         float gg = gv[e] + weight_decay * pv[e];
@@ -602,9 +607,9 @@ __global__ void __launch_bounds__(NT) adam_kernel(float* __restrict__ p, const f
         const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
         pv[e] -= step_size * mv[e] / denom;
       }
-      *reinterpret_cast<f32x4*>(p + o) = pv;
-      *reinterpret_cast<f32x4*>(m + o) = mv;
-      *reinterpret_cast<f32x4*>(v + o) = vv;
+      __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p + o));
+      __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m + o));
+      __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + o));
       if (shadow) {
         bf16x4 s;
 #pragma unroll
@@ -880,8 +885,8 @@ extern "C" int crog_adam_step(float* p, const float* g, float* m, float* v, int6
   // bias corrections in double, rounded once: the device-side form (adam_advance_kernel) computes the same expression
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  LAUNCH(adam_kernel, (n + 3) / 4, s, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, (bf16*)bf16_shadow,
-         (const float*)nullptr);
+  hipLaunchKernelGGL(adam_kernel, dim3(cdiv((n + 3) / 4, NT)), dim3(NT), 0, (hipStream_t)s, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
+                     (bf16*)bf16_shadow, (const float*)nullptr);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
@@ -910,7 +915,8 @@ extern "C" int crog_adam_step_dev(float* p, const float* g, float* m, float* v, 
   CROG_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
                  "adam: buffers must be 16-byte aligned");
   if (n == 0) return CROG_OK;
-  LAUNCH(adam_kernel, (n + 3) / 4, s, p, g, m, v, (long)n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, (bf16*)bf16_shadow, hyper_dev);
+  hipLaunchKernelGGL(adam_kernel, dim3(cdiv((n + 3) / 4, NT)), dim3(NT), 0, (hipStream_t)s, p, g, m, v, (long)n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f,
+                     (bf16*)bf16_shadow, hyper_dev);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
