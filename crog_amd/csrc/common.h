@@ -60,6 +60,12 @@ template <typename T>
 __device__ inline Vec16<T> ldg16(const T* p) {
   return *reinterpret_cast<const Vec16<T>*>(p);
 }
+// non-temporal 16-byte load: data that is read once and not again soon (the last reader of a tensor in a step)
+template <typename T>
+__device__ inline Vec16<T> ldg16_nt(const T* p) {
+  const f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return __builtin_bit_cast(Vec16<T>, r);
+}
 template <typename T>
 __device__ inline void stg16(T* p, const Vec16<T>& v) {
   *reinterpret_cast<Vec16<T>*>(p) = v;

@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
     };
     long r = i0 >> lg, i = i0;
     for (; r < M; r += rstep, i += G) {
-      Vec16<T> g = ldg16(dy + r * lddy + c), zz = ldg16(z + r * ldz + c), yy;
+      Vec16<T> g = ldg16_nt(dy + r * lddy + c), zz = ldg16_nt(z + r * ldz + c), yy;      // last readers of dy and z: non-temporal
       if (y) yy = ldg16(y + r * ldy + c);
       one(g, zz, yy, relu_mask ? relu_mask[i] : 0u, r);
     }
@@ -510,8 +510,8 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
     const long r = i / cvec;
     const int c = (int)(i % cvec) * VEC;
-    Vec16<T> g = ldg16(dy + r * lddy + c);
-    Vec16<T> zz = ldg16(z + r * ldz + c);
+    Vec16<T> g = ldg16_nt(dy + r * lddy + c);      // last readers of dy and z: non-temporal
+    Vec16<T> zz = ldg16_nt(z + r * ldz + c);
     Vec16<T> yy;
     if (y) yy = ldg16(y + r * ldy + c);
     Vec16<T> o, gr;
