@@ -188,7 +188,8 @@ class BnBuffers:
 class GradSlot:
     """Side channel that carries a residual branch's gradient from the op that consumes the identity (`res_slot`) to the op
     whose data gradient it must be added to (`grad_slot`), so the sum happens in that GEMM's residual epilogue instead of a
-    separate autograd accumulation pass (Bottleneck without downsample, clip.py:44-57: grad(x) = dgrad(conv1) + grad(identity))."""
+    separate autograd accumulation pass (Bottleneck, clip.py:44-57: grad(x) = dgrad(conv1) + grad(identity); with a downsample branch
+    the producer is that branch's last backward op - AvgPool2Fn or the 1x1 ConvBnAct, `dx_slot` - instead of conv3's residual)."""
 
     __slots__ = ("t",)
 
@@ -237,9 +238,10 @@ class ConvBnAct(Function):
 
     @staticmethod
     def forward(ctx, x, res, _wp, _gp, _bp, w: Optional[WRef], bn: BnBuffers, ksize, relu: bool, training: bool, out, wpad, dtype,
-                grad_slot=None, res_slot=None, stat_out=None, stat_in=None):
+                grad_slot=None, res_slot=None, stat_out=None, stat_in=None, dx_slot=None):
         dev = x.device
         ctx.slots = (grad_slot, res_slot)
+        ctx.dx_slot = dx_slot
         ctx.links = (stat_out, stat_in)
         if ksize == "s":
             B, _, Hi, Wi = x.shape
@@ -498,7 +500,10 @@ class ConvBnAct(Function):
                 stat_in.sums = None
             RT.flush_wgrad()       # (defer_wgrad: the weight gradient parked above forks here, behind the data gradient just enqueued)
             w.done()
-        return (dx, dres) + (None,) * 15
+        if ctx.dx_slot is not None and dx is not None:      # (see avgpool2: x's other consumer adds this gradient in its own epilogue)
+            ctx.dx_slot.t = dx
+            dx = None
+        return (dx, dres) + (None,) * 16
 
 
 EVAL_BN_FOLD = True
@@ -547,14 +552,14 @@ def _conv_bn_act_eval(x, w: WRef, bn: BnBuffers, ksize, relu, res, out, wpad, dt
 
 
 def conv_bn_act(x, w: Optional[WRef], bn: BnBuffers, *, ksize, relu=True, res=None, training=True, out=None, wpad=None, dtype=None,
-                grad_slot=None, res_slot=None, stat_out=None, stat_in=None):
+                grad_slot=None, res_slot=None, stat_out=None, stat_in=None, dx_slot=None):
     """stat_out / stat_in: a BnLink shared by two layers with y_L -> x_{L+1} and no other consumer of y_L (see BnLink)."""
     dtype = dtype if dtype is not None else x.dtype
     wp = w.param if w is not None else None
     if EVAL_BN_FOLD and not training and ksize != 0 and not torch.is_grad_enabled():
         return _conv_bn_act_eval(x, w, bn, ksize, relu, res, out, wpad, dtype)
     return ConvBnAct.apply(x, res, wp, bn.gamma.param, bn.beta.param, w, bn, ksize, relu, training, out, wpad, dtype, grad_slot, res_slot,
-                           stat_out, stat_in)
+                           stat_out, stat_in, dx_slot)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -894,22 +899,28 @@ def mha(xq, xk, xv, wq: WRef, wk: WRef, wv: WRef, bq, bk, bv, wo: WRef, bo, *, B
 # ------------------------------------------------------------------------------------------------
 class AvgPool2Fn(Function):
     @staticmethod
-    def forward(ctx, x, out):
+    def forward(ctx, x, out, grad_slot=None):
         B, H, W, C = x.shape
         y = _dest(out) if out is not None else torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=x.dtype)
         K.avgpool2_fwd(x, y)
         ctx.shape = x.shape
+        ctx.grad_slot = grad_slot
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dx = torch.empty(ctx.shape, device=dy.device, dtype=dy.dtype)
         K.avgpool2_bwd(K.as_mat(dy), dx)
-        return dx, None
+        if ctx.grad_slot is not None:      # the other consumer of x adds this branch's gradient in its data-gradient epilogue (GradSlot)
+            ctx.grad_slot.t = dx
+            return None, None, None
+        return dx, None, None
 
 
-def avgpool2(x, out=None):
-    return AvgPool2Fn.apply(x, out)
+def avgpool2(x, out=None, grad_slot=None):
+    """grad_slot: hand the gradient w.r.t. x to a GradSlot instead of autograd (the caller vouches that the slot's consumer - another
+    consumer of the same x - runs its backward AFTER this op: Bottleneck's downsample branch, created after conv1 / conv2)."""
+    return AvgPool2Fn.apply(x, out, grad_slot)
 
 
 class Upsample2Fn(Function):

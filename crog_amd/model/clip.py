@@ -38,8 +38,11 @@ class Bottleneck(Bound):
 
     def forward(self, x):
         tr = self.training
-        # identity blocks: the residual's gradient rides a slot into conv1's dgrad epilogue (no separate accumulation pass)
-        slot = Fn.GradSlot() if (self.downsample is None and tr and x.requires_grad) else None
+        # x has two consumers (conv1 and the identity / downsample branch): the second branch's gradient rides a slot into conv1's
+        # dgrad epilogue (no separate accumulation pass).  Valid because that branch is created after conv1 / conv2, so autograd runs
+        # its backward first; without a downsample the producer is conv3's residual gradient, with one the branch's last backward op
+        slot = Fn.GradSlot() if (tr and x.requires_grad) else None
+        ds = self.downsample is not None
         # bn1's output feeds conv2 and nothing else, bn2's feeds conv3 directly when no AvgPool sits between them: the data gradient
         # of the consuming convolution does the first pass of that BatchNorm's backward in its epilogue (Fn.BnLink)
         l1 = Fn.BnLink() if tr else None
@@ -51,10 +54,11 @@ class Bottleneck(Bound):
         identity = x
         if self.downsample is not None:
             if self.stride > 1:
-                identity = Fn.avgpool2(x)
-            identity = Fn.conv_bn_act(identity, self.downsample["0"].w, self.downsample["1"].buffers_ref(), ksize=1, relu=False, training=tr)
-        return Fn.conv_bn_act(out, self.conv3.w, self.bn3.buffers_ref(), ksize=1, relu=True, res=identity, training=tr, res_slot=slot,
-                              stat_in=l2)
+                identity = Fn.avgpool2(x, grad_slot=slot)
+            identity = Fn.conv_bn_act(identity, self.downsample["0"].w, self.downsample["1"].buffers_ref(), ksize=1, relu=False, training=tr,
+                                      dx_slot=slot if self.stride == 1 else None)
+        return Fn.conv_bn_act(out, self.conv3.w, self.bn3.buffers_ref(), ksize=1, relu=True, res=identity, training=tr,
+                              res_slot=None if ds else slot, stat_in=l2)
 
 
 _BICUBIC_CACHE = {}
