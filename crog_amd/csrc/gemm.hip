@@ -1835,10 +1835,15 @@ extern "C" int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int 
     s = std::min(std::max(1L, WGRAD256_BLOCKS / tiles), std::max(1L, ktiles / 32));
   } else if (small_wgrad(a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N)) {      // 64 x 64 tiles, ~2048 blocks, >= 16 k-tiles per block
     const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
-    s = std::min(std::max(1L, 2048 / tiles), std::max(1L, ktiles / 16));
+    // (the layer1 / stem gradients - reductions over >= 346112 pixels - are the LAST of the step and run after the main chain has
+    // finished, alone on the chip: twice the blocks there, except for the 9-tile 64 x 576 form, whose 2043 blocks already pay
+    // 33 MB of atomics: 128 x 1152 273 -> 227 us, 32 x 288 over 1.38 M 145 -> 127 us alone, scripts/bench_tail_wgrad.py)
+    const long target = (K >= (1 << 18) && (tiles >= 16 || tiles <= 5)) ? 4096 : 2048;
+    s = std::min(std::max(1L, target / tiles), std::max(1L, ktiles / 16));
   } else {      // 128 x 128 tiles: ~256 blocks (512 for the 3x3 form and for outputs above 1 M elements), >= 24 k-tiles per block
     const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-    const long target = b_layout == CROG_B_NC_IM2COL ? 512 : ((long)M * N <= (1L << 20) ? 256 : 512);
+    // (>= 346112-pixel reductions: the tail of the step, see above: 256 x 64 83 -> 60 us, 64 x 256 78 -> 55 us, 128 x 256 87 -> 70 us alone)
+    const long target = (b_layout == CROG_B_NC_IM2COL || K >= (1 << 18)) ? 512 : ((long)M * N <= (1L << 20) ? 256 : 512);
     s = std::min(std::max(1L, target / tiles), std::max(1L, ktiles / 24));
   }
   return (int)std::max(1L, std::min(s, 1024L));
