@@ -454,6 +454,8 @@ def main():
         dist.destroy_process_group()
         flush_c_stdio()
     if rank == 0:
+        if world > 1:
+            time.sleep(0.5)      # the other ranks' last flush (above) may still be on its way to the shared stdout
         print(json.dumps(out), flush=True)
 
 
