@@ -13,6 +13,8 @@
 // record / stream wait for every edge that crosses chains (redundant ones pruned).  Same kernels, same arguments (the node-owned
 // copies), same streams and the same edges as the eager step: ~3 us of host time per launch from one C loop.
 #include "common.h"
+#include <hip/hip_ext.h>
+#include <stdlib.h>
 
 #include <stdlib.h>
 #include <algorithm>
@@ -275,6 +277,15 @@ extern "C" int crog_replay_launch(void* replay, const crog_stream_t* streams, in
     for (int w : nd.waits) RP_HIP(hipStreamWaitEvent(s, R->events[w], 0), "hipStreamWaitEvent");
     const bool prof = R->profiling && nd.prof >= 0;
     if (prof) RP_HIP(hipEventRecord(R->prof_ev[2 * nd.prof], s), "hipEventRecord");
+    // A kernel that other chains wait for carries its event as the launch's own stop event (hipExtLaunchKernel: the dispatch packet's
+    // completion signal) instead of a marker packet behind it: a marker costs the producer's queue 6-12 us before its next kernel starts
+    // (scripts/chain_gaps.py: ~90 such gaps on the main chain of a step)
+    static const bool ext = [] { const char* e = getenv("CROG_REPLAY_EXT"); return !e || e[0] != '0'; }();
+    if (ext && nd.record >= 0 && !prof && nd.type == hipGraphNodeTypeKernel && !nd.module_launch) {
+      RP_HIP(hipExtLaunchKernel(nd.kp.func, nd.kp.gridDim, nd.kp.blockDim, nd.kp.kernelParams, nd.kp.sharedMemBytes, s, nullptr, R->events[nd.record], 0),
+             "hipExtLaunchKernel");
+      continue;
+    }
     const int rc = issue(nd, s);
     if (rc != CROG_OK) return rc;
     if (prof) RP_HIP(hipEventRecord(R->prof_ev[2 * nd.prof + 1], s), "hipEventRecord");
