@@ -20,6 +20,9 @@ for q in sorted({e[2] for e in seg}):
     print(f"queue {q}: {len(L)} launches, span {(L[0][0]-t0)/1e6:.2f}..{(L[-1][1]-t0)/1e6:.2f} ms, idle between kernels {tot/1e6:.2f} ms; gaps {dict(hist)}")
     for g, a, b in sorted(gaps, key=lambda x: -x[0])[:12]:
         print(f"    {g/1e3:8.1f} us at {(a[1]-t0)/1e6:6.2f} ms   {short(a[3])}  ->  {short(b[3])}")
+    print("    head of the queue:")
+    for a in L[:12]:
+        print(f"      {(a[0]-t0)/1e6:7.3f} .. {(a[1]-t0)/1e6:7.3f} ms  {(a[1]-a[0])/1e3:7.1f} us  {short(a[3])}")
     print("    tail of the queue:")
     for a in L[-14:]:
         print(f"      {(a[0]-t0)/1e6:7.3f} .. {(a[1]-t0)/1e6:7.3f} ms  {(a[1]-a[0])/1e3:7.1f} us  {short(a[3])}")
