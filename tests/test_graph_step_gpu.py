@@ -77,16 +77,22 @@ def test_replayed_steps_equal_eager_steps(dtype, executor):
 
     s0, p0, mv0 = run("eager")
     s1, p1, mv1 = run("eager")
+    s3, p3, mv3 = run("eager")
     s2, p2, mv2 = run("graph")
+    # The yardstick is the eager path's own run-to-run spread (split-K and statistics atomics, amplified by seven optimizer steps of a
+    # chaotic tiny model).  ONE eager pair under-estimates it now and then: with 4 x |s0 - s1| this test failed once in eight runs of a
+    # build whose replays were fine (0.229 against 4 x 0.045 on the fp32 loss).  Three eager runs, the largest pairwise distance, factor 6.
+    pairs = ((s0, s1), (s0, s3), (s1, s3))
     # column 0 = loss (continuous); columns 1-2 = 100 * IoU / Prec@50 of a thresholded mask: a count, it jumps when one pixel of the
     # chaotic tiny model crosses 0.35, so it is held to the loose bound and the loss to the tight one
-    noise_l = (s0[:, 0] - s1[:, 0]).abs().max().item()
-    assert (s0[:, 0] - s2[:, 0]).abs().max().item() <= max(4 * noise_l, 2e-3 if dtype == torch.float32 else 5e-2), (s0, s2)
-    noise_m = (s0[:, 1:] - s1[:, 1:]).abs().max().item()
+    noise_l = max((a[:, 0] - b[:, 0]).abs().max().item() for a, b in pairs)
+    assert (s0[:, 0] - s2[:, 0]).abs().max().item() <= max(6 * noise_l, 2e-3 if dtype == torch.float32 else 5e-2), (noise_l, s0, s2)
+    noise_m = max((a[:, 1:] - b[:, 1:]).abs().max().item() for a, b in pairs)
     assert (s0[:, 1:] - s2[:, 1:]).abs().max().item() <= max(10 * noise_m, 1.0), (s0, s2)
-    noise_p = _rel(p0, p1)
-    assert _rel(p0, p2) <= max(4 * noise_p, 1e-6 if dtype == torch.float32 else 1e-4), (noise_p, _rel(p0, p2))
-    assert _rel(mv0[0], mv2[0]) <= max(4 * _rel(mv0[0], mv1[0]), 1e-3 if dtype == torch.float32 else 5e-2)
+    noise_p = max(_rel(p0, p1), _rel(p0, p3), _rel(p1, p3))
+    assert _rel(p0, p2) <= max(6 * noise_p, 1e-6 if dtype == torch.float32 else 1e-4), (noise_p, _rel(p0, p2))
+    noise_mv = max(_rel(mv0[0], mv1[0]), _rel(mv0[0], mv3[0]), _rel(mv1[0], mv3[0]))
+    assert _rel(mv0[0], mv2[0]) <= max(6 * noise_mv, 1e-3 if dtype == torch.float32 else 5e-2)
 
 
 def test_replays_draw_fresh_dropout_masks_and_fresh_inputs():
@@ -255,9 +261,12 @@ def _forced_ddp_graph_case():
             return torch.stack(out).cpu(), model.store.P.clone()
         s0, p0 = run(False)
         s1, p1 = run(False)
+        s3, p3 = run(False)
         s2, p2 = run(True)
-        assert (s0[:, 0] - s2[:, 0]).abs().max().item() <= max(4 * (s0[:, 0] - s1[:, 0]).abs().max().item(), 5e-2)
-        assert _rel(p0, p2) <= max(4 * _rel(p0, p1), 1e-4)
+        # (three eager runs, largest pairwise distance, factor 6: see test_replayed_steps_equal_eager_steps)
+        noise_l = max((a[:, 0] - b[:, 0]).abs().max().item() for a, b in ((s0, s1), (s0, s3), (s1, s3)))
+        assert (s0[:, 0] - s2[:, 0]).abs().max().item() <= max(6 * noise_l, 5e-2), (noise_l, s0, s2)
+        assert _rel(p0, p2) <= max(6 * max(_rel(p0, p1), _rel(p0, p3), _rel(p1, p3)), 1e-4)
     finally:
         RT.comm = None
         RT.reducer = None
