@@ -140,7 +140,9 @@ typedef struct crog_gemm_desc {
                         global->LDS loads of the main loop, bit 1 skips the fragment reads + MFMAs (non-pipelined build only); bit 2
                         (results stay right) sends bf16 outputs through the LDS-staged epilogue instead of the direct pair stores, bit 3
                         the same for launches with a residual only; bit 5 (timing only, results wrong) skips the fp32 atomic adds of a
-                        split-K launch (scripts/ablate_wgrad.py) */
+                        split-K launch (scripts/ablate_wgrad.py); bits 6 / 7 / 8 (results stay right) choose the MFMA shape of that launch:
+                        6 = v_mfma_f32_16x16x32 on the 256 x 256 tile, 6 + 7 = also on lean 128 x 128 launches, 8 = 32x32x16 everywhere
+                        (tests/test_kernels_gpu.py, scripts/ab_mfma16.py; the default is CROG_MFMA16 / 2) */
   float* col_stats;  /* NULL, or [ceil(M/128)][N][2] fp32 partial (sum, sum of squares) over the
                         rows of each 128-row tile of v = alpha*acc + bias (BatchNorm statistics,
                         clip.py:18,21,26; layers.py:11).  batch must be 1, splitk 1. */
