@@ -10,6 +10,10 @@ shutil.copy(sf, os.path.join(out, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(sf)))
 probes_ns = sum(float(r["TotalDurationNs"]) for r in rows if "probe_kernel" in r["Name"])
 rows = [r for r in rows if "probe_kernel" not in r["Name"]]      # bench.py's peak probes run once per process: not part of a step
+# the runtime's blit kernel: ~970 back-to-back host-to-device uploads of the parameters while the model is built (kernel trace: each one's
+# neighbours are other copyBuffer launches), none inside a step
+upload_ns = sum(float(r["TotalDurationNs"]) for r in rows if "rocclr_copyBuffer" in r["Name"])
+rows = [r for r in rows if "rocclr_copyBuffer" not in r["Name"]]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 def agg(d, counter):
     acc = collections.defaultdict(lambda: [0, 0.0])
@@ -25,7 +29,7 @@ NOTE = os.environ.get("PROFILE_NOTE", "")
 L = [f"# rocprofv3 summary — {tag}", ""] + ([NOTE, ""] if NOTE else []) + [
      f"Command: `{os.environ.get('PROFILE_ENV', '')}rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline` (CROG-R50 bf16, B=32, 416x416, 1x MI355X; {steps} steps executed: warm-ups, the eager steps before the capture, the replays).",
      f"PMC passes (separate runs): `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction, MI355X_MICROARCH.md §HBM).", "",
-     f"Total kernel time: {tot/1e6/steps:.2f} ms per step ({steps} steps profiled; the peak probes of bench.py, {probes_ns/1e6:.1f} ms once per process, are left out).", "",
+     f"Total kernel time: {tot/1e6/steps:.2f} ms per step ({steps} steps profiled; the peak probes of bench.py, {probes_ns/1e6:.1f} ms once per process, are left out, and so are the {upload_ns/1e6:.1f} ms of `__amd_rocclr_copyBuffer` parameter uploads at model construction).", "",
      "| ms/step | % | launches/step | avg us | HBM MB/launch (PMC) | kernel |", "|---|---|---|---|---|---|"]
 for r in rows[:40]:
     k = r["Name"]
