@@ -10,8 +10,8 @@ shutil.copy(sf, os.path.join(out, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(sf)))
 probes_ns = sum(float(r["TotalDurationNs"]) for r in rows if "probe_kernel" in r["Name"])
 rows = [r for r in rows if "probe_kernel" not in r["Name"]]      # bench.py's peak probes run once per process: not part of a step
-# the runtime's blit kernel: ~970 back-to-back host-to-device uploads of the parameters while the model is built (kernel trace: each one's
-# neighbours are other copyBuffer launches), none inside a step
+# the runtime's blit kernel: ~950 back-to-back host-to-device uploads of the parameters while the model is built (kernel trace: each one's
+# neighbours are other copyBuffer launches; 967 launches with 7 executed steps, 987 with 17), 2 per step for the batch
 upload_ns = sum(float(r["TotalDurationNs"]) for r in rows if "rocclr_copyBuffer" in r["Name"])
 rows = [r for r in rows if "rocclr_copyBuffer" not in r["Name"]]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
