@@ -685,14 +685,15 @@ __global__ void __launch_bounds__(NT) ln_fwd_kernel(const T* __restrict__ x, lon
 }
 
 // LayerNorm backward.  g = dout (+ dout2);  dy = dropout_out_bwd(g);  dxin via LN backward;
-// dx = dropout_in_bwd(dxin).  Per-block partial (dgamma, dbeta) rows go to partial[block][C][2].
+// dx = dropout_in_bwd(dxin) (+ dxadd: the gradient of a residual branch that by-passes the norm, summed in fp32 here instead of by
+// an autograd accumulation pass).  Per-block partial (dgamma, dbeta) rows go to partial[block][C][2].
 template <typename T, int NV>
 __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, long lddo, const T* __restrict__ dout2, long lddo2,
                                                     const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                     const float* __restrict__ stats, long M, int C, T* __restrict__ dx, long lddx,
                                                     float* __restrict__ partial, int rows_per_block, float p_in, uint64_t seed_in,
                                                     float p_out, uint64_t seed_out, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                    const uint64_t* __restrict__ epoch) {
+                                                    const uint64_t* __restrict__ epoch, const T* __restrict__ dxadd, long lddxa) {
   constexpr int VEC = Elem<T>::VEC;
   if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -713,7 +714,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = min(r0 + rows_per_block, M);
   long row = r0 + wv;
-  Vec16<T> cg[NV], cg2[NV], cx[NV], ng[NP], ng2[NP], nx[NP];
+  Vec16<T> cg[NV], cg2[NV], cx[NV], ca[NV], ng[NP], ng2[NP], nx[NP], na[NP];
   if (PF && row < r1) {
 #pragma unroll
     for (int j = 0; j < NV; j++) {
@@ -722,6 +723,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
         cg[j] = ldg16(dout + row * lddo + cv * VEC);
         if (dout2) cg2[j] = ldg16(dout2 + row * lddo2 + cv * VEC);
         cx[j] = ldg16(x + row * ldx + cv * VEC);
+        if (dxadd) ca[j] = ldg16(dxadd + row * lddxa + cv * VEC);
       }
     }
   }
@@ -735,6 +737,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
           cg[j] = ldg16(dout + row * lddo + cv * VEC);
           if (dout2) cg2[j] = ldg16(dout2 + row * lddo2 + cv * VEC);
           cx[j] = ldg16(x + row * ldx + cv * VEC);
+          if (dxadd) ca[j] = ldg16(dxadd + row * lddxa + cv * VEC);
         }
       }
     }
@@ -746,6 +749,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
           ng[j % NP] = ldg16(dout + nrow * lddo + cv * VEC);
           if (dout2) ng2[j % NP] = ldg16(dout2 + nrow * lddo2 + cv * VEC);
           nx[j % NP] = ldg16(x + nrow * ldx + cv * VEC);
+          if (dxadd) na[j % NP] = ldg16(dxadd + nrow * lddxa + cv * VEC);
         }
       }
     }
@@ -803,6 +807,10 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
         if (p_in > 0.f) {
           dropout_apply<VEC>(d, seed_in, (uint64_t)row * C + c, thr_in, sc_in);
         }
+        if (dxadd) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) d[e] += Elem<T>::to_f(ca[j].v[e]);
+        }
 #pragma unroll
         for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(d[e]);
         stg16(dx + row * lddx + c, o);
@@ -810,7 +818,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
     }
     if (PF) {
 #pragma unroll
-      for (int j = 0; j < NV; j++) { cg[j] = ng[j % NP]; cg2[j] = ng2[j % NP]; cx[j] = nx[j % NP]; }
+      for (int j = 0; j < NV; j++) { cg[j] = ng[j % NP]; cg2[j] = ng2[j % NP]; cx[j] = nx[j % NP]; ca[j] = na[j % NP]; }
     }
   }
   // combine the block's 4 waves through LDS, then one plain store per value into this block's partial row — or, with dgamma / dbeta
@@ -1180,8 +1188,9 @@ extern "C" int crog_ln_bwd_blocks(int64_t M, int rows_per_block) { return cdiv(M
 extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void* dout2, int64_t lddo2, const void* x, int64_t ldx,
                            const float* gamma, const float* stats, int64_t M, int C, void* dx, int64_t lddx, float* partial,
                            int rows_per_block, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float* dgamma, float* dbeta,
-                           crog_stream_t stream) {
+                           const void* dxadd, int64_t lddxa, crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(!dxadd || (lddxa >= C && lddxa % vec == 0 && ((uintptr_t)dxadd % 16) == 0), "ln_bwd: dxadd rows must be 16-byte aligned (ld=%lld)", (long long)lddxa);
   CROG_CHECK_ARG(C % vec == 0 && C <= 2048, "ln_bwd: C=%d must be a multiple of %d and <= 2048", C, vec);
   CROG_CHECK_ARG((dgamma != nullptr) == (dbeta != nullptr) && (partial != nullptr) != (dgamma != nullptr),
                  "ln_bwd: give either the partial slab or both gradient vectors");
@@ -1190,7 +1199,8 @@ extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void
 #define CROG_LN_BWD(NV)                                                                                                           \
   DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dout, (long)lddo, \
                                        (const T*)dout2, (long)lddo2, (const T*)x, (long)ldx, gamma, stats, (long)M, C, (T*)dx,       \
-                                       (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out, dgamma, dbeta, crog_seed_epoch()))
+                                       (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out, dgamma, dbeta, crog_seed_epoch(),   \
+                                       (const T*)dxadd, (long)lddxa))
   if (nv <= 1) CROG_LN_BWD(1);
   else if (nv <= 2) CROG_LN_BWD(2);
   else if (nv <= 4) CROG_LN_BWD(4);

@@ -48,6 +48,7 @@ BN_ATOMIC_STATS = True           # BN statistics: atomic replicas in the GEMM ep
 RELU_BITMASK = True              # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
 LN_BWD_ATOMIC = False            # LayerNorm parameter gradients through atomics in ln_bwd itself: measured 0.5 % SLOWER (every block adds into the same 2 C floats)
 LN_REDUCE_SIDE = True            # LayerNorm parameter-gradient reduction on the weight-gradient stream
+LN_GRAD_SLOTS = True             # decoder: a residual's gradient is added inside the LayerNorm backward of the same tensor (GradSlot -> crog_ln_bwd dxadd)
 BN_BWD_ATOMIC = True             # backward partial sums through coalesced atomics (bf16)
 DGRAD_T = True                   # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
 LIN_DGRAD_T = True               # ... and the 1x1 / linear ones (round 3); tests compare with the transposed-read form
@@ -663,10 +664,13 @@ def quickgelu(u):
 # ------------------------------------------------------------------------------------------------
 class LayerNormFn(Function):
     """out = res + dropout_out(LN(dropout_in(x)));  out2 = out + pos (optional second output).
-    clip.py:226-231; layers.py:288-305,313-339."""
+    clip.py:226-231; layers.py:288-305,313-339.
+    GradSlots for the decoder's `vis -> norm(vis)` / `vis -> ... + vis` pairs (layers.py:313-338): the norm that consumes the identity
+    (`res_slot`) leaves the residual's gradient in the slot instead of returning it, and the norm applied to the same tensor
+    (`add_slot`, whose backward runs later: its output feeds the other one) adds it to its dx inside crog_ln_bwd."""
 
     @staticmethod
-    def forward(ctx, x, res, _gp, _bp, gamma: WRef, beta: WRef, eps, pos, p_in, p_out, want_out2):
+    def forward(ctx, x, res, _gp, _bp, gamma: WRef, beta: WRef, eps, pos, p_in, p_out, want_out2, res_slot=None, add_slot=None):
         ctx.set_materialize_grads(False)
         M, C, _ = K.mat(x)
         out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
@@ -677,6 +681,7 @@ class LayerNormFn(Function):
         K.ln_fwd(x, gamma.master(), beta.master(), eps, out, stats, res=res, out2=out2, pos=pos, p_in=p_in, seed_in=seed_in, p_out=p_out,
                  seed_out=seed_out)
         ctx.cfg = (gamma, beta, p_in, seed_in, p_out, seed_out, res is not None, want_out2)
+        ctx.slots = (res_slot, add_slot)
         ctx.save_for_backward(x, stats)
         if want_out2:
             return out, out2
@@ -687,12 +692,16 @@ class LayerNormFn(Function):
         gamma, beta, p_in, seed_in, p_out, seed_out, has_res, want_out2 = ctx.cfg
         x, stats = ctx.saved_tensors
         M, C, _ = K.mat(x)
+        res_slot, add_slot = ctx.slots
         if dout is None and dout2 is None:
-            return (None,) * 11
+            return (None,) * 13
         if dout is None:
             dout, dout2 = dout2, None
         dout = K.as_mat(dout)
         dout2 = K.as_mat(dout2) if dout2 is not None else None
+        dxadd = None
+        if add_slot is not None and add_slot.t is not None:
+            dxadd, add_slot.t = K.as_mat(add_slot.t), None
         dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
         rpb = K.ln_bwd_rows_per_block(M)
         nb = (M + rpb - 1) // rpb
@@ -700,10 +709,11 @@ class LayerNormFn(Function):
             # the blocks add their (dgamma, dbeta) sums straight into the gradient vectors: no slab, no reduction launch (85 launches
             # per CROG step).  fp32, the parity mode, keeps the ordered reduction (bit-reproducible run to run)
             K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, None, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out,
-                     dgamma=gamma.grad(), dbeta=beta.grad())
+                     dgamma=gamma.grad(), dbeta=beta.grad(), dxadd=dxadd)
         else:
             partial = torch.empty(nb, C, 2, device=x.device, dtype=torch.float32)
-            K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, partial, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out)
+            K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, partial, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out,
+                     dxadd=dxadd)
             # the parameter gradients are consumed by the optimizer only: their reduction leaves the dependency chain for the
             # weight-gradient stream (41 small launches per CROG step that sat between dependent kernels of the main stream)
             if LN_REDUCE_SIDE:
@@ -719,11 +729,13 @@ class LayerNormFn(Function):
             else:
                 dres = torch.empty(x.shape, device=x.device, dtype=x.dtype)
                 K.add_rows(dout, dout2, dres)
-        return dx, dres, None, None, None, None, None, None, None, None, None
+            if res_slot is not None:
+                res_slot.t, dres = dres, None
+        return (dx, dres) + (None,) * 11
 
 
-def layernorm(x, gamma: WRef, beta: WRef, *, eps=1e-5, res=None, pos=None, p_in=0.0, p_out=0.0, want_out2=False):
-    return LayerNormFn.apply(x, res, gamma.param, beta.param, gamma, beta, eps, pos, float(p_in), float(p_out), want_out2)
+def layernorm(x, gamma: WRef, beta: WRef, *, eps=1e-5, res=None, pos=None, p_in=0.0, p_out=0.0, want_out2=False, res_slot=None, add_slot=None):
+    return LayerNormFn.apply(x, res, gamma.param, beta.param, gamma, beta, eps, pos, float(p_in), float(p_out), want_out2, res_slot, add_slot)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1049,24 +1061,27 @@ class AddDropoutFn(Function):
     """out = a + dropout(b)   (layers.py:338 with p > 0)."""
 
     @staticmethod
-    def forward(ctx, a, b, p):
+    def forward(ctx, a, b, p, res_slot=None):
         out = torch.empty_like(b)
         seed = RT.next_seed() if p > 0 else 0
         K.add_dropout(a, b, out, p, seed)
-        ctx.cfg = (p, seed)
+        ctx.cfg = (p, seed, res_slot)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        p, seed = ctx.cfg
+        p, seed, res_slot = ctx.cfg
         dout = K.as_mat(dout)
         db = torch.empty_like(dout)
         K.add_dropout(None, dout, db, p, seed)
-        return dout, db, None
+        if res_slot is not None:      # `a`'s gradient rides the slot into the LayerNorm backward that also differentiates `a` (LayerNormFn)
+            res_slot.t = dout
+            return None, db, None, None
+        return dout, db, None, None
 
 
-def add_dropout(a, b, p):
-    return AddDropoutFn.apply(a, b, float(p))
+def add_dropout(a, b, p, res_slot=None):
+    return AddDropoutFn.apply(a, b, float(p), res_slot)
 
 
 # ------------------------------------------------------------------------------------------------

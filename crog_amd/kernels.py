@@ -308,12 +308,15 @@ def ln_bwd_rows_per_block(M: int) -> int:
     return max(8, (M + 1023) // 1024)
 
 
-def ln_bwd(dout, dout2, x, gamma, stats, dx, partial, rows_per_block, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0, dgamma=None, dbeta=None):
-    """partial: per-block slab for an ordered reduction (crog_reduce_split), or None with dgamma / dbeta: atomic adds into the gradients."""
+def ln_bwd(dout, dout2, x, gamma, stats, dx, partial, rows_per_block, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0, dgamma=None, dbeta=None,
+           dxadd=None):
+    """partial: per-block slab for an ordered reduction (crog_reduce_split), or None with dgamma / dbeta: atomic adds into the gradients.
+    dxadd: gradient of the residual branch around the norm, added to dx inside the kernel."""
     M, C, ldx = mat(x)
     check(lib().crog_ln_bwd(dcode(x), ptr(dout), mat(dout)[2], ptr(dout2), mat(dout2)[2] if dout2 is not None else 0, ptr(x), ldx,
                             ptr(gamma), ptr(stats), M, C, ptr(dx), mat(dx)[2], ptr(partial), rows_per_block, float(p_in),
-                            int(seed_in), float(p_out), int(seed_out), ptr(dgamma), ptr(dbeta), stream()), "ln_bwd")
+                            int(seed_in), float(p_out), int(seed_out), ptr(dgamma), ptr(dbeta), ptr(dxadd), mat(dxadd)[2] if dxadd is not None else 0,
+                            stream()), "ln_bwd")
 
 
 def softmax_fwd(S, rows, Lq, Lk, ldp, heads, causal, kpm, Pd, p_drop, seed):

@@ -133,17 +133,21 @@ class TransformerDecoderLayer(Bound):
     def forward(self, vis, txt, txt_k, vis_pos, pad_mask, B):
         p = self.p if self.training else 0.0
         tr = self.training
-        v2, qk = self.norm1(vis, pos=vis_pos, want_out2=True)
+        # each `vis` below has two consumers, a norm and the residual add after the sub-layer: the residual's gradient travels in a
+        # GradSlot to that norm's backward and is added there (crog_ln_bwd dxadd) instead of by an autograd accumulation pass
+        g = tr and torch.is_grad_enabled() and vis.requires_grad and Fn.LN_GRAD_SLOTS
+        s1, s2, s3 = (Fn.GradSlot(), Fn.GradSlot(), Fn.GradSlot()) if g else (None, None, None)
+        v2, qk = self.norm1(vis, pos=vis_pos, want_out2=True, add_slot=s1)
         a = self.self_attn(qk, qk, v2, B=B, training=tr)
-        vis = self.self_attn_norm(a, res=vis, p_out=p)
-        _, q = self.norm2(vis, pos=vis_pos, want_out2=True)
+        vis = self.self_attn_norm(a, res=vis, p_out=p, res_slot=s1)
+        _, q = self.norm2(vis, pos=vis_pos, want_out2=True, add_slot=s2)
         a = self.multihead_attn(q, txt_k, txt, B=B, kpm=pad_mask, training=tr)
-        vis = self.cross_attn_norm(a, res=vis, p_out=p)
-        v2 = self.norm3(vis)
+        vis = self.cross_attn_norm(a, res=vis, p_out=p, res_slot=s2)
+        v2 = self.norm3(vis, add_slot=s3 if p > 0 else None)
         h = Fn.linear(v2, self.ffn["0"].w, self.ffn["0"].b, act=K.ACT_RELU)
         h = self.ffn["3"](h, p_in=p)
         if p > 0:
-            return Fn.add_dropout(vis, Fn.linear(h, self.ffn["4"].w, self.ffn["4"].b), p)
+            return Fn.add_dropout(vis, Fn.linear(h, self.ffn["4"].w, self.ffn["4"].b), p, res_slot=s3)
         return Fn.linear(h, self.ffn["4"].w, self.ffn["4"].b, res=vis)
 
 

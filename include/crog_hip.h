@@ -251,11 +251,14 @@ int crog_ln_fwd(int dtype, const void* x, int64_t ldx, const float* gamma, const
 int crog_ln_bwd_blocks(int64_t M, int rows_per_block);
 /* dx from g = dout (+ dout2).  Parameter gradients, one of two forms: partial[block][C][2] = per-block (dgamma, dbeta) sums for an
  * ordered reduction by crog_reduce_split (dgamma = dbeta = NULL; the bit-reproducible fp32 parity mode), or partial = NULL and the
- * blocks ADD their sums atomically into the gradient vectors dgamma[C] / dbeta[C] (no reduction launch). */
+ * blocks ADD their sums atomically into the gradient vectors dgamma[C] / dbeta[C] (no reduction launch).
+ * dxadd (or NULL): the gradient of a residual branch that by-passes the norm (x -> LN(x) and x -> ... + x, clip.py:262-264,
+ * layers.py:313-338); it is added to dx in fp32 here, which replaces autograd's accumulation pass over the two gradients of x. */
 int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void* dout2, int64_t lddo2, const void* x,
                 int64_t ldx, const float* gamma, const float* stats, int64_t M, int C, void* dx,
                 int64_t lddx, float* partial, int rows_per_block, float p_in, uint64_t seed_in,
-                float p_out, uint64_t seed_out, float* dgamma, float* dbeta, crog_stream_t stream);
+                float p_out, uint64_t seed_out, float* dgamma, float* dbeta, const void* dxadd, int64_t lddxa,
+                crog_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Masked softmax over attention scores S[batch*heads*Lq][ldp] in place (the softmax inside

@@ -204,6 +204,48 @@ def test_decoder_return_intermediate_outputs():
     assert float(model.decoder.norm.bias.grad.sum()) == pytest.approx(3.0 * o2[0].numel(), rel=1e-4)     # 1 x (first use) + 2 x (second use), per element
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decoder_residual_gradients_ride_gradslots_into_the_layernorm_backward(dtype):
+    """layers.py:313-338: every `vis` of a decoder layer feeds a norm AND the residual add after the sub-layer.  With LN_GRAD_SLOTS the
+    residual's gradient is added inside crog_ln_bwd (dxadd) instead of by an autograd accumulation pass: same gradients (fp32: the same
+    fp32 sum; bf16: one rounding less), with dropout on (same seeds) and off."""
+    import crog_amd.functional as Fn
+    from crog_amd.model import build_crog
+    from crog_amd.runtime import RT
+    for p_drop in (0.0, 0.1):
+        cfg = tiny_cfg(num_layers=2, dropout=p_drop)
+        model, _ = build_crog(cfg)
+        model = model.cuda()
+        model.compute_dtype = dtype
+        model.prepare().train()
+        dec = model.decoder
+        torch.manual_seed(5)
+        fq0 = torch.randn(2, 6, 6, 512, device="cuda").to(dtype)
+        txt0 = torch.randn(2, 12, 512, device="cuda").to(dtype)
+        pad = torch.zeros(2, 12, dtype=torch.bool, device="cuda"); pad[:, 9:] = True
+        wgt = torch.randn(2, 6, 6, 512, device="cuda")
+        runs = {}
+        for slots in (True, False):
+            Fn.LN_GRAD_SLOTS = slots
+            try:
+                RT.manual_seed(1234)
+                model.store.zero_grad()
+                fq, txt = fq0.clone().requires_grad_(True), txt0.clone().requires_grad_(True)
+                out = dec(fq, txt, pad)
+                (out.float() * wgt).sum().backward()
+                torch.cuda.synchronize()
+                runs[slots] = (out.detach().float(), fq.grad.float().clone(), txt.grad.float().clone(), model.store.G.clone())
+            finally:
+                Fn.LN_GRAD_SLOTS = True
+        a, b = runs[True], runs[False]
+        assert torch.equal(a[0], b[0])
+        tol = 1e-5 if dtype == torch.float32 else 3e-2
+        for x, y, what in zip(a[1:], b[1:], ("d vis", "d txt", "parameter gradients")):
+            rel = float((x - y).norm() / y.norm().clamp_min(1e-12))
+            assert rel < tol, (what, p_drop, rel)
+        assert float(a[1].abs().max()) > 0
+
+
 def test_validate_with_grasp_is_a_callable_drop_in():
     """engine.validate_with_grasp (crog_engine.py:125-285): same arguments and return triple.  The device half (eval forward, sigmoid,
     bicubic align_corners resize) is checked against ATen on the model's own eval logits; the host half is injected (this image has no

@@ -389,6 +389,14 @@ def test_layernorm(K, dt, C):
     K.ln_bwd(d1, d2, x, g, stats, dx2, None, rpb, dgamma=dg, dbeta=db)
     assert torch.equal(dx2, dx)
     assert torch.allclose(dg - 0.5, sums[:, 0], rtol=1e-4, atol=1e-3) and torch.allclose(db + 0.25, sums[:, 1], rtol=1e-4, atol=1e-3)
+    # dxadd: the gradient of a residual branch around the norm is added to dx in fp32 inside the kernel (same parameter sums)
+    extra = rnd(M, C, dt=dt, seed=7)
+    dx3, partial3 = torch.empty_like(x), torch.empty_like(partial)
+    K.ln_bwd(d1, d2, x, g, stats, dx3, partial3, rpb, dxadd=extra)
+    assert torch.equal(partial3, partial)
+    close(dx3, xt.grad + extra.float(), dt, scale=4)
+    if dt == torch.float32:
+        assert torch.equal(dx3, dx + extra)          # fp32: bit-identical to the separate accumulation pass it replaces
 
 
 @pytest.mark.parametrize("dt", DT)
