@@ -22,7 +22,7 @@ CSRC = os.path.join(ROOT, "csrc")
 HEADER = os.path.join(REPO, "include", "crog_hip.h")
 LIB_PATH = os.environ.get("CROG_LIB") or os.path.join(ROOT, "libcrog_hip.so")
 BUILD_DIR = os.path.join(ROOT, "csrc", "build")
-SOURCES = ["api.hip", "gemm.hip", "norm.hip", "eltwise.hip", "head.hip", "conv_aux.hip", "attn.hip", "ssg.hip", "preprocess.hip", "replay.hip", "comm.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "norm.hip", "eltwise.hip", "head.hip", "conv_aux.hip", "attn.hip", "ssg.hip", "preprocess.hip", "replay.hip", "comm.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
 
 
@@ -86,7 +86,7 @@ def _needs_rebuild(obj: str, deps):
 def build(verbose: bool = False, force: bool = False) -> str:
     """Compile every HIP source for gfx950 and link crog_amd/libcrog_hip.so (in-tree)."""
     os.makedirs(BUILD_DIR, exist_ok=True)
-    common = [os.path.join(CSRC, "common.h"), HEADER]
+    common = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_dma.h"), HEADER]
     hipcc = os.environ.get("HIPCC", "hipcc")
 
     def compile_one(src):
@@ -140,7 +140,7 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
 
 def source_digest() -> str:
     h = hashlib.sha1()
-    for f in SOURCES + ["common.h"]:
+    for f in SOURCES + ["common.h", "gemm_dma.h"]:
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(HEADER, "rb").read())
     return h.hexdigest()[:12]

@@ -16,9 +16,14 @@
 //   are copied row-major into LDS as [BK][cols+pad] with full 16-byte coalesced loads and are
 //   transposed on the READ side: ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32.
 #include "common.h"
+#include "gemm_dma.h"
 #include <type_traits>
 #include <stdlib.h>
 #include <algorithm>
+
+// the ping-pong 256 x 256 x 64 kernel (gemm_pp.hip)
+bool crog_gemm_pp_eligible(const crog_gemm_desc& d, int rows);
+int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t s);
 
 namespace {
 
@@ -679,24 +684,7 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
 }
 
 
-// Workgroups are dealt to the 8 XCDs round-robin in launch order (linear id % 8), and every XCD has its own L2.
-//  * plain grid (tiles, batch*splitk): each XCD gets a contiguous run of output tiles, so neighbouring tiles share their
-//    A rows / B columns in one L2;
-//  * split-K grid (tiles*splitk, 1) (see splitk_by_xcd): the work items (reduction slice, tile), slice-major, are cut into 8
-//    contiguous runs, so an XCD runs all output tiles of a slice back to back and a slice of the two operands (the huge
-//    dimension of a weight-gradient GEMM) is fetched into one L2 (two at a run boundary) instead of all eight.
-__device__ inline void xcd_map(int nwg, int splitk, int& id, int& z) {
-  const int xcd = id & 7, loc = id >> 3;
-  const int total = (gridDim.y == 1 && splitk > 1) ? nwg * splitk : nwg;
-  const int q = total >> 3, rr = total & 7;
-  const int w = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-  if (total != nwg) {
-    z = w / nwg;
-    id = w - z * nwg;
-  } else {
-    id = w;
-  }
-}
+// (tile order across the 8 XCDs: xcd_map, gemm_dma.h)
 inline bool splitk_by_xcd(const crog_gemm_desc& d) { return d.batch == 1 && d.splitk > 1; }
 
 template <typename T, int AL, int BL, bool HWTR, typename S>
@@ -841,7 +829,6 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? (sizeof
 //   transposed tile    [BK rows][128 cols]: chunk ^= ((row&3)<<2)|((row>>2)&3) (bf16) -> ds_read_b64_tr_b16 conflict-free
 // Out-of-range rows/columns, conv padding and ragged K are an out-of-bounds buffer offset: the hardware writes zeros.
 // =================================================================================================
-constexpr unsigned DMA_OOB = 0x80000000u;
 // LDS ring depth (k-tiles in flight = depth - 1); tile edge = 32 * (waves per block): 128 (4 waves) or 256 (8 waves); one
 // operand tile = edge * 64 bytes.  128^2: 3 stages x 16 KiB, 3 blocks per CU (a 4-stage ring at 2 blocks per CU measured 10 %
 // slower: occupancy beats depth).  256^2: one 8-wave block per CU owns all 256 VGPRs per lane (128 of them accumulators), so
@@ -968,7 +955,6 @@ __device__ inline bf16x8 frag16_kc(const char* tile, int rbase, int lane) {
   const int row = rbase + (lane & 15), c = (lane >> 4) ^ kc_swz<1>(row);
   return *reinterpret_cast<const bf16x8*>(tile + row * 64 + c * 16);
 }
-__device__ inline void mma32(const bf16x8& a, const bf16x8& b, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 // Transposed operand: the tile is [BK reduction rows][128 columns] of memory (MODE as TrLoader: 0 dense, 1 dgrad weights, 2 wgrad im2col)
 // XOR applied to the 16-byte chunk index of a transposed bf16 tile row (the four reduction rows a ds_read_b64_tr_b16 group
@@ -1131,13 +1117,7 @@ template <typename T, int E, int NI> struct DmaBSel<T, CROG_B_NC_IM2COL, E, NI> 
 // the host pass rejects its second instantiation context ("substitution failure") while the device pass accepts it.
 // `live`: the tile exists (block-uniform); a request past the end of the reduction range is an out-of-bounds offset.
 // The buffer resources are rebuilt from the kernel-scope base pointers here, so they are provably wave-uniform (SGPRs).
-// One 1-KiB LDS-DMA request.  A plain (non-template) __device__ function: the AMDGCN builtins must not appear in the __global__ body
-// itself (the host pass then drops the kernel's stub without a diagnostic).
-__device__ __attribute__((always_inline)) inline void dma_piece(const void* base, int extent, char* dst, unsigned off) {
-  typedef __attribute__((address_space(3))) void lds_void;
-  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, extent, 0x00020000);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, off, 0, 0, 0);
-}
+// (one 1-KiB request: dma_piece, gemm_dma.h)
 #define CROG_DMA_ISSUE(KT, KMEM, STAGE, LIVE)                                                                          \
   do {                                                                                                                 \
     const int kt_ = (KT), km_ = (KMEM);                                                                                \
@@ -1149,11 +1129,6 @@ __device__ __attribute__((always_inline)) inline void dma_piece(const void* base
     da.advance(g); /* k-tiles are requested strictly in order, one call per tile */                                    \
     db.advance(g);                                                                                                     \
   } while (0)
-
-template <int N> __device__ inline void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // Wait until at most `behind` of this wave's most recently requested k-tiles (P DMA instructions each) are still in flight.
 // MAXB = the deepest value `behind` can take (ring depth - 1): deeper cases are not instantiated.
@@ -1759,6 +1734,25 @@ inline bool lean_epilogue_ok(const crog_gemm_desc& d) {
   return d.alpha == 1.f && !d.bias && d.act == CROG_ACT_NONE && !d.R && d.out_mode == CROG_OUT_T && d.dtype == CROG_BF16 && (d.N & 1) == 0;
 }
 
+// Which launches take the ping-pong kernel (gemm_pp.hip), and with which tile height: 0 = none, 256 or 192.  The tile height is the one
+// with the lower cost in (rounds of 256 one-per-CU blocks) x (rows per tile): 21632 x 512 is 170 tiles of 256 rows (one round at
+// 66 % of the CUs) but 226 tiles of 192 rows (one round, three quarters of the work per tile).  CROG_PP in the environment: 0 = never,
+// 1 = 3x3 launches from PP_MIN_TILES tiles, 2 (default) = also the 1x1 / linear forwards and data gradients.  Debug bits of a
+// descriptor (tests, scripts/ab_pp.py): 9 = force 256 rows, 10 = force 192 rows, 11 = never; bits 12-14 = DMA distance (3 .. 7, 0 = default).
+constexpr long PP_MIN_TILES = 150;
+inline int pp_rows(const crog_gemm_desc& d) {
+  static const int env = [] { const char* e = getenv("CROG_PP"); return e ? atoi(e) : 2; }();
+  if (d.debug & 2048) return 0;
+  if (d.debug & 512) return crog_gemm_pp_eligible(d, 256) ? 256 : 0;
+  if (d.debug & 1024) return crog_gemm_pp_eligible(d, 192) ? 192 : 0;
+  if (env <= 0 || !crog_gemm_pp_eligible(d, 256)) return 0;
+  if (d.a_layout != CROG_A_IM2COL && env < 2) return 0;
+  const long t256 = (long)cdiv(d.M, 256) * (d.N / 256), t192 = (long)cdiv(d.M, 192) * (d.N / 256);
+  if (t256 < PP_MIN_TILES) return 0;
+  const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
+  return (c192 * 11 < c256 * 10 && crog_gemm_pp_eligible(d, 192)) ? 192 : 256;      // (a 192-row tile runs ~10 % below the 256-row tile's rate per row)
+}
+
 template <typename T, bool HWTR>
 int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
   if (d.bwd_z) {      // BatchNorm-backward statistics: one dedicated tile, the three data-gradient layouts
@@ -1784,6 +1778,12 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     // training step -1.5 % (37.5 vs 38.2 ms, two interleaved A/B pairs); smaller launches lose to tile quantisation at one block per
     // CU and stay on 128 x 128.  (The same tile for 1x1 / linear forwards and data gradients, K = 128 ... 2048: no gain standalone -
     // their reductions are too short to amortise the 128 KiB ring's fill - and +0.4 ms in the step.)
+    if constexpr (sizeof(T) == 2) {
+      if (lean_epilogue_ok(d)) {
+        const int rows = pp_rows(d);
+        if (rows) return crog_gemm_pp_launch(d, rows, (d.debug >> 12) & 7, s);
+      }
+    }
     if constexpr (sizeof(T) == 2) {
       if (lean_epilogue_ok(d) && d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC && d.N % 256 == 0 && (long)cdiv(d.M, 256) * (d.N / 256) >= 160) {
         if (mf16_mode(d) >= 1) return launch_dma16<CROG_A_IM2COL, ShapeDma8>(d, s);

@@ -1,0 +1,47 @@
+// Helpers shared by the LDS-DMA GEMM kernels (gemm.hip, gemm_pp.hip): the buffer-addressed global -> LDS request, counted waits,
+// the XCD-aware tile order.  gfx950 only.
+#pragma once
+#include "common.h"
+
+namespace {
+
+// An out-of-bounds buffer offset: the request moves no bytes and the hardware writes zeros into LDS.
+constexpr unsigned DMA_OOB = 0x80000000u;
+
+// One 1-KiB LDS-DMA request (buffer_load_dwordx4 ... lds: wave-uniform LDS base + lane * 16, per-lane byte offset into the buffer).
+// A plain (non-template) __device__ function: the AMDGCN builtins must not appear in a __global__ body itself (the host pass then
+// drops the kernel's stub without a diagnostic).  The buffer resource is rebuilt from the (kernel-scope, wave-uniform) base pointer
+// and extent at the point of use, so that it is provably uniform and lives in SGPRs.
+__device__ __attribute__((always_inline)) inline void dma_piece(const void* base, int extent, char* dst, unsigned off) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, extent, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, off, 0, 0, 0);
+}
+
+template <int N> __device__ inline void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin in launch order (linear id % 8), and every XCD has its own L2.
+//  * plain grid (tiles, batch*splitk): each XCD gets a contiguous run of output tiles, so neighbouring tiles share their
+//    A rows / B columns in one L2;
+//  * split-K grid (tiles*splitk, 1): the work items (reduction slice, tile), slice-major, are cut into 8 contiguous runs, so an
+//    XCD runs all output tiles of a slice back to back and a slice of the two operands (the huge dimension of a weight-gradient
+//    GEMM) is fetched into one L2 (two at a run boundary) instead of all eight.
+__device__ inline void xcd_map(int nwg, int splitk, int& id, int& z) {
+  const int xcd = id & 7, loc = id >> 3;
+  const int total = (gridDim.y == 1 && splitk > 1) ? nwg * splitk : nwg;
+  const int q = total >> 3, rr = total & 7;
+  const int w = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  if (total != nwg) {
+    z = w / nwg;
+    id = w - z * nwg;
+  } else {
+    id = w;
+  }
+}
+
+__device__ inline void mma32(const bf16x8& a, const bf16x8& b, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+}  // namespace

@@ -151,6 +151,69 @@ def test_mfma_16x16x32_variant_equals_the_32x32x16_kernel(K, monkeypatch, case):
     assert _rel_l2(st[bits], st[256]) < 1e-5
 
 
+@pytest.mark.parametrize("case", [
+    # (B, HW, Cin, Cout, 3x3?, rows bit, distance bits)   bit 9: 256-row tile, bit 10: 192-row tile; bits 12-14: DMA distance
+    (40, 26, 64, 512, True, 512, 0),               # M = 27040: ragged last row tile, nine k-tiles (odd: one all-zero tile)
+    (40, 26, 64, 512, True, 1024, 0),              # the same on 192-row tiles (ragged too)
+    (8, 52, 128, 256, True, 512, 3 << 12),         # 18 k-tiles, distance 3
+    (8, 52, 128, 256, True, 1024, 6 << 12),        # 192 rows, distance 6
+    (3, 26, 192, 256, True, 512, 7 << 12),         # 27 k-tiles, M = 2028 (7.9 tiles), distance 7
+    (8, 52, 256, 512, False, 512, 0),              # 1x1 / linear form, K = 256
+    (8, 52, 320, 256, False, 1024, 0),             # K = 320: five k-tiles
+    (1, 9, 64, 256, True, 512, 0),                 # M = 81: a single, mostly empty tile
+])
+def test_ping_pong_256x256x64_kernel(K, monkeypatch, case):
+    """gemm_pp_kernel (csrc/gemm_pp.hip: two wave groups one barrier apart, 64-deep k-tiles in four half-tiles) against float64 and
+    against the gemm_dma16_kernel / 128 x 128 path (debug bit 11) on the same operands: outputs within bf16 rounding of the float64
+    result and no further from it than the reference kernel, BatchNorm column statistics (replica mode, and for the 256-row tile the
+    deterministic slab mode), nothing written outside the M x N block."""
+    B, HW, Cin, Cout, conv3, rows_bit, dist = case
+    dt = torch.bfloat16
+    M = B * HW * HW
+    Kd = 9 * Cin if conv3 else Cin
+    x = rnd(M, Cin, dt=dt)
+    w = (rnd(Cout, Kd, dt=dt, seed=1) * Kd ** -0.5).to(dt)
+    ld = Cout + 8
+    out, st = {}, {}
+    for flag in (2048, rows_bit | dist):
+        monkeypatch.setattr(K, "DEBUG_FLAGS", flag)
+        y = torch.full((M + 1, ld), 7.0, device="cuda", dtype=dt)
+        stats = torch.zeros(3, Cout, 2, device="cuda")
+        if conv3:
+            K.gemm(1, K.A_IM2COL, K.B_KC, x, w, y, M, Cout, Kd, Cin, Kd, ld, conv=(HW, HW, Cin), col_stats=stats, stat_replicas=3)
+        else:
+            K.gemm(1, K.A_KC, K.B_KC, x, w, y, M, Cout, Kd, Kd, Kd, ld, col_stats=stats, stat_replicas=3)
+        assert (y[M] == 7).all() and (y[:, Cout:] == 7).all(), "epilogue wrote outside the M x N block"
+        out[flag], st[flag] = y[:M, :Cout].clone(), stats.sum(0).double()
+    if conv3:
+        xi = x.double().view(B, HW, HW, Cin).permute(0, 3, 1, 2)
+        wi = w.double().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(xi, wi, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    else:
+        ref = x.double() @ w.double().t()
+    new, old = out[rows_bit | dist], out[2048]
+    close(new, ref.float(), dt, scale=1.0)
+    assert _rel_l2(new.double(), ref) <= 1.05 * _rel_l2(old.double(), ref) + 1e-6
+    for s_ in (st[2048], st[rows_bit | dist]):
+        assert _rel_l2(s_[:, 1], (ref ** 2).sum(0)) < 2e-3
+        assert float((s_[:, 0] - ref.sum(0)).abs().max()) < 2e-3 * math.sqrt(M)
+    assert _rel_l2(st[rows_bit | dist], st[2048]) < 1e-4
+    if rows_bit == 512:      # slab mode: one (sum, sum of squares) row per 128 matrix rows, plain stores
+        monkeypatch.setattr(K, "DEBUG_FLAGS", rows_bit | dist)
+        y = torch.empty(M, Cout, device="cuda", dtype=dt)
+        slab = torch.full((K.stat_tiles(M) + 1, Cout, 2), 3.0, device="cuda")
+        if conv3:
+            K.gemm(1, K.A_IM2COL, K.B_KC, x, w, y, M, Cout, Kd, Cin, Kd, Cout, conv=(HW, HW, Cin), col_stats=slab, stat_replicas=0)
+        else:
+            K.gemm(1, K.A_KC, K.B_KC, x, w, y, M, Cout, Kd, Kd, Kd, Cout, col_stats=slab, stat_replicas=0)
+        assert (slab[-1] == 3).all()
+        assert torch.equal(y, new)
+        assert _rel_l2(slab[:-1].sum(0).double(), st[rows_bit | dist]) < 1e-5
+        r0 = 128 * (K.stat_tiles(M) - 1)
+        assert _rel_l2(slab[-2, :, 1].double(), (ref[r0:] ** 2).sum(0)) < 2e-3
+    monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("shape", [(2, 13, 64, 72, 3, 64, True), (3, 10, 32, 40, 1, 32, True), (2, 9, 27, 64, 3, 32, False), (2, 12, 64, 64, 1, 64, False)])
 def test_eval_batchnorm_folded_into_the_convolution(K, dt, shape):
