@@ -24,6 +24,9 @@
 // the ping-pong 256 x 256 x 64 kernel (gemm_pp.hip)
 bool crog_gemm_pp_eligible(const crog_gemm_desc& d, int rows);
 int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t s);
+// the ping-pong weight-gradient kernel (gemm_ppt.hip)
+bool crog_gemm_ppt_eligible(const crog_gemm_desc& d);
+int crog_gemm_ppt_launch(const crog_gemm_desc& d, int dist, hipStream_t s);
 
 namespace {
 
@@ -715,7 +718,8 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? (sizeof
   const int zo = zb / p.batch_inner, zi = zb % p.batch_inner;
   const T* A = reinterpret_cast<const T*>(p.A) + zo * p.sAo + zi * p.sAi;
   const T* B = reinterpret_cast<const T*>(p.B) + zo * p.sBo + zi * p.sBi;
-  const int64_t coff = zo * p.sCo + zi * p.sCi;
+  // (split-K with plain fp32 stores: slice zs writes slab zs of a [splitk][M][ldc] workspace, crog_splitk_reduce sums them)
+  const int64_t coff = zo * p.sCo + zi * p.sCi + ((p.out_mode == CROG_OUT_F32 && p.splitk > 1) ? (int64_t)zs * p.M * p.ldc : 0);
 
   const int ktiles = (p.K + BK - 1) / BK;
   const int per = (ktiles + p.splitk - 1) / p.splitk;
@@ -1179,7 +1183,8 @@ gemm_dma_kernel(const crog_gemm_desc p) {   // (fp32 carries a second accumulato
   const int zo = zb / p.batch_inner, zi = zb % p.batch_inner;
   const T* A = reinterpret_cast<const T*>(p.A) + zo * p.sAo + zi * p.sAi;
   const T* B = reinterpret_cast<const T*>(p.B) + zo * p.sBo + zi * p.sBi;
-  const int64_t coff = zo * p.sCo + zi * p.sCi;
+  // (split-K with plain fp32 stores: slice zs writes slab zs of a [splitk][M][ldc] workspace, crog_splitk_reduce sums them)
+  const int64_t coff = zo * p.sCo + zi * p.sCi + ((p.out_mode == CROG_OUT_F32 && p.splitk > 1) ? (int64_t)zs * p.M * p.ldc : 0);
 
   const int ktiles = (p.K + BK - 1) / BK;
   const int per = (ktiles + p.splitk - 1) / p.splitk;
@@ -1707,12 +1712,24 @@ inline bool small_wgrad(int a_layout, int b_layout, int out_mode, long M, long N
 // whose four tiles need 21 splits).  Block targets of 80 / 96 / 112 help the neighbour more (617-629 TFLOP/s) and the step less,
 // 176-208 lose: 144.  (A first measurement of 31.8-32.2 ms for the 256 K variant was of a step whose text tower had gone NaN - an
 // unordered workspace, fixed - and NaN operands let the chip hold a higher clock: bench.py now refuses non-finite statistics.)
-constexpr long WGRAD256_BLOCKS = 144;
+static const long WGRAD256_BLOCKS = [] { const char* e = getenv("CROG_WGRAD_BLOCKS"); return e ? atol(e) : 144L; }();      // (the environment override is for scripts/ A-B runs)
 inline bool big_wgrad(int dtype, int a_layout, int b_layout, int out_mode, long M, long N, long K) {
   if (dtype != CROG_BF16 || out_mode != CROG_OUT_F32_ATOMIC || a_layout != CROG_A_MC) return false;
   if (M % 256 != 0 || N % 256 != 0 || K < 8192) return false;
   if (b_layout == CROG_B_NC_IM2COL) return M * N >= (1L << 19);
   return b_layout == CROG_B_NC && M * N >= (1L << 20);
+}
+
+// Which weight gradients take the ping-pong kernel (gemm_ppt.hip): the ones the 256 x 256 atomic tile took (big_wgrad), in either
+// output form (atomic adds, or split-K slabs for crog_splitk_reduce).  CROG_PPT = 0 in the environment keeps the previous kernel;
+// debug bit 15 of a descriptor forces the ping-pong kernel for any launch it can express (ragged tiles included), bit 16 forbids it.
+inline bool ppt_wanted(const crog_gemm_desc& d) {
+  static const int env = [] { const char* e = getenv("CROG_PPT"); return e ? atoi(e) : 1; }();
+  if ((d.debug & 65536) || d.a_layout != CROG_A_MC) return false;
+  if (d.debug & 32768) return crog_gemm_ppt_eligible(d);
+  if (env <= 0) return false;
+  const int om = d.out_mode == CROG_OUT_F32 ? CROG_OUT_F32_ATOMIC : d.out_mode;      // the slab form is sized like the atomic one
+  return big_wgrad(d.dtype, d.a_layout, d.b_layout, om, d.M, d.N, d.K) && crog_gemm_ppt_eligible(d);
 }
 
 // Which launches take the v_mfma_f32_16x16x32 kernel (gemm_dma16_kernel): 2 (default) = the 256 x 256 tile of the large 3x3 forward /
@@ -1789,6 +1806,9 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
         if (mf16_mode(d) >= 1) return launch_dma16<CROG_A_IM2COL, ShapeDma8>(d, s);
         return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, ShapeDma8>(d, s);
       }
+    }
+    if constexpr (sizeof(T) == 2) {
+      if (ppt_wanted(d)) return crog_gemm_ppt_launch(d, (d.debug >> 12) & 7, s);
     }
     if constexpr (sizeof(T) == 2) {
       if (big_wgrad(d.dtype, d.a_layout, d.b_layout, d.out_mode, d.M, d.N, d.K) && d.alpha == 1.f && !d.a_sum && !d.bias && !d.R && d.batch == 1) {
@@ -1895,8 +1915,9 @@ extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
                    "crog_gemm: C (dtype output) must be 16-byte aligned with ldc %% %d == 0", vec);
     if (d.R) CROG_CHECK_ARG(d.ldr % vec == 0 && ((uintptr_t)d.R % 16) == 0, "crog_gemm: R must be 16-byte aligned");
   }
-  CROG_CHECK_ARG(d.splitk == 1 || (d.out_mode == CROG_OUT_F32_ATOMIC && d.act == CROG_ACT_NONE && !d.R),
-                 "crog_gemm: splitk > 1 needs atomic fp32 output, no activation, no residual");
+  CROG_CHECK_ARG(d.splitk == 1 || ((d.out_mode == CROG_OUT_F32_ATOMIC || d.out_mode == CROG_OUT_F32) && d.act == CROG_ACT_NONE && !d.R),
+                 "crog_gemm: splitk > 1 needs fp32 output (atomic adds, or plain stores into [splitk][M][ldc] slabs), no activation, no residual");
+  CROG_CHECK_ARG(!(d.splitk > 1 && d.out_mode == CROG_OUT_F32) || d.batch == 1, "crog_gemm: split-K slabs need batch == 1");
   CROG_CHECK_ARG(!d.R || d.batch == 1, "crog_gemm: residual only for unbatched GEMM");
   CROG_CHECK_ARG(!d.col_stats || (d.batch == 1 && d.splitk == 1), "crog_gemm: col_stats needs batch == 1 and splitk == 1");
   if (d.bwd_z)

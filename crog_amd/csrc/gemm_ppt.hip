@@ -1,0 +1,330 @@
+// Ping-pong LDS-DMA kernel for WEIGHT GRADIENTS (gfx950): C[M][N] (+)= sum_k A[k][m] * B[k][n] with both operands stored with
+// the reduction index (the pixel / token) as the SLOW memory index — A = dy [K][M], B = x [K][N] (1x1 / linear) or the 3x3 im2col
+// view of an NHWC map (n = tap * C + c reads x[k shifted by the tap][c]).  256 x 256 output tile, 64-deep k-tiles, split-K over
+// the grid.  The schedule is gemm_pp.hip's (two wave groups one barrier apart; four 16-KiB half-tiles per k-tile; LOAD / MFMA
+// phases; the same RAW / WAR argument), what differs is the operand image:
+//   * a half-tile is [64 reduction rows][128 columns] (256-byte rows, contiguous in memory): A-h0 / A-h1 = tile columns 0-127 /
+//     128-255 of dy, B-h0 / B-h1 likewise of x.  Wave (wr, wc) owns output rows {64 wr .. +63} of EACH A half and output columns
+//     {32 wc .. +31} of EACH B half, so the phase order (A-h0 x B-h0, A-h0 x B-h1, A-h1 x B-h1, A-h1 x B-h0) and the staggered
+//     deadlines of the half-tiles are the forward kernel's.
+//   * fragments are read TRANSPOSED out of LDS: ds_read_b64_tr_b16 delivers a 4 (k) x 16 (column) block column-major, two reads per
+//     16x16x32 fragment (k = 8 g .. 8 g + 3 and + 4 .. + 7 of lane group g).  The 16-byte chunk index of a row is XOR-swizzled by
+//     ((row & 3) << 2) | ((row >> 2) & 3) on the DMA source address and again on the read (cdna_hip_programming.md T10, image (b)):
+//     conflict-free for two lane groups 8 rows apart in the same columns, which is what a 32-lane half of this read is.
+//   * 3x3 form: a lane's chunk has a fixed (tap, channel); the pixel of its row advances by 64 per k-tile — image coordinates are
+//     kept incrementally (two adds, two selects) and the tap's validity is four compares per request.
+// Output: fp32 atomic adds (out_mode CROG_OUT_F32_ATOMIC), or — CROG_OUT_F32 with splitk > 1 — plain stores of the block's partial
+// tile into slab z of a [splitk][M][ldc] workspace that crog_splitk_reduce then sums in slice order (bit-reproducible).
+#include "gemm_dma.h"
+#include <algorithm>
+#include <type_traits>
+
+namespace {
+
+__device__ __attribute__((always_inline)) inline bf16x8 tr_frag(const char* lo, const char* hi) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)lo);
+  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)hi);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// BL: CROG_B_NC (dense) or CROG_B_NC_IM2COL; SLAB: plain stores into the split's slab instead of atomic adds; D: DMA distance
+template <int BL, bool SLAB, int D>
+__global__ void __launch_bounds__(512, 2) gemm_ppt_kernel(const crog_gemm_desc p) {
+  static_assert(BL == CROG_B_NC || BL == CROG_B_NC_IM2COL, "transposed B operands");
+  static_assert(D >= 3 && D <= 7, "DMA distance in half-tiles");
+  constexpr int BM = 256, BN = 256, BK = 64, RBQ = 4, RB = 8, CB = 4;
+  constexpr int SLOT = 16384;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
+  const int nwg = tilesM * tilesN;
+  int id = blockIdx.x, z = 0;
+  xcd_map(nwg, p.splitk, id, z);          // (reduction slice, tile) runs per XCD: an operand slice lands in one L2
+  const int tm = id / tilesN, tn = id - tm * tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const bf16* A = reinterpret_cast<const bf16*>(p.A);
+  const bf16* B = reinterpret_cast<const bf16*>(p.B);
+  const int H = p.convH, W = p.convW, Cc = p.convC;
+
+  const int ktiles = (p.K + BK - 1) / BK;
+  const int per = (ktiles + p.splitk - 1) / p.splitk;
+  const int kt0 = z * per;
+  const int nt = min(per, ktiles - kt0);          // may be <= 0 for a trailing slice: it then only writes zeros (slab) / nothing
+  const int nt2 = (max(nt, 0) + 1) & ~1;
+  const int kbase = kt0 * BK;
+
+  // ---- DMA side: lane l of piece i of wave w fills slot row 8 w + 4 i + (l >> 4), chunk l & 15 from source chunk (l & 15) ^ swz(row)
+  const unsigned ldab = (unsigned)(p.lda * 2), ldbb = (unsigned)(p.ldb * 2);
+  unsigned abase[2], bbase[2];
+  unsigned avalid = 0, bvalid = 0;      // bit 2 i + h: the lane's 8 columns of request (i, h) exist
+  unsigned tapdd = 0;                   // 3x3: (dy + 1) | (dx + 1) << 2 of the tap of request (i, h), at bits 8 i + 4 h
+  int btap[2][2];                       // 3x3: byte offset of the request's (tap shift, channel)
+  int px[2], py[2];                     // 3x3: image coordinates of the lane's two rows in the k-tile the next B request belongs to
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int row = 8 * wave + 4 * i + (lane >> 4);
+    const int sc = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    abase[i] = (unsigned)(kbase + row) * ldab + (unsigned)((m0 + 8 * sc) * 2);
+    px[i] = py[i] = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (m0 + 128 * h + 8 * sc < p.M) avalid |= 1u << (2 * i + h);
+      const int ncol = n0 + 128 * h + 8 * sc;
+      if (ncol < p.N) bvalid |= 1u << (2 * i + h);
+      btap[i][h] = 0;
+      if constexpr (BL == CROG_B_NC_IM2COL) {
+        const int tap = min(ncol / Cc, 8), c = ncol - tap * Cc;
+        const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+        btap[i][h] = (dy * W + dx) * (int)ldbb + c * 2;
+        tapdd |= (unsigned)((dy + 1) | ((dx + 1) << 2)) << (8 * i + 4 * h);
+      }
+    }
+    if constexpr (BL == CROG_B_NC_IM2COL) {
+      bbase[i] = (unsigned)(kbase + row) * ldbb;
+      px[i] = (kbase + row) % W;
+      py[i] = ((kbase + row) / W) % H;
+    } else {
+      bbase[i] = (unsigned)(kbase + row) * ldbb + (unsigned)((n0 + 8 * sc) * 2);
+    }
+  }
+  const int stepx = BL == CROG_B_NC_IM2COL ? BK % W : 0, stepy = BL == CROG_B_NC_IM2COL ? (BK / W) % H : 0;
+  const int exa = (int)(((long)(p.K - 1) * p.lda + p.M) * 2);
+  const int exb = (int)(((long)(p.K - 1) * p.ldb + (BL == CROG_B_NC_IM2COL ? Cc : p.N)) * 2);
+
+  // ---- fragment side: lane (i = lane & 15: q = i >> 2, pp = i & 3; g = lane >> 4) addresses row 8 g + q (+ 4 for the second read),
+  // columns 4 pp .. 4 pp + 3 of the block
+  const int c16 = lane & 15, gq = lane >> 4, q4 = c16 >> 2, pp = c16 & 3;
+  unsigned aad[2][RBQ], bad[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const unsigned rowb = (unsigned)((8 * gq + q4 + 4 * s) * 256), sw = (unsigned)((q4 << 2) | ((2 * gq + s) & 3));
+#pragma unroll
+    for (int r = 0; r < RBQ; r++) aad[s][r] = rowb + ((((unsigned)(8 * wr + 2 * r + (pp >> 1))) ^ sw) << 4) + (unsigned)((pp & 1) * 8);
+#pragma unroll
+    for (int c = 0; c < 2; c++) bad[s][c] = rowb + ((((unsigned)(4 * wc + 2 * c + (pp >> 1))) ^ sw) << 4) + (unsigned)((pp & 1) * 8);
+  }
+
+  f32x4 acc[RB][CB];
+#pragma unroll
+  for (int i = 0; i < RB; i++)
+#pragma unroll
+    for (int j = 0; j < CB; j++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc[i][j][e] = 0.f;
+
+  // the two requests of half-tile type J (0: A-h0, 1: B-h0, 2: B-h1, 3: A-h1) of k-tile TI into buffer BUF.  k-tiles are requested
+  // strictly in order, so the 3x3 form advances its image coordinates after the B-h1 request of every k-tile.
+#define PT_ISSUE(J, BUF, TI)                                                                                           \
+  do {                                                                                                                 \
+    const int ti_ = (TI);                                                                                              \
+    const bool lv_ = ti_ < nt;                                                                                         \
+    char* dst_ = smem + ((BUF) * 4 + (J)) * SLOT + wave * 2048;                                                        \
+    if constexpr ((J) == 0 || (J) == 3) {                                                                              \
+      constexpr int h_ = (J) == 3 ? 1 : 0;                                                                             \
+      const unsigned kk_ = (unsigned)(ti_ * BK) * ldab + (h_ ? 256u : 0u);                                             \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                                               \
+        const bool ok_ = lv_ & (((avalid >> (2 * i_ + h_)) & 1u) != 0);                                                \
+        dma_piece(A, exa, dst_ + i_ * 1024, ok_ ? abase[i_] + kk_ : DMA_OOB);                                          \
+      }                                                                                                                \
+    } else {                                                                                                           \
+      constexpr int h_ = (J) == 2 ? 1 : 0;                                                                             \
+      const unsigned kk_ = (unsigned)(ti_ * BK) * ldbb;                                                                \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                                               \
+        bool ok_ = lv_ & (((bvalid >> (2 * i_ + h_)) & 1u) != 0);                                                      \
+        unsigned off_;                                                                                                 \
+        if constexpr (BL == CROG_B_NC_IM2COL) {                                                                        \
+          const int dd_ = (int)((tapdd >> (8 * i_ + 4 * h_)) & 15u);                                                   \
+          const int sy_ = py[i_] + (dd_ & 3) - 1, sx_ = px[i_] + (dd_ >> 2) - 1;                                        \
+          const int kr_ = kbase + ti_ * BK + 8 * wave + 4 * i_ + (lane >> 4);                                          \
+          ok_ = ok_ & ((unsigned)sy_ < (unsigned)H) & ((unsigned)sx_ < (unsigned)W) & (kr_ < p.K);                      \
+          off_ = bbase[i_] + kk_ + (unsigned)btap[i_][h_];                                                             \
+        } else {                                                                                                       \
+          off_ = bbase[i_] + kk_ + (h_ ? 256u : 0u);                                                                   \
+        }                                                                                                              \
+        dma_piece(B, exb, dst_ + i_ * 1024, ok_ ? off_ : DMA_OOB);                                                     \
+      }                                                                                                                \
+      if constexpr (BL == CROG_B_NC_IM2COL && (J) == 2) {                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                                             \
+          int x_ = px[i_] + stepx, y_ = py[i_] + stepy;                                                                \
+          const bool wrap_ = x_ >= W;                                                                                  \
+          x_ = wrap_ ? x_ - W : x_;                                                                                    \
+          y_ = wrap_ ? y_ + 1 : y_;                                                                                    \
+          y_ = y_ >= H ? y_ - H : y_;                                                                                  \
+          px[i_] = x_;                                                                                                 \
+          py[i_] = y_;                                                                                                 \
+        }                                                                                                              \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+
+#define PT_PROLOGUE_ONE(M_)                                                                                            \
+  if constexpr ((M_) < D) PT_ISSUE((M_) & 3, ((M_) >> 2) & 1, (M_) >> 2)
+  PT_PROLOGUE_ONE(0); PT_PROLOGUE_ONE(1); PT_PROLOGUE_ONE(2); PT_PROLOGUE_ONE(3);
+  PT_PROLOGUE_ONE(4); PT_PROLOGUE_ONE(5); PT_PROLOGUE_ONE(6);
+#undef PT_PROLOGUE_ONE
+  wait_vmcnt<2 * (D - 2)>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();      // the second group runs one barrier behind the first
+
+  bf16x8 fa[RBQ][2], fb0[2][2], fb1[2][2];
+#define PT_READ_A(SLOTIDX)                                                                                             \
+  _Pragma("unroll") for (int r_ = 0; r_ < RBQ; r_++)                                                                   \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++)                                                                \
+      fa[r_][ks_] = tr_frag(smem + (SLOTIDX) * SLOT + ks_ * 8192 + aad[0][r_], smem + (SLOTIDX) * SLOT + ks_ * 8192 + aad[1][r_])
+#define PT_READ_B(DST, SLOTIDX)                                                                                        \
+  _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++)                                                                     \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++)                                                                \
+      DST[c_][ks_] = tr_frag(smem + (SLOTIDX) * SLOT + ks_ * 8192 + bad[0][c_], smem + (SLOTIDX) * SLOT + ks_ * 8192 + bad[1][c_])
+#define PT_MFMA(FB, I0, J0)                                                                                            \
+  _Pragma("unroll") for (int r_ = 0; r_ < RBQ; r_++)                                                                   \
+    _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++)                                                                   \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) mma32(fa[r_][ks_], FB[c_][ks_], acc[(I0) + r_][(J0) + c_])
+#define PT_PHASE(P, BUF, T)                                                                                            \
+  do {                                                                                                                 \
+    if constexpr ((P) == 0) { PT_READ_A((BUF) * 4 + 0); PT_READ_B(fb0, (BUF) * 4 + 1); }                               \
+    if constexpr ((P) == 1) { PT_READ_B(fb1, (BUF) * 4 + 2); }                                                         \
+    if constexpr ((P) == 2) { PT_READ_A((BUF) * 4 + 3); }                                                              \
+    {                                                                                                                  \
+      constexpr int m_ = (P) + D, j_ = m_ & 3, dt_ = m_ >> 2, buf_ = ((BUF) + dt_) & 1;                                 \
+      PT_ISSUE(j_, buf_, (T) + dt_);                                                                                   \
+    }                                                                                                                  \
+    wait_vmcnt<2 * (D - 2)>();                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                     \
+    if constexpr ((P) == 0) { PT_MFMA(fb0, 0, 0); }                                                                    \
+    if constexpr ((P) == 1) { PT_MFMA(fb1, 0, 2); }                                                                    \
+    if constexpr ((P) == 2) { PT_MFMA(fb1, RBQ, 2); }                                                                  \
+    if constexpr ((P) == 3) { PT_MFMA(fb0, RBQ, 0); }                                                                  \
+    __builtin_amdgcn_s_setprio(0);                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  } while (0)
+
+  for (int t = 0; t < nt2; t += 2) {
+    PT_PHASE(0, 0, t); PT_PHASE(1, 0, t); PT_PHASE(2, 0, t); PT_PHASE(3, 0, t);
+    PT_PHASE(0, 1, t + 1); PT_PHASE(1, 1, t + 1); PT_PHASE(2, 1, t + 1); PT_PHASE(3, 1, t + 1);
+  }
+#undef PT_PHASE
+#undef PT_MFMA
+#undef PT_READ_A
+#undef PT_READ_B
+#undef PT_ISSUE
+  if (wr == 0) __builtin_amdgcn_s_barrier();      // equal barrier counts for both groups
+  wait_vmcnt<0>();
+
+  // ---- epilogue: acc[i][j][e] = C[m0 + 128 (i >> 2) + 64 wr + 16 (i & 3) + 4 g + e][n0 + 128 (j >> 1) + 32 wc + 16 (j & 1) + c]
+  float* Cf = reinterpret_cast<float*>(p.C) + (SLAB ? (int64_t)z * p.M * p.ldc : 0);
+  const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;
+  auto emit = [&](auto guarded) {
+    constexpr bool G = decltype(guarded)::value;
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+      const int mrow = m0 + 128 * (i >> 2) + 64 * wr + 16 * (i & 3) + 4 * gq;
+#pragma unroll
+      for (int j = 0; j < CB; j++) {
+        const int ncol = n0 + 128 * (j >> 1) + 32 * wc + 16 * (j & 1) + c16;
+        float* cb = Cf + (int64_t)mrow * p.ldc + ncol;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if (!G || (mrow + e < p.M && ncol < p.N)) {
+            if constexpr (SLAB) cb[(int64_t)e * p.ldc] = acc[i][j][e];
+            else atomicAdd(cb + (int64_t)e * p.ldc, acc[i][j][e]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (interior) emit(std::false_type{});
+  else emit(std::true_type{});
+}
+
+template <int BL, bool SLAB, int D>
+int launch_ppt(const crog_gemm_desc& d, hipStream_t s) {
+  constexpr int LDS = 8 * 16384;
+  static bool attr_set = false;
+  auto kern = gemm_ppt_kernel<BL, SLAB, D>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      crog_set_error("crog_gemm: hipFuncSetAttribute(%d bytes) failed: %s", LDS, hipGetErrorString(e));
+      return CROG_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(d.M, 256) * cdiv(d.N, 256) * d.splitk, 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(512), LDS, s, d);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
+
+// out[i] (+)= sum_z ws[z][i] over the slabs of a split-K launch, slice order (the same sum on every run)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, int64_t ldws, float* __restrict__ out,
+                                                            int64_t ldo, int accumulate) {
+  const int nv = N >> 2;
+  const int64_t total = (int64_t)M * nv, slab = (int64_t)M * ldws;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int m = (int)(idx / nv), v = (int)(idx - (int64_t)m * nv);
+    const float* src = ws + (int64_t)m * ldws + 4 * v;
+    f32x4 s = *reinterpret_cast<const f32x4*>(src);
+    for (int zz = 1; zz < splits; zz++) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src + zz * slab);
+      s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+    }
+    float* dst = out + (int64_t)m * ldo + 4 * v;
+    if (accumulate) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+      s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+    }
+    *reinterpret_cast<f32x4*>(dst) = s;
+  }
+}
+
+}  // namespace
+
+// Can the ping-pong weight-gradient kernel take this launch?  (the caller has checked dma_eligible)
+bool crog_gemm_ppt_eligible(const crog_gemm_desc& d) {
+  if (d.dtype != CROG_BF16 || d.a_layout != CROG_A_MC || d.batch != 1) return false;
+  if (d.b_layout != CROG_B_NC && d.b_layout != CROG_B_NC_IM2COL) return false;
+  if (d.out_mode != CROG_OUT_F32_ATOMIC && !(d.out_mode == CROG_OUT_F32 && d.splitk >= 1)) return false;
+  if (d.alpha != 1.f || d.bias || d.R || d.a_sum || d.act != CROG_ACT_NONE || d.col_stats) return false;
+  if (d.M % 8 != 0 || d.N % 8 != 0 || d.K < 128) return false;
+  if (d.b_layout == CROG_B_NC_IM2COL && (d.convC % 8 != 0 || d.N != 9 * d.convC)) return false;
+  if (d.out_mode == CROG_OUT_F32 && d.ldc % 4 != 0) return false;
+  if (((long)d.K + 64) * d.lda * 2 >= 0x7fffffffL || ((long)d.K + 64) * d.ldb * 2 >= 0x7fffffffL) return false;
+  return true;
+}
+
+int crog_gemm_ppt_launch(const crog_gemm_desc& d, int dist, hipStream_t s) {
+  if (dist == 0) dist = 5;      // scripts/ab_ppt.py: 5 is 4-7 % ahead of 3 / 4 / 6 on the large 3x3 forms, equal on the linear ones
+  const bool conv = d.b_layout == CROG_B_NC_IM2COL, slab = d.out_mode == CROG_OUT_F32;
+#define PT_CASE(DD)                                                                                                    \
+  if (dist == (DD)) {                                                                                                  \
+    if (conv) return slab ? launch_ppt<CROG_B_NC_IM2COL, true, DD>(d, s) : launch_ppt<CROG_B_NC_IM2COL, false, DD>(d, s); \
+    return slab ? launch_ppt<CROG_B_NC, true, DD>(d, s) : launch_ppt<CROG_B_NC, false, DD>(d, s);                       \
+  }
+  PT_CASE(3) PT_CASE(4) PT_CASE(5) PT_CASE(6) PT_CASE(7)
+#undef PT_CASE
+  crog_set_error("crog_gemm: no ping-pong weight-gradient instantiation for dist=%d", dist);
+  return CROG_ERR_ARG;
+}
+
+extern "C" int crog_splitk_reduce(const float* ws, int splits, int M, int N, int64_t ldws, float* out, int64_t ldo, int accumulate,
+                                  crog_stream_t stream) {
+  CROG_CHECK_ARG(ws && out && splits >= 1 && M > 0 && N > 0, "crog_splitk_reduce: bad arguments");
+  CROG_CHECK_ARG(N % 4 == 0 && ldws % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)ws % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                 "crog_splitk_reduce: N, ldws, ldo must be multiples of 4 and the buffers 16-byte aligned");
+  const int64_t total = (int64_t)M * (N / 4);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, splits, M, N, ldws, out, ldo, accumulate);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}

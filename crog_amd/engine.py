@@ -32,17 +32,24 @@ class AverageMeter:
         return ("{name} {val" + self.fmt + "} ({avg" + self.fmt + "})").format(**self.__dict__)
 
 
+# FusedAdam steps the chunks of the flat parameter buffer whose gradients are final INSIDE backward (optim.py: overlap_backward), when
+# the step has no gradient clipping (max_norm: 0 in config/OCID-VLG/crog_multiple_r50.yaml:35) and no live GradScaler.  CROG_ADAM_OVERLAP=0: off.
+ADAM_OVERLAP = os.environ.get("CROG_ADAM_OVERLAP", "1") != "0"
+
+
 def train_step(model, optimizer, scaler, batch, args=None, autocast_dtype=torch.bfloat16):
     """One optimisation step (crog_engine.py:60-90). `batch` holds device tensors img, word, mask, qua, sin, cos, wid with the
     masks already [B,1,H,W].  Returns a 3-element device tensor (loss, 100*IoU, 100*Prec@50), rank-averaged."""
     with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
         pred, target, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
     optimizer.zero_grad()
+    max_norm = getattr(args, "max_norm", 0.0) if args is not None else 0.0
     if scaler is not None and scaler.is_enabled():
         scaler.scale(loss).backward()
     else:
+        if ADAM_OVERLAP and not max_norm and hasattr(optimizer, "overlap_backward"):
+            optimizer.overlap_backward()      # nothing stands between backward and step: finished chunks are stepped inside backward
         loss.backward()
-    max_norm = getattr(args, "max_norm", 0.0) if args is not None else 0.0
     if max_norm:
         if scaler is not None and scaler.is_enabled():
             scaler.unscale_(optimizer)

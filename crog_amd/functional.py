@@ -116,6 +116,8 @@ class WRef:
             p.grad = st.gview[id(p)]
         if RT.reducer is not None:
             RT.reducer.mark_ready(p)
+        if RT.early_adam is not None:
+            RT.early_adam.mark_ready(p)
 
 
 # ------------------------------------------------------------------------------------------------

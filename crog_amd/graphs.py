@@ -154,8 +154,11 @@ class GraphedTrainStep:
         with torch.autocast("cuda", dtype=adt or torch.bfloat16, enabled=adt is not None):
             pred, target, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
         opt.zero_grad()
-        loss.backward()
         max_norm = getattr(self.args, "max_norm", 0.0) if self.args is not None else 0.0
+        from .engine import ADAM_OVERLAP
+        if ADAM_OVERLAP and not max_norm and hasattr(opt, "overlap_backward"):
+            opt.overlap_backward()
+        loss.backward()
         if max_norm:
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
         opt.step()
@@ -197,6 +200,9 @@ class GraphedTrainStep:
         if own and self.profile_key is not None:
             K.CAPTURE_NODES = dict(key=tuple(self.profile_key), nodes=[])
         host_step = getattr(self.optimizer, "_step", None)
+        # the learning rates reach the device state BEFORE the capture opens: a fill launched inside it would become a graph node that
+        # rewrites the capture-time rate on every replay, freezing any schedule (step() itself never syncs while capturing)
+        self.optimizer.sync_lr()
         try:
             RT._seed_ctr = self._seed0
             # with a process group alive, its watchdog thread polls events of earlier collectives while this thread captures: "relaxed"

@@ -194,6 +194,11 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
     check(lib().crog_gemm(ctypes.byref(d), stream()), "crog_gemm")
 
 
+def splitk_reduce(ws: torch.Tensor, splits: int, M: int, N: int, ldws: int, out: torch.Tensor, out_off: int, ldo: int, accumulate: bool = True):
+    """out[out_off + m * ldo + n] (+)= sum_z ws[z][m][n]: second stage of a split-K weight gradient written as slabs (OUT_F32, splitk > 1)."""
+    check(lib().crog_splitk_reduce(ptr(ws), splits, M, N, ldws, ptr(out) + 4 * out_off, ldo, int(accumulate), stream()), "splitk_reduce")
+
+
 def stat_tiles(M: int) -> int:
     return (M + 127) // 128
 

@@ -15,7 +15,20 @@ from . import kernels as K
 from .runtime import ALIGN, RT, ParamStore
 
 
+class _Chunk:
+    """A contiguous piece of one learning-rate segment of the flat buffer: the unit of the overlapped update."""
+    __slots__ = ("gi", "off", "numel", "params", "expect", "pending", "fired")
+
+    def __init__(self, gi, off):
+        self.gi, self.off, self.numel, self.params = gi, off, 0, []
+        self.expect = self.pending = 0
+        self.fired = False
+
+
 class FusedAdam(torch.optim.Optimizer):
+    # elements per chunk of the overlapped update (16 M floats = 64 MiB of parameters: ~0.1 ms of Adam, nine chunks for CROG-R50)
+    CHUNK_ELEMS = 1 << 24
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, store: ParamStore = None, capturable: bool = False):
         """capturable: the step count, its bias corrections and the learning rates live in device memory (one float[4] per
         parameter group, advanced by a one-thread kernel), so `step()` has no per-step scalar in a kernel argument and can be
@@ -29,6 +42,15 @@ class FusedAdam(torch.optim.Optimizer):
         self.capturable = capturable
         self._hyper = None          # [groups, 4] device floats {lr, 1 - beta1^t, sqrt(1 - beta2^t), t}
         self._hyper_lr = None       # the learning rates last written into it
+        # overlapped update (overlap_backward): chunks of the flat buffer are stepped inside backward, as their gradients become final
+        self._chunks = None         # list of _Chunk, built with the segments
+        self._chunk_of = {}         # id(param) -> chunk
+        self._done_counts = None    # id(param) -> gradient-ready announcements per backward, learnt from the first armed backward
+        self._recording = None
+        self._armed = False
+        self._ripe = []
+        self._advanced = set()      # groups whose device step state has been advanced for the step in flight
+        self.early_launches = 0     # Adam launches issued inside backward so far (tests, bench.py)
 
     def attach(self, store: ParamStore):
         self._store = store
@@ -61,6 +83,118 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     segs.append([o, n])
             self._segments.append(segs)
+        self._build_chunks()
+
+    def _build_chunks(self):
+        """Cut every segment at parameter boundaries into pieces of about CHUNK_ELEMS (the overlapped update's launch units)."""
+        store = self._store
+        self._chunks, self._chunk_of = [], {}
+        self._done_counts = None
+        for gi, group in enumerate(self.param_groups):
+            cur = None
+            for o, n, p in sorted((store.off(p), (p.numel() + ALIGN - 1) // ALIGN * ALIGN, p) for p in group["params"]):
+                if cur is None or cur.off + cur.numel != o or cur.numel + n > self.CHUNK_ELEMS:
+                    cur = _Chunk(gi, o)
+                    self._chunks.append(cur)
+                cur.numel += n
+                cur.params.append(p)
+                self._chunk_of[id(p)] = cur
+
+    # ---- overlapped update ------------------------------------------------------------------------------------------------
+    def overlap_backward(self):
+        """Arm the overlapped update for the backward pass that follows (engine.train_step calls this right after zero_grad, when
+        nothing stands between backward and step: no gradient clipping, no GradScaler, no gradient all-reduce).  While armed, every
+        WRef.done() is counted; a chunk whose announcements are complete is stepped on the weight-gradient stream one chunk LATER
+        (when the next chunk completes: by then every kernel of the first chunk's layers - also the data gradients that still read
+        its weights - has been enqueued, and the launch waits for all streams), the rest in step().  The announcement counts per
+        parameter are learnt from the first armed backward, which updates nothing early; a later backward that announces a
+        parameter MORE often than learnt (not a static step) raises in step()."""
+        if self._store is None or RT.reducer is not None or not self._store.explicit:
+            return
+        if any(g["weight_decay"] != 0 for g in self.param_groups):
+            return      # (weight decay skips parameters without a gradient, _decay_segments: known only once backward is over)
+        if self._segments is None:
+            self._build()
+        if self.capturable and not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        self._armed = True
+        self._ripe = []
+        self._advanced = set()
+        self._home = torch.cuda.current_stream() if torch.cuda.is_available() else None      # the stream forward ran on (the caller's)
+        RT.early_adam = self
+        if self._done_counts is None:
+            self._recording = {}
+            return
+        for c in self._chunks:
+            c.pending, c.fired = c.expect, False
+
+    def mark_ready(self, param):
+        """WRef.done(): one of the kernels that write this parameter's gradient has been enqueued."""
+        if not self._armed:
+            return
+        if self._recording is not None:
+            self._recording[id(param)] = self._recording.get(id(param), 0) + 1
+            return
+        c = self._chunk_of.get(id(param))
+        if c is None or c.expect == 0:
+            return
+        c.pending -= 1
+        if c.pending == 0:
+            for r in self._ripe:
+                self._launch_chunk(r, early=True)
+            self._ripe = [c]
+
+    def _launch_chunk(self, c, early: bool):
+        if c.fired:
+            return
+        c.fired = True
+        store, group = self._store, self.param_groups[c.gi]
+        b1, b2 = group["betas"]
+        side = RT.wgrad_stream() if early else None
+        if side is not None:
+            # gradients are written on every stream of the step (main chain: norm scales / biases; text tower: its own stream; weight
+            # gradients: `side` itself): the launch waits for all of them as they stand now.  The announcement that completed a chunk can
+            # come from a backward node running on ANY of these streams, so "the current stream" alone is not enough.
+            cur = torch.cuda.current_stream()
+            for s in {id(x): x for x in [cur, self._home] + list(RT.streams) if x is not None}.values():
+                if s != side:
+                    side.wait_stream(s)
+            K.set_stream_override(side.cuda_stream)
+        try:
+            if self.capturable:
+                hyper = self._hyper[c.gi]
+                if c.gi not in self._advanced:
+                    self._advanced.add(c.gi)
+                    K.adam_advance(hyper, b1, b2)
+                K.adam_step_dev(store.P, store.G, self.m, self.v, c.numel, hyper, b1, b2, group["eps"], group["weight_decay"],
+                                shadow=store.S, off=c.off)
+            else:
+                K.adam_step(store.P, store.G, self.m, self.v, c.numel, group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                            self._step + 1, shadow=store.S, off=c.off)
+        finally:
+            if side is not None:
+                K.set_stream_override(None)
+        if early:
+            self.early_launches += 1
+
+    def _finish_overlapped(self):
+        """step() of an armed backward: close the recording, or launch what backward left (the last ripe chunk, chunks of
+        parameters that were not announced) on the current stream."""
+        self._armed = False
+        RT.early_adam = None
+        store = self._store
+        if self._recording is not None:
+            counts, self._recording = self._recording, None
+            self._done_counts = counts
+            for c in self._chunks:
+                c.expect = sum(counts.get(id(p), 0) for p in c.params)
+            return False
+        over = [c for c in self._chunks if c.pending < 0]
+        if over:
+            raise RuntimeError("FusedAdam.overlap_backward: a parameter's gradient was announced more often than in the recorded step "
+                               "(gradient accumulation or a changing graph): parameters may have been updated before their gradient was "
+                               "complete.  Do not arm the overlapped update for such steps.")
+        return True
 
     def _decay_segments(self, group, segs):
         """torch.optim.Adam skips parameters whose gradient is None (CROG: `logit_scale`, never used by the forward): no decay,
@@ -129,10 +263,24 @@ class FusedAdam(torch.optim.Optimizer):
                                "after the optimizer was built): call optimizer.attach(model.store)")
         if self._segments is None:
             self._build()
-        if self.capturable:
-            self.sync_lr()        # (creates the device state from the host step count: before that count moves on)
-        self._step += 1
+        if self.capturable and not torch.cuda.is_current_stream_capturing():
+            # (creates the device state from the host step count: before that count moves on.  Never inside a capture: a fill launched
+            # there would be replayed with the capture-time learning rate every step - GraphedTrainStep syncs before capture / replay)
+            self.sync_lr()
         store = self._store
+        if self._armed and self._finish_overlapped():
+            # overlapped update: most chunks were stepped inside backward; the rest (and every chunk of a learning-rate group whose
+            # parameters never announce a gradient) go now, on the current stream, which has joined the side streams above
+            for c in self._chunks:
+                self._launch_chunk(c, early=False)
+            self._step += 1
+            if store.S is not None:
+                store.shadow_written()
+            else:
+                store.invalidate_shadow()
+            store.g_clean = False
+            return loss
+        self._step += 1
         shadow = store.S      # bf16 compute copy (None until a bf16 forward has run): refreshed by the same pass that updates P
         for gi, (group, segs) in enumerate(zip(self.param_groups, self._segments)):
             b1, b2 = group["betas"]

@@ -24,6 +24,7 @@ class Runtime:
     def __init__(self):
         self.comm = None       # object with .world_size and .all_reduce_sum(tensor) for SyncBatchNorm
         self.reducer = None    # gradient reducer (crog_amd.parallel); .mark_ready(param)
+        self.early_adam = None # FusedAdam with an armed overlapped update (optim.py: overlap_backward); .mark_ready(param)
         self.streams = []      # HIP streams the model's kernels run on (main + text-tower side stream + wgrad stream)
         self.overlap_wgrad = True     # weight gradients on a side stream (bench.py's CROG_SINGLE_STREAM profile mode switches it off)
         # A/B (round 3): weight gradients start after the layer's data gradient: "all" layers, or only the "big" ones whose data gradient

@@ -108,7 +108,9 @@ enum crog_act { CROG_ACT_NONE = 0, CROG_ACT_RELU = 1, CROG_ACT_QUICKGELU = 2, CR
                 CROG_ACT_RELU_POST = 4 /* relu(alpha*acc + bias + R): the ReLU AFTER the residual (eval-mode bn3 + identity of a Bottleneck, clip.py:55-56, with BatchNorm folded into the weights) */ };
 enum crog_out_mode {
   CROG_OUT_T = 0,         /* store as dtype                                                      */
-  CROG_OUT_F32 = 1,       /* store fp32                                                          */
+  CROG_OUT_F32 = 1,       /* store fp32; with splitk > 1: reduction slice z stores its partial result
+                             into slab z of a [splitk][M][ldc] fp32 workspace at C (no atomics: the sum
+                             over the slabs, crog_splitk_reduce, is bit-reproducible)            */
   CROG_OUT_F32_ATOMIC = 2 /* atomicAdd fp32 (required when splitk > 1; C must be pre-zeroed or
                              hold the value to accumulate onto)                                  */
 };
@@ -170,6 +172,12 @@ int crog_gemm_stat_tiles(int M);
 /* Split count for a weight-gradient GEMM (out_mode CROG_OUT_F32_ATOMIC) of logical size M x N over K, matched to the tile
  * shape crog_gemm selects for it (wgrad call sites: every conv / linear backward, e.g. clip.py:44-57, layers.py:298-301). */
 int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int M, int N, int K);
+/* out[m][n] (+)= sum over z < splits of ws[z][m][n]: the second stage of a split-K weight gradient launched with CROG_OUT_F32
+ * (slabs of M rows x ldws floats; out has row stride ldo; accumulate != 0 adds onto out, as gradient accumulation does).  The slabs are
+ * summed in slice order by one thread per four columns: the same bits on every run, unlike the atomic form (CROG_DETERMINISTIC,
+ * crog_engine.py:72-84 run twice gives the same loss curve).  N, ldws, ldo multiples of 4; ws and out 16-byte aligned. */
+int crog_splitk_reduce(const float* ws, int splits, int M, int N, int64_t ldws, float* out, int64_t ldo, int accumulate,
+                       crog_stream_t stream);
 /* Tile edge (64 / 128 / 256) crog_gemm takes for that weight gradient.  The 256 x 256 tile has an atomic-only epilogue: a launch that
  * also asks for a_sum stays on 128 x 128, so a caller that wants the wide tile sums the bias gradient with crog_colsum instead. */
 int crog_gemm_wgrad_tile(int dtype, int a_layout, int b_layout, int M, int N, int K);

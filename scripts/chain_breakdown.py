@@ -3,8 +3,9 @@ usage: chain_breakdown.py <kernel_trace.csv>"""
 import csv, collections, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in rows))
-ends = [i for i, e in enumerate(ev) if "adam_kernel" in e[3] and (i + 1 == len(ev) or "adam_kernel" not in ev[i + 1][3])]
-lo, hi = ends[-3] + 1, ends[-1] + 1          # one full step = two adam runs (two parameter groups)
+# one full step = from one stem_im2col launch (the first kernel of the image forward, once per step) to the next; the last complete one
+starts = [i for i, e in enumerate(ev) if "stem_im2col" in e[3]]
+lo, hi = starts[-2], starts[-1]
 seg = ev[lo:hi]
 t0 = seg[0][0]
 def short(n):
@@ -13,6 +14,10 @@ def short(n):
     if mm: return f"gemm A{mm.group(2)}B{mm.group(3)} {32*int(mm.group(4))*int(mm.group(6))}x{32*int(mm.group(5))*int(mm.group(7))}{' bwdz' if mm.group(9)=='1' else ''}{' atom' if mm.group(10)=='1' else ''}"
     mm = re.search(r'gemm_dma_kernel<.*?(\d), Shape<(\d), (\d), (\d), (\d), (\w+), \d, (\w+), (\w+)>', n)
     if mm: return f"gemm(?) {32*int(mm.group(2))*int(mm.group(4))}x{32*int(mm.group(3))*int(mm.group(5))}{' bwdz' if mm.group(7)=='true' else ''}{' atom' if mm.group(8)=='true' else ''}"
+    mm = re.search(r'gemm_pp_kernel(?:<|ILi)(\d)(?:, |ELi)(\d)', n)
+    if mm: return f"gemm_pp A{mm.group(1)} {64*int(mm.group(2))}x256"
+    mm = re.search(r'gemm_ppt_kernel(?:<|ILi)(\d)', n)
+    if mm: return f"gemm_ppt B{mm.group(1)} 256x256"
     m = re.search(r'_ZN12_GLOBAL__N_1\d+([a-z0-9_]+?)I', n)
     if m: return m.group(1)
     return n.split('(')[0].replace('void ', '')[:44]

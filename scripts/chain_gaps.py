@@ -4,8 +4,8 @@ import csv, sys, collections
 sys.path.insert(0, __file__.rsplit("/", 1)[0])
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in rows))
-ends = [i for i, e in enumerate(ev) if "adam_kernel" in e[3] and (i + 1 == len(ev) or "adam_kernel" not in ev[i + 1][3])]
-seg = ev[ends[-3] + 1:ends[-1] + 1]
+starts = [i for i, e in enumerate(ev) if "stem_im2col" in e[3]]      # once per step, the first kernel of the image forward
+seg = ev[starts[-2]:starts[-1]]
 t0 = seg[0][0]
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").replace("_ZN12_GLOBAL__N_1", "")[:46]
 for q in sorted({e[2] for e in seg}):

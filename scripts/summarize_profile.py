@@ -58,6 +58,12 @@ for k in f:   # one roofline key can cover several tile-shape instantiations of 
     m3 = re.search(r"gemm_dma16_kernel(?:<|ILi)(\d)", k)      # the 16x16x32 kernel: <AL, Shape>, B is K-contiguous
     if m3:
         lay = (int(m3.group(1)), 0)
+    m4 = re.search(r"gemm_pp_kernel(?:<|ILi)(\d)", k)        # the ping-pong kernel (gemm_pp.hip): <AL, RBQ, D>, B is K-contiguous
+    if m4:
+        lay = (int(m4.group(1)), 0)
+    m5 = re.search(r"gemm_ppt_kernel(?:<|ILi)(\d)", k)       # its weight-gradient form (gemm_ppt.hip): <BL, SLAB, D>, A is dy^T
+    if m5:
+        lay = (2, int(m5.group(1)))
     if lay in names and f[k][0]:
         key = names[lay]
         e = pm.setdefault(key, dict(kernels=[], launches=0, _bytes=0.0,

@@ -172,6 +172,58 @@ def test_gradients_accumulate_until_zero_grad():
     assert rel1 < 1e-4 and all(p.grad is not None for n, p in model.named_parameters() if n != "backbone.logit_scale")
 
 
+@pytest.mark.parametrize("capturable", [False, True])
+def test_adam_chunks_stepped_inside_backward_see_the_final_gradients(capturable, monkeypatch):
+    """FusedAdam.overlap_backward (crog_amd/optim.py; train_crog.py:119-121 + crog_engine.py:77-84 with max_norm 0): chunks of the
+    flat buffer are stepped on the weight-gradient stream while backward is still running.  After the step, G still holds the
+    gradients of that backward, so the update every parameter received can be recomputed from (P, m, v) before the step and G after
+    it: a chunk stepped before its gradient was complete would not match."""
+    from crog_amd.engine import train_step
+    from crog_amd.optim import FusedAdam
+    meta = _meta()
+    cfg = tiny_cfg()
+    model, groups = _build(cfg, meta)
+    monkeypatch.setattr(FusedAdam, "CHUNK_ELEMS", 1 << 13)          # many chunks on the tiny model
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    opt = FusedAdam(groups, lr=lr, betas=(b1, b2), eps=eps, store=model.store, capturable=capturable)
+    args = SimpleNamespace(max_norm=0.0)
+    b = {k: v.cuda() for k, v in synthetic_batch(4, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=31).items()}
+    st = model.store
+    for step in range(1, 5):
+        torch.cuda.synchronize()
+        P0 = st.P.clone()
+        m0 = opt.m.clone() if opt.m is not None else torch.zeros_like(P0)
+        v0 = opt.v.clone() if opt.v is not None else torch.zeros_like(P0)
+        launched = opt.early_launches
+        train_step(model, opt, None, b, args, autocast_dtype=None)
+        torch.cuda.synchronize()
+        G = st.G
+        m1 = b1 * m0 + (1 - b1) * G
+        v1 = b2 * v0 + (1 - b2) * G * G
+        want = P0 - lr / (1 - b1 ** step) * m1 / ((v1 / (1 - b2 ** step)).sqrt() + eps)
+        # the moments are linear / quadratic in the gradient the launch saw (tolerance relative to the two terms, not to their sum:
+        # b1 m0 and (1 - b1) G may cancel)
+        tol_m = 1e-5 * ((b1 * m0).abs() + ((1 - b1) * G).abs()) + 1e-12
+        bad = [n for n, p in model.named_parameters()
+               if bool(((opt.m - m1).abs() > tol_m)[st.off(p):st.off(p) + p.numel()].any())]
+        assert not bad, (step, bad[:8])
+        assert torch.allclose(opt.v.sqrt(), v1.sqrt(), rtol=1e-4, atol=1e-12), step
+        err = float(((st.P - want).abs() / (lr + want.abs() * 1e-5)).max())
+        assert err < 1e-3, (step, err)
+        if step == 1:
+            assert opt.early_launches == 0            # the first armed backward only records the announcement counts
+        else:
+            assert opt.early_launches - launched >= len(opt._chunks) // 2, (opt.early_launches - launched, len(opt._chunks))
+    # a second backward before the step (gradient accumulation) is not a static step: refused loudly, not silently wrong
+    opt.zero_grad()
+    opt.overlap_backward()
+    for _ in range(2):
+        _, _, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+        loss.backward()
+    with pytest.raises(RuntimeError, match="announced more often"):
+        opt.step()
+
+
 def test_decoder_return_intermediate_outputs():
     """layers.py:259-274: with return_intermediate the decoder returns the final-norm'd output of EVERY layer; the last entry is what
     the plain call returns.  CROG.forward fails on that list exactly as the reference does (crog.py:69)."""

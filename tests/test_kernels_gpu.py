@@ -214,6 +214,61 @@ def test_ping_pong_256x256x64_kernel(K, monkeypatch, case):
     monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
 
 
+@pytest.mark.parametrize("case", [
+    # (pixels as (B, H, W), Cin, Cout, 3x3?, splitk, DMA distance)
+    ((8, 26, 26), 256, 256, True, 3, 0),        # one M tile, nine N tiles; 84.5 k-tiles over 3 slices (ragged last k-tile)
+    ((8, 26, 26), 256, 512, True, 1, 5),        # no split
+    ((2, 52, 52), 64, 256, True, 2, 3),         # Cin = 64: a 128-column half-tile spans two taps; N = 576 (ragged column tile)
+    ((3, 13, 13), 512, 264, True, 2, 7),        # M = 264 (ragged row tile), H W = 169 < 2 k-tiles: several image wraps per k-tile
+    ((32, 26, 26), 512, 512, False, 4, 0),      # 1x1 / linear form
+    ((5, 26, 26), 2048, 264, False, 3, 6),      # linear, ragged M, eight column tiles
+    ((1, 20, 20), 320, 256, False, 7, 4),       # 6.25 k-tiles over 7 slices: the last slices are empty
+])
+def test_ping_pong_weight_gradient_kernel(K, monkeypatch, case):
+    """gemm_ppt_kernel (csrc/gemm_ppt.hip: transposed LDS reads, 64-deep k-tiles, split-K) against float64 and against the previous
+    weight-gradient kernels (debug bit 16) on the same operands, in both output forms: fp32 atomic adds onto a non-zero gradient, and
+    split-K slabs + crog_splitk_reduce, which must give the same bits on every run."""
+    (B, H, W), Cin, Cout, conv3, sk, dist = case
+    dt = torch.bfloat16
+    Mpix = B * H * W
+    N = 9 * Cin if conv3 else Cin
+    x = rnd(Mpix, Cin, dt=dt)
+    dy = (rnd(Mpix, Cout, dt=dt, seed=1) * 0.1).to(dt)
+    if conv3:
+        xi = x.double().view(B, H, W, Cin).permute(0, 3, 1, 2)
+        cols = torch.nn.functional.unfold(xi, 3, padding=1).view(B, Cin, 9, H * W).permute(0, 3, 2, 1).reshape(Mpix, 9 * Cin)
+        ref = dy.double().t() @ cols
+    else:
+        ref = dy.double().t() @ x.double()
+    ldc = N + 4
+    g0 = torch.randn(Cout + 1, ldc, device="cuda")
+    out = {}
+    for flag in (65536, 32768 | dist << 12):
+        monkeypatch.setattr(K, "DEBUG_FLAGS", flag)
+        g = g0.clone()
+        K.gemm(1, K.A_MC, K.B_NC_IM2COL if conv3 else K.B_NC, dy, x, g, Cout, N, Mpix, Cout, Cin, ldc, splitk=sk, out_mode=K.OUT_F32_ATOMIC,
+               conv=(H, W, Cin) if conv3 else (0, 0, 0))
+        assert torch.equal(g[Cout], g0[Cout]) and torch.equal(g[:, N:], g0[:, N:]), "epilogue wrote outside the M x N block"
+        out[flag] = (g[:Cout, :N] - g0[:Cout, :N]).double()
+    new, old = out[32768 | dist << 12], out[65536]
+    assert _rel_l2(new, ref) < 2e-5 and _rel_l2(new, ref) <= 1.5 * _rel_l2(old, ref) + 1e-6     # (fp32 adds onto O(1) values: 1e-7 relative each)
+    # slab form: [splitk][M][ldc] workspace, then the ordered reduction onto the gradient
+    monkeypatch.setattr(K, "DEBUG_FLAGS", 32768 | dist << 12)
+    res = []
+    for _ in range(2):
+        ws = torch.full((sk, Cout, ldc), float("nan"), device="cuda")
+        K.gemm(1, K.A_MC, K.B_NC_IM2COL if conv3 else K.B_NC, dy, x, ws, Cout, N, Mpix, Cout, Cin, ldc, splitk=sk, out_mode=K.OUT_F32,
+               conv=(H, W, Cin) if conv3 else (0, 0, 0))
+        assert not torch.isnan(ws[:, :, :N]).any() and torch.isnan(ws[:, :, N:]).all()
+        g = g0.clone()
+        K.splitk_reduce(ws, sk, Cout, N, ldc, g, 0, ldc, accumulate=True)
+        assert torch.equal(g[Cout], g0[Cout]) and torch.equal(g[:, N:], g0[:, N:])
+        res.append(g[:Cout, :N].clone())
+    assert torch.equal(res[0], res[1]), "the slab form must be bit-reproducible"
+    assert _rel_l2((res[0] - g0[:Cout, :N]).double(), ref) < 2e-5
+    monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("shape", [(2, 13, 64, 72, 3, 64, True), (3, 10, 32, 40, 1, 32, True), (2, 9, 27, 64, 3, 32, False), (2, 12, 64, 64, 1, 64, False)])
 def test_eval_batchnorm_folded_into_the_convolution(K, dt, shape):
