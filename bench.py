@@ -243,7 +243,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
-    ap.add_argument("--roofline-kernel", default="conv3x3_fwd", choices=["conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "lin_fwd", "none"])
+    ap.add_argument("--roofline-kernel", default="conv3x3_fwd", choices=["conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "lin_fwd", "lin_wgrad", "none"])
     ap.add_argument("--dry", action="store_true", help="launcher / rendezvous check only: gloo on CPU tensors, no model, no GPU")
     ap.add_argument("--eager", action="store_true", help="issue every step from Python instead of replaying the captured whole-step hipGraph")
     args = ap.parse_args()
@@ -314,17 +314,21 @@ def main():
     # Default: the step is captured once (ordinary stream capture) after 3 eager steps and then re-issued per step by ONE C call
     # (crog_amd/graphs.py, csrc/replay.hip: same kernels, arguments, streams and cross-stream edges as the eager step) instead of ~1300
     # launches through Python.  --eager (or CROG_STEP_GRAPH=0) issues every step from Python as rounds 1-2 did;
-    # CROG_STEP_GRAPH=hipgraph replays with hipGraphLaunch instead.  Multi-GPU runs stay eager unless CROG_STEP_GRAPH asks for replay:
-    # a captured RCCL collective has never run with real peers on this build.
+    # CROG_STEP_GRAPH=hipgraph replays with hipGraphLaunch instead.  Multi-GPU runs replay too when every collective of the step goes
+    # through the C-ABI communicators (crog_amd.parallel.step_is_capturable: RCCL / mailbox launches on captured streams, chosen by a
+    # start-up self-test); the first replay is then checked against an eager step from the same state (GraphedTrainStep verify=) and
+    # the run falls back to eager steps in the same process if it does not reproduce it.
     key = {"conv3x3_fwd": (K.A_IM2COL, K.B_KC), "conv3x3_dgrad": (K.A_IM2COL, K.B_NC_DGRAD), "conv3x3_wgrad": (K.A_MC, K.B_NC_IM2COL),
-           "lin_fwd": (K.A_KC, K.B_KC), "none": None}[args.roofline_kernel]
+           "lin_fwd": (K.A_KC, K.B_KC), "lin_wgrad": (K.A_MC, K.B_NC), "none": None}[args.roofline_kernel]
     graphed = None
-    # (also eager by default with CROG_FORCE_DDP: torch's process-group watchdog thread was seen to poll an event recorded inside the
-    # capture - hipErrorCapturedEvent, std::terminate - once in a few runs; tests/test_graph_step_gpu.py covers that combination in a child process)
-    want = os.environ.get("CROG_STEP_GRAPH", "1" if (world == 1 and not force_ddp) else "0")
+    # (torch's process-group watchdog thread was seen to poll an event recorded inside a capture - hipErrorCapturedEvent, std::terminate -
+    # once in a few runs when torch.distributed collectives were captured: with the C-ABI communicators no ProcessGroup work is in the step)
+    multi = world > 1 or force_ddp
+    from crog_amd.parallel import step_is_capturable
+    want = os.environ.get("CROG_STEP_GRAPH", "1" if (not multi or step_is_capturable(net)) else "0")
     if not args.eager and want != "0":
         from crog_amd.graphs import GraphedTrainStep
-        graphed = GraphedTrainStep(net, opt, cfg, adt, warmup=3, profile_key=key if rank == 0 else None)
+        graphed = GraphedTrainStep(net, opt, cfg, adt, warmup=3, profile_key=key if rank == 0 else None, verify=multi)
 
     def step(eager=False, profile=False):
         if graphed is not None:
@@ -387,6 +391,16 @@ def main():
             flops = [f for _, _, f, _ in recs]
         if recs:
             avg_d, avg_f = sum(durs) / len(durs), sum(flops) / len(flops)
+            # algorithmic bytes of the same launches: each operand and the output once (a 3x3 form reads its NHWC map once, not nine times)
+            def alg_bytes(meta):
+                al, bl, M, N, Kd, bt, sk = meta
+                esz = 2 if args.dtype == "bf16" else 4
+                a_el = M * Kd / (9 if al == K.A_IM2COL else 1)
+                b_el = N * Kd / (9 if bl == K.B_NC_IM2COL else 1)
+                out_b = M * N * (4 if al == K.A_MC else esz)
+                return bt * (esz * (a_el + b_el) + out_b)
+            metas = [r[2] for r in recs] if timers_in_replay else [r[3] for r in recs]
+            alg = sum(alg_bytes(m) for m in metas) / len(metas)
             # HBM bytes per launch of this kernel: NOT measured in this run (PMC counters need rocprofv3 around the process) but read from
             # the committed PMC passes of the same workload, and labelled as such - it goes stale when the kernels change and the
             # round's profile is not re-taken
@@ -400,6 +414,7 @@ def main():
                 pass
             roof = dict(bound="mfma", achieved=round(avg_f / avg_d / 1e12, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
                         frac=round(avg_f / avg_d / 1e12 / PEAK_MFMA_TF, 4), traffic=traffic, traffic_source=traffic_source,
+                        traffic_algorithmic=round(alg), traffic_ratio=(round(traffic / alg, 3) if traffic else None),
                         kernel=K.GEMM_SYMBOL[key], launches_per_step=len(recs) // max(sampled, 1), timed_steps_bracketed=sampled,
                         avg_launch_us=round(avg_d * 1e6, 1), avg_gflop_per_launch=round(avg_f / 1e9, 2),
                         share_of_step=round(sum(durs) / max(sampled, 1) / (dt / args.steps), 4))
@@ -407,8 +422,9 @@ def main():
             "metric": "training images/sec CROG-R50 416x416 bs32/GPU", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"CROG-R50 {args.dtype} training step (fwd+loss+bwd+allreduce+Adam+metric), {args.size}x{args.size} RGB + "
-                                   f"20 tokens, batch {args.batch}/GPU, dropout 0.1, SyncBN, random-init RN50 architecture",
+            "config": {"workload": f"CROG-R50 {args.dtype} training step (fwd+loss+bwd+{'gradient all-reduce+' if multi else ''}Adam+metric), "
+                                   f"{args.size}x{args.size} RGB + 20 tokens, batch {args.batch}/GPU, dropout 0.1, "
+                                   f"{'SyncBatchNorm, ' if multi else ''}random-init RN50 architecture",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "step_roofline": {"hbm_frac": round((BYTES_PER_IMG * args.batch + BYTES_PER_STEP_WEIGHTS) / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                               "mfma_frac": round(FLOP_PER_IMG * args.batch / (ms * 1e-3) / 1e12 / PEAK_MFMA_TF, 4),
@@ -425,8 +441,13 @@ def main():
             gb = per_step(net.reducer.launches, coll0[1])
             if replaying:      # the Python counters only move in eager steps: a replay re-issues what the capture recorded
                 sb, gb = graphed.collectives["syncbn"], graphed.collectives["buckets"]
+            if RT.comm is not None:
+                RT.comm.check()      # a timed-out mailbox exchange poisons the statistics: never report a throughput measured on it
             out["collectives_per_step"] = {"syncbn_allreduce": sb,
                                            "gradient_buckets": gb,
+                                           "syncbn_transport": RT.comm.kind if RT.comm is not None else None,
+                                           "bucket_transport": "crog_comm:rccl" if getattr(net, "bucket_comm", None) is not None else "torch.distributed",
+                                           "replay_verified": getattr(graphed, "verified", None),
                                            "note": "BatchNorm statistics on a communicator of their own (crog_amd/parallel.py); metric all-reduce not counted"}
         if world == 1:
             try:

@@ -104,6 +104,25 @@ extern "C" int crog_set_seed_epoch(const uint64_t* epoch_dev) {
   g_seed_epoch = epoch_dev;
   return CROG_OK;
 }
+// ---- deterministic mode (include/crog_hip.h: crog_set_deterministic): a process-wide launch state like the seed epoch.  The scratch
+// (per-block partial sums of the loss kernel) is allocated HERE, once, outside any capture: no launch ever allocates.
+static int g_deterministic = 0;
+static float* g_det_scratch = nullptr;
+bool crog_deterministic() { return g_deterministic != 0; }
+float* crog_det_scratch() { return g_det_scratch; }
+
+extern "C" int crog_set_deterministic(int on) {
+  if (on && !g_det_scratch) {
+    hipError_t e = hipMalloc((void**)&g_det_scratch, CROG_DET_SCRATCH_FLOATS * sizeof(float));
+    if (e != hipSuccess) {
+      crog_set_error("crog_set_deterministic: hipMalloc failed: %s", hipGetErrorString(e));
+      return CROG_ERR_LAUNCH;
+    }
+  }
+  g_deterministic = on ? 1 : 0;
+  return CROG_OK;
+}
+
 extern "C" int crog_counter_add(uint64_t* counter_dev, uint64_t inc, crog_stream_t stream) {
   CROG_CHECK_ARG(counter_dev != nullptr, "counter_add: null counter");
   hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter_dev, inc);

@@ -133,14 +133,22 @@ __device__ inline void st_sys(unsigned* p, unsigned v) { __hip_atomic_store(p, v
 __global__ void __launch_bounds__(256) peer_allreduce_kernel(float* __restrict__ x, int n, PeerPtrs peers, int rank, int world, int S, unsigned long long wait_ticks) {
   float* mine = peers.box[rank];
   unsigned* tail = reinterpret_cast<unsigned*>(mine + (size_t)2 * world * S + 2 * world);   // [seq, err]
-  __shared__ unsigned s_seq, s_bad;
+  __shared__ unsigned s_seq, s_bad, s_dead;
   if (threadIdx.x == 0) {
     s_seq = tail[0] + 1u;
     tail[0] = s_seq;
     s_bad = 0u;
+    s_dead = tail[1];
   }
   __syncthreads();
   const unsigned seq = s_seq;
+  if (s_dead) {
+    // an earlier exchange of this communicator timed out: its sequence numbers and slot parity are no longer aligned with the peers',
+    // so nothing it could deliver is trustworthy.  Poison the statistics (NaN reaches the loss within one layer; the engine polls
+    // crog_comm_status and raises) instead of exchanging
+    for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = __builtin_nanf("");
+    return;
+  }
   const int par = (int)(seq & 1u);
   // 1. my contribution into slot [par][rank] of EVERY mailbox (my own included: one code path, one summation order)
   for (int r = 0; r < world; r++) {
@@ -168,7 +176,11 @@ __global__ void __launch_bounds__(256) peer_allreduce_kernel(float* __restrict__
   }
   __syncthreads();
   if (s_bad) {
-    if (threadIdx.x == 0) tail[1] = seq;     // remembered for crog_comm_status; the data is left as it was
+    // A peer did not show up in time.  This rank has already published its data and flag, so the late peer may still complete with
+    // the correct sums while this rank cannot: returning the local sums would let the ranks diverge silently.  Make it loud: NaN
+    // statistics (the loss and bench.py's finite check trip on the same step) and the error word for crog_comm_status.
+    if (threadIdx.x == 0) tail[1] = seq;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = __builtin_nanf("");
     return;
   }
   __threadfence_system();
@@ -271,6 +283,7 @@ extern "C" int crog_comm_status(void* comm, int* timed_out_seq) {
 extern "C" int crog_syncbn_stats(void* comm, float* ptr, int64_t count, crog_stream_t stream) {
   CROG_CHECK_ARG(comm && ptr && count > 0, "syncbn_stats: null argument");
   auto* c = (Comm*)comm;
+  if (c->world == 1) return CROG_OK;      // a one-rank sum is the identity (as RCCL's own one-rank all-reduce): nothing to launch
   if (c->connected && count <= c->slot) {
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ptr, (int)count, c->peers, c->rank, c->world, c->slot, peer_wait_ticks());
     CROG_LAUNCH_CHECK();

@@ -36,6 +36,11 @@ void crog_set_error(const char* fmt, ...);
 // per-step dropout seed offset in device memory (crog_set_seed_epoch, api.hip); null when none is installed
 const uint64_t* crog_seed_epoch();
 
+// deterministic mode (crog_set_deterministic, api.hip): launchers pick order-independent kernels; the scratch holds per-block partials
+bool crog_deterministic();
+float* crog_det_scratch();
+constexpr int CROG_DET_SCRATCH_FLOATS = 8192;
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- element traits ----------------------------------------------------------------------
@@ -98,9 +103,21 @@ __device__ inline float wave_max(float v) {
 // murmur3's 32-bit finaliser - two multiplies instead of hash_u32's three.  v_mul_lo_u32 runs at a quarter of the VALU rate, and
 // with one three-multiply hash per score the fused forward was VALU-bound on its dropout (141 us with p = 0.1 against 72 us with
 // p = 0 at the decoder's shape): a multiply per score instead of three.  Index of a pair: row * ceil(ldp / 2) + (key >> 1).
+// The seed enters through a hash of its own (seed_mix: loop-invariant, a handful of instructions per thread), XORed into the counter:
+// consecutive seeds - Runtime.next_seed() hands them to consecutive dropout ops, and the per-step epoch advances by the number of ops -
+// give unrelated masks.  (Until round 4 the raw seed was ADDED to the index: op k + 1's mask was op k's shifted by one pair.)
+__device__ inline uint32_t seed_mix(uint64_t seed) {
+  uint32_t s = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u);
+  s ^= s >> 15;
+  s *= 0x2C1B3C6Du;
+  s ^= s >> 12;
+  s *= 0x297A2D39u;
+  s ^= s >> 15;
+  return s;
+}
 __device__ inline uint32_t attn_hash(uint64_t seed, uint64_t pair_idx) {
-  const uint32_t y = (uint32_t)(pair_idx >> 32) ^ (uint32_t)(seed >> 32);
-  uint32_t x = ((uint32_t)pair_idx + (uint32_t)seed) ^ ((y << 16) | (y >> 16));
+  const uint32_t y = (uint32_t)(pair_idx >> 32);
+  uint32_t x = ((uint32_t)pair_idx ^ seed_mix(seed)) ^ ((y << 16) | (y >> 16));
   x ^= x >> 16;
   x *= 0x85EBCA6Bu;
   x ^= x >> 13;

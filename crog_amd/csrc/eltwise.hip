@@ -171,6 +171,40 @@ __global__ void __launch_bounds__(NT) embedding_bwd_kernel(const int64_t* __rest
   }
 }
 
+// Deterministic form: blocks [0, rows) own the token rows - the block of the FIRST row that carries a token id sums every row with that
+// id, in row order, the others leave at once - and blocks [rows, rows + L) own the position rows (sum over the batch, in order).
+template <typename T>
+__global__ void __launch_bounds__(NT) embedding_bwd_det_kernel(const int64_t* __restrict__ word, const T* __restrict__ dout, float* __restrict__ dtok,
+                                                               float* __restrict__ dpos, long rows, int L, int C, int vocab) {
+  auto clampid = [&](long id) { return id < 0 ? 0L : (id >= vocab ? (long)vocab - 1 : id); };
+  if ((long)blockIdx.x < rows) {
+    const long r = blockIdx.x;
+    const long id = clampid(word[r]);
+    __shared__ int first;
+    if (threadIdx.x == 0) {
+      int f = 1;
+      for (long q = 0; q < r; q++)
+        if (clampid(word[q]) == id) { f = 0; break; }
+      first = f;
+    }
+    __syncthreads();
+    if (!first) return;
+    for (int c = threadIdx.x; c < C; c += NT) {
+      float acc = 0.f;
+      for (long q = r; q < rows; q++)
+        if (clampid(word[q]) == id) acc += Elem<T>::to_f(dout[q * C + c]);
+      dtok[id * C + c] += acc;
+    }
+  } else {
+    const long l = (long)blockIdx.x - rows;
+    for (int c = threadIdx.x; c < C; c += NT) {
+      float acc = 0.f;
+      for (long q = l; q < rows; q += L) acc += Elem<T>::to_f(dout[q * C + c]);
+      dpos[l * C + c] += acc;
+    }
+  }
+}
+
 // ---- row gather / scatter (EOT token select, clip.py:451-452) ---------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(NT) gather_rows_kernel(const T* __restrict__ x, long ldx, const int64_t* __restrict__ idx, T* __restrict__ out,
@@ -723,6 +757,13 @@ extern "C" int crog_embedding_fwd(int dtype, const int64_t* word, const void* to
 }
 extern "C" int crog_embedding_bwd(int dtype, const int64_t* word, const void* dout, float* dtok, float* dpos, int64_t rows, int L, int C, int vocab,
                                   crog_stream_t s) {
+  if (crog_deterministic()) {
+    CROG_CHECK_ARG(rows % L == 0 && rows + L < (1L << 30), "embedding_bwd (deterministic): rows must be whole sequences");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((embedding_bwd_det_kernel<T>), dim3((unsigned)(rows + L)), dim3(NT), 0, (hipStream_t)s, word, (const T*)dout, dtok,
+                                         dpos, (long)rows, L, C, vocab));
+    CROG_LAUNCH_CHECK();
+    return CROG_OK;
+  }
   DISPATCH_T(dtype, LAUNCH((embedding_bwd_kernel<T>), rows * C, s, word, (const T*)dout, dtok, dpos, (long)rows, L, C, vocab));
   CROG_LAUNCH_CHECK();
   return CROG_OK;

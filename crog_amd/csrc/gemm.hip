@@ -725,7 +725,9 @@ __global__ void __launch_bounds__(S::NT, (S::WM >= 4 ? 2 : (S::WM == 2 ? (sizeof
   const int per = (ktiles + p.splitk - 1) / p.splitk;
   const int kt0 = zs * per;
   const int kt1 = min(kt0 + per, ktiles);
-  if (kt0 >= kt1) return;
+  // an empty trailing slice (the split does not divide the k-tiles) has nothing to add - except in the slab form, where its slab must
+  // hold zeros for crog_splitk_reduce: it then runs the loop zero times and stores its all-zero accumulators
+  if (kt0 >= kt1 && !(p.out_mode == CROG_OUT_F32 && p.splitk > 1)) return;
 
   const ConvGeom g{p.convH, p.convW, p.convC};
   ALd la;
@@ -1190,7 +1192,9 @@ gemm_dma_kernel(const crog_gemm_desc p) {   // (fp32 carries a second accumulato
   const int per = (ktiles + p.splitk - 1) / p.splitk;
   const int kt0 = zs * per;
   const int kt1 = min(kt0 + per, ktiles);
-  if (kt0 >= kt1) return;
+  // an empty trailing slice (the split does not divide the k-tiles) has nothing to add - except in the slab form, where its slab must
+  // hold zeros for crog_splitk_reduce: it then runs the loop zero times and stores its all-zero accumulators
+  if (kt0 >= kt1 && !(p.out_mode == CROG_OUT_F32 && p.splitk > 1)) return;
   const int nt = kt1 - kt0;
 
   const ConvGeom g{p.convH, p.convW, p.convC};

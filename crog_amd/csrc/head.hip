@@ -7,6 +7,7 @@
 // which is the same sum re-associated; the stencil, the nearest-neighbour target resize, the five
 // losses and d(loss)/d(pred) are one pass each over the small maps.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -157,12 +158,23 @@ __global__ void __launch_bounds__(NT) head_tap_sums_kernel(const T* __restrict__
   const long p0 = blockIdx.x * per, p1 = min(p0 + per, P);
   float acc = 0.f;
   for (long p = p0 + grp; p < p1; p += groups) acc += Elem<T>::to_f(dt[(b * P + p) * cols + col]);
+  if (gridDim.x == 1) {      // deterministic form (one block per sample): the groups' sums meet in LDS and are added in group order
+    __shared__ float red[NT];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (grp == 0) {
+      float s = 0.f;
+      for (int q = 0; q < groups; q++) s += red[q * cols + col];
+      dcb[b * cols + col] = s;
+    }
+    return;
+  }
   atomicAdd(dcb + b * cols + col, acc);
 }
 // db5[h*C + c] += sum_{b,tap} dcb[b][h][tap] * w_b[c][tap];   dwpad[b][c][tap] += sum_h b5[h*C + c] * dcb[b][h][tap]
 template <typename T>
 __global__ void __launch_bounds__(NT) head_cb_bwd_kernel(const float* __restrict__ b5, const T* __restrict__ wpad, const float* __restrict__ dcb,
-                                                         float* __restrict__ db5, float* __restrict__ dwpad, int B, int heads, int C) {
+                                                         float* __restrict__ db5, float* __restrict__ dwpad, int B, int heads, int C, int add_db5) {
   GRID_STRIDE(i, (long)B * C) {
     const int c = (int)(i % C);
     const long b = i / C;
@@ -175,10 +187,28 @@ __global__ void __launch_bounds__(NT) head_cb_bwd_kernel(const float* __restrict
       float s = 0.f;
 #pragma unroll
       for (int t = 0; t < 16; t++) { s += d[t] * w[t]; dw[t] += bb * d[t]; }
-      atomicAdd(db5 + h * C + c, s);
+      if (add_db5) atomicAdd(db5 + h * C + c, s);
     }
 #pragma unroll
     for (int t = 0; t < 9; t++) atomicAdd(dwpad + i * 16 + t, dw[t]);
+  }
+}
+
+// deterministic db5: one thread per (head, channel) sums the samples in order
+template <typename T>
+__global__ void __launch_bounds__(NT) head_db5_det_kernel(const T* __restrict__ wpad, const float* __restrict__ dcb, float* __restrict__ db5, int B, int heads, int C) {
+  GRID_STRIDE(i, (long)heads * C) {
+    const int c = (int)(i % C), h = (int)(i / C);
+    float acc = 0.f;
+    for (long b = 0; b < B; b++) {
+      const float* d = dcb + (b * heads + h) * 16;
+      const T* w = wpad + (b * C + c) * 16;
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; t++) s += d[t] * Elem<T>::to_f(w[t]);
+      acc += s;
+    }
+    db5[i] += acc;
   }
 }
 
@@ -201,7 +231,7 @@ __global__ void __launch_bounds__(NT) head_bias_grad_kernel(const float* __restr
 struct LossTargets { const float* t[5]; };
 __global__ void __launch_bounds__(NT) head_loss_kernel(const float* __restrict__ pred, LossTargets tg, int B, int heads, int H, int W, int Hin, int Win,
                                                        int weighted, float* __restrict__ tgt_small, float* __restrict__ loss_sums,
-                                                       float* __restrict__ dpred) {
+                                                       float* __restrict__ dpred, float* __restrict__ part) {
   __shared__ float red[NT / 64][5];
   const long P = (long)H * W, N = (long)B * P;
   const float invN = 1.f / (float)N;
@@ -238,7 +268,15 @@ __global__ void __launch_bounds__(NT) head_loss_kernel(const float* __restrict__
   if (threadIdx.x < heads) {
     float s = 0.f;
     for (int w = 0; w < NT / 64; w++) s += red[w][threadIdx.x];
-    atomicAdd(loss_sums + threadIdx.x, s * invN);
+    if (part) part[blockIdx.x * 8 + threadIdx.x] = s * invN;      // deterministic form: head_loss_finalize_kernel adds the blocks in order
+    else atomicAdd(loss_sums + threadIdx.x, s * invN);
+  }
+}
+__global__ void __launch_bounds__(64) head_loss_finalize_kernel(const float* __restrict__ part, int nblocks, int heads, float* __restrict__ loss_sums) {
+  if ((int)threadIdx.x < heads) {
+    float s = 0.f;
+    for (int b = 0; b < nblocks; b++) s += part[b * 8 + threadIdx.x];
+    loss_sums[threadIdx.x] = s;
   }
 }
 
@@ -306,14 +344,20 @@ extern "C" int crog_head_tap_sums(int dtype, const void* dt, float* dcb, int B, 
   CROG_CHECK_ARG(heads >= 1 && heads * 16 <= NT, "head_tap_sums: heads must be in [1, %d]", NT / 16);
   hipError_t e = hipMemsetAsync(dcb, 0, (size_t)B * heads * 16 * sizeof(float), (hipStream_t)s);
   if (e != hipSuccess) { crog_set_error("head_tap_sums: memset failed"); return CROG_ERR_LAUNCH; }
-  DISPATCH_T(dtype, hipLaunchKernelGGL((head_tap_sums_kernel<T>), dim3(32, B), dim3(NT), 0, (hipStream_t)s, (const T*)dt, dcb, (long)P, heads));
+  const int chunks = crog_deterministic() ? 1 : 32;      // one block per sample: ordered sum inside the block
+  DISPATCH_T(dtype, hipLaunchKernelGGL((head_tap_sums_kernel<T>), dim3(chunks, B), dim3(NT), 0, (hipStream_t)s, (const T*)dt, dcb, (long)P, heads));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
 extern "C" int crog_head_cb_bwd(int dtype, const float* b5, const void* wpad, const float* dcb, float* db5, float* dwpad, int B, int heads, int C,
                                 crog_stream_t s) {
-  DISPATCH_T(dtype, LAUNCH((head_cb_bwd_kernel<T>), (long)B * C, s, b5, (const T*)wpad, dcb, db5, dwpad, B, heads, C));
+  const int det = crog_deterministic() ? 1 : 0;
+  DISPATCH_T(dtype, LAUNCH((head_cb_bwd_kernel<T>), (long)B * C, s, b5, (const T*)wpad, dcb, db5, dwpad, B, heads, C, det ? 0 : 1));
   CROG_LAUNCH_CHECK();
+  if (det) {
+    DISPATCH_T(dtype, LAUNCH((head_db5_det_kernel<T>), (long)heads * C, s, (const T*)wpad, dcb, db5, B, heads, C));
+    CROG_LAUNCH_CHECK();
+  }
   return CROG_OK;
 }
 extern "C" int crog_head_stencil_fwd(const float* t, const float* word, int64_t ldw, int bias_col, const float* tbias, float* out, int B, int heads,
@@ -348,7 +392,16 @@ extern "C" int crog_head_loss(const float* pred, const float* const* targets, in
   for (int h = 0; h < 5; h++) tg.t[h] = h < heads ? targets[h] : nullptr;
   hipError_t e = hipMemsetAsync(loss_sums, 0, 5 * sizeof(float), (hipStream_t)s);
   if (e != hipSuccess) { crog_set_error("head_loss: memset failed"); return CROG_ERR_LAUNCH; }
-  LAUNCH(head_loss_kernel, (long)B * H * W, s, pred, tg, B, heads, H, W, Hin, Win, weighted, tgt_small, loss_sums, dpred);
+  if (crog_deterministic()) {
+    const int nb = std::min(stream_grid((long)B * H * W), CROG_DET_SCRATCH_FLOATS / 8);
+    hipLaunchKernelGGL(head_loss_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)s, pred, tg, B, heads, H, W, Hin, Win, weighted, tgt_small, loss_sums, dpred,
+                       crog_det_scratch());
+    CROG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, crog_det_scratch(), nb, heads, loss_sums);
+    CROG_LAUNCH_CHECK();
+    return CROG_OK;
+  }
+  LAUNCH(head_loss_kernel, (long)B * H * W, s, pred, tg, B, heads, H, W, Hin, Win, weighted, tgt_small, loss_sums, dpred, (float*)nullptr);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

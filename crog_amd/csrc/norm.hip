@@ -1053,6 +1053,11 @@ extern "C" int crog_bn_partial_stats(int dtype, const void* x, int64_t M, int C,
 
 extern "C" int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, int sums_is_zero, crog_stream_t stream) {
   CROG_CHECK_ARG(nparts > 0 && C > 0, "reduce_pairs: bad sizes");
+  if (crog_deterministic()) {      // one block per 8 channels walks the slab in order and STORES the sums: no atomics, no memset needed
+    hipLaunchKernelGGL(reduce_split_kernel, dim3(cdiv(C, 8)), dim3(NT), 0, (hipStream_t)stream, partial, nparts, C, sums, (float*)nullptr, (float*)nullptr);
+    CROG_LAUNCH_CHECK();
+    return CROG_OK;
+  }
   if (!sums_is_zero) {   // callers that hand out pre-zeroed scratch (one memset per step for all layers) skip this launch
     hipError_t e = hipMemsetAsync(sums, 0, (size_t)C * 2 * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) { crog_set_error("reduce_pairs: memset failed"); return CROG_ERR_LAUNCH; }

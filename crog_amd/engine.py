@@ -62,8 +62,8 @@ def train_step(model, optimizer, scaler, batch, args=None, autocast_dtype=torch.
     m = Fn.train_metric(pred[0], target[0], 0.35, 0.5)
     stats = torch.stack([loss.detach().float(), m[0], m[1]])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(stats)
-        stats = stats / dist.get_world_size()
+        from .parallel import all_reduce_mean_
+        all_reduce_mean_(stats, model)
     return stats, loss_dict
 
 
@@ -185,27 +185,39 @@ def mask_iou(pred_map, target, thr=0.35):
 
 
 # Captured-step replay (crog_amd/graphs.py): "0" = issue every step from Python, "streams" / "1" = csrc/replay.hip on our own streams,
-# "hipgraph" = hipGraphLaunch.  Default: on with one rank, off with several (a captured RCCL collective never ran with real peers here).
+# "hipgraph" = hipGraphLaunch.  Default: on - with several ranks when every collective of the step goes through the C-ABI communicators
+# (parallel.step_is_capturable: plain RCCL / mailbox launches on captured streams, no torch ProcessGroup inside the step), and then the
+# first replay is checked against an eager step from the same state before it is trusted (GraphedTrainStep verify=).
 STEP_GRAPH = os.environ.get("CROG_STEP_GRAPH")
-_GRAPHED = {}
 
 
 def graphed_step_for(model, optimizer, scaler, args, autocast_dtype=torch.bfloat16):
     """The GraphedTrainStep of this (model, optimizer) pair, or None when the step cannot be one graph: a live GradScaler (its
     inf check steers the host), a stock torch optimizer (host-side step count), or CROG_STEP_GRAPH=0."""
     from .optim import FusedAdam
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    want = STEP_GRAPH if STEP_GRAPH is not None else ("0" if multi else "1")
+    from .parallel import step_is_capturable
+    from .runtime import RT
+    multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or RT.comm is not None or hasattr(model, "reducer"))
+    want = STEP_GRAPH if STEP_GRAPH is not None else ("1" if (not multi or step_is_capturable(model)) else "0")
     if want == "0" or not torch.cuda.is_available() or not isinstance(optimizer, FusedAdam):
         return None
     if scaler is not None and scaler.is_enabled():
         return None
-    key = (id(model), id(optimizer))
-    g = _GRAPHED.get(key)
-    if g is None or g.model is not model or g.optimizer is not optimizer:
+    # the captured step (its graph, replay handle and private memory pool) lives ON the optimizer object, one per model it has been
+    # asked to step: it is released with the optimizer instead of staying in a module-level table for the life of the process
+    table = optimizer.__dict__.setdefault("_crog_graphed", {})
+    g = table.get(id(model))
+    if g is None or g.model is not model:
         from .graphs import GraphedTrainStep
-        g = _GRAPHED[key] = GraphedTrainStep(model, optimizer, args, autocast_dtype)
+        g = table[id(model)] = GraphedTrainStep(model, optimizer, args, autocast_dtype, verify=multi)
     return g
+
+
+def release_graphed_step(model, optimizer):
+    """Drop the captured step of this pair now (its hipGraph, the replay object's events and the graph's memory pool)."""
+    g = optimizer.__dict__.get("_crog_graphed", {}).pop(id(model), None)
+    if g is not None:
+        g.release()
 
 
 def train_with_grasp(train_loader, model, optimizer, scheduler, scaler, epoch, args, log=print):
@@ -232,6 +244,9 @@ def train_with_grasp(train_loader, model, optimizer, scheduler, scaler, epoch, a
         pending.append((stats, batch["img"].size(0)))
         lr.update(scheduler.get_last_lr()[-1])
         if (i + 1) % args.print_freq == 0 or i + 1 == len(train_loader):
+            from .runtime import RT
+            if RT.comm is not None:         # a SyncBatchNorm exchange that gave up on a peer must stop the run here, not train on
+                RT.comm.check()
             for st, n in pending:           # one host sync per print window
                 v = st.tolist()
                 loss_meter.update(v[0], n)

@@ -20,7 +20,7 @@ import torch
 from torch.autograd import Function
 
 from . import kernels as K
-from .runtime import RT, ParamStore
+from .runtime import RT, ParamStore, slab_scratch
 
 
 def _cdt(t: torch.Tensor) -> int:
@@ -152,6 +152,23 @@ def lin_dgrad(dy, w: WRef, dx, *, accumulate_into: Optional[torch.Tensor] = None
            a_off=a_off, b_off=w.off, R=R, ldr=ldr)
 
 
+def wgrad_gemm(dt, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, *, a_off=0, c_off=0, conv=(0, 0, 0), a_sum=None, a_sum_off=0):
+    """G[c_off + m * ldc + n] += sum_k dy[k][m] * xcol[k][n]: every weight gradient of the package.  Split over the reduction; the
+    slices meet through fp32 atomic adds, or - deterministic mode - as slabs of a [splitk][M][N] workspace that crog_splitk_reduce adds
+    onto G in slice order (a_sum, an atomic sum as well, is refused there: the caller takes the two-pass column sum)."""
+    conv3 = b_layout == K.B_NC_IM2COL
+    sk = K.pick_splitk(M, N, Kd, _bk(dt), conv=conv3)
+    if not RT.deterministic:
+        K.gemm(dt, K.A_MC, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, a_off=a_off, c_off=c_off, conv=conv, splitk=sk,
+               out_mode=K.OUT_F32_ATOMIC, a_sum=a_sum, a_sum_off=a_sum_off)
+        return
+    assert a_sum is None, "deterministic mode: bias gradients go through bias_grad (crog_colsum), not a_sum"
+    ldws = _pad(N, 4)
+    ws = slab_scratch(sk * M * ldws, dy.device)
+    K.gemm(dt, K.A_MC, b_layout, dy, x, ws, M, N, Kd, lda, ldb, ldws, a_off=a_off, conv=conv, splitk=sk, out_mode=K.OUT_F32)
+    K.splitk_reduce(ws, sk, M, N, ldws, G, c_off, ldc, accumulate=True)
+
+
 def lin_wgrad(dy, x, w: WRef, *, a_off=0, lda=None, N=None, bias: Optional[WRef] = None):
     """G[w] += dy[M, N]^T @ x[M, K];  with `bias`: G[bias] += column sums of dy, folded into the same launch (a_sum)."""
     M, n, ld = K.mat(dy)
@@ -159,12 +176,13 @@ def lin_wgrad(dy, x, w: WRef, *, a_off=0, lda=None, N=None, bias: Optional[WRef]
         n = N
     _, Kd, ldx = K.mat(x)
     dt = _cdt(x)
-    sk = K.pick_splitk(n, Kd, M, _bk(dt))
-    if bias is not None and a_off == 0 and K.lib().crog_gemm_wgrad_tile(dt, K.A_MC, K.B_NC, n, Kd, M) == 256:
-        bias_grad(dy, bias, 0, n, pooled=True)      # the 256 x 256 weight-gradient tile has no a_sum path: the bias gradient is its own column sum
+    if bias is not None and (RT.deterministic or (a_off == 0 and K.lib().crog_gemm_wgrad_tile(dt, K.A_MC, K.B_NC, n, Kd, M) == 256)):
+        # the 256 x 256 weight-gradient tile has no a_sum path, and a_sum is an atomic sum (deterministic mode): the bias gradient is
+        # its own two-pass column sum
+        bias_grad(dy, bias, a_off, n, pooled=True)
         bias = None
-    K.gemm(dt, K.A_MC, K.B_NC, dy, x, w.G, n, Kd, M, lda if lda is not None else ld, ldx, w.cols, a_off=a_off, c_off=w.off,
-           splitk=sk, out_mode=K.OUT_F32_ATOMIC, a_sum=bias.G if bias is not None else None, a_sum_off=bias.off if bias is not None else 0)
+    wgrad_gemm(dt, K.B_NC, dy, x, w.G, n, Kd, M, lda if lda is not None else ld, ldx, w.cols, a_off=a_off, c_off=w.off,
+               a_sum=bias.G if bias is not None else None, a_sum_off=bias.off if bias is not None else 0)
 
 
 def bias_grad(dy, b: WRef, col0=0, n=None, pooled=False):
@@ -194,10 +212,28 @@ class GradSlot:
     separate autograd accumulation pass (Bottleneck, clip.py:44-57: grad(x) = dgrad(conv1) + grad(identity); with a downsample branch
     the producer is that branch's last backward op - AvgPool2Fn or the 1x1 ConvBnAct, `dx_slot` - instead of conv3's residual)."""
 
-    __slots__ = ("t",)
+    __slots__ = ("t", "consumed")
 
     def __init__(self):
         self.t = None
+        self.consumed = False
+
+    # The contract rests on autograd's ordering (the producer's backward node runs before the consumer's: it was recorded later), not
+    # on a data dependency.  Activation checkpointing, a partial torch.autograd.grad or a forward built on another thread can break
+    # that order; the slot then fails loudly instead of dropping a gradient: a producer that arrives after its consumer raises, and so
+    # does a gradient still parked in a slot when backward ends (Runtime._end_of_backward).
+    def put(self, t):
+        if self.consumed:
+            raise RuntimeError("crog_amd GradSlot: the producer's backward ran AFTER the consumer's - the residual / downsample gradient "
+                               "would have been dropped (autograd order violated: checkpointing or a partial backward over this block?)")
+        self.t = t
+        RT.watch_slot(self)
+
+    def take(self):
+        """The consumer's backward: the parked gradient (or None when the producer's branch carried no gradient)."""
+        t, self.t = self.t, None
+        self.consumed = True
+        return t
 
 
 class BnLink:
@@ -277,7 +313,7 @@ class ConvBnAct(Function):
             if training:
                 slabs = K.stat_tiles(M)
                 comm_on = RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force)
-                if BN_ATOMIC_STATS and dtype != torch.float32:
+                if BN_ATOMIC_STATS and dtype != torch.float32 and not RT.deterministic:
                     # (fp32 is the parity mode: it keeps the per-tile slab + ordered reduction, so the forward is bit-reproducible
                     # run to run; atomic accumulation order jitters the statistics by ~1e-7, which tiny BatchNorm layers amplify)
                     # statistics accumulate atomically into R pre-zeroed [C][2] rows in the GEMM epilogue and are finalised
@@ -323,7 +359,7 @@ class ConvBnAct(Function):
                 RT.comm.all_reduce_sum(sums)
                 count = float(M * RT.comm.world_size)
                 K.bn_finalize(sums, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum, bn.eps, C, ss, mi)
-            elif stats.shape[0] <= FUSED_REDUCE_MAX_PARTS:   # single replica, short slab: statistics -> scale/shift in one launch
+            elif stats.shape[0] <= FUSED_REDUCE_MAX_PARTS or RT.deterministic:   # single replica, short slab: statistics -> scale/shift in one launch
                 K.bn_reduce_finalize(stats, stats.shape[0], count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var,
                                      bn.momentum, bn.eps, C, ss, mi)
             else:                                            # long slab (>= 100k rows): split reduction across blocks first
@@ -343,7 +379,7 @@ class ConvBnAct(Function):
             # publish what the NEXT layer's data-gradient epilogue needs to do this layer's first backward pass (BnLink)
             # (no torch.is_grad_enabled() here: it is always False inside Function.forward)
             ok = (BN_BWD_FUSED and BN_BWD_ATOMIC and training and dtype == torch.bfloat16 and res is None and ksize != 0
-                  and M <= BN_BWD_FUSED_MAX_ROWS)
+                  and M <= BN_BWD_FUSED_MAX_ROWS and not RT.deterministic)      # (the epilogue's statistics are atomic adds)
             stat_out.z, stat_out.ss, stat_out.C, stat_out.M, stat_out.sums = (z if ok else None), (ss if relu else None), C, M, None
         ctx.wt = (wt, wbuf_off) if wpad is not None else None
         if ksize == "s":
@@ -384,7 +420,7 @@ class ConvBnAct(Function):
                            dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=None, param_grad_scale=scale)
             bn.beta.done()
             bn.gamma.done()
-        elif BN_BWD_ATOMIC and dtype != torch.float32:
+        elif BN_BWD_ATOMIC and dtype != torch.float32 and not RT.deterministic:
             # (sum g, sum g*xhat) accumulate atomically into R pre-zeroed [C][2] rows - each block parks its sums in LDS and adds them
             # as 256-byte runs - and the apply kernel adds the rows up itself and stores dbeta / dgamma: two launches, no slab, no
             # reduction kernel.  Under SyncBatchNorm the R rows are all-reduced in between; the totals are then global, and storing
@@ -405,7 +441,7 @@ class ConvBnAct(Function):
             # per-block slab -> one reduction launch -> apply kernel that stages the totals in LDS and (block 0) stores dbeta / dgamma
             partial = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
             K.bn_bwd_partial(dy, ymask, z, mi, rpb, partial, relu_ss, relu_mask=rmask)
-            fused = nparts <= FUSED_REDUCE_MAX_PARTS
+            fused = nparts <= FUSED_REDUCE_MAX_PARTS or RT.deterministic
             sums = torch.empty(2 * C, device=dev, dtype=torch.float32) if fused else RT.zeros(2 * C, dev)
             local_grads = fused or comm_on      # the parameter gradients are LOCAL sums: written before the all-reduce
             if fused:
@@ -437,11 +473,11 @@ class ConvBnAct(Function):
             K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, relu_mask=rmask)
         grad_slot, res_slot = ctx.slots
         if res_slot is not None and dres is not None:   # hand the identity's gradient to the block's first convolution
-            res_slot.t = dres
+            res_slot.put(dres)
             dres = None
         extra = None
-        if grad_slot is not None and grad_slot.t is not None and ksize == 1 and ctx.x_needs:
-            extra, grad_slot.t = grad_slot.t, None
+        if grad_slot is not None and ksize == 1 and ctx.x_needs:
+            extra = grad_slot.take()
         dx = None
         if ksize == 0:
             dx = dz
@@ -457,15 +493,11 @@ class ConvBnAct(Function):
                 gt, goff = w.G, w.off
             def wgrad():
                 if ksize == "s":
-                    sk = K.pick_splitk(C, 32, M, _bk(dt))
-                    K.gemm(dt, K.A_MC, K.B_NC, dz, x, gt, C, 32, M, C, 32, 32, c_off=goff, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+                    wgrad_gemm(dt, K.B_NC, dz, x, gt, C, 32, M, C, 32, 32, c_off=goff)
                 elif ksize == 1:
-                    sk = K.pick_splitk(C, cin, M, _bk(dt))
-                    K.gemm(dt, K.A_MC, K.B_NC, dz, x, gt, C, cin, M, C, K.mat(x)[2], wcols, c_off=goff, splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+                    wgrad_gemm(dt, K.B_NC, dz, x, gt, C, cin, M, C, K.mat(x)[2], wcols, c_off=goff)
                 else:
-                    sk = K.pick_splitk(C, 9 * cin, M, _bk(dt), conv=True)
-                    K.gemm(dt, K.A_MC, K.B_NC_IM2COL, dz, x, gt, C, 9 * cin, M, C, K.mat(x)[2], wcols, c_off=goff, conv=(lead[1], lead[2], cin),
-                           splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+                    wgrad_gemm(dt, K.B_NC_IM2COL, dz, x, gt, C, 9 * cin, M, C, K.mat(x)[2], wcols, c_off=goff, conv=(lead[1], lead[2], cin))
                 if wpad is not None:  # strip the zero padding back out into the real gradient
                     K.add_pad2d(gscratch, dst_cols, w.G, src_cols, src_cols, rows, dst_off=w.off)
             # (a data gradient that will take the one-block-per-CU 256 x 256 tile: csrc/gemm.hip dispatch_shape)
@@ -504,7 +536,7 @@ class ConvBnAct(Function):
             RT.flush_wgrad()       # (defer_wgrad: the weight gradient parked above forks here, behind the data gradient just enqueued)
             w.done()
         if ctx.dx_slot is not None and dx is not None:      # (see avgpool2: x's other consumer adds this gradient in its own epilogue)
-            ctx.dx_slot.t = dx
+            ctx.dx_slot.put(dx)
             dx = None
         return (dx, dres) + (None,) * 16
 
@@ -695,19 +727,18 @@ class LayerNormFn(Function):
         x, stats = ctx.saved_tensors
         M, C, _ = K.mat(x)
         res_slot, add_slot = ctx.slots
+        parked = add_slot.take() if add_slot is not None else None
         if dout is None and dout2 is None:
-            return (None,) * 13
+            return (parked,) + (None,) * 12      # no gradient through the norm itself: x's gradient is what the residual branch parked
         if dout is None:
             dout, dout2 = dout2, None
         dout = K.as_mat(dout)
         dout2 = K.as_mat(dout2) if dout2 is not None else None
-        dxadd = None
-        if add_slot is not None and add_slot.t is not None:
-            dxadd, add_slot.t = K.as_mat(add_slot.t), None
+        dxadd = K.as_mat(parked) if parked is not None else None
         dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
         rpb = K.ln_bwd_rows_per_block(M)
         nb = (M + rpb - 1) // rpb
-        if LN_BWD_ATOMIC and x.dtype != torch.float32:
+        if LN_BWD_ATOMIC and x.dtype != torch.float32 and not RT.deterministic:
             # the blocks add their (dgamma, dbeta) sums straight into the gradient vectors: no slab, no reduction launch (85 launches
             # per CROG step).  fp32, the parity mode, keeps the ordered reduction (bit-reproducible run to run)
             K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, None, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out,
@@ -732,7 +763,8 @@ class LayerNormFn(Function):
                 dres = torch.empty(x.shape, device=x.device, dtype=x.dtype)
                 K.add_rows(dout, dout2, dres)
             if res_slot is not None:
-                res_slot.t, dres = dres, None
+                res_slot.put(dres)
+                dres = None
         return (dx, dres) + (None,) * 11
 
 
@@ -926,7 +958,7 @@ class AvgPool2Fn(Function):
         dx = torch.empty(ctx.shape, device=dy.device, dtype=dy.dtype)
         K.avgpool2_bwd(K.as_mat(dy), dx)
         if ctx.grad_slot is not None:      # the other consumer of x adds this branch's gradient in its data-gradient epilogue (GradSlot)
-            ctx.grad_slot.t = dx
+            ctx.grad_slot.put(dx)
             return None, None, None
         return dx, None, None
 
@@ -1077,7 +1109,7 @@ class AddDropoutFn(Function):
         db = torch.empty_like(dout)
         K.add_dropout(None, dout, db, p, seed)
         if res_slot is not None:      # `a`'s gradient rides the slot into the LayerNorm backward that also differentiates `a` (LayerNormFn)
-            res_slot.t = dout
+            res_slot.put(dout)
             return None, db, None, None
         return dout, db, None, None
 
@@ -1142,9 +1174,12 @@ class Conv3BiasActFn(Function):
             K.act_bwd(K.as_mat(dy), y, g, 0 if act == K.ACT_RELU else 2)
         M = B * H * W
         def wgrad():
-            sk = K.pick_splitk(C, 9 * cin, M, _bk(dt), conv=True)
-            K.gemm(dt, K.A_MC, K.B_NC_IM2COL, g, x, w.G, C, 9 * cin, M, C, K.mat(x)[2], w.cols, c_off=w.off, conv=(H, W, cin), splitk=sk,
-                   out_mode=K.OUT_F32_ATOMIC, a_sum=b.G if b is not None else None, a_sum_off=b.off if b is not None else 0)
+            bb = b
+            if bb is not None and RT.deterministic:
+                bias_grad(g, bb, 0, C, pooled=True)
+                bb = None
+            wgrad_gemm(dt, K.B_NC_IM2COL, g, x, w.G, C, 9 * cin, M, C, K.mat(x)[2], w.cols, c_off=w.off, conv=(H, W, cin),
+                       a_sum=bb.G if bb is not None else None, a_sum_off=bb.off if bb is not None else 0)
         RT.on_wgrad_stream(wgrad, g, x)
         w.done()
         if b is not None:
@@ -1350,9 +1385,7 @@ class TableMatmulFn(Function):
         R, Kp = A.shape
         C = table.cols
         dt = K.dcode(dout)
-        sk = K.pick_splitk(table.rows, C, R, _bk(dt))
-        K.gemm(dt, K.A_MC, K.B_NC, A, dout, table.G, table.rows, C, R, Kp, K.mat(dout)[2], C, c_off=table.off, splitk=sk,
-               out_mode=K.OUT_F32_ATOMIC)
+        wgrad_gemm(dt, K.B_NC, A, dout, table.G, table.rows, C, R, Kp, K.mat(dout)[2], C, c_off=table.off)
         table.done()
         dA = None
         if a_grad:
@@ -1415,9 +1448,9 @@ class DynHeadFn(Function):
                sC=(P * groups * C, 0))
         # dw[b,c,tap] = sum_(p,g) x5[b,(p,g),c] * dt[b,(p,g),tap]
         dwpad = torch.zeros(B, C, 16, device=dev, dtype=torch.float32)
-        sk = max(1, min(16, (P * groups) // 2048))
+        sk = 1 if RT.deterministic else max(1, min(16, (P * groups) // 2048))      # (one slice per sample: plain stores, one summation order)
         K.gemm(dt, K.A_MC, K.B_NC, x5, dtb, dwpad, C, 16, P * groups, C, 16, 16, batch=B, sA=(P * groups * C, 0), sB=(P * groups * 16, 0),
-               sC=(C * 16, 0), splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+               sC=(C * 16, 0), splitk=sk, out_mode=K.OUT_F32 if RT.deterministic else K.OUT_F32_ATOMIC)
         dword = torch.empty(B, ldw, device=dev, dtype=dtype)
         K.head_unpack_wgrad(dwpad, dbias, dword, B, C)
         nout = C * 9 + 1
@@ -1488,22 +1521,34 @@ class FusedHeadFn(Function):
         K.gemm(dt, K.A_KC, K.B_NC, dtb, Wf, dx4, P, C, g * 16, g * 16, C, C, batch=B, sA=(P * g * 16, 0), sB=(g * 16 * C, 0), sC=(P * C, 0))
         # dWf[b][(g,tap)][k] = sum_p dt[b][p][(g,tap)] * x4[b][p][k]
         dWf = torch.zeros(B, g * 16, C, device=dev, dtype=torch.float32)
-        sk = max(1, min(24, P // 1024))
+        sk = 1 if RT.deterministic else max(1, min(24, P // 1024))
         K.gemm(dt, K.A_MC, K.B_NC, dtb, x4, dWf, g * 16, C, P, g * 16, ldx, C, batch=B, sA=(P * g * 16, 0), sB=(P * ldx, 0), sC=(g * 16 * C, 0),
-               splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+               splitk=sk, out_mode=K.OUT_F32 if RT.deterministic else K.OUT_F32_ATOMIC)
         if dtype == torch.float32:
             dWf_c = dWf
         else:
             dWf_c = torch.empty(B, g * 16, C, device=dev, dtype=dtype)
             K.cast_pad2d(dWf, C, C, dWf_c, C, C, B * g * 16)
         # dW5[g*C + c][k] += sum_b sum_tap wpad[b][c][tap] * dWf[b][g][tap][k]
-        K.gemm(dt, K.A_KC, K.B_NC, wpad, dWf_c, w5.G, C, C, 16, 16, C, w5.cols, batch=B * g, batch_inner=g, sA=(C * 16, 0),
-               sB=(g * 16 * C, 16 * C), sC=(0, C * w5.cols), c_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
+        if RT.deterministic:
+            # the B samples add into the same rows of dW5: one launch per sample (its g groups write disjoint rows), in stream order
+            for bi in range(B):
+                K.gemm(dt, K.A_KC, K.B_NC, wpad, dWf_c, w5.G, C, C, 16, 16, C, w5.cols, batch=g, batch_inner=g, sA=(0, 0),
+                       sB=(0, 16 * C), sC=(0, C * w5.cols), a_off=bi * C * 16, b_off=bi * g * 16 * C, c_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
+        else:
+            K.gemm(dt, K.A_KC, K.B_NC, wpad, dWf_c, w5.G, C, C, 16, 16, C, w5.cols, batch=B * g, batch_inner=g, sA=(C * 16, 0),
+                   sB=(g * 16 * C, 16 * C), sC=(0, C * w5.cols), c_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
         w5.done()
         # dwpad[b][c][tap] = sum_g sum_k W5[g*C + c][k] * dWf[b][g][tap][k]   (+ the cb share below)
         dwpad = torch.zeros(B, C, 16, device=dev, dtype=torch.float32)
-        K.gemm(dt, K.A_KC, K.B_KC, w5.w(dtype), dWf_c, dwpad, C, 16, C, w5.cols, C, 16, batch=B * g, batch_inner=g, sA=(0, C * w5.cols),
-               sB=(g * 16 * C, 16 * C), sC=(C * 16, 0), a_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
+        if RT.deterministic:
+            # the g groups add into the same dwpad[b]: one launch per group (its B samples write disjoint blocks), in stream order
+            for gi in range(g):
+                K.gemm(dt, K.A_KC, K.B_KC, w5.w(dtype), dWf_c, dwpad, C, 16, C, w5.cols, C, 16, batch=B, batch_inner=1, sA=(0, 0),
+                       sB=(g * 16 * C, 0), sC=(C * 16, 0), a_off=w5.off + gi * C * w5.cols, b_off=gi * 16 * C, out_mode=K.OUT_F32_ATOMIC)
+        else:
+            K.gemm(dt, K.A_KC, K.B_KC, w5.w(dtype), dWf_c, dwpad, C, 16, C, w5.cols, C, 16, batch=B * g, batch_inner=g, sA=(0, C * w5.cols),
+                   sB=(g * 16 * C, 16 * C), sC=(C * 16, 0), a_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
         K.head_cb_bwd(b5.P, b5.off, wpad, dcb, b5.G, b5.off, dwpad, B, g, C)
         b5.done()
         dword = torch.empty(B, ldw, device=dev, dtype=dtype)

@@ -117,12 +117,18 @@ class GraphedTrainStep:
     so they can be mixed (bench.py brackets kernels with timers in an occasional eager step)."""
 
     def __init__(self, model, optimizer, args=None, autocast_dtype=torch.bfloat16, warmup: int = 3, enabled: bool = True,
-                 executor: str = None, profile_key=None):
+                 executor: str = None, profile_key=None, verify: bool = False):
         """executor: "streams" (default) = csrc/replay.hip re-issues the captured nodes on this process's own three streams, so the
         weight-gradient / text-tower overlap is the eager step's; "hipgraph" = hipGraphLaunch (ROCm 7.0 re-partitions the branches
         over its own queues: 38.6 instead of 33 ms per CROG-R50 step, kept for A/B).  CROG_STEP_GRAPH=streams|hipgraph overrides.
         profile_key: (a_layout, b_layout) of the GEMM variant whose launches get timer pairs in profiled replays (bench.py)."""
         import os
+        # verify: check the FIRST replay against an eager step from the same state (parameters, moments, running statistics, seed
+        # epoch are snapshotted and rewound) before trusting the graph; on a mismatch - or any exception - the state is rewound once
+        # more, the step is issued eagerly and every later step stays eager (`self.failed` says why).  With several ranks the verdict is
+        # a MIN all-reduce, so all ranks replay or none does.  Default for multi-rank jobs (captured collectives), CROG_REPLAY_VERIFY=0/1.
+        self.verify = {"0": False, "1": True}.get(os.environ.get("CROG_REPLAY_VERIFY", ""), verify)
+        self.verified = None
         self.executor = executor or {"hip": "hipgraph", "hipgraph": "hipgraph"}.get(os.environ.get("CROG_STEP_GRAPH", ""), "streams")
         self.profile_key = profile_key
         self.prof_nodes = []            # (node handle, flops, meta) of the profiled launches, capture order
@@ -165,9 +171,69 @@ class GraphedTrainStep:
         m = Fn.train_metric(pred[0], target[0], 0.35, 0.5)
         stats = torch.stack([loss.detach().float(), m[0], m[1]])
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(stats)
-            stats = stats / dist.get_world_size()
+            from .parallel import all_reduce_mean_
+            all_reduce_mean_(stats, model)
         return stats, loss_dict
+
+    # ---- first-replay check -----------------------------------------------------------------------------------------------------
+    def _snapshot(self):
+        """Everything a training step changes, device tensors cloned and host flags copied."""
+        st, opt = self._store(), self.optimizer
+        m = self.model.module if hasattr(self.model, "module") and not hasattr(self.model, "store") else self.model
+        tens = dict(P=st.P, S=st.S, m=opt.m, v=opt.v, hyper=opt._hyper, epoch=RT.seed_epoch)
+        return dict(tens={k: (t, t.clone()) for k, t in tens.items() if t is not None},
+                    bufs=[(b, b.clone()) for b in m.buffers()],
+                    host=dict(step=opt._step, hyper_lr=list(opt._hyper_lr) if opt._hyper_lr is not None else None,
+                              shadow_fresh=st.shadow_fresh, synced=getattr(st, "synced", False), t_fresh=dict(st.t_fresh), g_clean=st.g_clean,
+                              written=set(st.written), seed_ctr=RT._seed_ctr))
+
+    def _restore(self, snap):
+        st, opt = self._store(), self.optimizer
+        for t, c in list(snap["tens"].values()) + snap["bufs"]:
+            t.copy_(c)
+        h = snap["host"]
+        opt._step, opt._hyper_lr = h["step"], (list(h["hyper_lr"]) if h["hyper_lr"] is not None else None)
+        st.shadow_fresh, st.synced, st.g_clean, st.written = h["shadow_fresh"], h["synced"], h["g_clean"], set(h["written"])
+        st.t_fresh.update(h["t_fresh"])
+        RT._seed_ctr = h["seed_ctr"]
+
+    def _verified_first_replay(self, batch):
+        """-> (stats, loss_dict) of the step, replayed when the replay reproduces the eager step, eager otherwise."""
+        import torch.distributed as dist
+        snap = self._snapshot()
+        e_stats, _ = self._eager(batch)
+        torch.cuda.synchronize()
+        ref = e_stats.tolist()
+        self._restore(snap)
+        why = None
+        try:
+            out = self._replay_once(batch)
+            torch.cuda.synchronize()
+            got = out[0].tolist()
+            if not all(v == v and abs(v) != float("inf") for v in got):
+                why = f"the replayed step produced non-finite statistics {got}"
+            elif abs(got[0] - ref[0]) > 0.05 * abs(ref[0]) + 1e-3:
+                # (same state, same seeds, same batch: the two differ only by the order of fp32 atomic sums, ~1 % of the loss at most)
+                why = f"the replayed step's loss {got[0]:.5f} differs from the eager step's {ref[0]:.5f} (same state, same seeds)"
+        except Exception as e:
+            why = f"the replay raised {e!r}"
+            out = None
+        ok = why is None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            flag = torch.tensor([1 if ok else 0], device=e_stats.device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if ok and not int(flag.item()):
+                ok, why = False, "another rank's first replay did not reproduce its eager step"
+        self.verified = ok
+        if ok:
+            return out
+        import warnings
+        warnings.warn(f"crog_amd: captured training step rejected ({why}); steps stay eager")
+        self.failed = why
+        self._drop_replay()
+        self.graph = None
+        self._restore(snap)
+        return self._eager(batch)
 
     def _eager(self, batch):
         """One eager step inside the seed protocol: seeds restart at the same host counter every step and the device epoch moves on by
@@ -284,13 +350,23 @@ class GraphedTrainStep:
             self._read_profile()
         return [(ms, f, meta) for step in self.prof_ms for ms, (_, f, meta) in zip(step, self.prof_nodes)]
 
-    def __del__(self):
-        try:
-            if self.replay_handle is not None:
+    def _drop_replay(self):
+        """Destroy the replay object (and its ~200 HIP events) before the graph it walks goes away."""
+        h, self.replay_handle = self.replay_handle, None
+        if h is not None:
+            try:
                 from . import kernels as K
-                K.lib().crog_replay_destroy(self.replay_handle)
-        except Exception:
-            pass
+                K.lib().crog_replay_destroy(h)
+            except Exception:
+                pass
+
+    def release(self):
+        self._drop_replay()
+        self.graph = None
+        self.static = None
+
+    def __del__(self):
+        self._drop_replay()
 
     def _store(self):
         m = self.model.module if hasattr(self.model, "module") and not hasattr(self.model, "store") else self.model
@@ -318,7 +394,14 @@ class GraphedTrainStep:
                 import warnings
                 self.failed = repr(e)
                 self.graph = None
+                self._drop_replay()
                 torch.cuda.synchronize()
+                st = self._store()
+                if st is not None:
+                    # the aborted capture ran the step's Python (zero_grad's "known clean" flag, the shadow / transposed-weight freshness
+                    # flags) without executing a kernel: forget what it claimed before falling back to eager steps
+                    st.g_clean = False
+                    st.invalidate_shadow()
                 warnings.warn(f"crog_amd: whole-step hipGraph capture failed ({e!r}); steps stay eager")
                 return self._eager(batch)
         if eager or any(batch[k].shape != t.shape or batch[k].dtype != t.dtype for k, t in self.static.items()):
@@ -326,12 +409,18 @@ class GraphedTrainStep:
         store = self._store()
         if store is not self._captured_store or not store.valid():
             # the parameters were re-materialised (.cuda() / .to() / .float()): the captured addresses are gone - capture again
-            self.graph, self.replay_handle, self.calls = None, None, self.warmup
+            self._drop_replay()
+            self.graph, self.calls = None, self.warmup
             return self._eager(batch)
         if store.S is not None and not getattr(store, "synced", False):
             # the fp32 parameters changed behind the captured step's back (load_state_dict, an in-place edit): the replay assumes
             # the bf16 shadow FusedAdam wrote last step; one eager step re-casts it and leaves the state a replay expects
             return self._eager(batch)
+        if self.verify and self.verified is None:
+            return self._verified_first_replay(batch)
+        return self._replay_once(batch, profile)
+
+    def _replay_once(self, batch, profile: bool = False):
         for k, dst in self.static.items():
             src = batch[k]
             if src.data_ptr() != dst.data_ptr():

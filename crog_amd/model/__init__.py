@@ -17,4 +17,11 @@ def build_crog(args):
     return model, param_list
 
 
-__all__ = ["CROG", "build_crog"]
+def build_ssg(args):
+    """model/__init__.py:26-29: returns (model, model.parameters()) - one parameter group, no learning-rate split."""
+    from .ssg import SSG
+    model = SSG(args)
+    return model, model.parameters()
+
+
+__all__ = ["CROG", "build_crog", "build_ssg"]

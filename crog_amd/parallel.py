@@ -30,9 +30,11 @@ def _direct_mode(direct):
     "peer": the one-shot hipIpc mailbox exchange only (any torch backend carries the set-up: two test ranks on one GPU use gloo);
     "rccl" / "1" / True: ncclAllReduce on the compute stream; "both": mailbox for what fits a slot, RCCL for the rest."""
     if direct is None:
-        direct = _os.environ.get("CROG_SYNCBN_DIRECT", "0")
-    if direct in (False, "0", "", "off"):
+        direct = _os.environ.get("CROG_SYNCBN_DIRECT", "auto")
+    if direct in (False, "0", "", "off", "torch"):
         return False, False
+    if direct == "auto":      # build both and let the start-up self-test decide (DirectComm.create(selftest=True))
+        return True, True
     if direct == "peer":
         return False, True
     if direct == "both":
@@ -46,11 +48,13 @@ class SyncBNComm:
     issue order, and a statistics exchange would queue behind whatever 64 MiB bucket is in flight — and, with `direct`, torch.distributed's
     stream/event fencing: `direct` = the C-ABI communicator (include/crog_hip.h crog_comm_*, crog_amd/rccl.py) whose exchange is
     enqueued on the compute stream itself, either as ONE single-block kernel per rank (peer writes into hipIpc mailboxes: one hop
-    instead of a ring) or as an ncclAllReduce.  OPT-IN (CROG_SYNCBN_DIRECT=peer | rccl | both, or direct=...).  Measured at world size
+    instead of a ring) or as an ncclAllReduce.  Chosen by the job itself since round 4 (CROG_SYNCBN_DIRECT unset = "auto": both transports
+    are built and self-tested at start-up with a collective verdict, rccl.DirectComm.create(selftest=True); "torch" / "0" forces the
+    process group, peer | rccl | both force a transport).  Measured at world size
     1, the only size a box of this pool has: the direct RCCL calls cost 1.2 us of host time and no GPU work per call against 7.7 us + a
     9.5 us stream round trip for torch's, and the forced-DDP step is 35.1-35.6 ms with them against 35.8-36.2 ms on torch's groups.  The
     mailbox exchange is validated with two processes sharing one GPU (tests/test_ddp2_gpu.py); neither has run across xGMI.
-    Default: a torch process group of its own (also the gloo path)."""
+    Fallback (self-test failed anywhere, or a gloo group): a torch process group of its own."""
 
     def __init__(self, group=None, direct=None):
         self.group = group
@@ -66,9 +70,9 @@ class SyncBNComm:
             # one-sidedly): either all ranks get the direct communicator or all of them fall back, so the ranks can never disagree
             # about the collectives that follow (the dedicated torch group below is created by all of them or by none)
             from .rccl import DirectComm
-            self.direct, err = DirectComm.create(group, rccl=rccl, peer=peer)
+            self.direct, err = DirectComm.create(group, rccl=rccl, peer=peer, selftest=True)
             if self.direct is not None:
-                self.kind = "crog_comm:" + "+".join(k for k, on in (("rccl", rccl), ("peer", peer)) if on)
+                self.kind = "crog_comm:" + "+".join(k for k, on in (("rccl", self.direct.has_rccl), ("peer", self.direct.has_peer)) if on)
             else:
                 import warnings
                 warnings.warn(f"crog_amd: direct communicator unavailable ({err!r}); SyncBatchNorm uses torch.distributed on every rank")
@@ -79,6 +83,16 @@ class SyncBNComm:
             self.direct.all_reduce_sum(t)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def check(self):
+        """Raise if an exchange of the direct communicator ever gave up waiting for a peer (the kernel then returns NaN statistics on
+        that and every later exchange, csrc/comm.hip): called where the host already synchronises - engine.train_with_grasp's print
+        window, the end of bench.py - so that a run cannot continue on diverged BatchNorm statistics.  Synchronises the device."""
+        if self.direct is not None:
+            seq = self.direct.timed_out()
+            if seq:
+                raise RuntimeError(f"crog_amd: SyncBatchNorm exchange #{seq} timed out waiting for a peer rank (CROG_COMM_TIMEOUT_S); "
+                                   "the communicator is dead and the BatchNorm statistics since then are NaN - restart from the last checkpoint")
 
     @staticmethod
     def _slot():
@@ -109,15 +123,40 @@ def convert_sync_batchnorm(model, process_group=None, force=False, dedicated_gro
     return model
 
 
+def all_reduce_mean_(t: torch.Tensor, net=None):
+    """In-place rank mean of a small fp32 tensor (the step's (loss, IoU, Prec@50) triple, crog_engine.py:88-93) on the current stream:
+    through the gradient-bucket communicator of `net` (crog_amd DistributedDataParallel) when it has one - a plain RCCL call that a
+    captured step can hold - otherwise torch.distributed."""
+    world = dist.get_world_size()
+    comm = getattr(net, "bucket_comm", None)
+    if comm is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+        comm.all_reduce_bucket(t, average=True)
+        return t
+    dist.all_reduce(t)
+    t.div_(world)
+    return t
+
+
+def step_is_capturable(net) -> bool:
+    """True when every collective of a training step goes through the C-ABI communicators (BatchNorm statistics: RT.comm.direct with
+    RCCL behind it; gradient buckets and the metric: net.bucket_comm): no torch ProcessGroup work inside the step, so nothing of it
+    records events a capture must not see (the watchdog thread polling a captured event aborted one run in a few in round 3)."""
+    if getattr(net, "bucket_comm", None) is None:
+        return False
+    return RT.comm is None or (RT.comm.direct is not None and RT.comm.direct.has_rccl)
+
+
 class Reducer:
     """Bucketed, overlapped mean all-reduce of a flat gradient buffer."""
 
-    def __init__(self, flat_grad: torch.Tensor, entries, group=None, bucket_cap_mb: float = 64.0, payload_dtype=None):
+    def __init__(self, flat_grad: torch.Tensor, entries, group=None, bucket_cap_mb: float = 64.0, payload_dtype=None, direct=None):
         """entries: iterable of (param, offset, numel) in registration order.
         payload_dtype: None = exchange the fp32 gradients as they are (the reference's DDP, bit-compatible); torch.bfloat16 = each
         bucket is rounded to bf16 for the wire (294 instead of 588 MB per step for CROG-R50), averaged, and widened back — an opt-in
         that changes the numerics (`DistributedDataParallel(..., gradient_payload=torch.bfloat16)` or CROG_GRAD_PAYLOAD=bf16)."""
         self.G = flat_grad
+        self.direct = direct      # rccl.DirectComm of the gradient buckets (crog_allreduce_bucket: one ncclAllReduce on the carrier stream,
+                                  # no ProcessGroup hop, capturable), or None: torch.distributed
         self.payload_dtype = payload_dtype
         self._wire = {}           # bucket index -> bf16 staging buffer
         self.group = group
@@ -169,6 +208,25 @@ class Reducer:
             if i not in self._wire:
                 self._wire[i] = torch.empty(b["numel"], device=view.device, dtype=self.payload_dtype)
             b["wire"] = self._wire[i]
+        if self.G.is_cuda and self.direct is not None:
+            # the C-ABI path: the collective is enqueued on the carrier stream itself (after it has waited for every writer), in
+            # bucket order - the same order on every rank, as RCCL requires of one communicator
+            from . import kernels as K
+            cur = torch.cuda.current_stream()
+            side = [s for s in RT.streams if s != cur]
+            carrier = side[-1] if side else cur
+            if side:
+                carrier.wait_stream(cur)
+                for s in side[:-1]:
+                    carrier.wait_stream(s)
+            with torch.cuda.stream(carrier):
+                t = self._to_wire(b, view)
+                self.direct.all_reduce_bucket(t, average=True)
+                if b["wire"] is not None:
+                    view.copy_(b["wire"])          # widen the averaged payload back into the fp32 gradient buffer
+            b["carrier"], b["work"], b["direct"] = carrier, None, True
+            return
+        b["direct"] = False
         if self.G.is_cuda:
             cur = torch.cuda.current_stream()
             side = [s for s in RT.streams if s != cur]
@@ -218,6 +276,10 @@ class Reducer:
         for b in self.buckets:
             self._launch(b)
         for b in self.buckets:
+            if b.get("direct"):
+                if b["carrier"] is not None and b["carrier"] != torch.cuda.current_stream():
+                    torch.cuda.current_stream().wait_stream(b["carrier"])
+                continue                        # averaged (and widened) on the carrier stream already
             if b["work"] is not None:
                 b["work"].wait()
             view = self.G[b["start"]:b["start"] + b["numel"]]
@@ -241,8 +303,10 @@ class DistributedDataParallel(torch.nn.Module):
         self.gradient_payload = gradient_payload
         self.force = force
         self.process_group = process_group
+        self.broadcast_buffers = broadcast_buffers
         self.bucket_cap_mb = bucket_cap_mb
         self.reducer: Optional[Reducer] = None
+        self.bucket_comm = None      # rccl.DirectComm for the gradient buckets (None: torch.distributed)
         self._hooks = []
         if hasattr(module, "prepare"):
             dev = torch.device("cuda", device_ids[0]) if device_ids else next(module.parameters()).device
@@ -253,6 +317,24 @@ class DistributedDataParallel(torch.nn.Module):
             else:
                 module.prepare(dev)
         self._sync_initial_state()
+        self._make_bucket_comm()
+
+    def _make_bucket_comm(self):
+        """The gradient buckets get an RCCL communicator of their own behind the C ABI (crog_allreduce_bucket): collectives of one
+        communicator run in issue order, so it is not the BatchNorm statistics' communicator.  Collective set-up with a collective
+        verdict and a self-test (rccl.DirectComm.create); CROG_DDP_DIRECT=0 keeps torch.distributed.  A gloo group (CPU tests) has none."""
+        if _os.environ.get("CROG_DDP_DIRECT", "1") == "0" or not torch.cuda.is_available():
+            return
+        if dist.get_world_size(self.process_group) == 1 and not self.force:
+            return
+        if dist.get_backend(self.process_group) != "nccl":
+            return
+        from .rccl import DirectComm
+        RT.ensure_streams()
+        self.bucket_comm, err = DirectComm.create(self.process_group, rccl=True, peer=False, selftest=True)
+        if self.bucket_comm is None:
+            import warnings
+            warnings.warn(f"crog_amd: direct gradient-bucket communicator unavailable ({err!r}); buckets use torch.distributed on every rank")
 
     def _sync_initial_state(self):
         """DDP broadcasts rank 0's parameters and buffers at construction."""
@@ -267,11 +349,31 @@ class DistributedDataParallel(torch.nn.Module):
         for b in self.module.buffers():
             dist.broadcast(b, 0, group=self.process_group)
 
+    def _broadcast_buffers(self):
+        """torch DDP's broadcast_buffers=True (the reference's default, train_crog.py:154-156): rank 0's buffers - BatchNorm running
+        statistics - replace every rank's before each training forward.  Under SyncBatchNorm (RT.comm installed, the reference's
+        configuration) all ranks compute the same running statistics from the same global sums and the broadcast would change nothing,
+        so it is skipped; with plain per-rank BatchNorm (sync_bn: False) the ranks' statistics drift apart and this keeps them rank
+        0's, as torch does.  One coalesced broadcast per dtype."""
+        if not self.broadcast_buffers or RT.comm is not None:
+            return
+        by_dtype = {}
+        for b in self.module.buffers():
+            if b.numel():
+                by_dtype.setdefault(b.dtype, []).append(b)
+        for bufs in by_dtype.values():
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            dist.broadcast(flat, 0, group=self.process_group)
+            off = 0
+            for b in bufs:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+
     def _ensure_reducer(self):
         store = self.module.store
         if self.reducer is None or self.reducer.G is not store.G:
             self.reducer = Reducer(store.G, [(p, o, n) for _, p, o, n, _ in store.entries], self.process_group, self.bucket_cap_mb,
-                                   payload_dtype=self.gradient_payload)
+                                   payload_dtype=self.gradient_payload, direct=self.bucket_comm)
             for h in self._hooks:
                 h.remove()
             self._hooks = []
@@ -284,6 +386,7 @@ class DistributedDataParallel(torch.nn.Module):
         if hasattr(self.module, "_ensure") and args:
             self.module._ensure(args[0].device)
         if out_is_training and (dist.get_world_size(self.process_group) > 1 or self.force):
+            self._broadcast_buffers()
             self._ensure_reducer()
             self.reducer.reset()
             RT.reducer = self.reducer

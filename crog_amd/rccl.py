@@ -13,8 +13,10 @@ carries the set-up, and nobody enters the next collective step unless everybody 
 the same thing on every rank: a communicator, or None plus the reason (crog_amd.parallel then uses a torch process group everywhere).
 
 STATUS.  The peer-write exchange is validated with two processes sharing one GPU (tests/test_ddp2_gpu.py: bit-identical to the
-gloo exchange); RCCL with more than one rank has not run on this build's hardware (one GPU per box).  Both stay opt-in
-(CROG_SYNCBN_DIRECT=peer | rccl | 1): the default SyncBatchNorm exchange is a dedicated torch process group.
+gloo exchange); RCCL with more than one rank has not run on this build's hardware (one GPU per box).  Since round 4 the choice is made
+by the job itself (CROG_SYNCBN_DIRECT unset = "auto"): every transport is built and SELF-TESTED at start-up (`create(selftest=True)`:
+one exchange of a known vector, collective verdict), and what fails on any rank is dropped on all of them - mailbox + RCCL, RCCL
+only, or a dedicated torch process group.
 """
 from __future__ import annotations
 
@@ -51,9 +53,12 @@ class DirectComm:
         self._lib = None
 
     @classmethod
-    def create(cls, group=None, device=None, rccl: bool = True, peer: bool = True, lib=None):
+    def create(cls, group=None, device=None, rccl: bool = True, peer: bool = True, lib=None, selftest: bool = False):
         """-> (comm, None) on every rank, or (None, reason) on every rank.  rccl: build the RCCL communicator (needs one GPU per
-        rank); peer: build the hipIpc mailboxes of the one-shot statistics exchange.  `lib` replaces the C ABI (protocol tests)."""
+        rank); peer: build the hipIpc mailboxes of the one-shot statistics exchange.  `lib` replaces the C ABI (protocol tests).
+        selftest: after the set-up, every transport exchanges a known vector once; a transport that does not return the right sums on
+        EVERY rank (collective verdict) is dropped - the mailbox by rebuilding the communicator without it - and if nothing is left the
+        result is (None, reason) everywhere: what `crog_amd.parallel` uses to pick peer / rccl / torch.distributed by itself."""
         if device is None:
             dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         else:
@@ -106,7 +111,39 @@ class DirectComm:
             if not _all_agree(err is None, group, dev):
                 self.close()
                 return None, err or RuntimeError("opening a peer mailbox failed on another rank")
+        if selftest and dev.type == "cuda":
+            ok_peer, ok_rccl = self._selftest(dev)
+            peer_ok = (not self.has_peer) or _all_agree(ok_peer, group, dev)
+            rccl_ok = (not self.has_rccl) or _all_agree(ok_rccl, group, dev)
+            if not rccl_ok or not peer_ok:
+                # a mailbox that timed out is dead for good (csrc/comm.hip), and RCCL that returns wrong sums is not worth keeping:
+                # rebuild with what passed (every rank takes the same branch: the verdicts are collective)
+                self.close()
+                keep_rccl, keep_peer = self.has_rccl and rccl_ok, self.has_peer and peer_ok
+                if not (keep_rccl or keep_peer):
+                    return None, RuntimeError("communicator self-test failed (peer mailbox: %s, RCCL: %s)" % (peer_ok, rccl_ok))
+                return cls.create(group, device, rccl=keep_rccl, peer=keep_peer, lib=lib, selftest=True)
         return self, None
+
+    def _selftest(self, dev):
+        """One exchange of a known vector per transport: rank r contributes r + 1, every element must come back as W (W + 1) / 2."""
+        want = self.world_size * (self.world_size + 1) / 2.0
+        ok_peer = ok_rccl = True
+        try:
+            if self.has_peer:
+                x = torch.full((256,), float(self.rank + 1), device=dev)
+                self.all_reduce_sum(x)                # 256 floats fit a mailbox slot: the peer-write path
+                ok_peer = bool((x == want).all().item()) and self.timed_out() == 0
+        except Exception:
+            ok_peer = False
+        try:
+            if self.has_rccl:
+                y = torch.full((4096,), float(self.rank + 1), device=dev)
+                self.all_reduce_bucket(y, average=False)
+                ok_rccl = bool((y == want).all().item())
+        except Exception:
+            ok_rccl = False
+        return ok_peer, ok_rccl
 
     def all_reduce_sum(self, t: torch.Tensor):
         """In-place fp32 sum over the ranks, enqueued on the stream the caller's kernels run on (crog_syncbn_stats)."""

@@ -32,10 +32,14 @@ class Runtime:
         self.defer_wgrad = {"1": "all", "all": "all", "big": "big"}.get(os.environ.get("CROG_DEFER_WGRAD", "0"), "")
         self._pending_wgrad = []
         self._pending_done = []
+        self._slots = []       # GradSlots filled during the backward pass in flight (functional.GradSlot): all must be empty when it ends
         self._wgrad_stream = None
         self.text_stream = None
         self._streams_ready = False
         self._join_armed = False
+        # deterministic mode (set_deterministic below; CROG_DETERMINISTIC=1): every sum whose order would depend on atomics takes its
+        # ordered form - same inputs, same bits, run after run, eager or replayed
+        self.deterministic = False
         self.seed_base = 0x5EED
         self._seed_ctr = 0
         self.seed_epoch = None   # device int64 added to every dropout seed inside the kernels (enable_seed_epoch)
@@ -79,8 +83,9 @@ class Runtime:
         self._streams_ready = True
 
     def wgrad_stream(self):
-        """The weight-gradient side stream (one: every reduction into a parameter gradient is ordered on it)."""
-        if not self.overlap_wgrad or not torch.cuda.is_available():
+        """The weight-gradient side stream (one: every reduction into a parameter gradient is ordered on it).  None in deterministic
+        mode: weight gradients then stay on the stream of the layer's backward (see set_deterministic)."""
+        if not self.overlap_wgrad or not torch.cuda.is_available() or self.deterministic:
             return None
         if self._wgrad_stream is None:
             self.ensure_streams()
@@ -145,10 +150,26 @@ class Runtime:
             if t is not None:
                 t.record_stream(s)
 
+    def _arm_end_of_backward(self):
+        if not self._join_armed:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+                self._join_armed = True
+            except RuntimeError:      # not inside a backward pass
+                pass
+
+    def watch_slot(self, slot):
+        self._slots.append(slot)
+        self._arm_end_of_backward()
+
     def _end_of_backward(self):
         self._join_armed = False
         self.flush_wgrad()
         self.join_streams()
+        slots, self._slots = self._slots, []
+        if any(s.t is not None for s in slots):
+            raise RuntimeError("crog_amd GradSlot: a residual / downsample gradient was parked for an op whose backward never took it "
+                               "(it would have been dropped silently): the autograd order the slot relies on did not hold for this backward")
 
     def join_streams(self):
         """Make the current stream wait for every side stream (before the optimizer step / gradient zeroing)."""
@@ -208,6 +229,30 @@ class Runtime:
 
 
 RT = Runtime()
+
+
+def set_deterministic(on: bool = True):
+    """Switch the bit-reproducible mode on or off, for the kernel library (crog_set_deterministic: ordered forms of the embedding
+    scatter, the head's bias / tap sums, the loss sums and the long-slab reductions) and for the launch policy of this package
+    (functional.py: BatchNorm / LayerNorm statistics as per-tile slabs + ordered reduction - the fp32 parity mode's path - for bf16
+    too, no BatchNorm-backward statistics in GEMM epilogues, split-K weight gradients as slabs + crog_splitk_reduce, bias gradients
+    by the two-pass column sum instead of a_sum), and the weight gradients stay on the main stream.  The last point is empirical:
+    with the weight-gradient stream forked, a LayerNorm backward launch running BESIDE a weight-gradient GEMM returned rows that
+    differed in the last bf16 bit from run to run (6 of 2704 rows at B = 4, identical inputs - cloned around the launch - and
+    bit-identical outputs whenever the launch was fenced or the side stream switched off; LAB_NOTES.md, round 4).  Not understood;
+    until it is, "deterministic" means one stream for everything that feeds a gradient.  Call it before the first step and outside a
+    capture (it allocates the library's scratch once)."""
+    K.check(K.lib().crog_set_deterministic(1 if on else 0), "set_deterministic")
+    RT.deterministic = bool(on)
+
+
+def slab_scratch(n: int, device) -> torch.Tensor:
+    """n fp32 elements of scratch for a launch that may run on the weight-gradient stream (split-K slabs): the block is kept from
+    being handed out again while that stream still uses it."""
+    t = torch.empty(n, device=device, dtype=torch.float32)
+    if K._STREAM_OVERRIDE is not None and RT._wgrad_stream:
+        t.record_stream(RT._wgrad_stream[0])
+    return t
 
 
 _LEGACY_SYNC = False   # (round-1 A/B: always memset G in zero_grad, always re-cast the shadow per forward)

@@ -49,6 +49,13 @@ int crog_probe_copy(const void* src, void* dst, int64_t bytes, int mode, crog_st
  * launch state like the current device: set once, before the first launch that should see it.  crog_counter_add: *counter += inc
  * on `stream` (the captured step advances the epoch by the number of seeds one step draws). */
 int crog_set_seed_epoch(const uint64_t* epoch_dev);
+/* Deterministic mode: process-wide launch state (like the seed epoch).  on != 0: every entry point whose result would otherwise depend
+ * on the arrival order of fp32 atomic adds launches an order-independent form instead - crog_reduce_pairs (ordered slab reduction),
+ * crog_embedding_bwd (one gatherer per destination row), crog_head_tap_sums / crog_head_cb_bwd / crog_head_loss (per-block partials
+ * summed in block order; the scratch they need is allocated by THIS call, never by a launch).  The caller's side of the mode lives in
+ * crog_amd/runtime.py set_deterministic: BatchNorm / LayerNorm statistics as slabs (stat_replicas 0, partial != NULL), split-K weight
+ * gradients as CROG_OUT_F32 slabs + crog_splitk_reduce, no a_sum.  Same inputs, same bits, run after run (crog_engine.py:72-84). */
+int crog_set_deterministic(int on);
 int crog_counter_add(uint64_t* counter_dev, uint64_t inc, crog_stream_t stream);
 
 /* Stream-faithful replay of a captured training step (csrc/replay.hip; replaces the ~1300 Python -> ctypes launches per step of
@@ -433,7 +440,8 @@ int crog_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, 
  *                        (peer writes + flag poll, sums formed in rank order: bit-identical on all ranks) when count fits a mailbox
  *                        slot, ncclAllReduce otherwise.  Capture-safe (the exchange counter lives in the mailbox)
  *   crog_allreduce_bucket  in-place ncclAllReduce (SUM, or AVG when `average`) of a gradient bucket, fp32 or bf16, on `stream`
- *   crog_comm_status     *timed_out_seq != 0: an exchange gave up waiting for a peer (120 s by default, CROG_COMM_TIMEOUT_S) - the training state is invalid
+ *   crog_comm_status     *timed_out_seq != 0: an exchange gave up waiting for a peer (120 s by default, CROG_COMM_TIMEOUT_S) - the training state
+ *                        is invalid: that exchange and every later one of the communicator return NaN statistics instead of local sums
  * RCCL is bound at run time (dlopen of the librccl.so already resident in the process; CROG_RCCL_LIB overrides): the library has no
  * link-time dependency on it. */
 int crog_comm_unique_id(void* id128);

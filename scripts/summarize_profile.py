@@ -44,7 +44,7 @@ if tb: L += ["", f"Measured HBM traffic of the training steps: {tb/1e9:.1f} GB o
                  f"the peak probes of bench.py moved another {tp/1e9:.1f} GB and are left out); algorithmic 56.2 GB/step (1.58 GB/img x 32 + 5.6 GB)."]
 # per-launch HBM traffic of the GEMM kernels whose (A layout, B layout) can be read off the mangled name; bench.py reports it as roofline.traffic
 import json
-names = {(1, 0): "conv3x3_fwd", (1, 2): "conv3x3_dgrad", (2, 3): "conv3x3_wgrad", (0, 0): "lin_fwd"}
+names = {(1, 0): "conv3x3_fwd", (1, 2): "conv3x3_dgrad", (2, 3): "conv3x3_wgrad", (0, 0): "lin_fwd", (2, 1): "lin_wgrad"}
 pm = {}
 for k in f:   # one roofline key can cover several tile-shape instantiations of the kernel: aggregate launches and bytes
     m = re.search(r"gemm_dma_kernelIDF16bLi(\d)ELi(\d)E", k)

@@ -21,6 +21,7 @@ class Net(torch.nn.Module):
         self.c = torch.nn.Conv2d(2, 3, 3, bias=False)
         self.b = torch.nn.Linear(40, 5)
         self.unused = torch.nn.Parameter(torch.ones(7))    # like CLIP.logit_scale: never receives a gradient
+        self.register_buffer("running", torch.zeros(3))    # like a BatchNorm running statistic
         self.explicit_grad_ready = False
         self._store = None
 
@@ -48,12 +49,15 @@ def _worker(rank, world, port, tmp):
     g = torch.Generator().manual_seed(7)
     X, I = torch.randn(8, 12, generator=g), torch.randn(8, 2, 6, 6, generator=g)
     xs, im = X[rank * 4:(rank + 1) * 4], I[rank * 4:(rank + 1) * 4]
+    # broadcast_buffers=True (torch DDP's default, train_crog.py:154-156) without SyncBatchNorm: rank 0's buffers win at every forward
+    net.running.fill_(10.0 + rank)
     for step in range(2):
         net.store.zero_grad()
         loss = ddp(xs, im)
         loss.backward()
         ddp.reducer.wait()
     assert len(ddp.reducer.buckets) > 2
+    assert torch.equal(net.running, torch.full((3,), 10.0)), (rank, net.running)
     # cross-replica BatchNorm statistics: all-reduce of (sum, sum^2) pairs
     convert_sync_batchnorm(net)         # installs the statistics communicator on a process group of its own
     comm = RT.comm

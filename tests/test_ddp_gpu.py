@@ -68,6 +68,9 @@ def test_ddp_syncbn_world1_matches_plain_step(rccl_world1, monkeypatch, text_gra
         torch.cuda.synchronize()
         if wrap:   # the reducer is built at the first forward: several buckets must have been in flight
             assert len(net.reducer.buckets) > 3
+            # ... through the C-ABI communicators the job selected by itself (self-tested at start-up): crog_allreduce_bucket / crog_syncbn_stats
+            assert net.bucket_comm is not None and net.reducer.direct is net.bucket_comm and RT.comm.kind.startswith("crog_comm:"), RT.comm.kind
+            RT.comm.check()
         res = out, model.store.P.clone(), {k: v.clone() for k, v in model.state_dict().items() if "running_" in k}
         if wrap:
             RT.comm = None

@@ -97,6 +97,9 @@ def test_config1_crog_r50_fp32_on_reference_conditioned_weights(case):
     print(f"{case} gradient norms: worst relative error image side %.2e, text side %.2e" % (float(rel[~text_side].max()), float(rel[text_side].max())))
     bad = ((gn - ref).abs() > 2e-2 * ref + 2e-5) & ~text_side
     assert not bad.any(), [(names[i], float(gn[i]), float(ref[i])) for i in bad.nonzero().flatten()[:8]]
+    if meta["B"] >= 4:      # with four samples txt_proj's BatchNorm1d is well conditioned: the twelve text blocks' backward is held to 3 %
+        bad_t = ((gn - ref).abs() > 3e-2 * ref + 2e-5) & text_side
+        assert not bad_t.any(), [(names[i], float(gn[i]), float(ref[i])) for i in bad_t.nonzero().flatten()[:8]]
     for k in g:
         if k.startswith("grad::"):
             r, a = g[k], params[k[6:]].grad.detach().cpu()
@@ -161,12 +164,13 @@ def test_bf16_training_step_against_the_reference_under_bf16_autocast():
     cos = lambda a, r: float(1 - torch.dot(a.flatten().float(), r.flatten()) / (a.float().norm() * r.norm() + 1e-30))
     for k in pinned:
         refd["1-cos:" + k[6:]] = cos(gbf[k], g32[k])
-    # The HIP bf16 step is not bit-reproducible: its BatchNorm sums are fp32 atomics whose order changes from run to run, and every
-    # bf16 rounding after them amplifies that - twelve passes over the same batch (scripts history, round 3) gave losses of
-    # 9.69 ... 9.95 around the fp32 fixture's 9.787, i.e. a SINGLE pass sits anywhere between 0 and 2x the reference-bf16 distance.
-    # The yardstick (one deterministic CPU run) has no such spread, so each metric is the MEDIAN over seven passes.
+    # Deterministic mode (round 4): ONE pass is the measurement - the default mode's BatchNorm sums are fp32 atomics whose order changes
+    # from run to run, and twelve passes over this batch gave losses of 9.69 ... 9.95 around the fp32 fixture's 9.787 (round 3 took the
+    # median of seven).  A second pass checks that the mode is what it says: the same numbers, bit for bit.
+    from crog_amd.runtime import set_deterministic
+    set_deterministic(True)
     runs = []
-    for it in range(7):
+    for it in range(2):
         if it:
             model._store.zero_grad()
         preds, tgts, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
@@ -176,23 +180,25 @@ def test_bf16_training_step_against_the_reference_under_bf16_autocast():
         for k in pinned:
             d["1-cos:" + k[6:]] = cos(params[k[6:]].grad.detach().cpu(), g32[k])
         runs.append(d)
-    hip = {k: float(np.median([r[k] for r in runs])) for k in runs[0]}
-    spread = {k: (min(r[k] for r in runs), max(r[k] for r in runs)) for k in runs[0]}
+    set_deterministic(False)
+    assert runs[0] == runs[1], {k: (runs[0][k], runs[1][k]) for k in runs[0] if runs[0][k] != runs[1][k]}
+    hip = runs[0]
+    spread = {k: (runs[0][k], runs[1][k]) for k in runs[0]}
     worst = {}
     ratios = []
     for k in sorted(hip):
         # floors: what the yardstick itself does not resolve.  A gradient-norm deviation below 1 % is bf16 rounding on either side (the
         # reference's own 90th percentiles run from 0.9 % to 7 % across the groups, and `proj` has eleven tensors: its p90 is one tensor)
         floor = {"logit_rms": 1e-4, "loss": 2e-3}.get(k, 1e-2 if k.startswith("gnorm_p90") else (2e-3 if k.startswith("gnorm") else 2e-4))
-        # the text tower is held to 2x: under autocast the reference keeps its residual stream in fp32 (fp32 embeddings + bf16 branch
-        # outputs promote), the HIP path stores every activation in bf16 - twelve blocks of that are worth 1.3-1.5x on the gradient
-        # norms (measured 3.5-4.1 % median against the reference's 2.7 %, run-to-run spread included).
+        # (round 4, one deterministic pass: the text tower - whose residual stream the reference keeps in fp32 under autocast while the
+        # HIP path stores every activation in bf16 - measures 3.0 % median against the reference's 2.7 %, inside 1.5x like the rest;
+        # round 3 needed 2x for it because the measurement itself had a 3.5-4.1 % spread.)
         # A single pinned gradient (a BatchNorm weight's 64 ... 2048 numbers, 1 - cos ~ 0.3 on BOTH sides: mostly rounding noise) is
         # held to 2x; the pinned gradients TOGETHER (median ratio below) to 1.25x.
         # The decoder is held to 2x for the same reason as the text tower: torch's autocast runs layer_norm and softmax in fp32 and
         # hands their fp32 outputs on (six LayerNorms and two softmaxes per decoder layer), the HIP path rounds each of them to bf16
-        # (measured: median over passes 1.9-2.2 % against the reference's 1.1 %).
-        mult = 2.0 if ("text tower" in k or k.endswith(":decoder") or k.startswith("1-cos:")) else 1.5
+        # (measured, one deterministic pass: 2.16 % against the reference's 1.15 %).
+        mult = 2.0 if (k.endswith(":decoder") or k.startswith("1-cos:")) else 1.5
         lim = mult * refd[k] + floor
         print(f"  {k:45s} HIP bf16 {hip[k]:.3e} [{spread[k][0]:.3e} .. {spread[k][1]:.3e}]   reference bf16 {refd[k]:.3e}   bound {lim:.3e}")
         if hip[k] > lim:

@@ -249,24 +249,40 @@ def _forced_ddp_graph_case():
             net = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True, force=True, bucket_cap_mb=0.25)
             opt.attach(model.store)        # the wrapper re-homed the parameters (prepare): the optimizer follows, as in bench.py
             RT.manual_seed(3)
-            graphed = GraphedTrainStep(net, opt, cfg, torch.bfloat16, warmup=3) if graph else None
+            # the job picks its transports itself (start-up self-test, collective verdict): at world size 1 both pass, so the
+            # statistics go through the C-ABI communicator, the buckets through crog_allreduce_bucket, and the step is capturable
+            from crog_amd.parallel import step_is_capturable
+            assert RT.comm.kind.startswith("crog_comm:") and "rccl" in RT.comm.kind, RT.comm.kind
+            assert net.bucket_comm is not None and step_is_capturable(net)
+            graphed = GraphedTrainStep(net, opt, cfg, torch.bfloat16, warmup=3, verify=True) if graph else None
+            if graph == "reject":          # a replay that does not reproduce the eager step: the first-replay check must refuse the graph
+                real = graphed._replay_once
+                graphed._replay_once = lambda b, profile=False: tuple((3.0 * real(b, profile)[0], None))
             out = []
             for b in batches:
                 st, _ = graphed(b) if graph else train_step(net, opt, None, b, cfg, autocast_dtype=torch.bfloat16)
                 out.append(st.clone())
             torch.cuda.synchronize()
-            if graph:
-                assert graphed.failed is None and graphed.replays == 3, graphed.failed
+            assert net.reducer.direct is net.bucket_comm
+            if graph == "reject":
+                assert graphed.verified is False and graphed.failed is not None and graphed.graph is None and graphed.replay_handle is None
+            elif graph:
+                assert graphed.failed is None and graphed.verified is True and graphed.replays == 3, graphed.failed
                 assert graphed.collectives["syncbn"] > 0 and graphed.collectives["buckets"] > 1
             return torch.stack(out).cpu(), model.store.P.clone()
         s0, p0 = run(False)
         s1, p1 = run(False)
         s3, p3 = run(False)
         s2, p2 = run(True)
+        s4, p4 = run("reject")
         # (three eager runs, largest pairwise distance, factor 6: see test_replayed_steps_equal_eager_steps)
         noise_l = max((a[:, 0] - b[:, 0]).abs().max().item() for a, b in ((s0, s1), (s0, s3), (s1, s3)))
+        noise_p = max(_rel(p0, p1), _rel(p0, p3), _rel(p1, p3))
         assert (s0[:, 0] - s2[:, 0]).abs().max().item() <= max(6 * noise_l, 5e-2), (noise_l, s0, s2)
-        assert _rel(p0, p2) <= max(6 * max(_rel(p0, p1), _rel(p0, p3), _rel(p1, p3)), 1e-4)
+        assert _rel(p0, p2) <= max(6 * noise_p, 1e-4)
+        # the refused graph left no trace: the state was rewound and every step ran eagerly
+        assert (s0[:, 0] - s4[:, 0]).abs().max().item() <= max(6 * noise_l, 5e-2), (noise_l, s0, s4)
+        assert _rel(p0, p4) <= max(6 * noise_p, 1e-4)
     finally:
         RT.comm = None
         RT.reducer = None
