@@ -28,6 +28,7 @@ class _Chunk:
 class FusedAdam(torch.optim.Optimizer):
     # elements per chunk of the overlapped update (16 M floats = 64 MiB of parameters: ~0.1 ms of Adam, nine chunks for CROG-R50)
     CHUNK_ELEMS = 1 << 24
+    FIRST_CHUNK_ELEMS = 1 << 20
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, store: ParamStore = None, capturable: bool = False):
         """capturable: the step count, its bias corrections and the learning rates live in device memory (one float[4] per
@@ -91,11 +92,15 @@ class FusedAdam(torch.optim.Optimizer):
         self._chunks, self._chunk_of = [], {}
         self._done_counts = None
         for gi, group in enumerate(self.param_groups):
-            cur = None
+            cur, made = None, 0
             for o, n, p in sorted((store.off(p), (p.numel() + ALIGN - 1) // ALIGN * ALIGN, p) for p in group["params"]):
-                if cur is None or cur.off + cur.numel != o or cur.numel + n > self.CHUNK_ELEMS:
+                # (the first chunk of a group is kept small: in CROG it holds the stem / layer1 weights, whose gradients are the LAST
+                # of the step - what step() still has to update after backward is then ~1 M parameters, not 16 M)
+                cap = self.FIRST_CHUNK_ELEMS if made == 1 else self.CHUNK_ELEMS
+                if cur is None or cur.off + cur.numel != o or cur.numel + n > cap:
                     cur = _Chunk(gi, o)
                     self._chunks.append(cur)
+                    made += 1
                 cur.numel += n
                 cur.params.append(p)
                 self._chunk_of[id(p)] = cur

@@ -186,6 +186,10 @@ class Runtime:
 
     def begin_step(self, device):
         """Called once per training forward: clears the zero pool and rewinds its bump pointer."""
+        if not getattr(self, "_env_checked", False):      # CROG_DETERMINISTIC=1: the bit-reproducible mode from the first step on
+            self._env_checked = True
+            if os.environ.get("CROG_DETERMINISTIC") == "1" and not self.deterministic and not torch.cuda.is_current_stream_capturing():
+                set_deterministic(True)
         if getattr(self, "_zpool", None) is None or self._zpool.device != device:
             self._zpool = torch.zeros(self.ZERO_POOL, device=device, dtype=torch.float32)
         else:

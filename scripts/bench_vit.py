@@ -26,3 +26,9 @@ torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / N * 1e3
 T, W = 197, 768
 flops = 3 * 2 * B * T * (12 * 12 * W * W + 12 * 2 * T * W) + 3 * 2 * B * 196 * (768 * 768 + 768 * 512)
 print(f"ViT-B/16 B={B} fwd+bwd {ms:.2f} ms  {B / ms * 1e3:.0f} img/s  {flops / ms / 1e9:.0f} TFLOP/s", flush=True)
+import json
+print(json.dumps({"metric": "encoder images/sec CLIP ViT-B/16 224x224 bs%d/GPU (forward + backward, encoder level: the reference has no end-to-end ViT path)" % B,
+                  "value": round(B / ms * 1e3, 1), "unit": "images/sec", "n_gpus": 1, "steps": N, "warmup": 3, "ms_per_step": round(ms, 3),
+                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                  "config": {"workload": "BASELINE config 4: CLIP ViT-B/16 image tower, fwd + bwd under a linear surrogate loss, eager issue", "global_batch": B, "parallelism": "dp1"},
+                  "step_roofline": {"mfma_frac": round(flops / ms / 1e9 / 2500.0, 4), "note": "analytic FLOPs of the 12 blocks + patch / output projections vs 2.5 PFLOP/s"}}), flush=True)
