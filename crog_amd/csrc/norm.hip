@@ -856,6 +856,277 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over WIDE rows (more than 128 16-byte vectors: the decoder's LayerNorm(2048) inside the FFN, layers.py:299-300): one row
+// per BLOCK iteration, thread t owns the vectors t + 256 j.  The wave-per-row kernels above need 184 (forward) / 268 (backward)
+// VGPRs at this width - one wave per SIMD, nothing to hide the load latency behind: 21632 x 2048 bf16 ran at 1.8 / 1.07 TB/s.  Here a
+// thread holds one vector per tensor (and the next row's, prefetched), the row's two sums cross the four waves through LDS - one
+// barrier per row, slots alternating by row parity - and each thread owns its columns' (dgamma, dbeta) for the whole block.
+// Same arguments and results as ln_fwd_kernel / ln_bwd_kernel (the order of the fp32 row sums differs).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NVT>
+__global__ void __launch_bounds__(NT) ln_fwd_row_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, long M, int C, T* __restrict__ out,
+                                                        long ldo, float* __restrict__ stats, const T* __restrict__ res, long ldr,
+                                                        T* __restrict__ out2, long ldo2, const T* __restrict__ pos, int pos_rows, long ldp,
+                                                        float p_in, uint64_t seed_in, float p_out, uint64_t seed_out,
+                                                        const uint64_t* __restrict__ epoch) {
+  constexpr int VEC = Elem<T>::VEC, NW = NT / 64;
+  if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cvec = C / VEC;
+  const uint32_t thr_in = attn_thr16(p_in), thr_out = attn_thr16(p_out);
+  const float sc_in = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, sc_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
+  const float invC = 1.f / C;
+  __shared__ float red[2][NW][2];
+  float nel[NW];      // elements of the row each wave owns (a row narrower than 256 NVT vectors leaves the last waves short)
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < NVT; j++) n += min(max(cvec - (w * 64 + j * NT), 0), 64);
+    nel[w] = (float)(n * VEC);
+  }
+  long row = blockIdx.x;
+  Vec16<T> cur[NVT], nxt[NVT];
+#pragma unroll
+  for (int j = 0; j < NVT; j++) {
+    const int cv = threadIdx.x + j * NT;
+    if (row < M && cv < cvec) cur[j] = ldg16(x + row * ldx + cv * VEC);
+  }
+  for (int par = 0; row < M; row += gridDim.x, par ^= 1) {
+    const long nrow = row + gridDim.x;
+    Vec16<T> rv[NVT], pv[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; j++) {
+      const int cv = threadIdx.x + j * NT;
+      if (cv < cvec) {
+        if (nrow < M) nxt[j] = ldg16(x + nrow * ldx + cv * VEC);
+        if (res) rv[j] = ldg16(res + row * ldr + cv * VEC);
+        if (out2 && pos) pv[j] = ldg16(pos + (row % pos_rows) * ldp + cv * VEC);
+      }
+    }
+    float vals[NVT][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVT; j++) {
+      const int cv = threadIdx.x + j * NT;
+      if (cv < cvec) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) vals[j][e] = Elem<T>::to_f(cur[j].v[e]);
+        if (p_in > 0.f) dropout_apply<VEC>(vals[j], seed_in, (uint64_t)row * C + cv * VEC, thr_in, sc_in);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) s += vals[j][e];
+      }
+    }
+    // per-wave (sum, centred sum of squares), combined exactly: Q = sum_w [ q_w + n_w (m_w - mean)^2 ]
+    const float sw = wave_sum(s);
+    const float mw = nel[wv] > 0.f ? sw / nel[wv] : 0.f;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVT; j++) {
+      const int cv = threadIdx.x + j * NT;
+      if (cv < cvec)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          const float d = vals[j][e] - mw;
+          q += d * d;
+        }
+    }
+    const float qw = wave_sum(q);
+    if (lane == 0) { red[par][wv][0] = sw; red[par][wv][1] = qw; }
+    __syncthreads();
+    float S = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) S += red[par][w][0];
+    const float mean = S * invC;
+    float Q = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const float d = (nel[w] > 0.f ? red[par][w][0] / nel[w] : mean) - mean;
+      Q += red[par][w][1] + nel[w] * d * d;
+    }
+    const float rstd = rsqrtf(Q * invC + eps);
+    if (threadIdx.x == 0 && stats) {
+      stats[2 * row] = mean;
+      stats[2 * row + 1] = rstd;
+    }
+#pragma unroll
+    for (int j = 0; j < NVT; j++) {
+      const int cv = threadIdx.x + j * NT;
+      if (cv < cvec) {
+        const int c = cv * VEC;
+        Vec16<T> o;
+        float gv[VEC], bv[VEC], f[VEC];
+        ld_f32v<VEC>(gamma + c, gv);
+        ld_f32v<VEC>(beta + c, bv);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) f[e] = (vals[j][e] - mean) * rstd * gv[e] + bv[e];
+        if (p_out > 0.f) dropout_apply<VEC>(f, seed_out, (uint64_t)row * C + c, thr_out, sc_out);
+        if (res) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) f[e] += Elem<T>::to_f(rv[j].v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(f[e]);
+        stg16(out + row * ldo + c, o);
+        if (out2) {
+          Vec16<T> o2;
+#pragma unroll
+          for (int e = 0; e < VEC; e++) o2.v[e] = Elem<T>::from_f(Elem<T>::to_f(o.v[e]) + (pos ? Elem<T>::to_f(pv[j].v[e]) : 0.f));
+          stg16(out2 + row * ldo2 + c, o2);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVT; j++) cur[j] = nxt[j];
+  }
+}
+
+template <typename T, int NVT>
+__global__ void __launch_bounds__(NT) ln_bwd_row_kernel(const T* __restrict__ dout, long lddo, const T* __restrict__ dout2, long lddo2,
+                                                        const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ stats, long M, int C, T* __restrict__ dx, long lddx,
+                                                        float* __restrict__ partial, int rows_per_block, float p_in, uint64_t seed_in,
+                                                        float p_out, uint64_t seed_out, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        const uint64_t* __restrict__ epoch, const T* __restrict__ dxadd, long lddxa) {
+  constexpr int VEC = Elem<T>::VEC, NW = NT / 64;
+  if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cvec = C / VEC;
+  const uint32_t thr_in = attn_thr16(p_in), thr_out = attn_thr16(p_out);
+  const float sc_in = p_in > 0.f ? 1.f / (1.f - p_in) : 1.f, sc_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
+  const float invC = 1.f / C;
+  __shared__ float red[2][NW][2];
+  __shared__ float colsum[2][NVT * NT * VEC];      // (dgamma, dbeta) of the block, staged for the contiguous atomic adds
+  float dg[NVT][VEC], db[NVT][VEC], gm[NVT][VEC];
+#pragma unroll
+  for (int j = 0; j < NVT; j++) {
+    const int cv = threadIdx.x + j * NT;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) dg[j][e] = db[j][e] = gm[j][e] = 0.f;
+    if (cv < cvec) ld_f32v<VEC>(gamma + cv * VEC, gm[j]);
+  }
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(r0 + rows_per_block, M);
+  Vec16<T> cg[NVT], cg2[NVT], cx[NVT], ca[NVT], ng[NVT], ng2[NVT], nx[NVT], na[NVT];
+#pragma unroll
+  for (int j = 0; j < NVT; j++) {
+    const int cv = threadIdx.x + j * NT;
+    if (r0 < r1 && cv < cvec) {
+      cg[j] = ldg16(dout + r0 * lddo + cv * VEC);
+      if (dout2) cg2[j] = ldg16(dout2 + r0 * lddo2 + cv * VEC);
+      cx[j] = ldg16(x + r0 * ldx + cv * VEC);
+      if (dxadd) ca[j] = ldg16(dxadd + r0 * lddxa + cv * VEC);
+    }
+  }
+  int par = 0;
+  for (long row = r0; row < r1; row++, par ^= 1) {
+    const long nrow = row + 1;
+    if (nrow < r1) {
+#pragma unroll
+      for (int j = 0; j < NVT; j++) {
+        const int cv = threadIdx.x + j * NT;
+        if (cv < cvec) {
+          ng[j] = ldg16(dout + nrow * lddo + cv * VEC);
+          if (dout2) ng2[j] = ldg16(dout2 + nrow * lddo2 + cv * VEC);
+          nx[j] = ldg16(x + nrow * ldx + cv * VEC);
+          if (dxadd) na[j] = ldg16(dxadd + nrow * lddxa + cv * VEC);
+        }
+      }
+    }
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[NVT][VEC], gy[NVT][VEC];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVT; j++) {
+      const int cv = threadIdx.x + j * NT;
+      if (cv < cvec) {
+        const int c = cv * VEC;
+        float gf[VEC], xf[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) { gf[e] = Elem<T>::to_f(cg[j].v[e]); xf[e] = Elem<T>::to_f(cx[j].v[e]); }
+        if (dout2) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) gf[e] += Elem<T>::to_f(cg2[j].v[e]);
+        }
+        if (p_out > 0.f) dropout_apply<VEC>(gf, seed_out, (uint64_t)row * C + c, thr_out, sc_out);
+        if (p_in > 0.f) dropout_apply<VEC>(xf, seed_in, (uint64_t)row * C + c, thr_in, sc_in);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          const float h = (xf[e] - mean) * rstd;
+          xh[j][e] = h;
+          dg[j][e] += gf[e] * h;
+          db[j][e] += gf[e];
+          const float gyv = gf[e] * gm[j][e];
+          gy[j][e] = gyv;
+          a += gyv;
+          b += gyv * h;
+        }
+      }
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) { red[par][wv][0] = a; red[par][wv][1] = b; }
+    __syncthreads();
+    a = b = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { a += red[par][w][0]; b += red[par][w][1]; }
+    a *= invC;
+    b *= invC;
+#pragma unroll
+    for (int j = 0; j < NVT; j++) {
+      const int cv = threadIdx.x + j * NT;
+      if (cv < cvec) {
+        const int c = cv * VEC;
+        Vec16<T> o;
+        float d[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) d[e] = rstd * (gy[j][e] - a - xh[j][e] * b);
+        if (p_in > 0.f) dropout_apply<VEC>(d, seed_in, (uint64_t)row * C + c, thr_in, sc_in);
+        if (dxadd) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) d[e] += Elem<T>::to_f(ca[j].v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(d[e]);
+        stg16(dx + row * lddx + c, o);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVT; j++) { cg[j] = ng[j]; cg2[j] = ng2[j]; cx[j] = nx[j]; ca[j] = na[j]; }
+  }
+  if (partial) {      // this block's row of the slab: every thread stores its own columns
+    float* dst = partial + (long)blockIdx.x * C * 2;
+#pragma unroll
+    for (int j = 0; j < NVT; j++) {
+      const int cv = threadIdx.x + j * NT;
+      if (cv < cvec)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          dst[2 * (cv * VEC + e)] = dg[j][e];
+          dst[2 * (cv * VEC + e) + 1] = db[j][e];
+        }
+    }
+  } else {            // ... or adds them to the gradient vectors, consecutive lanes on consecutive addresses (the full-rate atomic shape)
+#pragma unroll
+    for (int j = 0; j < NVT; j++) {
+      const int cv = threadIdx.x + j * NT;
+      if (cv < cvec)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          colsum[0][cv * VEC + e] = dg[j][e];
+          colsum[1][cv * VEC + e] = db[j][e];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) {
+      atomicAdd(dgamma + c, colsum[0][c]);
+      atomicAdd(dbeta + c, colsum[1][c]);
+    }
+  }
+}
+
 // pairs [C][2] -> ADDED to two separate fp32 gradient vectors (dgamma, dbeta)
 __global__ void split_pairs_kernel(const float* __restrict__ sums, int C, float* __restrict__ a, float* __restrict__ b) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1179,10 +1450,15 @@ extern "C" int crog_ln_fwd(int dtype, const void* x, int64_t ldx, const float* g
   DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)x,     \
                                        (long)ldx, gamma, beta, eps, (long)M, C, (T*)out, (long)ldo, stats, (const T*)res, (long)ldr, \
                                        (T*)out2, (long)ldo2, (const T*)pos, pos_rows, (long)ldp, p_in, seed_in, p_out, seed_out, crog_seed_epoch()))
+#define CROG_LN_FWD_ROW(NVT)                                                                                                      \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ln_fwd_row_kernel<T, NVT>), dim3((int)std::min<long>(M, 256 * 8)), dim3(NT), 0, (hipStream_t)stream, (const T*)x, \
+                                       (long)ldx, gamma, beta, eps, (long)M, C, (T*)out, (long)ldo, stats, (const T*)res, (long)ldr, \
+                                       (T*)out2, (long)ldo2, (const T*)pos, pos_rows, (long)ldp, p_in, seed_in, p_out, seed_out, crog_seed_epoch()))
   if (nv <= 1) CROG_LN_FWD(1);
   else if (nv <= 2) CROG_LN_FWD(2);
-  else if (nv <= 4) CROG_LN_FWD(4);
-  else CROG_LN_FWD(8);
+  else if (C / vec <= NT) CROG_LN_FWD_ROW(1);      // wide rows: one row per block iteration (ln_fwd_row_kernel)
+  else CROG_LN_FWD_ROW(2);
+#undef CROG_LN_FWD_ROW
 #undef CROG_LN_FWD
   CROG_LAUNCH_CHECK();
   return CROG_OK;
@@ -1206,10 +1482,16 @@ extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void
                                        (const T*)dout2, (long)lddo2, (const T*)x, (long)ldx, gamma, stats, (long)M, C, (T*)dx,       \
                                        (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out, dgamma, dbeta, crog_seed_epoch(),   \
                                        (const T*)dxadd, (long)lddxa))
+#define CROG_LN_BWD_ROW(NVT)                                                                                                       \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_row_kernel<T, NVT>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dout, (long)lddo, \
+                                       (const T*)dout2, (long)lddo2, (const T*)x, (long)ldx, gamma, stats, (long)M, C, (T*)dx,       \
+                                       (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out, dgamma, dbeta, crog_seed_epoch(),   \
+                                       (const T*)dxadd, (long)lddxa))
   if (nv <= 1) CROG_LN_BWD(1);
   else if (nv <= 2) CROG_LN_BWD(2);
-  else if (nv <= 4) CROG_LN_BWD(4);
-  else CROG_LN_BWD(8);
+  else if (C / vec <= NT) CROG_LN_BWD_ROW(1);      // wide rows: one row per block iteration (ln_bwd_row_kernel)
+  else CROG_LN_BWD_ROW(2);
+#undef CROG_LN_BWD_ROW
 #undef CROG_LN_BWD
   CROG_LAUNCH_CHECK();
   return CROG_OK;

@@ -98,7 +98,9 @@ extern "C" int crog_capture_last_node(crog_stream_t stream, void** node_out) {
   return CROG_OK;
 }
 
-extern "C" int crog_replay_build(void* hip_graph, int max_chains, void** replay_out) {
+namespace {
+// tags: node -> chain index known from the capture (the stream the launch went to), or null: topology only
+int build_replay(void* hip_graph, int max_chains, const std::unordered_map<hipGraphNode_t, int>* tags, int tagged_chains, void** replay_out) {
   CROG_CHECK_ARG(hip_graph && replay_out && max_chains >= 1, "replay_build: graph, output and max_chains >= 1 are required");
   hipGraph_t graph = (hipGraph_t)hip_graph;
   size_t n = 0;
@@ -152,7 +154,7 @@ extern "C" int crog_replay_build(void* hip_graph, int max_chains, void** replay_
   R->graph = graph;
   R->nodes.resize(n);
   R->handles.resize(n);
-  std::vector<int> chain_tail;   // per chain: issue position of its last node
+  std::vector<int> chain_tail(tagged_chains, -1);   // per chain: issue position of its last node
   for (size_t p = 0; p < n; p++) {
     const int v = order[p];
     RNode& nd = R->nodes[p];
@@ -198,12 +200,24 @@ extern "C" int crog_replay_build(void* hip_graph, int max_chains, void** replay_
     }
     // chain = the chain of the first dependency whose node is still a chain tail (stream capture lists the in-stream predecessor first)
     int chain = -1;
+    if (tags) {
+      // the capture knows the stream of every launch of this library; the few others (ATen, memsets, a process group's collectives)
+      // take the topological rule below
+      auto it = tags->find(hs[v]);
+      if (it != tags->end()) chain = it->second;
+    }
     for (int d : deps[v]) {
+      if (chain >= 0) break;
       const int c = R->nodes[pos[d]].chain;
       if (chain_tail[c] == pos[d]) {
         chain = c;
         break;
       }
+    }
+    if (chain < 0 && tags) {
+      // an untagged node without an in-stream predecessor (a root: the first ATen fill of the step; a node after a fork): stay with the
+      // first dependency's chain - a tagged capture knows its streams, a stray chain would only add a queue
+      chain = deps[v].empty() ? 0 : R->nodes[pos[deps[v][0]]].chain;
     }
     if (chain < 0) {
       if ((int)chain_tail.size() < max_chains) {
@@ -250,6 +264,23 @@ extern "C" int crog_replay_build(void* hip_graph, int max_chains, void** replay_
   RP_HIP(hipEventCreateWithFlags(&R->start, evflags), "hipEventCreateWithFlags");
   *replay_out = R;
   return CROG_OK;
+}
+}  // namespace
+
+extern "C" int crog_replay_build(void* hip_graph, int max_chains, void** replay_out) {
+  return build_replay(hip_graph, max_chains, nullptr, 0, replay_out);
+}
+
+extern "C" int crog_replay_build_tagged(void* hip_graph, int max_chains, void* const* nodes, const int* chains, int n_tags, void** replay_out) {
+  CROG_CHECK_ARG(n_tags >= 0 && (n_tags == 0 || (nodes && chains)), "replay_build_tagged: tag arrays missing");
+  std::unordered_map<hipGraphNode_t, int> tags;
+  int top = 0;
+  for (int i = 0; i < n_tags; i++) {
+    CROG_CHECK_ARG(chains[i] >= 0 && chains[i] < max_chains, "replay_build_tagged: chain index out of range");
+    tags[(hipGraphNode_t)nodes[i]] = chains[i];
+    top = std::max(top, chains[i] + 1);
+  }
+  return build_replay(hip_graph, max_chains, &tags, top, replay_out);
 }
 
 extern "C" int crog_replay_info(void* replay, int* n_nodes, int* n_kernels, int* n_chains, int* n_events, int* n_waits, int* chain_sizes,

@@ -265,6 +265,8 @@ class GraphedTrainStep:
         g = torch.cuda.CUDAGraph(keep_graph=True) if own else torch.cuda.CUDAGraph()
         if own and self.profile_key is not None:
             K.CAPTURE_NODES = dict(key=tuple(self.profile_key), nodes=[])
+        if own:
+            K.CAPTURE_TAGS = {}
         host_step = getattr(self.optimizer, "_step", None)
         # the learning rates reach the device state BEFORE the capture opens: a fill launched inside it would become a graph node that
         # rewrites the capture-time rate on every replay, freezing any schedule (step() itself never syncs while capturing)
@@ -276,6 +278,7 @@ class GraphedTrainStep:
             import torch.distributed as dist
             mode = "relaxed" if (dist.is_available() and dist.is_initialized()) else "thread_local"
             with torch.cuda.graph(g, capture_error_mode=mode):
+                self._capture_main = K.stream()      # (torch captures on a stream of its own: the "caller's stream" of this capture)
                 stats, loss_dict = self._body(self.static)
                 if self._seeds_per_step:
                     K.counter_add(RT.seed_epoch, self._seeds_per_step)
@@ -292,21 +295,38 @@ class GraphedTrainStep:
         finally:
             crog_mod.TEXT_GRAPH, K.PROF = saved_text_graph, saved_prof
             captured, K.CAPTURE_NODES = K.CAPTURE_NODES, None
+            tags, K.CAPTURE_TAGS = K.CAPTURE_TAGS, None
             if host_step is not None:
                 self.optimizer._step = host_step      # the capture ran step()'s Python once without executing anything
         if own:
-            self._build_replay(g, captured)
+            self._build_replay(g, captured, tags)
         self.graph, self._stats, self._loss_dict = g, stats, loss_dict
         self._captured_store = self._store()
         self._loss_sums = getattr(loss_dict, "_sums", None)
         self.collectives = dict(syncbn=(RT.comm.calls if RT.comm is not None else 0), buckets=(RT.reducer.launches if RT.reducer is not None else 0))
 
-    def _build_replay(self, g, captured):
+    def _build_replay(self, g, captured, tags=None):
         import ctypes
         from . import kernels as K
         lib = K.lib()
         h = ctypes.c_void_p()
-        K.check(lib.crog_replay_build(ctypes.c_void_p(g.raw_cuda_graph()), 8, ctypes.byref(h)), "replay_build")
+        # chain i of the replay = stream i of this list: the caller's stream, then the runtime's side streams, then whatever else the
+        # capture launched on (in the order it first did)
+        known = [s for s in ((RT._wgrad_stream or []) + [RT.text_stream, RT.aux_stream]) if s is not None]
+        tags = tags or {}
+        raws = [getattr(self, "_capture_main", None)] + [s.cuda_stream for s in known]
+        extra = [r for r in tags if r not in raws]
+        used = [r for r in raws if r in tags or r == raws[0]] + extra
+        pairs = [(nd, used.index(r)) for r, nodes in tags.items() for nd in nodes]
+        if pairs and len(used) <= 8:
+            nodes = (ctypes.c_void_p * len(pairs))(*[nd for nd, _ in pairs])
+            chains = (ctypes.c_int * len(pairs))(*[c for _, c in pairs])
+            K.check(lib.crog_replay_build_tagged(ctypes.c_void_p(g.raw_cuda_graph()), 8, nodes, chains, len(pairs), ctypes.byref(h)), "replay_build_tagged")
+            by_raw = {s.cuda_stream: s for s in known}
+            self._tagged_streams = [by_raw.get(r) for r in used]
+        else:
+            K.check(lib.crog_replay_build(ctypes.c_void_p(g.raw_cuda_graph()), 8, ctypes.byref(h)), "replay_build")
+            self._tagged_streams = None
         n = [ctypes.c_int() for _ in range(5)]
         sizes = (ctypes.c_int * 8)()
         K.check(lib.crog_replay_info(h, *[ctypes.byref(x) for x in n], sizes, 8), "replay_info")
@@ -314,10 +334,17 @@ class GraphedTrainStep:
         self.replay_info = dict(nodes=n[0].value, kernels=n[1].value, chains=n[2].value, events=n[3].value, waits=n[4].value,
                                 chain_sizes=list(sizes)[:n[2].value])
         # one stream per chain: the caller's current stream, then the runtime's weight-gradient and text streams, then fresh ones
-        pool = [s for s in ((RT._wgrad_stream or []) + [RT.text_stream]) if s is not None]
-        while len(pool) < n[2].value - 1:
-            pool.append(torch.cuda.Stream())
-        self._replay_side = pool[:n[2].value - 1]
+        if self._tagged_streams is not None:
+            # (a stream the capture used but the runtime does not own - none in CROG - gets a fresh stand-in)
+            side = [s if s is not None else torch.cuda.Stream() for s in self._tagged_streams[1:]]
+            while len(side) < n[2].value - 1:
+                side.append(torch.cuda.Stream())
+            self._replay_side = side[:n[2].value - 1]
+        else:
+            pool = [s for s in ((RT._wgrad_stream or []) + [RT.text_stream, RT.aux_stream]) if s is not None]
+            while len(pool) < n[2].value - 1:
+                pool.append(torch.cuda.Stream())
+            self._replay_side = pool[:n[2].value - 1]
         if captured is not None and captured["nodes"]:
             self.prof_nodes = captured["nodes"]
             arr = (ctypes.c_void_p * len(self.prof_nodes))(*[nd for nd, _, _ in self.prof_nodes])

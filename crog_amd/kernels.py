@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, check
+from ._lib import GemmDesc, check as _check
 
 F32, BF16 = 0, 1
 A_KC, A_IM2COL, A_MC = 0, 1, 2
@@ -27,6 +27,9 @@ PROF = None
 # While a training step is being captured for replay (crog_amd/graphs.py): {"key": (a_layout, b_layout), "nodes": []} collects the
 # graph node of every launch of that variant, so that the replay can put a timer pair around exactly those launches
 CAPTURE_NODES = None
+# ... and {raw stream: [graph nodes]}: after every launch of this library the node it created is noted under the stream it went to, so that
+# the replay re-issues each node on the stream it was captured on (crog_replay_build_tagged)
+CAPTURE_TAGS = None
 DEBUG_FLAGS = 0  # ablation / A-B bits of crog_gemm_desc.debug (set by tests and scripts/ablate_gemm.py); 0 in production
 GEMM_SYMBOL = {
     (A_KC, B_KC): "gemm_pp_kernel<A_KC, 4|3, 5> (>= 150 tiles of 256 x 256) / gemm_dma16_kernel<A_KC, 128x128> / gemm_dma_kernel<T, A_KC, B_KC>  "
@@ -43,6 +46,12 @@ GEMM_SYMBOL = {
 
 def lib():
     return _lib.load()
+
+
+def check(rc: int, what: str = ""):
+    _check(rc, what)
+    if CAPTURE_TAGS is not None:
+        _tag_last_launch()
 
 
 class Timer:
@@ -93,14 +102,27 @@ def set_stream_override(raw):
 def stream() -> int:
     """Raw hipStream_t of torch's current stream.  torch.cuda.current_stream() costs ~8 us of Python per call (device-index
     plumbing) and is hit once per kernel launch (~1300 per step); the raw accessor is ~0.3 us."""
-    global _DEV_INDEX
+    global _DEV_INDEX, _LAST_STREAM
     if _STREAM_OVERRIDE is not None:
+        _LAST_STREAM = _STREAM_OVERRIDE
         return _STREAM_OVERRIDE
     if _RAW_STREAM is None:
-        return torch.cuda.current_stream().cuda_stream
+        _LAST_STREAM = torch.cuda.current_stream().cuda_stream
+        return _LAST_STREAM
     if _DEV_INDEX is None:
         _DEV_INDEX = torch.cuda.current_device()
-    return _RAW_STREAM(_DEV_INDEX)
+    _LAST_STREAM = _RAW_STREAM(_DEV_INDEX)
+    return _LAST_STREAM
+
+
+_LAST_STREAM = None
+
+
+def _tag_last_launch():
+    """Capture only: note the graph node at the tail of the stream the last launch used."""
+    node = ctypes.c_void_p()
+    if _LAST_STREAM is not None and lib().crog_capture_last_node(_LAST_STREAM, ctypes.byref(node)) == 0 and node.value:
+        CAPTURE_TAGS.setdefault(_LAST_STREAM, []).append(node.value)
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

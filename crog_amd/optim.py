@@ -155,7 +155,7 @@ class FusedAdam(torch.optim.Optimizer):
         c.fired = True
         store, group = self._store, self.param_groups[c.gi]
         b1, b2 = group["betas"]
-        side = RT.wgrad_stream() if early else None
+        side = RT.adam_stream() if early else None
         if side is not None:
             # gradients are written on every stream of the step (main chain: norm scales / biases; text tower: its own stream; weight
             # gradients: `side` itself): the launch waits for all of them as they stand now.  The announcement that completed a chunk can

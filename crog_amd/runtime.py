@@ -35,6 +35,12 @@ class Runtime:
         self._slots = []       # GradSlots filled during the backward pass in flight (functional.GradSlot): all must be empty when it ends
         self._wgrad_stream = None
         self.text_stream = None
+        # fourth stream (CROG_AUX_STREAM=1, single rank only; A/B): the text tower's weight gradients and the Adam chunks stepped during
+        # backward.  On the weight-gradient stream both WAIT for the text chain (~200 latency-bound launches that finish with the
+        # image tower's layer1) and hold up the image tower's last weight gradients queued behind them; measured, moving them off
+        # changes nothing (30.00 vs 30.00 ms): the step is bound by the chip's throughput there, not by that queue's order - the
+        # weight gradients that start earlier slow the main chain's layer1 kernels by what they gain (LAB_NOTES section 9)
+        self.aux_stream = None
         self._streams_ready = False
         self._join_armed = False
         # deterministic mode (set_deterministic below; CROG_DETERMINISTIC=1): every sum whose order would depend on atomics takes its
@@ -74,6 +80,12 @@ class Runtime:
                 order += self._wgrad_stream
             self.text_stream = torch.cuda.Stream(device=dev)
             order.append(self.text_stream)
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            if self.overlap_wgrad and not multi and os.environ.get("CROG_AUX_STREAM", "0") == "1":
+                # (a communicator's internal stream takes the fourth hardware queue under DDP: see the note above)
+                self.aux_stream = torch.cuda.Stream(device=dev)
+                order.append(self.aux_stream)
             touch = torch.zeros(8, device=dev)
             for s in order:                     # first USE binds the stream to its hardware queue
                 s.wait_stream(main)
@@ -138,7 +150,10 @@ class Runtime:
             except RuntimeError:
                 pass
         cur = torch.cuda.current_stream()
+        if self.aux_stream is not None and self.text_stream is not None and cur == self.text_stream:
+            s = self.adam_stream()
         s.wait_stream(cur)
+        self._override = s
         # fn() only launches kernels of this library: point them at the side stream directly instead of paying torch's
         # stream-context manager (~25 us of Python) ~150 times per step
         K.set_stream_override(s.cuda_stream)
@@ -146,9 +161,18 @@ class Runtime:
             fn()
         finally:
             K.set_stream_override(None)
+            self._override = None
         for t in tensors:
             if t is not None:
                 t.record_stream(s)
+
+    def adam_stream(self):
+        """Where FusedAdam steps its chunks during backward: the aux stream, else the weight-gradient stream (None: no side streams)."""
+        if self.aux_stream is None or self.deterministic or not self.overlap_wgrad:
+            return self.wgrad_stream()
+        if self.aux_stream not in self.streams:
+            self.streams.append(self.aux_stream)
+        return self.aux_stream
 
     def _arm_end_of_backward(self):
         if not self._join_armed:
@@ -202,10 +226,10 @@ class Runtime:
         n8 = (n + 7) // 8 * 8
         if pool is None or pool.device != device or self._zptr + n8 > pool.numel():
             t = torch.zeros(n, device=device, dtype=torch.float32)
-            if K._STREAM_OVERRIDE is not None and self._wgrad_stream:
-                # the caller launches on the weight-gradient stream (on_wgrad_stream): order that stream behind the fill above and keep
+            if K._STREAM_OVERRIDE is not None and getattr(self, "_override", None) is not None:
+                # the caller launches on a side stream (on_wgrad_stream): order that stream behind the fill above and keep
                 # the block from being handed out again while it is still read there
-                s = self._wgrad_stream[0]
+                s = self._override
                 s.wait_stream(torch.cuda.current_stream())
                 t.record_stream(s)
             return t

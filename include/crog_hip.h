@@ -67,9 +67,14 @@ int crog_counter_add(uint64_t* counter_dev, uint64_t inc, crog_stream_t stream);
  * object (kernel arguments are the node-owned copies).  crog_replay_info: node / kernel / chain / event / wait counts and chain sizes.
  * Per-launch timing inside a replay: crog_capture_last_node (during capture: the node the last launch on `stream` created) gives
  * handles; crog_replay_profile_nodes selects them, _enable switches the timer pairs (timing-only events, no system fence) on for the
- * following launches, _read waits and returns the milliseconds of the LAST profiled launch, in the order the handles were given. */
+ * following launches, _read waits and returns the milliseconds of the LAST profiled launch, in the order the handles were given.
+ * crog_replay_build_tagged: the same, with the chain (= index into crog_replay_launch's streams) of n_tags nodes given by the caller, who
+ * saw which stream each launch went to while capturing (crog_capture_last_node after the launch); untagged nodes (ATen kernels,
+ * memsets) are placed by the topological rule of crog_replay_build.  Topology alone cannot tell a fork from a continuation at the first node of a side stream:
+ * with four streams it merged two chains and split the main one (round 4); tags make the replay use the streams of the capture. */
 int crog_capture_last_node(crog_stream_t stream, void** node_out);
 int crog_replay_build(void* hip_graph, int max_chains, void** replay_out);
+int crog_replay_build_tagged(void* hip_graph, int max_chains, void* const* nodes, const int* chains, int n_tags, void** replay_out);
 int crog_replay_info(void* replay, int* n_nodes, int* n_kernels, int* n_chains, int* n_events, int* n_waits, int* chain_sizes,
                      int chain_sizes_cap);
 int crog_replay_launch(void* replay, const crog_stream_t* streams, int n_streams);

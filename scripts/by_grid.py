@@ -1,8 +1,16 @@
 """Group a rocprofv3 kernel trace by (kernel, grid): ms per step, launches per step, mean duration - the table behind profiles/*_by_grid.txt.
-usage: python scripts/by_grid.py <kernel_trace.csv> <steps executed>"""
+usage: python scripts/by_grid.py <kernel_trace.csv> <steps executed> [rows] [--last K]
+--last K: only the last K complete steps of the trace (a step starts at its stem_im2col launch), i.e. replayed steps only."""
 import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])
+if "--last" in sys.argv:
+    k = int(sys.argv[sys.argv.index("--last") + 1])
+    del sys.argv[sys.argv.index("--last"):sys.argv.index("--last") + 2]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    st = [i for i, r in enumerate(rows) if "stem_im2col" in r["Kernel_Name"]]
+    rows = rows[st[-1 - k]:st[-1]]
+    steps = float(k)
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     name = r["Kernel_Name"]
