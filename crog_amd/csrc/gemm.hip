@@ -23,7 +23,8 @@
 
 // the ping-pong 256 x 256 x 64 kernel (gemm_pp.hip)
 bool crog_gemm_pp_eligible(const crog_gemm_desc& d, int rows);
-int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t s);
+int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t s, bool full = false);
+bool crog_gemm_pp_full_epilogue_ok(const crog_gemm_desc& d);
 // the ping-pong weight-gradient kernel (gemm_ppt.hip)
 bool crog_gemm_ppt_eligible(const crog_gemm_desc& d);
 int crog_gemm_ppt_launch(const crog_gemm_desc& d, int dist, hipStream_t s);
@@ -318,11 +319,6 @@ __device__ inline void flush_a_sum(const float (&asum)[WM], float* dst, int mbas
 // Branch-free activations: a per-lane branch inside the register loops (ocml's tanhf has one at |x| = 0.625) makes the compiler
 // carry the f32x16 accumulators through divergent control flow as whole vectors and spill them.
 // (v_rcp_f32 is within 1 ulp; an IEEE division would add a dozen temporaries per element to loops that hold 64-128 accumulators)
-__device__ inline float act_quickgelu(float v) { return v * __builtin_amdgcn_rcpf(1.f + expf(-1.702f * v)); }
-__device__ inline float act_tanh(float v) {      // (1 - t) / (1 + t), t = e^(-2|v|) in (0, 1]: absolute error ~1 ulp of 1
-  const float t = expf(-2.f * fabsf(v));
-  return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), v);
-}
 
 // value of lane ^ 1 (quad_perm [1, 0, 3, 2]): a DPP move, no LDS
 __device__ inline float dpp_swap1(float v) {
@@ -1800,9 +1796,15 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     // CU and stay on 128 x 128.  (The same tile for 1x1 / linear forwards and data gradients, K = 128 ... 2048: no gain standalone -
     // their reductions are too short to amortise the 128 KiB ring's fill - and +0.4 ms in the step.)
     if constexpr (sizeof(T) == 2) {
-      if (lean_epilogue_ok(d)) {
+      // (launches with a bias / activation / residual take the same tile with its full epilogue: the attention-pool and decoder
+      // linears, the 1x1 data gradients that add the identity path's gradient.  CROG_PP_FULL=0 / debug bit 17: back to the 128 x 128 tile)
+      static const bool pp_full = [] { const char* e = getenv("CROG_PP_FULL"); return !e || atoi(e) != 0; }();
+      const bool lean = lean_epilogue_ok(d);
+      // (measured per shape, single stream: K >= 512 gains 7-29 % - 5408 x 2048 x 2048 72.6 -> 51.6 us, 21632 x 512 x 2048 63 -> 54 -; the
+      // two- and four-k-tile launches that only these epilogues have lose 13-50 %: the ring fill is most of their run)
+      if (lean || (pp_full && !(d.debug & 131072) && (d.K >= 512 || (d.debug & (512 | 1024))) && crog_gemm_pp_full_epilogue_ok(d))) {
         const int rows = pp_rows(d);
-        if (rows) return crog_gemm_pp_launch(d, rows, (d.debug >> 12) & 7, s);
+        if (rows) return crog_gemm_pp_launch(d, rows, (d.debug >> 12) & 7, s, !lean);
       }
     }
     if constexpr (sizeof(T) == 2) {

@@ -44,4 +44,11 @@ __device__ inline void xcd_map(int nwg, int splitk, int& id, int& z) {
 
 __device__ inline void mma32(const bf16x8& a, const bf16x8& b, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
+// epilogue activations (crog_gemm_desc.act)
+__device__ inline float act_quickgelu(float v) { return v * __builtin_amdgcn_rcpf(1.f + expf(-1.702f * v)); }
+__device__ inline float act_tanh(float v) {      // (1 - t) / (1 + t), t = e^(-2|v|) in (0, 1]: absolute error ~1 ulp of 1
+  const float t = expf(-2.f * fabsf(v));
+  return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), v);
+}
+
 }  // namespace

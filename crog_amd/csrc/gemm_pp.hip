@@ -34,8 +34,11 @@ namespace {
 struct PpGeom { int H, W, C; };
 
 // RBQ: 16-row blocks per row quad (4: 256-row tile, 3: 192-row tile for launches the 256-row tile would quantise badly);
-// D: how many half-tiles the DMA runs ahead of the phase that issues it
-template <int AL, int RBQ, int D>
+// D: how many half-tiles the DMA runs ahead of the phase that issues it;
+// EPI: false = the lean epilogue (column statistics + bf16 stores), true = also bias, activation, residual, ReLU after the residual
+// (crog_gemm's order: + bias, statistics, activation, + R, CROG_ACT_RELU_POST) - a kernel of its own so that the lean launches carry
+// none of it
+template <int AL, int RBQ, int D, bool EPI = false>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p) {
   static_assert(AL == CROG_A_KC || AL == CROG_A_IM2COL, "K-contiguous A operands");
   static_assert(RBQ == 3 || RBQ == 4, "row quad of 3 or 4 blocks");
@@ -221,6 +224,17 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
   // ---- lean epilogue (as gemm_dma16_kernel): BatchNorm column statistics, bf16 stores -------------------------------
   const int arow = wr * (BM / 2), brow = wc * 64;
   const bool rows_in = m0 + BM <= p.M;
+  if constexpr (EPI) {
+    if (p.bias) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + brow + 4 * c16);      // (N % 256 == 0: always in range, 16-byte aligned)
+#pragma unroll
+      for (int i = 0; i < RB; i++)
+#pragma unroll
+        for (int j = 0; j < CB; j++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[i][j][e] += bv[j];
+    }
+  }
   if (p.col_stats) {
     float s1[CB], s2[CB];
 #pragma unroll
@@ -262,25 +276,60 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
   }
   bf16* C = reinterpret_cast<bf16*>(p.C);
   const int col = n0 + brow + 4 * c16;
+  if constexpr (EPI) {
+    if (p.act == CROG_ACT_RELU || p.act == CROG_ACT_QUICKGELU || p.act == CROG_ACT_TANH) {
+#pragma unroll
+      for (int i = 0; i < RB; i++)
+#pragma unroll
+        for (int j = 0; j < CB; j++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float v = acc[i][j][e];
+            acc[i][j][e] = p.act == CROG_ACT_RELU ? fmaxf(v, 0.f) : p.act == CROG_ACT_QUICKGELU ? act_quickgelu(v) : act_tanh(v);
+          }
+    }
+  }
+  const bf16* R = EPI ? reinterpret_cast<const bf16*>(p.R) : nullptr;
+  const bool post = EPI && p.act == CROG_ACT_RELU_POST;
 #pragma unroll
   for (int i = 0; i < RB; i++) {
     const int row0 = m0 + arow + i * 16 + 4 * gq;
     bf16* cb = C + (int64_t)row0 * p.ldc + col;
+    bf16x4 rv[4];
+    if constexpr (EPI) {
+      if (R) {      // the block's four residual rows in flight before the first is used; added in fp32 (one rounding)
+        const bf16* rb = R + (int64_t)row0 * p.ldr + col;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (rows_in || row0 + e < p.M) rv[e] = *reinterpret_cast<const bf16x4*>(rb + (int64_t)e * p.ldr);
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
+      float f[4] = {acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]};
+      if constexpr (EPI) {
+        if (R && (rows_in || row0 + e < p.M)) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) f[j] += (float)rv[e][j];
+        }
+        if (post) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) f[j] = fmaxf(f[j], 0.f);
+        }
+      }
       bf16x4 v;
-      v[0] = (bf16)acc[i][0][e]; v[1] = (bf16)acc[i][1][e]; v[2] = (bf16)acc[i][2][e]; v[3] = (bf16)acc[i][3][e];
+      v[0] = (bf16)f[0]; v[1] = (bf16)f[1]; v[2] = (bf16)f[2]; v[3] = (bf16)f[3];
       if (rows_in || row0 + e < p.M) *reinterpret_cast<bf16x4*>(cb + (int64_t)e * p.ldc) = v;
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <int AL, int RBQ, int D>
+template <int AL, int RBQ, int D, bool EPI = false>
 int launch_pp(const crog_gemm_desc& d, hipStream_t s) {
   constexpr int LDS = 8 * 16384;
   static bool attr_set = false;
-  auto kern = gemm_pp_kernel<AL, RBQ, D>;
+  auto kern = gemm_pp_kernel<AL, RBQ, D, EPI>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
@@ -310,9 +359,21 @@ bool crog_gemm_pp_eligible(const crog_gemm_desc& d, int rows) {
   return rows == 256 || rows == 192;
 }
 
-// dist: DMA distance in half-tiles (3 .. 7; 0 = the default of the tile height)
-int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t s) {
+// The full epilogue the EPI instantiations carry: alpha 1, bf16 output, optional bias / activation / residual (16-byte aligned rows).
+bool crog_gemm_pp_full_epilogue_ok(const crog_gemm_desc& d) {
+  if (d.alpha != 1.f || d.out_mode != CROG_OUT_T || d.dtype != CROG_BF16 || d.bwd_z) return false;
+  if (d.R && (d.ldr % 4 != 0 || ((uintptr_t)d.R % 8) != 0)) return false;
+  if (d.bias && ((uintptr_t)d.bias % 16) != 0) return false;
+  return true;
+}
+
+// dist: DMA distance in half-tiles (3 .. 7; 0 = the default of the tile height); full: the launch needs the EPI epilogue (default distance only)
+int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t s, bool full) {
   const bool conv = d.a_layout == CROG_A_IM2COL;
+  if (full) {
+    if (rows == 256) return conv ? launch_pp<CROG_A_IM2COL, 4, 4, true>(d, s) : launch_pp<CROG_A_KC, 4, 5, true>(d, s);
+    if (rows == 192) return conv ? launch_pp<CROG_A_IM2COL, 3, 4, true>(d, s) : launch_pp<CROG_A_KC, 3, 5, true>(d, s);
+  }
   // measured (scripts/ab_pp.py, distances 3 .. 7 on every 3x3 / 1x1 shape of the step): 4 for the 3x3 form (1333-1369 TFLOP/s on the
   // >= 676-tile forwards; 5: -1 %, 6: -6 %, 3: -11 %), 5 for the 1x1 / linear form (its k-loops are 4-32 tiles: the ring fill counts)
   if (dist == 0) dist = conv ? 4 : 5;

@@ -215,6 +215,68 @@ def test_ping_pong_256x256x64_kernel(K, monkeypatch, case):
 
 
 @pytest.mark.parametrize("case", [
+    # (M, K, N, 3x3 geometry or None, rows bit, bias, act, residual, statistics)
+    (2100, 256, 512, None, 512, True, "relu", False, False),          # linear + bias + ReLU (decoder FFN), ragged last row tile
+    (2100, 256, 512, None, 1024, True, "none", True, False),          # bias + residual on 192-row tiles
+    (5408, 512, 256, None, 512, False, "none", True, True),           # 1x1 data gradient + identity gradient, statistics of the sum's producer
+    (1352, 128, 256, None, 1024, False, "relu_post", True, False),    # ReLU after the residual
+    (2704, 2048, 256, None, 512, True, "quickgelu", False, False),    # 32 k-tiles
+    (2 * 26 * 26, 9 * 64, 256, (26, 26, 64), 512, True, "relu", True, False),   # 3x3 form with everything
+])
+def test_ping_pong_kernel_full_epilogue(K, monkeypatch, case):
+    """gemm_pp_kernel<..., EPI = true>: bias, activation, residual and the ReLU after the residual in crog_gemm's order (+ bias,
+    statistics, activation, + R, ReLU), against float64 and against the 128 x 128 kernel (debug bit 17) on the same operands."""
+    M, Kd, N, geom, rows_bit, with_bias, act, with_res, with_stats = case
+    dt = torch.bfloat16
+    cin = geom[2] if geom else Kd
+    x = rnd(M, cin, dt=dt)
+    w = (rnd(N, Kd, dt=dt, seed=1) * Kd ** -0.5).to(dt)
+    bias = rnd(N, seed=2) if with_bias else None
+    res = rnd(M, N + 8, dt=dt, seed=3) if with_res else None
+    code = dict(none=K.ACT_NONE, relu=K.ACT_RELU, relu_post=K.ACT_RELU_POST, quickgelu=K.ACT_QUICKGELU)[act]
+    ld = N + 8
+    out, st = {}, {}
+    for flag in (131072, rows_bit):
+        monkeypatch.setattr(K, "DEBUG_FLAGS", flag)
+        y = torch.full((M + 1, ld), 7.0, device="cuda", dtype=dt)
+        stats = torch.zeros(3, N, 2, device="cuda") if with_stats else None
+        kw = dict(bias=bias, act=code, R=res, ldr=N + 8 if with_res else 0, col_stats=stats, stat_replicas=3 if with_stats else 0)
+        if geom:
+            K.gemm(1, K.A_IM2COL, K.B_KC, x, w, y, M, N, Kd, cin, Kd, ld, conv=geom, **kw)
+        else:
+            K.gemm(1, K.A_KC, K.B_KC, x, w, y, M, N, Kd, Kd, Kd, ld, **kw)
+        assert (y[M] == 7).all() and (y[:, N:] == 7).all(), "epilogue wrote outside the M x N block"
+        out[flag] = y[:M, :N].clone()
+        st[flag] = stats.sum(0).double() if with_stats else None
+    if geom:
+        H, W, C = geom
+        xi = x.double().view(-1, H, W, C).permute(0, 3, 1, 2)
+        wi = w.double().view(N, 3, 3, C).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(xi, wi, padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    else:
+        ref = x.double() @ w.double().t()
+    if with_bias:
+        ref = ref + bias.double()
+    pre = ref.clone()
+    if act == "relu":
+        ref = ref.clamp_min(0)
+    elif act == "quickgelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if with_res:
+        ref = ref + res[:, :N].double()
+    if act == "relu_post":
+        ref = ref.clamp_min(0)
+    new, old = out[rows_bit], out[131072]
+    close(new, ref.float(), dt, scale=1.5)
+    assert _rel_l2(new.double(), ref) <= 1.05 * _rel_l2(old.double(), ref) + 1e-6
+    if with_stats:      # the statistics are those of the product + bias, before activation and residual
+        for s_ in (st[131072], st[rows_bit]):
+            assert _rel_l2(s_[:, 1], (pre ** 2).sum(0)) < 2e-3
+        assert _rel_l2(st[rows_bit], st[131072]) < 1e-4
+    monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
+
+
+@pytest.mark.parametrize("case", [
     # (pixels as (B, H, W), Cin, Cout, 3x3?, splitk, DMA distance)
     ((8, 26, 26), 256, 256, True, 3, 0),        # one M tile, nine N tiles; 84.5 k-tiles over 3 slices (ragged last k-tile)
     ((8, 26, 26), 256, 512, True, 1, 5),        # no split
