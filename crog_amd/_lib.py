@@ -42,7 +42,7 @@ class GemmDesc(ctypes.Structure):
         ("alpha", ctypes.c_float), ("bias", ctypes.c_void_p), ("act", ctypes.c_int),
         ("R", ctypes.c_void_p), ("ldr", ctypes.c_int64), ("out_mode", ctypes.c_int), ("debug", ctypes.c_int),
         ("col_stats", ctypes.c_void_p), ("stat_replicas", ctypes.c_int), ("a_sum", ctypes.c_void_p),
-        ("bwd_z", ctypes.c_void_p), ("ldz", ctypes.c_int64), ("bwd_ss", ctypes.c_void_p),
+        ("bwd_z", ctypes.c_void_p), ("ldz", ctypes.c_int64), ("bwd_ss", ctypes.c_void_p), ("bwd_mask", ctypes.c_void_p),
     ]
 
 

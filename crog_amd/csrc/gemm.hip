@@ -440,6 +440,29 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
             if (!G || (mrow + ro < p.M && colp < p.N)) P[q] = *reinterpret_cast<const unsigned*>(zb + (int64_t)ro * p.ldz);
             else P[q] = 0u;
           }
+          // residual layers (out = relu(bn(z) + identity)): the identity path's gradient R joins BEFORE the gate, and the gate is the
+          // forward's bit mask (crog_bn_apply: one byte per 8 columns) - z alone cannot tell which elements passed that ReLU
+          unsigned RP[8], MB[8];
+          const bool has_r = p.R != nullptr, has_m = p.bwd_mask != nullptr;
+          if (has_r) {
+            const T* rb = reinterpret_cast<const T*>(p.R) + (int64_t)mrow * p.ldr + colp;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              const int ro = (2 * q & 3) + 8 * (2 * q >> 2);
+              if (!G || (mrow + ro < p.M && colp < p.N)) RP[q] = *reinterpret_cast<const unsigned*>(rb + (int64_t)ro * p.ldr);
+              else RP[q] = 0u;
+            }
+          }
+          if (has_m) {
+            const unsigned char* mb = p.bwd_mask + (int64_t)mrow * (p.N >> 3) + (colp >> 3);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              const int ro = (2 * q & 3) + 8 * (2 * q >> 2);
+              if (!G || (mrow + ro < p.M && colp < p.N)) MB[q] = mb[(int64_t)ro * (p.N >> 3)];
+              else MB[q] = 0u;
+            }
+          }
+          const int mbit = (colp & 7) + (odd ? 1 : 0);      // this lane's column inside its mask byte
 #pragma unroll
           for (int q = 0; q < 8; q++) {
             const unsigned O = (unsigned)__builtin_amdgcn_update_dpp(0, (int)P[q], 0xB1, 0xF, 0xF, false);   // lane ^ 1
@@ -447,6 +470,17 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
             const float z0 = __builtin_bit_cast(float, odd ? (O & 0xffff0000u) : (P[q] << 16));
             const float z1 = __builtin_bit_cast(float, odd ? (P[q] & 0xffff0000u) : (O << 16));
             float a0 = acc[i][j][2 * q], a1 = acc[i][j][2 * q + 1];
+            if (has_r) {
+              const unsigned RO = (unsigned)__builtin_amdgcn_update_dpp(0, (int)RP[q], 0xB1, 0xF, 0xF, false);
+              a0 += __builtin_bit_cast(float, odd ? (RO & 0xffff0000u) : (RP[q] << 16));
+              a1 += __builtin_bit_cast(float, odd ? (RP[q] & 0xffff0000u) : (RO << 16));
+            }
+            if (has_m) {
+              const unsigned MO = (unsigned)__builtin_amdgcn_update_dpp(0, (int)MB[q], 0xB1, 0xF, 0xF, false);
+              const unsigned b0 = odd ? MO : MB[q], b1 = odd ? MB[q] : MO;      // the mask bytes of row(2q) / row(2q + 1)
+              a0 = ((b0 >> mbit) & 1u) ? a0 : 0.f;
+              a1 = ((b1 >> mbit) & 1u) ? a1 : 0.f;
+            }
             a0 = (z0 * gsc + gsh > 0.f) ? a0 : 0.f;
             a1 = (z1 * gsc + gsh > 0.f) ? a1 : 0.f;
             acc[i][j][2 * q] = a0;
@@ -1750,6 +1784,11 @@ inline int mf16_mode(const crog_gemm_desc& d) {
 inline bool lean_epilogue_ok(const crog_gemm_desc& d) {
   return d.alpha == 1.f && !d.bias && d.act == CROG_ACT_NONE && !d.R && d.out_mode == CROG_OUT_T && d.dtype == CROG_BF16 && (d.N & 1) == 0;
 }
+// ... and what the BatchNorm-backward statistics tile takes: the same, or with a residual that joins before the gate
+inline bool bwd_epilogue_ok(const crog_gemm_desc& d) {
+  return d.alpha == 1.f && !d.bias && d.act == CROG_ACT_NONE && d.out_mode == CROG_OUT_T && d.dtype == CROG_BF16 && (d.N & 1) == 0 &&
+         (!d.R || (d.ldr % 2 == 0 && ((uintptr_t)d.R % 4) == 0));
+}
 
 // Which launches take the ping-pong kernel (gemm_pp.hip), and with which tile height: 0 = none, 256 or 192.  The tile height is the one
 // with the lower cost in (rounds of 256 one-per-CU blocks) x (rows per tile): 21632 x 512 is 170 tiles of 256 rows (one round at
@@ -1774,7 +1813,7 @@ template <typename T, bool HWTR>
 int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
   if (d.bwd_z) {      // BatchNorm-backward statistics: one dedicated tile, the three data-gradient layouts
     if constexpr (sizeof(T) == 2) {
-      if (dma_eligible(d) && lean_epilogue_ok(d)) {
+      if (dma_eligible(d) && bwd_epilogue_ok(d)) {
         if (d.a_layout == CROG_A_KC && d.b_layout == CROG_B_NC) return launch_dma<T, CROG_A_KC, CROG_B_NC, ShapeMidBwd>(d, s);
         if (d.a_layout == CROG_A_KC && d.b_layout == CROG_B_KC) return launch_dma<T, CROG_A_KC, CROG_B_KC, ShapeMidBwd>(d, s);
         if (d.a_layout == CROG_A_IM2COL && d.b_layout == CROG_B_KC) return launch_dma<T, CROG_A_IM2COL, CROG_B_KC, ShapeMidBwd>(d, s);
@@ -1887,7 +1926,7 @@ extern "C" int crog_gemm_wgrad_tile(int dtype, int a_layout, int b_layout, int M
 extern "C" int crog_gemm_supports_bwd_z(const crog_gemm_desc* dp) {
   if (!dp) return 0;
   const crog_gemm_desc& d = *dp;
-  if (d.dtype != CROG_BF16 || !dma_eligible(d) || !lean_epilogue_ok(d)) return 0;
+  if (d.dtype != CROG_BF16 || !dma_eligible(d) || !bwd_epilogue_ok(d)) return 0;
   return (d.a_layout == CROG_A_KC && (d.b_layout == CROG_B_NC || d.b_layout == CROG_B_KC)) ||
          (d.a_layout == CROG_A_IM2COL && (d.b_layout == CROG_B_KC || d.b_layout == CROG_B_NC_DGRAD));
 }
@@ -1927,9 +1966,10 @@ extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
   CROG_CHECK_ARG(!d.R || d.batch == 1, "crog_gemm: residual only for unbatched GEMM");
   CROG_CHECK_ARG(!d.col_stats || (d.batch == 1 && d.splitk == 1), "crog_gemm: col_stats needs batch == 1 and splitk == 1");
   if (d.bwd_z)
-    CROG_CHECK_ARG(d.col_stats && d.stat_replicas > 0 && d.dtype == CROG_BF16 && d.out_mode == CROG_OUT_T && !d.R && (d.N & 1) == 0 &&
-                       d.ldz % vec == 0 && ((uintptr_t)d.bwd_z % 16) == 0 && d.act == CROG_ACT_NONE,
-                   "crog_gemm: bwd_z needs bf16 dtype output, col_stats with stat_replicas > 0, no residual / activation, even N, aligned z");
+    CROG_CHECK_ARG(d.col_stats && d.stat_replicas > 0 && d.dtype == CROG_BF16 && d.out_mode == CROG_OUT_T && (d.N & 1) == 0 &&
+                       d.ldz % vec == 0 && ((uintptr_t)d.bwd_z % 16) == 0 && d.act == CROG_ACT_NONE && (!d.bwd_mask || d.N % 8 == 0),
+                   "crog_gemm: bwd_z needs bf16 dtype output, col_stats with stat_replicas > 0, no activation, even N (a multiple of 8 with bwd_mask), aligned z");
+  CROG_CHECK_ARG(!d.bwd_mask || d.bwd_z, "crog_gemm: bwd_mask only with bwd_z");
   CROG_CHECK_ARG(!d.a_sum || d.batch == 1, "crog_gemm: a_sum needs batch == 1");
   CROG_CHECK_ARG((long)d.batch * d.splitk <= 65535, "crog_gemm: batch*splitk too large");
   hipStream_t s = (hipStream_t)stream;

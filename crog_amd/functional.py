@@ -14,6 +14,7 @@ Conventions
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -243,11 +244,11 @@ class BnLink:
     accumulate (sum g, sum g*z) (`stat_in`, crog_gemm bwd_z) — layer L then skips the first pass of BatchNorm backward, which
     would have re-read dy and z from HBM.  Only valid when NOTHING else consumes y_L: the model code that wires it vouches."""
 
-    __slots__ = ("z", "ss", "C", "M", "sums", "R")
+    __slots__ = ("z", "ss", "C", "M", "sums", "R", "mask", "dx_ptr")
 
     def __init__(self):
-        self.z = self.ss = self.sums = None
-        self.C = self.M = self.R = 0
+        self.z = self.ss = self.sums = self.mask = None
+        self.C = self.M = self.R = self.dx_ptr = 0
 
 
 BN_BWD_FUSED = True   # BnLink fusion on (bf16, atomic statistics path); tests compare with the two-launch form
@@ -256,6 +257,13 @@ BN_BWD_FUSED = True   # BnLink fusion on (bf16, atomic statistics path); tests c
 # saves (+17 us vs 19-21 us: bn_bwd_partial streams at 4.2 TB/s, the epilogue gathers z in 4-byte pieces and its atomics collide on 64
 # columns), and on the 1.38 M-row stem it LOSES 13-19 us.
 BN_BWD_FUSED_MAX_ROWS = 131072
+# The same between two Bottlenecks (a BnLink as `res_out` of block b-1's conv3 / bn3 layer and `res_in` of block b's conv1): the gradient
+# of out_{b-1} = relu(bn3(z) + identity) is conv1's data gradient plus block b's identity gradient, both already joined in that GEMM
+# (R) - its epilogue also gates the sum with the forward's bit mask and accumulates (sum g, sum g*z): block b-1 skips bn3's first
+# backward pass over the widest tensors of the stage, and the stored g is at once bn3's dy and block b-1's identity gradient (no dres
+# pass).  CROG_BN_RES_FUSED=0 switches it off; CROG_BN_RES_FUSED_MAX_ROWS limits the layer size.
+BN_RES_FUSED = os.environ.get("CROG_BN_RES_FUSED", "1") != "0"
+BN_RES_FUSED_MAX_ROWS = int(os.environ.get("CROG_BN_RES_FUSED_MAX_ROWS", str(1 << 30)))
 
 
 def stat_replicas(slabs: int, C: int) -> int:
@@ -277,11 +285,12 @@ class ConvBnAct(Function):
 
     @staticmethod
     def forward(ctx, x, res, _wp, _gp, _bp, w: Optional[WRef], bn: BnBuffers, ksize, relu: bool, training: bool, out, wpad, dtype,
-                grad_slot=None, res_slot=None, stat_out=None, stat_in=None, dx_slot=None):
+                grad_slot=None, res_slot=None, stat_out=None, stat_in=None, dx_slot=None, res_out=None, res_in=None):
         dev = x.device
         ctx.slots = (grad_slot, res_slot)
         ctx.dx_slot = dx_slot
         ctx.links = (stat_out, stat_in)
+        ctx.res_links = (res_out, res_in)
         if ksize == "s":
             B, _, Hi, Wi = x.shape
             H, W = Hi // 2, Wi // 2
@@ -381,6 +390,11 @@ class ConvBnAct(Function):
             ok = (BN_BWD_FUSED and BN_BWD_ATOMIC and training and dtype == torch.bfloat16 and res is None and ksize != 0
                   and M <= BN_BWD_FUSED_MAX_ROWS and not RT.deterministic)      # (the epilogue's statistics are atomic adds)
             stat_out.z, stat_out.ss, stat_out.C, stat_out.M, stat_out.sums = (z if ok else None), (ss if relu else None), C, M, None
+        if res_out is not None:
+            # ... and what the NEXT BLOCK's first data gradient needs to do this residual layer's first backward pass (BN_RES_FUSED)
+            ok = (BN_BWD_FUSED and BN_RES_FUSED and BN_BWD_ATOMIC and training and dtype == torch.bfloat16 and res is not None and relu
+                  and rmask is not None and ksize != 0 and M <= BN_RES_FUSED_MAX_ROWS and C % 8 == 0 and not RT.deterministic)
+            res_out.z, res_out.mask, res_out.C, res_out.M, res_out.sums, res_out.dx_ptr = (z if ok else None), rmask, C, M, None, 0
         ctx.wt = (wt, wbuf_off) if wpad is not None else None
         if ksize == "s":
             ctx.save_for_backward(patches, z, y, mi)
@@ -405,10 +419,30 @@ class ConvBnAct(Function):
         ymask = y if (relu and relu_ss is None and rmask is None) else None
         comm_on = RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force)
         dz = torch.empty(lead + (C,), device=dev, dtype=dtype)
-        dres = torch.empty(lead + (C,), device=dev, dtype=dtype) if ctx.has_res else None
         stat_out, stat_in = ctx.links
+        res_out, res_in = ctx.res_links
+        # (the pointer test: the sums describe the tensor the next block's GEMM stored; any other dy - a hook, a second consumer that
+        # autograd summed in - takes the two-pass path, which is still right: that tensor is gated already and gating is idempotent)
+        fused_res = res_out is not None and res_out.sums is not None and res_out.dx_ptr == dy.data_ptr()
+        if res_out is not None and not fused_res:
+            res_out.sums = res_out.z = None
+        dres = torch.empty(lead + (C,), device=dev, dtype=dtype) if (ctx.has_res and not fused_res) else None
         fused = stat_out is not None and stat_out.sums is not None
-        if fused:
+        if fused_res:
+            # the next block's first data gradient added its identity gradient, gated the sum with this layer's ReLU bits and left
+            # (sum g, sum g*z): no first pass, and dy IS the gradient of this block's identity path
+            sums, R = res_out.sums, res_out.R
+            res_out.sums = res_out.z = None
+            scale = 1.0
+            if comm_on:
+                RT.comm.all_reduce_sum(sums)
+                scale = 1.0 / RT.comm.world_size
+            K.bn_bwd_apply(dy, None, z, mi, bn.gamma.master(), sums, count, dz, None, None, sum_rows=-R,
+                           dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=None, param_grad_scale=scale)
+            bn.beta.done()
+            bn.gamma.done()
+            dres = dy.view(lead + (C,))
+        elif fused:
             # the layer that consumed y already gated dy and left (sum g, sum g*z) in R replica rows (BnLink): no first pass
             sums, R = stat_out.sums, stat_out.R
             stat_out.sums = stat_out.z = None
@@ -514,8 +548,16 @@ class ConvBnAct(Function):
                 stat_in.R = stat_replicas(K.stat_tiles(M), cin)
                 stat_in.sums = RT.zeros(stat_in.R * 2 * cin, dev)
                 bwd = dict(col_stats=stat_in.sums, stat_replicas=stat_in.R, bwd_z=stat_in.z, bwd_ss=stat_in.ss)
+            if (res_in is not None and res_in.z is not None and not bwd and ksize == 1 and ctx.x_needs and extra is not None
+                    and dtype == torch.bfloat16 and res_in.C == cin and res_in.M == M and cin % 8 == 0 and C % 8 == 0
+                    and 2 * M * max(C, cin) < 2 ** 31 and K.mat(extra)[2] % 2 == 0):
+                res_in.R = stat_replicas(K.stat_tiles(M), cin)
+                res_in.sums = RT.zeros(res_in.R * 2 * cin, dev)
+                bwd = dict(col_stats=res_in.sums, stat_replicas=res_in.R, bwd_z=res_in.z, bwd_mask=res_in.mask)
             if ksize == 1 and ctx.x_needs:
                 dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
+                if bwd and res_in is not None and res_in.sums is bwd.get("col_stats"):
+                    res_in.dx_ptr = dx.data_ptr()
                 if LIN_DGRAD_T and wpad is None and id(w.param) in w.store.lin_t:
                     # forward-shaped GEMM on the [Cin][Cout] copy of the weight: both operands K-contiguous
                     K.gemm(dt, K.A_KC, K.B_KC, dz, w.store.weights_t(dtype), dx, M, cin, C, C, C, cin, b_off=woff, R=extra,
@@ -538,7 +580,7 @@ class ConvBnAct(Function):
         if ctx.dx_slot is not None and dx is not None:      # (see avgpool2: x's other consumer adds this gradient in its own epilogue)
             ctx.dx_slot.put(dx)
             dx = None
-        return (dx, dres) + (None,) * 16
+        return (dx, dres) + (None,) * 18
 
 
 EVAL_BN_FOLD = True
@@ -587,14 +629,15 @@ def _conv_bn_act_eval(x, w: WRef, bn: BnBuffers, ksize, relu, res, out, wpad, dt
 
 
 def conv_bn_act(x, w: Optional[WRef], bn: BnBuffers, *, ksize, relu=True, res=None, training=True, out=None, wpad=None, dtype=None,
-                grad_slot=None, res_slot=None, stat_out=None, stat_in=None, dx_slot=None):
-    """stat_out / stat_in: a BnLink shared by two layers with y_L -> x_{L+1} and no other consumer of y_L (see BnLink)."""
+                grad_slot=None, res_slot=None, stat_out=None, stat_in=None, dx_slot=None, res_out=None, res_in=None):
+    """stat_out / stat_in: a BnLink shared by two layers with y_L -> x_{L+1} and no other consumer of y_L (see BnLink).
+    res_out / res_in: a BnLink between a residual layer and the first convolution of the block its output feeds (BN_RES_FUSED)."""
     dtype = dtype if dtype is not None else x.dtype
     wp = w.param if w is not None else None
     if EVAL_BN_FOLD and not training and ksize != 0 and not torch.is_grad_enabled():
         return _conv_bn_act_eval(x, w, bn, ksize, relu, res, out, wpad, dtype)
     return ConvBnAct.apply(x, res, wp, bn.gamma.param, bn.beta.param, w, bn, ksize, relu, training, out, wpad, dtype, grad_slot, res_slot,
-                           stat_out, stat_in, dx_slot)
+                           stat_out, stat_in, dx_slot, res_out, res_in)
 
 
 # ------------------------------------------------------------------------------------------------

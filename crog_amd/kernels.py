@@ -178,7 +178,7 @@ def as_mat(t: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, ldc, *, batch=1, batch_inner=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, conv=(0, 0, 0), alpha=1.0, bias=None, act=ACT_NONE, R=None,
-         ldr=0, out_mode=OUT_T, col_stats=None, a_off=0, b_off=0, c_off=0, a_sum=None, a_sum_off=0, stat_replicas=0, bwd_z=None,
+         ldr=0, out_mode=OUT_T, col_stats=None, a_off=0, b_off=0, c_off=0, a_sum=None, a_sum_off=0, stat_replicas=0, bwd_mask=None, bwd_z=None,
          bwd_ss=None):
     """Raw descriptor launch. A/B/C are tensors (or ints = device addresses); *_off are element offsets."""
     esz = 2 if dtype == BF16 else 4
@@ -195,7 +195,8 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
                  None if bias is None else bias.data_ptr(), act, None if R is None else R.data_ptr(), ldr, out_mode, DEBUG_FLAGS,
                  None if col_stats is None else col_stats.data_ptr(), stat_replicas,
                  None if a_sum is None else a_sum.data_ptr() + 4 * a_sum_off,
-                 None if bwd_z is None else bwd_z.data_ptr(), 0 if bwd_z is None else mat(bwd_z)[2], None if bwd_ss is None else bwd_ss.data_ptr())
+                 None if bwd_z is None else bwd_z.data_ptr(), 0 if bwd_z is None else mat(bwd_z)[2], None if bwd_ss is None else bwd_ss.data_ptr(),
+                 None if bwd_mask is None else bwd_mask.data_ptr())
     if PROF is not None and PROF.get("on", True) and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
         # timers go on the stream the kernel is actually launched on (the weight-gradient side stream while it is overridden)
         raw = stream()

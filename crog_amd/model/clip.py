@@ -36,7 +36,10 @@ class Bottleneck(Bound):
         if stride > 1 or inplanes != planes * 4:
             self.downsample = nn.ModuleDict({"0": Conv2d(inplanes, planes * 4, 1), "1": BatchNorm(planes * 4)})
 
-    def forward(self, x):
+    def forward(self, x, res_in=None, res_out=None):
+        """res_in / res_out (Stage.forward): BnLinks to the previous / next block of the stage - this block's first data
+        gradient does the previous block's bn3 first backward pass (Fn.BN_RES_FUSED).  Only an identity block can be the consumer:
+        its conv1 data gradient already adds the identity path's gradient, i.e. it writes the COMPLETE gradient of its input."""
         tr = self.training
         # x has two consumers (conv1 and the identity / downsample branch): the second branch's gradient rides a slot into conv1's
         # dgrad epilogue (no separate accumulation pass).  Valid because that branch is created after conv1 / conv2, so autograd runs
@@ -47,7 +50,8 @@ class Bottleneck(Bound):
         # of the consuming convolution does the first pass of that BatchNorm's backward in its epilogue (Fn.BnLink)
         l1 = Fn.BnLink() if tr else None
         l2 = Fn.BnLink() if (tr and self.stride == 1) else None
-        out = Fn.conv_bn_act(x, self.conv1.w, self.bn1.buffers_ref(), ksize=1, relu=True, training=tr, grad_slot=slot, stat_out=l1)
+        out = Fn.conv_bn_act(x, self.conv1.w, self.bn1.buffers_ref(), ksize=1, relu=True, training=tr, grad_slot=slot, stat_out=l1,
+                             res_in=res_in if not ds else None)
         out = Fn.conv_bn_act(out, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=l1, stat_out=l2)
         if self.stride > 1:
             out = Fn.avgpool2(out)
@@ -58,7 +62,21 @@ class Bottleneck(Bound):
             identity = Fn.conv_bn_act(identity, self.downsample["0"].w, self.downsample["1"].buffers_ref(), ksize=1, relu=False, training=tr,
                                       dx_slot=slot if self.stride == 1 else None)
         return Fn.conv_bn_act(out, self.conv3.w, self.bn3.buffers_ref(), ksize=1, relu=True, res=identity, training=tr,
-                              res_slot=None if ds else slot, stat_in=l2)
+                              res_slot=None if ds else slot, stat_in=l2, res_out=res_out)
+
+
+class Stage(nn.Sequential):
+    """A stage of Bottlenecks (clip.py:187-195: nn.Sequential, same child names) with a BnLink between consecutive blocks: block b's
+    output feeds block b + 1 and nothing else."""
+
+    def forward(self, x):
+        blocks = list(self)
+        link = None
+        for i, blk in enumerate(blocks):
+            nxt = Fn.BnLink() if (self.training and i + 1 < len(blocks) and blocks[i + 1].downsample is None) else None
+            x = blk(x, res_in=link, res_out=nxt)
+            link = nxt
+        return x
 
 
 _BICUBIC_CACHE = {}
@@ -139,7 +157,7 @@ class ModifiedResNet(Bound):
         mods = [Bottleneck(self._inplanes, planes, stride)]
         self._inplanes = planes * 4
         mods += [Bottleneck(self._inplanes, planes) for _ in range(1, blocks)]
-        return nn.Sequential(*mods)
+        return Stage(*mods)
 
     def forward(self, img, dtype, after_layer1=None):
         """`after_layer1`: host-side hook called after each of layer1, layer2, layer3 is enqueued (few launches, most of the

@@ -173,9 +173,14 @@ typedef struct crog_gemm_desc {
                         gradient, g = relu_gate(z) ? v : 0 with relu_gate(z) = z * bwd_ss[n][0] + bwd_ss[n][1] > 0 (all ones when
                         bwd_ss is NULL), STORES g instead of v, and accumulates (sum g, sum g * z) per column into col_stats —
                         the first pass of BatchNorm backward without re-reading dy (crog_bn_bwd_apply takes the raw z-moments
-                        with a negative sum_rows).  Needs dtype output, no residual, stat_replicas > 0, even N. */
+                        with a negative sum_rows).  Needs dtype output, stat_replicas > 0, even N; a residual R only as described under bwd_mask. */
   int64_t ldz;
   const float* bwd_ss; /* NULL, or fp32 [N][2]: (scale, shift) of the layer's normalisation, to recompute the ReLU gate from z */
+  const unsigned char* bwd_mask; /* NULL, or (with bwd_z) the ReLU bit mask crog_bn_apply wrote in the forward of a RESIDUAL layer
+                        (clip.py:52-57: out = relu(bn3(z) + identity)): [M][N / 8] bytes, bit e of byte (m, n / 8) = column 8 (n / 8) + e
+                        passed.  The gate is then these bits (z alone cannot tell), and a residual R - the identity path's gradient of the
+                        NEXT block, whose first convolution this data gradient belongs to - is added BEFORE the gate: the stored
+                        g = mask ? acc + R : 0 is at once the layer's gated dy and the gradient of its own identity path.  N % 8 == 0. */
 } crog_gemm_desc;
 
 int crog_gemm(const crog_gemm_desc* d, crog_stream_t stream);

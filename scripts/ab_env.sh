@@ -3,7 +3,7 @@
 # each argument is one configuration ("-" = defaults); prints ms_per_step per configuration, two passes.
 out=$1; shift
 : > $out
-for pass in 1 2; do
+for pass in $(seq 1 ${AB_PASSES:-2}); do
   for cfg in "$@"; do
     if [ "$cfg" = "-" ]; then e=""; else e="$cfg"; fi
     r=$(env $e python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])")

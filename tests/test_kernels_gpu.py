@@ -1320,6 +1320,39 @@ def test_timing_only_events_measure_a_launch(K):
         assert torch.equal(dst[:n], src[:n]) and int(dst[n:].sum()) == 0, mode
 
 
+@pytest.mark.parametrize("M,N,K_,layout", [(4096, 256, 64, "nc"), (1000, 72, 96, "kc"), (21632, 1024, 256, "kc"), (2500, 512, 128, "nc")])
+def test_dgrad_epilogue_gates_a_residual_layer_with_its_bit_mask(K, M, N, K_, layout):
+    """crog_gemm bwd_z + bwd_mask + R: the data gradient of a block's first convolution, plus the gradient of that block's identity
+    path, is the gradient of the PREVIOUS block's output relu(bn3(z) + identity): the epilogue adds R, gates with the forward's bit
+    mask (crog_bn_apply), stores g and accumulates (sum g, sum g*z) - against torch on the same operands."""
+    dt = torch.bfloat16
+    from crog_amd.functional import stat_replicas
+    a = rnd(M, K_, dt=dt)
+    w = (rnd(K_, N, dt=dt, seed=1) * 0.1).to(dt)
+    z = (rnd(M, N, dt=dt, seed=2) * 1.5 + 0.3).to(dt)
+    res = rnd(M, N + 8, dt=dt, seed=3)
+    passed = torch.rand(M, N, device="cuda") > 0.4
+    mask = torch.zeros(M, N // 8, device="cuda", dtype=torch.uint8)
+    for e in range(8):
+        mask |= (passed[:, e::8].to(torch.uint8) << e)
+    R = stat_replicas(K.stat_tiles(M), N)
+    sums = torch.zeros(R, N, 2, device="cuda")
+    dx = torch.full((M + 1, N), 7.0, device="cuda", dtype=dt)
+    kw = dict(col_stats=sums, stat_replicas=R, bwd_z=z, bwd_mask=mask, R=res, ldr=N + 8)
+    if layout == "nc":
+        K.gemm(K.dcode(dt), K.A_KC, K.B_NC, a, w, dx, M, N, K_, K_, N, N, **kw)
+    else:
+        K.gemm(K.dcode(dt), K.A_KC, K.B_KC, a, w.t().contiguous(), dx, M, N, K_, K_, K_, N, **kw)
+    assert (dx[M] == 7).all()
+    v = a.float() @ w.float() + res[:, :N].float()
+    g = torch.where(passed, v, torch.zeros_like(v))
+    close(dx[:M], g, dt, scale=math.sqrt(K_) / 4 + 1)
+    assert ((dx[:M] == 0) | passed).all()
+    tot = sums.sum(0)
+    assert torch.allclose(tot[:, 0], g.sum(0), rtol=2e-3, atol=2e-2 * g.abs().sum(0).max().item() / 100)
+    assert torch.allclose(tot[:, 1], (g * z.float()).sum(0), rtol=2e-3, atol=2e-2 * (g * z.float()).abs().sum(0).max().item() / 100)
+
+
 @pytest.mark.parametrize("M,N,K_,relu", [(4096, 64, 64, True), (1000, 72, 96, True), (21632, 256, 2304 // 9, False), (2500, 512, 128, True)])
 def test_dgrad_epilogue_does_the_first_batchnorm_backward_pass(K, M, N, K_, relu):
     """crog_gemm bwd_z: a data-gradient GEMM whose output is a BatchNorm(+ReLU) layer's dy gates it with the ReLU mask recomputed
