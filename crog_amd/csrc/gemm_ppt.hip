@@ -28,9 +28,23 @@ __device__ __attribute__((always_inline)) inline bf16x8 tr_frag(const char* lo, 
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// BL: CROG_B_NC (dense) or CROG_B_NC_IM2COL; SLAB: plain stores into the split's slab instead of atomic adds; D: DMA distance
-template <int BL, bool SLAB, int D>
-__global__ void __launch_bounds__(512, 2) gemm_ppt_kernel(const crog_gemm_desc p) {
+// One problem of a GROUPED launch (crog_gemm_group): what the kernel body reads of a descriptor, and the first block of the problem
+struct PptProb {
+  const void* A;
+  const void* B;
+  void* C;
+  int M, N, K, lda, ldb, ldc, splitk, convH, convW, convC, conv3, start;
+};
+constexpr int PPT_GROUP_MAX = 32;
+struct PptGroup {
+  int n, blocks;
+  PptProb p[PPT_GROUP_MAX];
+};
+
+// BL: CROG_B_NC (dense) or CROG_B_NC_IM2COL; SLAB: plain stores into the split's slab instead of atomic adds; D: DMA distance;
+// P: crog_gemm_desc or PptProb; blk: the block's index inside its problem
+template <int BL, bool SLAB, int D, typename P>
+__device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const int blk) {
   static_assert(BL == CROG_B_NC || BL == CROG_B_NC_IM2COL, "transposed B operands");
   static_assert(D >= 3 && D <= 7, "DMA distance in half-tiles");
   constexpr int BM = 256, BN = 256, BK = 64, RBQ = 4, RB = 8, CB = 4;
@@ -42,7 +56,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ppt_kernel(const crog_gemm_desc p
   const int wr = wave >> 2, wc = wave & 3;
   const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
   const int nwg = tilesM * tilesN;
-  int id = blockIdx.x, z = 0;
+  int id = blk, z = 0;
   xcd_map(nwg, p.splitk, id, z);          // (reduction slice, tile) runs per XCD: an operand slice lands in one L2
   const int tm = id / tilesN, tn = id - tm * tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -248,6 +262,24 @@ __global__ void __launch_bounds__(512, 2) gemm_ppt_kernel(const crog_gemm_desc p
 }
 
 template <int BL, bool SLAB, int D>
+__global__ void __launch_bounds__(512, 2) gemm_ppt_kernel(const crog_gemm_desc p) {
+  ppt_body<BL, SLAB, D>(p, (int)blockIdx.x);
+}
+
+// Several small weight gradients in ONE launch: block b belongs to the problem whose [start, next start) holds it.  A 512 x 512 x 21632
+// gradient alone is 4 tiles: split 16-fold to fill the chip it runs 21 k-tiles per block and spends its time in fills and atomic adds
+// (56 us); twelve of them side by side at split 4 take 206 us together (scripts/ab_group.py).
+template <int D>
+__global__ void __launch_bounds__(512, 2) gemm_ppt_group_kernel(const PptGroup g) {
+  const int b = (int)blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && b >= g.p[i + 1].start) i++;
+  const PptProb p = g.p[i];
+  if (p.conv3) ppt_body<CROG_B_NC_IM2COL, false, D>(p, b - p.start);
+  else ppt_body<CROG_B_NC, false, D>(p, b - p.start);
+}
+
+template <int BL, bool SLAB, int D>
 int launch_ppt(const crog_gemm_desc& d, hipStream_t s) {
   constexpr int LDS = 8 * 16384;
   static bool attr_set = false;
@@ -315,6 +347,50 @@ int crog_gemm_ppt_launch(const crog_gemm_desc& d, int dist, hipStream_t s) {
 #undef PT_CASE
   crog_set_error("crog_gemm: no ping-pong weight-gradient instantiation for dist=%d", dist);
   return CROG_ERR_ARG;
+}
+
+extern "C" int crog_gemm_group(const crog_gemm_desc* descs, int n, crog_stream_t stream) {
+  CROG_CHECK_ARG(descs && n >= 1 && n <= PPT_GROUP_MAX, "crog_gemm_group: 1 .. %d descriptors", PPT_GROUP_MAX);
+  PptGroup g;
+  g.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; i++) {
+    crog_gemm_desc d = descs[i];
+    if (d.batch < 1) d.batch = 1;
+    if (d.batch_inner < 1) d.batch_inner = 1;
+    if (d.splitk < 1) d.splitk = 1;
+    CROG_CHECK_ARG(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0, "crog_gemm_group: descriptor %d: null operand or empty size", i);
+    CROG_CHECK_ARG(crog_gemm_ppt_eligible(d) && d.out_mode == CROG_OUT_F32_ATOMIC,
+                   "crog_gemm_group: descriptor %d is not a bf16 weight gradient with atomic fp32 output the ping-pong kernel takes "
+                   "(A_MC x B_NC / B_NC_IM2COL, M and N multiples of 8, K >= 128, no bias / a_sum / statistics)", i);
+    CROG_CHECK_ARG(((uintptr_t)d.A % 16) == 0 && ((uintptr_t)d.B % 16) == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0,
+                   "crog_gemm_group: descriptor %d: A / B must be 16-byte aligned with lda, ldb multiples of 8", i);
+    CROG_CHECK_ARG((long)d.M * d.ldc < 0x7fffffffL && d.lda < 0x7fffffffL && d.ldb < 0x7fffffffL, "crog_gemm_group: descriptor %d: leading dimensions out of range", i);
+    PptProb& q = g.p[i];
+    q.A = d.A; q.B = d.B; q.C = d.C;
+    q.M = d.M; q.N = d.N; q.K = d.K;
+    q.lda = (int)d.lda; q.ldb = (int)d.ldb; q.ldc = (int)d.ldc;
+    q.splitk = d.splitk;
+    q.convH = d.convH; q.convW = d.convW; q.convC = d.convC;
+    q.conv3 = d.b_layout == CROG_B_NC_IM2COL ? 1 : 0;
+    q.start = blocks;
+    blocks += cdiv(d.M, 256) * cdiv(d.N, 256) * d.splitk;
+  }
+  g.blocks = blocks;
+  constexpr int LDS = 8 * 16384;
+  static bool attr_set = false;
+  auto kern = gemm_ppt_group_kernel<5>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      crog_set_error("crog_gemm_group: hipFuncSetAttribute(%d bytes) failed: %s", LDS, hipGetErrorString(e));
+      return CROG_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), LDS, (hipStream_t)stream, g);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
 }
 
 extern "C" int crog_splitk_reduce(const float* ws, int splits, int M, int N, int64_t ldws, float* out, int64_t ldo, int accumulate,

@@ -103,7 +103,7 @@ class WRef:
     def done(self):
         """The kernels that write this parameter's gradient are enqueued (or parked: Runtime.defer_wgrad - then the announcement waits
         for the flush that really enqueues them, so a DDP bucket can never be launched ahead of its last gradient)."""
-        if RT._pending_wgrad:
+        if RT._pending_wgrad or RT._group:
             RT._pending_done.append(self._done_now)
             return
         self._done_now()
@@ -153,11 +153,30 @@ def lin_dgrad(dy, w: WRef, dx, *, accumulate_into: Optional[torch.Tensor] = None
            a_off=a_off, b_off=w.off, R=R, ldr=ldr)
 
 
-def wgrad_gemm(dt, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, *, a_off=0, c_off=0, conv=(0, 0, 0), a_sum=None, a_sum_off=0):
+def wgrad_gemm(dt, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, *, a_off=0, c_off=0, conv=(0, 0, 0), a_sum=None, a_sum_off=0, park=True):
     """G[c_off + m * ldc + n] += sum_k dy[k][m] * xcol[k][n]: every weight gradient of the package.  Split over the reduction; the
     slices meet through fp32 atomic adds, or - deterministic mode - as slabs of a [splitk][M][N] workspace that crog_splitk_reduce adds
-    onto G in slice order (a_sum, an atomic sum as well, is refused there: the caller takes the two-pass column sum)."""
+    onto G in slice order (a_sum, an atomic sum as well, is refused there: the caller takes the two-pass column sum).
+    park=False: the caller reads the result on the same stream right after this call (a padded scratch gradient that is stripped into the
+    real one): the product must not wait for a grouped launch."""
     conv3 = b_layout == K.B_NC_IM2COL
+    if RT._group and RT._group_K != Kd:
+        RT.flush_group()      # the backward pass has moved on to layers of another resolution: what is parked goes now, not at the end
+    if (park and a_sum is None and dt == K.BF16 and RT.can_park() and M >= 256 and N >= 256 and M % 8 == 0 and N % 8 == 0 and Kd >= 4096
+            and a_off % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and (Kd + 64) * max(lda, ldb) * 2 < 2 ** 31 and M * ldc < 2 ** 31):
+        # a small output (a few 256 x 256 tiles) with a long reduction: parked, and launched together with its neighbours' by
+        # crog_gemm_group at ~84 k-tiles per block - alone it would be split 16-fold to fill the chip (Runtime.park_wgrad)
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        if tiles <= 36 and K.lib().crog_gemm_wgrad_tile(dt, K.A_MC, b_layout, M, N, Kd) != 256:
+            gsk = max(1, min(16, round(Kd / 64 / 84)))
+            K.GROUP_SINK = sink = []
+            try:
+                K.gemm(dt, K.A_MC, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, a_off=a_off, c_off=c_off, conv=conv, splitk=gsk,
+                       out_mode=K.OUT_F32_ATOMIC)
+            finally:
+                K.GROUP_SINK = None
+            RT.park_wgrad(sink[0], tiles * gsk, (dy, x, G), Kd)
+            return
     sk = K.pick_splitk(M, N, Kd, _bk(dt), conv=conv3)
     if not RT.deterministic:
         K.gemm(dt, K.A_MC, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, a_off=a_off, c_off=c_off, conv=conv, splitk=sk,
@@ -527,11 +546,12 @@ class ConvBnAct(Function):
                 gt, goff = w.G, w.off
             def wgrad():
                 if ksize == "s":
-                    wgrad_gemm(dt, K.B_NC, dz, x, gt, C, 32, M, C, 32, 32, c_off=goff)
+                    wgrad_gemm(dt, K.B_NC, dz, x, gt, C, 32, M, C, 32, 32, c_off=goff, park=wpad is None)
                 elif ksize == 1:
-                    wgrad_gemm(dt, K.B_NC, dz, x, gt, C, cin, M, C, K.mat(x)[2], wcols, c_off=goff)
+                    wgrad_gemm(dt, K.B_NC, dz, x, gt, C, cin, M, C, K.mat(x)[2], wcols, c_off=goff, park=wpad is None)
                 else:
-                    wgrad_gemm(dt, K.B_NC_IM2COL, dz, x, gt, C, 9 * cin, M, C, K.mat(x)[2], wcols, c_off=goff, conv=(lead[1], lead[2], cin))
+                    wgrad_gemm(dt, K.B_NC_IM2COL, dz, x, gt, C, 9 * cin, M, C, K.mat(x)[2], wcols, c_off=goff, conv=(lead[1], lead[2], cin),
+                               park=wpad is None)
                 if wpad is not None:  # strip the zero padding back out into the real gradient
                     K.add_pad2d(gscratch, dst_cols, w.G, src_cols, src_cols, rows, dst_off=w.off)
             # (a data gradient that will take the one-block-per-CU 256 x 256 tile: csrc/gemm.hip dispatch_shape)

@@ -30,6 +30,8 @@ CAPTURE_NODES = None
 # ... and {raw stream: [graph nodes]}: after every launch of this library the node it created is noted under the stream it went to, so that
 # the replay re-issues each node on the stream it was captured on (crog_replay_build_tagged)
 CAPTURE_TAGS = None
+# a list: gemm() appends its descriptor here instead of launching it (crog_amd.runtime parks small weight gradients for crog_gemm_group)
+GROUP_SINK = None
 DEBUG_FLAGS = 0  # ablation / A-B bits of crog_gemm_desc.debug (set by tests and scripts/ablate_gemm.py); 0 in production
 GEMM_SYMBOL = {
     (A_KC, B_KC): "gemm_pp_kernel<A_KC, 4|3, 5> (>= 150 tiles of 256 x 256) / gemm_dma16_kernel<A_KC, 128x128> / gemm_dma_kernel<T, A_KC, B_KC>  "
@@ -197,6 +199,9 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
                  None if a_sum is None else a_sum.data_ptr() + 4 * a_sum_off,
                  None if bwd_z is None else bwd_z.data_ptr(), 0 if bwd_z is None else mat(bwd_z)[2], None if bwd_ss is None else bwd_ss.data_ptr(),
                  None if bwd_mask is None else bwd_mask.data_ptr())
+    if GROUP_SINK is not None:
+        GROUP_SINK.append(d)
+        return
     if PROF is not None and PROF.get("on", True) and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
         # timers go on the stream the kernel is actually launched on (the weight-gradient side stream while it is overridden)
         raw = stream()
@@ -217,6 +222,13 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
             CAPTURE_NODES["nodes"].append((node.value, 2.0 * M * N * K * batch, (a_layout, b_layout, M, N, K, batch, splitk)))
         return
     check(lib().crog_gemm(ctypes.byref(d), stream()), "crog_gemm")
+
+
+def gemm_group(descs):
+    """One launch for a list of weight-gradient descriptors (crog_gemm_group; built by gemm() with GROUP_SINK set)."""
+    n = len(descs)
+    arr = (GemmDesc * n)(*descs)
+    check(lib().crog_gemm_group(arr, n, stream()), "crog_gemm_group")
 
 
 def splitk_reduce(ws: torch.Tensor, splits: int, M: int, N: int, ldws: int, out: torch.Tensor, out_off: int, ldo: int, accumulate: bool = True):

@@ -202,6 +202,12 @@ int crog_gemm_wgrad_tile(int dtype, int a_layout, int b_layout, int M, int N, in
  * data-gradient layouts, plain epilogue, operands addressable by the LDS-DMA path (32-bit byte offsets).  For callers that must
  * decide before the producing layer skips its own first pass. */
 int crog_gemm_supports_bwd_z(const crog_gemm_desc* d);
+/* n (1 .. 32) independent weight gradients in ONE launch of the ping-pong weight-gradient kernel (csrc/gemm_ppt.hip): every descriptor
+ * bf16, CROG_A_MC x CROG_B_NC / CROG_B_NC_IM2COL, CROG_OUT_F32_ATOMIC, M and N multiples of 8, K >= 128, no bias / residual / a_sum /
+ * statistics, its own splitk.  The blocks of all problems run side by side: the small weight gradients of consecutive layers (a 512 x 512
+ * output is four tiles) fill the chip together at a split of 4 instead of each at a split of 16 (model/layers.py, clip.py: what autograd
+ * does one layer at a time at crog_engine.py:87).  Same results as n crog_gemm calls up to the order of the fp32 atomic adds. */
+int crog_gemm_group(const crog_gemm_desc* descs, int n, crog_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm, training mode with optional cross-replica statistics (nn.BatchNorm2d/1d under

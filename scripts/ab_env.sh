@@ -6,7 +6,7 @@ out=$1; shift
 for pass in $(seq 1 ${AB_PASSES:-2}); do
   for cfg in "$@"; do
     if [ "$cfg" = "-" ]; then e=""; else e="$cfg"; fi
-    r=$(env $e python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])")
+    r=$(env $e python bench.py --no-cpu-baseline ${BENCH_ARGS:-} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])")
     echo "pass $pass [$cfg] $r" >> $out
   done
 done

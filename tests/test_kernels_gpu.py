@@ -214,6 +214,43 @@ def test_ping_pong_256x256x64_kernel(K, monkeypatch, case):
     monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
 
 
+def test_grouped_weight_gradients_in_one_launch(K):
+    """crog_gemm_group: dense and 3x3 weight gradients of different sizes and splits side by side in one launch of the ping-pong
+    weight-gradient kernel; every output equals the float64 product (and what was in the gradient before), nothing else is touched."""
+    dt = torch.bfloat16
+    probs = [  # (pixels (B, H, W), Cin, Cout, 3x3?, splitk)
+        ((8, 26, 26), 512, 512, False, 4), ((8, 26, 26), 256, 256, True, 3), ((8, 26, 26), 1024, 264, False, 2),
+        ((2, 52, 52), 64, 256, True, 5), ((3, 13, 13), 512, 264, True, 1), ((8, 26, 26), 256, 1024, False, 4)]
+    sink, keep, want = [], [], []
+    K.GROUP_SINK = sink
+    try:
+        for i, ((B, H, W), cin, cout, conv3, sk) in enumerate(probs):
+            Kd = B * H * W
+            N = 9 * cin if conv3 else cin
+            x = rnd(Kd, cin, dt=dt, seed=2 * i)
+            dy = (rnd(Kd, cout, dt=dt, seed=2 * i + 1) * 0.1).to(dt)
+            g = torch.full((cout + 1, N + 8), 0.5, device="cuda")
+            K.gemm(1, K.A_MC, K.B_NC_IM2COL if conv3 else K.B_NC, dy, x, g, cout, N, Kd, cout, cin, N + 8, splitk=sk,
+                   out_mode=K.OUT_F32_ATOMIC, conv=(H, W, cin) if conv3 else (0, 0, 0))
+            if conv3:
+                xi = x.double().view(B, H, W, cin).permute(0, 3, 1, 2)
+                cols = torch.nn.functional.unfold(xi, 3, padding=1).view(B, cin, 9, H * W).permute(0, 3, 2, 1).reshape(Kd, 9 * cin)
+            else:
+                cols = x.double()
+            keep.append((x, dy, g))
+            want.append(dy.double().t() @ cols)
+    finally:
+        K.GROUP_SINK = None
+    assert len(sink) == len(probs)
+    K.gemm_group(sink)
+    torch.cuda.synchronize()
+    for (x, dy, g), ref, ((B, H, W), cin, cout, conv3, sk) in zip(keep, want, probs):
+        N = ref.shape[1]
+        assert (g[cout] == 0.5).all() and (g[:, N:] == 0.5).all(), "wrote outside the M x N block"
+        got = g[:cout, :N].double() - 0.5
+        assert _rel_l2(got, ref) < 2e-3, (cin, cout, conv3, _rel_l2(got, ref))
+
+
 @pytest.mark.parametrize("case", [
     # (M, K, N, 3x3 geometry or None, rows bit, bias, act, residual, statistics)
     (2100, 256, 512, None, 512, True, "relu", False, False),          # linear + bias + ReLU (decoder FFN), ragged last row tile
