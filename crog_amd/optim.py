@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import List
 
+import os
+
 import torch
 
 from . import kernels as K
@@ -164,6 +166,7 @@ class FusedAdam(torch.optim.Optimizer):
             for s in {id(x): x for x in [cur, self._home] + list(RT.streams) if x is not None}.values():
                 if s != side:
                     side.wait_stream(s)
+            prev_override = K._STREAM_OVERRIDE      # (an announcement can arrive from inside a weight-gradient closure: Runtime.flush_group)
             K.set_stream_override(side.cuda_stream)
         try:
             if self.capturable:
@@ -178,7 +181,7 @@ class FusedAdam(torch.optim.Optimizer):
                             self._step + 1, shadow=store.S, off=c.off)
         finally:
             if side is not None:
-                K.set_stream_override(None)
+                K.set_stream_override(prev_override)
         if early:
             self.early_launches += 1
 
