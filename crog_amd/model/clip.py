@@ -38,8 +38,9 @@ class Bottleneck(Bound):
 
     def forward(self, x, res_in=None, res_out=None):
         """res_in / res_out (Stage.forward): BnLinks to the previous / next block of the stage - this block's first data
-        gradient does the previous block's bn3 first backward pass (Fn.BN_RES_FUSED).  Only an identity block can be the consumer:
-        its conv1 data gradient already adds the identity path's gradient, i.e. it writes the COMPLETE gradient of its input."""
+        gradient does the previous block's bn3 first backward pass (Fn.BN_RES_FUSED).  The consumer's conv1 data gradient adds the
+        gradient of the block's other branch (identity, or avgpool / downsample through the slot), i.e. it writes the COMPLETE gradient
+        of the block's input; ConvBnAct.backward only arms the link when that second gradient is really there."""
         tr = self.training
         # x has two consumers (conv1 and the identity / downsample branch): the second branch's gradient rides a slot into conv1's
         # dgrad epilogue (no separate accumulation pass).  Valid because that branch is created after conv1 / conv2, so autograd runs
@@ -51,7 +52,7 @@ class Bottleneck(Bound):
         l1 = Fn.BnLink() if tr else None
         l2 = Fn.BnLink() if (tr and self.stride == 1) else None
         out = Fn.conv_bn_act(x, self.conv1.w, self.bn1.buffers_ref(), ksize=1, relu=True, training=tr, grad_slot=slot, stat_out=l1,
-                             res_in=res_in if not ds else None)
+                             res_in=res_in)
         out = Fn.conv_bn_act(out, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=l1, stat_out=l2)
         if self.stride > 1:
             out = Fn.avgpool2(out)
@@ -69,11 +70,14 @@ class Stage(nn.Sequential):
     """A stage of Bottlenecks (clip.py:187-195: nn.Sequential, same child names) with a BnLink between consecutive blocks: block b's
     output feeds block b + 1 and nothing else."""
 
-    def forward(self, x):
+    def forward(self, x, res_in=None, res_out=None):
+        """res_in / res_out: links to the previous / next STAGE, when this stage's input / output has no other consumer (layer1 ->
+        layer2; the outputs of layer2 and layer3 also feed the neck, layer4's the attention pool)."""
         blocks = list(self)
-        link = None
+        link = res_in
         for i, blk in enumerate(blocks):
-            nxt = Fn.BnLink() if (self.training and i + 1 < len(blocks) and blocks[i + 1].downsample is None) else None
+            last = i + 1 == len(blocks)
+            nxt = res_out if last else (Fn.BnLink() if self.training else None)
             x = blk(x, res_in=link, res_out=nxt)
             link = nxt
         return x
@@ -172,10 +176,11 @@ class ModifiedResNet(Bound):
         x = Fn.conv_bn_act(x, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=s1, stat_out=s2)
         x = Fn.conv_bn_act(x, self.conv3.w, self.bn3.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=s2)
         x = Fn.avgpool2(x)
-        x = self.layer1(x)
+        l12 = Fn.BnLink() if tr else None          # layer1's output feeds layer2 and nothing else
+        x = self.layer1(x, res_out=l12)
         if after_layer1 is not None:
             after_layer1()
-        x2 = self.layer2(x)
+        x2 = self.layer2(x, res_in=l12)
         if after_layer1 is not None:
             after_layer1()
         x3 = self.layer3(x2)

@@ -31,9 +31,9 @@ class CoordConv(Bound):
         K.coord_fill(buf, self.cin, self.cpad)
         return buf
 
-    def forward(self, buf):
+    def forward(self, buf, stat_out=None):
         cout = self.conv1.conv.weight.shape[0]
-        return self.conv1.run(buf, ksize=3, wpad=(self.cin + 2, self.cpad, cout * 9))
+        return self.conv1.run(buf, ksize=3, wpad=(self.cin + 2, self.cpad, cout * 9), stat_out=stat_out)
 
 
 class FPN(Bound):
@@ -72,17 +72,21 @@ class FPN(Bound):
         f4 = self.f2_cat.run(Fn.join(cat2, [a, b]), out=cat3[..., o0:])
         # fusion 3: cat([avgpool(f3_v_proj(v3)), f4])
         f3 = Fn.avgpool2(self.f3_v_proj.run(v3), out=Fn.OutRef(cat3[..., :o0]))
-        f3 = self.f3_cat.run(Fn.join(cat3, [f3, f4]))
+        # (f3 feeds f4_proj3 and nothing else, the CoordConv output only coordconv[1]: the consumer's data gradient does the producer's
+        # first BatchNorm-backward pass, Fn.BnLink)
+        tr = self.training
+        l3, lc = (Fn.BnLink(), Fn.BnLink()) if tr else (None, None)
+        f3 = self.f3_cat.run(Fn.join(cat3, [f3, f4]), stat_out=l3)
         # fusion 4
         catq = torch.empty(B, H4, W4, 3 * o1, device=dev, dtype=dt)
         fq5 = Fn.upsample2(self.f4_proj5.run(f5), out=Fn.OutRef(catq[..., 2 * o1:]))
         fq4 = self.f4_proj4.run(f4, out=catq[..., o1:2 * o1])
-        fq3 = self.f4_proj3.run(f3, out=catq[..., :o1])
+        fq3 = self.f4_proj3.run(f3, out=catq[..., :o1], stat_in=l3)
         cc = self.coordconv[0]
         cbuf = cc.make_input(B, H4, W4, dev, dt)
         fq = self.aggr.run(Fn.join(catq, [fq3, fq4, fq5]), out=cbuf[..., :o1])
-        fq = cc(Fn.join(cbuf, [fq]))
-        return self.coordconv[1].run(fq)
+        fq = cc(Fn.join(cbuf, [fq]), stat_out=lc)
+        return self.coordconv[1].run(fq, stat_in=lc)
 
 
 _POS_CACHE = {}
