@@ -715,13 +715,15 @@ class LinearFn(Function):
             wgrad()   # dy is handed on as the residual's gradient and autograd may accumulate into it IN PLACE: keep the read ordered
         else:
             RT.on_wgrad_stream(wgrad, g, x)
-        w.done()
-        if b is not None:
-            b.done()
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
             lin_dgrad(g, w, dx)
+        # announced AFTER the data gradient that reads the weight is enqueued: an optimizer chunk / DDP bucket this completes may be
+        # stepped as soon as the NEXT one completes (optim.py: overlap_backward), which can be the bias a line below
+        w.done()
+        if b is not None:
+            b.done()
         return dx, dres, None, None, None, None, None, None
 
 
@@ -928,11 +930,11 @@ class MhaFn(Function):
             wgrad_out()   # dout doubles as the residual's gradient (possible in-place accumulation by autograd): stay on this stream
         else:
             RT.on_wgrad_stream(wgrad_out, dout, O)
-        wo.done()
-        if bo is not None:
-            bo.done()
         dO = torch.empty(B * Lq, E, device=dev, dtype=dtype)
         lin_dgrad(dout, wo, dO)
+        wo.done()      # (after the data gradient that reads it: see LinearFn.backward)
+        if bo is not None:
+            bo.done()
         # gradient buffers mirror the projection buffers
         if qb[0] is kb[0]:
             dqkv = torch.empty_like(qb[0])
@@ -1244,9 +1246,6 @@ class Conv3BiasActFn(Function):
             wgrad_gemm(dt, K.B_NC_IM2COL, g, x, w.G, C, 9 * cin, M, C, K.mat(x)[2], w.cols, c_off=w.off, conv=(H, W, cin),
                        a_sum=bb.G if bb is not None else None, a_sum_off=bb.off if bb is not None else 0)
         RT.on_wgrad_stream(wgrad, g, x)
-        w.done()
-        if b is not None:
-            b.done()
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
@@ -1254,6 +1253,9 @@ class Conv3BiasActFn(Function):
                 K.gemm(dt, K.A_IM2COL, K.B_KC, g, w.store.weights_t(x.dtype), dx, M, cin, 9 * C, C, 9 * C, cin, b_off=w.off, conv=(H, W, C))
             else:
                 K.gemm(dt, K.A_IM2COL, K.B_NC_DGRAD, g, w.w(x.dtype), dx, M, cin, 9 * C, C, cin, cin, b_off=w.off, conv=(H, W, C))
+        w.done()       # (after the data gradient that reads it: see LinearFn.backward)
+        if b is not None:
+            b.done()
         return dx, None, None, None, None, None
 
 
@@ -1449,7 +1451,6 @@ class TableMatmulFn(Function):
         C = table.cols
         dt = K.dcode(dout)
         wgrad_gemm(dt, K.B_NC, A, dout, table.G, table.rows, C, R, Kp, K.mat(dout)[2], C, c_off=table.off)
-        table.done()
         dA = None
         if a_grad:
             dA = torch.empty_like(A)
@@ -1457,6 +1458,7 @@ class TableMatmulFn(Function):
             K.gemm(dt, K.A_KC, K.B_KC, dout, table.w(dout.dtype), dA, R, table.rows, C, K.mat(dout)[2], C, Kp, b_off=table.off)
             if Kp > table.rows:
                 dA[:, table.rows:].zero_()
+        table.done()
         return dA, None, None, None
 
 
@@ -1518,11 +1520,11 @@ class DynHeadFn(Function):
         K.head_unpack_wgrad(dwpad, dbias, dword, B, C)
         nout = C * 9 + 1
         lin_wgrad(dword, state, tw, N=nout)
-        tw.done()
         bias_grad(dword[:, :nout], tb)
-        tb.done()
         dstate = torch.empty_like(state)
         lin_dgrad(dword, tw, dstate, N=nout)
+        tw.done()      # (after the data gradient that reads it: see LinearFn.backward)
+        tb.done()
         return dx5, dstate, None, None, None, None, None
 
 
@@ -1601,7 +1603,6 @@ class FusedHeadFn(Function):
         else:
             K.gemm(dt, K.A_KC, K.B_NC, wpad, dWf_c, w5.G, C, C, 16, 16, C, w5.cols, batch=B * g, batch_inner=g, sA=(C * 16, 0),
                    sB=(g * 16 * C, 16 * C), sC=(0, C * w5.cols), c_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
-        w5.done()
         # dwpad[b][c][tap] = sum_g sum_k W5[g*C + c][k] * dWf[b][g][tap][k]   (+ the cb share below)
         dwpad = torch.zeros(B, C, 16, device=dev, dtype=torch.float32)
         if RT.deterministic:
@@ -1613,16 +1614,18 @@ class FusedHeadFn(Function):
             K.gemm(dt, K.A_KC, K.B_KC, w5.w(dtype), dWf_c, dwpad, C, 16, C, w5.cols, C, 16, batch=B * g, batch_inner=g, sA=(0, C * w5.cols),
                    sB=(g * 16 * C, 16 * C), sC=(C * 16, 0), a_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
         K.head_cb_bwd(b5.P, b5.off, wpad, dcb, b5.G, b5.off, dwpad, B, g, C)
-        b5.done()
         dword = torch.empty(B, ldw, device=dev, dtype=dtype)
         K.head_unpack_wgrad(dwpad, dbias, dword, B, C)
         nout = C * 9 + 1
         lin_wgrad(dword, state, tw, N=nout)
-        tw.done()
         bias_grad(dword[:, :nout], tb)
-        tb.done()
         dstate = torch.empty_like(state)
         lin_dgrad(dword, tw, dstate, N=nout)
+        # (all four announced after the last kernel that reads them is enqueued: see LinearFn.backward)
+        w5.done()
+        b5.done()
+        tw.done()
+        tb.done()
         return (dx4, dstate) + (None,) * 10
 
 

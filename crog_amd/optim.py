@@ -116,10 +116,13 @@ class FusedAdam(torch.optim.Optimizer):
         its weights - has been enqueued, and the launch waits for all streams), the rest in step().  The announcement counts per
         parameter are learnt from the first armed backward, which updates nothing early; a later backward that announces a
         parameter MORE often than learnt (not a static step) raises in step()."""
-        if self._store is None or RT.reducer is not None or not self._store.explicit:
+        if self._store is None or not self._store.explicit:
             return
         if any(g["weight_decay"] != 0 for g in self.param_groups):
             return      # (weight decay skips parameters without a gradient, _decay_segments: known only once backward is over)
+        if RT.reducer is not None:
+            self._arm_buckets()
+            return
         if self._segments is None:
             self._build()
         if self.capturable and not torch.cuda.is_current_stream_capturing():
@@ -134,6 +137,87 @@ class FusedAdam(torch.optim.Optimizer):
             return
         for c in self._chunks:
             c.pending, c.fired = c.expect, False
+
+    # ---- the same under DistributedDataParallel: per gradient bucket ------------------------------------------------------------
+    def _arm_buckets(self):
+        """DDP (crog_amd.parallel.Reducer with the C-ABI communicator): a gradient bucket's all-reduce is enqueued on a carrier stream
+        as soon as its last gradient is announced; the bucket's slice of the parameters is stepped on that SAME stream, behind the
+        collective - one bucket LATER, when the next bucket is launched (by then every kernel of the first bucket's layers, also the
+        data gradients that still read its weights, has been enqueued, and the launch waits for all streams), the rest in step().
+        The update no longer waits for the last all-reduce: 0.9 ms of Adam per step leave the end of the step."""
+        red = RT.reducer
+        if getattr(red, "direct", None) is None or not self._store.G.is_cuda:
+            return      # (torch.distributed buckets are async work handles: no stream to ride on)
+        if self._segments is None:
+            self._build()
+        if self.capturable and not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        self._bucket_mode = True
+        self._bucket_done = []
+        self._bucket_ripe = None
+        self._advanced = set()
+        self._home = torch.cuda.current_stream()
+        red.after_launch = self._on_bucket
+
+    def _on_bucket(self, b, carrier):
+        prev, self._bucket_ripe = self._bucket_ripe, (b["start"], b["numel"], carrier)
+        if prev is not None:
+            self._step_range(*prev)
+
+    def _step_piece(self, gi, off, n):
+        store, group = self._store, self.param_groups[gi]
+        b1, b2 = group["betas"]
+        if self.capturable:
+            hyper = self._hyper[gi]
+            if gi not in self._advanced:
+                self._advanced.add(gi)
+                K.adam_advance(hyper, b1, b2)
+            K.adam_step_dev(store.P, store.G, self.m, self.v, n, hyper, b1, b2, group["eps"], group["weight_decay"], shadow=store.S, off=off)
+        else:
+            K.adam_step(store.P, store.G, self.m, self.v, n, group["lr"], b1, b2, group["eps"], group["weight_decay"], self._step + 1,
+                        shadow=store.S, off=off)
+
+    def _step_range(self, start, numel, carrier):
+        """Adam over [start, start + numel) of the flat buffers (cut along the learning-rate groups), on `carrier` behind everything
+        enqueued so far on any stream, or - carrier None - on the current stream."""
+        prev_override = K._STREAM_OVERRIDE
+        if carrier is not None:
+            cur = torch.cuda.current_stream()
+            for s in {id(x): x for x in [cur, self._home] + list(RT.streams) if x is not None}.values():
+                if s != carrier:
+                    carrier.wait_stream(s)
+            K.set_stream_override(carrier.cuda_stream)
+        try:
+            for gi, segs in enumerate(self._segments):
+                for o, n in segs:
+                    lo, hi = max(o, start), min(o + n, start + numel)
+                    if lo < hi:
+                        self._step_piece(gi, lo, hi - lo)
+        finally:
+            if carrier is not None:
+                K.set_stream_override(prev_override)
+        self._bucket_done.append((start, numel))
+        self.early_launches += 1
+
+    def _finish_buckets(self):
+        """step() after a backward with per-bucket updates: everything no bucket has stepped yet, on the current stream (which has
+        joined the carriers: Reducer.wait)."""
+        self._bucket_mode = False
+        if RT.reducer is not None:
+            RT.reducer.after_launch = None
+        done = sorted(self._bucket_done)
+        for gi, segs in enumerate(self._segments):
+            for o, n in segs:
+                pos = o
+                for ds, dn in done:
+                    if ds + dn <= pos or ds >= o + n:
+                        continue
+                    if ds > pos:
+                        self._step_piece(gi, pos, ds - pos)
+                    pos = max(pos, ds + dn)
+                if pos < o + n:
+                    self._step_piece(gi, pos, o + n - pos)
+        self._bucket_done, self._bucket_ripe = [], None
 
     def mark_ready(self, param):
         """WRef.done(): one of the kernels that write this parameter's gradient has been enqueued."""
@@ -276,6 +360,15 @@ class FusedAdam(torch.optim.Optimizer):
             # there would be replayed with the capture-time learning rate every step - GraphedTrainStep syncs before capture / replay)
             self.sync_lr()
         store = self._store
+        if getattr(self, "_bucket_mode", False):
+            self._finish_buckets()
+            self._step += 1
+            if store.S is not None:
+                store.shadow_written()
+            else:
+                store.invalidate_shadow()
+            store.g_clean = False
+            return loss
         if self._armed and self._finish_overlapped():
             # overlapped update: most chunks were stepped inside backward; the rest (and every chunk of a learning-rate group whose
             # parameters never announce a gradient) go now, on the current stream, which has joined the side streams above

@@ -179,6 +179,7 @@ class Reducer:
         self._armed = False
         self._use_avg = dist.get_backend(group) == "nccl"
         self.launches = 0       # bucket all-reduces issued (bench.py reports the per-step count)
+        self.after_launch = None   # callable(bucket, carrier stream): FusedAdam's per-bucket update rides the carrier (optim.py: _arm_buckets)
         self.reset()
 
     def reset(self):
@@ -225,6 +226,8 @@ class Reducer:
                 if b["wire"] is not None:
                     view.copy_(b["wire"])          # widen the averaged payload back into the fp32 gradient buffer
             b["carrier"], b["work"], b["direct"] = carrier, None, True
+            if self.after_launch is not None:
+                self.after_launch(b, carrier)
             return
         b["direct"] = False
         if self.G.is_cuda:

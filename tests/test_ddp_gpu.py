@@ -148,3 +148,55 @@ def test_syncbn_bf16_rows_allreduced_match_plain(rccl_world1):
         worst = max(worst, rel(a, c))
         assert rel(a, c) <= max(4 * rel(a, b), 2e-2), (n, rel(a, c), rel(a, b))
     print("bf16 SyncBN vs plain: worst relative L2 over", len(names), "parameters:", worst)
+
+
+def test_ddp_buckets_are_stepped_on_their_carrier_stream(rccl_world1, monkeypatch):
+    """FusedAdam.overlap_backward under DistributedDataParallel (optim.py: _arm_buckets): every gradient bucket but the last is stepped
+    inside backward, on the stream its all-reduce was enqueued on, one bucket late.  Adam is elementwise, so the parameters and moments
+    after two steps must equal - bit for bit, in deterministic mode - those of the same steps with the whole update in step()."""
+    import test_model_gpu as T
+    import crog_amd.model.crog as crog_mod
+    from crog_amd.optim import FusedAdam
+    from crog_amd.parallel import DistributedDataParallel, convert_sync_batchnorm
+    from crog_amd.runtime import RT, set_deterministic
+    g, meta = T.load_case("tiny_crog")
+    cfg = tiny_cfg()
+    b = T.batch_for(cfg, meta)
+    monkeypatch.setattr(crog_mod, "TEXT_GRAPH", False)
+    set_deterministic(True)
+    try:
+        def run(overlap):
+            model, groups = T.build(cfg, meta, dtype=torch.float32)
+            model.train()
+            convert_sync_batchnorm(model, force=True)
+            net = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True, force=True, bucket_cap_mb=0.25)
+            opt = FusedAdam(groups, lr=1e-4, store=model.store)
+            early = []
+            for _ in range(3):
+                RT.manual_seed(5)
+                _, _, loss, _ = net(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+                opt.zero_grad()
+                n0 = opt.early_launches
+                if overlap:
+                    opt.overlap_backward()
+                loss.backward()
+                early.append(opt.early_launches - n0)
+                opt.step()
+            torch.cuda.synchronize()
+            nb = len(net.reducer.buckets)
+            assert net.reducer.direct is not None and net.reducer.after_launch is None
+            res = model.store.P.clone(), opt.m.clone(), opt.v.clone(), opt._step
+            run.entries = [(n, o, k) for n, p_, o, k, _ in model.store.entries]
+            RT.comm = None
+            RT.reducer = None
+            return res, early, nb
+        (p0, m0, v0, s0), e0, nb = run(False)
+        (p1, m1, v1, s1), e1, _ = run(True)
+    finally:
+        set_deterministic(False)
+    bad = [(n, o, k, int((p0[o:o + k] != p1[o:o + k]).sum())) for n, o, k in run.entries if not torch.equal(p0[o:o + k], p1[o:o + k])]
+    assert e0 == [0, 0, 0] and nb > 3
+    assert all(e == nb - 1 for e in e1), (e1, nb)      # all buckets but the last launched one were stepped during backward
+    assert s0 == s1 == 3
+    assert not bad, (len(bad), bad[:8])      # (a parameter stepped while a data gradient still read it changes everything downstream)
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
