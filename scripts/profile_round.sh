@@ -16,10 +16,10 @@ cp profiles/pmc_traffic.json $out/pmc_keep.json
 PROFILE_ENV="CROG_SINGLE_STREAM=1 " PROFILE_NOTE="Single-stream run (no weight-gradient / text-tower side streams): per-kernel durations are the kernels' own." python3 scripts/summarize_profile.py ${tag}_serial $out/stats1 $out/fetch $out/write 7 6 > $out/summarize1.log 2>&1
 cp $out/pmc_keep.json profiles/pmc_traffic.json
 unset CROG_SINGLE_STREAM
-f=$(find $out/stats -name "*kernel_trace.csv" | head -1); python3 scripts/chain_breakdown.py $f > profiles/${tag}_chains.txt 2>&1; python3 scripts/by_grid.py $f 7 140 > profiles/${tag}_by_grid.txt 2>&1; python3 scripts/chain_gaps.py $f > profiles/${tag}_chain_gaps.txt 2>&1
-f1=$(find $out/stats1 -name "*kernel_trace.csv" | head -1); python3 scripts/by_grid.py $f1 7 140 > profiles/${tag}_serial_by_grid.txt 2>&1
+f=$(find $out/stats -name "*kernel_trace.csv" | head -1); python3 scripts/chain_breakdown.py $f > profiles/${tag}_chains.txt 2>&1; python3 scripts/by_grid.py $f 7 140 --last 3 > profiles/${tag}_by_grid.txt 2>&1; python3 scripts/chain_gaps.py $f > profiles/${tag}_chain_gaps.txt 2>&1
+f1=$(find $out/stats1 -name "*kernel_trace.csv" | head -1); python3 scripts/by_grid.py $f1 7 140 --last 3 > profiles/${tag}_serial_by_grid.txt 2>&1
 cp profiles/${tag}_chain_gaps.txt profiles/${tag}_by_grid.txt profiles/${tag}_serial_by_grid.txt profiles/${tag}_summary.md profiles/${tag}_serial_summary.md profiles/${tag}_kernel_stats.csv profiles/${tag}_serial_kernel_stats.csv profiles/pmc_traffic.json profiles/${tag}_chains.txt $out/ 2>/dev/null
 python3 bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.err
 tail -c 1500 $out/bench.json
 tail -3 $out/summarize.log; tail -3 $out/summarize1.log; head -3 profiles/${tag}_chains.txt
-find $out -name "*kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -size +15M -delete
+for t in $(find $out -name "*kernel_trace.csv"); do gzip -c $t > $out/$(basename $(dirname $(dirname $t)))_trace.csv.gz; done; find $out -name "*kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -size +15M -delete
