@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round profile on the GPU box (from the repo root): overlapped (default replay) and single-stream kernel stats, the two PMC passes,
-# then the default bench line.  usage: bash scripts/profile_round.sh <tag>
+# then the default bench line.  usage: bash scripts/profile_round.sh <tag>; afterwards copy gpurun_out/prof_<tag>/<tag>_* (and the two
+# *_trace.csv.gz as profiles/<tag>_[serial_]kernel_trace.csv.gz) into profiles/: only gpurun_out/ travels back from the GPU box
 # bench.py --steps 3 --warmup 2 executes 7 steps (2 warm-ups, 1 more eager step, capture + first replay, 3 timed replays);
 # --steps 2 --warmup 1 executes 6.
 tag=${1:-r04}
