@@ -882,7 +882,10 @@ extern "C" int crog_conv3_dgrad_weights(int dtype, const void* src, void* dst, c
 extern "C" int crog_dgrad_weights(int dtype, const void* src, void* dst, const int64_t* table, int count, crog_stream_t s) {
   if (count <= 0) return CROG_OK;
   CROG_CHECK_ARG(src && dst && table && count <= 65535, "dgrad_weights: null pointer or more than 65535 entries");
-  DISPATCH_T(dtype, hipLaunchKernelGGL((conv3_dgrad_weights_kernel<T, 4>), dim3(24, count), dim3(NT), 0, (hipStream_t)s, (const T*)src, (T*)dst,
+  static const int gx = [] { const char* e = getenv("CROG_DGW_GRID"); return e ? atoi(e) : 384; }();
+  // (blocks per table entry.  The matrices range from one 64 x 64 tile to 1152: with 24 blocks per entry the largest took 48 tiles per
+  // block and the launch 287 us for 450 MB of traffic; 96: 170, 192: 155, 384: 126, 768: 123 us - most blocks of a small entry exit at once)
+  DISPATCH_T(dtype, hipLaunchKernelGGL((conv3_dgrad_weights_kernel<T, 4>), dim3(gx, count), dim3(NT), 0, (hipStream_t)s, (const T*)src, (T*)dst,
                                        reinterpret_cast<const long*>(table)));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
