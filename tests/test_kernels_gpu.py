@@ -1357,7 +1357,8 @@ def test_timing_only_events_measure_a_launch(K):
         assert torch.equal(dst[:n], src[:n]) and int(dst[n:].sum()) == 0, mode
 
 
-@pytest.mark.parametrize("M,N,K_,layout", [(4096, 256, 64, "nc"), (1000, 72, 96, "kc"), (21632, 1024, 256, "kc"), (2500, 512, 128, "nc")])
+@pytest.mark.parametrize("M,N,K_,layout", [(4096, 256, 64, "nc"), (1000, 72, 96, "kc"), (21632, 1024, 256, "kc"), (2500, 512, 128, "nc"),
+                                           (4096, 256, 64, "kc"), (1280, 128, 512, "kc")])
 def test_dgrad_epilogue_gates_a_residual_layer_with_its_bit_mask(K, M, N, K_, layout):
     """crog_gemm bwd_z + bwd_mask + R: the data gradient of a block's first convolution, plus the gradient of that block's identity
     path, is the gradient of the PREVIOUS block's output relu(bn3(z) + identity): the epilogue adds R, gates with the forward's bit
