@@ -212,6 +212,12 @@ __device__ inline void ld_pairs(const float* __restrict__ p, float (&a)[VEC], fl
   }
 }
 
+// Row of a 2 x 2-average-pooled [B][H/2][W/2] map that pixel row r of the [B][H][W] map falls into (H, W even; r < 2^31)
+__device__ inline long pooled_row(long r, int H, int W) {
+  const unsigned rr = (unsigned)r, x = rr % (unsigned)W, t = rr / (unsigned)W, y = t % (unsigned)H, b = t / (unsigned)H;
+  return (long)(b * (unsigned)(H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+}
+
 // y = [relu]( z*scale + shift [+ res] )
 template <typename T>
 __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ z, long ldz, const float* __restrict__ scale_shift,
@@ -261,7 +267,7 @@ __global__ void __launch_bounds__(NT) bn_apply_stats_kernel(const T* __restrict_
                                                             float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                                                             float eps, float* __restrict__ scale_shift, float* __restrict__ mean_invstd,
                                                             const T* __restrict__ res, long ldr, int relu, T* __restrict__ y, long ldy, long M,
-                                                            int C, unsigned char* __restrict__ relu_mask) {
+                                                            int C, unsigned char* __restrict__ relu_mask, int poolH, int poolW) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) float ss[];   // [C][2]
   for (int c = threadIdx.x; c < C; c += NT) {
@@ -290,6 +296,32 @@ __global__ void __launch_bounds__(NT) bn_apply_stats_kernel(const T* __restrict_
   }
   __syncthreads();
   const int cvec = C / VEC;
+  if (poolW) {
+    // ... followed by the 2 x 2 average pooling of the reference's strided layers (clip.py:49-50 avgpool after bn2 + relu, 213-214 the
+    // stem's): y is the POOLED [B][H/2][W/2][C] map, one thread per output vector, its four pixels normalised (and rectified) in
+    // registers - the full-resolution activation is never written or read back (the backward pass regates from z)
+    const int Wo = poolW >> 1, Ho = poolH >> 1;
+    const long total = (M >> 2) * cvec;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+      const unsigned ro = (unsigned)(i / cvec);
+      const int c = (int)(i % cvec) * VEC;
+      const unsigned xo = ro % (unsigned)Wo, t = ro / (unsigned)Wo, yo = t % (unsigned)Ho, b = t / (unsigned)Ho;
+      const long r00 = ((long)(b * (unsigned)poolH + 2 * yo)) * poolW + 2 * xo;
+      const Vec16<T> v0 = ldg16(z + r00 * ldz + c), v1 = ldg16(z + (r00 + 1) * ldz + c);
+      const Vec16<T> v2 = ldg16(z + (r00 + poolW) * ldz + c), v3 = ldg16(z + (r00 + poolW + 1) * ldz + c);
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        const float sc = ss[2 * (c + e)], sh = ss[2 * (c + e) + 1];
+        float a0 = Elem<T>::to_f(v0.v[e]) * sc + sh, a1 = Elem<T>::to_f(v1.v[e]) * sc + sh;
+        float a2 = Elem<T>::to_f(v2.v[e]) * sc + sh, a3 = Elem<T>::to_f(v3.v[e]) * sc + sh;
+        if (relu) { a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f); a2 = fmaxf(a2, 0.f); a3 = fmaxf(a3, 0.f); }
+        o.v[e] = Elem<T>::from_f(0.25f * ((a0 + a1) + (a2 + a3)));
+      }
+      stg16(y + (long)ro * ldy + c, o);
+    }
+    return;
+  }
   const long total = M * cvec;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
     const long r = i / cvec;
@@ -326,7 +358,9 @@ template <typename T>
 __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
                                                             const T* __restrict__ z, long ldz, const float* __restrict__ mean_invstd,
                                                             const float* __restrict__ relu_ss, long M, int C, int rows_per_block,
-                                                            float* __restrict__ partial, int replicas, const unsigned char* __restrict__ relu_mask) {
+                                                            float* __restrict__ partial, int replicas, const unsigned char* __restrict__ relu_mask,
+                                                            int poolH, int poolW) {
+  // poolW != 0: dy is the gradient of the 2 x 2-average-POOLED output ([B][poolH/2][poolW/2][C]); pixel r takes a quarter of its cell's
   constexpr int VEC = Elem<T>::VEC;
   __shared__ float red[NT][2 * VEC + 1];
   const int cvec = C / VEC;
@@ -342,13 +376,17 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
     ld_pairs<VEC>(mean_invstd + 2 * c, mu, is);
     if (relu_ss) ld_pairs<VEC>(relu_ss + 2 * c, rsc, rsh);
     for (long r = r0 + ty; r < r1; r += nty) {
-      Vec16<T> g = ldg16(dy + r * lddy + c);
+      Vec16<T> g = ldg16(dy + (poolW ? pooled_row(r, poolH, poolW) : r) * lddy + c);
       Vec16<T> zz = ldg16(z + r * ldz + c);
       Vec16<T> yy;
       if (y) yy = ldg16(y + r * ldy + c);
       float gf[VEC], zf[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; e++) { gf[e] = Elem<T>::to_f(g.v[e]); zf[e] = Elem<T>::to_f(zz.v[e]); }
+      if (poolW) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) gf[e] *= 0.25f;
+      }
       if (y) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) gf[e] = Elem<T>::to_f(yy.v[e]) > 0.f ? gf[e] : 0.f;
@@ -422,8 +460,10 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
                                                           const float* __restrict__ gamma, const float* __restrict__ sums, float count,
                                                           const float* __restrict__ relu_ss, T* __restrict__ dz, long lddz, T* __restrict__ dres,
                                                           long lddres, long M, int C, int sum_rows, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, const unsigned char* __restrict__ relu_mask, float pgrad_scale) {
+                                                          float* __restrict__ dbeta, const unsigned char* __restrict__ relu_mask, float pgrad_scale,
+                                                          int poolH, int poolW) {
   constexpr int VEC = Elem<T>::VEC;
+  const float gscale = poolW ? 0.25f : 1.f;      // pooled dy (see bn_bwd_partial_kernel): each pixel takes a quarter of its cell's gradient
   // sum_rows > 0: `sums` is [sum_rows][C][2] (atomic replicas of bn_bwd_partial, or the all-reduced totals): every block adds the
   // rows up into LDS once; block 0 also stores the parameter gradients (dbeta = sum g, dgamma = sum g*zhat) when asked to.
   // sum_rows < 0: |sum_rows| rows of RAW z-moments (sum g, sum g*z) from a data-gradient GEMM's epilogue (crog_gemm bwd_z):
@@ -478,7 +518,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
     auto one = [&](const Vec16<T>& g, const Vec16<T>& zz, const Vec16<T>& yy, unsigned bits, long r) {
       float gf[VEC], zf[VEC];
 #pragma unroll
-      for (int e = 0; e < VEC; e++) { gf[e] = Elem<T>::to_f(g.v[e]); zf[e] = Elem<T>::to_f(zz.v[e]); }
+      for (int e = 0; e < VEC; e++) { gf[e] = Elem<T>::to_f(g.v[e]) * gscale; zf[e] = Elem<T>::to_f(zz.v[e]); }
       if (y) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) gf[e] = Elem<T>::to_f(yy.v[e]) > 0.f ? gf[e] : 0.f;
@@ -501,7 +541,8 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
     };
     long r = i0 >> lg, i = i0;
     for (; r < M; r += rstep, i += G) {
-      Vec16<T> g = ldg16_nt(dy + r * lddy + c), zz = ldg16_nt(z + r * ldz + c), yy;      // last readers of dy and z: non-temporal
+      // last readers of dy and z: non-temporal (a pooled dy row is read by four pixels: plain)
+      Vec16<T> g = poolW ? ldg16(dy + pooled_row(r, poolH, poolW) * lddy + c) : ldg16_nt(dy + r * lddy + c), zz = ldg16_nt(z + r * ldz + c), yy;
       if (y) yy = ldg16(y + r * ldy + c);
       one(g, zz, yy, relu_mask ? relu_mask[i] : 0u, r);
     }
@@ -510,7 +551,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
     const long r = i / cvec;
     const int c = (int)(i % cvec) * VEC;
-    Vec16<T> g = ldg16_nt(dy + r * lddy + c);      // last readers of dy and z: non-temporal
+    Vec16<T> g = poolW ? ldg16(dy + pooled_row(r, poolH, poolW) * lddy + c) : ldg16_nt(dy + r * lddy + c);      // last readers of dy and z: non-temporal
     Vec16<T> zz = ldg16_nt(z + r * ldz + c);
     Vec16<T> yy;
     if (y) yy = ldg16(y + r * ldy + c);
@@ -525,7 +566,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
     }
     ld_f32v<VEC>(gamma + c, gm);
 #pragma unroll
-    for (int e = 0; e < VEC; e++) { gf[e] = Elem<T>::to_f(g.v[e]); zf[e] = Elem<T>::to_f(zz.v[e]); }
+    for (int e = 0; e < VEC; e++) { gf[e] = Elem<T>::to_f(g.v[e]) * gscale; zf[e] = Elem<T>::to_f(zz.v[e]); }
     if (y) {
 #pragma unroll
       for (int e = 0; e < VEC; e++) gf[e] = Elem<T>::to_f(yy.v[e]) > 0.f ? gf[e] : 0.f;
@@ -1389,41 +1430,74 @@ extern "C" int crog_bn_apply(int dtype, const void* z, int64_t ldz, const float*
   return CROG_OK;
 }
 
-extern "C" int crog_bn_apply_stats(int dtype, const void* z, int64_t ldz, const float* sums, int replicas, float count, const float* gamma,
-                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                   float* scale_shift, float* mean_invstd, const void* res, int64_t ldr, int relu, void* y, int64_t ldy,
-                                   int64_t M, int C, void* relu_mask, crog_stream_t stream) {
+static int bn_apply_stats_impl(int dtype, const void* z, int64_t ldz, const float* sums, int replicas, float count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* scale_shift, float* mean_invstd, const void* res, int64_t ldr, int relu, void* y, int64_t ldy,
+                               int64_t M, int C, void* relu_mask, int poolH, int poolW, crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(poolW == 0 || (poolH > 0 && poolW > 0 && poolH % 2 == 0 && poolW % 2 == 0 && M % ((int64_t)poolH * poolW) == 0 && M < 0x7fffffffL &&
+                                !res && !relu_mask),
+                 "bn_apply_stats: pooled form needs even H, W, M = B * H * W < 2^31, no residual");
   CROG_CHECK_ARG(C % vec == 0 && ldz % vec == 0 && ldy % vec == 0 && (!res || ldr % vec == 0), "bn_apply_stats: C/ld must be multiples of %d", vec);
   CROG_CHECK_ARG(sums && replicas >= 1 && count > 0 && scale_shift && mean_invstd && C <= 8192, "bn_apply_stats: bad arguments");
   const int grid = std::min(stream_grid(M * (C / vec)), 1024);   // every block re-derives the C scale/shift pairs: keep the grid modest
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_stats_kernel<T>), dim3(grid), dim3(NT), (size_t)C * 2 * sizeof(float), (hipStream_t)stream,
                                        (const T*)z, (long)ldz, sums, replicas, count, gamma, beta, running_mean, running_var, momentum, eps,
-                                       scale_shift, mean_invstd, (const T*)res, (long)ldr, relu, (T*)y, (long)ldy, (long)M, C, (unsigned char*)relu_mask));
+                                       scale_shift, mean_invstd, (const T*)res, (long)ldr, relu, (T*)y, (long)ldy, (long)M, C, (unsigned char*)relu_mask,
+                                       poolH, poolW));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
+extern "C" int crog_bn_apply_stats(int dtype, const void* z, int64_t ldz, const float* sums, int replicas, float count, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                   float* scale_shift, float* mean_invstd, const void* res, int64_t ldr, int relu, void* y, int64_t ldy,
+                                   int64_t M, int C, void* relu_mask, crog_stream_t stream) {
+  return bn_apply_stats_impl(dtype, z, ldz, sums, replicas, count, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, mean_invstd,
+                             res, ldr, relu, y, ldy, M, C, relu_mask, 0, 0, stream);
+}
+extern "C" int crog_bn_apply_stats_pool(int dtype, const void* z, int64_t ldz, const float* sums, int replicas, float count, const float* gamma,
+                                        const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                        float* scale_shift, float* mean_invstd, int relu, void* y, int64_t ldy, int64_t M, int C, int H, int W,
+                                        crog_stream_t stream) {
+  return bn_apply_stats_impl(dtype, z, ldz, sums, replicas, count, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, mean_invstd,
+                             nullptr, 0, relu, y, ldy, M, C, nullptr, H, W, stream);
+}
 
-extern "C" int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
-                                   const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C, int rows_per_block,
-                                   float* partial, int replicas, const void* relu_mask, crog_stream_t stream) {
+static int bn_bwd_partial_impl(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
+                               const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C, int rows_per_block,
+                               float* partial, int replicas, const void* relu_mask, int poolH, int poolW, crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(poolW == 0 || (poolH > 0 && poolH % 2 == 0 && poolW % 2 == 0 && M % ((int64_t)poolH * poolW) == 0 && M < 0x7fffffffL),
+                 "bn_bwd_partial: pooled form needs even H, W and M = B * H * W < 2^31");
   CROG_CHECK_ARG(C % vec == 0 && pow2(C / vec), "bn_bwd_partial: C/vec must be a power of two (C=%d)", C);
   CROG_CHECK_ARG(replicas >= 0, "bn_bwd_partial: replicas must be >= 0");
   const int blocks = cdiv(M, rows_per_block);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dy,
                                        (long)lddy, (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, relu_scale_shift, (long)M, C,
-                                       rows_per_block, partial, replicas, (const unsigned char*)relu_mask));
+                                       rows_per_block, partial, replicas, (const unsigned char*)relu_mask, poolH, poolW));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
+extern "C" int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
+                                   const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C, int rows_per_block,
+                                   float* partial, int replicas, const void* relu_mask, crog_stream_t stream) {
+  return bn_bwd_partial_impl(dtype, dy, lddy, y, ldy, z, ldz, mean_invstd, relu_scale_shift, M, C, rows_per_block, partial, replicas, relu_mask, 0, 0, stream);
+}
+extern "C" int crog_bn_bwd_partial_pool(int dtype, const void* dy_pooled, int64_t lddy, const void* z, int64_t ldz, const float* mean_invstd,
+                                        const float* relu_scale_shift, int64_t M, int C, int rows_per_block, float* partial, int replicas,
+                                        int H, int W, crog_stream_t stream) {
+  return bn_bwd_partial_impl(dtype, dy_pooled, lddy, nullptr, 0, z, ldz, mean_invstd, relu_scale_shift, M, C, rows_per_block, partial, replicas, nullptr,
+                             H, W, stream);
+}
 
-extern "C" int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
-                                 const float* mean_invstd, const float* gamma, const float* sums, float count,
-                                 const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres, int64_t M, int C,
-                                 int sum_rows, float* dgamma, float* dbeta, float param_grad_scale, const void* relu_mask,
-                                 crog_stream_t stream) {
+static int bn_bwd_apply_impl(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
+                             const float* mean_invstd, const float* gamma, const float* sums, float count,
+                             const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres, int64_t M, int C,
+                             int sum_rows, float* dgamma, float* dbeta, float param_grad_scale, const void* relu_mask, int poolH, int poolW,
+                             crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
+  CROG_CHECK_ARG(poolW == 0 || (poolH > 0 && poolH % 2 == 0 && poolW % 2 == 0 && M % ((int64_t)poolH * poolW) == 0 && M < 0x7fffffffL && !dres),
+                 "bn_bwd_apply: pooled form needs even H, W, M = B * H * W < 2^31, no residual output");
   CROG_CHECK_ARG(C % vec == 0, "bn_bwd_apply: C %% %d != 0", vec);
   CROG_CHECK_ARG(C <= 8192 && (!dgamma || (dbeta && sum_rows != 0)), "bn_bwd_apply: bad sum_rows / parameter-gradient outputs");
   int grid = stream_grid(M * (C / vec));
@@ -1432,9 +1506,24 @@ extern "C" int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const 
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(NT), lds, (hipStream_t)stream, (const T*)dy, (long)lddy,
                                        (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, gamma, sums, count, relu_scale_shift,
                                        (T*)dz, (long)lddz, (T*)dres, (long)lddres, (long)M, C, sum_rows, dgamma, dbeta, (const unsigned char*)relu_mask,
-                                       param_grad_scale));
+                                       param_grad_scale, poolH, poolW));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
+}
+extern "C" int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
+                                 const float* mean_invstd, const float* gamma, const float* sums, float count,
+                                 const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres, int64_t M, int C,
+                                 int sum_rows, float* dgamma, float* dbeta, float param_grad_scale, const void* relu_mask,
+                                 crog_stream_t stream) {
+  return bn_bwd_apply_impl(dtype, dy, lddy, y, ldy, z, ldz, mean_invstd, gamma, sums, count, relu_scale_shift, dz, lddz, dres, lddres, M, C, sum_rows,
+                           dgamma, dbeta, param_grad_scale, relu_mask, 0, 0, stream);
+}
+extern "C" int crog_bn_bwd_apply_pool(int dtype, const void* dy_pooled, int64_t lddy, const void* z, int64_t ldz, const float* mean_invstd,
+                                      const float* gamma, const float* sums, float count, const float* relu_scale_shift, void* dz, int64_t lddz,
+                                      int64_t M, int C, int sum_rows, float* dgamma, float* dbeta, float param_grad_scale, int H, int W,
+                                      crog_stream_t stream) {
+  return bn_bwd_apply_impl(dtype, dy_pooled, lddy, nullptr, 0, z, ldz, mean_invstd, gamma, sums, count, relu_scale_shift, dz, lddz, nullptr, 0, M, C,
+                           sum_rows, dgamma, dbeta, param_grad_scale, nullptr, H, W, stream);
 }
 
 extern "C" int crog_ln_fwd(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, int64_t M, int C,

@@ -282,6 +282,7 @@ BN_BWD_FUSED_MAX_ROWS = 131072
 # backward pass over the widest tensors of the stage, and the stored g is at once bn3's dy and block b-1's identity gradient (no dres
 # pass).  CROG_BN_RES_FUSED=0 switches it off; CROG_BN_RES_FUSED_MAX_ROWS limits the layer size.
 BN_RES_FUSED = os.environ.get("CROG_BN_RES_FUSED", "1") != "0"
+POOL_FUSED = os.environ.get("CROG_POOL_FUSED", "1") != "0"      # average pooling inside the BatchNorm apply / backward passes (conv_bn_act pool=True)
 BN_RES_FUSED_MAX_ROWS = int(os.environ.get("CROG_BN_RES_FUSED_MAX_ROWS", str(1 << 30)))
 
 
@@ -304,8 +305,9 @@ class ConvBnAct(Function):
 
     @staticmethod
     def forward(ctx, x, res, _wp, _gp, _bp, w: Optional[WRef], bn: BnBuffers, ksize, relu: bool, training: bool, out, wpad, dtype,
-                grad_slot=None, res_slot=None, stat_out=None, stat_in=None, dx_slot=None, res_out=None, res_in=None):
+                grad_slot=None, res_slot=None, stat_out=None, stat_in=None, dx_slot=None, res_out=None, res_in=None, pool=False):
         dev = x.device
+        ctx.pool = None
         ctx.slots = (grad_slot, res_slot)
         ctx.dx_slot = dx_slot
         ctx.links = (stat_out, stat_in)
@@ -362,7 +364,13 @@ class ConvBnAct(Function):
         ss = torch.empty(C, 2, device=dev, dtype=torch.float32)
         mi = None
         count = float(M)
-        y = _dest(out) if out is not None else torch.empty(lead + (C,), device=dev, dtype=dtype)
+        if pool:
+            # (conv_bn_act only asks for this on the bf16 training path with in-kernel statistics, ReLU, no residual: POOL_FUSED)
+            assert training and stat_R > 0 and relu and res is None and out is None and len(lead) == 3 and lead[1] % 2 == 0 and lead[2] % 2 == 0
+            ctx.pool = (lead[1], lead[2])
+            y = torch.empty((lead[0], lead[1] // 2, lead[2] // 2, C), device=dev, dtype=dtype)
+        else:
+            y = _dest(out) if out is not None else torch.empty(lead + (C,), device=dev, dtype=dtype)
         applied = False
         # residual + ReLU layers: backward needs sign(y); one bit per element is kept instead of re-reading y twice
         rmask = K.relu_mask_like(y) if (RELU_BITMASK and training and relu and res is not None) else None
@@ -372,7 +380,7 @@ class ConvBnAct(Function):
                 RT.comm.all_reduce_sum(stats)
                 count = float(M * RT.comm.world_size)
             K.bn_apply_stats(z, stats, stat_R, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum,
-                             bn.eps, ss, mi, res, relu, y, relu_mask=rmask)
+                             bn.eps, ss, mi, res, relu, y, relu_mask=rmask, pool=ctx.pool)
             applied = True
         elif training:
             if stats is None:
@@ -481,15 +489,17 @@ class ConvBnAct(Function):
             # Not in fp32: the parity mode keeps the ordered slab reduction below.
             R = stat_replicas(nparts, C)
             sums = RT.zeros(R * 2 * C, dev)
-            K.bn_bwd_partial(dy, ymask, z, mi, rpb, sums, relu_ss, replicas=R, relu_mask=rmask)
+            K.bn_bwd_partial(dy, ymask, z, mi, rpb, sums, relu_ss, replicas=R, relu_mask=rmask, pool=ctx.pool)
             scale = 1.0
             if comm_on:
                 RT.comm.all_reduce_sum(sums)
                 scale = 1.0 / RT.comm.world_size
             K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=R,
-                           dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=rmask, param_grad_scale=scale)
+                           dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=rmask, param_grad_scale=scale, pool=ctx.pool)
             bn.beta.done()
             bn.gamma.done()
+        elif ctx.pool is not None:
+            raise RuntimeError("crog_amd: the pooled BatchNorm backward only exists on the atomic-statistics path (the mode changed between forward and backward)")
         elif BN_ATOMIC_STATS:
             # per-block slab -> one reduction launch -> apply kernel that stages the totals in LDS and (block 0) stores dbeta / dgamma
             partial = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
@@ -600,7 +610,7 @@ class ConvBnAct(Function):
         if ctx.dx_slot is not None and dx is not None:      # (see avgpool2: x's other consumer adds this gradient in its own epilogue)
             ctx.dx_slot.put(dx)
             dx = None
-        return (dx, dres) + (None,) * 18
+        return (dx, dres) + (None,) * 19
 
 
 EVAL_BN_FOLD = True
@@ -649,15 +659,21 @@ def _conv_bn_act_eval(x, w: WRef, bn: BnBuffers, ksize, relu, res, out, wpad, dt
 
 
 def conv_bn_act(x, w: Optional[WRef], bn: BnBuffers, *, ksize, relu=True, res=None, training=True, out=None, wpad=None, dtype=None,
-                grad_slot=None, res_slot=None, stat_out=None, stat_in=None, dx_slot=None, res_out=None, res_in=None):
+                grad_slot=None, res_slot=None, stat_out=None, stat_in=None, dx_slot=None, res_out=None, res_in=None, pool=False):
     """stat_out / stat_in: a BnLink shared by two layers with y_L -> x_{L+1} and no other consumer of y_L (see BnLink).
-    res_out / res_in: a BnLink between a residual layer and the first convolution of the block its output feeds (BN_RES_FUSED)."""
+    res_out / res_in: a BnLink between a residual layer and the first convolution of the block its output feeds (BN_RES_FUSED).
+    pool: follow the layer by the 2 x 2 average pooling (clip.py:49-50, 213-214) - inside the BatchNorm passes on the bf16 training path
+    (POOL_FUSED: the full-resolution activation and its gradient never reach HBM), as a separate avgpool2 otherwise."""
     dtype = dtype if dtype is not None else x.dtype
     wp = w.param if w is not None else None
     if EVAL_BN_FOLD and not training and ksize != 0 and not torch.is_grad_enabled():
-        return _conv_bn_act_eval(x, w, bn, ksize, relu, res, out, wpad, dtype)
-    return ConvBnAct.apply(x, res, wp, bn.gamma.param, bn.beta.param, w, bn, ksize, relu, training, out, wpad, dtype, grad_slot, res_slot,
-                           stat_out, stat_in, dx_slot, res_out, res_in)
+        y = _conv_bn_act_eval(x, w, bn, ksize, relu, res, out, wpad, dtype)
+        return avgpool2(y) if pool else y
+    fuse = (pool and POOL_FUSED and training and relu and res is None and out is None and ksize != 0 and dtype == torch.bfloat16
+            and BN_ATOMIC_STATS and BN_BWD_ATOMIC and not RT.deterministic and stat_out is None and res_out is None)
+    y = ConvBnAct.apply(x, res, wp, bn.gamma.param, bn.beta.param, w, bn, ksize, relu, training, out, wpad, dtype, grad_slot, res_slot,
+                        stat_out, stat_in, dx_slot, res_out, res_in, fuse)
+    return avgpool2(y) if (pool and not fuse) else y
 
 
 # ------------------------------------------------------------------------------------------------

@@ -299,16 +299,28 @@ def bn_apply(z, scale_shift, res, relu: bool, y, relu_mask=None):
 
 
 def bn_apply_stats(z, sums, replicas, count, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, mean_invstd, res, relu, y,
-                   relu_mask=None):
+                   relu_mask=None, pool=None):
+    """pool=(H, W): y is the 2 x 2-average-pooled map (crog_bn_apply_stats_pool)."""
     M, C, ldz = mat(z)
+    if pool is not None:
+        check(lib().crog_bn_apply_stats_pool(dcode(z), ptr(z), ldz, ptr(sums), replicas, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
+                                             ptr(running_var), float(momentum), float(eps), ptr(scale_shift), ptr(mean_invstd), int(relu), ptr(y),
+                                             mat(y)[2], M, C, pool[0], pool[1], stream()), "bn_apply_stats_pool")
+        return
     ldr = mat(res)[2] if res is not None else 0
     check(lib().crog_bn_apply_stats(dcode(z), ptr(z), ldz, ptr(sums), replicas, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
                                     ptr(running_var), float(momentum), float(eps), ptr(scale_shift), ptr(mean_invstd), ptr(res), ldr,
                                     int(relu), ptr(y), mat(y)[2], M, C, ptr(relu_mask), stream()), "bn_apply_stats")
 
 
-def bn_bwd_partial(dy, y, z, mean_invstd, rows_per_block, partial, relu_ss=None, replicas=0, relu_mask=None):
+def bn_bwd_partial(dy, y, z, mean_invstd, rows_per_block, partial, relu_ss=None, replicas=0, relu_mask=None, pool=None):
+    """pool=(H, W): dy is the gradient of the pooled map (crog_bn_bwd_partial_pool)."""
     M, C, lddy = mat(dy)
+    if pool is not None:
+        M = mat(z)[0]
+        check(lib().crog_bn_bwd_partial_pool(dcode(dy), ptr(dy), lddy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(relu_ss), M, C, rows_per_block,
+                                             ptr(partial), replicas, pool[0], pool[1], stream()), "bn_bwd_partial_pool")
+        return
     ldy = mat(y)[2] if y is not None else 0
     check(lib().crog_bn_bwd_partial(dcode(dy), ptr(dy), lddy, ptr(y), ldy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(relu_ss), M, C,
                                     rows_per_block, ptr(partial), replicas, ptr(relu_mask), stream()), "bn_bwd_partial")
@@ -324,8 +336,14 @@ def reduce_split(partial, nparts, C, sums, a, b):
 
 
 def bn_bwd_apply(dy, y, z, mean_invstd, gamma, sums, count, dz, dres, relu_ss=None, sum_rows=0, dgamma=None, dbeta=None, relu_mask=None,
-                 param_grad_scale=1.0):
+                 param_grad_scale=1.0, pool=None):
     M, C, lddy = mat(dy)
+    if pool is not None:
+        M = mat(z)[0]
+        check(lib().crog_bn_bwd_apply_pool(dcode(dy), ptr(dy), lddy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(gamma), ptr(sums), float(count),
+                                           ptr(relu_ss), ptr(dz), mat(dz)[2], M, C, sum_rows, ptr(dgamma), ptr(dbeta), float(param_grad_scale),
+                                           pool[0], pool[1], stream()), "bn_bwd_apply_pool")
+        return
     ldy = mat(y)[2] if y is not None else 0
     lddres = mat(dres)[2] if dres is not None else 0
     check(lib().crog_bn_bwd_apply(dcode(dy), ptr(dy), lddy, ptr(y), ldy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(gamma),

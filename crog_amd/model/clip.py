@@ -53,9 +53,9 @@ class Bottleneck(Bound):
         l2 = Fn.BnLink() if (tr and self.stride == 1) else None
         out = Fn.conv_bn_act(x, self.conv1.w, self.bn1.buffers_ref(), ksize=1, relu=True, training=tr, grad_slot=slot, stat_out=l1,
                              res_in=res_in)
-        out = Fn.conv_bn_act(out, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=l1, stat_out=l2)
-        if self.stride > 1:
-            out = Fn.avgpool2(out)
+        # (a strided block's AvgPool2d(stride) after bn2 + relu, clip.py:49-50, runs inside the BatchNorm passes: Fn.POOL_FUSED)
+        out = Fn.conv_bn_act(out, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=l1, stat_out=l2,
+                             pool=self.stride > 1)
         identity = x
         if self.downsample is not None:
             if self.stride > 1:
@@ -174,8 +174,7 @@ class ModifiedResNet(Bound):
         x = Fn.conv_bn_act(img, self.conv1.w, self.bn1.buffers_ref(), ksize="s", relu=True, training=tr, wpad=(27, 32, c1), dtype=dtype,
                            stat_out=s1)
         x = Fn.conv_bn_act(x, self.conv2.w, self.bn2.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=s1, stat_out=s2)
-        x = Fn.conv_bn_act(x, self.conv3.w, self.bn3.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=s2)
-        x = Fn.avgpool2(x)
+        x = Fn.conv_bn_act(x, self.conv3.w, self.bn3.buffers_ref(), ksize=3, relu=True, training=tr, stat_in=s2, pool=True)      # + the stem's AvgPool2d(2)
         l12 = Fn.BnLink() if tr else None          # layer1's output feeds layer2 and nothing else
         x = self.layer1(x, res_out=l12)
         if after_layer1 is not None:

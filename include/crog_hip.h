@@ -261,6 +261,22 @@ int crog_bn_bwd_apply(int dtype, const void* dy, int64_t lddy, const void* y, in
                       float count, const float* relu_scale_shift, void* dz, int64_t lddz, void* dres, int64_t lddres,
                       int64_t M, int C, int sum_rows, float* dgamma, float* dbeta, float param_grad_scale,
                       const void* relu_mask, crog_stream_t stream);
+/* BatchNorm + ReLU followed by the 2 x 2 average pooling of the reference's strided layers (clip.py:49-50: avgpool after bn2 + relu of a
+ * strided Bottleneck; clip.py:213-214: the stem's) as ONE pass each way: the forward writes the POOLED map y [B][H/2][W/2][C] from z
+ * [B][H][W][C] (M = B H W rows) - the full-resolution activation is never stored -, the two backward passes take the gradient of the
+ * pooled map (each pixel's share is a quarter of its cell's, the ReLU gate is recomputed from z with relu_scale_shift) - no
+ * pooling-backward launch and no full-resolution gradient in HBM.  Arguments as in the plain forms (no residual, no mask, no y). */
+int crog_bn_apply_stats_pool(int dtype, const void* z, int64_t ldz, const float* sums, int replicas, float count, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                             float* scale_shift, float* mean_invstd, int relu, void* y, int64_t ldy, int64_t M, int C, int H, int W,
+                             crog_stream_t stream);
+int crog_bn_bwd_partial_pool(int dtype, const void* dy_pooled, int64_t lddy, const void* z, int64_t ldz, const float* mean_invstd,
+                             const float* relu_scale_shift, int64_t M, int C, int rows_per_block, float* partial, int replicas,
+                             int H, int W, crog_stream_t stream);
+int crog_bn_bwd_apply_pool(int dtype, const void* dy_pooled, int64_t lddy, const void* z, int64_t ldz, const float* mean_invstd,
+                           const float* gamma, const float* sums, float count, const float* relu_scale_shift, void* dz, int64_t lddz,
+                           int64_t M, int C, int sum_rows, float* dgamma, float* dbeta, float param_grad_scale, int H, int W,
+                           crog_stream_t stream);
 /* single-replica fast paths: slab [nparts][C][2] -> (reduce + finalize) / (reduce + split) in one launch; crog_reduce_split
  * stores the reduced pairs to `sums` (optional) and ADDS the two halves to the gradient vectors a / b (optional) */
 int crog_bn_reduce_finalize(const float* partial, int nparts, float count, const float* gamma, const float* beta,

@@ -575,6 +575,41 @@ def test_batchnorm_train_fwd_bwd(K, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("shape", [(2, 8, 12, 64), (3, 26, 26, 128), (1, 4, 4, 32)])
+def test_batchnorm_relu_avgpool_in_one_pass_each_way(K, dt, shape):
+    """crog_bn_apply_stats_pool / crog_bn_bwd_partial_pool / crog_bn_bwd_apply_pool (clip.py:49-50, 213-214: AvgPool2d(2) after
+    bn + relu): the pooled output and the gradient of z from the POOLED gradient, against torch's batch_norm -> relu -> avg_pool2d."""
+    B, H, W, C = shape
+    M = B * H * W
+    z = rnd(M, C, dt=dt)
+    gamma, beta = rnd(C, seed=1) * 0.5 + 1.0, rnd(C, seed=2) * 0.1
+    zf = z.float()
+    sums = torch.zeros(2, C, 2, device="cuda")
+    sums[0, :, 0], sums[0, :, 1] = zf.sum(0), (zf * zf).sum(0)      # what the GEMM epilogue leaves (one replica used, one empty)
+    ss, mi = torch.empty(C, 2, device="cuda"), torch.empty(C, 2, device="cuda")
+    y = torch.empty(B, H // 2, W // 2, C, device="cuda", dtype=dt)
+    K.bn_apply_stats(z, sums, 2, float(M), gamma, beta, None, None, 0.1, 1e-5, ss, mi, None, True, y, pool=(H, W))
+    zt = zf.view(B, H, W, C).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gt, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.avg_pool2d(F.relu(F.batch_norm(zt, None, None, gt, bt, True, 0.0, 1e-5)), 2)
+    close(y, ref.permute(0, 2, 3, 1), dt, scale=2)
+    dyp = rnd(B * (H // 2) * (W // 2), C, dt=dt, seed=3)
+    ref.backward(dyp.float().view(B, H // 2, W // 2, C).permute(0, 3, 1, 2))
+    rpb = K.bn_rows_per_block(M)
+    nb = (M + rpb - 1) // rpb
+    from crog_amd.functional import stat_replicas
+    R = stat_replicas(nb, C)
+    part = torch.zeros(R, C, 2, device="cuda")
+    K.bn_bwd_partial(dyp, None, z, mi, rpb, part, ss, replicas=R, pool=(H, W))
+    dz = torch.empty_like(z)
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    K.bn_bwd_apply(dyp, None, z, mi, gamma, part, float(M), dz, None, ss, sum_rows=R, dgamma=dg, dbeta=db, pool=(H, W))
+    close(dz, zt.grad.permute(0, 2, 3, 1).reshape(M, C), dt, scale=4)
+    close(db, bt.grad, dt, scale=30)
+    close(dg, gt.grad, dt, scale=30)
+
+
+@pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("C", [512, 2048, 768, 1536])      # (> 128 vectors per row: the one-row-per-block kernels)
 def test_layernorm(K, dt, C):
     M, R = 300, 100
