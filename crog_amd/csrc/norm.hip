@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
                                                     const float* __restrict__ stats, long M, int C, T* __restrict__ dx, long lddx,
                                                     float* __restrict__ partial, int rows_per_block, float p_in, uint64_t seed_in,
                                                     float p_out, uint64_t seed_out, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                    const uint64_t* __restrict__ epoch, const T* __restrict__ dxadd, long lddxa) {
+                                                    const uint64_t* __restrict__ epoch, const T* __restrict__ dxadd, long lddxa, int relu_in) {
   constexpr int VEC = Elem<T>::VEC;
   if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -847,6 +847,10 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
         for (int e = 0; e < VEC; e++) d[e] = rstd * (gy[j][e] - a - xh[j][e] * b);
         if (p_in > 0.f) {
           dropout_apply<VEC>(d, seed_in, (uint64_t)row * C + c, thr_in, sc_in);
+        }
+        if (relu_in) {      // x is a ReLU output (layers.py:298-300: Linear -> ReLU -> Dropout -> LayerNorm): its backward rides along
+#pragma unroll
+          for (int e = 0; e < VEC; e++) d[e] = Elem<T>::to_f(cx[j].v[e]) > 0.f ? d[e] : 0.f;
         }
         if (dxadd) {
 #pragma unroll
@@ -1030,7 +1034,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_row_kernel(const T* __restrict__ do
                                                         const float* __restrict__ stats, long M, int C, T* __restrict__ dx, long lddx,
                                                         float* __restrict__ partial, int rows_per_block, float p_in, uint64_t seed_in,
                                                         float p_out, uint64_t seed_out, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                        const uint64_t* __restrict__ epoch, const T* __restrict__ dxadd, long lddxa) {
+                                                        const uint64_t* __restrict__ epoch, const T* __restrict__ dxadd, long lddxa, int relu_in) {
   constexpr int VEC = Elem<T>::VEC, NW = NT / 64;
   if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1125,6 +1129,10 @@ __global__ void __launch_bounds__(NT) ln_bwd_row_kernel(const T* __restrict__ do
 #pragma unroll
         for (int e = 0; e < VEC; e++) d[e] = rstd * (gy[j][e] - a - xh[j][e] * b);
         if (p_in > 0.f) dropout_apply<VEC>(d, seed_in, (uint64_t)row * C + c, thr_in, sc_in);
+        if (relu_in) {      // (see ln_bwd_kernel)
+#pragma unroll
+          for (int e = 0; e < VEC; e++) d[e] = Elem<T>::to_f(cx[j].v[e]) > 0.f ? d[e] : 0.f;
+        }
         if (dxadd) {
 #pragma unroll
           for (int e = 0; e < VEC; e++) d[e] += Elem<T>::to_f(ca[j].v[e]);
@@ -1555,10 +1563,10 @@ extern "C" int crog_ln_fwd(int dtype, const void* x, int64_t ldx, const float* g
 
 extern "C" int crog_ln_bwd_blocks(int64_t M, int rows_per_block) { return cdiv(M, rows_per_block); }
 
-extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void* dout2, int64_t lddo2, const void* x, int64_t ldx,
-                           const float* gamma, const float* stats, int64_t M, int C, void* dx, int64_t lddx, float* partial,
-                           int rows_per_block, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float* dgamma, float* dbeta,
-                           const void* dxadd, int64_t lddxa, crog_stream_t stream) {
+static int ln_bwd_impl(int dtype, const void* dout, int64_t lddo, const void* dout2, int64_t lddo2, const void* x, int64_t ldx,
+                       const float* gamma, const float* stats, int64_t M, int C, void* dx, int64_t lddx, float* partial,
+                       int rows_per_block, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float* dgamma, float* dbeta,
+                       const void* dxadd, int64_t lddxa, int relu_in, crog_stream_t stream) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(!dxadd || (lddxa >= C && lddxa % vec == 0 && ((uintptr_t)dxadd % 16) == 0), "ln_bwd: dxadd rows must be 16-byte aligned (ld=%lld)", (long long)lddxa);
   CROG_CHECK_ARG(C % vec == 0 && C <= 2048, "ln_bwd: C=%d must be a multiple of %d and <= 2048", C, vec);
@@ -1570,12 +1578,12 @@ extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void
   DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dout, (long)lddo, \
                                        (const T*)dout2, (long)lddo2, (const T*)x, (long)ldx, gamma, stats, (long)M, C, (T*)dx,       \
                                        (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out, dgamma, dbeta, crog_seed_epoch(),   \
-                                       (const T*)dxadd, (long)lddxa))
+                                       (const T*)dxadd, (long)lddxa, relu_in))
 #define CROG_LN_BWD_ROW(NVT)                                                                                                       \
   DISPATCH_T(dtype, hipLaunchKernelGGL((ln_bwd_row_kernel<T, NVT>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dout, (long)lddo, \
                                        (const T*)dout2, (long)lddo2, (const T*)x, (long)ldx, gamma, stats, (long)M, C, (T*)dx,       \
                                        (long)lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out, dgamma, dbeta, crog_seed_epoch(),   \
-                                       (const T*)dxadd, (long)lddxa))
+                                       (const T*)dxadd, (long)lddxa, relu_in))
   if (nv <= 1) CROG_LN_BWD(1);
   else if (nv <= 2) CROG_LN_BWD(2);
   else if (C / vec <= NT) CROG_LN_BWD_ROW(1);      // wide rows: one row per block iteration (ln_bwd_row_kernel)
@@ -1584,6 +1592,20 @@ extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void
 #undef CROG_LN_BWD
   CROG_LAUNCH_CHECK();
   return CROG_OK;
+}
+extern "C" int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void* dout2, int64_t lddo2, const void* x, int64_t ldx,
+                           const float* gamma, const float* stats, int64_t M, int C, void* dx, int64_t lddx, float* partial,
+                           int rows_per_block, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float* dgamma, float* dbeta,
+                           const void* dxadd, int64_t lddxa, crog_stream_t stream) {
+  return ln_bwd_impl(dtype, dout, lddo, dout2, lddo2, x, ldx, gamma, stats, M, C, dx, lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out,
+                     dgamma, dbeta, dxadd, lddxa, 0, stream);
+}
+extern "C" int crog_ln_bwd_relu(int dtype, const void* dout, int64_t lddo, const void* dout2, int64_t lddo2, const void* x, int64_t ldx,
+                                const float* gamma, const float* stats, int64_t M, int C, void* dx, int64_t lddx, float* partial,
+                                int rows_per_block, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, float* dgamma, float* dbeta,
+                                const void* dxadd, int64_t lddxa, crog_stream_t stream) {
+  return ln_bwd_impl(dtype, dout, lddo, dout2, lddo2, x, ldx, gamma, stats, M, C, dx, lddx, partial, rows_per_block, p_in, seed_in, p_out, seed_out,
+                     dgamma, dbeta, dxadd, lddxa, 1, stream);
 }
 
 extern "C" int crog_softmax_fwd(int dtype, void* S, int64_t rows, int Lq, int Lk, int ldp, int heads, int causal,

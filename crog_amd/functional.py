@@ -282,6 +282,7 @@ BN_BWD_FUSED_MAX_ROWS = 131072
 # backward pass over the widest tensors of the stage, and the stored g is at once bn3's dy and block b-1's identity gradient (no dres
 # pass).  CROG_BN_RES_FUSED=0 switches it off; CROG_BN_RES_FUSED_MAX_ROWS limits the layer size.
 BN_RES_FUSED = os.environ.get("CROG_BN_RES_FUSED", "1") != "0"
+LN_RELU_FUSED = os.environ.get("CROG_LN_RELU_FUSED", "1") != "0"     # decoder FFN: ReLU backward inside the LayerNorm backward
 POOL_FUSED = os.environ.get("CROG_POOL_FUSED", "1") != "0"      # average pooling inside the BatchNorm apply / backward passes (conv_bn_act pool=True)
 BN_RES_FUSED_MAX_ROWS = int(os.environ.get("CROG_BN_RES_FUSED_MAX_ROWS", str(1 << 30)))
 
@@ -686,7 +687,8 @@ class LinearFn(Function):
     channels) lives in a padded buffer; the Function hands out the [.., :N] view."""
 
     @staticmethod
-    def forward(ctx, x, res, _wp, _bp, w: WRef, b: Optional[WRef], act, out):
+    def forward(ctx, x, res, _wp, _bp, w: WRef, b: Optional[WRef], act, out, grad_gated=False):
+        ctx.grad_gated = grad_gated      # the consumer's backward already gated dy by y > 0 (layernorm(relu_in=True)): no activation-backward pass
         M, Kd, _ = K.mat(x)
         N = w.rows
         Np = _pad(N, _vec(_cdt(x)))
@@ -715,7 +717,7 @@ class LinearFn(Function):
             dy = K.as_mat(dy)
         dres = dy if has_res else None
         g = dy
-        if act in (K.ACT_RELU, K.ACT_TANH):
+        if act in (K.ACT_RELU, K.ACT_TANH) and not (ctx.grad_gated and act == K.ACT_RELU):
             if has_res:
                 raise NotImplementedError("activation + residual epilogue backward")
             if Np != N:
@@ -740,7 +742,7 @@ class LinearFn(Function):
         w.done()
         if b is not None:
             b.done()
-        return dx, dres, None, None, None, None, None, None
+        return dx, dres, None, None, None, None, None, None, None
 
 
 def y_full(y: torch.Tensor, Np: int) -> torch.Tensor:
@@ -748,8 +750,10 @@ def y_full(y: torch.Tensor, Np: int) -> torch.Tensor:
     return y.as_strided(tuple(y.shape[:-1]) + (Np,), y.stride(), y.storage_offset())
 
 
-def linear(x, w: WRef, b: Optional[WRef] = None, *, act=K.ACT_NONE, res=None, out=None):
-    return LinearFn.apply(x, res, w.param, b.param if b is not None else None, w, b, act, out)
+def linear(x, w: WRef, b: Optional[WRef] = None, *, act=K.ACT_NONE, res=None, out=None, grad_gated=False):
+    """grad_gated (act = ReLU only): the ONLY consumer of the output is a layernorm(relu_in=True), whose backward hands back the gradient
+    of the ReLU's input."""
+    return LinearFn.apply(x, res, w.param, b.param if b is not None else None, w, b, act, out, bool(grad_gated))
 
 
 class QuickGeluFn(Function):
@@ -785,8 +789,9 @@ class LayerNormFn(Function):
     (`add_slot`, whose backward runs later: its output feeds the other one) adds it to its dx inside crog_ln_bwd."""
 
     @staticmethod
-    def forward(ctx, x, res, _gp, _bp, gamma: WRef, beta: WRef, eps, pos, p_in, p_out, want_out2, res_slot=None, add_slot=None):
+    def forward(ctx, x, res, _gp, _bp, gamma: WRef, beta: WRef, eps, pos, p_in, p_out, want_out2, res_slot=None, add_slot=None, relu_in=False):
         ctx.set_materialize_grads(False)
+        ctx.relu_in = relu_in      # x is the output of a ReLU whose backward this norm's backward does (crog_ln_bwd_relu; linear(grad_gated=True))
         M, C, _ = K.mat(x)
         out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
         out2 = torch.empty(x.shape, device=x.device, dtype=x.dtype) if want_out2 else None
@@ -810,7 +815,7 @@ class LayerNormFn(Function):
         res_slot, add_slot = ctx.slots
         parked = add_slot.take() if add_slot is not None else None
         if dout is None and dout2 is None:
-            return (parked,) + (None,) * 12      # no gradient through the norm itself: x's gradient is what the residual branch parked
+            return (parked,) + (None,) * 13      # no gradient through the norm itself: x's gradient is what the residual branch parked
         if dout is None:
             dout, dout2 = dout2, None
         dout = K.as_mat(dout)
@@ -823,11 +828,11 @@ class LayerNormFn(Function):
             # the blocks add their (dgamma, dbeta) sums straight into the gradient vectors: no slab, no reduction launch (85 launches
             # per CROG step).  fp32, the parity mode, keeps the ordered reduction (bit-reproducible run to run)
             K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, None, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out,
-                     dgamma=gamma.grad(), dbeta=beta.grad(), dxadd=dxadd)
+                     dgamma=gamma.grad(), dbeta=beta.grad(), dxadd=dxadd, relu_in=ctx.relu_in)
         else:
             partial = torch.empty(nb, C, 2, device=x.device, dtype=torch.float32)
             K.ln_bwd(dout, dout2, x, gamma.master(), stats, dx, partial, rpb, p_in=p_in, seed_in=seed_in, p_out=p_out, seed_out=seed_out,
-                     dxadd=dxadd)
+                     dxadd=dxadd, relu_in=ctx.relu_in)
             # the parameter gradients are consumed by the optimizer only: their reduction leaves the dependency chain for the
             # weight-gradient stream (41 small launches per CROG step that sat between dependent kernels of the main stream)
             if LN_REDUCE_SIDE:
@@ -846,11 +851,14 @@ class LayerNormFn(Function):
             if res_slot is not None:
                 res_slot.put(dres)
                 dres = None
-        return (dx, dres) + (None,) * 11
+        return (dx, dres) + (None,) * 12
 
 
-def layernorm(x, gamma: WRef, beta: WRef, *, eps=1e-5, res=None, pos=None, p_in=0.0, p_out=0.0, want_out2=False, res_slot=None, add_slot=None):
-    return LayerNormFn.apply(x, res, gamma.param, beta.param, gamma, beta, eps, pos, float(p_in), float(p_out), want_out2, res_slot, add_slot)
+def layernorm(x, gamma: WRef, beta: WRef, *, eps=1e-5, res=None, pos=None, p_in=0.0, p_out=0.0, want_out2=False, res_slot=None, add_slot=None,
+              relu_in=False):
+    """relu_in: x is `linear(..., act=ReLU, grad_gated=True)` and has no other consumer - this norm's backward also does that ReLU's."""
+    return LayerNormFn.apply(x, res, gamma.param, beta.param, gamma, beta, eps, pos, float(p_in), float(p_out), want_out2, res_slot, add_slot,
+                             bool(relu_in))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -369,11 +369,12 @@ def ln_bwd_rows_per_block(M: int) -> int:
 
 
 def ln_bwd(dout, dout2, x, gamma, stats, dx, partial, rows_per_block, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0, dgamma=None, dbeta=None,
-           dxadd=None):
+           dxadd=None, relu_in=False):
     """partial: per-block slab for an ordered reduction (crog_reduce_split), or None with dgamma / dbeta: atomic adds into the gradients.
     dxadd: gradient of the residual branch around the norm, added to dx inside the kernel."""
     M, C, ldx = mat(x)
-    check(lib().crog_ln_bwd(dcode(x), ptr(dout), mat(dout)[2], ptr(dout2), mat(dout2)[2] if dout2 is not None else 0, ptr(x), ldx,
+    fn = lib().crog_ln_bwd_relu if relu_in else lib().crog_ln_bwd      # relu_in: x is a ReLU output, dx is also gated by x > 0
+    check(fn(dcode(x), ptr(dout), mat(dout)[2], ptr(dout2), mat(dout2)[2] if dout2 is not None else 0, ptr(x), ldx,
                             ptr(gamma), ptr(stats), M, C, ptr(dx), mat(dx)[2], ptr(partial), rows_per_block, float(p_in),
                             int(seed_in), float(p_out), int(seed_out), ptr(dgamma), ptr(dbeta), ptr(dxadd), mat(dxadd)[2] if dxadd is not None else 0,
                             stream()), "ln_bwd")

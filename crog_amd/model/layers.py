@@ -148,8 +148,11 @@ class TransformerDecoderLayer(Bound):
         a = self.multihead_attn(q, txt_k, txt, B=B, kpm=pad_mask, training=tr)
         vis = self.cross_attn_norm(a, res=vis, p_out=p, res_slot=s2)
         v2 = self.norm3(vis, add_slot=s3 if p > 0 else None)
-        h = Fn.linear(v2, self.ffn["0"].w, self.ffn["0"].b, act=K.ACT_RELU)
-        h = self.ffn["3"](h, p_in=p)
+        # (the ReLU's backward rides in the LayerNorm's, which holds the ReLU output in registers anyway: no activation-backward pass
+        # over the 21632 x 2048 map)
+        fuse = tr and torch.is_grad_enabled() and Fn.LN_RELU_FUSED
+        h = Fn.linear(v2, self.ffn["0"].w, self.ffn["0"].b, act=K.ACT_RELU, grad_gated=fuse)
+        h = self.ffn["3"](h, p_in=p, relu_in=fuse)
         if p > 0:
             return Fn.add_dropout(vis, Fn.linear(h, self.ffn["4"].w, self.ffn["4"].b), p, res_slot=s3)
         return Fn.linear(h, self.ffn["4"].w, self.ffn["4"].b, res=vis)

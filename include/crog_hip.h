@@ -306,6 +306,14 @@ int crog_ln_bwd(int dtype, const void* dout, int64_t lddo, const void* dout2, in
                 int64_t lddx, float* partial, int rows_per_block, float p_in, uint64_t seed_in,
                 float p_out, uint64_t seed_out, float* dgamma, float* dbeta, const void* dxadd, int64_t lddxa,
                 crog_stream_t stream);
+/* The same for a LayerNorm whose input x is a ReLU output (layers.py:298-300: Linear -> ReLU -> Dropout -> LayerNorm in the decoder's
+ * FFN): dx is also gated by x > 0, i.e. it is the gradient of the ReLU's INPUT - the producing Linear skips its activation-backward
+ * pass (21632 x 2048: one read of dx and y and one write less per layer). */
+int crog_ln_bwd_relu(int dtype, const void* dout, int64_t lddo, const void* dout2, int64_t lddo2, const void* x,
+                int64_t ldx, const float* gamma, const float* stats, int64_t M, int C, void* dx,
+                int64_t lddx, float* partial, int rows_per_block, float p_in, uint64_t seed_in,
+                float p_out, uint64_t seed_out, float* dgamma, float* dbeta, const void* dxadd, int64_t lddxa,
+                crog_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Masked softmax over attention scores S[batch*heads*Lq][ldp] in place (the softmax inside

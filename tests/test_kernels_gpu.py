@@ -649,6 +649,14 @@ def test_layernorm(K, dt, C):
     close(dx3, xt.grad + extra.float(), dt, scale=4)
     if dt == torch.float32:
         assert torch.equal(dx3, dx + extra)          # fp32: bit-identical to the separate accumulation pass it replaces
+    # relu_in: x is a ReLU output, dx is the gradient of the ReLU's input (crog_ln_bwd_relu)
+    xr = x.clamp_min(0)
+    stats_r = torch.empty(M, 2, device="cuda")
+    K.ln_fwd(xr, g, b, 1e-5, torch.empty_like(x), stats_r)
+    dx4, dx5 = torch.empty_like(x), torch.empty_like(x)
+    K.ln_bwd(d1, d2, xr, g, stats_r, dx4, partial, rpb)
+    K.ln_bwd(d1, d2, xr, g, stats_r, dx5, torch.empty_like(partial), rpb, relu_in=True)
+    assert torch.equal(dx5, torch.where(xr > 0, dx4, torch.zeros_like(dx4)))
 
 
 @pytest.mark.parametrize("dt", DT)
