@@ -1801,10 +1801,18 @@ inline int pp_rows(const crog_gemm_desc& d) {
   if (d.debug & 2048) return 0;
   if (d.debug & 512) return crog_gemm_pp_eligible(d, 256) ? 256 : 0;
   if (d.debug & 1024) return crog_gemm_pp_eligible(d, 192) ? 192 : 0;
+  if (d.debug & 524288) return crog_gemm_pp_eligible(d, 128) ? 128 : 0;      // bit 19: the 128-row tile
   if (env <= 0 || !crog_gemm_pp_eligible(d, 256)) return 0;
   if (d.a_layout != CROG_A_IM2COL && env < 2) return 0;
   const long t256 = (long)cdiv(d.M, 256) * (d.N / 256), t192 = (long)cdiv(d.M, 192) * (d.N / 256);
-  if (t256 < PP_MIN_TILES) return 0;
+  if (t256 < PP_MIN_TILES) {
+    // 21632 x 256 (85 tiles of 256 rows): 169 tiles of 128 rows fill two thirds of the chip in one round - 1x1 / linear launches with
+    // K >= 512 gain 15-25 % over the 128 x 128 tile (K = 1024: 27.2 -> 20.4 us), the 3x3 form does not (43.0 vs 43.8)
+    const long t128 = (long)cdiv(d.M, 128) * (d.N / 256);
+    static const bool pp128 = [] { const char* e = getenv("CROG_PP128"); return !e || atoi(e) != 0; }();
+    if (pp128 && d.a_layout == CROG_A_KC && d.K >= 512 && t128 >= PP_MIN_TILES && crog_gemm_pp_eligible(d, 128)) return 128;
+    return 0;
+  }
   const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
   return (c192 * 11 < c256 * 10 && crog_gemm_pp_eligible(d, 192)) ? 192 : 256;      // (a 192-row tile runs ~10 % below the 256-row tile's rate per row)
 }

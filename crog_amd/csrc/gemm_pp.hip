@@ -41,7 +41,7 @@ struct PpGeom { int H, W, C; };
 template <int AL, int RBQ, int D, bool EPI = false>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p) {
   static_assert(AL == CROG_A_KC || AL == CROG_A_IM2COL, "K-contiguous A operands");
-  static_assert(RBQ == 3 || RBQ == 4, "row quad of 3 or 4 blocks");
+  static_assert(RBQ == 2 || RBQ == 3 || RBQ == 4, "row quad of 2, 3 or 4 blocks");
   static_assert(D >= 3 && D <= 7, "DMA distance in half-tiles (see the hazard notes)");
   constexpr int BM = 64 * RBQ, BN = 256, BK = 64, RB = 2 * RBQ, CB = 4;
   constexpr int SLOT = 16384;
@@ -353,10 +353,10 @@ bool crog_gemm_pp_eligible(const crog_gemm_desc& d, int rows) {
   if (d.a_layout != CROG_A_KC && d.a_layout != CROG_A_IM2COL) return false;
   if (d.N % 256 != 0 || d.K % 64 != 0 || d.K < 128) return false;
   if (d.a_layout == CROG_A_IM2COL && d.convC % 64 != 0) return false;
-  if (rows == 192 && d.col_stats && d.stat_replicas <= 0) return false;      // the 128-row slab rows do not divide a 192-row tile
+  if (rows != 256 && d.col_stats && d.stat_replicas <= 0) return false;      // the 128-row slab rows only line up with the 256-row tile's halves
   // 32-bit byte offsets, with the rows of the last (ragged) tile included
   if (((long)d.M + 256) * d.lda * 2 >= 0x7fffffffL || (long)d.N * d.ldb * 2 >= 0x7fffffffL) return false;
-  return rows == 256 || rows == 192;
+  return rows == 256 || rows == 192 || rows == 128;
 }
 
 // The full epilogue the EPI instantiations carry: alpha 1, bf16 output, optional bias / activation / residual (16-byte aligned rows).
@@ -382,6 +382,7 @@ int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t
     return conv ? launch_pp<CROG_A_IM2COL, R, DD>(d, s) : launch_pp<CROG_A_KC, R, DD>(d, s)
   PP_CASE(4, 3); PP_CASE(4, 4); PP_CASE(4, 5); PP_CASE(4, 6); PP_CASE(4, 7);
   PP_CASE(3, 3); PP_CASE(3, 4); PP_CASE(3, 5); PP_CASE(3, 6); PP_CASE(3, 7);
+  PP_CASE(2, 4); PP_CASE(2, 5);      // 128-row tile: default distances only
 #undef PP_CASE
   crog_set_error("crog_gemm: no ping-pong instantiation for rows=%d dist=%d", rows, dist);
   return CROG_ERR_ARG;

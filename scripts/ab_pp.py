@@ -24,6 +24,10 @@ shapes = [(32, 104, 256, 512, True), (32, 104, 512, 256, True), (32, 52, 512, 51
           (32, 26, 512, 512, True), (32, 26, 512, 1024, True), (32, 26, 1024, 512, True), (32, 26, 256, 256, True), (32, 104, 128, 256, True),
           (32, 26, 2048, 512, False), (32, 26, 512, 2048, False), (32, 52, 512, 512, False), (32, 26, 1024, 1024, False), (32, 104, 256, 256, False)]
 variants = [("prev", 2048)] + [(f"pp256/{d}", 512 | d << 12) for d in (3, 4, 5, 6, 7)] + [(f"pp192/{d}", 1024 | d << 12) for d in (3, 4, 5, 6, 7)]
+if "rows" in sys.argv:      # tile heights at the default distance, on the mid-size launches: "prev" here is today's DEFAULT dispatch
+    variants = [("default", 0), ("pp256", 512), ("pp192", 1024), ("pp128", 524288)]
+    shapes = [(32, 26, 256, 256, True), (32, 13, 512, 512, True), (32, 26, 512, 512, True), (32, 52, 128, 128, True), (32, 26, 1024, 256, False),
+              (32, 26, 256, 1024, False), (32, 13, 2048, 512, False), (32, 13, 512, 2048, False), (32, 13, 1024, 2048, False), (32, 26, 512, 256, False)]
 if len(sys.argv) > 1 and sys.argv[1] == "stats":      # with BatchNorm statistics in the epilogue, as the training step launches them
     with_stats = True
 else:

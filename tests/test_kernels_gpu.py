@@ -161,6 +161,8 @@ def test_mfma_16x16x32_variant_equals_the_32x32x16_kernel(K, monkeypatch, case):
     (8, 52, 256, 512, False, 512, 0),              # 1x1 / linear form, K = 256
     (8, 52, 320, 256, False, 1024, 0),             # K = 320: five k-tiles
     (1, 9, 64, 256, True, 512, 0),                 # M = 81: a single, mostly empty tile
+    (8, 52, 512, 256, False, 524288, 0),           # 128-row tile (bit 19), linear form
+    (5, 26, 128, 256, True, 524288, 0),            # 128-row tile, 3x3 form, ragged last row tile
 ])
 def test_ping_pong_256x256x64_kernel(K, monkeypatch, case):
     """gemm_pp_kernel (csrc/gemm_pp.hip: two wave groups one barrier apart, 64-deep k-tiles in four half-tiles) against float64 and
