@@ -25,6 +25,8 @@
 bool crog_gemm_pp_eligible(const crog_gemm_desc& d, int rows);
 int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t s, bool full = false);
 bool crog_gemm_pp_full_epilogue_ok(const crog_gemm_desc& d);
+bool crog_conv_sw_eligible(const crog_gemm_desc& d);      // conv_sw.hip: sliding-window 3x3 convolution for 32 / 64 channels
+int crog_conv_sw_launch(const crog_gemm_desc& d, hipStream_t s);
 // the ping-pong weight-gradient kernel (gemm_ppt.hip)
 bool crog_gemm_ppt_eligible(const crog_gemm_desc& d);
 int crog_gemm_ppt_launch(const crog_gemm_desc& d, int dist, hipStream_t s);
@@ -1181,7 +1183,10 @@ __device__ __attribute__((always_inline)) inline void wait_tiles(int behind) {
 // 64 x 128 (20-45 % slower), 64 x 256 for Cout <= 64 weight gradients (two blocks per CU, 20 KiB per k-tile: 14 % slower).
 using ShapeDma8 = Shape<4, 2, 2, 4, true>;   // 256 x 256, 8 waves, 128 accumulator registers per lane (lean epilogue: at the 256-VGPR limit the full one spills)
 using ShapeDma8A = Shape<4, 2, 2, 4, true, 0, false, true>;   // the same tile with the atomic-only epilogue: large 3x3 weight gradients
-using ShapeTall = Shape<2, 2, 4, 1>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
+#ifndef CROG_TALL_NSTAGE
+#define CROG_TALL_NSTAGE 0             // (A/B builds: depth of the 256 x 64 tile's LDS-DMA ring; 0 = the default of its size)
+#endif
+using ShapeTall = Shape<2, 2, 4, 1, false, CROG_TALL_NSTAGE>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
 using ShapeDma64 = Shape<1, 1, 2, 2>;  //  64 x  64, 4 waves: small GEMMs (text tower, attention pooling), no BN statistics
 using ShapeMidBwd = Shape<2, 2, 2, 2, true, 0, true>;   // 128 x 128 data gradient that does the consumer BatchNorm's first backward pass
 // (8-deep rings for launches of <= 1-2 blocks per CU were tried: no gain standalone -- those launches are not bound by request
@@ -1831,6 +1836,13 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     crog_set_error("crog_gemm: bwd_z is implemented for bf16 data gradients (A_KC x B_NC / B_KC, A_IM2COL x B_KC / B_NC_DGRAD) with a plain epilogue "
                    "and operands the LDS-DMA path can address (crog_gemm_supports_bwd_z)");
     return CROG_ERR_ARG;
+  }
+  if constexpr (sizeof(T) == 2) {
+    // small-channel 3x3 convolutions (stem, layer1: N = 32 / 64, K = 288 / 576) with at least 64 K pixels: the sliding-window kernel
+    // fetches every input row once instead of nine times through L2 -> LDS.  CROG_CONV_SW=0 / debug bit 20: the implicit GEMM
+    static const bool conv_sw = [] { const char* e = getenv("CROG_CONV_SW"); return !e || atoi(e) != 0; }();
+    if (conv_sw && !(d.debug & 1048576) && d.a_layout == CROG_A_IM2COL && (d.M >= 65536 || (d.debug & 2097152)) && crog_conv_sw_eligible(d))
+      return crog_conv_sw_launch(d, s);
   }
   const int shape = pick_shape(d);
   if (dma_eligible(d)) {

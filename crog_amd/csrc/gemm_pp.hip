@@ -373,6 +373,9 @@ int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t
   if (full) {
     if (rows == 256) return conv ? launch_pp<CROG_A_IM2COL, 4, 4, true>(d, s) : launch_pp<CROG_A_KC, 4, 5, true>(d, s);
     if (rows == 192) return conv ? launch_pp<CROG_A_IM2COL, 3, 4, true>(d, s) : launch_pp<CROG_A_KC, 3, 5, true>(d, s);
+    if (rows == 128) return conv ? launch_pp<CROG_A_IM2COL, 2, 4, true>(d, s) : launch_pp<CROG_A_KC, 2, 5, true>(d, s);
+    crog_set_error("crog_gemm: no ping-pong instantiation with the full epilogue for rows=%d", rows);      // (never fall through to a lean kernel)
+    return CROG_ERR_ARG;
   }
   // measured (scripts/ab_pp.py, distances 3 .. 7 on every 3x3 / 1x1 shape of the step): 4 for the 3x3 form (1333-1369 TFLOP/s on the
   // >= 676-tile forwards; 5: -1 %, 6: -6 %, 3: -11 %), 5 for the 1x1 / linear form (its k-loops are 4-32 tiles: the ring fill counts)

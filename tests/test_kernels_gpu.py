@@ -216,6 +216,44 @@ def test_ping_pong_256x256x64_kernel(K, monkeypatch, case):
     monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
 
 
+@pytest.mark.parametrize("case", [
+    # (B, H, W, Cin, Cout, statistics)
+    (2, 20, 32, 32, 32, True), (3, 5, 40, 64, 64, True), (1, 7, 208, 32, 64, False), (2, 9, 24, 64, 32, True), (2, 13, 104, 64, 64, True),
+    (1, 1, 16, 32, 32, True), (1, 5, 208, 64, 32, False), (2, 11, 208, 64, 64, True),      # (208 x 64 channels: single-row groups)
+])
+def test_sliding_window_small_channel_convolution(K, monkeypatch, case):
+    """conv_sw_kernel (csrc/conv_sw.hip: input rows once through an LDS ring, weights in registers as the MFMA's A operand) against
+    float64 and against the implicit-GEMM kernels (debug bit 20) on the same operands: image borders inside a strip (strips cross
+    images), ragged last pixel block, 1-row images, BatchNorm statistics in replica mode, nothing written outside the output."""
+    B, H, W, Cin, Cout, with_stats = case
+    dt = torch.bfloat16
+    M = B * H * W
+    x = rnd(M, Cin, dt=dt)
+    w = (rnd(Cout, 9 * Cin, dt=dt, seed=1) * (9 * Cin) ** -0.5).to(dt)
+    ld = Cout + 8
+    out, st = {}, {}
+    for flag in (1048576, 2097152):      # implicit GEMM / sliding window forced (bit 21 lifts the size threshold)
+        monkeypatch.setattr(K, "DEBUG_FLAGS", flag)
+        y = torch.full((M + 1, ld), 7.0, device="cuda", dtype=dt)
+        stats = torch.zeros(3, Cout, 2, device="cuda") if with_stats else None
+        K.gemm(1, K.A_IM2COL, K.B_KC, x, w, y, M, Cout, 9 * Cin, Cin, 9 * Cin, ld, conv=(H, W, Cin), col_stats=stats, stat_replicas=3 if with_stats else 0)
+        assert (y[M] == 7).all() and (y[:, Cout:] == 7).all(), "wrote outside the M x N block"
+        out[flag] = y[:M, :Cout].clone()
+        st[flag] = stats.sum(0).double() if with_stats else None
+    monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
+    xi = x.double().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    wi = w.double().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xi, wi, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    new, old = out[2097152], out[1048576]
+    close(new, ref.float(), dt, scale=1.0)
+    assert _rel_l2(new.double(), ref) <= 1.05 * _rel_l2(old.double(), ref) + 1e-6
+    if with_stats:
+        for s_ in (st[1048576], st[2097152]):
+            assert _rel_l2(s_[:, 1], (ref ** 2).sum(0)) < 2e-3
+            assert float((s_[:, 0] - ref.sum(0)).abs().max()) < 2e-3 * math.sqrt(M) + 1e-3
+        assert _rel_l2(st[2097152], st[1048576]) < 1e-3
+
+
 def test_grouped_weight_gradients_in_one_launch(K):
     """crog_gemm_group: dense and 3x3 weight gradients of different sizes and splits side by side in one launch of the ping-pong
     weight-gradient kernel; every output equals the float64 product (and what was in the gradient before), nothing else is touched."""
@@ -261,6 +299,8 @@ def test_grouped_weight_gradients_in_one_launch(K):
     (1352, 128, 256, None, 1024, False, "relu_post", True, False),    # ReLU after the residual
     (2704, 2048, 256, None, 512, True, "quickgelu", False, False),    # 32 k-tiles
     (2 * 26 * 26, 9 * 64, 256, (26, 26, 64), 512, True, "relu", True, False),   # 3x3 form with everything
+    (2704, 512, 2048, None, 524288, True, "relu", False, False),      # 128-row tile (bit 19) with bias + ReLU: the decoder FFN at B = 4
+    (2100, 256, 256, None, 524288, False, "relu_post", True, True),   # 128-row tile, residual + ReLU after it, statistics, ragged
 ])
 def test_ping_pong_kernel_full_epilogue(K, monkeypatch, case):
     """gemm_pp_kernel<..., EPI = true>: bias, activation, residual and the ReLU after the residual in crog_gemm's order (+ bias,
