@@ -187,21 +187,26 @@ class CROG(nn.Module):
                 t_side = RT.wgrad_stream()
                 store.ensure_t(dtype)
                 RT._issue_wgrad(lambda: store.weights_t(dtype), ())
-            if self.overlap_text:
+            # (deterministic mode: ONE stream.  With the text tower's backward running beside the image tower's, its gradients differed
+            # in the last bit in about one run of four at B = 8 - the same unexplained dependence on a concurrent kernel that keeps the
+            # weight gradients on the main stream in that mode: runtime.set_deterministic, LAB_NOTES section 9)
+            overlap_text = self.overlap_text and not RT.deterministic
+            graphed = None
+            if overlap_text:
                 if self._side is None:
                     RT.ensure_streams(dev)      # creation ORDER of the side streams decides which hardware queues they share
                     self._side = RT.text_stream if RT.text_stream is not None else torch.cuda.Stream(device=dev)
                 RT.streams = [main, self._side]
                 self._side.wait_stream(main)
                 graphed = self._text_graph(word, dtype) if (TEXT_GRAPH and self.training and torch.is_grad_enabled()) else None
-            if self.overlap_text and graphed is not None:
+            if overlap_text and graphed is not None:
                 # both passes of the text tower are one hipGraph replay each (crog_amd/graphs.py): issued up front, it runs
                 # beside the image stem without costing the host ~650 launches per step
                 with torch.cuda.stream(self._side):
                     wfeat, state = graphed(self.backbone.tok.param, word)
                 vis = self.backbone.image_features(img, dtype)
                 main.wait_stream(self._side)
-            elif self.overlap_text:
+            elif overlap_text:
                 txt = []
                 steps = self.backbone.text_features_steps(word, dtype, parts=3)
 
