@@ -9,6 +9,7 @@ st = [i for i, r in enumerate(rows) if "stem_im2col" in r["Kernel_Name"]]
 rows = rows[st[-1 - k]:st[-1]]
 def family(n):
     if "gemm_ppt" in n: return "weight gradient (ping-pong 256x256 / grouped)"
+    if "conv_sw" in n: return "3x3 conv forward + data gradient"
     m = re.search(r"gemm_dma_kernelIDF16bLi(\d)ELi(\d)E", n)
     lay = (int(m.group(1)), int(m.group(2))) if m else None
     if lay is None:
