@@ -90,7 +90,10 @@ __global__ void __launch_bounds__(SW_NT, 1) conv_sw_kernel(const crog_gemm_desc 
       const unsigned q = (unsigned)tid + (unsigned)i * SW_NT;
       const unsigned rr = q / row_chunks, c = q - rr * row_chunks;
       const int gr = first + (int)rr;
-      if ((int)rr < count && gr >= 0 && gr <= last_in) stage[i] = *reinterpret_cast<const f32x4*>(X + ((int64_t)gr * row_chunks + c) * 8);
+      // UNCONDITIONAL loads (a row that is not wanted reads row r0 instead and is dropped by commit): under a per-load branch the
+      // compiler waited for each load before issuing the next - five serialised round trips to memory per batch
+      const int gs = ((int)rr < count && gr >= 0 && gr <= last_in) ? gr : r0;
+      stage[i] = *reinterpret_cast<const f32x4*>(X + ((int64_t)gs * row_chunks + c) * 8);
     }
   };
   auto commit = [&](int first, int count) {
