@@ -27,6 +27,8 @@ int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t
 bool crog_gemm_pp_full_epilogue_ok(const crog_gemm_desc& d);
 bool crog_conv_sw_eligible(const crog_gemm_desc& d);      // conv_sw.hip: sliding-window 3x3 convolution for 32 / 64 channels
 int crog_conv_sw_launch(const crog_gemm_desc& d, hipStream_t s);
+bool crog_wgrad_sw_eligible(const crog_gemm_desc& d);     // wgrad_sw.hip: sliding-window 3x3 weight gradient for 32 / 64 channels
+int crog_wgrad_sw_launch(const crog_gemm_desc& d, hipStream_t s);
 // the ping-pong weight-gradient kernel (gemm_ppt.hip)
 bool crog_gemm_ppt_eligible(const crog_gemm_desc& d);
 int crog_gemm_ppt_launch(const crog_gemm_desc& d, int dist, hipStream_t s);
@@ -1843,6 +1845,13 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     static const bool conv_sw = [] { const char* e = getenv("CROG_CONV_SW"); return !e || atoi(e) != 0; }();
     if (conv_sw && !(d.debug & 1048576) && d.a_layout == CROG_A_IM2COL && (d.M >= 65536 || (d.debug & 2097152)) && crog_conv_sw_eligible(d))
       return crog_conv_sw_launch(d, s);
+  }
+  if constexpr (sizeof(T) == 2) {
+    // ... and their weight gradients (the tail of the step): CROG_WGRAD_SW=0 / debug bit 22: the implicit GEMM; bit 23 lifts the size threshold
+    static const bool wgrad_sw = [] { const char* e = getenv("CROG_WGRAD_SW"); return !e || atoi(e) != 0; }();
+    if (wgrad_sw && !(d.debug & 4194304) && d.a_layout == CROG_A_MC && d.b_layout == CROG_B_NC_IM2COL && (d.K >= 65536 || (d.debug & 8388608)) &&
+        crog_wgrad_sw_eligible(d) && (d.convC == 32 || (d.debug & 8388608)))      // (64 -> 64: 89 us either way - its 9.4 M atomic adds cost 49 us)
+      return crog_wgrad_sw_launch(d, s);
   }
   const int shape = pick_shape(d);
   if (dma_eligible(d)) {

@@ -254,6 +254,31 @@ def test_sliding_window_small_channel_convolution(K, monkeypatch, case):
         assert _rel_l2(st[2097152], st[1048576]) < 1e-3
 
 
+@pytest.mark.parametrize("case", [(2, 20, 32, 32, 32), (3, 5, 40, 64, 64), (1, 7, 208, 32, 64), (2, 9, 24, 64, 32), (2, 13, 104, 64, 64), (1, 1, 16, 32, 32)])
+def test_sliding_window_small_channel_weight_gradient(K, monkeypatch, case):
+    """wgrad_sw_kernel (csrc/wgrad_sw.hip: one wave per tap, operands through LDS row rings, transposed fragment reads) against float64
+    and against the implicit-GEMM weight gradient (debug bit 22) on the same operands; accumulates onto what the gradient held."""
+    B, H, W, Cin, Cout = case
+    dt = torch.bfloat16
+    M = B * H * W
+    x = rnd(M, Cin, dt=dt)
+    dy = (rnd(M, Cout, dt=dt, seed=1) * 0.1).to(dt)
+    N = 9 * Cin
+    out = {}
+    for flag in (4194304, 8388608):      # implicit GEMM / sliding window forced (bit 23 lifts the size threshold)
+        monkeypatch.setattr(K, "DEBUG_FLAGS", flag)
+        g = torch.full((Cout + 1, N + 8), 0.5, device="cuda")
+        K.gemm(1, K.A_MC, K.B_NC_IM2COL, dy, x, g, Cout, N, M, Cout, Cin, N + 8, splitk=4, out_mode=K.OUT_F32_ATOMIC, conv=(H, W, Cin))
+        assert (g[Cout] == 0.5).all() and (g[:, N:] == 0.5).all(), "wrote outside the M x N block"
+        out[flag] = g[:Cout, :N].double() - 0.5
+    monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
+    xi = x.double().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    cols = torch.nn.functional.unfold(xi, 3, padding=1).view(B, Cin, 9, H * W).permute(0, 3, 2, 1).reshape(M, 9 * Cin)
+    ref = dy.double().t() @ cols
+    assert _rel_l2(out[8388608], ref) < 2e-3, _rel_l2(out[8388608], ref)
+    assert _rel_l2(out[4194304], ref) < 2e-3
+
+
 def test_grouped_weight_gradients_in_one_launch(K):
     """crog_gemm_group: dense and 3x3 weight gradients of different sizes and splits side by side in one launch of the ping-pong
     weight-gradient kernel; every output equals the float64 product (and what was in the gradient before), nothing else is touched."""
