@@ -1850,7 +1850,9 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     // ... and their weight gradients (the tail of the step): CROG_WGRAD_SW=0 / debug bit 22: the implicit GEMM; bit 23 lifts the size threshold
     static const bool wgrad_sw = [] { const char* e = getenv("CROG_WGRAD_SW"); return !e || atoi(e) != 0; }();
     if (wgrad_sw && !(d.debug & 4194304) && d.a_layout == CROG_A_MC && d.b_layout == CROG_B_NC_IM2COL && (d.K >= 65536 || (d.debug & 8388608)) &&
-        crog_wgrad_sw_eligible(d) && (d.convC == 32 || (d.debug & 8388608)))      // (64 -> 64: 89 us either way - its 9.4 M atomic adds cost 49 us)
+        crog_wgrad_sw_eligible(d) && (d.convC == 32 || d.out_mode == CROG_OUT_F32 || (d.debug & 8388608)))
+      // (64 -> 64 with atomic adds: 89 us either way - its 9.4 M adds cost 49 us; 256 slabs + crog_splitk_reduce: 108 us.  The slab form
+      // serves deterministic mode, whose weight gradients are all slabs)
       return crog_wgrad_sw_launch(d, s);
   }
   const int shape = pick_shape(d);

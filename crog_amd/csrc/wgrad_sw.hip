@@ -57,7 +57,15 @@ __global__ void __launch_bounds__(WS_NT, 1) wgrad_sw_kernel(const crog_gemm_desc
   char* dring = xzero + XRS;                               // 2 rows: dy row r in slot r & 1
 
   const int r0 = blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, total_rows);
-  if (r0 >= r1) return;
+  // CROG_OUT_F32 (slab form): workgroup b STORES its sums into slab b of a [strips][Cout][ldc] workspace; the caller adds the slabs up
+  // in order (crog_splitk_reduce).  For 64 -> 64 channels the 9.4 M atomic adds of the other form cost more than the products.
+  const bool slab = p.out_mode == CROG_OUT_F32;
+  float* G = reinterpret_cast<float*>(p.C) + (slab ? (int64_t)blockIdx.x * p.M * p.ldc : 0);
+  if (r0 >= r1) {
+    if (slab)
+      for (int i = tid; i < p.M * 9 * CI; i += WS_NT) G[(int64_t)(i / (9 * CI)) * p.ldc + i % (9 * CI)] = 0.f;
+    return;
+  }
 
   // everything starts as zeros: borders, padding pixels and the zero row are never written again
   for (unsigned i = tid * 16u; i < 5u * XRS + 2u * DRS; i += WS_NT * 16u) *reinterpret_cast<f32x4*>(smem + i) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -171,22 +179,27 @@ __global__ void __launch_bounds__(WS_NT, 1) wgrad_sw_kernel(const crog_gemm_desc
   }
 
   // acc[c][i][e] = dW[co = 16 c + 4 g4 + e][tap][ci = 16 i + l15]
-  float* G = reinterpret_cast<float*>(p.C);
   if (p.debug & 32) return;          // timing-only ablation (as in crog_gemm's split-K kernels): what the atomic adds cost
 #pragma unroll
   for (int c = 0; c < CB; c++)
 #pragma unroll
     for (int i = 0; i < IB; i++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) atomicAdd(G + (int64_t)(16 * c + 4 * g4 + e) * p.ldc + tap * CI + 16 * i + l15, acc[c][i][e]);
+      for (int e = 0; e < 4; e++) {
+        float* dst = G + (int64_t)(16 * c + 4 * g4 + e) * p.ldc + tap * CI + 16 * i + l15;
+        if (slab) *dst = acc[c][i][e];
+        else atomicAdd(dst, acc[c][i][e]);
+      }
 }
 
 template <int CI, int CO>
 int launch_wsw(const crog_gemm_desc& d, hipStream_t s) {
   const int W = d.convW, WP = (W + 31) & ~31;
   const int rows = d.K / W;
-  const int per = std::max(cdiv(rows, 256), std::min(4, rows));
-  const int wgs = cdiv(rows, per);
+  // atomic form: ~one workgroup per CU; slab form: exactly d.splitk strips (slabs), empty ones store zeros
+  const bool slab = d.out_mode == CROG_OUT_F32;
+  const int per = slab ? cdiv(rows, d.splitk) : std::max(cdiv(rows, 256), std::min(4, rows));
+  const int wgs = slab ? d.splitk : cdiv(rows, per);
   const int lds = 5 * (WP + 2) * CI * 2 + 2 * WP * CO * 2;
   static bool attr_set = false;
   auto kern = wgrad_sw_kernel<CI, CO>;
@@ -208,7 +221,8 @@ int launch_wsw(const crog_gemm_desc& d, hipStream_t s) {
 // Can the sliding-window weight-gradient kernel take this launch?
 bool crog_wgrad_sw_eligible(const crog_gemm_desc& d) {
   if (d.dtype != CROG_BF16 || d.a_layout != CROG_A_MC || d.b_layout != CROG_B_NC_IM2COL || d.batch != 1) return false;
-  if (d.out_mode != CROG_OUT_F32_ATOMIC || d.alpha != 1.f || d.bias || d.R || d.a_sum || d.col_stats || d.act != CROG_ACT_NONE) return false;
+  if (d.out_mode != CROG_OUT_F32_ATOMIC && !(d.out_mode == CROG_OUT_F32 && d.splitk >= 1 && d.splitk <= 4096)) return false;
+  if (d.alpha != 1.f || d.bias || d.R || d.a_sum || d.col_stats || d.act != CROG_ACT_NONE) return false;
   if ((d.M != 32 && d.M != 64) || (d.convC != 32 && d.convC != 64) || d.N != 9 * d.convC) return false;
   if (d.lda != d.M || d.ldb != d.convC) return false;                              // dense [pixels][C] operands
   if (d.convW < 16 || d.convH < 1 || d.K % ((long)d.convH * d.convW) != 0) return false;

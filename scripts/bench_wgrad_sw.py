@@ -27,4 +27,10 @@ for B, HW, Cin, Cout in [(32, 104, 64, 64), (32, 208, 32, 32), (32, 208, 32, 64)
     K.DEBUG_FLAGS = 4194304; t0 = timeit(run, 3 * nset)
     K.DEBUG_FLAGS = 0; t1 = timeit(run, 3 * nset)
     K.DEBUG_FLAGS = 32; t2 = timeit(run, 3 * nset); K.DEBUG_FLAGS = 0
-    print(f"dW[{Cout} x {N}] over {M} pixels: implicit GEMM (split {sk}) {t0:6.1f} us, sliding window {t1:6.1f} us (without its atomic adds {t2:6.1f}); operands at 5 TB/s {M*(Cin+Cout)*2/5e6:5.1f} us", flush=True)
+    ws = torch.empty(256, Cout, N, device="cuda")
+    def run_slab():
+        i = it[0] = (it[0] + 1) % nset
+        K.gemm(1, K.A_MC, K.B_NC_IM2COL, dys[i], xs[i], ws, Cout, N, M, Cout, Cin, N, splitk=256, out_mode=K.OUT_F32, conv=(HW, HW, Cin))
+        K.splitk_reduce(ws, 256, Cout, N, N, dw, 0, N, accumulate=True)
+    t3 = timeit(run_slab, 3 * nset)
+    print(f"dW[{Cout} x {N}] over {M} pixels: implicit GEMM (split {sk}) {t0:6.1f} us, sliding window {t1:6.1f} us (without its atomic adds {t2:6.1f}; 256 slabs + ordered reduction {t3:6.1f}); operands at 5 TB/s {M*(Cin+Cout)*2/5e6:5.1f} us", flush=True)

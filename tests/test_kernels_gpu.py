@@ -277,6 +277,18 @@ def test_sliding_window_small_channel_weight_gradient(K, monkeypatch, case):
     ref = dy.double().t() @ cols
     assert _rel_l2(out[8388608], ref) < 2e-3, _rel_l2(out[8388608], ref)
     assert _rel_l2(out[4194304], ref) < 2e-3
+    # slab form: 7 strips (more than rows for the 1-row case: empty strips store zeros) + the ordered reduction, twice: bit-identical
+    monkeypatch.setattr(K, "DEBUG_FLAGS", 8388608)
+    res = []
+    for _ in range(2):
+        ws = torch.full((7, Cout, N + 4), float("nan"), device="cuda")
+        K.gemm(1, K.A_MC, K.B_NC_IM2COL, dy, x, ws, Cout, N, M, Cout, Cin, N + 4, splitk=7, out_mode=K.OUT_F32, conv=(H, W, Cin))
+        g = torch.full((Cout, N), 0.25, device="cuda")
+        K.splitk_reduce(ws, 7, Cout, N, N + 4, g, 0, N, accumulate=True)
+        res.append(g)
+    monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
+    assert torch.equal(res[0], res[1])
+    assert _rel_l2(res[0].double() - 0.25, ref) < 2e-3
 
 
 def test_grouped_weight_gradients_in_one_launch(K):
