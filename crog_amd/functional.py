@@ -687,7 +687,8 @@ class LinearFn(Function):
     channels) lives in a padded buffer; the Function hands out the [.., :N] view."""
 
     @staticmethod
-    def forward(ctx, x, res, _wp, _bp, w: WRef, b: Optional[WRef], act, out, grad_gated=False):
+    def forward(ctx, x, res, _wp, _bp, w: WRef, b: Optional[WRef], act, out, grad_gated=False, res_slot=None):
+        ctx.res_slot = res_slot          # the residual's gradient goes to the LayerNorm backward of the same tensor (GradSlot), not to autograd
         ctx.grad_gated = grad_gated      # the consumer's backward already gated dy by y > 0 (layernorm(relu_in=True)): no activation-backward pass
         M, Kd, _ = K.mat(x)
         N = w.rows
@@ -729,7 +730,7 @@ class LinearFn(Function):
                 K.act_bwd(dy, y, g, 0 if act == K.ACT_RELU else 2)
         def wgrad():
             lin_wgrad(g, x, w, bias=b)
-        if has_res and g is dy:
+        if has_res and g is dy and ctx.res_slot is None:
             wgrad()   # dy is handed on as the residual's gradient and autograd may accumulate into it IN PLACE: keep the read ordered
         else:
             RT.on_wgrad_stream(wgrad, g, x)
@@ -742,7 +743,10 @@ class LinearFn(Function):
         w.done()
         if b is not None:
             b.done()
-        return dx, dres, None, None, None, None, None, None, None
+        if ctx.res_slot is not None and dres is not None:
+            ctx.res_slot.put(dres)
+            dres = None
+        return dx, dres, None, None, None, None, None, None, None, None
 
 
 def y_full(y: torch.Tensor, Np: int) -> torch.Tensor:
@@ -750,10 +754,10 @@ def y_full(y: torch.Tensor, Np: int) -> torch.Tensor:
     return y.as_strided(tuple(y.shape[:-1]) + (Np,), y.stride(), y.storage_offset())
 
 
-def linear(x, w: WRef, b: Optional[WRef] = None, *, act=K.ACT_NONE, res=None, out=None, grad_gated=False):
+def linear(x, w: WRef, b: Optional[WRef] = None, *, act=K.ACT_NONE, res=None, out=None, grad_gated=False, res_slot=None):
     """grad_gated (act = ReLU only): the ONLY consumer of the output is a layernorm(relu_in=True), whose backward hands back the gradient
-    of the ReLU's input."""
-    return LinearFn.apply(x, res, w.param, b.param if b is not None else None, w, b, act, out, bool(grad_gated))
+    of the ReLU's input.  res_slot: `res` is also the input of a layernorm(add_slot=...) whose backward adds the residual's gradient."""
+    return LinearFn.apply(x, res, w.param, b.param if b is not None else None, w, b, act, out, bool(grad_gated), res_slot)
 
 
 class QuickGeluFn(Function):
@@ -872,7 +876,8 @@ class MhaFn(Function):
 
     @staticmethod
     def forward(ctx, xq, xk, xv, res, *args):
-        (wq, wk, wv, bq, bk, bv, wo, bo, B, heads, causal, kpm, p_drop) = args[-13:]
+        (wq, wk, wv, bq, bk, bv, wo, bo, B, heads, causal, kpm, p_drop, res_slot) = args[-14:]
+        ctx.res_slot = res_slot
         dev, dtype = xq.device, xq.dtype
         dt = K.dcode(dtype)
         E = wq.rows
@@ -950,7 +955,7 @@ class MhaFn(Function):
         # out projection
         def wgrad_out():
             lin_wgrad(dout, O, wo, bias=bo)
-        if has_res:
+        if has_res and ctx.res_slot is None:
             wgrad_out()   # dout doubles as the residual's gradient (possible in-place accumulation by autograd): stay on this stream
         else:
             RT.on_wgrad_stream(wgrad_out, dout, O)
@@ -1012,7 +1017,10 @@ class MhaFn(Function):
         dxk = None if same_qk else grads.get(id(xk))
         dxv = None if (same_kv or xv is xq) else grads.get(id(xv))
         dres = dout if has_res else None
-        n_extra = 13 + 8
+        if ctx.res_slot is not None and dres is not None:      # (LinearFn: the LayerNorm backward of the same tensor adds it)
+            ctx.res_slot.put(dres)
+            dres = None
+        n_extra = 14 + 8
         return (dxq, dxk, dxv, dres) + (None,) * n_extra
 
 
@@ -1023,10 +1031,11 @@ def _merge_w(a: WRef, b: WRef) -> WRef:
     return m
 
 
-def mha(xq, xk, xv, wq: WRef, wk: WRef, wv: WRef, bq, bk, bv, wo: WRef, bo, *, B, heads, causal=False, kpm=None, p_drop=0.0, res=None):
+def mha(xq, xk, xv, wq: WRef, wk: WRef, wv: WRef, bq, bk, bv, wo: WRef, bo, *, B, heads, causal=False, kpm=None, p_drop=0.0, res=None,
+        res_slot=None):
     params = [r.param for r in (wq, wk, wv, bq, bk, bv, wo, bo) if r is not None]
     params = params + [None] * (8 - len(params))
-    return MhaFn.apply(xq, xk, xv, res, *params, wq, wk, wv, bq, bk, bv, wo, bo, B, heads, causal, kpm, float(p_drop))
+    return MhaFn.apply(xq, xk, xv, res, *params, wq, wk, wv, bq, bk, bv, wo, bo, B, heads, causal, kpm, float(p_drop), res_slot)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -202,12 +202,16 @@ class ResidualAttentionBlock(Bound):
         self.causal = causal
 
     def forward(self, x, B):
-        h = self.ln_1(x)
-        x = self.attn(h, h, h, B=B, causal=self.causal, res=x, training=self.training)
-        h = self.ln_2(x)
+        # both residual streams have two consumers (a norm and the add after the sub-layer): the add's gradient rides a GradSlot into
+        # that norm's backward (crog_ln_bwd dxadd) instead of an autograd accumulation pass - 24 launches per text tower
+        g = self.training and torch.is_grad_enabled() and x.requires_grad and Fn.LN_GRAD_SLOTS
+        s1, s2 = (Fn.GradSlot(), Fn.GradSlot()) if g else (None, None)
+        h = self.ln_1(x, add_slot=s1)
+        x = self.attn(h, h, h, B=B, causal=self.causal, res=x, training=self.training, res_slot=s1)
+        h = self.ln_2(x, add_slot=s2)
         u = Fn.linear(h, self.mlp["c_fc"].w, self.mlp["c_fc"].b)
         a = Fn.quickgelu(u)
-        return Fn.linear(a, self.mlp["c_proj"].w, self.mlp["c_proj"].b, res=x)
+        return Fn.linear(a, self.mlp["c_proj"].w, self.mlp["c_proj"].b, res=x, res_slot=s2)
 
 
 class Transformer(Bound):

@@ -1,7 +1,8 @@
 """Last stretch of every queue of the last replayed step in a rocprofv3 kernel trace: what the step's end waits for.
 usage: tail_view.py <kernel_trace.csv> [from_ms]"""
 import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
+import gzip
+rows = list(csv.DictReader(gzip.open(sys.argv[1], "rt") if sys.argv[1].endswith(".gz") else open(sys.argv[1])))
 lo = float(sys.argv[2]) if len(sys.argv) > 2 else 27.0
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))) for r in rows))
 st = [i for i, e in enumerate(ev) if "stem_im2col" in e[3]]
