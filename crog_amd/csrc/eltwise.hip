@@ -40,8 +40,8 @@ __global__ void __launch_bounds__(NT) avgpool2_fwd_kernel(const T* __restrict__ 
   }
 }
 template <typename T>
-__global__ void __launch_bounds__(NT) avgpool2_bwd_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx, int B, int H,
-                                                          int W, int C) {
+__global__ void __launch_bounds__(NT) avgpool2_bwd_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ add, long ldadd,
+                                                          T* __restrict__ dx, long lddx, int B, int H, int W, int C) {
   constexpr int VEC = Elem<T>::VEC;
   const int OH = H / 2, OW = W / 2, cvec = C / VEC;
   const long total = (long)B * OH * OW * cvec;
@@ -56,10 +56,21 @@ __global__ void __launch_bounds__(NT) avgpool2_bwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int e = 0; e < VEC; e++) g.v[e] = Elem<T>::from_f(0.25f * Elem<T>::to_f(g.v[e]));
     const long base = ((b * H + 2 * oy) * W + 2 * ox);
-    stg16(dx + base * lddx + c, g);
-    stg16(dx + (base + 1) * lddx + c, g);
-    stg16(dx + (base + W) * lddx + c, g);
-    stg16(dx + (base + W + 1) * lddx + c, g);
+    if (add == nullptr) {
+      stg16(dx + base * lddx + c, g);
+      stg16(dx + (base + 1) * lddx + c, g);
+      stg16(dx + (base + W) * lddx + c, g);
+      stg16(dx + (base + W + 1) * lddx + c, g);
+    } else {      // + the gradient another consumer of the pooled map's input left behind (a pyramid level that also feeds the neck)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const long px = base + (q >> 1) * W + (q & 1);
+        Vec16<T> a = ldg16(add + px * ldadd + c), o;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(Elem<T>::to_f(g.v[e]) + Elem<T>::to_f(a.v[e]));
+        stg16(dx + px * lddx + c, o);
+      }
+    }
   }
 }
 
@@ -726,12 +737,18 @@ extern "C" int crog_avgpool2_fwd(int dtype, const void* x, int64_t ldx, void* y,
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
-extern "C" int crog_avgpool2_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int H, int W, int C, crog_stream_t s) {
+extern "C" int crog_avgpool2_bwd_add(int dtype, const void* dy, int64_t lddy, const void* add, int64_t ldadd, void* dx, int64_t lddx, int B, int H,
+                                    int W, int C, crog_stream_t s) {
   const int vec = VECOF(dtype);
-  CROG_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % vec == 0 && lddy % vec == 0 && lddx % vec == 0, "avgpool2_bwd: bad shape");
-  DISPATCH_T(dtype, LAUNCH((avgpool2_bwd_kernel<T>), (long)B * (H / 2) * (W / 2) * (C / vec), s, (const T*)dy, (long)lddy, (T*)dx, (long)lddx, B, H, W, C));
+  CROG_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % vec == 0 && lddy % vec == 0 && lddx % vec == 0 && (add == nullptr || ldadd % vec == 0),
+                 "avgpool2_bwd: bad shape");
+  DISPATCH_T(dtype, LAUNCH((avgpool2_bwd_kernel<T>), (long)B * (H / 2) * (W / 2) * (C / vec), s, (const T*)dy, (long)lddy, (const T*)add,
+                           (long)ldadd, (T*)dx, (long)lddx, B, H, W, C));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
+}
+extern "C" int crog_avgpool2_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int H, int W, int C, crog_stream_t s) {
+  return crog_avgpool2_bwd_add(dtype, dy, lddy, nullptr, 0, dx, lddx, B, H, W, C, s);
 }
 extern "C" int crog_upsample2_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C, crog_stream_t s) {
   const int vec = VECOF(dtype);

@@ -49,6 +49,7 @@ BN_ATOMIC_STATS = True           # BN statistics: atomic replicas in the GEMM ep
 RELU_BITMASK = True              # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
 LN_BWD_ATOMIC = False            # LayerNorm parameter gradients through atomics in ln_bwd itself: measured 0.5 % SLOWER (every block adds into the same 2 C floats)
 LN_REDUCE_SIDE = True            # LayerNorm parameter-gradient reduction on the weight-gradient stream
+FAN_SLOTS = True                 # a map with a consumer outside its block (layer2 / layer3 -> neck, layer4 -> attention tokens): that gradient rides a GradSlot too
 LN_GRAD_SLOTS = True             # decoder: a residual's gradient is added inside the LayerNorm backward of the same tensor (GradSlot -> crog_ln_bwd dxadd)
 BN_BWD_ATOMIC = True             # backward partial sums through coalesced atomics (bf16)
 DGRAD_T = True                   # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
@@ -1043,28 +1044,31 @@ def mha(xq, xk, xv, wq: WRef, wk: WRef, wv: WRef, bq, bk, bv, wo: WRef, bo, *, B
 # ------------------------------------------------------------------------------------------------
 class AvgPool2Fn(Function):
     @staticmethod
-    def forward(ctx, x, out, grad_slot=None):
+    def forward(ctx, x, out, grad_slot=None, add_slot=None):
         B, H, W, C = x.shape
         y = _dest(out) if out is not None else torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=x.dtype)
         K.avgpool2_fwd(x, y)
         ctx.shape = x.shape
-        ctx.grad_slot = grad_slot
+        ctx.grad_slot, ctx.add_slot = grad_slot, add_slot
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dx = torch.empty(ctx.shape, device=dy.device, dtype=dy.dtype)
-        K.avgpool2_bwd(K.as_mat(dy), dx)
+        parked = ctx.add_slot.take() if ctx.add_slot is not None else None
+        K.avgpool2_bwd(K.as_mat(dy), dx, add=parked)
         if ctx.grad_slot is not None:      # the other consumer of x adds this branch's gradient in its data-gradient epilogue (GradSlot)
             ctx.grad_slot.put(dx)
-            return None, None, None
-        return dx, None, None
+            return None, None, None, None
+        return dx, None, None, None
 
 
-def avgpool2(x, out=None, grad_slot=None):
+def avgpool2(x, out=None, grad_slot=None, add_slot=None):
     """grad_slot: hand the gradient w.r.t. x to a GradSlot instead of autograd (the caller vouches that the slot's consumer - another
-    consumer of the same x - runs its backward AFTER this op: Bottleneck's downsample branch, created after conv1 / conv2)."""
-    return AvgPool2Fn.apply(x, out, grad_slot)
+    consumer of the same x - runs its backward AFTER this op: Bottleneck's downsample branch, created after conv1 / conv2).
+    add_slot: a third consumer of x whose backward ran BEFORE this one (the neck, for the outputs of layer2 / layer3) left its gradient
+    there; the pool backward adds it while it writes dx."""
+    return AvgPool2Fn.apply(x, out, grad_slot, add_slot)
 
 
 class Upsample2Fn(Function):
@@ -1164,11 +1168,12 @@ class AddRowsFn(Function):
     """out = a + table[row % rows(table)]; the table is a constant (sin/cos encodings) or carries its own grad path."""
 
     @staticmethod
-    def forward(ctx, a, table):
+    def forward(ctx, a, table, grad_slot=None):
         out = torch.empty_like(a)
         K.add_rows(a, table, out)
         ctx.tshape = table.shape
         ctx.tgrad = table.requires_grad
+        ctx.grad_slot = grad_slot      # a's other consumer (a convolution created BEFORE this op) adds this gradient in its dgrad epilogue
         return out
 
     @staticmethod
@@ -1182,11 +1187,14 @@ class AddRowsFn(Function):
             acc = torch.empty(rows, ctx.tshape[-1], device=dout.device, dtype=torch.float32)
             K.sum_over_batch(dout_m.reshape(-1, ctx.tshape[-1]), acc, dout_m.numel() // (rows * ctx.tshape[-1]))
             dt_ = acc.to(dout.dtype).view(ctx.tshape) if dout.dtype != torch.float32 else acc.view(ctx.tshape)
-        return dout, dt_
+        if ctx.grad_slot is not None:
+            ctx.grad_slot.put(dout)
+            return None, dt_, None
+        return dout, dt_, None
 
 
-def add_rows(a, table):
-    return AddRowsFn.apply(a, table)
+def add_rows(a, table, grad_slot=None):
+    return AddRowsFn.apply(a, table, grad_slot)
 
 
 class AddDropoutFn(Function):

@@ -419,9 +419,11 @@ def avgpool2_fwd(x, y):
     check(lib().crog_avgpool2_fwd(dcode(x), ptr(x), ld, ptr(y), mat(y)[2], B, H, W, C, stream()), "avgpool2_fwd")
 
 
-def avgpool2_bwd(dy, dx):
+def avgpool2_bwd(dy, dx, add=None):
+    """add: a gradient of the same map another branch already produced (dx = pool-backward(dy) + add)."""
     B, H, W, C, ld = _nhwc(dx)
-    check(lib().crog_avgpool2_bwd(dcode(dy), ptr(dy), mat(dy)[2], ptr(dx), ld, B, H, W, C, stream()), "avgpool2_bwd")
+    check(lib().crog_avgpool2_bwd_add(dcode(dy), ptr(dy), mat(dy)[2], ptr(add) if add is not None else None, mat(add)[2] if add is not None else 0,
+                                      ptr(dx), ld, B, H, W, C, stream()), "avgpool2_bwd")
 
 
 def upsample2_fwd(x, y):

@@ -137,13 +137,13 @@ class ConvBN(Bound):
     def bn(self):
         return getattr(self, self._names[1])
 
-    def run(self, x, *, ksize=None, relu=True, res=None, out=None, wpad=None, dtype=None, stat_out=None, stat_in=None):
+    def run(self, x, *, ksize=None, relu=True, res=None, out=None, wpad=None, dtype=None, stat_out=None, stat_in=None, dx_slot=None):
         conv = self.conv
         if ksize is None:
             ksize = 0 if conv is None else (conv.k if isinstance(conv, Conv2d) else 1)
         o = Fn.OutRef(out) if out is not None else None
         return Fn.conv_bn_act(x, conv.w if conv is not None else None, self.bn.buffers_ref(), ksize=ksize, relu=relu, res=res,
-                              training=self.bn.training, out=o, wpad=wpad, dtype=dtype, stat_out=stat_out, stat_in=stat_in)
+                              training=self.bn.training, out=o, wpad=wpad, dtype=dtype, stat_out=stat_out, stat_in=stat_in, dx_slot=dx_slot)
 
 
 def conv_layer(cin, cout, k=1):

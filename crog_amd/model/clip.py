@@ -36,8 +36,10 @@ class Bottleneck(Bound):
         if stride > 1 or inplanes != planes * 4:
             self.downsample = nn.ModuleDict({"0": Conv2d(inplanes, planes * 4, 1), "1": BatchNorm(planes * 4)})
 
-    def forward(self, x, res_in=None, res_out=None):
-        """res_in / res_out (Stage.forward): BnLinks to the previous / next block of the stage - this block's first data
+    def forward(self, x, res_in=None, res_out=None, fan_slot=None):
+        """fan_slot (strided blocks): a GradSlot in which a consumer of x OUTSIDE the tower (the neck) leaves its gradient; the
+        downsample branch's pool backward adds it.
+        res_in / res_out (Stage.forward): BnLinks to the previous / next block of the stage - this block's first data
         gradient does the previous block's bn3 first backward pass (Fn.BN_RES_FUSED).  The consumer's conv1 data gradient adds the
         gradient of the block's other branch (identity, or avgpool / downsample through the slot), i.e. it writes the COMPLETE gradient
         of the block's input; ConvBnAct.backward only arms the link when that second gradient is really there."""
@@ -59,7 +61,7 @@ class Bottleneck(Bound):
         identity = x
         if self.downsample is not None:
             if self.stride > 1:
-                identity = Fn.avgpool2(x, grad_slot=slot)
+                identity = Fn.avgpool2(x, grad_slot=slot, add_slot=fan_slot if slot is not None else None)
             identity = Fn.conv_bn_act(identity, self.downsample["0"].w, self.downsample["1"].buffers_ref(), ksize=1, relu=False, training=tr,
                                       dx_slot=slot if self.stride == 1 else None)
         return Fn.conv_bn_act(out, self.conv3.w, self.bn3.buffers_ref(), ksize=1, relu=True, res=identity, training=tr,
@@ -70,15 +72,15 @@ class Stage(nn.Sequential):
     """A stage of Bottlenecks (clip.py:187-195: nn.Sequential, same child names) with a BnLink between consecutive blocks: block b's
     output feeds block b + 1 and nothing else."""
 
-    def forward(self, x, res_in=None, res_out=None):
-        """res_in / res_out: links to the previous / next STAGE, when this stage's input / output has no other consumer (layer1 ->
+    def forward(self, x, res_in=None, res_out=None, fan_slot=None):
+        """fan_slot: see Bottleneck.forward (first block).  res_in / res_out: links to the previous / next STAGE, when this stage's input / output has no other consumer (layer1 ->
         layer2; the outputs of layer2 and layer3 also feed the neck, layer4's the attention pool)."""
         blocks = list(self)
         link = res_in
         for i, blk in enumerate(blocks):
             last = i + 1 == len(blocks)
             nxt = res_out if last else (Fn.BnLink() if self.training else None)
-            x = blk(x, res_in=link, res_out=nxt)
+            x = blk(x, res_in=link, res_out=nxt, **({"fan_slot": fan_slot} if i == 0 and fan_slot is not None else {}))
             link = nxt
         return x
 
@@ -120,10 +122,14 @@ class AttentionPool2d(Bound):
 
     def forward(self, x):
         B, H, W, C = x.shape
-        res = Fn.conv_bn_act(x, self.connect["0"].w, self.connect["1"].buffers_ref(), ksize=1, relu=False, training=self.training)
+        # x feeds the `connect` convolution and the attention tokens: the token branch's gradient (created later, so its backward runs
+        # first) rides a slot into the convolution's data-gradient epilogue
+        slot = Fn.GradSlot() if (self.training and torch.is_grad_enabled() and x.requires_grad and Fn.FAN_SLOTS) else None
+        res = Fn.conv_bn_act(x, self.connect["0"].w, self.connect["1"].buffers_ref(), ksize=1, relu=False, training=self.training,
+                             grad_slot=slot)
         R = bicubic_matrix(self.spacial_dim, H, W, x.device, x.dtype)
         pos = Fn.table_matmul(R, self.pos_rows, x.dtype)                      # [H*W, C]
-        tok = Fn.add_rows(x.view(B * H * W, C), pos)
+        tok = Fn.add_rows(x.view(B * H * W, C), pos, grad_slot=slot)
         o = Fn.mha(tok, tok, tok, self.q_proj.w, self.k_proj.w, self.v_proj.w, self.q_proj.b, self.k_proj.b, self.v_proj.b,
                    self.c_proj.w, self.c_proj.b, B=B, heads=self.num_heads)
         out = Fn.add_relu(o, res.view(B * H * W, -1))
@@ -147,6 +153,7 @@ class ModifiedResNet(Bound):
         self.layer3 = self._make_layer(width * 4, layers[2], stride=2)
         self.layer4 = self._make_layer(width * 8, layers[3], stride=2)
         self.attnpool = AttentionPool2d(input_resolution // 32, width * 32, heads, output_dim)
+        self.fan = None
 
     def check_supported(self, source: str = ""):
         """clip.py:165-185 is width-generic (RN50x4 = 80, RN50x16 = 96, RN50x64 = 128).  The 3x3 implicit-GEMM kernels need
@@ -182,10 +189,14 @@ class ModifiedResNet(Bound):
         x2 = self.layer2(x, res_in=l12)
         if after_layer1 is not None:
             after_layer1()
-        x3 = self.layer3(x2)
+        # layer2's / layer3's outputs also feed the neck (layers.py:373-386), whose backward runs first: its gradients wait in these
+        # slots (`self.fan`, handed to FPN.forward by CROG.forward) and are added by the next stage's downsample pool backward
+        g = tr and torch.is_grad_enabled() and x2.requires_grad and Fn.FAN_SLOTS and self.layer3[0].stride > 1 and self.layer4[0].stride > 1
+        self.fan = (Fn.GradSlot(), Fn.GradSlot()) if g else None
+        x3 = self.layer3(x2, fan_slot=self.fan[0] if g else None)
         if after_layer1 is not None:
             after_layer1()
-        x4 = self.layer4(x3)
+        x4 = self.layer4(x3, fan_slot=self.fan[1] if g else None)
         x4 = self.attnpool(x4)
         return x2, x3, x4
 

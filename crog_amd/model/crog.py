@@ -230,7 +230,9 @@ class CROG(nn.Module):
                 # too: ViT parity is encoder-level (encode_image / encode_text).
                 raise ValueError("too many values to unpack (expected 3): the FPN neck needs the (C3, C4, C5) maps of the "
                                  "ModifiedResNet tower; with a ViT tower use backbone.encode_image / encode_text")
-            fq = self.neck(vis, state)
+            fan = getattr(self.backbone.visual, "fan", None)
+            self.backbone.visual.fan = None
+            fq = self.neck(vis, state, fan=fan)
             if self.use_contrastive:
                 fq = self.decoder(fq, wfeat, pad_mask)
                 if isinstance(fq, list):

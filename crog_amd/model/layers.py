@@ -56,8 +56,10 @@ class FPN(Bound):
         self.coordconv = nn.Sequential(CoordConv(o[1], o[1], 3), conv_layer(o[1], o[1], 3))
         self.o = tuple(o)
 
-    def forward(self, imgs, state):
+    def forward(self, imgs, state, fan=None):
+        """fan: (slot for v3's gradient, slot for v4's) - ModifiedResNet.fan; the tower's own backward adds them (clip.py Bottleneck)."""
         v3, v4, v5 = imgs                      # [B,52,52,512] [B,26,26,1024] [B,13,13,1024] channels-last
+        fan3, fan4 = fan if fan is not None else (None, None)
         o0, o1, o2 = self.o
         dev, dt = v4.device, v4.dtype
         B, H4, W4, _ = v4.shape
@@ -66,12 +68,12 @@ class FPN(Bound):
         f5 = self.norm_layer.run(Fn.mul_bcast(f5, s), ksize=0)                 # relu(bn(f5 * state))
         # fusion 2: cat([f2_v_proj(v4), up(f5)])
         cat2 = torch.empty(B, H4, W4, o1 + o2, device=dev, dtype=dt)
-        a = self.f2_v_proj.run(v4, out=cat2[..., :o1])
+        a = self.f2_v_proj.run(v4, out=cat2[..., :o1], dx_slot=fan4)
         b = Fn.upsample2(f5, out=Fn.OutRef(cat2[..., o1:]))
         cat3 = torch.empty(B, H4, W4, o0 + o1, device=dev, dtype=dt)
         f4 = self.f2_cat.run(Fn.join(cat2, [a, b]), out=cat3[..., o0:])
         # fusion 3: cat([avgpool(f3_v_proj(v3)), f4])
-        f3 = Fn.avgpool2(self.f3_v_proj.run(v3), out=Fn.OutRef(cat3[..., :o0]))
+        f3 = Fn.avgpool2(self.f3_v_proj.run(v3, dx_slot=fan3), out=Fn.OutRef(cat3[..., :o0]))
         # (f3 feeds f4_proj3 and nothing else, the CoordConv output only coordconv[1]: the consumer's data gradient does the producer's
         # first BatchNorm-backward pass, Fn.BnLink)
         tr = self.training

@@ -334,6 +334,10 @@ int crog_avgpool2_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ld
                       crog_stream_t stream);
 int crog_avgpool2_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int H, int W,
                       int C, crog_stream_t stream);
+/* the same with dx = pool-backward(dy) + add (add may be NULL): the pooled map's input also feeds another branch whose gradient is
+ * already there (layer2 / layer3 outputs feed the next stage's downsample AvgPool AND the neck, clip.py:219-222 + layers.py:373-386) */
+int crog_avgpool2_bwd_add(int dtype, const void* dy, int64_t lddy, const void* add, int64_t ldadd, void* dx, int64_t lddx,
+                          int B, int H, int W, int C, crog_stream_t stream);
 /* bilinear x2, align_corners=False: layers.py:54,56,382,393.  (H, W) is the INPUT size. */
 int crog_upsample2_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C,
                        crog_stream_t stream);

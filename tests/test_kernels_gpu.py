@@ -802,6 +802,10 @@ def test_pool_upsample(K, dt):
     dx = torch.empty_like(x)
     K.avgpool2_bwd(dy, dx)
     close(dx, xt.grad.permute(0, 2, 3, 1), dt)
+    other = rnd(B, H, W, C, dt=dt, seed=5)          # the gradient another consumer of x already produced: added while dx is written
+    dx2 = torch.empty_like(x)
+    K.avgpool2_bwd(dy, dx2, add=other)
+    close(dx2, xt.grad.permute(0, 2, 3, 1) + other.float(), dt)
     xt.grad = None
     up = torch.empty(B, 2 * H, 2 * W, C, device="cuda", dtype=dt)
     K.upsample2_fwd(x, up)
