@@ -1947,6 +1947,17 @@ extern "C" int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int 
 
 // Edge of the tile crog_gemm takes for a weight-gradient GEMM (256: the atomic-only 256 x 256 tile, which cannot also form a_sum - the caller
 // then sums the bias gradient separately, crog_colsum).
+extern "C" int crog_wgrad_sw_slabs(int M, int convH, int convW, int convC, int K) {
+  static const bool wgrad_sw = [] { const char* e = getenv("CROG_WGRAD_SW"); return !e || atoi(e) != 0; }();
+  static const bool slabs = [] { const char* e = getenv("CROG_WGRAD_SW_SLABS"); return !e || atoi(e) != 0; }();
+  if (!wgrad_sw || !slabs || K < 65536 || convC <= 0) return 0;
+  crog_gemm_desc d{};
+  d.dtype = CROG_BF16; d.a_layout = CROG_A_MC; d.b_layout = CROG_B_NC_IM2COL;
+  d.M = M; d.N = 9 * convC; d.K = K; d.lda = M; d.ldb = convC; d.ldc = 9 * convC; d.batch = 1; d.batch_inner = 1; d.splitk = 256;
+  d.convH = convH; d.convW = convW; d.convC = convC; d.alpha = 1.f; d.out_mode = CROG_OUT_F32;
+  return crog_wgrad_sw_eligible(d) ? 256 : 0;
+}
+
 extern "C" int crog_gemm_wgrad_tile(int dtype, int a_layout, int b_layout, int M, int N, int K) {
   if (big_wgrad(dtype, a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N, K)) return 256;
   return small_wgrad(a_layout, b_layout, CROG_OUT_F32_ATOMIC, M, N) ? 64 : 128;

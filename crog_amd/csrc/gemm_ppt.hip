@@ -320,6 +320,51 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   }
 }
 
+// The same sum for MANY slabs of a SMALL output (the sliding-window weight gradients: 256 slabs of 64 x 576): one float4 per lane, the
+// W waves of a block each add a contiguous run of slabs, wave 0 adds the W partial sums in run order (a fixed order as well).  The
+// kernel above would put 256 dependent-latency loads on each of 9216 threads (36 blocks).
+template <int W>
+__global__ void __launch_bounds__(64 * W) splitk_reduce_par_kernel(const float* __restrict__ ws, int splits, int M, int N, int64_t ldws,
+                                                                   float* __restrict__ out, int64_t ldo, int accumulate) {
+  __shared__ f32x4 part[W][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nv = N >> 2;
+  const int64_t total = (int64_t)M * nv, slab = (int64_t)M * ldws;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + lane;
+  const bool valid = idx < total;
+  const int m = valid ? (int)(idx / nv) : 0, v = valid ? (int)(idx - (int64_t)m * nv) : 0;
+  const float* src = ws + (int64_t)m * ldws + 4 * v;
+  const int per = (splits + W - 1) / W, z0 = w * per, z1 = min(splits, z0 + per);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int z = z0;
+  for (; z + 4 <= z1; z += 4) {
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(src + (int64_t)z * slab), t1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 1) * slab);
+    const f32x4 t2 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 2) * slab), t3 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 3) * slab);
+#pragma unroll
+    for (int e = 0; e < 4; e++) s[e] = (((s[e] + t0[e]) + t1[e]) + t2[e]) + t3[e];
+  }
+  for (; z < z1; z++) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(src + (int64_t)z * slab);
+#pragma unroll
+    for (int e = 0; e < 4; e++) s[e] += t[e];
+  }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w != 0 || !valid) return;
+  for (int ww = 1; ww < W; ww++) {
+    const f32x4 t = part[ww][lane];
+#pragma unroll
+    for (int e = 0; e < 4; e++) s[e] += t[e];
+  }
+  float* dst = out + (int64_t)m * ldo + 4 * v;
+  if (accumulate) {
+    const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+    for (int e = 0; e < 4; e++) s[e] += o[e];
+  }
+  *reinterpret_cast<f32x4*>(dst) = s;
+}
+
 }  // namespace
 
 // Can the ping-pong weight-gradient kernel take this launch?  (the caller has checked dma_eligible)
@@ -399,6 +444,12 @@ extern "C" int crog_splitk_reduce(const float* ws, int splits, int M, int N, int
   CROG_CHECK_ARG(N % 4 == 0 && ldws % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)ws % 16) == 0 && ((uintptr_t)out % 16) == 0,
                  "crog_splitk_reduce: N, ldws, ldo must be multiples of 4 and the buffers 16-byte aligned");
   const int64_t total = (int64_t)M * (N / 4);
+  if (splits >= 32 && total <= 32768) {      // few outputs, many slabs: spread the slabs over the waves of a block too
+    hipLaunchKernelGGL(splitk_reduce_par_kernel<16>, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, ws, splits, M, N, ldws, out,
+                       ldo, accumulate);
+    CROG_LAUNCH_CHECK();
+    return CROG_OK;
+  }
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, splits, M, N, ldws, out, ldo, accumulate);
   CROG_LAUNCH_CHECK();

@@ -49,6 +49,7 @@ BN_ATOMIC_STATS = True           # BN statistics: atomic replicas in the GEMM ep
 RELU_BITMASK = True              # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
 LN_BWD_ATOMIC = False            # LayerNorm parameter gradients through atomics in ln_bwd itself: measured 0.5 % SLOWER (every block adds into the same 2 C floats)
 LN_REDUCE_SIDE = True            # LayerNorm parameter-gradient reduction on the weight-gradient stream
+SW_SLABS = True                  # sliding-window 3x3 weight gradients (stem, layer1) meet in slabs + one ordered reduction, not in atomic adds
 FAN_SLOTS = True                 # a map with a consumer outside its block (layer2 / layer3 -> neck, layer4 -> attention tokens): that gradient rides a GradSlot too
 LN_GRAD_SLOTS = True             # decoder: a residual's gradient is added inside the LayerNorm backward of the same tensor (GradSlot -> crog_ln_bwd dxadd)
 BN_BWD_ATOMIC = True             # backward partial sums through coalesced atomics (bf16)
@@ -177,6 +178,14 @@ def wgrad_gemm(dt, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, *, a_off=0, c_of
             finally:
                 K.GROUP_SINK = None
             RT.park_wgrad(sink[0], tiles * gsk, (dy, x, G), Kd)
+            return
+    if conv3 and not RT.deterministic and a_sum is None and dt == K.BF16 and a_off == 0 and lda == M and ldb == conv[2] and SW_SLABS:
+        # stem / layer1: the sliding-window kernel, one strip of image rows per workgroup, meeting in slabs rather than 9.4 M atomic adds
+        slabs = K.lib().crog_wgrad_sw_slabs(int(M), int(conv[0]), int(conv[1]), int(conv[2]), int(Kd))
+        if slabs:
+            ws = slab_scratch(slabs * M * N, dy.device)
+            K.gemm(dt, K.A_MC, b_layout, dy, x, ws, M, N, Kd, lda, ldb, N, conv=conv, splitk=slabs, out_mode=K.OUT_F32)
+            K.splitk_reduce(ws, slabs, M, N, N, G, c_off, ldc, accumulate=True)
             return
     sk = K.pick_splitk(M, N, Kd, _bk(dt), conv=conv3)
     if not RT.deterministic:

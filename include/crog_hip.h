@@ -191,13 +191,19 @@ int crog_gemm_stat_tiles(int M);
 int crog_gemm_splitk_hint(int dtype, int a_layout, int b_layout, int M, int N, int K);
 /* out[m][n] (+)= sum over z < splits of ws[z][m][n]: the second stage of a split-K weight gradient launched with CROG_OUT_F32
  * (slabs of M rows x ldws floats; out has row stride ldo; accumulate != 0 adds onto out, as gradient accumulation does).  The slabs are
- * summed in slice order by one thread per four columns: the same bits on every run, unlike the atomic form (CROG_DETERMINISTIC,
+ * summed in a fixed order (one thread per four columns; many slabs of a small output: a run of slabs per wave, runs added in order): the same bits on every run, unlike the atomic form (CROG_DETERMINISTIC,
  * crog_engine.py:72-84 run twice gives the same loss curve).  N, ldws, ldo multiples of 4; ws and out 16-byte aligned. */
 int crog_splitk_reduce(const float* ws, int splits, int M, int N, int64_t ldws, float* out, int64_t ldo, int accumulate,
                        crog_stream_t stream);
 /* Tile edge (64 / 128 / 256) crog_gemm takes for that weight gradient.  The 256 x 256 tile has an atomic-only epilogue: a launch that
  * also asks for a_sum stays on 128 x 128, so a caller that wants the wide tile sums the bias gradient with crog_colsum instead. */
 int crog_gemm_wgrad_tile(int dtype, int a_layout, int b_layout, int M, int N, int K);
+/* Small-channel 3x3 weight gradients (stem, layer1: clip.py:16-19,156-161 backward): the number of slabs the sliding-window kernel
+ * wants for dW[M][9 convC] over K pixels of convH x convW maps with dense [pixels][channels] bf16 operands, or 0 when crog_gemm would
+ * not take that kernel.  A caller that gets n > 0 launches crog_gemm with out_mode CROG_OUT_F32, splitk = n into an [n][M][9 convC]
+ * workspace and adds the slabs with crog_splitk_reduce: 37.7 MB of plain stores and one reduction launch instead of 9.4 M atomic adds
+ * (64 -> 64 over 346112 pixels: 55 us against 89). */
+int crog_wgrad_sw_slabs(int M, int convH, int convW, int convC, int K);
 /* 1 when crog_gemm can run this descriptor with the BatchNorm-backward statistics epilogue (bwd_z): bf16, one of the three
  * data-gradient layouts, plain epilogue, operands addressable by the LDS-DMA path (32-bit byte offsets).  For callers that must
  * decide before the producing layer skips its own first pass. */
