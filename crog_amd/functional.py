@@ -49,6 +49,7 @@ BN_ATOMIC_STATS = True           # BN statistics: atomic replicas in the GEMM ep
 RELU_BITMASK = True              # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
 LN_BWD_ATOMIC = False            # LayerNorm parameter gradients through atomics in ln_bwd itself: measured 0.5 % SLOWER (every block adds into the same 2 C floats)
 LN_REDUCE_SIDE = True            # LayerNorm parameter-gradient reduction on the weight-gradient stream
+CONV3_SLAB_MAX = 147456          # ... and so do the other 3x3 weight gradients with outputs up to 128 x 1152
 SW_SLABS = True                  # sliding-window 3x3 weight gradients (stem, layer1) meet in slabs + one ordered reduction, not in atomic adds
 FAN_SLOTS = True                 # a map with a consumer outside its block (layer2 / layer3 -> neck, layer4 -> attention tokens): that gradient rides a GradSlot too
 LN_GRAD_SLOTS = True             # decoder: a residual's gradient is added inside the LayerNorm backward of the same tensor (GradSlot -> crog_ln_bwd dxadd)
@@ -188,6 +189,15 @@ def wgrad_gemm(dt, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, *, a_off=0, c_of
             K.splitk_reduce(ws, slabs, M, N, N, G, c_off, ldc, accumulate=True)
             return
     sk = K.pick_splitk(M, N, Kd, _bk(dt), conv=conv3)
+    if (conv3 and not RT.deterministic and a_sum is None and dt == K.BF16 and SW_SLABS and M * N <= CONV3_SLAB_MAX and sk >= 16
+            and K.lib().crog_gemm_wgrad_tile(dt, K.A_MC, b_layout, M, N, Kd) == 128):
+        # small 3x3 outputs (layer2: 128 x 1152) split 56-113 ways: slabs at two workgroups per CU + the ordered reduction beat the atomic
+        # adds (86528 pixels 78-86 -> 55 us, 346112 pixels 229 -> 170; scripts/ab_wgrad_slab.py)
+        sk = min(sk, 512 // (((M + 127) // 128) * ((N + 127) // 128)))
+        ws = slab_scratch(sk * M * N, dy.device)
+        K.gemm(dt, K.A_MC, b_layout, dy, x, ws, M, N, Kd, lda, ldb, N, a_off=a_off, conv=conv, splitk=sk, out_mode=K.OUT_F32)
+        K.splitk_reduce(ws, sk, M, N, N, G, c_off, ldc, accumulate=True)
+        return
     if not RT.deterministic:
         K.gemm(dt, K.A_MC, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, a_off=a_off, c_off=c_off, conv=conv, splitk=sk,
                out_mode=K.OUT_F32_ATOMIC, a_sum=a_sum, a_sum_off=a_sum_off)
