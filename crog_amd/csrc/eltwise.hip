@@ -113,6 +113,134 @@ __global__ void __launch_bounds__(NT) upsample2_fwd_kernel(const T* __restrict__
     stg16(y + ((b * OH + oy) * OW + ox) * ldy + c, o);
   }
 }
+// Workgroup bid of an n-block launch runs on XCD bid % 8: hand each XCD a CONTIGUOUS band of the logical block order, so that blocks whose
+// windows overlap (neighbouring image rows) meet in one L2 instead of fetching the shared rows into two.
+__device__ inline unsigned xcd_band(unsigned bid, unsigned n) {
+  const unsigned x = bid & 7, per = n >> 3, rem = n & 7;
+  return x * per + min(x, rem) + (bid >> 3);
+}
+// The two kernels the launchers use.  The per-output forms above / below spend ~150 (forward) / ~500-1000 (backward: a 6 x 6 candidate loop
+// with branches around every load) instructions per 16-byte vector and ran at 2.8 TB/s on the projector's 346112 x 512 map; these are
+// organised around what neighbouring outputs share.
+// Forward, by PATCH: the 2 x 2 outputs (2 py + 1 .. 2 py + 2) x (2 px + 1 .. 2 px + 2) all interpolate the same four inputs (py, py + 1) x
+// (px, px + 1) with weights {0.75, 0.25}; patches py = -1 .. H - 1 with clamped input indices cover every output, borders included (an
+// index clamped onto its neighbour IS align_corners = False's border rule).  Four loads, four stores, one index computation.
+// grid B * (H + 1) * chunks, chunks = ceil((W + 1) * C / VEC / NT) column chunks per patch row, taken in xcd_band order
+template <typename T>
+__global__ void __launch_bounds__(NT) upsample2_fwd_patch_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int H, int W, int C,
+                                                                 int cshift, int chunks) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC, OH = 2 * H, OW = 2 * W;
+  const unsigned lb = xcd_band(blockIdx.x, gridDim.x), rowi = lb / (unsigned)chunks;
+  const int b = rowi / (H + 1), py = (int)(rowi - (unsigned)b * (H + 1)) - 1;
+  const int j = (int)(lb - rowi * (unsigned)chunks) * NT + threadIdx.x;
+  if (j >= (W + 1) * cvec) return;
+  const int pxi = cshift >= 0 ? j >> cshift : j / cvec;
+  const int c = (j - pxi * cvec) * VEC, px = pxi - 1;
+  const int y0 = max(py, 0), y1 = min(py + 1, H - 1), x0 = max(px, 0), x1 = min(px + 1, W - 1);
+  const T* xb = x + ((long)b * H * W) * ldx + c;
+  const Vec16<T> v00 = ldg16(xb + ((long)y0 * W + x0) * ldx), v01 = ldg16(xb + ((long)y0 * W + x1) * ldx);
+  const Vec16<T> v10 = ldg16(xb + ((long)y1 * W + x0) * ldx), v11 = ldg16(xb + ((long)y1 * W + x1) * ldx);
+  Vec16<T> o[2][2];
+#pragma unroll
+  for (int e = 0; e < VEC; e++) {
+    const float a = Elem<T>::to_f(v00.v[e]), bb = Elem<T>::to_f(v01.v[e]), cc = Elem<T>::to_f(v10.v[e]), d = Elem<T>::to_f(v11.v[e]);
+    const float t0 = 0.75f * a + 0.25f * bb, t1 = 0.25f * a + 0.75f * bb;       // row y0 at columns 2 px + 1, 2 px + 2
+    const float u0 = 0.75f * cc + 0.25f * d, u1 = 0.25f * cc + 0.75f * d;      // row y1
+    o[0][0].v[e] = Elem<T>::from_f(0.75f * t0 + 0.25f * u0);
+    o[0][1].v[e] = Elem<T>::from_f(0.75f * t1 + 0.25f * u1);
+    o[1][0].v[e] = Elem<T>::from_f(0.25f * t0 + 0.75f * u0);
+    o[1][1].v[e] = Elem<T>::from_f(0.25f * t1 + 0.75f * u1);
+  }
+  T* yb = y + ((long)b * OH * OW) * ldy + c;
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int oy = 2 * py + 1 + r;
+    if (oy < 0 || oy >= OH) continue;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int ox = 2 * px + 1 + q;
+      if (ox >= 0 && ox < OW) stg16(yb + ((long)oy * OW + ox) * ldy, o[r][q]);
+    }
+  }
+}
+// Backward (the transpose, gather form), a 2 x 2 block of inputs per thread: input i receives outputs 2 i - 1 .. 2 i + 2 with weights
+// {0.25, 0.75, 0.75, 0.25} (border: the missing output's weight goes to its neighbour - {-, 1, 0.75, 0.25} at i = 0, {0.25, 0.75, 1, -} at
+// i = n - 1), separably.  The block shares a 6 x 6 window of outputs: 36 unconditional loads (clamped addresses; an absent output enters as
+// zero bits, never as 0 x inf) for four inputs instead of 64, each row reduced horizontally as it arrives (two 8-float sums per row, not a
+// 6-column register tile).  grid B * ceil(H / 2) * chunks, chunks = ceil(ceil(W / 2) * C / VEC / NT), in xcd_band order: vertically
+// neighbouring blocks share two of their six rows
+template <typename T>
+__global__ void __launch_bounds__(NT) upsample2_bwd_quad_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx, int H, int W, int C,
+                                                                int cshift, int chunks) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cvec = C / VEC, OH = 2 * H, OW = 2 * W, pairs = (W + 1) >> 1, rpairs = (H + 1) >> 1;
+  const unsigned lb = xcd_band(blockIdx.x, gridDim.x), rowi = lb / (unsigned)chunks;
+  const int b = rowi / rpairs, iy0 = 2 * (int)(rowi - (unsigned)b * rpairs), iy1 = iy0 + 1;
+  const int j = (int)(lb - rowi * (unsigned)chunks) * NT + threadIdx.x;
+  if (j >= pairs * cvec) return;
+  const int pj = cshift >= 0 ? j >> cshift : j / cvec;
+  const int c = (j - pj * cvec) * VEC, ix0 = 2 * pj, ix1 = ix0 + 1;
+  float wa[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wb[4] = {0.25f, 0.75f, 0.75f, 0.25f};      // columns 2 ix0 - 1 + k: input ix0 takes k = 0..3, ix1 k = 2..5
+  if (ix0 == 0) wa[1] = 1.f;
+  if (ix0 == W - 1) wa[2] = 1.f;
+  if (ix1 == W - 1) wb[2] = 1.f;
+  float va[4] = {0.25f, 0.75f, 0.75f, 0.25f}, vb[4] = {0.25f, 0.75f, 0.75f, 0.25f};      // rows 2 iy0 - 1 + r: input iy0 takes r = 0..3, iy1 r = 2..5
+  if (iy0 == 0) va[1] = 1.f;
+  if (iy0 == H - 1) va[2] = 1.f;
+  if (iy1 == H - 1) vb[2] = 1.f;
+  const T* gb = dy + ((long)b * OH * OW) * lddy + c;
+  long coff[6];
+  bool cok[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int ox = 2 * ix0 - 1 + k;
+    cok[k] = ox >= 0 && ox < OW;
+    coff[k] = (long)min(max(ox, 0), OW - 1) * lddy;
+  }
+  float acc[2][2][VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; e++) acc[0][0][e] = acc[0][1][e] = acc[1][0][e] = acc[1][1][e] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const int oy = 2 * iy0 - 1 + r;
+    const bool rok = oy >= 0 && oy < OH;
+    const T* row = gb + ((long)min(max(oy, 0), OH - 1) * OW) * lddy;
+    Vec16<T> g[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) g[k] = ldg16(row + coff[k]);
+    float ha[VEC], hb[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) {
+      float f[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) f[k] = (rok && cok[k]) ? Elem<T>::to_f(g[k].v[e]) : 0.f;
+      ha[e] = wa[0] * f[0] + wa[1] * f[1] + wa[2] * f[2] + wa[3] * f[3];
+      hb[e] = wb[0] * f[2] + wb[1] * f[3] + wb[2] * f[4] + wb[3] * f[5];
+    }
+    if (r < 4) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) { acc[0][0][e] += va[r] * ha[e]; acc[0][1][e] += va[r] * hb[e]; }
+    }
+    if (r >= 2) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) { acc[1][0][e] += vb[r - 2] * ha[e]; acc[1][1][e] += vb[r - 2] * hb[e]; }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 2; rr++) {
+    if (iy0 + rr >= H) continue;
+    T* ob = dx + (((long)b * H + iy0 + rr) * W) * lddx + c;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (ix0 + q >= W) continue;
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < VEC; e++) o.v[e] = Elem<T>::from_f(acc[rr][q][e]);
+      stg16(ob + (long)(ix0 + q) * lddx, o);
+    }
+  }
+}
 // gather form of the transpose: input pixel i receives from outputs d in [2i-2, 2i+3]
 template <typename T>
 __global__ void __launch_bounds__(NT) upsample2_bwd_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx, int B, int H,
@@ -753,14 +881,32 @@ extern "C" int crog_avgpool2_bwd(int dtype, const void* dy, int64_t lddy, void* 
 extern "C" int crog_upsample2_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C, crog_stream_t s) {
   const int vec = VECOF(dtype);
   CROG_CHECK_ARG(C % vec == 0 && ldx % vec == 0 && ldy % vec == 0, "upsample2: C %% %d == 0 required", vec);
-  DISPATCH_T(dtype, LAUNCH((upsample2_fwd_kernel<T>), (long)B * 4 * H * W * (C / vec), s, (const T*)x, (long)ldx, (T*)y, (long)ldy, B, H, W, C));
+  static const bool per_output = [] { const char* e = getenv("CROG_UPSAMPLE_OLD"); return e && atoi(e) != 0; }();
+  const int cvec = C / vec, cshift = (cvec & (cvec - 1)) == 0 ? __builtin_ctz(cvec) : -1;
+  const int fchunks = cdiv((long)(W + 1) * cvec, NT);
+  if (per_output || (long)B * (H + 1) * fchunks >= (1L << 31)) {
+    DISPATCH_T(dtype, LAUNCH((upsample2_fwd_kernel<T>), (long)B * 4 * H * W * (C / vec), s, (const T*)x, (long)ldx, (T*)y, (long)ldy, B, H, W, C));
+  } else {
+    const dim3 grid((unsigned)((long)B * (H + 1) * fchunks));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2_fwd_patch_kernel<T>), grid, dim3(NT), 0, (hipStream_t)s, (const T*)x, (long)ldx, (T*)y, (long)ldy, H, W, C,
+                                         cshift, fchunks));
+  }
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
 extern "C" int crog_upsample2_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int H, int W, int C, crog_stream_t s) {
   const int vec = VECOF(dtype);
   CROG_CHECK_ARG(C % vec == 0 && lddy % vec == 0 && lddx % vec == 0, "upsample2_bwd: C %% %d == 0 required", vec);
-  DISPATCH_T(dtype, LAUNCH((upsample2_bwd_kernel<T>), (long)B * H * W * (C / vec), s, (const T*)dy, (long)lddy, (T*)dx, (long)lddx, B, H, W, C));
+  static const bool per_output = [] { const char* e = getenv("CROG_UPSAMPLE_OLD"); return e && atoi(e) != 0; }();
+  const int cvec = C / vec, cshift = (cvec & (cvec - 1)) == 0 ? __builtin_ctz(cvec) : -1;
+  const int bchunks = cdiv((long)((W + 1) / 2) * cvec, NT);
+  if (per_output || (long)B * ((H + 1) / 2) * bchunks >= (1L << 31)) {
+    DISPATCH_T(dtype, LAUNCH((upsample2_bwd_kernel<T>), (long)B * H * W * (C / vec), s, (const T*)dy, (long)lddy, (T*)dx, (long)lddx, B, H, W, C));
+  } else {
+    const dim3 grid((unsigned)((long)B * ((H + 1) / 2) * bchunks));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2_bwd_quad_kernel<T>), grid, dim3(NT), 0, (hipStream_t)s, (const T*)dy, (long)lddy, (T*)dx, (long)lddx, H, W, C,
+                                         cshift, bchunks));
+  }
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -818,6 +818,25 @@ def test_pool_upsample(K, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("shape", [(2, 13, 13, 64), (1, 5, 7, 24), (3, 1, 1, 8), (2, 1, 4, 16), (1, 4, 1, 40), (2, 26, 26, 512)])
+def test_upsample_borders_odd_sizes_and_ragged_channel_counts(K, dt, shape):
+    """The patch (forward) / pair (backward) kernels against F.interpolate on odd widths (a pair without its second member), single-row and
+    single-column maps (both border rules on one pixel) and channel counts whose vector count is not a power of two."""
+    B, H, W, C = shape
+    x = rnd(B, H, W, C, dt=dt, seed=11)
+    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    up = torch.empty(B, 2 * H, 2 * W, C, device="cuda", dtype=dt)
+    K.upsample2_fwd(x, up)
+    ref = F.interpolate(xt, scale_factor=2, mode="bilinear")
+    close(up, ref.permute(0, 2, 3, 1), dt)
+    dup = rnd(B, 2 * H, 2 * W, C, dt=dt, seed=12)
+    ref.backward(dup.float().permute(0, 3, 1, 2))
+    dx = torch.full_like(x, float("nan"))
+    K.upsample2_bwd(dup, dx)
+    close(dx, xt.grad.permute(0, 2, 3, 1), dt, scale=2)
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_embedding_gather(K, dt):
     B, L, C, V = 4, 20, 512, 1000
     tok, pos = rnd(V, C, dt=dt), rnd(77, C, dt=dt, seed=1)
