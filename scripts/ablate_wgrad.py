@@ -3,7 +3,14 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from crog_amd import kernels as K
-from bench_gemm import timeit
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n      # ms per call
 dt = torch.bfloat16
 def lin(M, Kd, N):
     # rotate over enough operand sets to overflow the 256 MB Infinity Cache: in the training step these operands come from HBM

@@ -4,9 +4,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from crog_amd import kernels as K
 from crog_amd.functional import stat_replicas
-from bench_gemm import timeit
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n      # ms per call
 dt = torch.bfloat16
-for B, HW, Cin, Cout, ks in [(32, 104, 64, 64, 3), (32, 104, 64, 256, 1), (32, 52, 128, 128, 3), (32, 52, 128, 512, 1), (32, 26, 256, 256, 3), (32, 26, 256, 1024, 1), (32, 208, 32, 32, 3), (32, 208, 32, 64, 3)]:
+for B, HW, Cin, Cout, ks in [(32, 104, 64, 64, 3), (32, 104, 64, 256, 1), (32, 52, 128, 128, 3), (32, 52, 128, 512, 1), (32, 26, 256, 256, 3), (32, 26, 256, 1024, 1), (32, 208, 32, 32, 3), (32, 208, 32, 64, 3), (32, 13, 512, 512, 3), (32, 13, 512, 2048, 1), (32, 26, 256, 512, 1), (32, 52, 128, 256, 1)]:
     M = B * HW * HW
     # layer L+1: conv Cin -> Cout; its dgrad maps dz [M, Cout] -> dx [M, Cin] = dy of layer L (C = Cin)
     nset = max(1, int(600e6 / (M * (Cin * 2 + Cout) * 2)) + 1)
@@ -21,8 +28,8 @@ for B, HW, Cin, Cout, ks in [(32, 104, 64, 64, 3), (32, 104, 64, 256, 1), (32, 5
     def dgrad(fused):
         i = it[0] = (it[0] + 1) % nset
         kw = dict(col_stats=sums, stat_replicas=R, bwd_z=zs[i], bwd_ss=ss) if fused else {}
-        if ks == 1:
-            K.gemm(1, K.A_KC, K.B_NC, dzs[i], w, dxs[i], M, Cin, Cout, Cout, Cin, Cin, **kw)
+        if ks == 1:      # (functional.LIN_DGRAD_T: the [Cin][Cout] copy of the weight, both operands K-contiguous)
+            K.gemm(1, K.A_KC, K.B_KC, dzs[i], wt, dxs[i], M, Cin, Cout, Cout, Cout, Cin, **kw)
         else:
             K.gemm(1, K.A_IM2COL, K.B_KC, dzs[i], wt, dxs[i], M, Cin, 9 * Cout, Cout, 9 * Cout, Cin, conv=(HW, HW, Cout), **kw)
     rpb = K.bn_rows_per_block(M)

@@ -4,7 +4,14 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from crog_amd import kernels as K
-from bench_gemm import timeit
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n      # ms per call
 dt = torch.bfloat16
 tot = [0.0, 0.0]
 for M, cin, C, n in [(21632, 2048, 512, 3), (640, 512, 2048, 12), (640, 512, 1536, 12), (21632, 512, 512, 12), (21632, 1024, 256, 5), (346112, 256, 64, 2),
