@@ -22,7 +22,7 @@ CSRC = os.path.join(ROOT, "csrc")
 HEADER = os.path.join(REPO, "include", "crog_hip.h")
 LIB_PATH = os.environ.get("CROG_LIB") or os.path.join(ROOT, "libcrog_hip.so")
 BUILD_DIR = os.path.join(ROOT, "csrc", "build")
-SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_ppt.hip", "conv_sw.hip", "wgrad_sw.hip", "norm.hip", "eltwise.hip", "head.hip", "conv_aux.hip", "attn.hip", "ssg.hip", "preprocess.hip", "replay.hip", "comm.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_ppt.hip", "conv_sw.hip", "wgrad_sw.hip", "gemm_skinny.hip", "norm.hip", "eltwise.hip", "head.hip", "conv_aux.hip", "attn.hip", "ssg.hip", "preprocess.hip", "replay.hip", "comm.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
 
 

@@ -27,6 +27,8 @@ int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t
 bool crog_gemm_pp_full_epilogue_ok(const crog_gemm_desc& d);
 bool crog_conv_sw_eligible(const crog_gemm_desc& d);      // conv_sw.hip: sliding-window 3x3 convolution for 32 / 64 channels
 int crog_conv_sw_launch(const crog_gemm_desc& d, hipStream_t s);
+bool crog_gemm_skinny_eligible(const crog_gemm_desc& d);  // gemm_skinny.hip: [M][32] x [32][32] streamed without an LDS stage (the stem's first convolution)
+int crog_gemm_skinny_launch(const crog_gemm_desc& d, hipStream_t s);
 bool crog_wgrad_sw_eligible(const crog_gemm_desc& d);     // wgrad_sw.hip: sliding-window 3x3 weight gradient for 32 / 64 channels
 int crog_wgrad_sw_launch(const crog_gemm_desc& d, hipStream_t s);
 // the ping-pong weight-gradient kernel (gemm_ppt.hip)
@@ -1838,6 +1840,11 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
     crog_set_error("crog_gemm: bwd_z is implemented for bf16 data gradients (A_KC x B_NC / B_KC, A_IM2COL x B_KC / B_NC_DGRAD) with a plain epilogue "
                    "and operands the LDS-DMA path can address (crog_gemm_supports_bwd_z)");
     return CROG_ERR_ARG;
+  }
+  if constexpr (sizeof(T) == 2) {
+    // the stem's first convolution on its im2col rows (N = K = 32, 1.38 M rows): streamed, no LDS stage.  CROG_SKINNY=0: the tiled kernel
+    static const bool skinny = [] { const char* e = getenv("CROG_SKINNY"); return !e || atoi(e) != 0; }();
+    if (skinny && d.M >= 16384 && crog_gemm_skinny_eligible(d)) return crog_gemm_skinny_launch(d, s);
   }
   if constexpr (sizeof(T) == 2) {
     // small-channel 3x3 convolutions (stem, layer1: N = 32 / 64, K = 288 / 576) with at least 64 K pixels: the sliding-window kernel

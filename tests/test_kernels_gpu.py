@@ -254,6 +254,32 @@ def test_sliding_window_small_channel_convolution(K, monkeypatch, case):
         assert _rel_l2(st[2097152], st[1048576]) < 1e-3
 
 
+@pytest.mark.parametrize("M,with_stats", [(70001, True), (16384, False), (16384 + 4 * 32 * 4 + 31, True), (1384448, True)])
+def test_streamed_skinny_gemm_of_the_stem(K, M, with_stats):
+    """gemm_skinny32_kernel (csrc/gemm_skinny.hip: [M][32] x [32][32]^T, weights in registers, A streamed into the MFMA without an LDS stage)
+    against float64 and against the tiled kernel on the same operands (M below the dispatch threshold is not possible for the same M, so
+    the tiled kernel runs on a row slice): ragged last tile, a last batch of tiles that is partly past the end, BatchNorm statistics in
+    replica mode, nothing written outside the output."""
+    dt = torch.bfloat16
+    a = rnd(M, 32, dt=dt)
+    a[:, 27:] = 0          # (the stem's 27 taps padded to 32)
+    w = (rnd(32, 32, dt=dt, seed=1) * 27 ** -0.5).to(dt)
+    y = torch.full((M + 1, 32), 7.0, device="cuda", dtype=dt)
+    stats = torch.zeros(5, 32, 2, device="cuda") if with_stats else None
+    K.gemm(1, K.A_KC, K.B_KC, a, w, y, M, 32, 32, 32, 32, 32, col_stats=stats, stat_replicas=5 if with_stats else 0)
+    assert (y[M] == 7).all(), "wrote past the last row"
+    ref = a.double() @ w.double().t()
+    close(y[:M], ref.float(), dt, scale=1.0)
+    n = 8192                # below the dispatch threshold: the tiled LDS-DMA kernel
+    y2 = torch.empty(n, 32, device="cuda", dtype=dt)
+    K.gemm(1, K.A_KC, K.B_KC, a[:n], w, y2, n, 32, 32, 32, 32, 32)
+    assert _rel_l2(y[:n].double(), ref[:n]) <= 1.05 * _rel_l2(y2.double(), ref[:n]) + 1e-6
+    if with_stats:
+        st = stats.sum(0).double()
+        assert _rel_l2(st[:, 1], (ref ** 2).sum(0)) < 2e-3
+        assert float((st[:, 0] - ref.sum(0)).abs().max()) < 2e-3 * math.sqrt(M) + 1e-3
+
+
 @pytest.mark.parametrize("case", [(2, 20, 32, 32, 32), (3, 5, 40, 64, 64), (1, 7, 208, 32, 64), (2, 9, 24, 64, 32), (2, 13, 104, 64, 64), (1, 1, 16, 32, 32)])
 def test_sliding_window_small_channel_weight_gradient(K, monkeypatch, case):
     """wgrad_sw_kernel (csrc/wgrad_sw.hip: one wave per tap, operands through LDS row rings, transposed fragment reads) against float64
