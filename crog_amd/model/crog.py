@@ -22,6 +22,7 @@ from .layers import FPN, MultiTaskProjector, Projector, TransformerDecoder
 # time) per step, but the step is GPU-bound on one MI355X (measured 39.8 vs 39.7 ms/step, 43.2 vs 43.4 under DDP), so the eager
 # path stays the default until the host becomes the limiter.
 TEXT_GRAPH = os.environ.get("CROG_TEXT_GRAPH", "0") == "1"
+DGW_LATE = os.environ.get("CROG_DGW_LATE", "1") != "0"      # the data-gradient weight copies are refreshed beside the neck, not beside the stem
 
 RN50_ARCH = dict(embed_dim=1024, image_resolution=224, vision_layers=(3, 4, 6, 3), vision_width=64, vision_patch_size=None,
                  context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12)
@@ -179,14 +180,18 @@ class CROG(nn.Module):
             # node on its forward stream, which overlaps the two backward passes the same way.
             main = torch.cuda.current_stream()
             store.weights(dtype)               # refresh the bf16 shadow on the main stream BEFORE the streams fork
-            t_side = None
+            t_side = refresh_t = None
             if self.training and torch.is_grad_enabled():
                 # ... and the data-gradient copies of the weights (one launch over all of them, ~0.3 ms of HBM traffic).  Backward reads
                 # them on both streams, the forward not at all: the launch goes to the weight-gradient stream, idle during the forward,
                 # and the main stream joins it at the end of this forward - ahead of every backward node on any stream
+                # (issued AFTER the image tower below: the side stream then waits for the tower, and the refresh - pure HBM traffic - runs
+                # beside the neck's MFMA-bound 3x3 convolutions instead of beside the HBM-bound stem, whose kernels it slowed threefold)
                 t_side = RT.wgrad_stream()
                 store.ensure_t(dtype)
-                RT._issue_wgrad(lambda: store.weights_t(dtype), ())
+                refresh_t = (lambda: RT._issue_wgrad(lambda: store.weights_t(dtype), ())) if DGW_LATE else None
+                if refresh_t is None:
+                    RT._issue_wgrad(lambda: store.weights_t(dtype), ())
             # (deterministic mode: ONE stream.  With the text tower's backward running beside the image tower's, its gradients differed
             # in the last bit in about one run of four at B = 8 - the same unexplained dependence on a concurrent kernel that keeps the
             # weight gradients on the main stream in that mode: runtime.set_deterministic, LAB_NOTES section 9)
@@ -225,6 +230,8 @@ class CROG(nn.Module):
             else:
                 vis = self.backbone.image_features(img, dtype)
                 wfeat, state = self.backbone.text_features(word, dtype)
+            if refresh_t is not None:
+                refresh_t()
             if not isinstance(vis, tuple):
                 # layers.py:373 unpacks three pyramid levels; a ViT tower returns one token tensor, so the reference fails here
                 # too: ViT parity is encoder-level (encode_image / encode_text).
