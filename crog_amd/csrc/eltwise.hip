@@ -1066,6 +1066,19 @@ extern "C" int crog_cast_pad2d(int dtype_dst, const float* src, int64_t lds_, in
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
+// optimizer.zero_grad() on the flat gradient buffer (crog_engine.py:77) as a launch of this library: it can go to any stream the caller names
+// (torch's fill runs on torch's current stream), e.g. the weight-gradient stream while the forward pass keeps the main one busy
+__global__ void __launch_bounds__(NT) zero_f32_kernel(float* __restrict__ p, long n4, long n) {
+  GRID_STRIDE(i, n4) { reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[4 * n4 + threadIdx.x] = 0.f;
+}
+extern "C" int crog_zero_f32(float* p, int64_t n, crog_stream_t s) {
+  CROG_CHECK_ARG(p && n >= 0 && ((uintptr_t)p % 16) == 0, "zero_f32: 16-byte aligned buffer");
+  if (n == 0) return CROG_OK;
+  LAUNCH(zero_f32_kernel, n / 4 + 1, s, p, (long)(n / 4), (long)n);
+  CROG_LAUNCH_CHECK();
+  return CROG_OK;
+}
 extern "C" int crog_cast_f32_to_bf16(const float* src, void* dst, int64_t n, crog_stream_t s) {
   CROG_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "cast: pointers must be 16-byte aligned");
   LAUNCH(cast_f32_to_bf16_kernel, n / 8 + 1, s, src, (bf16*)dst, (long)n);

@@ -37,9 +37,17 @@ class AverageMeter:
 ADAM_OVERLAP = os.environ.get("CROG_ADAM_OVERLAP", "1") != "0"
 
 
+EARLY_ZERO = os.environ.get("CROG_EARLY_ZERO", "1") != "0"
+
+
 def train_step(model, optimizer, scaler, batch, args=None, autocast_dtype=torch.bfloat16):
     """One optimisation step (crog_engine.py:60-90). `batch` holds device tensors img, word, mask, qua, sin, cos, wid with the
     masks already [B,1,H,W].  Returns a 3-element device tensor (loss, 100*IoU, 100*Prec@50), rank-averaged."""
+    store = getattr(optimizer, "_store", None)
+    if store is not None and EARLY_ZERO:
+        # this step zeroes the gradients between forward and backward (below, crog_engine.py:77): a model that forks a side stream in its
+        # forward may do the memset there, beside its MFMA-bound layers (588 MB of writes: 74 us of the main chain otherwise)
+        store.request_zero()
     with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
         pred, target, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
     optimizer.zero_grad()

@@ -157,6 +157,9 @@ class GraphedTrainStep:
         import torch.distributed as dist
         model, opt = self.model, self.optimizer
         adt = self.autocast_dtype
+        from .engine import EARLY_ZERO
+        if EARLY_ZERO and getattr(opt, "_store", None) is not None:
+            opt._store.request_zero()      # (engine.train_step: the gradient memset may run on the forward's side stream)
         with torch.autocast("cuda", dtype=adt or torch.bfloat16, enabled=adt is not None):
             pred, target, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
         opt.zero_grad()

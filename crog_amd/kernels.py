@@ -579,6 +579,10 @@ def add_pad2d(src, lds, dst, ldd, cols, rows, dst_off=0):
     check(lib().crog_add_pad2d(ptr(src), lds, ptr(dst) + 4 * dst_off, ldd, cols, rows, stream()), "add_pad2d")
 
 
+def zero_f32(t):
+    check(lib().crog_zero_f32(ptr(t), t.numel(), stream()), "zero_f32")
+
+
 def cast_f32_to_bf16(src, dst, n):
     check(lib().crog_cast_f32_to_bf16(ptr(src), ptr(dst), n, stream()), "cast_f32_to_bf16")
 

@@ -189,7 +189,8 @@ class CROG(nn.Module):
                 # beside the neck's MFMA-bound 3x3 convolutions instead of beside the HBM-bound stem, whose kernels it slowed threefold)
                 t_side = RT.wgrad_stream()
                 store.ensure_t(dtype)
-                refresh_t = (lambda: RT._issue_wgrad(lambda: store.weights_t(dtype), ())) if DGW_LATE else None
+                # (not with the text tower as hipGraphs: their capture reads the copies, and a refresh captured INTO the text graph would re-run every step)
+                refresh_t = (lambda: RT._issue_wgrad(lambda: store.weights_t(dtype), ())) if (DGW_LATE and not TEXT_GRAPH) else None
                 if refresh_t is None:
                     RT._issue_wgrad(lambda: store.weights_t(dtype), ())
             # (deterministic mode: ONE stream.  With the text tower's backward running beside the image tower's, its gradients differed
@@ -232,6 +233,8 @@ class CROG(nn.Module):
                 wfeat, state = self.backbone.text_features(word, dtype)
             if refresh_t is not None:
                 refresh_t()
+            if t_side is not None:
+                store.zero_early()      # (engine.train_step: the gradient memset, also beside the neck)
             if not isinstance(vis, tuple):
                 # layers.py:373 unpacks three pyramid levels; a ViT tower returns one token tensor, so the reference fails here
                 # too: ViT parity is encoder-level (encode_image / encode_text).

@@ -443,11 +443,27 @@ class ParamStore:
                 return True
         return False
 
+    def request_zero(self):
+        """engine.train_step, before the forward: the caller WILL call zero_grad() between this forward and its backward, so the forward may
+        do the memset early on a side stream it joins before it returns (`zero_early`).  Forgotten by the next zero_grad() either way."""
+        self._zero_req = True
+
+    def zero_early(self):
+        """CROG.forward, on the weight-gradient stream (idle during the forward): the memset zero_grad() would do on the main stream."""
+        if not getattr(self, "_zero_req", False):
+            return
+        self._zero_req = False
+        if _LEGACY_SYNC or not getattr(self, "explicit", False) or getattr(self, "g_clean", False):
+            return
+        RT._issue_wgrad(lambda: K.zero_f32(self.G), ())      # (behind everything enqueued on the caller's stream so far)
+        self.g_clean = True
+
     def zero_grad(self):
         """One memset of the flat gradient buffer, skipped while the buffer is known to be all zeros.  "Known" needs the owner's
         promise (`explicit`, set by the crog_amd models) that every gradient it produces is written by a kernel path ending in
         WRef.done(), which marks the buffer dirty; a generic module whose gradients arrive through autograd's AccumulateGrad gets
         the memset every time.  Also restores dropped .grad links."""
+        self._zero_req = False
         if _LEGACY_SYNC or not (getattr(self, "explicit", False) and getattr(self, "g_clean", False)):
             self.G.zero_()
             self.g_clean = getattr(self, "explicit", False) and not _LEGACY_SYNC

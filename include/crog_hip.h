@@ -457,6 +457,9 @@ int crog_cast_pad2d(int dtype_dst, const float* src, int64_t lds, int cols_src, 
 int crog_add_pad2d(const float* src, int64_t lds, float* dst, int64_t ldd, int cols, int64_t rows,
                    crog_stream_t stream);
 int crog_cast_f32_to_bf16(const float* src, void* dst, int64_t n, crog_stream_t stream);
+/* p[0 .. n) = 0 (fp32, 16-byte aligned): optimizer.zero_grad() on the flat gradient buffer (crog_engine.py:77) on the stream the caller
+ * names - the weight-gradient stream during the forward pass, where the 588 MB of writes cost the main chain nothing */
+int crog_zero_f32(float* p, int64_t n, crog_stream_t stream);
 int crog_cast_to_f32(int dtype, const void* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C,
                      crog_stream_t stream);
 /* CoordConv coordinate channels: layers.py:30-39 */
