@@ -156,13 +156,15 @@ class ModifiedResNet(Bound):
         self.fan = None
 
     def check_supported(self, source: str = ""):
-        """clip.py:165-185 is width-generic (RN50x4 = 80, RN50x16 = 96, RN50x64 = 128).  The 3x3 implicit-GEMM kernels need
-        Cin % 32 == 0; widths 80 / 96 give 40- / 48- / 80-channel maps that would need zero-padded channel strides through the stem and
-        layer1 (the mechanism CoordConv's 514 -> 544 uses) - not built and not fixture-tested.  Called by CROG.prepare(), i.e. when
-        the model is bound to the GPU, so an unsupported archive is refused by name before the first forward."""
-        if self.width != 64:
+        """clip.py:165-185 is width-generic (RN50x4 = 80, RN50x16 = 96, RN50x64 = 128).  Widths that are multiples of 64 run (RN50 / RN101
+        = 64; RN50x64 = 128 is pinned by `tests/golden/rn_wide`, a reference fixture at depth (1, 1, 1, 1)).  The 3x3 implicit-GEMM kernels
+        need Cin % 32 == 0; widths 80 / 96 give 40- / 48- / 80-channel maps that would need zero-padded channel strides through the stem and
+        layer1 (the mechanism CoordConv's 514 -> 544 uses) - not built.  Called by CROG.prepare(), i.e. when the model is bound to the GPU,
+        so an unsupported archive is refused by name before the first forward."""
+        if self.width % 64 != 0:
             raise NotImplementedError(f"crog_amd: CLIP ModifiedResNet of width {self.width}{' (' + source + ')' if source else ''} is not supported: the HIP "
-                                      "path implements width 64 (RN50, RN101 archives); RN50x4 / x16 / x64 need padded channel strides")
+                                      "path implements widths that are multiples of 64 (RN50, RN101, RN50x64 archives); RN50x4 / x16 need padded "
+                                      "channel strides")
 
     def _make_layer(self, planes, blocks, stride=1):
         mods = [Bottleneck(self._inplanes, planes, stride)]

@@ -447,6 +447,33 @@ def ssg_detect_fixture(name, cfg, seed):
     print(name, "detections", int(ids.numel()), "of", int(keep.sum()), "score-filtered anchors", flush=True)
 
 
+
+def rn_wide_fixture(ref_clip):
+    """A width-128 ModifiedResNet (the RN50x64 family, clip.py:165-185,517-532: stem 64 / 64 / 128, stages 128 .. 1024 planes, 64 heads) at
+    depth (1, 1, 1, 1) and 128 x 128 input, B = 2, training mode, name-seeded weights (not committed).  Pinned: the three returned maps,
+    every parameter-gradient norm, the head of every gradient, the BatchNorm running statistics after the forward."""
+    torch.manual_seed(0)
+    m = ref_clip.ModifiedResNet((1, 1, 1, 1), 512, 64, input_resolution=128, width=128).train()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    from crog_amd.testing import vit_seeded_state
+    m.load_state_dict(vit_seeded_state(shapes, seed=33))
+    img = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(3301))
+    x2, x3, x4 = m(img)
+    loss = sum((o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum() for o in (x2, x3, x4))
+    loss.backward()
+    fx = {"x2": x2.detach(), "x3": x3.detach(), "x4": x4.detach()}
+    names = [n for n, _ in m.named_parameters()]
+    fx["grad_norms"] = torch.tensor([float(p.grad.norm()) for _, p in m.named_parameters()])
+    for n, p in m.named_parameters():
+        fx["grad::" + n] = p.grad.flatten()[:64].clone()
+    for k, v in m.state_dict().items():
+        if "running_" in k:
+            fx["buf::" + k] = v.clone()
+    np.savez_compressed(os.path.join(GOLD, "rn_wide.npz"), **{k: v.detach().numpy() for k, v in fx.items()})
+    json.dump(dict(param_names=names, shapes={k: list(v) for k, v in shapes.items()}, seed=33, img_seed=3301, B=2),
+              open(os.path.join(GOLD, "rn_wide.json"), "w"))
+    print("rn_wide fixture: x2", tuple(x2.shape), "x3", tuple(x3.shape), "x4", tuple(x4.shape), "absmax", float(x4.abs().max()), flush=True)
+
 def shapes_only(ref_clip):
     """Parameter names/shapes of the real CLIP RN50 and ViT-B/16 towers + CROG heads (names are the checkpoint contract)."""
     vit = ref_clip.CLIP(512, 224, 12, 768, 16, 77, 20, 49408, 512, 8, 12)
@@ -456,7 +483,7 @@ def shapes_only(ref_clip):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_clip, ref_crog, ref_layers = import_reference()
-    which = sys.argv[1:] or ["tiny", "ops", "vit", "ssg", "shapes", "full", "damped", "damped4", "vitfull", "ssgfull", "ssgloss", "ssgdet", "clipload"]
+    which = sys.argv[1:] or ["tiny", "ops", "vit", "ssg", "shapes", "full", "damped", "damped4", "vitfull", "ssgfull", "ssgloss", "ssgdet", "clipload", "rnwide"]
     if "tiny" in which:
         run_case("tiny_crog", tiny_cfg(), B=4, seed=3, ref_model=ref_model, ref_clip=ref_clip, store_intermediates=True)
         run_case("tiny_crog_nomask", tiny_cfg(use_grasp_masks=False), B=4, seed=4, ref_model=ref_model, ref_clip=ref_clip,
@@ -477,6 +504,8 @@ def main():
         ssg_detect_fixture("ssg_detect", ssg_cfg(nms_score_thre=0.05, nms_iou_thre=0.5, top_k=200, max_detections=100), seed=14)
     if "vitfull" in which:
         vit_full_fixture(ref_clip)
+    if "rnwide" in which:
+        rn_wide_fixture(ref_clip)
     if "ssgfull" in which:
         from crog_amd.testing import ssg_cfg
         ssg_full_fixture("ssg_r50_rgbd", ssg_cfg(), B=2, seed=8)

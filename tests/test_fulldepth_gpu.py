@@ -307,6 +307,63 @@ def test_config4_vit_b16_full_depth_matches_reference():
     assert cos > 0.999, cos
 
 
+def test_wide_modified_resnet_matches_reference():
+    """clip.py:147-223 with width 128 (the RN50x64 family: 64 / 64 / 128-channel stem, 128 ... 1024 planes, 64 attention-pool heads) against
+    the reference's own forward / backward (`tests/golden/rn_wide`: depth (1, 1, 1, 1), 128 x 128, B = 2, training mode, name-seeded
+    weights).  fp32: the three returned maps within 1e-3, every parameter-gradient norm within 1e-2 relative, gradient heads within 5e-2 of
+    the gradient's scale, BatchNorm running statistics."""
+    from crog_amd.model.blocks import bind_all
+    from crog_amd.model.clip import ModifiedResNet
+    from crog_amd.runtime import ParamStore
+    fx, meta = load_case("rn_wide")
+    net = ModifiedResNet((1, 1, 1, 1), 512, 64, input_resolution=128, width=128)
+    net.check_supported("RN50x64-shaped")
+    assert [n for n, _ in net.named_parameters()] == meta["param_names"]
+    net.load_state_dict(vit_seeded_state({k: tuple(v) for k, v in meta["shapes"].items()}, seed=meta["seed"]))
+    store = ParamStore(net, torch.device("cuda"))
+    store.explicit = True
+    bind_all(net, store)
+    net.cuda().train()
+    store.zero_grad()
+    img = torch.randn(meta["B"], 3, 128, 128, generator=torch.Generator().manual_seed(meta["img_seed"])).cuda()
+    outs = net(img, torch.float32)
+    loss = 0
+    for name, o in zip(("x2", "x3", "x4"), outs):
+        ref = fx[name].permute(0, 2, 3, 1)
+        assert tuple(o.shape) == tuple(ref.shape)
+        e = err(o, ref)
+        print(f"width-128 tower {name}: max err {e:.2e} (|ref| max {float(ref.abs().max()):.2f})")
+        assert e < 1e-3
+        on = o.permute(0, 3, 1, 2)                       # the reference's loss weights run over its NCHW element order
+        loss = loss + (on * torch.linspace(-1, 1, on.numel(), device="cuda").view(on.shape)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    worst_n = worst_h = 0.0
+    for i, (n, p) in enumerate(net.named_parameters()):
+        gref = float(fx["grad_norms"][i])
+        g = p.grad
+        if g.dim() == 4 and g.shape[-1] == 3:            # 3 x 3 weights: logical [Cout, Cin, 3, 3] (state_dict order) for the head comparison
+            g = g.contiguous()
+        gn = float(g.norm())
+        if "k_proj.bias" in n:      # (mathematically zero: a key bias shifts every score of a row alike; both sides hold rounding noise)
+            assert gn < 1e-4 and gref < 1e-4
+            continue
+        worst_n = max(worst_n, abs(gn - gref) / (gref + 1e-9))
+        assert abs(gn - gref) <= 1e-2 * gref + 1e-6, (n, gn, gref)
+        head = fx["grad::" + n]
+        scale = max(float(head.abs().max()), gref / max(1.0, p.numel() ** 0.5))
+        eh = err(g.flatten()[:64], head) / (scale + 1e-12)
+        worst_h = max(worst_h, eh)
+        # (single elements: a ReLU input within fp32 rounding of zero flips its gate on one side only - 8 x 8 and 4 x 4 maps at B = 2 give a
+        # channel 32-128 samples, so one flip is a few per cent of that channel's gradient; the norms above do not move)
+        assert eh < 5e-2, (n, eh)
+    print(f"width-128 tower gradients: worst norm error {worst_n:.2e}, worst head error / scale {worst_h:.2e} over {len(meta['param_names'])} tensors")
+    sd = net.state_dict()
+    for k, v in fx.items():
+        if k.startswith("buf::"):
+            assert err(sd[k[5:]], v) < 1e-4 * max(1.0, float(v.abs().max())), k
+
+
 def test_config5_ssg_r50_full_depth_matches_reference():
     """BASELINE config 5 at the yaml's own size (ssg_r50.yaml: ResNet-50 [3, 4, 6, 3], 544 x 544, with_depth): raw predictions
     against fixed-stride samples and sums of the reference's, surrogate-loss gradients, BatchNorm statistics."""
