@@ -1454,7 +1454,7 @@ def test_production_conv3x3_fwd_dgrad_wgrad(K, dt, B, HW, Cin, Cout):
     """3x3 convolutions at bench resolution (layer1 conv2, layer2 conv2, the projector's 512 -> 256 at 104 x 104 on a quarter of the
     batch, the neck's 512 -> 512 at 26 x 26): forward with statistics, data gradient on the transposed weight copy, weight gradient."""
     if dt == torch.float32 and Cin * Cout >= 512 * 256:
-        pytest.skip("fp32 checker convolution of this size takes minutes; the bf16 case covers the shape")
+        B = max(1, B // 8)      # the fp32 parity kernels take minutes at the full batch: same maps, an eighth of the images
     H = W = HW
     M = B * H * W
     x = rnd(B, H, W, Cin, dt=dt)
