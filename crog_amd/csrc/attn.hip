@@ -67,6 +67,8 @@ __device__ inline bf16x8 pack8(const f32x16& v, int t) {
 }
 
 __device__ inline float xor32(float v) { return __shfl_xor(v, 32, 64); }
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+__device__ inline float ex2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32 (arguments here are <= 0 or -inf)
 
 // =====================================================================================================================
 // forward: O = softmax(scale Q K^T) [dropout] V, lse = row log-sum-exp.  grid (ceil(Lq / 128), B * heads)
@@ -87,6 +89,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
 #pragma unroll
   for (int e = 0; e < 16; e++) o[0][e] = o[1][e] = 0.f;
   float m = -INFINITY, l = 0.f;
+  const float c2 = a.scale * LOG2E;      // scores in log2 units: exp(x) = v_exp_f32(x log2 e) - the factor folded into the scale saves a multiply per score
 
   const int lrow = tid >> 3, lch = tid & 7;
   const bf16* kg = a.K + (long)b * a.Lk * a.ldk + hd * DH + lch * 8;
@@ -121,17 +124,17 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
     float mt = -INFINITY;
     if (kb + TT <= a.Lk) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) { s[r] *= a.scale; mt = fmaxf(mt, s[r]); }
+      for (int r = 0; r < 16; r++) { s[r] *= c2; mt = fmaxf(mt, s[r]); }
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; r++) { s[r] = (kb + acc_row(r, h) < a.Lk) ? s[r] * a.scale : -INFINITY; mt = fmaxf(mt, s[r]); }
+      for (int r = 0; r < 16; r++) { s[r] = (kb + acc_row(r, h) < a.Lk) ? s[r] * c2 : -INFINITY; mt = fmaxf(mt, s[r]); }
     }
     mt = fmaxf(mt, xor32(mt));
     const float mn = fmaxf(m, mt);
-    const float alpha = __expf(m - mn);
+    const float alpha = ex2(m - mn);
     float ps = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; r++) { s[r] = __expf(s[r] - mn); ps += s[r]; }
+    for (int r = 0; r < 16; r++) { s[r] = ex2(s[r] - mn); ps += s[r]; }
     l = l * alpha + ps;
     m = mn;
 #pragma unroll
@@ -170,7 +173,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
         for (int j = 0; j < 4; j++) w[j] = (bf16)(o[mt2][4 * g + j] * inv);
         *reinterpret_cast<bf16x4*>(op + mt2 * 32 + 8 * g) = w;
       }
-    if (h == 0) a.lse[(long)bh * a.Lq + q] = m + __logf(l);
+    if (h == 0) a.lse[(long)bh * a.Lq + q] = m * LN2 + __logf(l);      // (natural-log units for the backward kernels and the caller)
   }
 }
 
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
     }
     Dq += xor32(Dq);
   }
-  const float Lr = a.lse[(long)bh * a.Lq + qc];
+  const float Lr = a.lse[(long)bh * a.Lq + qc] * LOG2E, c2 = a.scale * LOG2E;      // (log2 units, as in the forward)
   if (h == 0 && q < a.Lq) a.D[(long)bh * a.Lq + q] = Dq;
   f32x16 dq[2];
 #pragma unroll
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
     const int kb = kt * TT;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const float p = (kb + acc_row(r, h) < a.Lk) ? __expf(s[r] * a.scale - Lr) : 0.f;
+      const float p = (kb + acc_row(r, h) < a.Lk) ? ex2(s[r] * c2 - Lr) : 0.f;
       s[r] = p;
     }
     if (a.p_drop > 0.f) {
@@ -321,6 +324,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
   const int nqt = (a.Lq + TT - 1) / TT;
   const uint32_t thr = attn_thr16(a.p_drop);
   const float sc = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const float c2 = a.scale * LOG2E;
 
   bf16x8 rq, ro;
   float rs = 0.f;
@@ -332,7 +336,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
     *reinterpret_cast<bf16x8*>(&sQt[0][tr_off(lrow, lch)]) = rq;
     *reinterpret_cast<bf16x8*>(&sOc[0][kc_off(lrow, lch)]) = ro;
     *reinterpret_cast<bf16x8*>(&sOt[0][tr_off(lrow, lch)]) = ro;
-    if (tid < TT) sL[0][tid] = lg[min(tid, a.Lq - 1)];
+    if (tid < TT) sL[0][tid] = lg[min(tid, a.Lq - 1)] * LOG2E;      // (log2 units, as in the forward)
     else if (tid < 2 * TT) sD[0][tid - TT] = dg[min(tid - TT, a.Lq - 1)];
   }
   __syncthreads();
@@ -342,7 +346,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
       const int qq = min((qt + 1) * TT + lrow, a.Lq - 1);
       rq = *reinterpret_cast<const bf16x8*>(qg + (long)qq * a.ldq);
       ro = *reinterpret_cast<const bf16x8*>(og + (long)qq * a.lddo);
-      if (tid < TT) rs = lg[min((qt + 1) * TT + tid, a.Lq - 1)];
+      if (tid < TT) rs = lg[min((qt + 1) * TT + tid, a.Lq - 1)] * LOG2E;
       else if (tid < 2 * TT) rs = dg[min((qt + 1) * TT + tid - TT, a.Lq - 1)];
     }
     f32x16 s, dp;
@@ -376,7 +380,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int qr = acc_row(r, h);
-      const float p = (qb + qr < a.Lq) ? __expf(s[r] * a.scale - sL[buf][qr]) : 0.f;
+      const float p = (qb + qr < a.Lq) ? ex2(s[r] * c2 - sL[buf][qr]) : 0.f;
       const bool keep = (keepbits >> r) & 1u;
       const float g = keep ? dp[r] * sc : 0.f;
       pd[r] = keep ? p * sc : 0.f;
