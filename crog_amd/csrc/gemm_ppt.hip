@@ -444,8 +444,7 @@ extern "C" int crog_splitk_reduce(const float* ws, int splits, int M, int N, int
   CROG_CHECK_ARG(N % 4 == 0 && ldws % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)ws % 16) == 0 && ((uintptr_t)out % 16) == 0,
                  "crog_splitk_reduce: N, ldws, ldo must be multiples of 4 and the buffers 16-byte aligned");
   const int64_t total = (int64_t)M * (N / 4);
-  static const int par_min = [] { const char* e = getenv("CROG_REDUCE_PAR_MIN"); return e ? atoi(e) : 16; }();
-  if (splits >= par_min && total <= 65536) {      // few outputs, many slabs: spread the slabs over the waves of a block too
+  if (splits >= 16 && total <= 65536) {      // few outputs, many slabs: spread the slabs over the waves of a block too
     if (splits >= 64)
       hipLaunchKernelGGL(splitk_reduce_par_kernel<16>, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, ws, splits, M, N, ldws,
                          out, ldo, accumulate);
