@@ -22,6 +22,7 @@ from .layers import FPN, MultiTaskProjector, Projector, TransformerDecoder
 # time) per step, but the step is GPU-bound on one MI355X (measured 39.8 vs 39.7 ms/step, 43.2 vs 43.4 under DDP), so the eager
 # path stays the default until the host becomes the limiter.
 TEXT_GRAPH = os.environ.get("CROG_TEXT_GRAPH", "0") == "1"
+TEXT_AFTER = os.environ.get("CROG_TEXT_AFTER", "0") == "1"
 DGW_LATE = os.environ.get("CROG_DGW_LATE", "1") != "0"      # the data-gradient weight copies are refreshed beside the neck, not beside the stem
 
 RN50_ARCH = dict(embed_dim=1024, image_resolution=224, vision_layers=(3, 4, 6, 3), vision_width=64, vision_patch_size=None,
@@ -221,7 +222,9 @@ class CROG(nn.Module):
                         r = next(steps, None)
                         if r is not None:
                             txt.extend(r)
-                vis = self.backbone.image_features(img, dtype, issue_text)
+                # (CROG_TEXT_AFTER=1, A/B: the whole text tower issued AFTER the image tower - its autograd nodes then run, host-side, before
+                # the image tower's backward, so its Adam chunks ripen early in the weight-gradient / aux stream's queue)
+                vis = self.backbone.image_features(img, dtype, None if TEXT_AFTER else issue_text)
                 while not txt:          # whatever the image tower's hooks did not get to
                     issue_text()
                 wfeat, state = txt

@@ -43,11 +43,10 @@ class Runtime:
         self._slots = []       # GradSlots filled during the backward pass in flight (functional.GradSlot): all must be empty when it ends
         self._wgrad_stream = None
         self.text_stream = None
-        # fourth stream (CROG_AUX_STREAM=1, single rank only; A/B): the text tower's weight gradients and the Adam chunks stepped during
-        # backward.  On the weight-gradient stream both WAIT for the text chain (~200 latency-bound launches that finish with the
-        # image tower's layer1) and hold up the image tower's last weight gradients queued behind them; measured, moving them off
-        # changes nothing (30.00 vs 30.00 ms): the step is bound by the chip's throughput there, not by that queue's order - the
-        # weight gradients that start earlier slow the main chain's layer1 kernels by what they gain (LAB_NOTES section 9)
+        # fourth stream (single-process jobs by default, CROG_AUX_STREAM): the text tower's weight gradients and the Adam chunks stepped during
+        # backward.  On the weight-gradient stream both WAIT for the text chain (~200 latency-bound launches) and hold up the image tower's
+        # weight gradients queued behind them.  Alone the stream changes nothing (30.00 vs 30.00 ms; 28.34 / 28.42 vs 28.34); together with a
+        # high-priority text stream it is worth 0.1-0.6 ms (ensure_streams)
         self.aux_stream = None
         self._streams_ready = False
         self._join_armed = False
@@ -86,12 +85,20 @@ class Runtime:
                 # gradients need half of the chip-time of a step and cannot finish on a slice of it).
                 self._wgrad_stream = [torch.cuda.Stream()]
                 order += self._wgrad_stream
-            self.text_stream = torch.cuda.Stream(device=dev)
-            order.append(self.text_stream)
             import torch.distributed as dist
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-            if self.overlap_wgrad and not multi and os.environ.get("CROG_AUX_STREAM", "0") == "1":
-                # (a communicator's internal stream takes the fourth hardware queue under DDP: see the note above)
+            # Fourth stream (the text tower's weight gradients and the Adam chunks stepped during backward) + a HIGH-priority text stream:
+            # together 28.33 / 28.56 / 29.05 / 28.89 -> 28.27 / 28.29 / 28.85 / 28.27 ms and 29.08 / 28.60 / 28.62 -> 28.47 / 28.50 / 28.51
+            # (two boxes, alternating passes): the text tower's ~200 latency-bound backward launches no longer wait for free CUs behind the
+            # image tower's kernels, and nothing queues behind them.  Each alone: the aux stream neutral (28.34 / 28.42 vs 28.34), the
+            # priority a loss (28.76 / 28.97).  Default in a single-process job; with torch.distributed initialised (a communicator's internal
+            # stream takes the fourth hardware queue under DDP: see the note above) both stay off unless the environment asks for them.
+            solo = not (dist.is_available() and dist.is_initialized())
+            want_aux = self.overlap_wgrad and not multi and os.environ.get("CROG_AUX_STREAM", "1" if solo else "0") == "1"
+            text_prio = os.environ.get("CROG_TEXT_PRIO", "1" if want_aux else "0") == "1"
+            self.text_stream = torch.cuda.Stream(device=dev, priority=-1 if text_prio else 0)
+            order.append(self.text_stream)
+            if want_aux:
                 self.aux_stream = torch.cuda.Stream(device=dev)
                 order.append(self.aux_stream)
             touch = torch.zeros(8, device=dev)
