@@ -29,6 +29,7 @@ struct AttnArgs {
   float *lse, *D;
   long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int Lq, Lk, heads, ldp;
+  int causal;              // key k contributes to query q only if k <= q (CLIP text transformer, clip.py:446-452 build_attention_mask)
   float scale, p_drop;
   uint64_t seed;
   const uint64_t* epoch;   // crog_set_seed_epoch: per-step seed offset in device memory (null = none)
@@ -122,12 +123,16 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
     for (int ks = 0; ks < 4; ks++) s = mfma(kc_frag(sK[buf], ln, 2 * ks + h), qf[ks], s);
     const int kb = kt * TT;
     float mt = -INFINITY;
-    if (kb + TT <= a.Lk) {
+    if (kb + TT <= a.Lk && !a.causal) {
 #pragma unroll
       for (int r = 0; r < 16; r++) { s[r] *= c2; mt = fmaxf(mt, s[r]); }
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; r++) { s[r] = (kb + acc_row(r, h) < a.Lk) ? s[r] * c2 : -INFINITY; mt = fmaxf(mt, s[r]); }
+      for (int r = 0; r < 16; r++) {
+        const int kk = kb + acc_row(r, h);
+        s[r] = (kk < a.Lk && (!a.causal || kk <= q)) ? s[r] * c2 : -INFINITY;
+        mt = fmaxf(mt, s[r]);
+      }
     }
     mt = fmaxf(mt, xor32(mt));
     const float mn = fmaxf(m, mt);
@@ -249,7 +254,8 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
     const int kb = kt * TT;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const float p = (kb + acc_row(r, h) < a.Lk) ? ex2(s[r] * c2 - Lr) : 0.f;
+      const int kk = kb + acc_row(r, h);
+      const float p = (kk < a.Lk && (!a.causal || kk <= q)) ? ex2(s[r] * c2 - Lr) : 0.f;
       s[r] = p;
     }
     if (a.p_drop > 0.f) {
@@ -380,7 +386,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int qr = acc_row(r, h);
-      const float p = (qb + qr < a.Lq) ? ex2(s[r] * c2 - sL[buf][qr]) : 0.f;
+      const float p = (qb + qr < a.Lq && (!a.causal || key <= qb + qr)) ? ex2(s[r] * c2 - sL[buf][qr]) : 0.f;
       const bool keep = (keepbits >> r) & 1u;
       const float g = keep ? dp[r] * sc : 0.f;
       pd[r] = keep ? p * sc : 0.f;
@@ -422,9 +428,9 @@ bool aligned8(long ld, const void* p) { return ld % 8 == 0 && ((uintptr_t)p % 16
 
 }  // namespace
 
-extern "C" int crog_flash_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
-                                   float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed, int ldp,
-                                   crog_stream_t stream) {
+extern "C" int crog_flash_attn_fwd_masked(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
+                                          float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed,
+                                          int ldp, int causal, crog_stream_t stream) {
   CROG_CHECK_ARG(head_dim == DH, "flash_attn: head_dim must be %d (got %d)", DH, head_dim);
   CROG_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && ldp >= Lk && p_drop >= 0.f && p_drop < 1.f, "flash_attn_fwd: bad sizes");
   CROG_CHECK_ARG(aligned8(ldq, Q) && aligned8(ldk, K) && aligned8(ldv, V) && ldo % 4 == 0 && ((uintptr_t)O % 8) == 0 && lse,
@@ -434,15 +440,22 @@ extern "C" int crog_flash_attn_fwd(const void* Q, int64_t ldq, const void* K, in
   a.Q = (const bf16*)Q; a.K = (const bf16*)K; a.V = (const bf16*)V; a.Out = (bf16*)O; a.lse = lse;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.Lq = Lq; a.Lk = Lk; a.heads = heads; a.ldp = ldp; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.epoch = crog_seed_epoch();
+  a.causal = causal != 0;
+  CROG_CHECK_ARG(!causal || Lq == Lk, "flash_attn: the causal mask is defined for self-attention (Lq == Lk)");
   hipLaunchKernelGGL(flash_fwd_kernel, dim3(cdiv(Lq, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
+extern "C" int crog_flash_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
+                                   float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed, int ldp,
+                                   crog_stream_t stream) {
+  return crog_flash_attn_fwd_masked(Q, ldq, K, ldk, V, ldv, O, ldo, lse, B, heads, Lq, Lk, head_dim, scale, p_drop, seed, ldp, 0, stream);
+}
 
-extern "C" int crog_flash_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo,
-                                   const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq, void* dK, int64_t lddk,
-                                   void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop,
-                                   uint64_t seed, int ldp, crog_stream_t stream) {
+extern "C" int crog_flash_attn_bwd_masked(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo,
+                                          const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq, void* dK, int64_t lddk,
+                                          void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop,
+                                          uint64_t seed, int ldp, int causal, crog_stream_t stream) {
   CROG_CHECK_ARG(head_dim == DH, "flash_attn: head_dim must be %d (got %d)", DH, head_dim);
   CROG_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && ldp >= Lk && p_drop >= 0.f && p_drop < 1.f, "flash_attn_bwd: bad sizes");
   CROG_CHECK_ARG(aligned8(ldq, Q) && aligned8(ldk, K) && aligned8(ldv, V) && aligned8(ldo, O) && aligned8(lddo, dO) && lse && D && dQ && dK && dV,
@@ -453,9 +466,18 @@ extern "C" int crog_flash_attn_bwd(const void* Q, int64_t ldq, const void* K, in
   a.dQ = (bf16*)dQ; a.dK = (bf16*)dK; a.dV = (bf16*)dV; a.lse = const_cast<float*>(lse); a.D = D;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.Lq = Lq; a.Lk = Lk; a.heads = heads; a.ldp = ldp; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.epoch = crog_seed_epoch();
+  a.causal = causal != 0;
+  CROG_CHECK_ARG(!causal || Lq == Lk, "flash_attn: the causal mask is defined for self-attention (Lq == Lk)");
   hipLaunchKernelGGL(flash_bwd_dq_kernel, dim3(cdiv(Lq, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
   hipLaunchKernelGGL(flash_bwd_dkdv_kernel, dim3(cdiv(Lk, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
+}
+extern "C" int crog_flash_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo,
+                                   const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq, void* dK, int64_t lddk,
+                                   void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop,
+                                   uint64_t seed, int ldp, crog_stream_t stream) {
+  return crog_flash_attn_bwd_masked(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, lse, D, dQ, lddq, dK, lddk, dV, lddv, B, heads, Lq, Lk, head_dim, scale,
+                                    p_drop, seed, ldp, 0, stream);
 }

@@ -45,6 +45,7 @@ def _pad(n: int, m: int) -> int:
 FUSED_REDUCE_MAX_PARTS = 256     # BatchNorm slab reductions up to this many partial rows are folded into the finalize launch
 FLASH_ATTN = True                # fused attention kernels (csrc/attn.hip) where they apply; tests compare with the unfused path
 FLASH_MIN_KEYS = 64
+FLASH_CAUSAL = os.environ.get("CROG_FLASH_CAUSAL", "1") != "0"      # causal self-attention (the CLIP text tower) through the fused kernels too
 BN_ATOMIC_STATS = True           # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize (bf16)
 RELU_BITMASK = True              # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
 LN_BWD_ATOMIC = False            # LayerNorm parameter gradients through atomics in ln_bwd itself: measured 0.5 % SLOWER (every block adds into the same 2 C floats)
@@ -932,11 +933,15 @@ class MhaFn(Function):
         Lkp = _pad(Lk, 8)
         scale = dh ** -0.5
         # ---- fused attention: no score matrix in HBM (unmasked bf16, head_dim 64, long key rows) ----
-        if FLASH_ATTN and dtype == torch.bfloat16 and dh == 64 and not causal and kpm is None and Lk >= FLASH_MIN_KEYS:
+        # (... and - FLASH_CAUSAL - the text tower's causal 20-token blocks: one launch instead of three, two instead of five backward, on a
+        # stream whose ~150 backward launches are latency-bound)
+        if FLASH_ATTN and dtype == torch.bfloat16 and dh == 64 and kpm is None and (
+                (not causal and Lk >= FLASH_MIN_KEYS) or (causal and FLASH_CAUSAL and Lq == Lk)):
             seed = RT.next_seed() if p_drop > 0 else 0
             O = torch.empty(B * Lq, E, device=dev, dtype=dtype)
             lse = torch.empty(B * heads * Lq, device=dev, dtype=torch.float32)
-            K.flash_attn_fwd(qb, kb, vb, (O, 0, E), lse, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp)
+            K.flash_attn_fwd(qb, kb, vb, (O, 0, E), lse, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp, causal=causal)
+            ctx.causal = bool(causal)
             out = torch.empty(B * Lq, wo.rows, device=dev, dtype=dtype)
             lin_fwd(O, wo, out, bias=bo, res=res)
             ctx.cfg = (merged, qb, kb, vb, wo, bo, B, heads, Lq, Lk, Lkp, E, dh, scale, p_drop, seed, res is not None, same_qk, same_kv)
@@ -995,7 +1000,8 @@ class MhaFn(Function):
         if ctx.flash:
             lse = S
             D = torch.empty_like(lse)
-            K.flash_attn_bwd(qb, kb, vb, (O, 0, E), (dO, 0, E), lse, D, dqb, dkb, dvb, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp)
+            K.flash_attn_bwd(qb, kb, vb, (O, 0, E), (dO, 0, E), lse, D, dqb, dkb, dvb, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp,
+                             causal=ctx.causal)
             return MhaFn._proj_backward(ctx, merged, qb, dqb, dkb, xq, xk, xv, dout, has_res, same_qk, same_kv, dev, dtype)
         Pm = Pd if Pd is not None else S
         bh = B * heads

@@ -389,6 +389,15 @@ int crog_flash_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, 
                         int64_t ldo, const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq,
                         void* dK, int64_t lddk, void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim,
                         float scale, float p_drop, uint64_t seed, int ldp, crog_stream_t stream);
+/* The same with the causal mask of the CLIP text transformer (clip.py:446-452 build_attention_mask; causal != 0: key k reaches query q only
+ * if k <= q, self-attention only): the text tower's 20-token attention as one launch forward and two backward instead of three and five. */
+int crog_flash_attn_fwd_masked(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O,
+                               int64_t ldo, float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale,
+                               float p_drop, uint64_t seed, int ldp, int causal, crog_stream_t stream);
+int crog_flash_attn_bwd_masked(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O,
+                               int64_t ldo, const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq,
+                               void* dK, int64_t lddk, void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim,
+                               float scale, float p_drop, uint64_t seed, int ldp, int causal, crog_stream_t stream);
 /* QuickGELU x*sigmoid(1.702x): clip.py:234-236 */
 int crog_quickgelu_fwd(int dtype, const void* u, int64_t ldu, void* out, int64_t ldo, int64_t M, int C,
                        crog_stream_t stream);

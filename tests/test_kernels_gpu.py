@@ -1168,10 +1168,11 @@ def test_gemm_tanh_epilogue_and_act_bwd(K, dt):
 
 
 # ---- fused attention -------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,H,Lq,Lk", [(2, 3, 197, 197), (1, 2, 300, 676), (2, 1, 64, 70), (1, 4, 33, 129)])
-def test_flash_attention_matches_torch(K, B, H, Lq, Lk):
-    """crog_flash_attn_fwd/bwd (bf16, head_dim 64, no mask, no dropout) against fp32 softmax attention on the same bf16 inputs;
-    Q/K/V are column slices of one packed buffer, as the MHA projections produce them."""
+@pytest.mark.parametrize("B,H,Lq,Lk,causal", [(2, 3, 197, 197, False), (1, 2, 300, 676, False), (2, 1, 64, 70, False), (1, 4, 33, 129, False),
+                                               (4, 8, 20, 20, True), (2, 2, 77, 77, True), (1, 3, 160, 160, True)])
+def test_flash_attention_matches_torch(K, B, H, Lq, Lk, causal):
+    """crog_flash_attn_fwd/bwd (bf16, head_dim 64, no dropout; unmasked, or with the text tower's causal mask) against fp32 softmax attention
+    on the same bf16 inputs; Q/K/V are column slices of one packed buffer, as the MHA projections produce them."""
     dh, E = 64, 64 * H
     dt = torch.bfloat16
     qkv = (rnd(B * max(Lq, Lk), 3 * E, dt=dt) * 0.7).contiguous()
@@ -1193,12 +1194,14 @@ def test_flash_attention_matches_torch(K, B, H, Lq, Lk):
         Vf = kvbuf[:, E:].float().view(B, Lk, H, dh).permute(0, 2, 1, 3)
     Qf, Kf, Vf = Qf.contiguous().requires_grad_(True), Kf.contiguous().requires_grad_(True), Vf.contiguous().requires_grad_(True)
     S = scale * Qf @ Kf.transpose(-1, -2)
+    if causal:
+        S = S + torch.full((Lq, Lk), float("-inf"), device="cuda").triu(1)
     ref = (torch.softmax(S, -1) @ Vf)
     ref.backward(dO.float().view(B, Lq, H, dh).permute(0, 2, 1, 3))
     O = torch.empty(B * Lq, E, device="cuda", dtype=dt)
     lse = torch.empty(B * H * Lq, device="cuda")
     Lkp = (Lk + 7) // 8 * 8
-    K.flash_attn_fwd(qs, ks, vs, (O, 0, E), lse, B, H, Lq, Lk, dh, scale, 0.0, 0, Lkp)
+    K.flash_attn_fwd(qs, ks, vs, (O, 0, E), lse, B, H, Lq, Lk, dh, scale, 0.0, 0, Lkp, causal=causal)
     close(O.view(B, Lq, H, dh).permute(0, 2, 1, 3), ref, dt)
     close(lse.view(B, H, Lq), torch.logsumexp(S, -1), torch.float32, scale=50)
     D = torch.empty_like(lse)
@@ -1208,7 +1211,7 @@ def test_flash_attention_matches_torch(K, B, H, Lq, Lk):
     else:
         dqb, dkvb = torch.zeros_like(qs[0]), torch.zeros_like(ks[0])
         dq, dk, dv = (dqb, 0, E), (dkvb, 0, 2 * E), (dkvb, E, 2 * E)
-    K.flash_attn_bwd(qs, ks, vs, (O, 0, E), (dO, 0, E), lse, D, dq, dk, dv, B, H, Lq, Lk, dh, scale, 0.0, 0, Lkp)
+    K.flash_attn_bwd(qs, ks, vs, (O, 0, E), (dO, 0, E), lse, D, dq, dk, dv, B, H, Lq, Lk, dh, scale, 0.0, 0, Lkp, causal=causal)
     def sl(t3, L):
         t, c, ld = t3
         return t[:B * L, c:c + E].float().view(B, L, H, dh).permute(0, 2, 1, 3)
