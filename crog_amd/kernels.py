@@ -34,14 +34,17 @@ CAPTURE_TAGS = None
 GROUP_SINK = None
 DEBUG_FLAGS = 0  # ablation / A-B bits of crog_gemm_desc.debug (set by tests and scripts/ablate_gemm.py); 0 in production
 GEMM_SYMBOL = {
-    (A_KC, B_KC): "gemm_pp_kernel<A_KC, 4|3, 5> (>= 150 tiles of 256 x 256) / gemm_dma16_kernel<A_KC, 128x128> / gemm_dma_kernel<T, A_KC, B_KC>  "
+    (A_KC, B_KC): "gemm_pp_kernel<A_KC, 4|3|2, 5> (>= 150 tiles of 256 x 256) / gemm_dma16_kernel<A_KC, 128x128> / gemm_dma_kernel<T, A_KC, B_KC> / "
+                  "gemm_skinny32_kernel (the stem's im2col GEMM)  "
                   "(1x1 conv / linear forward and data gradient on the transposed weight copy, Q.K^T)",
     (A_IM2COL, B_KC): "gemm_pp_kernel<A_IM2COL, 4|3, 4> (ping-pong 256 / 192 x 256 x 64: launches of >= 150 tiles) / gemm_dma16_kernel<A_IM2COL, 128x128> / "
-                      "gemm_dma_kernel<T, A_IM2COL, B_KC> (smaller launches)  (3x3 conv forward and data gradient, implicit GEMM)",
+                      "gemm_dma_kernel<T, A_IM2COL, B_KC> (smaller launches) / conv_sw_kernel<CI, CO, G> (32 / 64 channels on >= 64 K pixels: stem, layer1)  "
+                      "(3x3 conv forward and data gradient)",
     (A_KC, B_NC): "gemm_dma_kernel<T, A_KC, B_NC>  (1x1 / linear dgrad, P.V)",
     (A_IM2COL, B_NC_DGRAD): "gemm_dma_kernel<T, A_IM2COL, B_NC_DGRAD>  (3x3 conv dgrad)",
     (A_MC, B_NC): "gemm_ppt_kernel<B_NC> (outputs >= 1 M, both sides multiples of 256) / gemm_dma_kernel<T, A_MC, B_NC>  (1x1 / linear wgrad)",
-    (A_MC, B_NC_IM2COL): "gemm_ppt_kernel<B_NC_IM2COL> (outputs >= 512 K, both sides multiples of 256) / gemm_dma_kernel<T, A_MC, B_NC_IM2COL>  (3x3 conv wgrad)",
+    (A_MC, B_NC_IM2COL): "gemm_ppt_kernel<B_NC_IM2COL> (outputs >= 512 K, both sides multiples of 256) / gemm_dma_kernel<T, A_MC, B_NC_IM2COL> / "
+                         "wgrad_sw_kernel<CI, CO> (32 / 64 channels: stem, layer1)  (3x3 conv wgrad)",
     (A_MC, B_KC): "gemm_dma_kernel<T, A_MC, B_KC>",
 }
 
