@@ -67,7 +67,6 @@ __device__ inline bf16x8 pack8(const f32x16& v, int t) {
   return o;
 }
 
-__device__ inline float xor32(float v) { return __shfl_xor(v, 32, 64); }
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 __device__ inline float ex2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32 (arguments here are <= 0 or -inf)
 
@@ -134,7 +133,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
         mt = fmaxf(mt, s[r]);
       }
     }
-    mt = fmaxf(mt, xor32(mt));
+    mt = xor32_max(mt);
     const float mn = fmaxf(m, mt);
     const float alpha = ex2(m - mn);
     float ps = 0.f;
@@ -165,7 +164,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
     }
     __syncthreads();
   }
-  l += xor32(l);
+  l = xor32_sum(l);
   if (q < a.Lq) {
     const float inv = 1.f / l;
     bf16* op = a.Out + ((long)b * a.Lq + q) * a.ldo + hd * DH + 4 * h;
@@ -210,7 +209,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
 #pragma unroll
       for (int j = 0; j < 8; j++) Dq += (float)dof[ks][j] * (float)of[j];
     }
-    Dq += xor32(Dq);
+    Dq = xor32_sum(Dq);
   }
   const float Lr = a.lse[(long)bh * a.Lq + qc] * LOG2E, c2 = a.scale * LOG2E;      // (log2 units, as in the forward)
   if (h == 0 && q < a.Lq) a.D[(long)bh * a.Lq + q] = Dq;

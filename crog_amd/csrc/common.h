@@ -84,6 +84,97 @@ __device__ inline Vec16<T> zero16() {
 }
 
 // ---- wave / block reductions ---------------------------------------------------------------
+// Cross-lane exchange through DPP modifiers and v_readlane only: no instruction of these reductions goes to the LDS unit.
+// (__shfl_xor lowers to ds_bpermute_b32, which does.  scripts/det_probe.py, round 5: with the text tower's kernels running beside the
+// image tower's LDS-DMA GEMMs, a LayerNorm backward row - identical operands, bit-identical on a quiet chip - came back with both of
+// its row sums slightly off in 1-2 of 160 rows, in 2-15 % of the passes.)
+template <int CTRL>
+__device__ inline float dpp_get(float v) {      // the DPP-selected lane's v (every selected lane exists for the controls used here)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;   // quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror
+__device__ inline float readlane_f(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+// sum / max over each row of 16 lanes, in every lane of the row (after the two quad steps a quad is uniform, so the mirrors pair each
+// lane with the other quad / the other half: the xor-butterfly's tree)
+__device__ inline float row16_sum(float v) {
+  v += dpp_get<DPP_XOR1>(v);
+  v += dpp_get<DPP_XOR2>(v);
+  v += dpp_get<DPP_HALF_MIRROR>(v);
+  v += dpp_get<DPP_MIRROR>(v);
+  return v;
+}
+__device__ inline float row16_max(float v) {
+  v = fmaxf(v, dpp_get<DPP_XOR1>(v));
+  v = fmaxf(v, dpp_get<DPP_XOR2>(v));
+  v = fmaxf(v, dpp_get<DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_get<DPP_MIRROR>(v));
+  return v;
+}
+// Exchange across rows of 16 lanes: gfx950's v_permlane16_swap_b32 / v_permlane32_swap_b32 (VALU).  With both operands = v the first
+// comes back as [r0 r0 r2 r2] / [lo lo] and the second as [r1 r1 r3 r3] / [hi hi] (rows of 16 / halves of 32 lanes), so their sum (max)
+// is v + v(lane ^ 16) resp. v + v(lane ^ 32) in EVERY lane.  Inline asm with its own wait states: the builtin's two results were seen
+// folded into one register when added (hipcc 7.2: `v_permlane16_swap v1, v2; v_add v1, v1, v1`).
+__device__ inline void permlane16_swap(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ inline void permlane32_swap(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+#if defined(CROG_BPERMUTE_SUMS) || defined(CROG_BPERM_XOR)
+__device__ inline float xor16_sum(float v) { return v + __shfl_xor(v, 16, 64); }
+__device__ inline float xor32_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+__device__ inline float xor32_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ inline float xor16_max(float v) { return fmaxf(v, __shfl_xor(v, 16, 64)); }
+#else
+__device__ inline float xor16_sum(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  permlane16_swap(a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ inline float xor32_sum(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  permlane32_swap(a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ inline float xor16_max(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  permlane16_swap(a, b);
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+__device__ inline float xor32_max(float v) {
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  permlane32_swap(a, b);
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+#endif
+// sum / max over aligned groups of LPR lanes (2 .. 64), in every lane of the group
+template <int LPR>
+__device__ inline float group_sum(float v) {
+#if defined(CROG_BPERMUTE_SUMS) || defined(CROG_BPERM_GROUP)
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+#else
+  if constexpr (LPR >= 2) v += dpp_get<DPP_XOR1>(v);
+  if constexpr (LPR >= 4) v += dpp_get<DPP_XOR2>(v);
+  if constexpr (LPR >= 8) v += dpp_get<DPP_HALF_MIRROR>(v);
+  if constexpr (LPR >= 16) v += dpp_get<DPP_MIRROR>(v);
+  if constexpr (LPR >= 32) v = xor16_sum(v);
+  if constexpr (LPR >= 64) v = xor32_sum(v);
+#endif
+  return v;
+}
+template <int LPR>
+__device__ inline float group_max(float v) {
+#if defined(CROG_BPERMUTE_SUMS) || defined(CROG_BPERM_GROUP)
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+#else
+  if constexpr (LPR >= 2) v = fmaxf(v, dpp_get<DPP_XOR1>(v));
+  if constexpr (LPR >= 4) v = fmaxf(v, dpp_get<DPP_XOR2>(v));
+  if constexpr (LPR >= 8) v = fmaxf(v, dpp_get<DPP_HALF_MIRROR>(v));
+  if constexpr (LPR >= 16) v = fmaxf(v, dpp_get<DPP_MIRROR>(v));
+  if constexpr (LPR >= 32) v = xor16_max(v);
+  if constexpr (LPR >= 64) v = xor32_max(v);
+#endif
+  return v;
+}
+#if defined(CROG_BPERMUTE_SUMS) || defined(CROG_BPERM_WAVE)      // (A/B builds of scripts/build_variant.py: the ds_bpermute butterfly of rounds 1-4)
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -94,6 +185,17 @@ __device__ inline float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+#else
+// all 64 lanes (the wave must be converged): the four row totals meet through scalar registers, the result is wave-uniform
+__device__ inline float wave_sum(float v) {
+  v = row16_sum(v);
+  return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+__device__ inline float wave_max(float v) {
+  v = row16_max(v);
+  return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+#endif
 
 // Counter-based RNG for dropout: the keep-mask is reproducible between forward and backward (and between the fused and unfused
 // attention paths) because every kernel recomputes it from the same (seed, element index).

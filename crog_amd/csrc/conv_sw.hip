@@ -180,8 +180,8 @@ __global__ void __launch_bounds__(SW_NT, 1) conv_sw_kernel(const crog_gemm_desc 
     for (int n = 0; n < NCG; n++)
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s1[n][e] += __shfl_xor(s1[n][e], o, 64); s2[n][e] += __shfl_xor(s2[n][e], o, 64); }
+        s1[n][e] = row16_sum(s1[n][e]);
+        s2[n][e] = row16_sum(s2[n][e]);
       }
     float* red = reinterpret_cast<float*>(smem);           // [PS][CO][2]; the loop's last barrier has passed: the ring is dead
     if (l15 == 0) {

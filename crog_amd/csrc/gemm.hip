@@ -316,7 +316,7 @@ template <int WM>
 __device__ inline void flush_a_sum(const float (&asum)[WM], float* dst, int mbase, int M, int lane) {
 #pragma unroll
   for (int i = 0; i < WM; i++) {
-    const float v = asum[i] + __shfl_xor(asum[i], 32, 64);
+    const float v = xor32_sum(asum[i]);
     const int m = mbase + i * 32 + (lane & 31);
     if ((lane >> 5) == 0 && m < M) atomicAdd(dst + m, v);
   }
@@ -542,8 +542,8 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
     float* red = reinterpret_cast<float*>(smem);  // [WVM][BN][2]; the k-loop's last barrier has passed
 #pragma unroll
     for (int j = 0; j < WN; j++) {
-      s1[j] += __shfl_xor(s1[j], 32, 64);
-      s2[j] += __shfl_xor(s2[j], 32, 64);
+      s1[j] = xor32_sum(s1[j]);
+      s2[j] = xor32_sum(s2[j]);
       if (h == 0) {
         const int c = (wc * WN + j) * 32 + r;
         red[(wr * BN + c) * 2 + 0] = s1[j];
@@ -1549,8 +1549,8 @@ __global__ void __launch_bounds__(S::NT, S::NT == 512 ? 1 : 3) gemm_dma16_kernel
     float* red = reinterpret_cast<float*>(smem);      // [WVM][BN][2]
 #pragma unroll
     for (int j = 0; j < CB; j++) {
-      s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
-      s2[j] += __shfl_xor(s2[j], 16, 64); s2[j] += __shfl_xor(s2[j], 32, 64);
+      s1[j] = xor32_sum(xor16_sum(s1[j]));
+      s2[j] = xor32_sum(xor16_sum(s2[j]));
     }
     if (gq == 0) {
 #pragma unroll

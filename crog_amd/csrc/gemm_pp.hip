@@ -251,8 +251,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
     float* red = reinterpret_cast<float*>(smem);      // [2 row halves][BN][2]
 #pragma unroll
     for (int j = 0; j < CB; j++) {
-      s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
-      s2[j] += __shfl_xor(s2[j], 16, 64); s2[j] += __shfl_xor(s2[j], 32, 64);
+      s1[j] = xor32_sum(xor16_sum(s1[j]));
+      s2[j] = xor32_sum(xor16_sum(s2[j]));
     }
     if (gq == 0) {
 #pragma unroll

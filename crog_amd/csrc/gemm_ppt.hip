@@ -33,6 +33,7 @@ struct PptProb {
   const void* A;
   const void* B;
   void* C;
+  float* a_sum;      // bias gradient riding along: a_sum[m] += sum_k A[k][m], by cdiv(M, 256) * splitk extra blocks behind the problem's GEMM blocks
   int M, N, K, lda, ldb, ldc, splitk, convH, convW, convC, conv3, start;
 };
 constexpr int PPT_GROUP_MAX = 32;
@@ -237,8 +238,10 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
   // ---- epilogue: acc[i][j][e] = C[m0 + 128 (i >> 2) + 64 wr + 16 (i & 3) + 4 g + e][n0 + 128 (j >> 1) + 32 wc + 16 (j & 1) + c]
   float* Cf = reinterpret_cast<float*>(p.C) + (SLAB ? (int64_t)z * p.M * p.ldc : 0);
   const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;
-  auto emit = [&](auto guarded) {
-    constexpr bool G = decltype(guarded)::value;
+  // (an unsplit reduction: this block is the only writer of its tile - plain read-modify-write instead of 64 K atomic adds)
+  const bool solo = !SLAB && p.splitk == 1;
+  auto emit = [&](auto guarded, auto alone) {
+    constexpr bool G = decltype(guarded)::value, SOLO = decltype(alone)::value;
 #pragma unroll
     for (int i = 0; i < RB; i++) {
       const int mrow = m0 + 128 * (i >> 2) + 64 * wr + 16 * (i & 3) + 4 * gq;
@@ -250,6 +253,7 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
         for (int e = 0; e < 4; e++) {
           if (!G || (mrow + e < p.M && ncol < p.N)) {
             if constexpr (SLAB) cb[(int64_t)e * p.ldc] = acc[i][j][e];
+            else if constexpr (SOLO) cb[(int64_t)e * p.ldc] += acc[i][j][e];
             else atomicAdd(cb + (int64_t)e * p.ldc, acc[i][j][e]);
           }
         }
@@ -257,8 +261,54 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if (interior) emit(std::false_type{});
-  else emit(std::true_type{});
+  if (solo) {
+    if (interior) emit(std::false_type{}, std::true_type{});
+    else emit(std::true_type{}, std::true_type{});
+  } else {
+    if (interior) emit(std::false_type{}, std::false_type{});
+    else emit(std::true_type{}, std::false_type{});
+  }
+}
+
+// The bias gradient of a grouped linear weight gradient: a_sum[m] += sum over this block's reduction slice of A[k][m] for 256 columns.
+// 512 threads = 16 rows x 32 lanes of 8 columns per step; the 16 row groups meet in LDS.
+__device__ __attribute__((always_inline)) inline void ppt_colsum(const PptProb& p, const int blk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tilesM = (p.M + 255) / 256;
+  const int tm = blk % tilesM, z = blk / tilesM;
+  const int ktiles = (p.K + 63) / 64, per = (ktiles + p.splitk - 1) / p.splitk;
+  const int k0 = z * per * 64, k1 = min(p.K, k0 + per * 64);
+  const int tid = threadIdx.x, cg = tid & 31, rg = tid >> 5;
+  const int col = tm * 256 + cg * 8;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) s[e] = 0.f;
+  if (col < p.M) {      // (M % 8 == 0: a vector is inside the row or outside it)
+    const bf16* A = reinterpret_cast<const bf16*>(p.A) + col;
+    int k = k0 + rg;
+    for (; k + 48 < k1; k += 64) {      // four rows in flight per thread
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(A + (int64_t)k * p.lda), v1 = *reinterpret_cast<const bf16x8*>(A + (int64_t)(k + 16) * p.lda);
+      const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(A + (int64_t)(k + 32) * p.lda), v3 = *reinterpret_cast<const bf16x8*>(A + (int64_t)(k + 48) * p.lda);
+#pragma unroll
+      for (int e = 0; e < 8; e++) s[e] += ((float)v0[e] + (float)v1[e]) + ((float)v2[e] + (float)v3[e]);
+    }
+    for (; k < k1; k += 16) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(A + (int64_t)k * p.lda);
+#pragma unroll
+      for (int e = 0; e < 8; e++) s[e] += (float)v[e];
+    }
+  }
+  float* red = reinterpret_cast<float*>(smem);      // [16][256]
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[rg * 256 + cg * 8 + e] = s[e];
+  __syncthreads();
+  if (tid < 256 && tm * 256 + tid < p.M) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) t += red[r * 256 + tid];
+    if (p.splitk == 1) p.a_sum[tm * 256 + tid] += t;
+    else atomicAdd(p.a_sum + tm * 256 + tid, t);
+  }
 }
 
 template <int BL, bool SLAB, int D>
@@ -275,6 +325,11 @@ __global__ void __launch_bounds__(512, 2) gemm_ppt_group_kernel(const PptGroup g
   int i = 0;
   while (i + 1 < g.n && b >= g.p[i + 1].start) i++;
   const PptProb p = g.p[i];
+  const int gemm_blocks = ((p.M + 255) / 256) * ((p.N + 255) / 256) * p.splitk;
+  if (b - p.start >= gemm_blocks) {      // (block-uniform: only problems with a_sum own such blocks)
+    ppt_colsum(p, b - p.start - gemm_blocks);
+    return;
+  }
   if (p.conv3) ppt_body<CROG_B_NC_IM2COL, false, D>(p, b - p.start);
   else ppt_body<CROG_B_NC, false, D>(p, b - p.start);
 }
@@ -405,14 +460,18 @@ extern "C" int crog_gemm_group(const crog_gemm_desc* descs, int n, crog_stream_t
     if (d.batch_inner < 1) d.batch_inner = 1;
     if (d.splitk < 1) d.splitk = 1;
     CROG_CHECK_ARG(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0, "crog_gemm_group: descriptor %d: null operand or empty size", i);
+    float* a_sum = d.a_sum;      // (the single-launch kernel has no a_sum path; the group sums the bias gradient with blocks of its own)
+    d.a_sum = nullptr;
     CROG_CHECK_ARG(crog_gemm_ppt_eligible(d) && d.out_mode == CROG_OUT_F32_ATOMIC,
                    "crog_gemm_group: descriptor %d is not a bf16 weight gradient with atomic fp32 output the ping-pong kernel takes "
-                   "(A_MC x B_NC / B_NC_IM2COL, M and N multiples of 8, K >= 128, no bias / a_sum / statistics)", i);
+                   "(A_MC x B_NC / B_NC_IM2COL, M and N multiples of 8, K >= 128, no bias / statistics)", i);
+    CROG_CHECK_ARG(!a_sum || d.b_layout == CROG_B_NC, "crog_gemm_group: descriptor %d: a_sum only with the dense (B_NC) form", i);
     CROG_CHECK_ARG(((uintptr_t)d.A % 16) == 0 && ((uintptr_t)d.B % 16) == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0,
                    "crog_gemm_group: descriptor %d: A / B must be 16-byte aligned with lda, ldb multiples of 8", i);
     CROG_CHECK_ARG((long)d.M * d.ldc < 0x7fffffffL && d.lda < 0x7fffffffL && d.ldb < 0x7fffffffL, "crog_gemm_group: descriptor %d: leading dimensions out of range", i);
     PptProb& q = g.p[i];
     q.A = d.A; q.B = d.B; q.C = d.C;
+    q.a_sum = a_sum;
     q.M = d.M; q.N = d.N; q.K = d.K;
     q.lda = (int)d.lda; q.ldb = (int)d.ldb; q.ldc = (int)d.ldc;
     q.splitk = d.splitk;
@@ -420,6 +479,7 @@ extern "C" int crog_gemm_group(const crog_gemm_desc* descs, int n, crog_stream_t
     q.conv3 = d.b_layout == CROG_B_NC_IM2COL ? 1 : 0;
     q.start = blocks;
     blocks += cdiv(d.M, 256) * cdiv(d.N, 256) * d.splitk;
+    if (a_sum) blocks += cdiv(d.M, 256) * d.splitk;
   }
   g.blocks = blocks;
   constexpr int LDS = 8 * 16384;

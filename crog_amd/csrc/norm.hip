@@ -1193,18 +1193,7 @@ __global__ void split_pairs_kernel(const float* __restrict__ sums, int C, float*
 // =============================================================================================
 // LPR lanes share one row (64 / LPR rows per wave), each lane owns NJ 16-byte vectors: (LPR, NJ) = (4, 1) covers the
 // 20-key rows of the text tower / cross attention (16 rows per wave instead of one), (64, 2) the 676-key decoder rows.
-template <int LPR>
-__device__ inline float group_sum(float v) {
-#pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-template <int LPR>
-__device__ inline float group_max(float v) {
-#pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
+// (group_sum<LPR> / group_max<LPR>: common.h - DPP / permlane swaps, nothing through the LDS unit)
 
 template <typename T, int LPR, int NJ>
 __global__ void __launch_bounds__(NT) softmax_fwd_kernel(T* __restrict__ S, long rows, int Lq, int Lk, int ldp, int heads,

@@ -58,6 +58,9 @@ BN_BWD_ATOMIC = True             # backward partial sums through coalesced atomi
 DGRAD_T = True                   # 3x3 data gradients on the transposed weight copy (forward-shaped GEMM)
 LIN_DGRAD_T = True               # ... and the 1x1 / linear ones (round 3); tests compare with the transposed-read form
 FUSED_HEAD = True                # fold vis.4 into the dynamic head (no groups*C-channel map)
+GROUP_BIAS = os.environ.get("CROG_GROUP_BIAS", "1") != "0"        # grouped weight gradients may carry their bias gradient (crog_gemm_group: a_sum blocks)
+GROUP_MIN_K = int(os.environ.get("CROG_GROUP_MIN_K", "512"))      # shortest reduction that is parked for a grouped launch (4096 until round 5)
+GROUP_MAX_TILES = int(os.environ.get("CROG_GROUP_MAX_TILES", "36"))
 
 
 class OutRef:
@@ -107,9 +110,13 @@ class WRef:
     def done(self):
         """The kernels that write this parameter's gradient are enqueued (or parked: Runtime.defer_wgrad - then the announcement waits
         for the flush that really enqueues them, so a DDP bucket can never be launched ahead of its last gradient)."""
-        if RT._pending_wgrad or RT._group:
+        if RT._pending_wgrad:
             RT._pending_done.append(self._done_now)
             return
+        if RT._groups:      # parked for a grouped launch (Runtime.park_wgrad): announced when that launch is enqueued
+            lo = self.store.G.data_ptr() + 4 * self.off
+            if RT.defer_done(lo, lo + 4 * self.rows * self.cols, self._done_now):
+                return
         self._done_now()
 
     def _done_now(self):
@@ -164,22 +171,26 @@ def wgrad_gemm(dt, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, *, a_off=0, c_of
     park=False: the caller reads the result on the same stream right after this call (a padded scratch gradient that is stripped into the
     real one): the product must not wait for a grouped launch."""
     conv3 = b_layout == K.B_NC_IM2COL
-    if RT._group and RT._group_K != Kd:
-        RT.flush_group()      # the backward pass has moved on to layers of another resolution: what is parked goes now, not at the end
-    if (park and a_sum is None and dt == K.BF16 and RT.can_park() and M >= 256 and N >= 256 and M % 8 == 0 and N % 8 == 0 and Kd >= 4096
-            and a_off % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and (Kd + 64) * max(lda, ldb) * 2 < 2 ** 31 and M * ldc < 2 ** 31):
-        # a small output (a few 256 x 256 tiles) with a long reduction: parked, and launched together with its neighbours' by
-        # crog_gemm_group at ~84 k-tiles per block - alone it would be split 16-fold to fill the chip (Runtime.park_wgrad)
+    pk = RT.parked_K() if RT._groups else None
+    if pk is not None and pk != Kd:
+        RT.flush_group(RT._override)      # the backward pass has moved on to layers of another resolution: what is parked goes now, not at the end
+    if (park and (a_sum is None or (GROUP_BIAS and not conv3)) and dt == K.BF16 and RT.can_park() and M >= 256 and N >= 256 and M % 8 == 0
+            and N % 8 == 0 and Kd >= GROUP_MIN_K and a_off % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and (Kd + 64) * max(lda, ldb) * 2 < 2 ** 31
+            and M * ldc < 2 ** 31):
+        # a small output (a few 256 x 256 tiles): parked, and launched together with its neighbours' by crog_gemm_group at ~84 k-tiles per
+        # block - alone it would be split 16-fold to fill the chip (Runtime.park_wgrad).  Round 5: a bias gradient (a_sum) rides along as
+        # extra blocks of the same launch, and short reductions qualify too (the text tower: 48 linears over 640 token rows, each a
+        # latency-bound launch of its own before)
         tiles = ((M + 255) // 256) * ((N + 255) // 256)
-        if tiles <= 36 and K.lib().crog_gemm_wgrad_tile(dt, K.A_MC, b_layout, M, N, Kd) != 256:
+        if tiles <= GROUP_MAX_TILES and K.lib().crog_gemm_wgrad_tile(dt, K.A_MC, b_layout, M, N, Kd) != 256:
             gsk = max(1, min(16, round(Kd / 64 / 84)))
             K.GROUP_SINK = sink = []
             try:
                 K.gemm(dt, K.A_MC, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, a_off=a_off, c_off=c_off, conv=conv, splitk=gsk,
-                       out_mode=K.OUT_F32_ATOMIC)
+                       out_mode=K.OUT_F32_ATOMIC, a_sum=a_sum, a_sum_off=a_sum_off)
             finally:
                 K.GROUP_SINK = None
-            RT.park_wgrad(sink[0], tiles * gsk, (dy, x, G), Kd)
+            RT.park_wgrad(sink[0], (tiles + (((M + 255) // 256) if a_sum is not None else 0)) * gsk, (dy, x, G, a_sum), Kd)
             return
     if conv3 and not RT.deterministic and a_sum is None and dt == K.BF16 and a_off == 0 and lda == M and ldb == conv[2] and SW_SLABS:
         # stem / layer1: the sliding-window kernel, one strip of image rows per workgroup, meeting in slabs rather than 9.4 M atomic adds
@@ -588,7 +599,7 @@ class ConvBnAct(Function):
                     K.add_pad2d(gscratch, dst_cols, w.G, src_cols, src_cols, rows, dst_off=w.off)
             # (a data gradient that will take the one-block-per-CU 256 x 256 tile: csrc/gemm.hip dispatch_shape)
             big = ksize == 3 and ctx.x_needs and wpad is None and dtype == torch.bfloat16 and cin % 256 == 0 and ((M + 255) // 256) * (cin // 256) >= 160
-            RT.on_wgrad_stream(wgrad, dz, x, gt if wpad is not None else None, defer=big)
+            RT.on_wgrad_stream(wgrad, dz, x, gt if wpad is not None else None, defer=big, tag="conv")
             # BnLink: this data gradient is the previous layer's dy -> its epilogue does that layer's first BatchNorm-backward pass
             bwd = {}
             # (the last two terms mirror crog_gemm's own eligibility test for bwd_z - operands the LDS-DMA path can address with 32-bit
@@ -691,7 +702,11 @@ def conv_bn_act(x, w: Optional[WRef], bn: BnBuffers, *, ksize, relu=True, res=No
     if EVAL_BN_FOLD and not training and ksize != 0 and not torch.is_grad_enabled():
         y = _conv_bn_act_eval(x, w, bn, ksize, relu, res, out, wpad, dtype)
         return avgpool2(y) if pool else y
-    fuse = (pool and POOL_FUSED and training and relu and res is None and out is None and ksize != 0 and dtype == torch.bfloat16
+    # (odd maps - 400 x 400 inputs reach 25 x 25 in layer4 - take the separate avgpool2, which floors like nn.AvgPool2d)
+    even = ksize == "s" or (x.dim() == 4 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0)
+    if ksize == "s":
+        even = (x.shape[2] // 2) % 2 == 0 and (x.shape[3] // 2) % 2 == 0
+    fuse = (pool and POOL_FUSED and even and training and relu and res is None and out is None and ksize != 0 and dtype == torch.bfloat16
             and BN_ATOMIC_STATS and BN_BWD_ATOMIC and not RT.deterministic and stat_out is None and res_out is None)
     y = ConvBnAct.apply(x, res, wp, bn.gamma.param, bn.beta.param, w, bn, ksize, relu, training, out, wpad, dtype, grad_slot, res_slot,
                         stat_out, stat_in, dx_slot, res_out, res_in, fuse)
@@ -754,7 +769,7 @@ class LinearFn(Function):
         if has_res and g is dy and ctx.res_slot is None:
             wgrad()   # dy is handed on as the residual's gradient and autograd may accumulate into it IN PLACE: keep the read ordered
         else:
-            RT.on_wgrad_stream(wgrad, g, x)
+            RT.on_wgrad_stream(wgrad, g, x, tag="linear")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
@@ -861,7 +876,7 @@ class LayerNormFn(Function):
             # the parameter gradients are consumed by the optimizer only: their reduction leaves the dependency chain for the
             # weight-gradient stream (41 small launches per CROG step that sat between dependent kernels of the main stream)
             if LN_REDUCE_SIDE:
-                RT.on_wgrad_stream(lambda: K.reduce_split(partial, nb, C, None, gamma.grad(), beta.grad()), partial)
+                RT.on_wgrad_stream(lambda: K.reduce_split(partial, nb, C, None, gamma.grad(), beta.grad()), partial, tag="ln")
             else:
                 K.reduce_split(partial, nb, C, None, gamma.grad(), beta.grad())
         gamma.done()
@@ -983,7 +998,7 @@ class MhaFn(Function):
         if has_res and ctx.res_slot is None:
             wgrad_out()   # dout doubles as the residual's gradient (possible in-place accumulation by autograd): stay on this stream
         else:
-            RT.on_wgrad_stream(wgrad_out, dout, O)
+            RT.on_wgrad_stream(wgrad_out, dout, O, tag="mha")
         dO = torch.empty(B * Lq, E, device=dev, dtype=dtype)
         lin_dgrad(dout, wo, dO)
         wo.done()      # (after the data gradient that reads it: see LinearFn.backward)
@@ -1028,7 +1043,7 @@ class MhaFn(Function):
             dbuf = dqb[0] if buf is qb[0] else dkb[0]
             def wgrad_proj(dbuf=dbuf, x_=x_, w_=w_, b_=b_, col=col, ld=ld):
                 lin_wgrad(dbuf, x_, w_, a_off=col, lda=ld, N=w_.rows, bias=b_)
-            RT.on_wgrad_stream(wgrad_proj, dbuf, x_)
+            RT.on_wgrad_stream(wgrad_proj, dbuf, x_, tag="mha")
             prev = grads.get(id(x_))
             dx = prev if prev is not None else torch.empty(x_.shape, device=dev, dtype=dtype)
             lin_dgrad(dbuf, w_, dx, accumulate_into=prev, a_off=col, lda=ld, N=w_.rows)

@@ -94,6 +94,9 @@ class _Replay(Function):
 _FAILED_CAPTURES = []
 
 
+UPDATE_TOL = 0.25      # first-replay check: relative L2 distance of the replayed step's (dP, dm, dv) from the eager step's
+
+
 class GraphedTrainStep:
     """engine.train_step (crog_engine.py:60-90: autocast forward, zero_grad, backward, optimizer step, train metric, rank-averaged
     scalars) as ONE hipGraph launch per step.
@@ -207,6 +210,9 @@ class GraphedTrainStep:
         e_stats, _ = self._eager(batch)
         torch.cuda.synchronize()
         ref = e_stats.tolist()
+        # what the step did to the parameters and both Adam moments (the loss above is computed BEFORE backward, the gradient all-reduce
+        # and the optimizer run: a replay that dropped or mis-ordered a captured bucket all-reduce or an Adam chunk has the same loss)
+        ref_upd = {k: snap["tens"][k][0] - snap["tens"][k][1] for k in ("P", "m", "v") if k in snap["tens"]}
         self._restore(snap)
         why = None
         try:
@@ -218,6 +224,17 @@ class GraphedTrainStep:
             elif abs(got[0] - ref[0]) > 0.05 * abs(ref[0]) + 1e-3:
                 # (same state, same seeds, same batch: the two differ only by the order of fp32 atomic sums, ~1 % of the loss at most)
                 why = f"the replayed step's loss {got[0]:.5f} differs from the eager step's {ref[0]:.5f} (same state, same seeds)"
+            else:
+                for k, r in ref_upd.items():
+                    t, before = snap["tens"][k]
+                    d = ((t - before) - r).double().norm().item()
+                    n = r.double().norm().item()
+                    # same gradients up to the order of fp32 atomic sums (~1e-3 of a gradient; Adam turns that into a few per cent of the
+                    # elements whose gradient is noise): a missing all-reduce / Adam chunk changes the update by its own size
+                    if not d <= UPDATE_TOL * n + 1e-12:
+                        why = (f"the replayed step's update of {dict(P='the parameters', m='exp_avg', v='exp_avg_sq')[k]} differs from the eager step's "
+                               f"by {d / max(n, 1e-30):.3f} of its norm (tolerance {UPDATE_TOL})")
+                        break
         except Exception as e:
             why = f"the replay raised {e!r}"
             out = None

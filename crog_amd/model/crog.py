@@ -194,10 +194,10 @@ class CROG(nn.Module):
                 refresh_t = (lambda: RT._issue_wgrad(lambda: store.weights_t(dtype), ())) if (DGW_LATE and not TEXT_GRAPH) else None
                 if refresh_t is None:
                     RT._issue_wgrad(lambda: store.weights_t(dtype), ())
-            # (deterministic mode: ONE stream.  With the text tower's backward running beside the image tower's, its gradients differed
-            # in the last bit in about one run of four at B = 8 - the same unexplained dependence on a concurrent kernel that keeps the
-            # weight gradients on the main stream in that mode: runtime.set_deterministic, LAB_NOTES section 9)
-            overlap_text = self.overlap_text and not RT.deterministic
+            # (deterministic mode keeps the text stream since round 5: the run-to-run differences of rounds 3-4 were ds_bpermute_b32 returning
+            # 0 for a lane beside the image tower's 3x3 LDS-DMA kernel - runtime.set_deterministic, LAB_NOTES section 10; RT.det_streams = False
+            # restores the one-stream form)
+            overlap_text = self.overlap_text and (not RT.deterministic or RT.det_streams)
             graphed = None
             if overlap_text:
                 if self._side is None:

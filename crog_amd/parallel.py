@@ -143,7 +143,11 @@ def step_is_capturable(net) -> bool:
     records events a capture must not see (the watchdog thread polling a captured event aborted one run in a few in round 3)."""
     if getattr(net, "bucket_comm", None) is None:
         return False
-    return RT.comm is None or (RT.comm.direct is not None and RT.comm.direct.has_rccl)
+    if RT.comm is None:
+        # plain per-rank BatchNorm (sync_bn: False): DistributedDataParallel._broadcast_buffers then runs a torch.distributed broadcast
+        # inside every training forward - ProcessGroup work a capture must not hold (the configuration that aborted in round 3)
+        return not (getattr(net, "broadcast_buffers", False) and dist.is_initialized() and dist.get_world_size(getattr(net, "process_group", None)) > 1)
+    return RT.comm.direct is not None and RT.comm.direct.has_rccl
 
 
 class Reducer:

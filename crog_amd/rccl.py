@@ -89,6 +89,10 @@ class DirectComm:
             err = e
         if not _all_agree(err is None, group, dev):
             self.close()
+            if rccl and peer:
+                # ncclCommInitRank failed somewhere (every rank takes this branch: the verdict is collective): the mailbox transport does
+                # not need RCCL - try it alone before giving the statistics back to torch.distributed
+                return cls.create(group, device, rccl=False, peer=True, lib=lib, selftest=selftest)
             return None, err or RuntimeError("crog_comm_init failed on another rank")
         if peer:
             handle = (ctypes.c_char * 64)()
@@ -126,21 +130,36 @@ class DirectComm:
         return self, None
 
     def _selftest(self, dev):
-        """One exchange of a known vector per transport: rank r contributes r + 1, every element must come back as W (W + 1) / 2."""
-        want = self.world_size * (self.world_size + 1) / 2.0
+        """Known vectors through every transport at the sizes and in the pattern a training step uses them: rank r contributes
+        (r + 1) * (1 + i mod 7) in element i, so every element must come back as W (W + 1) / 2 * (1 + i mod 7) - exact in fp32.
+        Mailbox: a burst of back-to-back exchanges of every statistics size from 128 floats to a full slot, with no host
+        synchronisation in between (a step issues 142 such exchanges; both slot parities and the sequence counter are exercised, and a
+        rank that runs ahead meets the peer's previous exchange still in flight).  RCCL: a 4096-float vector and one full-size gradient
+        bucket (64 MiB), summed and averaged."""
+        W = self.world_size
         ok_peer = ok_rccl = True
+
+        def vec(n):
+            return (torch.arange(n, device=dev, dtype=torch.float32) % 7 + 1.0) * float(self.rank + 1)
+
+        def want(n, avg=False):
+            return (torch.arange(n, device=dev, dtype=torch.float32) % 7 + 1.0) * (W * (W + 1) / 2.0 / (W if avg else 1))
         try:
             if self.has_peer:
-                x = torch.full((256,), float(self.rank + 1), device=dev)
-                self.all_reduce_sum(x)                # 256 floats fit a mailbox slot: the peer-write path
-                ok_peer = bool((x == want).all().item()) and self.timed_out() == 0
+                sizes = [128, 256, 512, 1024, 2048, 4096, SLOT_FLOATS] * 4 + [256] * 36      # 64 exchanges in one burst
+                xs = [vec(n) for n in sizes]
+                for x in xs:
+                    self.all_reduce_sum(x)
+                ok_peer = all(bool(torch.equal(x, want(x.numel()))) for x in xs) and self.timed_out() == 0
         except Exception:
             ok_peer = False
         try:
             if self.has_rccl:
-                y = torch.full((4096,), float(self.rank + 1), device=dev)
-                self.all_reduce_bucket(y, average=False)
-                ok_rccl = bool((y == want).all().item())
+                for n, avg in ((4096, False), (1 << 24, True)):
+                    y = vec(n)
+                    self.all_reduce_bucket(y, average=avg)
+                    ref = want(n, avg)
+                    ok_rccl = ok_rccl and bool(torch.allclose(y, ref, rtol=1e-6, atol=0.0))
         except Exception:
             ok_rccl = False
         return ok_peer, ok_rccl

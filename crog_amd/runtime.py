@@ -39,7 +39,9 @@ class Runtime:
         # the main chain.  CROG_WGRAD_GROUP=0 switches it off.
         self.group_wgrad = os.environ.get("CROG_WGRAD_GROUP", "1") != "0"
         self.group_blocks = int(os.environ.get("CROG_WGRAD_GROUP_BLOCKS", "144"))
-        self._group, self._group_keep, self._group_n, self._group_stream, self._group_K = [], [], 0, None, 0
+        # one parked group per side stream (round 5: the text tower's weight gradients go to the aux stream and are grouped there, beside the
+        # image tower's on the weight-gradient stream): stream -> dict(descs, keep, n, K, done)
+        self._groups = {}
         self._slots = []       # GradSlots filled during the backward pass in flight (functional.GradSlot): all must be empty when it ends
         self._wgrad_stream = None
         self.text_stream = None
@@ -53,6 +55,10 @@ class Runtime:
         # deterministic mode (set_deterministic below; CROG_DETERMINISTIC=1): every sum whose order would depend on atomics takes its
         # ordered form - same inputs, same bits, run after run, eager or replayed
         self.deterministic = False
+        # deterministic mode keeps the default stream layout (round 5; CROG_DET_STREAMS=0: everything that feeds a gradient on one stream,
+        # as rounds 3-4 had to - see set_deterministic)
+        self.det_streams = os.environ.get("CROG_DET_STREAMS", "1") != "0"
+        self.no_fork = set()   # probe only: on_wgrad_stream tags ("conv", "linear", "mha", "ln") whose launches stay on the caller's stream
         self.seed_base = 0x5EED
         self._seed_ctr = 0
         self.seed_epoch = None   # device int64 added to every dropout seed inside the kernels (enable_seed_epoch)
@@ -112,7 +118,7 @@ class Runtime:
     def wgrad_stream(self):
         """The weight-gradient side stream (one: every reduction into a parameter gradient is ordered on it).  None in deterministic
         mode: weight gradients then stay on the stream of the layer's backward (see set_deterministic)."""
-        if not self.overlap_wgrad or not torch.cuda.is_available() or self.deterministic:
+        if not self.overlap_wgrad or not torch.cuda.is_available() or (self.deterministic and not self.det_streams):
             return None
         if self._wgrad_stream is None:
             self.ensure_streams()
@@ -123,13 +129,16 @@ class Runtime:
             self.streams.append(s)
         return s
 
-    def on_wgrad_stream(self, fn, *tensors, defer=None):
+    def on_wgrad_stream(self, fn, *tensors, defer=None, tag=None):
         """Run fn() (kernel launches only) on the weight-gradient stream, after everything enqueued so far on the current
         stream; `tensors` are the operands it reads (kept alive for that stream).
         With `defer_wgrad` the fork is taken one launch LATER: the request is parked and issued by the next `flush_wgrad()` - which
         ConvBnAct.backward calls right after it has enqueued the layer's data-gradient GEMM - so a weight gradient starts when that
         data gradient has finished instead of next to it (both are MFMA-bound: side by side the one on the critical path takes up
         to 2.5x its own time)."""
+        if tag is not None and tag in self.no_fork:
+            fn()
+            return
         want = self.defer_wgrad == "all" or (self.defer_wgrad == "big" and defer)
         if want and self.overlap_wgrad and torch.cuda.is_available():
             self.flush_wgrad()
@@ -147,38 +156,58 @@ class Runtime:
         pend, self._pending_wgrad = self._pending_wgrad, []
         for fn, tensors in pend:
             self._issue_wgrad(fn, tensors)
-        if self._group:      # (announcements also wait for a parked group: flush_group lets them through)
-            return
         done, self._pending_done = self._pending_done, []
         for d in done:
             d()
 
     # ---- grouped weight gradients ---------------------------------------------------------------------------------------
     def can_park(self):
-        """Inside on_wgrad_stream's closure, on the weight-gradient stream proper (not the aux stream, not inline)."""
+        """Inside on_wgrad_stream's closure, on a side stream (not inline)."""
         # (not under DDP: a parked gradient announces itself late, and the bucket all-reduce it completes would start late)
-        return (self.group_wgrad and not self.deterministic and self.reducer is None and getattr(self, "_override", None) is not None
-                and self._wgrad_stream and self._override is self._wgrad_stream[0])
+        return self.group_wgrad and not self.deterministic and self.reducer is None and getattr(self, "_override", None) is not None
+
+    @property
+    def _group(self):
+        """Anything parked on any stream?"""
+        return any(g["descs"] for g in self._groups.values())
+
+    def parked_K(self, stream=None):
+        g = self._groups.get(stream if stream is not None else getattr(self, "_override", None))
+        return g["K"] if g and g["descs"] else None
 
     def park_wgrad(self, desc, blocks, keep, Kd):
-        if self._group and self._group_stream is not self._override:
-            self.flush_group()
-        self._group_K = Kd
-        self._group.append(desc)
-        self._group_keep.append(keep)
-        self._group_n += blocks
-        self._group_stream = self._override
+        s = self._override
+        g = self._groups.get(s)
+        if g is not None and g["descs"] and g["K"] != Kd:
+            self.flush_group(s)      # the backward pass has moved on to layers of another resolution: what is parked goes now, not at the end
+        g = self._groups.setdefault(s, dict(descs=[], keep=[], n=0, K=Kd, done=[]))
+        g["K"] = Kd
+        g["descs"].append(desc)
+        g["keep"].append(keep)
+        g["n"] += blocks
         self._arm_end_of_backward()
-        if self._group_n >= self.group_blocks or len(self._group) >= 32:
-            self.flush_group()
+        if g["n"] >= self.group_blocks or len(g["descs"]) >= 32:
+            self.flush_group(s)
 
-    def flush_group(self):
-        """Launch what is parked (the stream was ordered behind each request's producers when it was parked), then let the
-        announcements that waited for it through (WRef.done)."""
-        if self._group:
-            descs, self._group, self._group_n = self._group, [], 0
-            keep, self._group_keep = self._group_keep, []
-            s, self._group_stream = self._group_stream, None
+    def defer_done(self, lo: int, hi: int, fn) -> bool:
+        """WRef.done(): is a gradient in the address range [lo, hi) still parked?  Then its announcement waits for that group's launch."""
+        for g in self._groups.values():
+            for d in g["descs"]:
+                c, a = d.C or 0, d.a_sum or 0
+                if lo <= c < hi or lo <= a < hi:
+                    g["done"].append(fn)
+                    return True
+        return False
+
+    def flush_group(self, stream=None):
+        """Launch what is parked on `stream` (None: on every stream) - each stream was ordered behind a request's producers when it was
+        parked - then let the announcements that waited for it through (WRef.done)."""
+        for s in ([stream] if stream is not None else list(self._groups)):
+            g = self._groups.get(s)
+            if not g or not g["descs"]:
+                continue
+            descs, keep, done = g["descs"], g["keep"], g["done"]
+            g["descs"], g["keep"], g["done"], g["n"] = [], [], [], 0
             prev = K._STREAM_OVERRIDE
             K.set_stream_override(s.cuda_stream)
             try:
@@ -186,8 +215,6 @@ class Runtime:
             finally:
                 K.set_stream_override(prev)
             del keep
-        if not self._pending_wgrad and self._pending_done:
-            done, self._pending_done = self._pending_done, []
             for d in done:
                 d()
 
@@ -223,7 +250,7 @@ class Runtime:
 
     def adam_stream(self):
         """Where FusedAdam steps its chunks during backward: the aux stream, else the weight-gradient stream (None: no side streams)."""
-        if self.aux_stream is None or self.deterministic or not self.overlap_wgrad:
+        if self.aux_stream is None or (self.deterministic and not self.det_streams) or not self.overlap_wgrad:
             return self.wgrad_stream()
         if self.aux_stream not in self.streams:
             self.streams.append(self.aux_stream)
@@ -321,12 +348,15 @@ def set_deterministic(on: bool = True):
     scatter, the head's bias / tap sums, the loss sums and the long-slab reductions) and for the launch policy of this package
     (functional.py: BatchNorm / LayerNorm statistics as per-tile slabs + ordered reduction - the fp32 parity mode's path - for bf16
     too, no BatchNorm-backward statistics in GEMM epilogues, split-K weight gradients as slabs + crog_splitk_reduce, bias gradients
-    by the two-pass column sum instead of a_sum), and the weight gradients stay on the main stream.  The last point is empirical:
-    with the weight-gradient stream forked, a LayerNorm backward launch running BESIDE a weight-gradient GEMM returned rows that
-    differed in the last bf16 bit from run to run (6 of 2704 rows at B = 4, identical inputs - cloned around the launch - and
-    bit-identical outputs whenever the launch was fenced or the side stream switched off; LAB_NOTES.md, round 4).  Not understood;
-    until it is, "deterministic" means one stream for everything that feeds a gradient.  Call it before the first step and outside a
-    capture (it allocates the library's scratch once)."""
+    by the two-pass column sum instead of a_sum, no grouped weight-gradient launches).
+    Streams: the mode runs on the DEFAULT stream layout (weight-gradient, text-tower and aux side streams) since round 5.  Rounds 3-4
+    had to keep it on one stream: beside a forked stream a LayerNorm backward returned rows that differed in the last bf16 bit from run
+    to run with identical operands.  Root cause (scripts/det_probe.py, bperm_hunt.py, LAB_NOTES section 10): `__shfl_xor` lowers to
+    ds_bpermute_b32, and a ds_bpermute_b32 of one wave returns 0 for a lane while another workgroup on the same CU runs the 3x3
+    ping-pong kernel's LDS-DMA requests with out-of-range (zero-fill) lanes - the row sum lost one lane's partial.  Every cross-lane
+    reduction of the library now goes through DPP modifiers, v_readlane and v_permlane*_swap (csrc/common.h: nothing in the LDS unit),
+    and 0 of 350+ passes differ where 26 of 238 did.  CROG_DET_STREAMS=0 restores the one-stream form.
+    Call it before the first step and outside a capture (it allocates the library's scratch once)."""
     K.check(K.lib().crog_set_deterministic(1 if on else 0), "set_deterministic")
     RT.deterministic = bool(on)
 
@@ -335,8 +365,11 @@ def slab_scratch(n: int, device) -> torch.Tensor:
     """n fp32 elements of scratch for a launch that may run on the weight-gradient stream (split-K slabs): the block is kept from
     being handed out again while that stream still uses it."""
     t = torch.empty(n, device=device, dtype=torch.float32)
-    if K._STREAM_OVERRIDE is not None and RT._wgrad_stream:
-        t.record_stream(RT._wgrad_stream[0])
+    if K._STREAM_OVERRIDE is not None:
+        # (the stream the closure is really launched on: _issue_wgrad redirects the text tower's weight gradients to the aux stream)
+        s = getattr(RT, "_override", None) or (RT._wgrad_stream[0] if RT._wgrad_stream else None)
+        if s is not None:
+            t.record_stream(s)
     return t
 
 

@@ -106,8 +106,8 @@ def test_reducer_matches_single_process(tmp_path):
 class _FakeLib:
     """Stands in for the C ABI (crog_comm_*) in the set-up protocol test: every call succeeds unless told to fail on this rank."""
 
-    def __init__(self, fail_uid=False, fail_init=False, fail_handle=False, fail_connect=False):
-        self.fail = dict(uid=fail_uid, init=fail_init, handle=fail_handle, connect=fail_connect)
+    def __init__(self, fail_uid=False, fail_init=False, fail_handle=False, fail_connect=False, fail_init_rccl=False):
+        self.fail = dict(uid=fail_uid, init=fail_init, handle=fail_handle, connect=fail_connect, init_rccl=fail_init_rccl)
         self.destroyed = 0
 
     def crog_last_error(self):
@@ -117,7 +117,7 @@ class _FakeLib:
         return -2 if self.fail["uid"] else 0
 
     def crog_comm_init(self, rank, world, uid, comm_p):
-        if self.fail["init"]:
+        if self.fail["init"] or (self.fail["init_rccl"] and uid is not None):
             return -2
         comm_p._obj.value = 0x1234          # ctypes.byref(c_void_p): the handle the real library would write
         return 0
@@ -143,7 +143,8 @@ def _setup_worker(rank, world, port, tmp):
     outcomes = []
     scenarios = [("library missing on rank 1", dict(load_fail=1)), ("unique id fails on rank 0", dict(uid=0)), ("comm init fails on rank 0", dict(init=0)),
                  ("comm init fails on rank 1", dict(init=1)), ("mailbox allocation fails on rank 1", dict(handle=1)),
-                 ("opening a peer mailbox fails on rank 0", dict(connect=0)), ("all fine", dict())]
+                 ("opening a peer mailbox fails on rank 0", dict(connect=0)),
+                 ("RCCL init fails on rank 1, the mailbox alone survives", dict(init_rccl=1)), ("all fine", dict())]
     for name, sc in scenarios:
         fake = _FakeLib(**{"fail_" + k: v == rank for k, v in sc.items() if k != "load_fail"})
         _lib._lib = fake                      # what K.lib() / check() return from now on
@@ -155,7 +156,9 @@ def _setup_worker(rank, world, port, tmp):
             lib = Missing()
         comm, err = rccl.DirectComm.create(None, device="cpu", rccl=True, peer=True, lib=lib or fake)
         outcomes.append((name, comm is not None, repr(err)[:60]))
-        if name != "all fine":
+        if "mailbox alone" in name:      # every rank retried without RCCL (collective verdict) and got the peer-only communicator
+            assert comm is not None and err is None and not comm.has_rccl and comm.has_peer, (rank, name)
+        elif name != "all fine":
             assert comm is None and err is not None, (rank, name)
         else:
             assert comm is not None and err is None and comm._h.value == 0x1234 and comm.has_rccl and comm.has_peer
@@ -168,4 +171,4 @@ def test_direct_comm_setup_verdict_is_collective(tmp_path):
     world, port = 2, 31000 + os.getpid() % 2000
     mp.start_processes(_setup_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     o0, o1 = torch.load(tmp_path / "setup0.pt"), torch.load(tmp_path / "setup1.pt")
-    assert [(n, ok) for n, ok, _ in o0] == [(n, ok) for n, ok, _ in o1] and len(o0) == 7
+    assert [(n, ok) for n, ok, _ in o0] == [(n, ok) for n, ok, _ in o1] and len(o0) == 8

@@ -258,14 +258,22 @@ def _forced_ddp_graph_case():
             if graph == "reject":          # a replay that does not reproduce the eager step: the first-replay check must refuse the graph
                 real = graphed._replay_once
                 graphed._replay_once = lambda b, profile=False: tuple((3.0 * real(b, profile)[0], None))
+            if graph == "reject_update":   # ... and one with the right loss whose optimizer update went missing (a dropped bucket
+                real = graphed._replay_once      # all-reduce / Adam chunk leaves the forward loss untouched): refused on the post-step state
+                def lossy(b, profile=False):
+                    r = real(b, profile)
+                    opt.m.mul_(0.5)
+                    return r
+                graphed._replay_once = lossy
             out = []
             for b in batches:
                 st, _ = graphed(b) if graph else train_step(net, opt, None, b, cfg, autocast_dtype=torch.bfloat16)
                 out.append(st.clone())
             torch.cuda.synchronize()
             assert net.reducer.direct is net.bucket_comm
-            if graph == "reject":
+            if graph in ("reject", "reject_update"):
                 assert graphed.verified is False and graphed.failed is not None and graphed.graph is None and graphed.replay_handle is None
+                assert graph == "reject" or "exp_avg" in graphed.failed, graphed.failed
             elif graph:
                 assert graphed.failed is None and graphed.verified is True and graphed.replays == 3, graphed.failed
                 assert graphed.collectives["syncbn"] > 0 and graphed.collectives["buckets"] > 1
@@ -275,6 +283,7 @@ def _forced_ddp_graph_case():
         s3, p3 = run(False)
         s2, p2 = run(True)
         s4, p4 = run("reject")
+        s5, p5 = run("reject_update")
         # (three eager runs, largest pairwise distance, factor 6: see test_replayed_steps_equal_eager_steps)
         noise_l = max((a[:, 0] - b[:, 0]).abs().max().item() for a, b in ((s0, s1), (s0, s3), (s1, s3)))
         noise_p = max(_rel(p0, p1), _rel(p0, p3), _rel(p1, p3))
@@ -283,6 +292,8 @@ def _forced_ddp_graph_case():
         # the refused graph left no trace: the state was rewound and every step ran eagerly
         assert (s0[:, 0] - s4[:, 0]).abs().max().item() <= max(6 * noise_l, 5e-2), (noise_l, s0, s4)
         assert _rel(p0, p4) <= max(6 * noise_p, 1e-4)
+        assert (s0[:, 0] - s5[:, 0]).abs().max().item() <= max(6 * noise_l, 5e-2), (noise_l, s0, s5)
+        assert _rel(p0, p5) <= max(6 * noise_p, 1e-4)
     finally:
         RT.comm = None
         RT.reducer = None

@@ -321,20 +321,25 @@ def test_grouped_weight_gradients_in_one_launch(K):
     """crog_gemm_group: dense and 3x3 weight gradients of different sizes and splits side by side in one launch of the ping-pong
     weight-gradient kernel; every output equals the float64 product (and what was in the gradient before), nothing else is touched."""
     dt = torch.bfloat16
-    probs = [  # (pixels (B, H, W), Cin, Cout, 3x3?, splitk)
+    probs = [  # (pixels (B, H, W), Cin, Cout, 3x3?, splitk[, bias gradient rides along])
         ((8, 26, 26), 512, 512, False, 4), ((8, 26, 26), 256, 256, True, 3), ((8, 26, 26), 1024, 264, False, 2),
-        ((2, 52, 52), 64, 256, True, 5), ((3, 13, 13), 512, 264, True, 1), ((8, 26, 26), 256, 1024, False, 4)]
-    sink, keep, want = [], [], []
+        ((2, 52, 52), 64, 256, True, 5), ((3, 13, 13), 512, 264, True, 1), ((8, 26, 26), 256, 1024, False, 4),
+        # round 5: a_sum blocks (bias gradients) and short unsplit reductions (the text tower's 640 token rows: plain read-modify-write)
+        ((8, 26, 26), 512, 520, False, 4, True), ((32, 20, 1), 512, 1536, False, 1, True), ((32, 20, 1), 2048, 512, False, 1, True),
+        ((1, 13, 10), 512, 264, False, 1, True), ((32, 20, 1), 512, 512, False, 1)]
+    sink, keep, want, biases = [], [], [], []
     K.GROUP_SINK = sink
     try:
-        for i, ((B, H, W), cin, cout, conv3, sk) in enumerate(probs):
+        for i, ((B, H, W), cin, cout, conv3, sk, *rest) in enumerate(probs):
             Kd = B * H * W
             N = 9 * cin if conv3 else cin
             x = rnd(Kd, cin, dt=dt, seed=2 * i)
             dy = (rnd(Kd, cout, dt=dt, seed=2 * i + 1) * 0.1).to(dt)
             g = torch.full((cout + 1, N + 8), 0.5, device="cuda")
+            bg = torch.full((cout + 8,), 0.25, device="cuda") if rest and rest[0] else None
+            biases.append((bg, dy.double().sum(0)))
             K.gemm(1, K.A_MC, K.B_NC_IM2COL if conv3 else K.B_NC, dy, x, g, cout, N, Kd, cout, cin, N + 8, splitk=sk,
-                   out_mode=K.OUT_F32_ATOMIC, conv=(H, W, cin) if conv3 else (0, 0, 0))
+                   out_mode=K.OUT_F32_ATOMIC, conv=(H, W, cin) if conv3 else (0, 0, 0), a_sum=bg)
             if conv3:
                 xi = x.double().view(B, H, W, cin).permute(0, 3, 1, 2)
                 cols = torch.nn.functional.unfold(xi, 3, padding=1).view(B, cin, 9, H * W).permute(0, 3, 2, 1).reshape(Kd, 9 * cin)
@@ -347,11 +352,14 @@ def test_grouped_weight_gradients_in_one_launch(K):
     assert len(sink) == len(probs)
     K.gemm_group(sink)
     torch.cuda.synchronize()
-    for (x, dy, g), ref, ((B, H, W), cin, cout, conv3, sk) in zip(keep, want, probs):
+    for (x, dy, g), ref, ((B, H, W), cin, cout, conv3, sk, *rest), (bg, bref) in zip(keep, want, probs, biases):
         N = ref.shape[1]
         assert (g[cout] == 0.5).all() and (g[:, N:] == 0.5).all(), "wrote outside the M x N block"
         got = g[:cout, :N].double() - 0.5
         assert _rel_l2(got, ref) < 2e-3, (cin, cout, conv3, _rel_l2(got, ref))
+        if bg is not None:
+            assert (bg[cout:] == 0.25).all(), "the bias sum wrote past its M columns"
+            assert _rel_l2(bg[:cout].double() - 0.25, bref) < 2e-3, (cin, cout, _rel_l2(bg[:cout].double() - 0.25, bref))
 
 
 @pytest.mark.parametrize("case", [
