@@ -318,8 +318,14 @@ def main():
     # through the C-ABI communicators (crog_amd.parallel.step_is_capturable: RCCL / mailbox launches on captured streams, chosen by a
     # start-up self-test); the first replay is then checked against an eager step from the same state (GraphedTrainStep verify=) and
     # the run falls back to eager steps in the same process if it does not reproduce it.
-    key = {"conv3x3_fwd": (K.A_IM2COL, K.B_KC), "conv3x3_dgrad": (K.A_IM2COL, K.B_NC_DGRAD), "conv3x3_wgrad": (K.A_MC, K.B_NC_IM2COL),
-           "lin_fwd": (K.A_KC, K.B_KC), "lin_wgrad": (K.A_MC, K.B_NC), "none": None}[args.roofline_kernel]
+    KEYS = {"conv3x3_fwd": (K.A_IM2COL, K.B_KC), "conv3x3_dgrad": (K.A_IM2COL, K.B_NC_DGRAD), "conv3x3_wgrad": (K.A_MC, K.B_NC_IM2COL),
+            "lin_fwd": (K.A_KC, K.B_KC), "lin_wgrad": (K.A_MC, K.B_NC), "none": None}
+    key = KEYS[args.roofline_kernel]
+    # `roofline` is the headline family (--roofline-kernel); `roofline_dominant` is the family of the kernel that takes the most time in the
+    # step (profiles/r0N_summary.md: the 3x3 weight gradient, gemm_ppt_kernel<B_NC_IM2COL>) - bracketed in the same sampled steps
+    DOMINANT = "conv3x3_wgrad"
+    dom_key = KEYS[DOMINANT] if (key is not None and args.roofline_kernel != DOMINANT) else None
+    keys = [k for k in (key, dom_key) if k is not None]
     graphed = None
     # (torch's process-group watchdog thread was seen to poll an event recorded inside a capture - hipErrorCapturedEvent, std::terminate -
     # once in a few runs when torch.distributed collectives were captured: with the C-ABI communicators no ProcessGroup work is in the step)
@@ -328,7 +334,7 @@ def main():
     want = os.environ.get("CROG_STEP_GRAPH", "1" if (not multi or step_is_capturable(net)) else "0")
     if not args.eager and want != "0":
         from crog_amd.graphs import GraphedTrainStep
-        graphed = GraphedTrainStep(net, opt, cfg, adt, warmup=3, profile_key=key if rank == 0 else None, verify=multi)
+        graphed = GraphedTrainStep(net, opt, cfg, adt, warmup=3, profile_key=(keys if len(keys) > 1 else key) if rank == 0 else None, verify=multi)
 
     def step(eager=False, profile=False):
         if graphed is not None:
@@ -345,7 +351,7 @@ def main():
         batch = graphed.static_batch()     # the synthetic batch is resident in the captured step's own input tensors (no per-step copy, as in the eager loop)
     timers_in_replay = replaying and bool(graphed.prof_nodes)      # the replay brackets the roofline kernel's launches itself
     if key is not None and rank == 0 and not timers_in_replay:
-        K.PROF = dict(key=key, records=[], on=False)
+        K.PROF = dict(key=key, keys=set(keys), records=[], on=False)
     coll0 = (RT.comm.calls if RT.comm is not None else 0, net.reducer.launches if (world > 1 or force_ddp) else 0)
     t0 = time.perf_counter()
     # Roofline leg, measured inside the timed region: a timing-only HIP event pair (no system fence) around every launch of the roofline
@@ -378,20 +384,23 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         ips = args.batch * world * args.steps / dt
-        roof = None
+        roof = roof_dom = None
         recs = None
         if timers_in_replay:
-            recs = graphed.profile_records()
-            durs = [ms * 1e-3 for ms, _, _ in recs]
-            flops = [f for _, f, _ in recs]
+            recs = [(ms_ * 1e-3, f, meta) for ms_, f, meta in graphed.profile_records()]
         elif K.PROF is not None and K.PROF["records"]:
-            recs = K.PROF["records"]
+            recs = [(e0.elapsed_time(e1) * 1e-3, f, meta) for e0, e1, f, meta in K.PROF["records"]]
             K.PROF = None
-            durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _, _ in recs]
-            flops = [f for _, _, f, _ in recs]
-        if recs:
+
+        def leg(name, k):
+            """Roofline leg of one GEMM family from its bracketed launches: MFMA fraction, and the HBM fraction of its ALGORITHMIC bytes
+            (each operand and the output once; a 3x3 form reads its NHWC map once, not nine times) - `bound` names the larger of the two."""
+            mine = [(d, f, m) for d, f, m in recs if (m[0], m[1]) == k]
+            if not mine:
+                return None
+            durs, flops = [d for d, _, _ in mine], [f for _, f, _ in mine]
             avg_d, avg_f = sum(durs) / len(durs), sum(flops) / len(flops)
-            # algorithmic bytes of the same launches: each operand and the output once (a 3x3 form reads its NHWC map once, not nine times)
+
             def alg_bytes(meta):
                 al, bl, M, N, Kd, bt, sk = meta
                 esz = 2 if args.dtype == "bf16" else 4
@@ -399,8 +408,7 @@ def main():
                 b_el = N * Kd / (9 if bl == K.B_NC_IM2COL else 1)
                 out_b = M * N * (4 if al == K.A_MC else esz)
                 return bt * (esz * (a_el + b_el) + out_b)
-            metas = [r[2] for r in recs] if timers_in_replay else [r[3] for r in recs]
-            alg = sum(alg_bytes(m) for m in metas) / len(metas)
+            alg = sum(alg_bytes(m) for _, _, m in mine) / len(mine)
             # HBM bytes per launch of this kernel: NOT measured in this run (PMC counters need rocprofv3 around the process) but read from
             # the committed PMC passes of the same workload, and labelled as such - it goes stale when the kernels change and the
             # round's profile is not re-taken
@@ -408,16 +416,24 @@ def main():
             try:
                 pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
                 if args.dtype == "bf16" and args.batch == 32:
-                    traffic = pm[args.roofline_kernel]["bytes_per_launch"]
-                    traffic_source = "committed profile, not this run: profiles/pmc_traffic.json (" + pm[args.roofline_kernel].get("source", "?") + ")"
+                    traffic = pm[name]["bytes_per_launch"]
+                    traffic_source = "committed profile, not this run: profiles/pmc_traffic.json (" + pm[name].get("source", "?") + ")"
             except (OSError, KeyError, ValueError):
                 pass
-            roof = dict(bound="mfma", achieved=round(avg_f / avg_d / 1e12, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
-                        frac=round(avg_f / avg_d / 1e12 / PEAK_MFMA_TF, 4), traffic=traffic, traffic_source=traffic_source,
+            mf, hf = avg_f / avg_d / 1e12 / PEAK_MFMA_TF, alg / avg_d / 1e9 / PEAK_HBM_GBS
+            return dict(bound="mfma" if mf >= hf else "hbm", achieved=round(avg_f / avg_d / 1e12, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
+                        frac=round(mf, 4), hbm_frac=round(hf, 4), hbm_achieved_GBps=round(alg / avg_d / 1e9, 1),
+                        traffic=traffic, traffic_source=traffic_source,
                         traffic_algorithmic=round(alg), traffic_ratio=(round(traffic / alg, 3) if traffic else None),
-                        kernel=K.GEMM_SYMBOL[key], launches_per_step=len(recs) // max(sampled, 1), timed_steps_bracketed=sampled,
+                        kernel=K.GEMM_SYMBOL[k], launches_per_step=len(mine) // max(sampled, 1), timed_steps_bracketed=sampled,
                         avg_launch_us=round(avg_d * 1e6, 1), avg_gflop_per_launch=round(avg_f / 1e9, 2),
                         share_of_step=round(sum(durs) / max(sampled, 1) / (dt / args.steps), 4))
+        if recs:
+            roof = leg(args.roofline_kernel, key)
+            if dom_key is not None:
+                roof_dom = leg(DOMINANT, dom_key)
+                if roof_dom is not None:
+                    roof_dom["why"] = "the family of the kernel with the largest share of the step's kernel time (profiles/r0N_summary.md: gemm_ppt_kernel<B_NC_IM2COL>, the 3x3 weight gradient)"
         out = {
             "metric": "training images/sec CROG-R50 416x416 bs32/GPU", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
@@ -430,6 +446,7 @@ def main():
                               "mfma_frac": round(FLOP_PER_IMG * args.batch / (ms * 1e-3) / 1e12 / PEAK_MFMA_TF, 4),
                               "note": "per-GPU algorithmic bytes (1.58 GB/img + 5.6 GB/step) and FLOPs (413.6 GFLOP/img) / step time vs 8 TB/s, 2.5 PFLOP/s"},
             "roofline": roof,
+            "roofline_dominant": roof_dom,
             "last_step": {"loss": round(last[0], 4), "iou": round(last[1], 3), "prec50": round(last[2], 3)},
         }
         out["step_issue"] = ({"mode": "replay:" + graphed.executor, "replays": graphed.replays, "captured": graphed.replay_info,

@@ -14,6 +14,9 @@ constexpr unsigned DMA_OOB = 0x80000000u;
 // and extent at the point of use, so that it is provably uniform and lives in SGPRs.
 __device__ __attribute__((always_inline)) inline void dma_piece(const void* base, int extent, char* dst, unsigned off) {
   typedef __attribute__((address_space(3))) void lds_void;
+#ifdef CROG_PROBE_NO_OOB      // probe build (LAB_NOTES section 10): no lane is ever out of range - border taps read the operand's first bytes (WRONG values, on purpose)
+  off = off == DMA_OOB ? 0u : off;
+#endif
   __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, extent, 0x00020000);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, off, 0, 0, 0);
 }

@@ -327,7 +327,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
 
 template <int AL, int RBQ, int D, bool EPI = false>
 int launch_pp(const crog_gemm_desc& d, hipStream_t s) {
+  #ifdef CROG_PROBE_LDS160
+  constexpr int LDS = 160 * 1024;      // probe build: the whole CU's LDS, nothing that uses LDS can share the CU
+#else
   constexpr int LDS = 8 * 16384;
+#endif
   static bool attr_set = false;
   auto kern = gemm_pp_kernel<AL, RBQ, D, EPI>;
   if (!attr_set) {

@@ -336,7 +336,11 @@ __global__ void __launch_bounds__(512, 2) gemm_ppt_group_kernel(const PptGroup g
 
 template <int BL, bool SLAB, int D>
 int launch_ppt(const crog_gemm_desc& d, hipStream_t s) {
+  #ifdef CROG_PROBE_LDS160
+  constexpr int LDS = 160 * 1024;      // probe build: the whole CU's LDS, nothing that uses LDS can share the CU
+#else
   constexpr int LDS = 8 * 16384;
+#endif
   static bool attr_set = false;
   auto kern = gemm_ppt_kernel<BL, SLAB, D>;
   if (!attr_set) {
@@ -482,7 +486,11 @@ extern "C" int crog_gemm_group(const crog_gemm_desc* descs, int n, crog_stream_t
     if (a_sum) blocks += cdiv(d.M, 256) * d.splitk;
   }
   g.blocks = blocks;
+  #ifdef CROG_PROBE_LDS160
+  constexpr int LDS = 160 * 1024;      // probe build: the whole CU's LDS, nothing that uses LDS can share the CU
+#else
   constexpr int LDS = 8 * 16384;
+#endif
   static bool attr_set = false;
   auto kern = gemm_ppt_group_kernel<5>;
   if (!attr_set) {

@@ -640,6 +640,8 @@ class ConvBnAct(Function):
                 stat_in.sums = None
             RT.flush_wgrad()       # (defer_wgrad: the weight gradient parked above forks here, behind the data gradient just enqueued)
             w.done()
+        if getattr(RT, "_dbg_dump", None) is not None and getattr(RT, "_fork_ctr", 0) in RT._dbg_dump_at:      # probe only (scripts/det_stress.py)
+            RT._dbg_dump.append((RT._fork_ctr, dict(dy=dy.clone(), dz=dz.clone(), dx=dx.clone() if dx is not None else None, x=x.clone(), z=z.clone())))
         if ctx.dx_slot is not None and dx is not None:      # (see avgpool2: x's other consumer adds this gradient in its own epilogue)
             ctx.dx_slot.put(dx)
             dx = None

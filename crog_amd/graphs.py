@@ -94,7 +94,8 @@ class _Replay(Function):
 _FAILED_CAPTURES = []
 
 
-UPDATE_TOL = 0.25      # first-replay check: relative L2 distance of the replayed step's (dP, dm, dv) from the eager step's
+UPDATE_TOL = 0.1       # first-replay check: relative L2 distance of the replayed step's (dm, dv) from the eager step's
+UPDATE_TOL_P = 0.9     # ... and of dP (see _verified_first_replay)
 
 
 class GraphedTrainStep:
@@ -229,11 +230,15 @@ class GraphedTrainStep:
                     t, before = snap["tens"][k]
                     d = ((t - before) - r).double().norm().item()
                     n = r.double().norm().item()
-                    # same gradients up to the order of fp32 atomic sums (~1e-3 of a gradient; Adam turns that into a few per cent of the
-                    # elements whose gradient is noise): a missing all-reduce / Adam chunk changes the update by its own size
-                    if not d <= UPDATE_TOL * n + 1e-12:
+                    # Same gradients up to the order of fp32 atomic sums (~1e-3 ... 1e-2 of a gradient): the moments' updates
+                    # (1 - beta) (g - m), (1 - beta2) (g^2 - v) inherit exactly that, a missing all-reduce or Adam chunk changes them by
+                    # their own size.  The PARAMETER update is Adam's normalised step: an element whose gradient is noise takes a full
+                    # +-lr step of noisy sign (measured 0.27 of the update's norm between two CORRECT steps of the tiny model), so it only
+                    # tells whether the optimizer ran at all.
+                    tol = UPDATE_TOL_P if k == "P" else UPDATE_TOL
+                    if not d <= tol * n + 1e-12:
                         why = (f"the replayed step's update of {dict(P='the parameters', m='exp_avg', v='exp_avg_sq')[k]} differs from the eager step's "
-                               f"by {d / max(n, 1e-30):.3f} of its norm (tolerance {UPDATE_TOL})")
+                               f"by {d / max(n, 1e-30):.3f} of its norm (tolerance {tol})")
                         break
         except Exception as e:
             why = f"the replay raised {e!r}"
@@ -284,7 +289,10 @@ class GraphedTrainStep:
         own = self.executor == "streams"
         g = torch.cuda.CUDAGraph(keep_graph=True) if own else torch.cuda.CUDAGraph()
         if own and self.profile_key is not None:
-            K.CAPTURE_NODES = dict(key=tuple(self.profile_key), nodes=[])
+            # (one (a_layout, b_layout) pair, or a list of pairs: bench.py brackets the headline family and the dominant-by-time one)
+            pk = self.profile_key
+            many = isinstance(pk[0], (tuple, list))
+            K.CAPTURE_NODES = dict(key=None if many else tuple(pk), keys={tuple(k) for k in pk} if many else (), nodes=[])
         if own:
             K.CAPTURE_TAGS = {}
         host_step = getattr(self.optimizer, "_step", None)

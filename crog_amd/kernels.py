@@ -205,7 +205,7 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
     if GROUP_SINK is not None:
         GROUP_SINK.append(d)
         return
-    if PROF is not None and PROF.get("on", True) and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout)):
+    if PROF is not None and PROF.get("on", True) and (PROF["key"] is None or PROF["key"] == (a_layout, b_layout) or (a_layout, b_layout) in PROF.get("keys", ())):
         # timers go on the stream the kernel is actually launched on (the weight-gradient side stream while it is overridden)
         raw = stream()
         e0, e1 = Timer(), Timer()
@@ -216,7 +216,7 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
         if "descs" in PROF:      # scripts/profile_gemms.py replays the launch on the same memory after the step
             PROF["descs"].append(d)
         return
-    if CAPTURE_NODES is not None and CAPTURE_NODES["key"] == (a_layout, b_layout):
+    if CAPTURE_NODES is not None and (CAPTURE_NODES["key"] == (a_layout, b_layout) or (a_layout, b_layout) in CAPTURE_NODES.get("keys", ())):
         raw = stream()
         check(lib().crog_gemm(ctypes.byref(d), raw), "crog_gemm")
         node = ctypes.c_void_p()

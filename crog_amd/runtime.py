@@ -55,9 +55,10 @@ class Runtime:
         # deterministic mode (set_deterministic below; CROG_DETERMINISTIC=1): every sum whose order would depend on atomics takes its
         # ordered form - same inputs, same bits, run after run, eager or replayed
         self.deterministic = False
-        # deterministic mode keeps the default stream layout (round 5; CROG_DET_STREAMS=0: everything that feeds a gradient on one stream,
-        # as rounds 3-4 had to - see set_deterministic)
-        self.det_streams = os.environ.get("CROG_DET_STREAMS", "1") != "0"
+        # which side streams deterministic mode keeps (set_deterministic): "text" (default: the text tower beside the image tower, weight
+        # gradients on the stream of their layer), "all" (also the weight-gradient / aux streams: NOT bit-reproducible yet, LAB_NOTES
+        # section 10), "0" (one stream, rounds 3-4)
+        self.det_streams = {"1": "all", "all": "all", "0": "0", "none": "0"}.get(os.environ.get("CROG_DET_STREAMS", "text"), "text")
         self.no_fork = set()   # probe only: on_wgrad_stream tags ("conv", "linear", "mha", "ln") whose launches stay on the caller's stream
         self.seed_base = 0x5EED
         self._seed_ctr = 0
@@ -118,7 +119,7 @@ class Runtime:
     def wgrad_stream(self):
         """The weight-gradient side stream (one: every reduction into a parameter gradient is ordered on it).  None in deterministic
         mode: weight gradients then stay on the stream of the layer's backward (see set_deterministic)."""
-        if not self.overlap_wgrad or not torch.cuda.is_available() or (self.deterministic and not self.det_streams):
+        if not self.overlap_wgrad or not torch.cuda.is_available() or (self.deterministic and self.det_streams != "all"):
             return None
         if self._wgrad_stream is None:
             self.ensure_streams()
@@ -139,6 +140,25 @@ class Runtime:
         if tag is not None and tag in self.no_fork:
             fn()
             return
+        if tag == "conv" and getattr(self, "fork_range", None) is not None:      # probe only (scripts/det_stress.py): fork the i-th conv weight gradient of the pass only for lo <= i < hi
+            i = self._fork_ctr = getattr(self, "_fork_ctr", 0) + 1
+            if not (self.fork_range[0] <= i - 1 < self.fork_range[1]):
+                fn()
+                return
+            dummy = getattr(self, "fork_dummy", None)
+            if dummy:      # the real launches stay on the caller's stream; the side stream gets a stand-in (a sleep, or a copy that streams HBM)
+                fn()
+                s = self.wgrad_stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    if dummy == "sleep":
+                        torch.cuda._sleep(600000)
+                    else:
+                        if getattr(self, "_dummy_buf", None) is None:
+                            self._dummy_buf = torch.empty(2, 1 << 28, device="cuda", dtype=torch.uint8)
+                        for _ in range(4):
+                            self._dummy_buf[1].copy_(self._dummy_buf[0])
+                return
         want = self.defer_wgrad == "all" or (self.defer_wgrad == "big" and defer)
         if want and self.overlap_wgrad and torch.cuda.is_available():
             self.flush_wgrad()
@@ -247,10 +267,18 @@ class Runtime:
         for t in tensors:
             if t is not None:
                 t.record_stream(s)
+        dbg = os.environ.get("CROG_DBG_FORK", "")      # probe only (scripts/det_stress.py)
+        if dbg:
+            if "keep" in dbg:
+                self._dbg_keep = getattr(self, "_dbg_keep", [])
+                self._dbg_keep.append(tensors)
+                self._arm_end_of_backward()
+            if "serial" in dbg:
+                cur.wait_stream(s)
 
     def adam_stream(self):
         """Where FusedAdam steps its chunks during backward: the aux stream, else the weight-gradient stream (None: no side streams)."""
-        if self.aux_stream is None or (self.deterministic and not self.det_streams) or not self.overlap_wgrad:
+        if self.aux_stream is None or (self.deterministic and self.det_streams != "all") or not self.overlap_wgrad:
             return self.wgrad_stream()
         if self.aux_stream not in self.streams:
             self.streams.append(self.aux_stream)
@@ -270,6 +298,7 @@ class Runtime:
 
     def _end_of_backward(self):
         self._join_armed = False
+        self._dbg_keep = []
         self.flush_wgrad()
         self.flush_group()
         self.join_streams()
@@ -303,6 +332,7 @@ class Runtime:
         else:
             self._zpool.zero_()
         self._zptr = 0
+        self._fork_ctr = 0
 
     def zeros(self, n: int, device):
         """n pre-zeroed floats valid until the next begin_step() -> (tensor, True), or a fresh torch.zeros -> (tensor, True)."""
@@ -349,13 +379,16 @@ def set_deterministic(on: bool = True):
     (functional.py: BatchNorm / LayerNorm statistics as per-tile slabs + ordered reduction - the fp32 parity mode's path - for bf16
     too, no BatchNorm-backward statistics in GEMM epilogues, split-K weight gradients as slabs + crog_splitk_reduce, bias gradients
     by the two-pass column sum instead of a_sum, no grouped weight-gradient launches).
-    Streams: the mode runs on the DEFAULT stream layout (weight-gradient, text-tower and aux side streams) since round 5.  Rounds 3-4
-    had to keep it on one stream: beside a forked stream a LayerNorm backward returned rows that differed in the last bf16 bit from run
-    to run with identical operands.  Root cause (scripts/det_probe.py, bperm_hunt.py, LAB_NOTES section 10): `__shfl_xor` lowers to
+    Streams (round 5): the text tower keeps its side stream, weight gradients stay on the stream of their layer (RT.det_streams =
+    "text"; CROG_DET_STREAMS=0: one stream as in rounds 3-4, =all: also the weight-gradient / aux streams).  Rounds 3-4 had to keep the
+    whole mode on one stream: beside a forked stream a LayerNorm backward returned rows that differed in the last bf16 bit from run to run
+    with identical operands.  Root cause of THAT (scripts/det_probe.py, bperm_hunt.py, LAB_NOTES section 10): `__shfl_xor` lowers to
     ds_bpermute_b32, and a ds_bpermute_b32 of one wave returns 0 for a lane while another workgroup on the same CU runs the 3x3
-    ping-pong kernel's LDS-DMA requests with out-of-range (zero-fill) lanes - the row sum lost one lane's partial.  Every cross-lane
-    reduction of the library now goes through DPP modifiers, v_readlane and v_permlane*_swap (csrc/common.h: nothing in the LDS unit),
-    and 0 of 350+ passes differ where 26 of 238 did.  CROG_DET_STREAMS=0 restores the one-stream form.
+    ping-pong LDS-DMA kernel - the row sum lost one lane's partial.  Every cross-lane reduction of the library now goes through DPP
+    modifiers, v_readlane and v_permlane*_swap (csrc/common.h: nothing in the LDS unit): 0 of 350+ passes differ with the text stream on
+    where 26 of 238 did.  A SECOND source remains when the convolution weight gradients are forked as well (one fork is enough:
+    DET_VARIANT=range:6-7 of scripts/det_stress.py, 9 of 9 passes differ; not a lifetime, not an uninitialised read, not the LDS-DMA
+    zero fill - LAB_NOTES section 10), which is why "all" is not the default.
     Call it before the first step and outside a capture (it allocates the library's scratch once)."""
     K.check(K.lib().crog_set_deterministic(1 if on else 0), "set_deterministic")
     RT.deterministic = bool(on)
@@ -365,6 +398,10 @@ def slab_scratch(n: int, device) -> torch.Tensor:
     """n fp32 elements of scratch for a launch that may run on the weight-gradient stream (split-K slabs): the block is kept from
     being handed out again while that stream still uses it."""
     t = torch.empty(n, device=device, dtype=torch.float32)
+    if "keepws" in os.environ.get("CROG_DBG_FORK", ""):
+        RT._dbg_keep = getattr(RT, "_dbg_keep", [])
+        RT._dbg_keep.append(t)
+        RT._arm_end_of_backward()
     if K._STREAM_OVERRIDE is not None:
         # (the stream the closure is really launched on: _issue_wgrad redirects the text tower's weight gradients to the aux stream)
         s = getattr(RT, "_override", None) or (RT._wgrad_stream[0] if RT._wgrad_stream else None)

@@ -22,7 +22,7 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 variants = sys.argv[4:] or ["all"]
 
 set_deterministic(True)
-RT.det_streams = True
+RT.det_streams = "all"
 torch.manual_seed(0)
 cfg = make_cfg(dropout=p)
 model, _ = build_crog(cfg); model = model.cuda().prepare(); model.train()
@@ -30,6 +30,7 @@ b = {k: v.cuda() for k, v in synthetic_batch(B, 416, cfg.word_len, cfg.clip_arch
 sd = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
 
 CONTRIB = None  # clones of what AddRowsFn / GatherRowsFn backward hand on (the pieces autograd sums into the text features' gradient)
+LAG_MS = float(os.environ.get("PROBE_LAG_MS", "0"))
 REC = None      # list of (name, [checksum tensors before], [after], [outputs]) of the pass in flight
 LN = None       # list of dicts of clones, LayerNormFn.backward only
 
@@ -94,6 +95,13 @@ def grads(record):
     REC, LN, CONTRIB = ([], [], []) if record else (None, None, None)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         _, _, loss, _ = model(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
+    if AGGR is not None:
+        AGGR()      # a burst of one kernel on a stream of its own, beside the whole backward pass (variant aggr:<kind>)
+    if LAG_MS and RT._wgrad_stream:
+        # hold the weight-gradient stream back: everything forked onto it queues up behind a sleep while the main stream runs ahead
+        # (the checksum kernels of this probe slow the main stream down, which otherwise hides a race that needs the side stream to LAG)
+        with torch.cuda.stream(RT._wgrad_stream[0]):
+            torch.cuda._sleep(int(LAG_MS * 2.0e6))
     loss.backward()
     torch.cuda.synchronize()
     rec, ln = REC, (LN, CONTRIB)
@@ -221,7 +229,64 @@ def analyse_ln(k0, k1, contrib=None):
                   f"{int((d.to(bad.dtype) != re[r]).sum())} from the re-run")
 
 
+AGGR = None
+_AG = {}
+
+
+def make_aggressor(kind, n):
+    """n back-to-back launches of one kernel of the step on a stream of its own: slab = the 3x3 weight gradient in deterministic form
+    (ping-pong transposed-operand kernel, plain slab stores) + crog_splitk_reduce; wg = the same GEMM with atomic adds; red = the reduction
+    alone; fwd = the 3x3 forward."""
+    bf = torch.bfloat16
+    if not _AG:
+        Bn, H, W = 32, 26, 26
+        P = Bn * H * W
+        _AG.update(P=P, H=H, W=W, x=torch.randn(P, 512, device="cuda").to(bf), dy=(torch.randn(P, 512, device="cuda") * 0.1).to(bf),
+                   ws=torch.empty(4 * 512 * 4608, device="cuda"), G=torch.zeros(512, 4608, device="cuda"), s=torch.cuda.Stream(),
+                   w3=(torch.randn(512, 4608, device="cuda") * 0.02).to(bf), y=torch.empty(P, 512, device="cuda", dtype=bf))
+    a = _AG
+
+    def go():
+        K.set_stream_override(a["s"].cuda_stream)
+        try:
+            for _ in range(n):
+                if kind in ("slab", "wg"):
+                    if kind == "slab":
+                        K.gemm(K.BF16, K.A_MC, K.B_NC_IM2COL, a["dy"], a["x"], a["ws"], 512, 4608, a["P"], 512, 512, 4608, splitk=4, out_mode=K.OUT_F32, conv=(a["H"], a["W"], 512))
+                        K.splitk_reduce(a["ws"], 4, 512, 4608, 4608, a["G"], 0, 4608, accumulate=True)
+                    else:
+                        K.gemm(K.BF16, K.A_MC, K.B_NC_IM2COL, a["dy"], a["x"], a["G"], 512, 4608, a["P"], 512, 512, 4608, splitk=4, out_mode=K.OUT_F32_ATOMIC, conv=(a["H"], a["W"], 512))
+                elif kind == "red":
+                    K.splitk_reduce(a["ws"], 4, 512, 4608, 4608, a["G"], 0, 4608, accumulate=True)
+                else:
+                    K.gemm(K.BF16, K.A_IM2COL, K.B_KC, a["x"], a["w3"], a["y"], a["P"], 512, 4608, 512, 4608, 512, conv=(a["H"], a["W"], 512))
+        finally:
+            K.set_stream_override(None)
+    return go
+
+
 def run_variant(v):
+    global AGGR
+    AGGR = None
+    if v.startswith("aggr:"):      # one stream for the step itself; the only neighbour is the aggressor's burst
+        kind = v.split(":")[1]
+        RT.overlap_wgrad = False
+        model.overlap_text = False
+        RT.no_fork = set()
+        AGGR = make_aggressor(kind, {"slab": 150, "wg": 150, "red": 600, "fwd": 300}[kind])
+        return _run_variant_body(v)
+    return _run_variant_body(v, set_flags=True)
+
+
+def _run_variant_body(v, set_flags=False):
+    if not set_flags:
+        pass
+    else:
+        _set_flags(v)
+    return _body(v)
+
+
+def _set_flags(v):
     RT.no_fork = set()
     model.overlap_text = True
     RT.overlap_wgrad = True
@@ -231,7 +296,14 @@ def run_variant(v):
         model.overlap_text = False
     elif v == "nowgrad":
         RT.overlap_wgrad = False
-    l0, g0, r0, (ln0, con0) = grads(True)
+
+
+def _body(v):
+    global LAG_MS, AGGR
+    lag, LAG_MS = LAG_MS, 0.0
+    ag, AGGR = AGGR, None
+    l0, g0, r0, (ln0, con0) = grads(True)      # the reference pass: no artificial lag, no aggressor
+    LAG_MS, AGGR = lag, ag
     f0 = flat(r0)
     bad = 0
     shown = 0

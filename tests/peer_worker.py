@@ -27,7 +27,8 @@ def main():
         sizes = [2, 64, 128, 512, 1000, 4096, SLOT_FLOATS, 6, 2 * 2048, 130]
         for it in range(60):
             n = sizes[it % len(sizes)]
-            x = torch.randn(n, generator=g).cuda()
+            mine0 = torch.randn(n, generator=g)
+            x = mine0.cuda()
             want = x.clone()
             dist.all_reduce(want)                      # gloo on a CUDA tensor: the reference exchange
             comm.all_reduce_sum(x)
@@ -35,11 +36,17 @@ def main():
             if comm.timed_out():
                 res["timed_out_at"] = it
                 break
-            # two ranks: a + b in rank order on both sides == gloo's a + b bit for bit; more ranks: same set, maybe another order
+            # two ranks: a + b in rank order on both sides == gloo's a + b bit for bit; more ranks: gloo's tree adds in another order, so the
+            # bit-exact reference is the rank-order sum of the gathered contributions (what the mailbox kernel promises: slots added 0, 1, 2, ...)
             if world == 2:
                 bad += int(not torch.equal(x, want))
             else:
-                bad += int(not torch.allclose(x, want, rtol=1e-6, atol=1e-6))
+                parts = [torch.empty_like(mine0) for _ in range(world)]
+                dist.all_gather(parts, mine0)
+                acc = torch.zeros_like(mine0)
+                for q in parts:
+                    acc = acc + q
+                bad += int(not torch.equal(x.cpu(), acc)) + int(not torch.allclose(x, want, rtol=1e-5, atol=1e-5))
         res["mismatches"] = bad
         # every rank must hold the SAME bits (the sum is formed in rank order everywhere)
         y = torch.randn(4096, generator=torch.Generator().manual_seed(7 + rank)).cuda()
