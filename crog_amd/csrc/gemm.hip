@@ -23,7 +23,8 @@
 
 // the ping-pong 256 x 256 x 64 kernel (gemm_pp.hip)
 bool crog_gemm_pp_eligible(const crog_gemm_desc& d, int rows);
-int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t s, bool full = false);
+int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t s, int full = 0);
+bool crog_gemm_pp_bwdz_ok(const crog_gemm_desc& d);
 bool crog_gemm_pp_full_epilogue_ok(const crog_gemm_desc& d);
 bool crog_conv_sw_eligible(const crog_gemm_desc& d);      // conv_sw.hip: sliding-window 3x3 convolution for 32 / 64 channels
 int crog_conv_sw_launch(const crog_gemm_desc& d, hipStream_t s);
@@ -1830,6 +1831,13 @@ template <typename T, bool HWTR>
 int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
   if (d.bwd_z) {      // BatchNorm-backward statistics: one dedicated tile, the three data-gradient layouts
     if constexpr (sizeof(T) == 2) {
+      // round 5: the ping-pong tile with the same epilogue where its shape rules hold (N a multiple of 256, K >= 512 as for its full epilogue,
+      // >= 150 tiles of 256 / 192 / 128 rows).  CROG_PP_BWDZ=0 / debug bit 11: the 128 x 128 tile
+      static const bool pp_bwdz = [] { const char* e = getenv("CROG_PP_BWDZ"); return !e || atoi(e) != 0; }();
+      if (pp_bwdz && !(d.debug & 2048) && dma_eligible(d) && bwd_epilogue_ok(d) && crog_gemm_pp_bwdz_ok(d) && (d.K >= 512 || (d.debug & (512 | 1024 | 524288)))) {
+        const int rows = pp_rows(d);
+        if (rows) return crog_gemm_pp_launch(d, rows, 0, s, 2);
+      }
       if (dma_eligible(d) && bwd_epilogue_ok(d)) {
         if (d.a_layout == CROG_A_KC && d.b_layout == CROG_B_NC) return launch_dma<T, CROG_A_KC, CROG_B_NC, ShapeMidBwd>(d, s);
         if (d.a_layout == CROG_A_KC && d.b_layout == CROG_B_KC) return launch_dma<T, CROG_A_KC, CROG_B_KC, ShapeMidBwd>(d, s);

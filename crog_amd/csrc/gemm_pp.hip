@@ -35,10 +35,12 @@ struct PpGeom { int H, W, C; };
 
 // RBQ: 16-row blocks per row quad (4: 256-row tile, 3: 192-row tile for launches the 256-row tile would quantise badly);
 // D: how many half-tiles the DMA runs ahead of the phase that issues it;
-// EPI: false = the lean epilogue (column statistics + bf16 stores), true = also bias, activation, residual, ReLU after the residual
-// (crog_gemm's order: + bias, statistics, activation, + R, CROG_ACT_RELU_POST) - a kernel of its own so that the lean launches carry
-// none of it
-template <int AL, int RBQ, int D, bool EPI = false>
+// EPI: 0 = the lean epilogue (column statistics + bf16 stores), 1 = also bias, activation, residual, ReLU after the residual
+// (crog_gemm's order: + bias, statistics, activation, + R, CROG_ACT_RELU_POST), 2 = the BatchNorm-backward statistics epilogue of a data
+// gradient (crog_gemm_desc.bwd_z: the accumulators are a gradient; + R, gate with the forward's ReLU bit mask and / or the sign of
+// bwd_ss.scale * z + shift, store the gated value, column sums (sum g, sum g * z) into the replica rows) - kernels of their own so that the
+// lean launches carry none of it
+template <int AL, int RBQ, int D, int EPI = 0>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p) {
   static_assert(AL == CROG_A_KC || AL == CROG_A_IM2COL, "K-contiguous A operands");
   static_assert(RBQ == 2 || RBQ == 3 || RBQ == 4, "row quad of 2, 3 or 4 blocks");
@@ -224,7 +226,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
   // ---- lean epilogue (as gemm_dma16_kernel): BatchNorm column statistics, bf16 stores -------------------------------
   const int arow = wr * (BM / 2), brow = wc * 64;
   const bool rows_in = m0 + BM <= p.M;
-  if constexpr (EPI) {
+  if constexpr (EPI == 1) {
     if (p.bias) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + brow + 4 * c16);      // (N % 256 == 0: always in range, 16-byte aligned)
 #pragma unroll
@@ -239,6 +241,47 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
     float s1[CB], s2[CB];
 #pragma unroll
     for (int j = 0; j < CB; j++) s1[j] = s2[j] = 0.f;
+    if constexpr (EPI == 2) {
+      // the lane's four adjacent columns of a row are one 8-byte load of z (and of R), one mask byte holds their four bits
+      const int colz = n0 + wc * 64 + 4 * c16;
+      const bf16* Z = reinterpret_cast<const bf16*>(p.bwd_z);
+      const bf16* Rz = reinterpret_cast<const bf16*>(p.R);
+      const unsigned char* MK = p.bwd_mask;
+      float gsc[CB], gsh[CB];
+#pragma unroll
+      for (int j = 0; j < CB; j++) { gsc[j] = p.bwd_ss ? p.bwd_ss[2 * (colz + j)] : 0.f; gsh[j] = p.bwd_ss ? p.bwd_ss[2 * (colz + j) + 1] : 1.f; }      // (no ReLU: 0 * z + 1 > 0)
+      const int mbit = colz & 7;
+#pragma unroll
+      for (int i = 0; i < RB; i++) {
+        const int row0 = m0 + arow + i * 16 + 4 * gq;
+        bf16x4 zv[4], rv[4];
+        unsigned mb[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {      // the block's loads in flight before the first is used
+          const bool ok = rows_in || row0 + e < p.M;
+          const int64_t r = ok ? row0 + e : 0;
+          zv[e] = *reinterpret_cast<const bf16x4*>(Z + r * p.ldz + colz);
+          if (Rz) rv[e] = *reinterpret_cast<const bf16x4*>(Rz + r * p.ldr + colz);
+          mb[e] = MK ? (unsigned)MK[r * (p.N >> 3) + (colz >> 3)] : 0xffu;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const bool ok = rows_in || row0 + e < p.M;
+#pragma unroll
+          for (int j = 0; j < CB; j++) {
+            const float z = (float)zv[e][j];
+            float a = acc[i][j][e];
+            if (Rz) a += (float)rv[e][j];
+            a = ((mb[e] >> (mbit + j)) & 1u) ? a : 0.f;
+            a = (z * gsc[j] + gsh[j] > 0.f) ? a : 0.f;
+            a = ok ? a : 0.f;
+            acc[i][j][e] = a;
+            s1[j] += a;
+            s2[j] += a * z;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < RB; i++) {
 #pragma unroll
@@ -247,6 +290,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
 #pragma unroll
         for (int j = 0; j < CB; j++) { const float v = ok ? acc[i][j][e] : 0.f; s1[j] += v; s2[j] += v * v; }
       }
+    }
     }
     float* red = reinterpret_cast<float*>(smem);      // [2 row halves][BN][2]
 #pragma unroll
@@ -276,7 +320,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
   }
   bf16* C = reinterpret_cast<bf16*>(p.C);
   const int col = n0 + brow + 4 * c16;
-  if constexpr (EPI) {
+  if constexpr (EPI == 1) {
     if (p.act == CROG_ACT_RELU || p.act == CROG_ACT_QUICKGELU || p.act == CROG_ACT_TANH) {
 #pragma unroll
       for (int i = 0; i < RB; i++)
@@ -289,14 +333,14 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
           }
     }
   }
-  const bf16* R = EPI ? reinterpret_cast<const bf16*>(p.R) : nullptr;
-  const bool post = EPI && p.act == CROG_ACT_RELU_POST;
+  const bf16* R = EPI == 1 ? reinterpret_cast<const bf16*>(p.R) : nullptr;      // (EPI == 2 has added R before its gate)
+  const bool post = EPI == 1 && p.act == CROG_ACT_RELU_POST;
 #pragma unroll
   for (int i = 0; i < RB; i++) {
     const int row0 = m0 + arow + i * 16 + 4 * gq;
     bf16* cb = C + (int64_t)row0 * p.ldc + col;
     bf16x4 rv[4];
-    if constexpr (EPI) {
+    if constexpr (EPI == 1) {
       if (R) {      // the block's four residual rows in flight before the first is used; added in fp32 (one rounding)
         const bf16* rb = R + (int64_t)row0 * p.ldr + col;
 #pragma unroll
@@ -307,7 +351,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       float f[4] = {acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]};
-      if constexpr (EPI) {
+      if constexpr (EPI == 1) {
         if (R && (rows_in || row0 + e < p.M)) {
 #pragma unroll
           for (int j = 0; j < 4; j++) f[j] += (float)rv[e][j];
@@ -325,7 +369,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
   }
 }
 
-template <int AL, int RBQ, int D, bool EPI = false>
+template <int AL, int RBQ, int D, int EPI = 0>
 int launch_pp(const crog_gemm_desc& d, hipStream_t s) {
   #ifdef CROG_PROBE_LDS160
   constexpr int LDS = 160 * 1024;      // probe build: the whole CU's LDS, nothing that uses LDS can share the CU
@@ -371,13 +415,29 @@ bool crog_gemm_pp_full_epilogue_ok(const crog_gemm_desc& d) {
   return true;
 }
 
-// dist: DMA distance in half-tiles (3 .. 7; 0 = the default of the tile height); full: the launch needs the EPI epilogue (default distance only)
-int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t s, bool full) {
+// The BatchNorm-backward statistics epilogue (EPI = 2): what crog_gemm checks for bwd_z, plus rows the 8-byte z / R loads can take
+bool crog_gemm_pp_bwdz_ok(const crog_gemm_desc& d) {
+  if (!d.bwd_z || !d.col_stats || d.stat_replicas <= 0 || d.alpha != 1.f || d.bias || d.act != CROG_ACT_NONE || d.out_mode != CROG_OUT_T) return false;
+  if (d.ldz % 4 != 0 || ((uintptr_t)d.bwd_z % 8) != 0) return false;
+  if (d.R && (d.ldr % 4 != 0 || ((uintptr_t)d.R % 8) != 0)) return false;
+  return true;
+}
+
+// dist: DMA distance in half-tiles (3 .. 7; 0 = the default of the tile height); full: 1 = the launch needs the EPI epilogue, 2 = the
+// bwd_z epilogue (default distances only)
+int crog_gemm_pp_launch(const crog_gemm_desc& d, int rows, int dist, hipStream_t s, int full) {
   const bool conv = d.a_layout == CROG_A_IM2COL;
+  if (full == 2) {
+    if (rows == 256) return conv ? launch_pp<CROG_A_IM2COL, 4, 4, 2>(d, s) : launch_pp<CROG_A_KC, 4, 5, 2>(d, s);
+    if (rows == 192) return conv ? launch_pp<CROG_A_IM2COL, 3, 4, 2>(d, s) : launch_pp<CROG_A_KC, 3, 5, 2>(d, s);
+    if (rows == 128) return conv ? launch_pp<CROG_A_IM2COL, 2, 4, 2>(d, s) : launch_pp<CROG_A_KC, 2, 5, 2>(d, s);
+    crog_set_error("crog_gemm: no ping-pong instantiation with the bwd_z epilogue for rows=%d", rows);
+    return CROG_ERR_ARG;
+  }
   if (full) {
-    if (rows == 256) return conv ? launch_pp<CROG_A_IM2COL, 4, 4, true>(d, s) : launch_pp<CROG_A_KC, 4, 5, true>(d, s);
-    if (rows == 192) return conv ? launch_pp<CROG_A_IM2COL, 3, 4, true>(d, s) : launch_pp<CROG_A_KC, 3, 5, true>(d, s);
-    if (rows == 128) return conv ? launch_pp<CROG_A_IM2COL, 2, 4, true>(d, s) : launch_pp<CROG_A_KC, 2, 5, true>(d, s);
+    if (rows == 256) return conv ? launch_pp<CROG_A_IM2COL, 4, 4, 1>(d, s) : launch_pp<CROG_A_KC, 4, 5, 1>(d, s);
+    if (rows == 192) return conv ? launch_pp<CROG_A_IM2COL, 3, 4, 1>(d, s) : launch_pp<CROG_A_KC, 3, 5, 1>(d, s);
+    if (rows == 128) return conv ? launch_pp<CROG_A_IM2COL, 2, 4, 1>(d, s) : launch_pp<CROG_A_KC, 2, 5, 1>(d, s);
     crog_set_error("crog_gemm: no ping-pong instantiation with the full epilogue for rows=%d", rows);      // (never fall through to a lean kernel)
     return CROG_ERR_ARG;
   }

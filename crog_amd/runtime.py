@@ -42,6 +42,8 @@ class Runtime:
         # one parked group per side stream (round 5: the text tower's weight gradients go to the aux stream and are grouped there, beside the
         # image tower's on the weight-gradient stream): stream -> dict(descs, keep, n, K, done)
         self._groups = {}
+        self._override = None        # the side stream a weight-gradient closure is being launched on (None: inline)
+        self._in_wgrad = False
         self._slots = []       # GradSlots filled during the backward pass in flight (functional.GradSlot): all must be empty when it ends
         self._wgrad_stream = None
         self.text_stream = None
@@ -182,9 +184,12 @@ class Runtime:
 
     # ---- grouped weight gradients ---------------------------------------------------------------------------------------
     def can_park(self):
-        """Inside on_wgrad_stream's closure, on a side stream (not inline)."""
+        """Inside on_wgrad_stream's closure: on a side stream, or - one-stream runs (bench.py's CROG_SINGLE_STREAM profile mode) - inline, the
+        group then goes to the caller's stream when it is flushed (same kernels as the default path, so the single-stream profile shows them)."""
         # (not under DDP: a parked gradient announces itself late, and the bucket all-reduce it completes would start late)
-        return self.group_wgrad and not self.deterministic and self.reducer is None and getattr(self, "_override", None) is not None
+        if not (self.group_wgrad and not self.deterministic and self.reducer is None and getattr(self, "_in_wgrad", False)):
+            return False
+        return getattr(self, "_override", None) is not None or not self.overlap_wgrad
 
     @property
     def _group(self):
@@ -196,7 +201,7 @@ class Runtime:
         return g["K"] if g and g["descs"] else None
 
     def park_wgrad(self, desc, blocks, keep, Kd):
-        s = self._override
+        s = getattr(self, "_override", None)
         g = self._groups.get(s)
         if g is not None and g["descs"] and g["K"] != Kd:
             self.flush_group(s)      # the backward pass has moved on to layers of another resolution: what is parked goes now, not at the end
@@ -229,7 +234,7 @@ class Runtime:
             descs, keep, done = g["descs"], g["keep"], g["done"]
             g["descs"], g["keep"], g["done"], g["n"] = [], [], [], 0
             prev = K._STREAM_OVERRIDE
-            K.set_stream_override(s.cuda_stream)
+            K.set_stream_override(s.cuda_stream if s is not None else None)      # (None: parked inline, launched on the caller's stream)
             try:
                 K.gemm_group(descs)
             finally:
@@ -241,7 +246,11 @@ class Runtime:
     def _issue_wgrad(self, fn, tensors):
         s = self.wgrad_stream()
         if s is None:
-            fn()
+            self._in_wgrad = True
+            try:
+                fn()
+            finally:
+                self._in_wgrad = False
             return
         if not self._join_armed:
             # at the end of this backward pass the caller's stream waits for the side streams, so that whatever the user
@@ -259,9 +268,11 @@ class Runtime:
         # fn() only launches kernels of this library: point them at the side stream directly instead of paying torch's
         # stream-context manager (~25 us of Python) ~150 times per step
         K.set_stream_override(s.cuda_stream)
+        self._in_wgrad = True
         try:
             fn()
         finally:
+            self._in_wgrad = False
             K.set_stream_override(None)
             self._override = None
         for t in tensors:

@@ -1540,7 +1540,10 @@ def test_timing_only_events_measure_a_launch(K):
 
 
 @pytest.mark.parametrize("M,N,K_,layout", [(4096, 256, 64, "nc"), (1000, 72, 96, "kc"), (21632, 1024, 256, "kc"), (2500, 512, 128, "nc"),
-                                           (4096, 256, 64, "kc"), (1280, 128, 512, "kc")])
+                                           (4096, 256, 64, "kc"), (1280, 128, 512, "kc"),
+                                           # round 5: the ping-pong tile's bwd_z epilogue (N % 256 == 0, K >= 512, >= 150 tiles): 128-row tiles, 256-row
+                                           # tiles, a ragged last row tile
+                                           (21632, 256, 1024, "kc"), (43264, 512, 512, "kc"), (21000, 256, 512, "kc")])
 def test_dgrad_epilogue_gates_a_residual_layer_with_its_bit_mask(K, M, N, K_, layout):
     """crog_gemm bwd_z + bwd_mask + R: the data gradient of a block's first convolution, plus the gradient of that block's identity
     path, is the gradient of the PREVIOUS block's output relu(bn3(z) + identity): the epilogue adds R, gates with the forward's bit
@@ -1571,6 +1574,36 @@ def test_dgrad_epilogue_gates_a_residual_layer_with_its_bit_mask(K, M, N, K_, la
     tot = sums.sum(0)
     assert torch.allclose(tot[:, 0], g.sum(0), rtol=2e-3, atol=2e-2 * g.abs().sum(0).max().item() / 100)
     assert torch.allclose(tot[:, 1], (g * z.float()).sum(0), rtol=2e-3, atol=2e-2 * (g * z.float()).abs().sum(0).max().item() / 100)
+
+
+@pytest.mark.parametrize("M,N,K_,relu", [(21632, 256, 1024, True), (43264, 256, 512, False)])
+def test_ping_pong_tile_does_the_first_batchnorm_backward_pass(K, monkeypatch, M, N, K_, relu):
+    """The same epilogue on the ping-pong tile (gemm_pp_kernel<..., 2>, K-contiguous operands: the data gradients on the transposed weight
+    copies), gate from bwd_ss or none: stored gradient and (sum g, sum g*z) against torch, and against the 128 x 128 tile (CROG_PP_BWDZ
+    off = debug bit 11) on the same operands."""
+    dt = torch.bfloat16
+    from crog_amd.functional import stat_replicas
+    a, b = rnd(M, K_, dt=dt), (rnd(N, K_, dt=dt, seed=1) * 0.1).to(dt)
+    z = (rnd(M, N, dt=dt, seed=2) * 1.5 + 0.3).to(dt)
+    ss = torch.stack([torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda") * 0.3], 1).contiguous()
+    R = stat_replicas(K.stat_tiles(M), N)
+    outs = []
+    for flags in (0, 2048):
+        monkeypatch.setattr(K, "DEBUG_FLAGS", flags)
+        sums = torch.zeros(R, N, 2, device="cuda")
+        dx = torch.full((M + 1, N), 7.0, device="cuda", dtype=dt)
+        K.gemm(K.dcode(dt), K.A_KC, K.B_KC, a, b, dx, M, N, K_, K_, K_, N, col_stats=sums, stat_replicas=R, bwd_z=z, bwd_ss=ss if relu else None)
+        outs.append((dx, sums.sum(0)))
+    monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
+    v = a.float() @ b.float().t()
+    gate = (z.float() * ss[:, 0] + ss[:, 1] > 0) if relu else torch.ones_like(v, dtype=torch.bool)
+    g = torch.where(gate, v, torch.zeros_like(v))
+    for dx, tot in outs:
+        assert (dx[M] == 7).all()
+        close(dx[:M], g, dt, scale=math.sqrt(K_) / 4)
+        assert torch.allclose(tot[:, 0], g.sum(0), rtol=2e-3, atol=2e-2 * g.abs().sum(0).max().item() / 100)
+        assert torch.allclose(tot[:, 1], (g * z.float()).sum(0), rtol=2e-3, atol=2e-2 * (g * z.float()).abs().sum(0).max().item() / 100)
+    assert (outs[0][0][:M] != outs[1][0][:M]).float().mean().item() < 0.05      # (same products, possibly another order inside a k-tile: a few last-bit differences)
 
 
 @pytest.mark.parametrize("M,N,K_,relu", [(4096, 64, 64, True), (1000, 72, 96, True), (21632, 256, 2304 // 9, False), (2500, 512, 128, True)])
