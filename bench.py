@@ -353,6 +353,7 @@ def main():
     if key is not None and rank == 0 and not timers_in_replay:
         K.PROF = dict(key=key, keys=set(keys), records=[], on=False)
     coll0 = (RT.comm.calls if RT.comm is not None else 0, net.reducer.launches if (world > 1 or force_ddp) else 0)
+    fused0 = getattr(RT.comm, "fused", 0) if RT.comm is not None else 0
     t0 = time.perf_counter()
     # Roofline leg, measured inside the timed region: a timing-only HIP event pair (no system fence) around every launch of the roofline
     # kernel, on the stream it is launched on, in every PROF_EVERY-th timed step (106 event records per bracketed step cost ~0.3 ms:
@@ -456,11 +457,13 @@ def main():
             per_step = (lambda now, then: (now - then) // args.steps)
             sb = per_step(RT.comm.calls, coll0[0]) if RT.comm is not None else 0
             gb = per_step(net.reducer.launches, coll0[1])
+            fb = (getattr(RT.comm, "fused", 0) - fused0) // args.steps if RT.comm is not None else 0
             if replaying:      # the Python counters only move in eager steps: a replay re-issues what the capture recorded
-                sb, gb = graphed.collectives["syncbn"], graphed.collectives["buckets"]
+                sb, gb, fb = graphed.collectives["syncbn"], graphed.collectives["buckets"], graphed.collectives.get("fused", 0)
             if RT.comm is not None:
                 RT.comm.check()      # a timed-out mailbox exchange poisons the statistics: never report a throughput measured on it
             out["collectives_per_step"] = {"syncbn_allreduce": sb,
+                                           "syncbn_exchanges_inside_a_producing_kernel": fb,
                                            "gradient_buckets": gb,
                                            "syncbn_transport": RT.comm.kind if RT.comm is not None else None,
                                            "bucket_transport": "crog_comm:rccl" if getattr(net, "bucket_comm", None) is not None else "torch.distributed",

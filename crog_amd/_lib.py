@@ -43,6 +43,7 @@ class GemmDesc(ctypes.Structure):
         ("R", ctypes.c_void_p), ("ldr", ctypes.c_int64), ("out_mode", ctypes.c_int), ("debug", ctypes.c_int),
         ("col_stats", ctypes.c_void_p), ("stat_replicas", ctypes.c_int), ("a_sum", ctypes.c_void_p),
         ("bwd_z", ctypes.c_void_p), ("ldz", ctypes.c_int64), ("bwd_ss", ctypes.c_void_p), ("bwd_mask", ctypes.c_void_p),
+        ("stat_sync", ctypes.c_void_p),
     ]
 
 
@@ -86,7 +87,7 @@ def _needs_rebuild(obj: str, deps):
 def build(verbose: bool = False, force: bool = False) -> str:
     """Compile every HIP source for gfx950 and link crog_amd/libcrog_hip.so (in-tree)."""
     os.makedirs(BUILD_DIR, exist_ok=True)
-    common = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_dma.h"), HEADER]
+    common = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_dma.h"), os.path.join(CSRC, "comm_dev.h"), HEADER]
     hipcc = os.environ.get("HIPCC", "hipcc")
 
     def compile_one(src):
@@ -140,7 +141,7 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
 
 def source_digest() -> str:
     h = hashlib.sha1()
-    for f in SOURCES + ["common.h", "gemm_dma.h"]:
+    for f in SOURCES + ["common.h", "gemm_dma.h", "comm_dev.h"]:
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(HEADER, "rb").read())
     return h.hexdigest()[:12]

@@ -19,7 +19,7 @@
 //    The sequence number lives in device memory and is advanced by the kernel, so the launch carries no per-step scalar and can be
 //    captured / replayed (crog_amd/graphs.py).  Every wait is bounded (120 s of wall clock by default, CROG_COMM_TIMEOUT_S): a missing peer raises the mailbox's error word
 //    instead of hanging the GPU.
-#include "common.h"
+#include "comm_dev.h"
 
 #include <dlfcn.h>
 #include <string.h>
@@ -99,8 +99,8 @@ bool rccl_bind() {
 // layout (floats / 32-bit words):  [0 .. 2*W*S)            data  [parity][rank][S]
 //                                  [2*W*S .. 2*W*S + 2*W)  flags [parity][rank]   (sequence number of the exchange that filled the slot)
 //                                  then: seq (this rank's exchange counter), err (non-zero after a timed-out wait)
-constexpr int MAX_WORLD = 16;
-struct PeerPtrs { float* box[MAX_WORLD]; };
+constexpr int MAX_WORLD = CROG_MAX_WORLD;
+typedef CrogPeerPtrs PeerPtrs;
 
 struct Comm {
   int rank = 0, world = 1;
@@ -112,6 +112,7 @@ struct Comm {
   bool connected = false;
   PeerPtrs peers{};
   std::vector<void*> opened;     // hipIpcOpenMemHandle mappings to close
+  CrogSyncBlock* sync_dev = nullptr;      // device copy of what a kernel-tail exchange needs (crog_comm_sync_block)
 };
 
 // How long a rank waits for its peers inside one exchange before it gives up and raises the mailbox's error word.  Ranks of one job
@@ -127,70 +128,8 @@ inline unsigned long long peer_wait_ticks() {
   return t;
 }
 
-__device__ inline unsigned ld_sys(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ inline void st_sys(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-
 __global__ void __launch_bounds__(256) peer_allreduce_kernel(float* __restrict__ x, int n, PeerPtrs peers, int rank, int world, int S, unsigned long long wait_ticks) {
-  float* mine = peers.box[rank];
-  unsigned* tail = reinterpret_cast<unsigned*>(mine + (size_t)2 * world * S + 2 * world);   // [seq, err]
-  __shared__ unsigned s_seq, s_bad, s_dead;
-  if (threadIdx.x == 0) {
-    s_seq = tail[0] + 1u;
-    tail[0] = s_seq;
-    s_bad = 0u;
-    s_dead = tail[1];
-  }
-  __syncthreads();
-  const unsigned seq = s_seq;
-  if (s_dead) {
-    // an earlier exchange of this communicator timed out: its sequence numbers and slot parity are no longer aligned with the peers',
-    // so nothing it could deliver is trustworthy.  Poison the statistics (NaN reaches the loss within one layer; the engine polls
-    // crog_comm_status and raises) instead of exchanging
-    for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = __builtin_nanf("");
-    return;
-  }
-  const int par = (int)(seq & 1u);
-  // 1. my contribution into slot [par][rank] of EVERY mailbox (my own included: one code path, one summation order)
-  for (int r = 0; r < world; r++) {
-    float* dst = peers.box[r] + ((size_t)par * world + rank) * S;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) __builtin_nontemporal_store(x[i], dst + i);
-  }
-  __threadfence_system();
-  __syncthreads();
-  // 2. publish: flag [par][rank] of every mailbox = seq
-  if (threadIdx.x < world) {
-    unsigned* f = reinterpret_cast<unsigned*>(peers.box[threadIdx.x] + (size_t)2 * world * S) + par * world + rank;
-    st_sys(f, seq);
-  }
-  // 3. wait for every rank's flag in MY mailbox (bounded: wait_ticks of the 100 MHz wall clock, peer_wait_ticks())
-  if (threadIdx.x < world) {
-    const unsigned* f = reinterpret_cast<const unsigned*>(mine + (size_t)2 * world * S) + par * world + threadIdx.x;
-    const unsigned long long t0 = wall_clock64();
-    while (ld_sys(f) != seq) {
-      if (wall_clock64() - t0 > wait_ticks) {
-        atomicOr(&s_bad, 1u);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  }
-  __syncthreads();
-  if (s_bad) {
-    // A peer did not show up in time.  This rank has already published its data and flag, so the late peer may still complete with
-    // the correct sums while this rank cannot: returning the local sums would let the ranks diverge silently.  Make it loud: NaN
-    // statistics (the loss and bench.py's finite check trip on the same step) and the error word for crog_comm_status.
-    if (threadIdx.x == 0) tail[1] = seq;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = __builtin_nanf("");
-    return;
-  }
-  __threadfence_system();
-  // 4. sum in rank order (identical on every rank)
-  const float* slots = mine + (size_t)par * world * S;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float acc = 0.f;
-    for (int r = 0; r < world; r++) acc += __builtin_nontemporal_load(slots + (size_t)r * S + i);
-    x[i] = acc;
-  }
+  crog_peer_exchange(x, n, peers, rank, world, S, wait_ticks);
 }
 
 }  // namespace
@@ -268,6 +207,24 @@ extern "C" int crog_comm_peer_connect(void* comm, const void* handles) {
   return CROG_OK;
 }
 
+extern "C" int crog_comm_sync_block(void* comm, void** dev_block) {
+  CROG_CHECK_ARG(comm && dev_block, "comm_sync_block: null argument");
+  auto* c = (Comm*)comm;
+  CROG_CHECK_ARG(c->connected, "comm_sync_block: the communicator has no peer mailboxes (crog_comm_peer_connect)");
+  if (!c->sync_dev) {
+    CrogSyncBlock h{};
+    h.peers = c->peers;
+    h.rank = c->rank;
+    h.world = c->world;
+    h.S = c->slot;
+    h.wait_ticks = peer_wait_ticks();
+    CM_HIP(hipMalloc((void**)&c->sync_dev, sizeof(CrogSyncBlock)), "hipMalloc(sync block)");
+    CM_HIP(hipMemcpy(c->sync_dev, &h, sizeof(h), hipMemcpyHostToDevice), "hipMemcpy(sync block)");
+  }
+  *dev_block = c->sync_dev;
+  return CROG_OK;
+}
+
 extern "C" int crog_comm_status(void* comm, int* timed_out_seq) {
   CROG_CHECK_ARG(comm && timed_out_seq, "comm_status: null argument");
   auto* c = (Comm*)comm;
@@ -283,7 +240,9 @@ extern "C" int crog_comm_status(void* comm, int* timed_out_seq) {
 extern "C" int crog_syncbn_stats(void* comm, float* ptr, int64_t count, crog_stream_t stream) {
   CROG_CHECK_ARG(comm && ptr && count > 0, "syncbn_stats: null argument");
   auto* c = (Comm*)comm;
-  if (c->world == 1) return CROG_OK;      // a one-rank sum is the identity (as RCCL's own one-rank all-reduce): nothing to launch
+  // (a one-rank communicator WITH a mailbox - bench.py's CROG_FORCE_DDP=1 - runs the protocol against its own mailbox, so that the
+  // world-size-1 number carries the launch and fence cost of every exchange; without a mailbox a one-rank sum is the identity)
+  if (c->world == 1 && !c->connected) return CROG_OK;
   if (c->connected && count <= c->slot) {
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ptr, (int)count, c->peers, c->rank, c->world, c->slot, peer_wait_ticks());
     CROG_LAUNCH_CHECK();
@@ -308,6 +267,7 @@ extern "C" int crog_comm_destroy(void* comm) {
   auto* c = (Comm*)comm;
   for (void* p : c->opened) (void)hipIpcCloseMemHandle(p);
   if (c->box) (void)hipFree(c->box);
+  if (c->sync_dev) (void)hipFree(c->sync_dev);
   if (c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl);
   delete c;
   return CROG_OK;

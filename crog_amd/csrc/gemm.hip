@@ -17,6 +17,7 @@
 //   transposed on the READ side: ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32.
 #include "common.h"
 #include "gemm_dma.h"
+#include "comm_dev.h"
 #include <type_traits>
 #include <stdlib.h>
 #include <algorithm>
@@ -569,6 +570,9 @@ __device__ __attribute__((always_inline)) inline void gemm_epilogue(f32x16 (&acc
       }
     }
     __syncthreads();
+    if constexpr (S::BWD) {      // SyncBatchNorm backward: the last block exchanges the totals (crog_gemm_desc.stat_sync, comm_dev.h)
+      if (p.stat_sync) crog_stat_sync_tail(reinterpret_cast<const CrogSyncBlock*>(p.stat_sync), p.col_stats, p.stat_replicas, 2 * p.N, gridDim.x * gridDim.y);
+    }
   }
 
   const T* R = LEAN ? nullptr : reinterpret_cast<const T*>(p.R);
@@ -2027,6 +2031,7 @@ extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
                        d.ldz % vec == 0 && ((uintptr_t)d.bwd_z % 16) == 0 && d.act == CROG_ACT_NONE && (!d.bwd_mask || d.N % 8 == 0),
                    "crog_gemm: bwd_z needs bf16 dtype output, col_stats with stat_replicas > 0, no activation, even N (a multiple of 8 with bwd_mask), aligned z");
   CROG_CHECK_ARG(!d.bwd_mask || d.bwd_z, "crog_gemm: bwd_mask only with bwd_z");
+  CROG_CHECK_ARG(!d.stat_sync || d.bwd_z, "crog_gemm: stat_sync (an exchange in the kernel's tail) only with bwd_z");
   CROG_CHECK_ARG(!d.a_sum || d.batch == 1, "crog_gemm: a_sum needs batch == 1");
   CROG_CHECK_ARG((long)d.batch * d.splitk <= 65535, "crog_gemm: batch*splitk too large");
   hipStream_t s = (hipStream_t)stream;

@@ -28,6 +28,7 @@
 // Accumulators / epilogue: as gemm_dma16_kernel — lane (c = lane & 15, g = lane >> 4), acc[i][j][e] = C[16 i + 4 g + e][4 c + j]
 // of the wave's tile; the B image is stored de-interleaved so that a lane owns four ADJACENT output columns (one 8-byte store per row).
 #include "gemm_dma.h"
+#include "comm_dev.h"
 
 namespace {
 
@@ -316,6 +317,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
         if (p.stat_replicas > 0) atomicAdd(p.col_stats + ((int64_t)((2 * tm + sl) % p.stat_replicas) * p.N + n0) * 2 + k, v);
         else p.col_stats[((int64_t)(m0 / 128 + sl) * p.N + n0) * 2 + k] = v;
       }
+    }
+    if constexpr (EPI == 2) {      // SyncBatchNorm backward: the last block exchanges the totals (crog_gemm_desc.stat_sync, comm_dev.h)
+      if (p.stat_sync) crog_stat_sync_tail(reinterpret_cast<const CrogSyncBlock*>(p.stat_sync), p.col_stats, p.stat_replicas, 2 * p.N, gridDim.x);
     }
   }
   bf16* C = reinterpret_cast<bf16*>(p.C);

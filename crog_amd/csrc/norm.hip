@@ -1,6 +1,6 @@
 // BatchNorm (training, cross-replica capable), LayerNorm and masked softmax kernels.
 // All are HBM-bound streaming kernels: 16-byte vector loads, fp32 math, wave-shuffle reductions.
-#include "common.h"
+#include "comm_dev.h"
 #include <algorithm>
 
 namespace {
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
                                                             const T* __restrict__ z, long ldz, const float* __restrict__ mean_invstd,
                                                             const float* __restrict__ relu_ss, long M, int C, int rows_per_block,
                                                             float* __restrict__ partial, int replicas, const unsigned char* __restrict__ relu_mask,
-                                                            int poolH, int poolW) {
+                                                            int poolH, int poolW, const CrogSyncBlock* __restrict__ sync, int tail) {
   // poolW != 0: dy is the gradient of the 2 x 2-average-POOLED output ([B][poolH/2][poolW/2][C]); pixel r takes a quarter of its cell's
   constexpr int VEC = Elem<T>::VEC;
   __shared__ float red[NT][2 * VEC + 1];
@@ -443,6 +443,9 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
       __syncthreads();
     }
   }
+  // tail != 0 (replicas > 0): `partial` carries 2 C floats of totals and a counter behind its rows - the block that finishes last adds
+  // the rows up, exchanges the sums with the other ranks (sync != NULL: SyncBatchNorm) and stores the totals (comm_dev.h)
+  if (tail) crog_stat_sync_tail(sync, partial, replicas, 2 * C, gridDim.x);
 }
 
 // dgamma/dbeta from the (local) sums: dbeta = sum g, dgamma = sum g*zhat.  accumulate flag adds.
@@ -1462,7 +1465,8 @@ extern "C" int crog_bn_apply_stats_pool(int dtype, const void* z, int64_t ldz, c
 
 static int bn_bwd_partial_impl(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
                                const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C, int rows_per_block,
-                               float* partial, int replicas, const void* relu_mask, int poolH, int poolW, crog_stream_t stream) {
+                               float* partial, int replicas, const void* relu_mask, int poolH, int poolW, crog_stream_t stream,
+                               const void* sync = nullptr, int tail = 0) {
   const int vec = dtype == CROG_BF16 ? 8 : 4;
   CROG_CHECK_ARG(poolW == 0 || (poolH > 0 && poolH % 2 == 0 && poolW % 2 == 0 && M % ((int64_t)poolH * poolW) == 0 && M < 0x7fffffffL),
                  "bn_bwd_partial: pooled form needs even H, W and M = B * H * W < 2^31");
@@ -1471,9 +1475,16 @@ static int bn_bwd_partial_impl(int dtype, const void* dy, int64_t lddy, const vo
   const int blocks = cdiv(M, rows_per_block);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const T*)dy,
                                        (long)lddy, (const T*)y, (long)ldy, (const T*)z, (long)ldz, mean_invstd, relu_scale_shift, (long)M, C,
-                                       rows_per_block, partial, replicas, (const unsigned char*)relu_mask, poolH, poolW));
+                                       rows_per_block, partial, replicas, (const unsigned char*)relu_mask, poolH, poolW, (const CrogSyncBlock*)sync, tail));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
+}
+extern "C" int crog_bn_bwd_partial_sync(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
+                                        const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C, int rows_per_block,
+                                        float* partial, int replicas, const void* relu_mask, int H, int W, const void* stat_sync, crog_stream_t stream) {
+  CROG_CHECK_ARG(replicas > 0, "bn_bwd_partial_sync: the totals tail needs the atomic replica form (replicas > 0)");
+  return bn_bwd_partial_impl(dtype, dy, lddy, y, ldy, z, ldz, mean_invstd, relu_scale_shift, M, C, rows_per_block, partial, replicas, relu_mask, H, W, stream,
+                             stat_sync, 1);
 }
 extern "C" int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z, int64_t ldz,
                                    const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C, int rows_per_block,

@@ -174,7 +174,7 @@ def wgrad_gemm(dt, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, *, a_off=0, c_of
     pk = RT.parked_K() if RT._groups else None
     if pk is not None and pk != Kd:
         RT.flush_group(RT._override)      # the backward pass has moved on to layers of another resolution: what is parked goes now, not at the end
-    if (park and (a_sum is None or (GROUP_BIAS and not conv3)) and dt == K.BF16 and RT.can_park() and M >= 256 and N >= 256 and M % 8 == 0
+    if (park and (a_sum is None or (GROUP_BIAS and not conv3)) and dt == K.BF16 and RT.can_park() and RT.can_park_K(Kd) and M >= 256 and N >= 256 and M % 8 == 0
             and N % 8 == 0 and Kd >= GROUP_MIN_K and a_off % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and (Kd + 64) * max(lda, ldb) * 2 < 2 ** 31
             and M * ldc < 2 ** 31):
         # a small output (a few 256 x 256 tiles): parked, and launched together with its neighbours' by crog_gemm_group at ~84 k-tiles per
@@ -295,11 +295,12 @@ class BnLink:
     accumulate (sum g, sum g*z) (`stat_in`, crog_gemm bwd_z) — layer L then skips the first pass of BatchNorm backward, which
     would have re-read dy and z from HBM.  Only valid when NOTHING else consumes y_L: the model code that wires it vouches."""
 
-    __slots__ = ("z", "ss", "C", "M", "sums", "R", "mask", "dx_ptr")
+    __slots__ = ("z", "ss", "C", "M", "sums", "R", "mask", "dx_ptr", "synced")
 
     def __init__(self):
         self.z = self.ss = self.sums = self.mask = None
         self.C = self.M = self.R = self.dx_ptr = 0
+        self.synced = False      # the GEMM that left `sums` also exchanged them across the ranks (stat_sync): totals behind the R rows
 
 
 BN_BWD_FUSED = True   # BnLink fusion on (bf16, atomic statistics path); tests compare with the two-launch form
@@ -495,7 +496,10 @@ class ConvBnAct(Function):
             res_out.sums = res_out.z = None
             scale = 1.0
             if comm_on:
-                RT.comm.all_reduce_sum(sums)
+                if res_out.synced:      # the GEMM's last block exchanged the sums: one row of global totals behind the R rows
+                    sums, R = sums[R * 2 * C:(R + 1) * 2 * C], 1
+                else:
+                    RT.comm.all_reduce_sum(sums)
                 scale = 1.0 / RT.comm.world_size
             K.bn_bwd_apply(dy, None, z, mi, bn.gamma.master(), sums, count, dz, None, None, sum_rows=-R,
                            dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=None, param_grad_scale=scale)
@@ -508,7 +512,10 @@ class ConvBnAct(Function):
             stat_out.sums = stat_out.z = None
             scale = 1.0
             if comm_on:
-                RT.comm.all_reduce_sum(sums)
+                if stat_out.synced:
+                    sums, R = sums[R * 2 * C:(R + 1) * 2 * C], 1
+                else:
+                    RT.comm.all_reduce_sum(sums)
                 scale = 1.0 / RT.comm.world_size
             K.bn_bwd_apply(dy, None, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=-R,
                            dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=None, param_grad_scale=scale)
@@ -521,12 +528,21 @@ class ConvBnAct(Function):
             # them divided by the world size equals what DDP's averaging makes of the local sums, so no local-sum pass is needed.
             # Not in fp32: the parity mode keeps the ordered slab reduction below.
             R = stat_replicas(nparts, C)
-            sums = RT.zeros(R * 2 * C, dev)
-            K.bn_bwd_partial(dy, ymask, z, mi, rpb, sums, relu_ss, replicas=R, relu_mask=rmask, pool=ctx.pool)
+            sync = RT.comm.fuse_ptr(2 * C) if comm_on else None
             scale = 1.0
-            if comm_on:
-                RT.comm.all_reduce_sum(sums)
+            if sync is not None:
+                # SyncBatchNorm: the first pass's last block adds its R rows up, exchanges the 2 C sums through the peer mailboxes and
+                # stores the global totals behind the rows - no exchange launch between the two passes
+                buf = RT.zeros(R * 2 * C + 2 * C + 8, dev)
+                K.bn_bwd_partial(dy, ymask, z, mi, rpb, buf, relu_ss, replicas=R, relu_mask=rmask, pool=ctx.pool, stat_sync=sync, tail=True)
+                sums, R = buf[R * 2 * C:(R + 1) * 2 * C], 1
                 scale = 1.0 / RT.comm.world_size
+            else:
+                sums = RT.zeros(R * 2 * C, dev)
+                K.bn_bwd_partial(dy, ymask, z, mi, rpb, sums, relu_ss, replicas=R, relu_mask=rmask, pool=ctx.pool)
+                if comm_on:
+                    RT.comm.all_reduce_sum(sums)
+                    scale = 1.0 / RT.comm.world_size
             K.bn_bwd_apply(dy, ymask, z, mi, bn.gamma.master(), sums, count, dz, dres, relu_ss, sum_rows=R,
                            dgamma=bn.gamma.grad(), dbeta=bn.beta.grad(), relu_mask=rmask, param_grad_scale=scale, pool=ctx.pool)
             bn.beta.done()
@@ -609,14 +625,18 @@ class ConvBnAct(Function):
                     and stat_in.C == cin and stat_in.M == M and cin % 8 == 0 and C % 8 == 0
                     and 2 * M * max(C, cin) < 2 ** 31):
                 stat_in.R = stat_replicas(K.stat_tiles(M), cin)
-                stat_in.sums = RT.zeros(stat_in.R * 2 * cin, dev)
-                bwd = dict(col_stats=stat_in.sums, stat_replicas=stat_in.R, bwd_z=stat_in.z, bwd_ss=stat_in.ss)
+                sync = RT.comm.fuse_ptr(2 * cin) if comm_on else None      # SyncBatchNorm: this GEMM's last block also exchanges the sums
+                stat_in.synced = sync is not None
+                stat_in.sums = RT.zeros(stat_in.R * 2 * cin + (2 * cin + 8 if sync is not None else 0), dev)
+                bwd = dict(col_stats=stat_in.sums, stat_replicas=stat_in.R, bwd_z=stat_in.z, bwd_ss=stat_in.ss, stat_sync=sync)
             if (res_in is not None and res_in.z is not None and not bwd and ksize == 1 and ctx.x_needs and extra is not None
                     and dtype == torch.bfloat16 and res_in.C == cin and res_in.M == M and cin % 8 == 0 and C % 8 == 0
                     and 2 * M * max(C, cin) < 2 ** 31 and K.mat(extra)[2] % 2 == 0):
                 res_in.R = stat_replicas(K.stat_tiles(M), cin)
-                res_in.sums = RT.zeros(res_in.R * 2 * cin, dev)
-                bwd = dict(col_stats=res_in.sums, stat_replicas=res_in.R, bwd_z=res_in.z, bwd_mask=res_in.mask)
+                sync = RT.comm.fuse_ptr(2 * cin) if comm_on else None
+                res_in.synced = sync is not None
+                res_in.sums = RT.zeros(res_in.R * 2 * cin + (2 * cin + 8 if sync is not None else 0), dev)
+                bwd = dict(col_stats=res_in.sums, stat_replicas=res_in.R, bwd_z=res_in.z, bwd_mask=res_in.mask, stat_sync=sync)
             if ksize == 1 and ctx.x_needs:
                 dx = torch.empty(lead + (cin,), device=dev, dtype=dtype)
                 if bwd and res_in is not None and res_in.sums is bwd.get("col_stats"):

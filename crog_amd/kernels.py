@@ -184,7 +184,7 @@ def as_mat(t: torch.Tensor) -> torch.Tensor:
 def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, ldc, *, batch=1, batch_inner=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, conv=(0, 0, 0), alpha=1.0, bias=None, act=ACT_NONE, R=None,
          ldr=0, out_mode=OUT_T, col_stats=None, a_off=0, b_off=0, c_off=0, a_sum=None, a_sum_off=0, stat_replicas=0, bwd_mask=None, bwd_z=None,
-         bwd_ss=None):
+         bwd_ss=None, stat_sync=None):
     """Raw descriptor launch. A/B/C are tensors (or ints = device addresses); *_off are element offsets."""
     esz = 2 if dtype == BF16 else 4
     csz = esz if out_mode == OUT_T else 4
@@ -201,7 +201,7 @@ def gemm(dtype: int, a_layout: int, b_layout: int, A, B, C, M, N, K, lda, ldb, l
                  None if col_stats is None else col_stats.data_ptr(), stat_replicas,
                  None if a_sum is None else a_sum.data_ptr() + 4 * a_sum_off,
                  None if bwd_z is None else bwd_z.data_ptr(), 0 if bwd_z is None else mat(bwd_z)[2], None if bwd_ss is None else bwd_ss.data_ptr(),
-                 None if bwd_mask is None else bwd_mask.data_ptr())
+                 None if bwd_mask is None else bwd_mask.data_ptr(), stat_sync)
     if GROUP_SINK is not None:
         GROUP_SINK.append(d)
         return
@@ -316,9 +316,18 @@ def bn_apply_stats(z, sums, replicas, count, gamma, beta, running_mean, running_
                                     int(relu), ptr(y), mat(y)[2], M, C, ptr(relu_mask), stream()), "bn_apply_stats")
 
 
-def bn_bwd_partial(dy, y, z, mean_invstd, rows_per_block, partial, relu_ss=None, replicas=0, relu_mask=None, pool=None):
-    """pool=(H, W): dy is the gradient of the pooled map (crog_bn_bwd_partial_pool)."""
+def bn_bwd_partial(dy, y, z, mean_invstd, rows_per_block, partial, relu_ss=None, replicas=0, relu_mask=None, pool=None, stat_sync=None, tail=False):
+    """pool=(H, W): dy is the gradient of the pooled map (crog_bn_bwd_partial_pool).
+    tail: `partial` is [R][C][2] rows + [C][2] totals + a counter word; the last block stores the totals, after exchanging them with the other
+    ranks when stat_sync (rccl.DirectComm.sync_block()) is given (crog_bn_bwd_partial_sync)."""
     M, C, lddy = mat(dy)
+    if tail:
+        Mz = mat(z)[0] if pool is not None else M
+        ldy = mat(y)[2] if y is not None else 0
+        check(lib().crog_bn_bwd_partial_sync(dcode(dy), ptr(dy), lddy, ptr(y), ldy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(relu_ss), Mz, C,
+                                             rows_per_block, ptr(partial), replicas, ptr(relu_mask), pool[0] if pool is not None else 0,
+                                             pool[1] if pool is not None else 0, stat_sync, stream()), "bn_bwd_partial_sync")
+        return
     if pool is not None:
         M = mat(z)[0]
         check(lib().crog_bn_bwd_partial_pool(dcode(dy), ptr(dy), lddy, ptr(z), mat(z)[2], ptr(mean_invstd), ptr(relu_ss), M, C, rows_per_block,

@@ -77,6 +77,16 @@ class SyncBNComm:
                 import warnings
                 warnings.warn(f"crog_amd: direct communicator unavailable ({err!r}); SyncBatchNorm uses torch.distributed on every rank")
 
+    def fuse_ptr(self, n: int):
+        """The kernel-tail form of a BACKWARD statistics exchange of n floats (round 5: the kernel that produces the sums - the first
+        BatchNorm-backward pass or a data-gradient GEMM's bwd_z epilogue - exchanges them in its last block, comm_dev.h): the device
+        block to hand to that kernel, or None when the exchange has to be a launch of its own (no mailboxes, too large for a slot,
+        CROG_SYNCBN_FUSE=0).  Counted in `fused` (bench.py reports both counts)."""
+        if self.direct is None or not self.direct.has_peer or n > self._slot() or _os.environ.get("CROG_SYNCBN_FUSE", "1") == "0":
+            return None
+        self.fused = getattr(self, "fused", 0) + 1
+        return self.direct.sync_block()
+
     def all_reduce_sum(self, t: torch.Tensor):
         self.calls += 1
         if self.direct is not None and t.is_cuda and (self.direct.has_rccl or t.numel() <= self._slot()):

@@ -174,6 +174,17 @@ class DirectComm:
         """In-place RCCL all-reduce of a gradient bucket (crog_allreduce_bucket) on the current stream."""
         K.check(self._lib.crog_allreduce_bucket(self._h, t.data_ptr(), t.numel(), K.dcode(t), 1 if average else 0, K.stream()), "allreduce_bucket")
 
+    def sync_block(self) -> int:
+        """Device address of the block that lets a kernel run an exchange in its own tail (crog_comm_sync_block): what
+        crog_gemm_desc.stat_sync and crog_bn_bwd_partial_sync take.  Needs the peer mailboxes."""
+        if not self.has_peer:
+            raise RuntimeError("DirectComm.sync_block needs the peer mailboxes")
+        if getattr(self, "_sync_ptr", None) is None:
+            p = ctypes.c_void_p()
+            K.check(self._lib.crog_comm_sync_block(self._h, ctypes.byref(p)), "comm_sync_block")
+            self._sync_ptr = p.value
+        return self._sync_ptr
+
     def timed_out(self) -> int:
         """Sequence number of an exchange that gave up waiting for a peer (0 = none).  Synchronises the device."""
         n = ctypes.c_int()

@@ -187,9 +187,15 @@ class Runtime:
         """Inside on_wgrad_stream's closure: on a side stream, or - one-stream runs (bench.py's CROG_SINGLE_STREAM profile mode) - inline, the
         group then goes to the caller's stream when it is flushed (same kernels as the default path, so the single-stream profile shows them)."""
         # (not under DDP: a parked gradient announces itself late, and the bucket all-reduce it completes would start late)
-        if not (self.group_wgrad and not self.deterministic and self.reducer is None and getattr(self, "_in_wgrad", False)):
+        if not (self.group_wgrad and not self.deterministic and getattr(self, "_in_wgrad", False)):
             return False
         return getattr(self, "_override", None) is not None or not self.overlap_wgrad
+
+    def can_park_K(self, Kd: int) -> bool:
+        """Under DistributedDataParallel only SHORT reductions are parked (the text tower's 640 token rows: its buckets complete when its
+        latency-bound chain does, grouped or not); a parked image-tower gradient would announce itself - and start its bucket's
+        all-reduce - a few layers late."""
+        return self.reducer is None or Kd < 4096
 
     @property
     def _group(self):

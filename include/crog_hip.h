@@ -181,6 +181,11 @@ typedef struct crog_gemm_desc {
                         passed.  The gate is then these bits (z alone cannot tell), and a residual R - the identity path's gradient of the
                         NEXT block, whose first convolution this data gradient belongs to - is added BEFORE the gate: the stored
                         g = mask ? acc + R : 0 is at once the layer's gated dy and the gradient of its own identity path.  N % 8 == 0. */
+  const void* stat_sync; /* NULL, or (with bwd_z, stat_replicas = R > 0) the device block of a communicator (crog_comm_sync_block): col_stats is
+                        then [R][N][2] replica rows FOLLOWED by [N][2] totals and one counter word (all zero before the launch), and the block that
+                        finishes last adds the rows up, exchanges the 2 N sums with the other ranks through the peer mailboxes and stores the
+                        totals - the SyncBatchNorm backward exchange (train_crog.py:113-114) without a launch of its own.  The consumer
+                        (crog_bn_bwd_apply) is handed col_stats + R * 2 N with sum_rows = -1. */
 } crog_gemm_desc;
 
 int crog_gemm(const crog_gemm_desc* d, crog_stream_t stream);
@@ -253,6 +258,14 @@ int crog_bn_apply(int dtype, const void* z, int64_t ldz, const float* scale_shif
 int crog_bn_bwd_partial(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
                         int64_t ldz, const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C,
                         int rows_per_block, float* partial, int replicas, const void* relu_mask, crog_stream_t stream);
+/* The same pass (replicas = R > 0 only; H = W = 0, or the pooled form's map size) whose LAST block adds the R rows up, exchanges the 2 C
+ * sums with the other ranks (stat_sync = crog_comm_sync_block's device block; NULL: no exchange, totals only) and stores them behind
+ * the rows: partial = [R][C][2] rows, [C][2] totals, one counter word, all zero before the launch.  crog_bn_bwd_apply then takes
+ * partial + R * 2 C with sum_rows = 1. */
+int crog_bn_bwd_partial_sync(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* z,
+                             int64_t ldz, const float* mean_invstd, const float* relu_scale_shift, int64_t M, int C,
+                             int rows_per_block, float* partial, int replicas, const void* relu_mask, int H, int W,
+                             const void* stat_sync, crog_stream_t stream);
 /* dz = gamma*invstd*(g - sums.g/count - xhat*sums.gx/count);  dres = g when dres != NULL.
  * replicas (partial) / sum_rows (apply) = 0: `partial` is the per-block slab [blocks][C][2] and `sums` the reduced [C][2].
  * replicas = R > 0: the partial kernel adds atomically into a PRE-ZEROED [R][C][2]; the apply kernel is handed the same buffer
@@ -510,6 +523,9 @@ int crog_comm_unique_id(void* id128);
 int crog_comm_init(int rank, int world, const void* id128, void** comm_out);
 int crog_comm_peer_handle(void* comm, int slot_floats, void* handle64);
 int crog_comm_peer_connect(void* comm, const void* handles);
+/* Device-resident block (mailbox pointers, rank, world size, slot size, wait bound) that lets a kernel run an exchange in its own tail:
+ * crog_gemm_desc.stat_sync, crog_bn_bwd_partial_sync.  Needs the peer mailboxes (crog_comm_peer_connect); owned by the communicator. */
+int crog_comm_sync_block(void* comm, void** dev_block);
 int crog_comm_status(void* comm, int* timed_out_seq);
 int crog_syncbn_stats(void* comm, float* ptr, int64_t count, crog_stream_t stream);
 int crog_allreduce_bucket(void* comm, void* ptr, int64_t count, int dtype, int average, crog_stream_t stream);

@@ -4,7 +4,7 @@
 # *_trace.csv.gz as profiles/<tag>_[serial_]kernel_trace.csv.gz) into profiles/: only gpurun_out/ travels back from the GPU box
 # bench.py --steps 3 --warmup 2 executes 7 steps (2 warm-ups, 1 more eager step, capture + first replay, 3 timed replays);
 # --steps 2 --warmup 1 executes 6.
-tag=${1:-r04}
+tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $out/stats.log 2>&1
@@ -19,7 +19,8 @@ cp $out/pmc_keep.json profiles/pmc_traffic.json
 unset CROG_SINGLE_STREAM
 f=$(find $out/stats -name "*kernel_trace.csv" | head -1); python3 scripts/chain_breakdown.py $f > profiles/${tag}_chains.txt 2>&1; python3 scripts/by_grid.py $f 7 140 --last 3 > profiles/${tag}_by_grid.txt 2>&1; python3 scripts/chain_gaps.py $f > profiles/${tag}_chain_gaps.txt 2>&1
 f1=$(find $out/stats1 -name "*kernel_trace.csv" | head -1); python3 scripts/by_grid.py $f1 7 140 --last 3 > profiles/${tag}_serial_by_grid.txt 2>&1
-cp profiles/${tag}_chain_gaps.txt profiles/${tag}_by_grid.txt profiles/${tag}_serial_by_grid.txt profiles/${tag}_summary.md profiles/${tag}_serial_summary.md profiles/${tag}_kernel_stats.csv profiles/${tag}_serial_kernel_stats.csv profiles/pmc_traffic.json profiles/${tag}_chains.txt $out/ 2>/dev/null
+python3 scripts/family_breakdown.py $f 3 > profiles/${tag}_families.txt 2>&1; python3 scripts/family_breakdown.py $f1 3 > profiles/${tag}_serial_families.txt 2>&1
+cp profiles/${tag}_families.txt profiles/${tag}_serial_families.txt profiles/${tag}_traffic_table.md profiles/${tag}_chain_gaps.txt profiles/${tag}_by_grid.txt profiles/${tag}_serial_by_grid.txt profiles/${tag}_summary.md profiles/${tag}_serial_summary.md profiles/${tag}_kernel_stats.csv profiles/${tag}_serial_kernel_stats.csv profiles/pmc_traffic.json profiles/${tag}_chains.txt $out/ 2>/dev/null
 python3 bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.err
 tail -c 1500 $out/bench.json
 tail -3 $out/summarize.log; tail -3 $out/summarize1.log; head -3 profiles/${tag}_chains.txt

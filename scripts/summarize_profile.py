@@ -64,6 +64,10 @@ for k in f:   # one roofline key can cover several tile-shape instantiations of 
     m5 = re.search(r"gemm_ppt_kernel(?:<|ILi)(\d)", k)       # its weight-gradient form (gemm_ppt.hip): <BL, SLAB, D>, A is dy^T
     if m5:
         lay = (2, int(m5.group(1)))
+    if "conv_sw_kernel" in k:                                # the sliding-window 3x3 forward / data gradient (conv_sw.hip): 10 of the family's 53 launches
+        lay = (1, 0)
+    if "wgrad_sw_kernel" in k:                               # ... and the stem / layer1 3x3 weight gradients (wgrad_sw.hip)
+        lay = (2, 3)
     if lay in names and f[k][0]:
         key = names[lay]
         e = pm.setdefault(key, dict(kernels=[], launches=0, _bytes=0.0,
@@ -74,5 +78,19 @@ for k in f:   # one roofline key can cover several tile-shape instantiations of 
 for e in pm.values():
     e["bytes_per_launch"] = round(e.pop("_bytes") / e["launches"])
 if pm: json.dump(pm, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+if tb and not os.environ.get("PROFILE_ENV"):
+    # where the step's HBM bytes go: every kernel's PMC bytes per step, largest first (profiles/<tag>_traffic.md; the text around the table is
+    # written by hand after reading it)
+    T = [f"# HBM traffic per kernel — {tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024)", "",
+         f"Step total {tb/1e9/PMC_STEPS:.1f} GB (algorithmic 56.2 GB: 1.58 GB/img x 32 + 5.6 GB of weight-side traffic).", "",
+         "| GB/step | % | launches/step | MB/launch | read MB | written MB | kernel |", "|---|---|---|---|---|---|---|"]
+    per = []
+    for k in f:
+        if probe(k) or not f[k][0]: continue
+        rd, wr = 2 * f[k][1] * 1024, (w[k][1] if k in w else 0.0) * 1024
+        per.append((rd + wr, f[k][0], rd, wr, k))
+    for b, n, rd, wr, k in sorted(per, reverse=True)[:45]:
+        T.append(f"| {b/1e9/PMC_STEPS:.2f} | {100*b/tb:.1f} | {n/PMC_STEPS:.1f} | {b/n/1e6:.1f} | {rd/n/1e6:.1f} | {wr/n/1e6:.1f} | `{clean(k)[:100]}` |")
+    open(os.path.join(out, f"{tag}_traffic_table.md"), "w").write("\n".join(T) + "\n")
 open(os.path.join(out, f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
 print("\n".join(L[:16]))

@@ -70,6 +70,9 @@ def main():
     res["P"] = model.store.P.cpu().numpy()
     sd = model.state_dict()
     res["bn_final"] = np.concatenate([sd[k].float().cpu().numpy().ravel() for k in meta["bn_keys"]])
+    if world > 1:
+        res["syncbn_launches"] = np.int64(RT.comm.calls)
+        res["syncbn_in_kernel"] = np.int64(getattr(RT.comm, "fused", 0))
     if world > 1 and RT.comm.direct is not None:
         assert RT.comm.direct.timed_out() == 0
     np.savez(os.path.join(out_dir, f"{tag}_rank{rank}_of{world}.npz"), **res)

@@ -215,3 +215,32 @@ def test_eight_rank_ddp_syncbn_over_the_peer_mailboxes(tmp_path):
     print(f"averaged gradient buffer: vs gloo run {rel:.2e}, vs one process {rel1:.2e}")
     assert rel < 2e-2 and rel1 < 2e-2
     assert np.allclose(peer[0]["bn_checksum"], one["bn_checksum"], rtol=1e-4, atol=1e-3)
+
+
+def test_two_rank_bf16_backward_exchanges_ride_in_the_producing_kernels(tmp_path):
+    """Round 5: under SyncBatchNorm the BACKWARD statistics are exchanged by the last block of the kernel that produces them
+    (crog_bn_bwd_partial_sync, crog_gemm_desc.stat_sync: comm_dev.h) instead of by a launch of their own.  Two ranks sharing cuda:0,
+    bf16 (the path with atomic replica rows), statistics through the peer mailboxes: half of the exchanges of a step are in-kernel, both
+    ranks end on identical bits, and the run agrees with the same two ranks exchanging through gloo (launches of their own) and with one
+    process on the whole batch within the bf16 path's run-to-run noise."""
+    kw = dict(size=160, B=8)
+    r0, r1 = _run(2, tmp_path, "bf16", 0.25, tag="fused", extra_env={"CROG_SYNCBN_DIRECT": "peer"}, **kw)
+    u0, u1 = _run(2, tmp_path, "bf16", 0.25, tag="unfused", extra_env={"CROG_SYNCBN_DIRECT": "peer", "CROG_SYNCBN_FUSE": "0"}, **kw)
+    (one,) = _run(1, tmp_path, "bf16", 0.25, tag="one_f", **kw)
+    (two,) = _run(1, tmp_path, "bf16", 0.25, tag="one_f2", **kw)
+    assert int(r0["syncbn_in_kernel"]) > 0 and int(u0["syncbn_in_kernel"]) == 0
+    print(f"exchanges over two steps: fused run {int(r0['syncbn_launches'])} launches + {int(r0['syncbn_in_kernel'])} in-kernel; unfused run {int(u0['syncbn_launches'])} launches")
+    assert int(r0["syncbn_launches"]) + int(r0["syncbn_in_kernel"]) == int(u0["syncbn_launches"])
+    assert int(r0["syncbn_in_kernel"]) >= int(u0["syncbn_launches"]) // 2 - 2      # every backward exchange (the forward's stay launches)
+    assert np.array_equal(r0["G"], r1["G"]) and np.array_equal(r0["P"], r1["P"]) and np.array_equal(r0["bn_final"], r1["bn_final"])
+
+    def rms(a, b):
+        return float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    got, ref = np.concatenate([r0["preds"], r1["preds"]], 0), np.concatenate([u0["preds"], u1["preds"]], 0)
+    floor = rms(two["preds"], one["preds"])
+    print(f"bf16 logits relative RMS: fused vs unfused 2-rank {rms(got, ref):.3e}; fused vs 1-process {rms(got, one['preds']):.3e}; 1-process run-to-run {floor:.3e}")
+    assert rms(got, ref) < max(4 * floor, 2e-2) and rms(got, one["preds"]) < max(4 * floor, 5e-2)
+    ga, gb, gc, gd = (x["G"].astype(np.float64) for x in (r0, u0, one, two))
+    cos = lambda x, y: float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y)))
+    print(f"flat gradient cosine: fused vs unfused {cos(ga, gb):.5f}; fused vs 1-process {cos(ga, gc):.5f}; run-to-run {cos(gd, gc):.5f}")
+    assert cos(ga, gb) > min(0.98, 1 - 4 * (1 - cos(gd, gc))) and cos(ga, gc) > min(0.98, 1 - 4 * (1 - cos(gd, gc)))
