@@ -61,6 +61,10 @@ FUSED_HEAD = True                # fold vis.4 into the dynamic head (no groups*C
 GROUP_BIAS = os.environ.get("CROG_GROUP_BIAS", "1") != "0"        # grouped weight gradients may carry their bias gradient (crog_gemm_group: a_sum blocks)
 GROUP_MIN_K = int(os.environ.get("CROG_GROUP_MIN_K", "512"))      # shortest reduction that is parked for a grouped launch (4096 until round 5)
 GROUP_MAX_TILES = int(os.environ.get("CROG_GROUP_MAX_TILES", "36"))
+# ... and outputs of at most this many 256 x 256 tiles that crog_gemm would give the ping-pong tile ALONE (split 9-16 ways to reach 144 blocks:
+# 9.4 M atomic adds per launch whatever the output size) join a group too, at ~84 k-tiles per block
+GROUP_BIG_TILES = int(os.environ.get("CROG_GROUP_BIG_TILES", "16"))
+GROUP_KT = int(os.environ.get("CROG_GROUP_KT", "120"))      # k-tiles (of 64 rows) per block of a grouped launch
 
 
 class OutRef:
@@ -182,8 +186,8 @@ def wgrad_gemm(dt, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, *, a_off=0, c_of
         # extra blocks of the same launch, and short reductions qualify too (the text tower: 48 linears over 640 token rows, each a
         # latency-bound launch of its own before)
         tiles = ((M + 255) // 256) * ((N + 255) // 256)
-        if tiles <= GROUP_MAX_TILES and K.lib().crog_gemm_wgrad_tile(dt, K.A_MC, b_layout, M, N, Kd) != 256:
-            gsk = max(1, min(16, round(Kd / 64 / 84)))
+        if tiles <= GROUP_MAX_TILES and (tiles <= GROUP_BIG_TILES or K.lib().crog_gemm_wgrad_tile(dt, K.A_MC, b_layout, M, N, Kd) != 256):
+            gsk = max(1, min(16, round(Kd / 64 / GROUP_KT)))
             K.GROUP_SINK = sink = []
             try:
                 K.gemm(dt, K.A_MC, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, a_off=a_off, c_off=c_off, conv=conv, splitk=gsk,
