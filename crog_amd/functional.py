@@ -175,9 +175,6 @@ def wgrad_gemm(dt, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, *, a_off=0, c_of
     park=False: the caller reads the result on the same stream right after this call (a padded scratch gradient that is stripped into the
     real one): the product must not wait for a grouped launch."""
     conv3 = b_layout == K.B_NC_IM2COL
-    pk = RT.parked_K() if RT._groups else None
-    if pk is not None and pk != Kd:
-        RT.flush_group(RT._override)      # the backward pass has moved on to layers of another resolution: what is parked goes now, not at the end
     if (park and (a_sum is None or (GROUP_BIAS and not conv3)) and dt == K.BF16 and RT.can_park() and RT.can_park_K(Kd) and M >= 256 and N >= 256 and M % 8 == 0
             and N % 8 == 0 and Kd >= GROUP_MIN_K and a_off % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and (Kd + 64) * max(lda, ldb) * 2 < 2 ** 31
             and M * ldc < 2 ** 31):
@@ -1472,6 +1469,9 @@ class EmbeddingFn(Function):
                                            dout.shape[0], L, C, tok.rows, K.stream()), "embedding_bwd")
         tok.done()
         pos.done()
+        # the text tower's backward ends here: whatever it still has parked (its first block's projections: 24 blocks) goes now, not at the
+        # end of the image tower's backward 3 ms later, where it sat between the last weight gradient and the last Adam launch (79 us)
+        RT.flush_short_groups()
         return (None,) * 6
 
 

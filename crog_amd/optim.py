@@ -7,9 +7,8 @@ per-parameter views are exposed through `optimizer.state`, so `state_dict()` has
 """
 from __future__ import annotations
 
-from typing import List
-
 import os
+from typing import List
 
 import torch
 
@@ -31,6 +30,10 @@ class FusedAdam(torch.optim.Optimizer):
     # elements per chunk of the overlapped update (16 M floats = 64 MiB of parameters: ~0.1 ms of Adam, nine chunks for CROG-R50)
     CHUNK_ELEMS = 1 << 24
     FIRST_CHUNK_ELEMS = 1 << 20
+    # ... and the second one as well (CROG: the rest of layer2 and the first convolutions of layer3).  A chunk is stepped one chunk LATE, so
+    # with a 16 M-parameter second chunk the end of backward launched the small first chunk AND 16 M parameters (89 us behind the last
+    # weight gradient); now the big one goes when the second completes, ~2 ms before the end
+    SECOND_CHUNK_ELEMS = int(os.environ.get("CROG_ADAM_SECOND_CHUNK", str(1 << 21)))
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, store: ParamStore = None, capturable: bool = False):
         """capturable: the step count, its bias corrections and the learning rates live in device memory (one float[4] per
@@ -98,7 +101,7 @@ class FusedAdam(torch.optim.Optimizer):
             for o, n, p in sorted((store.off(p), (p.numel() + ALIGN - 1) // ALIGN * ALIGN, p) for p in group["params"]):
                 # (the first chunk of a group is kept small: in CROG it holds the stem / layer1 weights, whose gradients are the LAST
                 # of the step - what step() still has to update after backward is then ~1 M parameters, not 16 M)
-                cap = self.FIRST_CHUNK_ELEMS if made == 1 else self.CHUNK_ELEMS
+                cap = self.FIRST_CHUNK_ELEMS if made == 1 else self.SECOND_CHUNK_ELEMS if made == 2 else self.CHUNK_ELEMS
                 if cur is None or cur.off + cur.numel != o or cur.numel + n > cap:
                     cur = _Chunk(gi, o)
                     self._chunks.append(cur)

@@ -20,6 +20,9 @@ from . import kernels as K
 ALIGN = 8  # elements; keeps every parameter 16-byte aligned in the bf16 shadow too
 
 
+_DBG_GROUP = os.environ.get("CROG_DBG_GROUP") == "1"      # print every grouped weight-gradient launch (what was parked together)
+
+
 class Runtime:
     def __init__(self):
         self.comm = None       # object with .world_size and .all_reduce_sum(tensor) for SyncBatchNorm
@@ -200,54 +203,71 @@ class Runtime:
     @property
     def _group(self):
         """Anything parked on any stream?"""
-        return any(g["descs"] for g in self._groups.values())
+        return any(g["descs"] for gs in self._groups.values() for g in gs.values())
 
-    def parked_K(self, stream=None):
-        g = self._groups.get(stream if stream is not None else getattr(self, "_override", None))
-        return g["K"] if g and g["descs"] else None
+    GROUPS_PER_STREAM = 2      # open groups per stream (one per reduction length): the decoder alternates 21632-pixel and 640-token reductions
 
     def park_wgrad(self, desc, blocks, keep, Kd):
+        """Park one weight gradient for a grouped launch on the current weight-gradient stream.  Groups are kept per reduction length
+        (round 5: until then a change of length flushed what was parked, and the decoder, whose cross-attention alternates pixel and
+        token rows, went out in launches of 12-36 blocks); a THIRD length on a stream flushes the oldest group - the backward pass has
+        moved on to layers of another resolution, what is parked goes now, not at the end."""
         s = getattr(self, "_override", None)
-        g = self._groups.get(s)
-        if g is not None and g["descs"] and g["K"] != Kd:
-            self.flush_group(s)      # the backward pass has moved on to layers of another resolution: what is parked goes now, not at the end
-        g = self._groups.setdefault(s, dict(descs=[], keep=[], n=0, K=Kd, done=[]))
-        g["K"] = Kd
+        gs = self._groups.setdefault(s, {})
+        if Kd not in gs:
+            while len(gs) >= self.GROUPS_PER_STREAM:
+                self.flush_group(s, next(iter(gs)), all_streams=False)
+            gs[Kd] = dict(descs=[], keep=[], n=0, K=Kd, done=[])
+        g = gs[Kd]
         g["descs"].append(desc)
         g["keep"].append(keep)
         g["n"] += blocks
         self._arm_end_of_backward()
         if g["n"] >= self.group_blocks or len(g["descs"]) >= 32:
-            self.flush_group(s)
+            self.flush_group(s, Kd, all_streams=False)
+
+    def flush_short_groups(self, below: int = 4096):
+        """Launch the parked groups of token-row reductions (the text tower's: K = batch x context length) on every stream."""
+        for s, gs in list(self._groups.items()):
+            for k in [k for k in gs if k < below]:
+                self.flush_group(s, k, all_streams=False)
 
     def defer_done(self, lo: int, hi: int, fn) -> bool:
         """WRef.done(): is a gradient in the address range [lo, hi) still parked?  Then its announcement waits for that group's launch."""
-        for g in self._groups.values():
-            for d in g["descs"]:
-                c, a = d.C or 0, d.a_sum or 0
-                if lo <= c < hi or lo <= a < hi:
-                    g["done"].append(fn)
-                    return True
+        for gs in self._groups.values():
+            for g in gs.values():
+                for d in g["descs"]:
+                    c, a = d.C or 0, d.a_sum or 0
+                    if lo <= c < hi or lo <= a < hi:
+                        g["done"].append(fn)
+                        return True
         return False
 
-    def flush_group(self, stream=None):
-        """Launch what is parked on `stream` (None: on every stream) - each stream was ordered behind a request's producers when it was
-        parked - then let the announcements that waited for it through (WRef.done)."""
-        for s in ([stream] if stream is not None else list(self._groups)):
-            g = self._groups.get(s)
-            if not g or not g["descs"]:
+    def flush_group(self, stream=None, Kd=None, all_streams=True):
+        """Launch what is parked on `stream` (None with all_streams: on every stream; Kd: only the group of that reduction length) - each
+        stream was ordered behind a request's producers when it was parked - then let the announcements that waited for it through
+        (WRef.done)."""
+        streams = list(self._groups) if (stream is None and all_streams) else [stream]
+        for s in streams:
+            gs = self._groups.get(s)
+            if not gs:
                 continue
-            descs, keep, done = g["descs"], g["keep"], g["done"]
-            g["descs"], g["keep"], g["done"], g["n"] = [], [], [], 0
-            prev = K._STREAM_OVERRIDE
-            K.set_stream_override(s.cuda_stream if s is not None else None)      # (None: parked inline, launched on the caller's stream)
-            try:
-                K.gemm_group(descs)
-            finally:
-                K.set_stream_override(prev)
-            del keep
-            for d in done:
-                d()
+            for k in ([Kd] if Kd is not None else list(gs)):
+                g = gs.pop(k, None)
+                if not g or not g["descs"]:
+                    continue
+                descs, keep, done = g["descs"], g["keep"], g["done"]
+                if _DBG_GROUP:
+                    print(f"[group] stream {'caller' if s is None else hex(s.cuda_stream)} blocks {g['n']} K {g['K']}: " + ", ".join(f"{d.M}x{d.N}/{d.splitk}" for d in descs), flush=True)
+                prev = K._STREAM_OVERRIDE
+                K.set_stream_override(s.cuda_stream if s is not None else None)      # (None: parked inline, launched on the caller's stream)
+                try:
+                    K.gemm_group(descs)
+                finally:
+                    K.set_stream_override(prev)
+                del keep
+                for d in done:
+                    d()
 
     def _issue_wgrad(self, fn, tensors):
         s = self.wgrad_stream()
