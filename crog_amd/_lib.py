@@ -23,7 +23,15 @@ HEADER = os.path.join(REPO, "include", "crog_hip.h")
 LIB_PATH = os.environ.get("CROG_LIB") or os.path.join(ROOT, "libcrog_hip.so")
 BUILD_DIR = os.path.join(ROOT, "csrc", "build")
 SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_ppt.hip", "conv_sw.hip", "wgrad_sw.hip", "gemm_skinny.hip", "norm.hip", "eltwise.hip", "head.hip", "conv_aux.hip", "attn.hip", "ssg.hip", "preprocess.hip", "replay.hip", "comm.hip"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
+# NO_PACKED_F32: the device code is built WITHOUT the packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: what the
+# SLP vectoriser makes of adjacent scalar fp32 operations - 19 880 of them in 236 kernels under plain -O3).  Round 5 found their results wrong
+# in lanes 48-63 of a wave when an MFMA kernel of ANOTHER stream shares the SIMD: the bilinear x2 backward beside a weight-gradient GEMM
+# differed from its serial result in 2997 of 3000 launches (scripts/pk_probe.py), 0 of 3000 without the instructions, and deterministic mode
+# with every side stream went from 11 / 11 differing passes to 0 / 23 (LAB_NOTES section 10).  The host half of the compile does not know
+# the feature and says so ("not a recognized feature for this target (ignoring feature)"): harmless.  scripts/count_pk.py counts them;
+# tests/test_abi_host.py checks that a rebuilt source holds none.
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"] + NO_PACKED_F32
 
 
 class GemmDesc(ctypes.Structure):
@@ -87,7 +95,8 @@ def _needs_rebuild(obj: str, deps):
 def build(verbose: bool = False, force: bool = False) -> str:
     """Compile every HIP source for gfx950 and link crog_amd/libcrog_hip.so (in-tree)."""
     os.makedirs(BUILD_DIR, exist_ok=True)
-    common = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_dma.h"), os.path.join(CSRC, "comm_dev.h"), HEADER]
+    common = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_dma.h"), os.path.join(CSRC, "comm_dev.h"), HEADER,
+              os.path.abspath(__file__)]      # (this file holds the compile flags)
     hipcc = os.environ.get("HIPCC", "hipcc")
 
     def compile_one(src):

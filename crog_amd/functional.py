@@ -662,7 +662,11 @@ class ConvBnAct(Function):
             RT.flush_wgrad()       # (defer_wgrad: the weight gradient parked above forks here, behind the data gradient just enqueued)
             w.done()
         if getattr(RT, "_dbg_dump", None) is not None and getattr(RT, "_fork_ctr", 0) in RT._dbg_dump_at:      # probe only (scripts/det_stress.py)
-            RT._dbg_dump.append((RT._fork_ctr, dict(dy=dy.clone(), dz=dz.clone(), dx=dx.clone() if dx is not None else None, x=x.clone(), z=z.clone())))
+            # (_dbg_ref: keep REFERENCES - no launch is added to the step, whose timing is what the probe is about; they are compared after the pass)
+            cl = (lambda t: t) if getattr(RT, "_dbg_ref", False) else (lambda t: t.clone())
+            loc = locals()
+            RT._dbg_dump.append((RT._fork_ctr, {k_: (cl(v_) if v_ is not None else None) for k_, v_ in
+                                                dict(dy=dy, dz=dz, dx=dx, x=x, z=z, partial=loc.get("partial"), sums=loc.get("sums"), dres=loc.get("dres")).items()}))
         if ctx.dx_slot is not None and dx is not None:      # (see avgpool2: x's other consumer adds this gradient in its own epilogue)
             ctx.dx_slot.put(dx)
             dx = None

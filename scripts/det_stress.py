@@ -29,6 +29,7 @@ if V == "notext":
 b = {k: v.cuda() for k, v in synthetic_batch(B, 416, cfg.word_len, cfg.clip_arch["vocab_size"], seed=9).items()}
 sd = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
 DUMP = [int(v) for v in os.environ.get("DET_DUMP", "").split(",") if v]      # conv-backward call numbers (1-based) whose tensors are cloned and compared
+RT._dbg_ref = os.environ.get("DET_DUMP_REF") == "1"      # references instead of clones: nothing is added to the step (a few copies after the fork hide the effect)
 def grads():
     RT._dbg_dump, RT._dbg_dump_at = ([], set(DUMP)) if DUMP else (None, set())
     model.load_state_dict({**model.state_dict(), **sd})
@@ -57,6 +58,8 @@ for i in range(1, N):
             groups[k] = groups.get(k, 0) + 1
         print(f"run {i}: loss equal {l == l0}; {int(diff.sum())} elements in {len(names)} parameters differ; by module: {groups}")
         for k, t in sorted(dumped().items()):
+            if i == 1:
+                print(f"    (conv backward #{k}: " + ", ".join(f"{nm} {tuple(v.shape)}" for nm, v in t.items() if v is not None) + ")")
             for nm in t:
                 if t[nm] is not None and k in d0 and not torch.equal(t[nm], d0[k][nm]):
                     a, c = t[nm].reshape(-1, t[nm].shape[-1]), d0[k][nm].reshape(-1, t[nm].shape[-1])

@@ -157,3 +157,17 @@ def test_checkpoint_prefix_handling(tmp_path):
     import pytest
     with pytest.raises(KeyError):
         load_checkpoint(p, other)
+
+
+def test_device_code_is_built_without_packed_fp32_instructions(tmp_path):
+    """crog_amd/_lib.py NO_PACKED_F32 (LAB_NOTES section 10): v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 return wrong results in lanes 48-63
+    while another stream's MFMA kernel shares the SIMD, so no kernel of the library may contain them.  Compiles the source that held the kernel
+    the effect was found in (eltwise.hip: 728 of them under plain -O3) to ISA with the library's flags and looks."""
+    assert _lib.NO_PACKED_F32 and all(f in _lib.HIPCC_FLAGS for f in _lib.NO_PACKED_F32)
+    out = tmp_path / "eltwise.s"
+    flags = [f for f in _lib.HIPCC_FLAGS if f != "-fPIC"]
+    subprocess.check_call(["hipcc"] + flags + ["-S", "--cuda-device-only", os.path.join(_lib.CSRC, "eltwise.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    assert "upsample2_bwd_quad_kernel" in text
+    assert not re.search(r"\bv_pk_(fma|mul|add)_f32\b", text)

@@ -1643,3 +1643,50 @@ def test_dgrad_epilogue_does_the_first_batchnorm_backward_pass(K, M, N, K_, relu
     assert (dz_raw.float() - dz_ref.float()).abs().max().item() <= 2e-2 * scale
     assert torch.allclose(dg[1], dg[3], rtol=5e-3, atol=5e-3 * dg[3].abs().max().item())
     assert torch.allclose(dg[0], dg[2], rtol=5e-3, atol=5e-3 * dg[2].abs().max().item() + 1e-3)
+
+
+def test_register_only_kernels_are_stable_beside_another_streams_gemm(K):
+    """Round 5's root cause of "a kernel's result depends on what runs beside it" (LAB_NOTES section 10, scripts/pk_probe.py): built with the
+    packed-fp32 VALU instructions (v_pk_fma_f32 ...: the SLP vectoriser's form of adjacent scalar fp32 operations), the bilinear x2 backward -
+    loads, register arithmetic, stores; no LDS, no cross-lane operation - returned wrong values in lanes 48-63 in 2997 of 3000 launches while a
+    3x3 weight-gradient GEMM ran on another stream.  The library is built without those instructions (crog_amd/_lib.py NO_PACKED_F32): the
+    same launch beside the same GEMM must reproduce its serial result every time; a LayerNorm backward (the kernel rounds 3-4 saw it in) too."""
+    B, H, W, C = 8, 13, 13, 512
+    torch.manual_seed(0)
+    cat = (torch.randn(B, 2 * H, 2 * W, 3 * C, device="cuda") * 0.01).to(torch.bfloat16)
+    dy, dx = cat[..., 2 * C:], torch.empty(B, H, W, C, device="cuda", dtype=torch.bfloat16)
+    x = (torch.randn(B, 2 * H, 2 * W, C, device="cuda") * 0.5).to(torch.bfloat16)
+    G = torch.zeros(C, 9 * C, device="cuda", dtype=torch.float32)
+    rows = B * 2 * H * 2 * W
+    sk = K.pick_splitk(C, 9 * C, rows, 64, conv=True)
+    side = torch.cuda.Stream()
+    # the LayerNorm backward of the decoder's token rows
+    R_, Cn = 2704, 512
+    lx = torch.randn(R_, Cn, device="cuda").to(torch.bfloat16)
+    lw = torch.rand(Cn, device="cuda") + 0.5
+    ldo = (torch.randn(R_, Cn, device="cuda") * 0.1).to(torch.bfloat16)
+    ly, lstats = torch.empty_like(lx), torch.empty(R_, 2, device="cuda")
+    K.ln_fwd(lx, lw, torch.zeros(Cn, device="cuda"), 1e-5, ly, lstats)
+    rpb = K.ln_bwd_rows_per_block(R_)
+    ldx, lpart = torch.empty_like(lx), torch.empty((R_ + rpb - 1) // rpb, Cn, 2, device="cuda")
+
+    def victims():
+        K.upsample2_bwd(dy, dx)
+        K.ln_bwd(ldo, None, lx, lw, lstats, ldx, lpart, rpb)
+
+    victims()
+    torch.cuda.synchronize()
+    ref, lref = dx.clone(), ldx.clone()
+    bad = 0
+    for it in range(300):
+        dx.fill_(7.0)
+        side.wait_stream(torch.cuda.current_stream())
+        K.set_stream_override(side.cuda_stream)
+        try:
+            K.gemm(K.BF16, K.A_MC, K.B_NC_IM2COL, cat, x, G, C, 9 * C, rows, 3 * C, C, 9 * C, a_off=C, conv=(2 * H, 2 * W, C), splitk=sk, out_mode=K.OUT_F32_ATOMIC)
+        finally:
+            K.set_stream_override(None)
+        victims()
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(dx, ref)) + int(not torch.equal(ldx, lref))
+    assert bad == 0, f"{bad} of 600 launches beside a GEMM differ from their serial result"
