@@ -32,6 +32,12 @@ SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_ppt.hip", "conv_sw.hip", 
 # tests/test_abi_host.py checks that a rebuilt source holds none.
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"] + NO_PACKED_F32
+# norm.hip (BatchNorm / LayerNorm / softmax) is compiled WITHOUT fused-multiply-add contraction: its kernels are HBM-bound, and its fp32
+# arithmetic then has the reference's structure - every product rounded, as torch's kernels form them.  y = z * scale + (beta - mean * scale)
+# relies on fl(z * scale) and fl(mean * scale) rounding alike when z is close to the channel's mean (two samples per channel in config 1's
+# BatchNorm1d); contracted, the exact z * scale meets the rounded mean * scale.  Measured on config 1 at B = 2 (tests/test_fulldepth_gpu.py):
+# logits 2.6-2.8e-3 from the float64 result with contraction, 0.7-0.9e-3 without (the reference's own fp32: 1.3e-3).
+EXTRA_FLAGS = {"norm.hip": ["-ffp-contract=off"]}
 
 
 class GemmDesc(ctypes.Structure):
@@ -103,7 +109,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(BUILD_DIR, src.replace(".hip", ".o"))
         if force or _needs_rebuild(o, [s] + common):
-            cmd = [hipcc] + HIPCC_FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + HIPCC_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)

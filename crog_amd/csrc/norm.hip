@@ -95,6 +95,7 @@ __device__ inline void reduce_slab_16(const float* __restrict__ partial, int npa
   __syncthreads();
 }
 // BN forward (single replica): slab -> sums -> scale/shift, mean/invstd, running statistics
+// (this file is compiled with -ffp-contract=off: crog_amd/_lib.py EXTRA_FLAGS says why - y = z * scale + shift wants ROUNDED products)
 __global__ void __launch_bounds__(NT) bn_reduce_finalize_kernel(const float* __restrict__ partial, int nparts, float count,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
@@ -270,18 +271,38 @@ __global__ void __launch_bounds__(NT) bn_apply_stats_kernel(const T* __restrict_
                                                             int C, unsigned char* __restrict__ relu_mask, int poolH, int poolW) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) float ss[];   // [C][2]
+  const bool tiny = M <= 64 && count == (float)M && !poolW;      // local statistics (not SyncBatchNorm totals) over a handful of rows
   for (int c = threadIdx.x; c < C; c += NT) {
     float s = 0.f, q = 0.f;
     for (int r = 0; r < R; r++) {
       s += sums[((long)r * C + c) * 2];
       q += sums[((long)r * C + c) * 2 + 1];
     }
-    const float mean = s / count;
-    const float var = fmaxf(q / count - mean * mean, 0.f);
+    float mean = s / count;
+    float var = fmaxf(q / count - mean * mean, 0.f);
+    if (tiny) {
+      // BatchNorm1d over the rows of a batch (linear_layer, layers.py:14-16: M = B = 2 in config 1): E[x^2] - mean^2 cancels to the last bits
+      // when a channel's two values are close, and the normalisation then amplifies that rounding ~60x (tests/test_fulldepth_gpu.py, B = 2).
+      // With at most 64 rows the channel is simply read twice: mean, then the sum of squared deviations - what torch's two-pass kernel does.
+      float m = 0.f;
+      for (long r = 0; r < M; r++) m += Elem<T>::to_f(z[r * ldz + c]);
+      m /= (float)M;
+      float v = 0.f;
+      for (long r = 0; r < M; r++) {
+        const float d = Elem<T>::to_f(z[r * ldz + c]) - m;
+        v += d * d;
+      }
+      mean = m;
+      var = v / (float)M;
+    }
     const float invstd = rsqrtf(var + eps);
     const float sc = gamma[c] * invstd, sh = beta[c] - mean * sc;
     ss[2 * c] = sc;
     ss[2 * c + 1] = sh;
+    if (tiny) {      // (the launcher sized the LDS for it) the apply loop below subtracts the mean FIRST: see there
+      ss[2 * C + 2 * c] = mean;
+      ss[2 * C + 2 * c + 1] = beta[c];
+    }
     if (blockIdx.x == 0) {
       scale_shift[2 * c] = sc;
       scale_shift[2 * c + 1] = sh;
@@ -331,8 +352,16 @@ __global__ void __launch_bounds__(NT) bn_apply_stats_kernel(const T* __restrict_
     if (res) rv = ldg16(res + r * ldr + c);
     Vec16<T> o;
     float f[VEC];
+    if (tiny) {
+      // (z - mean) * scale + beta, the subtraction first (exact when z is close to the mean): over two samples every z IS close to the mean,
+      // and z * scale + (beta - mean * scale) then rounds at the size of mean * scale, not of the deviation - config 1's B = 2 logits sat
+      // 2.6e-3 from the float64 result with that form against the reference's 1.3e-3
 #pragma unroll
-    for (int e = 0; e < VEC; e++) f[e] = Elem<T>::to_f(v.v[e]) * ss[2 * (c + e)] + ss[2 * (c + e) + 1];
+      for (int e = 0; e < VEC; e++) f[e] = (Elem<T>::to_f(v.v[e]) - ss[2 * C + 2 * (c + e)]) * ss[2 * (c + e)] + ss[2 * C + 2 * (c + e) + 1];
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) f[e] = Elem<T>::to_f(v.v[e]) * ss[2 * (c + e)] + ss[2 * (c + e) + 1];
+    }
     if (res) {
 #pragma unroll
       for (int e = 0; e < VEC; e++) f[e] += Elem<T>::to_f(rv.v[e]);
@@ -1441,7 +1470,8 @@ static int bn_apply_stats_impl(int dtype, const void* z, int64_t ldz, const floa
   CROG_CHECK_ARG(C % vec == 0 && ldz % vec == 0 && ldy % vec == 0 && (!res || ldr % vec == 0), "bn_apply_stats: C/ld must be multiples of %d", vec);
   CROG_CHECK_ARG(sums && replicas >= 1 && count > 0 && scale_shift && mean_invstd && C <= 8192, "bn_apply_stats: bad arguments");
   const int grid = std::min(stream_grid(M * (C / vec)), 1024);   // every block re-derives the C scale/shift pairs: keep the grid modest
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_stats_kernel<T>), dim3(grid), dim3(NT), (size_t)C * 2 * sizeof(float), (hipStream_t)stream,
+  const bool tiny = M <= 64 && count == (float)M && !poolW;      // (the kernel's own test: it then keeps (mean, beta) per channel in LDS as well)
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_stats_kernel<T>), dim3(grid), dim3(NT), (size_t)C * (tiny ? 4 : 2) * sizeof(float), (hipStream_t)stream,
                                        (const T*)z, (long)ldz, sums, replicas, count, gamma, beta, running_mean, running_var, momentum, eps,
                                        scale_shift, mean_invstd, (const T*)res, (long)ldr, relu, (T*)y, (long)ldy, (long)M, C, (unsigned char*)relu_mask,
                                        poolH, poolW));

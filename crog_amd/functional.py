@@ -424,7 +424,14 @@ class ConvBnAct(Function):
                 stats = torch.empty(nparts, C, 2, device=dev, dtype=torch.float32)
                 K.bn_partial_stats(z, stats, rpb)
             mi = torch.empty(C, 2, device=dev, dtype=torch.float32)
-            if RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force):
+            comm_on = RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force)
+            if M <= 64 and not comm_on and stats.shape[0] <= 8:
+                # BatchNorm1d over the rows of a batch (linear_layer, layers.py:14-16): the in-kernel finalisation reads the few rows twice
+                # (mean, then squared deviations) instead of E[x^2] - mean^2, which cancels to the last bits at B = 2 (crog_bn_apply_stats)
+                K.bn_apply_stats(z, stats, stats.shape[0], count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum,
+                                 bn.eps, ss, mi, res, relu, y, relu_mask=rmask)
+                applied = True
+            elif comm_on:
                 sums = RT.zeros(2 * C, dev).view(C, 2)
                 K.reduce_pairs(stats, stats.shape[0], C, sums, zeroed=True)
                 RT.comm.all_reduce_sum(sums)

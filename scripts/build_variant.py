@@ -12,7 +12,7 @@ os.makedirs(os.path.join(ROOT, "crog_amd", "variants"), exist_ok=True)
 out = os.path.join(ROOT, "crog_amd", "variants", f"libcrog_{name}.so")
 def one(src):
     o = os.path.join(bdir, src.replace(".hip", ".o"))
-    r = subprocess.run(["hipcc"] + _lib.HIPCC_FLAGS + flags + ["-c", os.path.join(_lib.CSRC, src), "-o", o], capture_output=True, text=True)
+    r = subprocess.run(["hipcc"] + _lib.HIPCC_FLAGS + _lib.EXTRA_FLAGS.get(src, []) + flags + ["-c", os.path.join(_lib.CSRC, src), "-o", o], capture_output=True, text=True)
     if r.returncode:
         raise SystemExit(r.stderr)
     return o

@@ -1,0 +1,155 @@
+// Minimal form of round 5's finding (LAB_NOTES section 10): do the packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
+// return what two scalar instructions return when ANOTHER stream's kernel shares the SIMD?
+// scripts/pk_probe.py shows it with the library's kernels (the bilinear x2 backward beside a 3x3 weight-gradient GEMM: 2997 of 3000 launches
+// wrong, lanes 48-63, 0 of 3000 once the victim is built without packed fp32).  This file needs nothing but hipcc: a VICTIM whose lanes run
+// the same chain of fused multiply-adds twice - as v_pk_fma_f32 on register pairs and as v_fma_f32 on single registers (inline asm, so that
+// the compiler re-packs nothing) - and count lanes whose two results differ, while an AGGRESSOR of a chosen kind runs on another stream.
+//   build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/pk_min.bin scripts/pk_min.hip
+//   run:    scripts/pk_min.bin [rounds=200]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x)                                                                              \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) {                                                                \
+      printf("%s failed: %s\n", #x, hipGetErrorString(e_));                                \
+      exit(1);                                                                             \
+    }                                                                                      \
+  } while (0)
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+// flavour 0: all operands VGPR pairs; 1: src0 broadcast from its low half (op_sel_hi:[0,1,1], what the compiler emits for a scalar weight);
+// 2: v_pk_mul_f32 by an SGPR pair + v_pk_add_f32
+template <int FL>
+__global__ void __launch_bounds__(256) victim(const float* __restrict__ in, int n, int iters, float ws0, float ws1, float* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  // operands from memory (loads in flight when the arithmetic starts, as in the real kernel)
+  const f32x4 u = *reinterpret_cast<const f32x4*>(in + ((size_t)t * 4) % n);
+  const f32x4 w = *reinterpret_cast<const f32x4*>(in + ((size_t)t * 4 + 1024) % n);
+  f32x2 a = {u[0], u[1]}, b = {u[2], u[3]}, acc = {w[0], w[1]};
+  float a0 = u[0], a1 = u[1], b0 = u[2], b1 = u[3], s0 = w[0], s1 = w[1];
+  f32x2 ws = {ws0, ws1};
+  for (int it = 0; it < iters; it++) {
+    if constexpr (FL == 0) {
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+      asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(a0), "v"(b0));
+      asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(a1), "v"(b1));
+    } else if constexpr (FL == 1) {
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+      asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(a0), "v"(b0));
+      asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(a0), "v"(b1));
+    } else {
+      f32x2 m;
+      asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(m) : "v"(a), "s"(ws));
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(m));
+      float m0, m1;
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m0) : "v"(a0), "s"(ws0));
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1) : "v"(a1), "s"(ws1));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(s0) : "v"(m0));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(s1) : "v"(m1));
+    }
+    // keep the values bounded and changing: a <- 0.5 a + 0.25 (scalar instructions on both copies, identical)
+    a0 = a0 * 0.5f + 0.25f; a1 = a1 * 0.5f + 0.125f;
+    a[0] = a0; a[1] = a1;
+    if ((it & 15) == 15) { acc[0] *= 0.001f; acc[1] *= 0.001f; s0 *= 0.001f; s1 *= 0.001f; }
+  }
+  // both results go to memory; a second kernel compares them (nothing of the comparison is in this kernel's instruction stream)
+  f32x4 o = {acc[0], acc[1], s0, s1};
+  *reinterpret_cast<f32x4*>(out + (size_t)t * 4) = o;
+}
+
+__global__ void __launch_bounds__(256) compare(const unsigned* __restrict__ out, int nthreads, unsigned* errs, unsigned* detail) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nthreads) return;
+  const unsigned p0 = out[(size_t)t * 4], p1 = out[(size_t)t * 4 + 1], q0 = out[(size_t)t * 4 + 2], q1 = out[(size_t)t * 4 + 3];
+  if (p0 != q0 || p1 != q1) {
+    const unsigned k = atomicAdd(&errs[0], 1u);
+    if (k < 8) { detail[6 * k] = (unsigned)(t & 63); detail[6 * k + 1] = p0; detail[6 * k + 2] = q0; detail[6 * k + 3] = p1; detail[6 * k + 4] = q1; detail[6 * k + 5] = (unsigned)(t >> 8); }
+  }
+}
+
+// aggressors: 1 = MFMA only (8 waves per block), 2 = MFMA + LDS traffic + barriers (a GEMM-like loop without memory), 3 = plain fp32 VALU
+__global__ void __launch_bounds__(512) aggressor(int kind, int loops, float* sink) {
+  __shared__ __attribute__((aligned(16))) char smem[65536];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  bf16x8 fa, fb;
+  for (int e = 0; e < 8; e++) { fa[e] = (__bf16)(float)((lane + e) & 7); fb[e] = (__bf16)1.f; }
+  float v = (float)lane;
+  for (int it = 0; it < loops; it++) {
+    if (kind == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[i & 3], 0, 0, 0);
+    } else if (kind == 2) {
+      *reinterpret_cast<bf16x8*>(smem + ((wave * 64 + lane) * 16 + (it & 7) * 8192)) = fa;
+      __syncthreads();
+      const bf16x8 ra = *reinterpret_cast<const bf16x8*>(smem + ((((wave + 1) & 7) * 64 + lane) * 16 + (it & 7) * 8192));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra, fb, acc[i & 3], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int i = 0; i < 64; i++) v = v * 1.0001f + 0.5f;
+    }
+  }
+  if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + v == 12345.678f) sink[0] = v;
+}
+
+int main(int argc, char** argv) {
+  const int rounds = argc > 1 ? atoi(argv[1]) : 200;
+  hipStream_t sa, sv;
+  CK(hipStreamCreate(&sa));
+  CK(hipStreamCreate(&sv));
+  const int n = 1 << 22;
+  float *in, *sink;
+  unsigned *errs, *detail;
+  CK(hipMalloc(&in, n * sizeof(float) + 8192));
+  CK(hipMalloc(&sink, 64));
+  CK(hipMalloc(&errs, 64));
+  CK(hipMalloc(&detail, 512));
+  float* out;
+  CK(hipMalloc(&out, (size_t)2048 * 256 * 16));
+  float* h = (float*)malloc(n * sizeof(float));
+  for (int i = 0; i < n; i++) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+  CK(hipMemcpy(in, h, n * sizeof(float), hipMemcpyHostToDevice));
+  const char* an[] = {"none", "MFMA only", "MFMA + LDS + barriers + s_setprio", "fp32 VALU only"};
+  const char* fn[] = {"v_pk_fma_f32, VGPR pairs", "v_pk_fma_f32 op_sel_hi:[0,1,1]", "v_pk_mul_f32 by an SGPR pair + v_pk_add_f32"};
+  const int loops[] = {0, 4000, 1500, 4000};
+  for (int kind = 0; kind < 4; kind++) {
+    for (int fl = 0; fl < 3; fl++) {
+      for (int big = 0; big < 2; big++) {      // victim grid: 112 blocks (the bilinear backward's) or 2048
+        CK(hipMemset(errs, 0, 64));
+        CK(hipDeviceSynchronize());
+        long lanes = 0;
+        for (int r = 0; r < rounds; r++) {
+          if (kind) hipLaunchKernelGGL(aggressor, dim3(kind == 3 ? 1024 : 256), dim3(512), 0, sa, kind, loops[kind], sink);
+          const int vb = big ? 2048 : 112, it = 256;
+          for (int q = 0; q < 6; q++) {
+            if (fl == 0) hipLaunchKernelGGL(victim<0>, dim3(vb), dim3(256), 0, sv, in, n, it, 0.75f, 0.25f, out);
+            if (fl == 1) hipLaunchKernelGGL(victim<1>, dim3(vb), dim3(256), 0, sv, in, n, it, 0.75f, 0.25f, out);
+            if (fl == 2) hipLaunchKernelGGL(victim<2>, dim3(vb), dim3(256), 0, sv, in, n, it, 0.75f, 0.25f, out);
+            hipLaunchKernelGGL(compare, dim3(vb), dim3(256), 0, sv, (const unsigned*)out, vb * 256, errs, detail);
+            lanes += (long)vb * 256;
+          }
+          CK(hipStreamSynchronize(sv));
+          CK(hipStreamSynchronize(sa));
+        }
+        unsigned he[1], hd[48];
+        CK(hipMemcpy(he, errs, 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hd, detail, 192, hipMemcpyDeviceToHost));
+        printf("aggressor %-34s | victim %-44s %4d blocks | %9ld lane results, packed != scalar: %u\n", an[kind], fn[fl], big ? 2048 : 112, lanes, he[0]);
+        for (unsigned i = 0; i < (he[0] < 3 ? he[0] : 3); i++)
+          printf("      lane %2u of block %u: packed (%.9g, %.9g) scalar (%.9g, %.9g)\n", hd[6 * i], hd[6 * i + 5], *(float*)&hd[6 * i + 1], *(float*)&hd[6 * i + 3], *(float*)&hd[6 * i + 2], *(float*)&hd[6 * i + 4]);
+        fflush(stdout);
+      }
+    }
+  }
+  return 0;
+}
