@@ -84,10 +84,11 @@ __device__ inline Vec16<T> zero16() {
 }
 
 // ---- wave / block reductions ---------------------------------------------------------------
-// Cross-lane exchange through DPP modifiers and v_readlane only: no instruction of these reductions goes to the LDS unit.
-// (__shfl_xor lowers to ds_bpermute_b32, which does.  scripts/det_probe.py, round 5: with the text tower's kernels running beside the
-// image tower's LDS-DMA GEMMs, a LayerNorm backward row - identical operands, bit-identical on a quiet chip - came back with both of
-// its row sums slightly off in 1-2 of 160 rows, in 2-15 % of the passes.)
+// Cross-lane exchange through DPP modifiers and v_readlane only: no instruction of these reductions goes to the LDS unit (__shfl_xor lowers to
+// ds_bpermute_b32, which does: one round trip more per step).  History: round 5 first blamed ds_bpermute_b32 for LayerNorm-backward rows that
+// differed run to run beside another stream's GEMM; the cause was the v_pk_add_f32 pair the compiler made of the two row sums behind each
+// shuffle - the library is built without packed-fp32 instructions now, and the shuffle form (-DCROG_BPERMUTE_SUMS) is clean as well
+// (LAB_NOTES section 10).
 template <int CTRL>
 __device__ inline float dpp_get(float v) {      // the DPP-selected lane's v (every selected lane exists for the controls used here)
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));

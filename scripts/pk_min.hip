@@ -102,6 +102,51 @@ __global__ void __launch_bounds__(512) aggressor(int kind, int loops, float* sin
   if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + v == 12345.678f) sink[0] = v;
 }
 
+// flavour 3: the packed instruction is the FIRST consumer of registers a global load has just written (counted vmcnt waits, four loads in
+// flight per step, the destination registers reused step after step - the shape of the bilinear backward's inner loop); the scalar copy of the
+// same arithmetic reads the same registers a few instructions later
+__global__ void __launch_bounds__(256) victim_ld(const float* __restrict__ in, int n, int iters, float* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  f32x2 acc = {0.f, 0.f};
+  float s0 = 0.f, s1 = 0.f;
+  size_t off = ((size_t)t * 4) % n;
+  for (int it = 0; it < iters; it++) {
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(in + off);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(in + (off + 4096) % n);
+    const f32x4 g2 = *reinterpret_cast<const f32x4*>(in + (off + 8192) % n);
+    const f32x4 g3 = *reinterpret_cast<const f32x4*>(in + (off + 12288) % n);
+#define PK_STEP(G)                                                                                                         \
+    {                                                                                                                      \
+      f32x2 a_ = {G[0], G[1]}, b_ = {G[2], G[3]};                                                                          \
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_));                                          \
+      asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(G[0]), "v"(G[2]));                                          \
+      asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(G[1]), "v"(G[3]));                                          \
+    }
+    PK_STEP(g0) PK_STEP(g1) PK_STEP(g2) PK_STEP(g3)
+#undef PK_STEP
+    off = (off + 16384 + 4 * (size_t)(it & 7)) % n;
+    off &= ~(size_t)3;
+    if ((it & 7) == 7) { acc[0] *= 0.01f; acc[1] *= 0.01f; s0 *= 0.01f; s1 *= 0.01f; }
+  }
+  f32x4 o = {acc[0], acc[1], s0, s1};
+  *reinterpret_cast<f32x4*>(out + (size_t)t * 4) = o;
+}
+
+// the same victim / comparison as C entry points (hipcc -shared -fPIC -DPK_MIN_LIB -o scripts/pk_min.so): scripts/pk_probe.py runs them beside the
+// LIBRARY's weight-gradient GEMM, the neighbour that does trigger the effect
+extern "C" int pk_victim_launch(int fl, int blocks, int iters, const float* in, int n, float* out, void* stream) {
+  if (fl == 0) hipLaunchKernelGGL(victim<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, n, iters, 0.75f, 0.25f, out);
+  if (fl == 1) hipLaunchKernelGGL(victim<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, n, iters, 0.75f, 0.25f, out);
+  if (fl == 2) hipLaunchKernelGGL(victim<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, n, iters, 0.75f, 0.25f, out);
+  if (fl == 3) hipLaunchKernelGGL(victim_ld, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, n, iters, out);
+  return (int)hipGetLastError();
+}
+extern "C" int pk_compare_launch(const float* out, int nthreads, unsigned* errs, unsigned* detail, void* stream) {
+  hipLaunchKernelGGL(compare, dim3((nthreads + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const unsigned*)out, nthreads, errs, detail);
+  return (int)hipGetLastError();
+}
+
+#ifndef PK_MIN_LIB
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 200;
   hipStream_t sa, sv;
@@ -153,3 +198,4 @@ int main(int argc, char** argv) {
   }
   return 0;
 }
+#endif

@@ -60,3 +60,31 @@ for it in range(N):
             print(f"  iteration {it}: {int(d.sum())} elements differ, pixel rows {r.tolist()[:8]}, columns {c.tolist()[:10]} .. {c.tolist()[-2:]}; "
                   f"got {a[:4].float().tolist()} want {b[:4].float().tolist()}")
 print(f"[{os.environ.get('CROG_LIB', 'default build')}] aggressor {AGG} (splitk {sk}): {bad} of {N} launches of the bilinear backward differ from the serial result", flush=True)
+
+# ---- the SYNTHETIC victim of scripts/pk_min.hip (one chain of v_pk_fma_f32 / v_pk_mul_f32 + v_pk_add_f32 per lane against the same chain in
+# scalar instructions, compared by a second kernel) beside the same GEMM: is a bare packed instruction enough, or does it take the real kernel?
+so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pk_min.so")
+if AGG != "none" and os.path.exists(so):
+    import ctypes
+    pk = ctypes.CDLL(so)
+    pk.pk_victim_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    pk.pk_compare_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    n = 1 << 22
+    src = torch.rand(n + 2048, device="cuda") - 0.5
+    names = ["v_pk_fma_f32, VGPR pairs", "v_pk_fma_f32 op_sel_hi:[0,1,1]", "v_pk_mul_f32 by an SGPR pair + v_pk_add_f32", "v_pk_fma_f32 as the first reader of just-loaded registers"]
+    for blocks in (112, 1024):
+        out = torch.empty(blocks * 256 * 4, device="cuda")
+        for fl in range(4):
+            errs, detail = torch.zeros(16, device="cuda", dtype=torch.int32), torch.zeros(64, device="cuda", dtype=torch.int32)
+            main = torch.cuda.current_stream().cuda_stream
+            for it in range(min(N, 1000)):
+                aggressor()
+                for _ in range(4):
+                    assert pk.pk_victim_launch(fl, blocks, 256 if fl < 3 else 48, src.data_ptr(), n, out.data_ptr(), main) == 0
+                    assert pk.pk_compare_launch(out.data_ptr(), blocks * 256, errs.data_ptr(), detail.data_ptr(), main) == 0
+                torch.cuda.synchronize()
+            e = int(errs[0])
+            print(f"synthetic victim ({names[fl]}, {blocks} blocks) beside the GEMM: {e} of {min(N, 1000) * 4 * blocks * 256} lane results packed != scalar", flush=True)
+            if e:
+                d = detail.cpu().tolist()
+                print("    first: lane", d[0], "packed", [hex(d[1] & 0xffffffff), hex(d[3] & 0xffffffff)], "scalar", [hex(d[2] & 0xffffffff), hex(d[4] & 0xffffffff)])
