@@ -240,7 +240,9 @@ def test_bf16_training_step_against_the_reference_under_bf16_autocast():
         # (measured, one deterministic pass: 2.16 % against the reference's 1.15 %).
         # (round 5: the text tower too - the median of seven default-mode passes measured 4.3-4.4 % twice, 3.2 % once, against the
         # reference's 2.7 %: its LayerNorm outputs and residual stream are bf16 where autocast keeps fp32, as in the decoder)
-        mult = 2.0 if (k.endswith(":decoder") or k.endswith(":text tower") or k.startswith("1-cos:")) else 1.5
+        # (end of round 5 - no packed-fp32 instructions, norm.hip unfused: the decoder measures 0.4-0.6 % median / 1.2 % p90 against the reference's
+        # 1.1 % / 2.1 %, the text tower's shape deviation 0.8-1.0 % against 1.3 %: both back on the common 1.5x; single pinned gradients keep 2x)
+        mult = 2.0 if k.startswith("1-cos:") else 1.5
         lim = mult * refd[k] + floor
         if k in ("gnorm_med:text tower", "gnorm_p90:text tower", "gscale:text tower"):
             # Round 5, after five rebuilds of the library moved this ONE number between 3.2 % and 7.4 % (median of seven) with single passes
