@@ -39,7 +39,8 @@ const uint64_t* crog_seed_epoch();
 // deterministic mode (crog_set_deterministic, api.hip): launchers pick order-independent kernels; the scratch holds per-block partials
 bool crog_deterministic();
 float* crog_det_scratch();
-constexpr int CROG_DET_SCRATCH_FLOATS = 8192;
+constexpr int CROG_DET_LOSS_FLOATS = 8192, CROG_DET_TAP_FLOATS = 131072;      // head_loss's per-block partials | head_tap_sums's per-chunk partials
+constexpr int CROG_DET_SCRATCH_FLOATS = CROG_DET_LOSS_FLOATS + CROG_DET_TAP_FLOATS;      // (disjoint regions: the two may run on different streams)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(NT) head_cb_fwd_kernel(const float* __restrict
 }
 // dcb[(b*heads + h)*16 + tap] += sum_p dt[((b*P + p)*heads + h)*16 + tap]      grid (chunks, B), dcb zeroed by the launcher
 template <typename T>
-__global__ void __launch_bounds__(NT) head_tap_sums_kernel(const T* __restrict__ dt, float* __restrict__ dcb, long P, int heads) {
+__global__ void __launch_bounds__(NT) head_tap_sums_kernel(const T* __restrict__ dt, float* __restrict__ dcb, long P, int heads, float* __restrict__ part) {
   const int cols = heads * 16;
   const int groups = NT / cols;
   const int col = threadIdx.x % cols, grp = threadIdx.x / cols;
@@ -158,18 +158,27 @@ __global__ void __launch_bounds__(NT) head_tap_sums_kernel(const T* __restrict__
   const long p0 = blockIdx.x * per, p1 = min(p0 + per, P);
   float acc = 0.f;
   for (long p = p0 + grp; p < p1; p += groups) acc += Elem<T>::to_f(dt[(b * P + p) * cols + col]);
-  if (gridDim.x == 1) {      // deterministic form (one block per sample): the groups' sums meet in LDS and are added in group order
-    __shared__ float red[NT];
+  if (part) {      // deterministic form: the groups' sums meet in LDS and are added in group order; the block's sums go to its row of `part`
+    __shared__ float red[NT];      // ([B][chunks][cols]), which head_tap_sums_final_kernel adds in chunk order
     red[threadIdx.x] = acc;
     __syncthreads();
     if (grp == 0) {
       float s = 0.f;
       for (int q = 0; q < groups; q++) s += red[q * cols + col];
-      dcb[b * cols + col] = s;
+      part[(b * gridDim.x + blockIdx.x) * cols + col] = s;
     }
     return;
   }
   atomicAdd(dcb + b * cols + col, acc);
+}
+__global__ void __launch_bounds__(NT) head_tap_sums_final_kernel(const float* __restrict__ part, float* __restrict__ dcb, int chunks, int cols, int B) {
+  GRID_STRIDE(i, (long)B * cols) {
+    const long b = i / cols;
+    const int col = (int)(i % cols);
+    float s = 0.f;
+    for (int c = 0; c < chunks; c++) s += part[(b * chunks + c) * cols + col];
+    dcb[i] = s;
+  }
 }
 // db5[h*C + c] += sum_{b,tap} dcb[b][h][tap] * w_b[c][tap];   dwpad[b][c][tap] += sum_h b5[h*C + c] * dcb[b][h][tap]
 template <typename T>
@@ -344,8 +353,20 @@ extern "C" int crog_head_tap_sums(int dtype, const void* dt, float* dcb, int B, 
   CROG_CHECK_ARG(heads >= 1 && heads * 16 <= NT, "head_tap_sums: heads must be in [1, %d]", NT / 16);
   hipError_t e = hipMemsetAsync(dcb, 0, (size_t)B * heads * 16 * sizeof(float), (hipStream_t)s);
   if (e != hipSuccess) { crog_set_error("head_tap_sums: memset failed"); return CROG_ERR_LAUNCH; }
-  const int chunks = crog_deterministic() ? 1 : 32;      // one block per sample: ordered sum inside the block
-  DISPATCH_T(dtype, hipLaunchKernelGGL((head_tap_sums_kernel<T>), dim3(chunks, B), dim3(NT), 0, (hipStream_t)s, (const T*)dt, dcb, (long)P, heads));
+  if (crog_deterministic()) {
+    // per-chunk sums into the library's scratch, added in chunk order by a second launch (round 5; one block per sample walked its 10816
+    // pixels alone before: 0.89 ms on the critical chain of the deterministic step)
+    const int cols = heads * 16;
+    const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(32, CROG_DET_TAP_FLOATS / ((int64_t)B * cols)));
+    float* part = crog_det_scratch() + CROG_DET_LOSS_FLOATS;
+    CROG_CHECK_ARG((int64_t)B * cols <= CROG_DET_TAP_FLOATS, "head_tap_sums (deterministic): B * heads * 16 = %ld exceeds the scratch", (long)B * cols);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((head_tap_sums_kernel<T>), dim3(chunks, B), dim3(NT), 0, (hipStream_t)s, (const T*)dt, dcb, (long)P, heads, part));
+    CROG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_tap_sums_final_kernel, dim3(cdiv((long)B * cols, NT)), dim3(NT), 0, (hipStream_t)s, part, dcb, chunks, cols, B);
+    CROG_LAUNCH_CHECK();
+    return CROG_OK;
+  }
+  DISPATCH_T(dtype, hipLaunchKernelGGL((head_tap_sums_kernel<T>), dim3(32, B), dim3(NT), 0, (hipStream_t)s, (const T*)dt, dcb, (long)P, heads, (float*)nullptr));
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
@@ -393,7 +414,7 @@ extern "C" int crog_head_loss(const float* pred, const float* const* targets, in
   hipError_t e = hipMemsetAsync(loss_sums, 0, 5 * sizeof(float), (hipStream_t)s);
   if (e != hipSuccess) { crog_set_error("head_loss: memset failed"); return CROG_ERR_LAUNCH; }
   if (crog_deterministic()) {
-    const int nb = std::min(stream_grid((long)B * H * W), CROG_DET_SCRATCH_FLOATS / 8);
+    const int nb = std::min(stream_grid((long)B * H * W), CROG_DET_LOSS_FLOATS / 8);
     hipLaunchKernelGGL(head_loss_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)s, pred, tg, B, heads, H, W, Hin, Win, weighted, tgt_small, loss_sums, dpred,
                        crog_det_scratch());
     CROG_LAUNCH_CHECK();

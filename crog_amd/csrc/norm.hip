@@ -76,20 +76,34 @@ __global__ void __launch_bounds__(NT) reduce_pairs_kernel(const float* __restric
   if (lane_p == 0 && col < 2 * C) atomicAdd(sums + col, red[0][f] + red[1][f] + red[2][f] + red[3][f]);
 }
 
-// Single-launch reductions of a partial slab [nparts][C][2] (no atomics, no memset): block = 8 channels (16 floats,
-// one 64-byte segment per slab row) x 16 part lanes, LDS tree over the lanes, then the per-channel tail runs in-block.
-__device__ inline void reduce_slab_16(const float* __restrict__ partial, int nparts, int C, float (&red)[16][17], float& out) {
-  const int f = threadIdx.x & 15, lane_p = threadIdx.x >> 4;
-  const int col = blockIdx.x * 16 + f;
+// Single-launch reductions of a partial slab [nparts][C][2] (no atomics, no memset): block = SLAB_CH channels (2 SLAB_CH floats of a slab
+// row) x SLAB_LANES part lanes; every lane adds its rows p = lane, lane + SLAB_LANES, ... in order, thread f < 2 SLAB_CH then adds the lanes'
+// sums in lane order: a FIXED association, so the result is the same bits run after run.  Round 5: 2 channels x 64 lanes instead of 8 x 16
+// - the launch sits between a convolution and its BatchNorm apply on the critical chain, and with 2704 slab rows (346112 pixels) and a grid
+// of 8 blocks it took 21-23 us of pure latency, 140 launches per deterministic step.
+constexpr int SLAB_CH = 2, SLAB_F = 2 * SLAB_CH, SLAB_LANES = NT / SLAB_F;
+__device__ inline void reduce_slab(const float* __restrict__ partial, int nparts, int C, float (&red)[SLAB_LANES][SLAB_F + 1], float& out) {
+  const int f = threadIdx.x % SLAB_F, lane_p = threadIdx.x / SLAB_F;
+  const int col = blockIdx.x * SLAB_F + f;
   float acc = 0.f;
-  if (col < 2 * C)
-    for (int p = lane_p; p < nparts; p += 16) acc += partial[(long)p * 2 * C + col];
+  if (col < 2 * C) {
+    int p = lane_p;
+    for (; p + 3 * SLAB_LANES < nparts; p += 4 * SLAB_LANES) {      // four independent loads in flight, added in row order
+      const float v0 = partial[(long)p * 2 * C + col], v1 = partial[(long)(p + SLAB_LANES) * 2 * C + col];
+      const float v2 = partial[(long)(p + 2 * SLAB_LANES) * 2 * C + col], v3 = partial[(long)(p + 3 * SLAB_LANES) * 2 * C + col];
+      acc += v0;
+      acc += v1;
+      acc += v2;
+      acc += v3;
+    }
+    for (; p < nparts; p += SLAB_LANES) acc += partial[(long)p * 2 * C + col];
+  }
   red[lane_p][f] = acc;
   __syncthreads();
   out = 0.f;
   if (lane_p == 0) {
-#pragma unroll
-    for (int q = 0; q < 16; q++) out += red[q][f];
+#pragma unroll 8
+    for (int q = 0; q < SLAB_LANES; q++) out += red[q][f];
     red[0][f] = out;
   }
   __syncthreads();
@@ -100,12 +114,12 @@ __global__ void __launch_bounds__(NT) bn_reduce_finalize_kernel(const float* __r
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                                                                 float eps, int C, float* __restrict__ scale_shift, float* __restrict__ mean_invstd) {
-  __shared__ float red[16][17];
+  __shared__ float red[SLAB_LANES][SLAB_F + 1];
   float dummy;
-  reduce_slab_16(partial, nparts, C, red, dummy);
+  reduce_slab(partial, nparts, C, red, dummy);
   const int t = threadIdx.x;
-  const int c = blockIdx.x * 8 + t;
-  if (t < 8 && c < C) {
+  const int c = blockIdx.x * SLAB_CH + t;
+  if (t < SLAB_CH && c < C) {
     const float mean = red[0][2 * t] / count;
     float var = red[0][2 * t + 1] / count - mean * mean;
     var = fmaxf(var, 0.f);
@@ -125,12 +139,12 @@ __global__ void __launch_bounds__(NT) bn_reduce_finalize_kernel(const float* __r
 // backward-side: slab -> sums[C][2] (optional) and the two per-channel vectors a[c] = sum of .x, b[c] = sum of .y
 __global__ void __launch_bounds__(NT) reduce_split_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ sums,
                                                           float* __restrict__ a, float* __restrict__ b) {
-  __shared__ float red[16][17];
+  __shared__ float red[SLAB_LANES][SLAB_F + 1];
   float dummy;
-  reduce_slab_16(partial, nparts, C, red, dummy);
+  reduce_slab(partial, nparts, C, red, dummy);
   const int t = threadIdx.x;
-  const int col = blockIdx.x * 16 + t;
-  if (t < 16 && col < 2 * C) {
+  const int col = blockIdx.x * SLAB_F + t;
+  if (t < SLAB_F && col < 2 * C) {
     const float v = red[0][t];
     if (sums) sums[col] = v;
     // a / b are gradient vectors of the flat buffer: ADD (torch accumulates gradients until zero_grad; a shared norm that is
@@ -1395,7 +1409,7 @@ extern "C" int crog_bn_partial_stats(int dtype, const void* x, int64_t M, int C,
 extern "C" int crog_reduce_pairs(const float* partial, int nparts, int C, float* sums, int sums_is_zero, crog_stream_t stream) {
   CROG_CHECK_ARG(nparts > 0 && C > 0, "reduce_pairs: bad sizes");
   if (crog_deterministic()) {      // one block per 8 channels walks the slab in order and STORES the sums: no atomics, no memset needed
-    hipLaunchKernelGGL(reduce_split_kernel, dim3(cdiv(C, 8)), dim3(NT), 0, (hipStream_t)stream, partial, nparts, C, sums, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(reduce_split_kernel, dim3(cdiv(C, SLAB_CH)), dim3(NT), 0, (hipStream_t)stream, partial, nparts, C, sums, (float*)nullptr, (float*)nullptr);
     CROG_LAUNCH_CHECK();
     return CROG_OK;
   }
@@ -1681,7 +1695,7 @@ extern "C" int crog_bn_reduce_finalize(const float* partial, int nparts, float c
                                        float* running_mean, float* running_var, float momentum, float eps, int C, float* scale_shift,
                                        float* mean_invstd, crog_stream_t stream) {
   CROG_CHECK_ARG(nparts > 0 && C > 0 && count > 0, "bn_reduce_finalize: bad sizes");
-  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(C, 8)), dim3(NT), 0, (hipStream_t)stream, partial, nparts, count, gamma, beta,
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(C, SLAB_CH)), dim3(NT), 0, (hipStream_t)stream, partial, nparts, count, gamma, beta,
                      running_mean, running_var, momentum, eps, C, scale_shift, mean_invstd);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
@@ -1689,7 +1703,7 @@ extern "C" int crog_bn_reduce_finalize(const float* partial, int nparts, float c
 
 extern "C" int crog_reduce_split(const float* partial, int nparts, int C, float* sums, float* a, float* b, crog_stream_t stream) {
   CROG_CHECK_ARG(nparts > 0 && C > 0, "reduce_split: bad sizes");
-  hipLaunchKernelGGL(reduce_split_kernel, dim3(cdiv(C, 8)), dim3(NT), 0, (hipStream_t)stream, partial, nparts, C, sums, a, b);
+  hipLaunchKernelGGL(reduce_split_kernel, dim3(cdiv(C, SLAB_CH)), dim3(NT), 0, (hipStream_t)stream, partial, nparts, C, sums, a, b);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

@@ -42,7 +42,11 @@ def _pad(n: int, m: int) -> int:
 
 # Policy constants of the operator layer.  They were environment switches while rounds 1-2 measured them (DESIGN.md section 4 has the
 # numbers); the measured winners are now fixed, and tests that compare two forms set the module attribute.
-FUSED_REDUCE_MAX_PARTS = 256     # BatchNorm slab reductions up to this many partial rows are folded into the finalize launch
+# BatchNorm slab reductions up to this many partial rows are folded into the finalize launch (ordered: same bits run after run).  256 until
+# round 5; longer slabs then went through crog_reduce_pairs' atomic adds, and the fp32 parity path was NOT bit-reproducible on layers of more
+# than 32768 rows (scripts/fp32_repro.py: config 1's logits differed in every pass).  The ordered reduction walks 64 rows at a time now
+# (norm.hip reduce_slab): every slab takes it.
+FUSED_REDUCE_MAX_PARTS = 1 << 30
 FLASH_ATTN = True                # fused attention kernels (csrc/attn.hip) where they apply; tests compare with the unfused path
 FLASH_MIN_KEYS = 64
 FLASH_CAUSAL = os.environ.get("CROG_FLASH_CAUSAL", "1") != "0"      # causal self-attention (the CLIP text tower) through the fused kernels too
