@@ -84,6 +84,8 @@ class SyncBNComm:
         CROG_SYNCBN_FUSE=0).  Counted in `fused` (bench.py reports both counts)."""
         if self.direct is None or not self.direct.has_peer or n > self._slot() or _os.environ.get("CROG_SYNCBN_FUSE", "1") == "0":
             return None
+        if not getattr(self.direct, "tail_ok", False) and getattr(self.direct, "selftested", False):
+            return None      # the tail form failed its start-up self-test on some rank: exchanges stay launches of their own
         self.fused = getattr(self, "fused", 0) + 1
         return self.direct.sync_block()
 

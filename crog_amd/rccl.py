@@ -50,15 +50,17 @@ class DirectComm:
         self._h = ctypes.c_void_p()
         self.rank = self.world_size = 0
         self.has_rccl = self.has_peer = False
+        self.tail_ok = False      # the kernel-tail exchange passed its self-test on every rank (create(selftest=True))
         self._lib = None
 
     @classmethod
-    def create(cls, group=None, device=None, rccl: bool = True, peer: bool = True, lib=None, selftest: bool = False):
+    def create(cls, group=None, device=None, rccl: bool = True, peer: bool = True, lib=None, selftest: bool = False, tail: bool = True):
         """-> (comm, None) on every rank, or (None, reason) on every rank.  rccl: build the RCCL communicator (needs one GPU per
         rank); peer: build the hipIpc mailboxes of the one-shot statistics exchange.  `lib` replaces the C ABI (protocol tests).
         selftest: after the set-up, every transport exchanges a known vector once; a transport that does not return the right sums on
         EVERY rank (collective verdict) is dropped - the mailbox by rebuilding the communicator without it - and if nothing is left the
-        result is (None, reason) everywhere: what `crog_amd.parallel` uses to pick peer / rccl / torch.distributed by itself."""
+        result is (None, reason) everywhere: what `crog_amd.parallel` uses to pick peer / rccl / torch.distributed by itself.
+        tail: also self-test the kernel-tail form of the mailbox exchange (round 5); a failure rebuilds everything with it switched off."""
         if device is None:
             dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         else:
@@ -92,7 +94,7 @@ class DirectComm:
             if rccl and peer:
                 # ncclCommInitRank failed somewhere (every rank takes this branch: the verdict is collective): the mailbox transport does
                 # not need RCCL - try it alone before giving the statistics back to torch.distributed
-                return cls.create(group, device, rccl=False, peer=True, lib=lib, selftest=selftest)
+                return cls.create(group, device, rccl=False, peer=True, lib=lib, selftest=selftest, tail=tail)
             return None, err or RuntimeError("crog_comm_init failed on another rank")
         if peer:
             handle = (ctypes.c_char * 64)()
@@ -116,6 +118,7 @@ class DirectComm:
                 self.close()
                 return None, err or RuntimeError("opening a peer mailbox failed on another rank")
         if selftest and dev.type == "cuda":
+            self.selftested = True
             ok_peer, ok_rccl = self._selftest(dev)
             peer_ok = (not self.has_peer) or _all_agree(ok_peer, group, dev)
             rccl_ok = (not self.has_rccl) or _all_agree(ok_rccl, group, dev)
@@ -126,7 +129,15 @@ class DirectComm:
                 keep_rccl, keep_peer = self.has_rccl and rccl_ok, self.has_peer and peer_ok
                 if not (keep_rccl or keep_peer):
                     return None, RuntimeError("communicator self-test failed (peer mailbox: %s, RCCL: %s)" % (peer_ok, rccl_ok))
-                return cls.create(group, device, rccl=keep_rccl, peer=keep_peer, lib=lib, selftest=True)
+                return cls.create(group, device, rccl=keep_rccl, peer=keep_peer, lib=lib, selftest=True, tail=tail)
+            if self.has_peer and tail:
+                # the kernel-tail form of the exchange (crog_bn_bwd_partial_sync / crog_gemm_desc.stat_sync) on known sums; a failure on any
+                # rank may leave a mailbox dead, so everything is rebuilt with that form switched off (SyncBNComm.fuse_ptr then returns None
+                # and the 71 backward exchanges stay launches of their own)
+                if not _all_agree(self._selftest_tail(dev), group, dev):
+                    self.close()
+                    return cls.create(group, device, rccl=self.has_rccl, peer=True, lib=lib, selftest=True, tail=False)
+                self.tail_ok = True
         return self, None
 
     def _selftest(self, dev):
@@ -163,6 +174,25 @@ class DirectComm:
         except Exception:
             ok_rccl = False
         return ok_peer, ok_rccl
+
+    def _selftest_tail(self, dev) -> bool:
+        """The first BatchNorm-backward pass with the exchange in its tail, eight times back to back (both slot parities, no host
+        synchronisation in between): rank r's gradient is r + 1 everywhere and x-hat is 1, so every channel's two totals must come back as
+        M W (W + 1) / 2 - exact in fp32."""
+        try:
+            W, C, M, R = self.world_size, 64, 4096, 2
+            dy = torch.full((M, C), float(self.rank + 1), device=dev, dtype=torch.bfloat16)
+            z = torch.ones(M, C, device=dev, dtype=torch.bfloat16)
+            mi = torch.tensor([0.0, 1.0], device=dev).repeat(C).view(C, 2).contiguous()
+            rpb = K.bn_rows_per_block(M)
+            bufs = [torch.zeros(R * 2 * C + 2 * C + 8, device=dev) for _ in range(8)]
+            for buf in bufs:
+                K.bn_bwd_partial(dy, None, z, mi, rpb, buf, None, replicas=R, stat_sync=self.sync_block(), tail=True)
+            want = float(M * W * (W + 1) // 2)
+            ok = all(bool((buf[R * 2 * C:(R + 1) * 2 * C] == want).all()) for buf in bufs)
+            return ok and self.timed_out() == 0
+        except Exception:
+            return False
 
     def all_reduce_sum(self, t: torch.Tensor):
         """In-place fp32 sum over the ranks, enqueued on the stream the caller's kernels run on (crog_syncbn_stats)."""
