@@ -179,6 +179,7 @@ def wgrad_gemm(dt, b_layout, dy, x, G, M, N, Kd, lda, ldb, ldc, *, a_off=0, c_of
     park=False: the caller reads the result on the same stream right after this call (a padded scratch gradient that is stripped into the
     real one): the product must not wait for a grouped launch."""
     conv3 = b_layout == K.B_NC_IM2COL
+    RT.note_wgrad()
     if (park and (a_sum is None or (GROUP_BIAS and not conv3)) and dt == K.BF16 and RT.can_park() and RT.can_park_K(Kd) and M >= 256 and N >= 256 and M % 8 == 0
             and N % 8 == 0 and Kd >= GROUP_MIN_K and a_off % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and (Kd + 64) * max(lda, ldb) * 2 < 2 ** 31
             and M * ldc < 2 ** 31):

@@ -166,6 +166,7 @@ class GraphedTrainStep:
             opt._store.request_zero()      # (engine.train_step: the gradient memset may run on the forward's side stream)
         with torch.autocast("cuda", dtype=adt or torch.bfloat16, enabled=adt is not None):
             pred, target, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
+        m = Fn.train_metric(pred[0], target[0], 0.35, 0.5)      # (beside the start of backward, not behind the last Adam launch: engine.train_step)
         opt.zero_grad()
         max_norm = getattr(self.args, "max_norm", 0.0) if self.args is not None else 0.0
         from .engine import ADAM_OVERLAP
@@ -175,7 +176,6 @@ class GraphedTrainStep:
         if max_norm:
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
         opt.step()
-        m = Fn.train_metric(pred[0], target[0], 0.35, 0.5)
         stats = torch.stack([loss.detach().float(), m[0], m[1]])
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             from .parallel import all_reduce_mean_

@@ -218,12 +218,26 @@ class Runtime:
                 self.flush_group(s, next(iter(gs)), all_streams=False)
             gs[Kd] = dict(descs=[], keep=[], n=0, K=Kd, done=[])
         g = gs[Kd]
+        g["last"] = getattr(self, "_wgrad_calls", 0)
         g["descs"].append(desc)
         g["keep"].append(keep)
         g["n"] += blocks
         self._arm_end_of_backward()
         if g["n"] >= self.group_blocks or len(g["descs"]) >= 32:
             self.flush_group(s, Kd, all_streams=False)
+
+    GROUP_STALE = int(os.environ.get("CROG_GROUP_STALE", "8"))
+
+    def note_wgrad(self):
+        """Every weight gradient passes here (functional.wgrad_gemm), parked or not: a group that nothing has joined for GROUP_STALE weight
+        gradients goes now - the backward pass has left its layers.  (Without this the remainders of layer3 and layer2 - 99 and 143 blocks,
+        just under the launch threshold - waited for the end of backward, where they ran alone behind the last weight gradient: 0.6 ms of
+        the step's tail in profiles/r05_kernel_trace; layer1's and the stem's weight gradients are never parked, so no third reduction
+        length arrived to push them out.  Flushing on every other length instead cut the neck's groups into launches of 16-36 blocks.)"""
+        self._wgrad_calls = n = getattr(self, "_wgrad_calls", 0) + 1
+        for s, gs in list(self._groups.items()):
+            for k in [k for k, g in gs.items() if g["descs"] and n - g.get("last", n) >= self.GROUP_STALE]:
+                self.flush_group(s, k, all_streams=False)
 
     def flush_short_groups(self, below: int = 4096):
         """Launch the parked groups of token-row reductions (the text tower's: K = batch x context length) on every stream."""
