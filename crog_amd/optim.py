@@ -15,6 +15,12 @@ import torch
 from . import kernels as K
 from .runtime import ALIGN, RT, ParamStore
 
+# 0 (default since the end of round 5): a chunk is stepped the moment its last announcement arrives; 1: when the NEXT chunk completes (rounds 4-5:
+# a margin for an announcement that came before the last reader of the weight was enqueued - WRef.done() is placed behind that reader everywhere,
+# and scripts/adam_late_check.py / tests/test_engine_gpu.py hold the parameters and both moments to the bits of the update done in step()).
+# The margin kept the text tower's last 15.8 M-parameter chunk until the end of backward: 83 us of the step's tail.
+ADAM_LATE = int(os.environ.get("CROG_ADAM_LATE", "0"))
+
 
 class _Chunk:
     """A contiguous piece of one learning-rate segment of the flat buffer: the unit of the overlapped update."""
@@ -234,6 +240,9 @@ class FusedAdam(torch.optim.Optimizer):
             return
         c.pending -= 1
         if c.pending == 0:
+            if ADAM_LATE == 0:
+                self._launch_chunk(c, early=True)
+                return
             for r in self._ripe:
                 self._launch_chunk(r, early=True)
             self._ripe = [c]

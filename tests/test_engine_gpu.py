@@ -224,6 +224,24 @@ def test_adam_chunks_stepped_inside_backward_see_the_final_gradients(capturable,
         opt.step()
 
 
+def test_overlapped_adam_leaves_the_bits_of_the_update_done_in_step():
+    """Full-depth CROG-R50 bf16, deterministic mode (every side stream on), four optimizer steps: the overlapped update (chunks stepped
+    inside backward the moment their last gradient is announced) must leave the SAME bits in the parameters and both Adam moments as the
+    update done after backward (CROG_ADAM_OVERLAP=0) - a chunk stepped before its gradient was final, or a weight updated under a data
+    gradient that still reads it, would show (scripts/adam_late_check.py prints the checksums; engine.train_step, crog_engine.py:77-84)."""
+    import subprocess
+    out = {}
+    for tag, env in (("in step()", {"CROG_ADAM_OVERLAP": "0"}), ("overlapped", {})):
+        e = {k: v for k, v in os.environ.items() if k not in ("CROG_ADAM_OVERLAP", "CROG_ADAM_LATE")}
+        e.update(env)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "adam_late_check.py")], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("P ")][-1].split()
+        out[tag] = (line[1], line[3], line[5], int(line[-1]))
+    assert out["in step()"][:3] == out["overlapped"][:3], out
+    assert out["in step()"][3] == 0 and out["overlapped"][3] >= 20, out
+
+
 def test_decoder_return_intermediate_outputs():
     """layers.py:259-274: with return_intermediate the decoder returns the final-norm'd output of EVERY layer; the last entry is what
     the plain call returns.  CROG.forward fails on that list exactly as the reference does (crog.py:69)."""
