@@ -23,6 +23,13 @@ ALIGN = 8  # elements; keeps every parameter 16-byte aligned in the bf16 shadow 
 _DBG_GROUP = os.environ.get("CROG_DBG_GROUP") == "1"      # print every grouped weight-gradient launch (what was parked together)
 
 
+# Under DistributedDataParallel, park image-tower weight gradients for grouped launches too (until the end of round 5 only the text tower's: a
+# parked gradient announces itself - and starts its bucket's all-reduce - when its group goes out).  With the stale-group rule (note_wgrad) that
+# is at most a few layers late, and the last bucket's layers (stem, layer1) are never parked: forced DDP 30.6 -> 30.0-30.5 ms.  CROG_DDP_PARK_ALL=0
+# restores the old rule.
+DDP_PARK_ALL = os.environ.get("CROG_DDP_PARK_ALL", "1") == "1"
+
+
 class Runtime:
     def __init__(self):
         self.comm = None       # object with .world_size and .all_reduce_sum(tensor) for SyncBatchNorm
@@ -194,10 +201,9 @@ class Runtime:
         return getattr(self, "_override", None) is not None or not self.overlap_wgrad
 
     def can_park_K(self, Kd: int) -> bool:
-        """Under DistributedDataParallel only SHORT reductions are parked (the text tower's 640 token rows: its buckets complete when its
-        latency-bound chain does, grouped or not); a parked image-tower gradient would announce itself - and start its bucket's
-        all-reduce - a few layers late."""
-        return self.reducer is None or Kd < 4096
+        """Which reduction lengths may be parked under DistributedDataParallel: all (DDP_PARK_ALL above), or only the text tower's 640 token
+        rows (its buckets complete when its latency-bound chain does, grouped or not)."""
+        return self.reducer is None or Kd < 4096 or DDP_PARK_ALL
 
     @property
     def _group(self):
