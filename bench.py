@@ -463,7 +463,7 @@ def main():
             if RT.comm is not None:
                 RT.comm.check()      # a timed-out mailbox exchange poisons the statistics: never report a throughput measured on it
             out["collectives_per_step"] = {"syncbn_allreduce": sb,
-                                           "syncbn_exchanges_inside_a_producing_kernel": fb,
+                                           "syncbn_exchanges_inside_or_right_behind_a_producing_kernel": fb,
                                            "gradient_buckets": gb,
                                            "syncbn_transport": RT.comm.kind if RT.comm is not None else None,
                                            "bucket_transport": "crog_comm:rccl" if getattr(net, "bucket_comm", None) is not None else "torch.distributed",

@@ -1831,6 +1831,13 @@ inline int pp_rows(const crog_gemm_desc& d) {
   return (c192 * 11 < c256 * 10 && crog_gemm_pp_eligible(d, 192)) ? 192 : 256;      // (a 192-row tile runs ~10 % below the 256-row tile's rate per row)
 }
 
+// forward statistics + stat_sync: did the launched kernel carry the exchange in its own tail (the ping-pong tile), or does crog_gemm add the
+// single-block finish launch behind it?
+static thread_local bool g_fwd_tail = false;
+__global__ void __launch_bounds__(256) stat_sync_finish_kernel(const CrogSyncBlock* sb, float* sums, int R, int n2) {
+  crog_stat_sync_tail(sb, sums, R, n2, 1u);
+}
+
 template <typename T, bool HWTR>
 int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
   if (d.bwd_z) {      // BatchNorm-backward statistics: one dedicated tile, the three data-gradient layouts
@@ -1893,7 +1900,10 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
       // two- and four-k-tile launches that only these epilogues have lose 13-50 %: the ring fill is most of their run)
       if (lean || (pp_full && !(d.debug & 131072) && (d.K >= 512 || (d.debug & (512 | 1024))) && crog_gemm_pp_full_epilogue_ok(d))) {
         const int rows = pp_rows(d);
-        if (rows) return crog_gemm_pp_launch(d, rows, (d.debug >> 12) & 7, s, !lean);
+        if (rows) {
+          g_fwd_tail = true;      // (gemm_pp_kernel<.., EPI 0 / 1> ends with crog_stat_sync_tail when stat_sync is set)
+          return crog_gemm_pp_launch(d, rows, (d.debug >> 12) & 7, s, !lean);
+        }
       }
     }
     if constexpr (sizeof(T) == 2) {
@@ -2031,11 +2041,19 @@ extern "C" int crog_gemm(const crog_gemm_desc* dp, crog_stream_t stream) {
                        d.ldz % vec == 0 && ((uintptr_t)d.bwd_z % 16) == 0 && d.act == CROG_ACT_NONE && (!d.bwd_mask || d.N % 8 == 0),
                    "crog_gemm: bwd_z needs bf16 dtype output, col_stats with stat_replicas > 0, no activation, even N (a multiple of 8 with bwd_mask), aligned z");
   CROG_CHECK_ARG(!d.bwd_mask || d.bwd_z, "crog_gemm: bwd_mask only with bwd_z");
-  CROG_CHECK_ARG(!d.stat_sync || d.bwd_z, "crog_gemm: stat_sync (an exchange in the kernel's tail) only with bwd_z");
+  CROG_CHECK_ARG(!d.stat_sync || d.bwd_z || (d.col_stats && d.stat_replicas > 0 && d.dtype == CROG_BF16),
+                 "crog_gemm: stat_sync (an exchange in the kernel's tail) needs bwd_z, or forward statistics in replica rows (bf16)");
   CROG_CHECK_ARG(!d.a_sum || d.batch == 1, "crog_gemm: a_sum needs batch == 1");
   CROG_CHECK_ARG((long)d.batch * d.splitk <= 65535, "crog_gemm: batch*splitk too large");
   hipStream_t s = (hipStream_t)stream;
-  if (d.dtype == CROG_BF16) return dispatch_shape<bf16, true>(d, s);
-  return dispatch_shape<float, true>(d, s);
+  g_fwd_tail = false;
+  const int rc = d.dtype == CROG_BF16 ? dispatch_shape<bf16, true>(d, s) : dispatch_shape<float, true>(d, s);
+  if (rc == CROG_OK && d.stat_sync && !d.bwd_z && !g_fwd_tail) {
+    // SyncBatchNorm forward statistics behind a kernel that does not carry the exchange in its own tail (everything but the ping-pong tile):
+    // one single-block launch adds the replica rows up and runs it - the same totals in the same place for the consumer
+    hipLaunchKernelGGL(stat_sync_finish_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const CrogSyncBlock*>(d.stat_sync), d.col_stats, d.stat_replicas, 2 * d.N);
+    CROG_LAUNCH_CHECK();
+  }
+  return rc;
 }
 #endif  // CROG_GEMM_PROBE

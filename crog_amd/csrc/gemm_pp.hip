@@ -371,6 +371,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  if constexpr (EPI != 2) {
+    // SyncBatchNorm FORWARD: the block that takes the last ticket adds the replica rows of (sum x, sum x^2) up and exchanges them with the other
+    // ranks (crog_gemm_desc.stat_sync, comm_dev.h) - at the very END of the kernel, where no accumulator is live any more
+    if (p.stat_sync && p.col_stats) crog_stat_sync_tail(reinterpret_cast<const CrogSyncBlock*>(p.stat_sync), p.col_stats, p.stat_replicas, 2 * p.N, gridDim.x);
+  }
 }
 
 template <int AL, int RBQ, int D, int EPI = 0>

@@ -50,6 +50,7 @@ FUSED_REDUCE_MAX_PARTS = 1 << 30
 FLASH_ATTN = True                # fused attention kernels (csrc/attn.hip) where they apply; tests compare with the unfused path
 FLASH_MIN_KEYS = 64
 FLASH_CAUSAL = os.environ.get("CROG_FLASH_CAUSAL", "1") != "0"      # causal self-attention (the CLIP text tower) through the fused kernels too
+FWD_STAT_SYNC = os.environ.get("CROG_SYNCBN_FUSE_FWD", "1") != "0"      # SyncBatchNorm forward exchanges in / behind the statistics GEMM (round 5)
 BN_ATOMIC_STATS = True           # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize (bf16)
 RELU_BITMASK = True              # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
 LN_BWD_ATOMIC = False            # LayerNorm parameter gradients through atomics in ln_bwd itself: measured 0.5 % SLOWER (every block adds into the same 2 C floats)
@@ -376,6 +377,7 @@ class ConvBnAct(Function):
                 wcols = dst_cols * (9 if ksize == 3 else 1)
         stats = None
         stat_R = 0
+        fwd_sync = None
         if ksize == 0:
             z = x
         else:
@@ -389,18 +391,21 @@ class ConvBnAct(Function):
                     # statistics accumulate atomically into R pre-zeroed [C][2] rows in the GEMM epilogue and are finalised
                     # inside bn_apply: GEMM -> (all-reduce of all R rows) -> apply, no reduction / finalize launches in between
                     stat_R = stat_replicas(slabs, C)
-                    stats = RT.zeros(stat_R * C * 2, dev)
+                    # SyncBatchNorm: the exchange of the (sum x, sum x^2) totals rides in the tail of the GEMM that accumulates them (the
+                    # ping-pong tile) or in a single-block launch crog_gemm adds behind any other kernel: [R rows][totals][ticket]
+                    fwd_sync = RT.comm.fuse_ptr(2 * C) if (comm_on and FWD_STAT_SYNC) else None
+                    stats = RT.zeros(stat_R * C * 2 + (2 * C + 8 if fwd_sync is not None else 0), dev)
                 else:
                     stats = torch.empty(slabs, C, 2, device=dev, dtype=torch.float32)
             if ksize == "s":
                 patches = torch.empty(M, 32, device=dev, dtype=dtype)
                 K.stem_im2col(x, patches)
-                K.gemm(dt, K.A_KC, K.B_KC, patches, wt, z, M, C, 32, 32, 32, C, b_off=wbuf_off, col_stats=stats, stat_replicas=stat_R)
+                K.gemm(dt, K.A_KC, K.B_KC, patches, wt, z, M, C, 32, 32, 32, C, b_off=wbuf_off, col_stats=stats, stat_replicas=stat_R, stat_sync=fwd_sync)
             elif ksize == 1:
-                K.gemm(dt, K.A_KC, K.B_KC, x, wt, z, M, C, cin, K.mat(x)[2], wcols, C, b_off=wbuf_off, col_stats=stats, stat_replicas=stat_R)
+                K.gemm(dt, K.A_KC, K.B_KC, x, wt, z, M, C, cin, K.mat(x)[2], wcols, C, b_off=wbuf_off, col_stats=stats, stat_replicas=stat_R, stat_sync=fwd_sync)
             else:
                 K.gemm(dt, K.A_IM2COL, K.B_KC, x, wt, z, M, C, 9 * cin, K.mat(x)[2], wcols, C, b_off=wbuf_off, conv=(H, W, cin),
-                       col_stats=stats, stat_replicas=stat_R)
+                       col_stats=stats, stat_replicas=stat_R, stat_sync=fwd_sync)
         ss = torch.empty(C, 2, device=dev, dtype=torch.float32)
         mi = None
         count = float(M)
@@ -416,10 +421,14 @@ class ConvBnAct(Function):
         rmask = K.relu_mask_like(y) if (RELU_BITMASK and training and relu and res is not None) else None
         if training and stat_R > 0:
             mi = torch.empty(C, 2, device=dev, dtype=torch.float32)
+            sums_in, rows_in = stats, stat_R
             if RT.comm is not None and (RT.comm.world_size > 1 or RT.comm.force):
-                RT.comm.all_reduce_sum(stats)
+                if fwd_sync is not None:      # the totals are already global: one row behind the replica rows
+                    sums_in, rows_in = stats[stat_R * 2 * C:(stat_R + 1) * 2 * C], 1
+                else:
+                    RT.comm.all_reduce_sum(stats)
                 count = float(M * RT.comm.world_size)
-            K.bn_apply_stats(z, stats, stat_R, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum,
+            K.bn_apply_stats(z, sums_in, rows_in, count, bn.gamma.master(), bn.beta.master(), bn.running_mean, bn.running_var, bn.momentum,
                              bn.eps, ss, mi, res, relu, y, relu_mask=rmask, pool=ctx.pool)
             applied = True
         elif training:

@@ -232,7 +232,9 @@ def test_two_rank_bf16_backward_exchanges_ride_in_the_producing_kernels(tmp_path
     assert int(r0["syncbn_in_kernel"]) > 0 and int(u0["syncbn_in_kernel"]) == 0
     print(f"exchanges over two steps: fused run {int(r0['syncbn_launches'])} launches + {int(r0['syncbn_in_kernel'])} in-kernel; unfused run {int(u0['syncbn_launches'])} launches")
     assert int(r0["syncbn_launches"]) + int(r0["syncbn_in_kernel"]) == int(u0["syncbn_launches"])
-    assert int(r0["syncbn_in_kernel"]) >= int(u0["syncbn_launches"]) // 2 - 2      # every backward exchange (the forward's stay launches)
+    # every backward exchange, and - end of round 5 - the forward ones too: in the tail of the ping-pong GEMM that accumulates the statistics, or in
+    # a single-block launch crog_gemm adds behind any other kernel (counted as in-kernel by SyncBNComm.fuse_ptr: no Python-side exchange call)
+    assert int(r0["syncbn_in_kernel"]) >= int(u0["syncbn_launches"]) - 4
     assert np.array_equal(r0["G"], r1["G"]) and np.array_equal(r0["P"], r1["P"]) and np.array_equal(r0["bn_final"], r1["bn_final"])
 
     def rms(a, b):
