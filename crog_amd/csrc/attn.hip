@@ -11,7 +11,9 @@
 // with the reduction index permuted consistently on both operands (slot (h, j) of k-step t <-> row 16t + 8(j>>2) + 4h + (j&3));
 // the other operand comes out of LDS through ds_read_b64_tr_b16 with the same permutation.  No shuffles, no LDS round trip
 // for P.  Attention dropout uses the same pair hash and index (attn_hash, common.h: one hash per two neighbouring keys) as crog_softmax_fwd, so the fused and the
-// unfused paths drop identical elements for a given seed.
+// unfused paths drop identical elements for a given seed.  Round 5: the forward can leave its keep decisions as a bit map (AttnArgs::keep, 32 bits per
+// score row and key tile = 15 MB for the decoder's 676 x 676 x 8 heads x B = 32) which both backward kernels read instead of hashing again: the
+// hash is two quarter-rate multiplies per key pair and made the three kernels VALU-bound (common.h).
 #include "common.h"
 
 namespace {
@@ -33,6 +35,8 @@ struct AttnArgs {
   float scale, p_drop;
   uint64_t seed;
   const uint64_t* epoch;   // crog_set_seed_epoch: per-step seed offset in device memory (null = none)
+  uint16_t* keep;          // dropout keep bits (null = every kernel hashes for itself): written by the forward, read by both backward kernels.
+                           // Word [((bh * ceil(Lk / 32) + key tile) * Lq + q) * 2 + h], bit r = key 32 * tile + acc_row(r, h) of score row q is kept
 };
 
 // ---- LDS images of a [32][64] bf16 tile (128-byte rows) -------------------------------------------------------------
@@ -145,12 +149,17 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
     for (int e = 0; e < 16; e++) { o[0][e] *= alpha; o[1][e] *= alpha; }
     if (a.p_drop > 0.f) {
       // registers 4 g .. 4 g + 3 hold keys kb + 8 g + 4 h + {0, 1, 2, 3}: two pairs, one hash each (attn_hash, common.h)
+      unsigned bits = 0u;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const uint32_t hh = attn_hash(seed, rowbase2 + (uint64_t)((kb + acc_row(r, h)) >> 1));
-        s[r] = attn_keep_lo(hh, thr) ? s[r] * sc : 0.f;
-        s[r + 1] = attn_keep_hi(hh, thr) ? s[r + 1] * sc : 0.f;
+        const bool k0 = attn_keep_lo(hh, thr), k1 = attn_keep_hi(hh, thr);
+        s[r] = k0 ? s[r] * sc : 0.f;
+        s[r + 1] = k1 ? s[r + 1] * sc : 0.f;
+        bits |= ((k0 ? 1u : 0u) | (k1 ? 2u : 0u)) << r;
       }
+      // the wave's 64 lanes are 32 consecutive score rows x 2 halves: one 256-byte store per key tile
+      if (a.keep && q < a.Lq) a.keep[(((long)bh * nkt + kt) * a.Lq + q) * 2 + h] = (uint16_t)bits;
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -234,6 +243,10 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
     *reinterpret_cast<bf16x8*>(&sKt[0][tr_off(lrow, lch)]) = rk;
     *reinterpret_cast<bf16x8*>(&sVc[0][kc_off(lrow, lch)]) = rv;
   }
+  // the forward's dropout decisions (a.keep: non-null only with p_drop > 0), same lane <-> (row, half) mapping as there: one coalesced
+  // 2-byte load per key tile, fetched a tile ahead
+  const uint16_t* kw = a.keep ? a.keep + ((long)bh * nkt * a.Lq + qc) * 2 + h : nullptr;
+  unsigned kbits = kw ? (unsigned)kw[0] : 0u, kbits_next = 0u;
   __syncthreads();
   for (int kt = 0; kt < nkt; kt++) {
     const int buf = kt & 1;
@@ -241,6 +254,7 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
       const int key = min((kt + 1) * TT + lrow, a.Lk - 1);
       rk = *reinterpret_cast<const bf16x8*>(kg + (long)key * a.ldk);
       rv = *reinterpret_cast<const bf16x8*>(vg + (long)key * a.ldv);
+      if (kw) kbits_next = kw[(long)(kt + 1) * a.Lq * 2];
     }
     f32x16 s, dp;
 #pragma unroll
@@ -258,11 +272,17 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
       s[r] = p;
     }
     if (a.p_drop > 0.f) {
+      if (kw) {
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const uint32_t hh = attn_hash(seed, rowbase2 + (uint64_t)((kb + acc_row(r, h)) >> 1));
-        dp[r] = attn_keep_lo(hh, thr) ? dp[r] * sc : 0.f;
-        dp[r + 1] = attn_keep_hi(hh, thr) ? dp[r + 1] * sc : 0.f;
+        for (int r = 0; r < 16; r++) dp[r] = ((kbits >> r) & 1u) ? dp[r] * sc : 0.f;
+        kbits = kbits_next;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const uint32_t hh = attn_hash(seed, rowbase2 + (uint64_t)((kb + acc_row(r, h)) >> 1));
+          dp[r] = attn_keep_lo(hh, thr) ? dp[r] * sc : 0.f;
+          dp[r + 1] = attn_keep_hi(hh, thr) ? dp[r + 1] * sc : 0.f;
+        }
       }
     }
 #pragma unroll
@@ -302,6 +322,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
   __shared__ __attribute__((aligned(16))) bf16 sOt[2][TILE];
   __shared__ __attribute__((aligned(16))) float sL[2][TT];
   __shared__ __attribute__((aligned(16))) float sD[2][TT];
+  __shared__ __attribute__((aligned(16))) uint32_t sM[2][4][TT];      // a.keep: the 32 + 32 keep bits of (query, this wave's key tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ln = lane & 31;
   const int bh = blockIdx.y, b = bh / a.heads, hd = bh % a.heads;
   const int k0 = blockIdx.x * 128 + wave * 32;
@@ -331,9 +352,19 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
   const float sc = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const float c2 = a.scale * LOG2E;
 
+  // keep bits: thread t < 128 stages the word of (key tile of wave t / 32, query t % 32); this lane's key is bit 16 hf + rf of it, with
+  // (hf, rf) the half and register that hold key k0 + ln in the forward's tile: acc_row(rf, hf) = ln
+  const int nktk = (a.Lk + TT - 1) / TT;
+  const uint32_t* mg = a.keep ? reinterpret_cast<const uint32_t*>(a.keep) + ((long)bh * nktk + min((int)blockIdx.x * 4 + (tid >> 5), nktk - 1)) * a.Lq
+                              : nullptr;
+  const bool mstage = mg && tid < 128;
+  const int mbit = 16 * ((ln >> 2) & 1) + (ln & 3) + 4 * (ln >> 3);
+  uint32_t rm = 0u;
+
   bf16x8 rq, ro;
   float rs = 0.f;
   {
+    if (mstage) sM[0][tid >> 5][tid & 31] = mg[min(tid & 31, a.Lq - 1)];
     const int qq = min(lrow, a.Lq - 1);
     rq = *reinterpret_cast<const bf16x8*>(qg + (long)qq * a.ldq);
     ro = *reinterpret_cast<const bf16x8*>(og + (long)qq * a.lddo);
@@ -353,6 +384,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
       ro = *reinterpret_cast<const bf16x8*>(og + (long)qq * a.lddo);
       if (tid < TT) rs = lg[min((qt + 1) * TT + tid, a.Lq - 1)] * LOG2E;
       else if (tid < 2 * TT) rs = dg[min((qt + 1) * TT + tid - TT, a.Lq - 1)];
+      if (mstage) rm = mg[min((qt + 1) * TT + (tid & 31), a.Lq - 1)];
     }
     f32x16 s, dp;
 #pragma unroll
@@ -367,7 +399,15 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
     // dropout decisions: a hash covers the key pair (2 j, 2 j + 1) of one score row = lanes (2 j, 2 j + 1) of one register, so of
     // every two rows the even lane hashes the first and the odd lane the second, and a DPP swap hands each its partner's value
     unsigned keepbits = 0xffffu;
-    if (a.p_drop > 0.f) {
+    if (mg) {
+      keepbits = 0u;
+      const uint4* mrow = reinterpret_cast<const uint4*>(&sM[buf][wave][0]);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {      // registers 4 g .. 4 g + 3 are queries qb + 8 g + 4 h + {0, 1, 2, 3}
+        const uint4 w = mrow[2 * g + h];
+        keepbits |= (((w.x >> mbit) & 1u) | (((w.y >> mbit) & 1u) << 1) | (((w.z >> mbit) & 1u) << 2) | (((w.w >> mbit) & 1u) << 3)) << (4 * g);
+      }
+    } else if (a.p_drop > 0.f) {
       const bool odd = lane & 1;
       keepbits = 0u;
 #pragma unroll
@@ -407,6 +447,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
       *reinterpret_cast<bf16x8*>(&sOt[buf ^ 1][tr_off(lrow, lch)]) = ro;
       if (tid < TT) sL[buf ^ 1][tid] = rs;
       else if (tid < 2 * TT) sD[buf ^ 1][tid - TT] = rs;
+      if (mstage) sM[buf ^ 1][tid >> 5][tid & 31] = rm;
     }
     __syncthreads();
   }
@@ -427,9 +468,9 @@ bool aligned8(long ld, const void* p) { return ld % 8 == 0 && ((uintptr_t)p % 16
 
 }  // namespace
 
-extern "C" int crog_flash_attn_fwd_masked(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
-                                          float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed,
-                                          int ldp, int causal, crog_stream_t stream) {
+extern "C" int crog_flash_attn_fwd_bits(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
+                                        float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed,
+                                        int ldp, int causal, void* keep_bits, crog_stream_t stream) {
   CROG_CHECK_ARG(head_dim == DH, "flash_attn: head_dim must be %d (got %d)", DH, head_dim);
   CROG_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && ldp >= Lk && p_drop >= 0.f && p_drop < 1.f, "flash_attn_fwd: bad sizes");
   CROG_CHECK_ARG(aligned8(ldq, Q) && aligned8(ldk, K) && aligned8(ldv, V) && ldo % 4 == 0 && ((uintptr_t)O % 8) == 0 && lse,
@@ -441,9 +482,16 @@ extern "C" int crog_flash_attn_fwd_masked(const void* Q, int64_t ldq, const void
   a.Lq = Lq; a.Lk = Lk; a.heads = heads; a.ldp = ldp; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.epoch = crog_seed_epoch();
   a.causal = causal != 0;
   CROG_CHECK_ARG(!causal || Lq == Lk, "flash_attn: the causal mask is defined for self-attention (Lq == Lk)");
+  CROG_CHECK_ARG(((uintptr_t)keep_bits % 4) == 0, "flash_attn_fwd: keep_bits must be 4-byte aligned");
+  a.keep = p_drop > 0.f ? (uint16_t*)keep_bits : nullptr;
   hipLaunchKernelGGL(flash_fwd_kernel, dim3(cdiv(Lq, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
+}
+extern "C" int crog_flash_attn_fwd_masked(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
+                                          float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed,
+                                          int ldp, int causal, crog_stream_t stream) {
+  return crog_flash_attn_fwd_bits(Q, ldq, K, ldk, V, ldv, O, ldo, lse, B, heads, Lq, Lk, head_dim, scale, p_drop, seed, ldp, causal, nullptr, stream);
 }
 extern "C" int crog_flash_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
                                    float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed, int ldp,
@@ -451,10 +499,10 @@ extern "C" int crog_flash_attn_fwd(const void* Q, int64_t ldq, const void* K, in
   return crog_flash_attn_fwd_masked(Q, ldq, K, ldk, V, ldv, O, ldo, lse, B, heads, Lq, Lk, head_dim, scale, p_drop, seed, ldp, 0, stream);
 }
 
-extern "C" int crog_flash_attn_bwd_masked(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo,
-                                          const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq, void* dK, int64_t lddk,
-                                          void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop,
-                                          uint64_t seed, int ldp, int causal, crog_stream_t stream) {
+extern "C" int crog_flash_attn_bwd_bits(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo,
+                                        const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq, void* dK, int64_t lddk,
+                                        void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop,
+                                        uint64_t seed, int ldp, int causal, const void* keep_bits, crog_stream_t stream) {
   CROG_CHECK_ARG(head_dim == DH, "flash_attn: head_dim must be %d (got %d)", DH, head_dim);
   CROG_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && ldp >= Lk && p_drop >= 0.f && p_drop < 1.f, "flash_attn_bwd: bad sizes");
   CROG_CHECK_ARG(aligned8(ldq, Q) && aligned8(ldk, K) && aligned8(ldv, V) && aligned8(ldo, O) && aligned8(lddo, dO) && lse && D && dQ && dK && dV,
@@ -467,11 +515,20 @@ extern "C" int crog_flash_attn_bwd_masked(const void* Q, int64_t ldq, const void
   a.Lq = Lq; a.Lk = Lk; a.heads = heads; a.ldp = ldp; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.epoch = crog_seed_epoch();
   a.causal = causal != 0;
   CROG_CHECK_ARG(!causal || Lq == Lk, "flash_attn: the causal mask is defined for self-attention (Lq == Lk)");
+  CROG_CHECK_ARG(((uintptr_t)keep_bits % 4) == 0, "flash_attn_bwd: keep_bits must be 4-byte aligned");
+  a.keep = p_drop > 0.f ? (uint16_t*)const_cast<void*>(keep_bits) : nullptr;
   hipLaunchKernelGGL(flash_bwd_dq_kernel, dim3(cdiv(Lq, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
   hipLaunchKernelGGL(flash_bwd_dkdv_kernel, dim3(cdiv(Lk, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
+}
+extern "C" int crog_flash_attn_bwd_masked(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo,
+                                          const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq, void* dK, int64_t lddk,
+                                          void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop,
+                                          uint64_t seed, int ldp, int causal, crog_stream_t stream) {
+  return crog_flash_attn_bwd_bits(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, lse, D, dQ, lddq, dK, lddk, dV, lddv, B, heads, Lq, Lk, head_dim, scale,
+                                  p_drop, seed, ldp, causal, nullptr, stream);
 }
 extern "C" int crog_flash_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo,
                                    const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq, void* dK, int64_t lddk,

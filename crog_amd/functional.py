@@ -50,6 +50,7 @@ FUSED_REDUCE_MAX_PARTS = 1 << 30
 FLASH_ATTN = True                # fused attention kernels (csrc/attn.hip) where they apply; tests compare with the unfused path
 FLASH_MIN_KEYS = 64
 FLASH_CAUSAL = os.environ.get("CROG_FLASH_CAUSAL", "1") != "0"      # causal self-attention (the CLIP text tower) through the fused kernels too
+FLASH_KEEP = os.environ.get("CROG_FLASH_KEEP", "1") != "0"          # the fused forward leaves its dropout decisions as a bit map for the two backward kernels
 FWD_STAT_SYNC = os.environ.get("CROG_SYNCBN_FUSE_FWD", "1") != "0"      # SyncBatchNorm forward exchanges in / behind the statistics GEMM (round 5)
 BN_ATOMIC_STATS = True           # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize (bf16)
 RELU_BITMASK = True              # residual+ReLU layers keep a bit mask of y for backward (1/16 of y's bytes)
@@ -1003,13 +1004,14 @@ class MhaFn(Function):
             seed = RT.next_seed() if p_drop > 0 else 0
             O = torch.empty(B * Lq, E, device=dev, dtype=dtype)
             lse = torch.empty(B * heads * Lq, device=dev, dtype=torch.float32)
-            K.flash_attn_fwd(qb, kb, vb, (O, 0, E), lse, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp, causal=causal)
+            keep = torch.empty(K.flash_keep_words(B, heads, Lq, Lk), device=dev, dtype=torch.int32) if (p_drop > 0 and FLASH_KEEP) else None
+            K.flash_attn_fwd(qb, kb, vb, (O, 0, E), lse, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp, causal=causal, keep=keep)
             ctx.causal = bool(causal)
             out = torch.empty(B * Lq, wo.rows, device=dev, dtype=dtype)
             lin_fwd(O, wo, out, bias=bo, res=res)
             ctx.cfg = (merged, qb, kb, vb, wo, bo, B, heads, Lq, Lk, Lkp, E, dh, scale, p_drop, seed, res is not None, same_qk, same_kv)
             ctx.flash = True
-            ctx.save_for_backward(xq, xk, xv, lse, None, O)
+            ctx.save_for_backward(xq, xk, xv, lse, keep, O)
             return out
         ctx.flash = False
         # ---- scores, softmax ----
@@ -1064,7 +1066,7 @@ class MhaFn(Function):
             lse = S
             D = torch.empty_like(lse)
             K.flash_attn_bwd(qb, kb, vb, (O, 0, E), (dO, 0, E), lse, D, dqb, dkb, dvb, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp,
-                             causal=ctx.causal)
+                             causal=ctx.causal, keep=Pd)      # (Pd: the forward's keep-bit map in the fused case)
             return MhaFn._proj_backward(ctx, merged, qb, dqb, dkb, xq, xk, xv, dout, has_res, same_qk, same_kv, dev, dtype)
         Pm = Pd if Pd is not None else S
         bh = B * heads

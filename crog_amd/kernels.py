@@ -401,21 +401,34 @@ def softmax_bwd(P, dPd, rows, Lk, ldp, p_drop, seed):
     check(lib().crog_softmax_bwd(dcode(P), ptr(P), ptr(dPd), rows, Lk, ldp, float(p_drop), int(seed), stream()), "softmax_bwd")
 
 
-def flash_attn_fwd(q, k, v, o, lse, B, heads, Lq, Lk, dh, scale, p_drop, seed, ldp, causal=False):
-    """q/k/v/o: (tensor, column offset, row stride) triples addressing [B*L, heads*dh] column slices (bf16)."""
+def flash_keep_words(B, heads, Lq, Lk):
+    """int32 words of the fused attention's dropout keep-bit map (include/crog_hip.h: crog_flash_attn_fwd_bits)."""
+    return B * heads * ((Lk + 31) // 32) * Lq
+
+
+def _keep_ptr(keep, B, heads, Lq, Lk):
+    if keep is None:
+        return None
+    assert keep.dtype == torch.int32 and keep.is_contiguous() and keep.numel() >= flash_keep_words(B, heads, Lq, Lk), "flash_attn: keep-bit buffer"
+    return ptr(keep)
+
+
+def flash_attn_fwd(q, k, v, o, lse, B, heads, Lq, Lk, dh, scale, p_drop, seed, ldp, causal=False, keep=None):
+    """q/k/v/o: (tensor, column offset, row stride) triples addressing [B*L, heads*dh] column slices (bf16).  keep: int32 buffer of
+    flash_keep_words() words that receives the dropout decisions (p_drop > 0) for flash_attn_bwd."""
     (qt, qc, ldq), (kt, kc, ldk), (vt, vc, ldv), (ot, oc, ldo) = q, k, v, o
-    check(lib().crog_flash_attn_fwd_masked(ptr(qt) + 2 * qc, ldq, ptr(kt) + 2 * kc, ldk, ptr(vt) + 2 * vc, ldv, ptr(ot) + 2 * oc, ldo, ptr(lse),
-                                           B, heads, Lq, Lk, dh, float(scale), float(p_drop), int(seed), int(ldp), int(bool(causal)), stream()),
-          "flash_attn_fwd")
+    check(lib().crog_flash_attn_fwd_bits(ptr(qt) + 2 * qc, ldq, ptr(kt) + 2 * kc, ldk, ptr(vt) + 2 * vc, ldv, ptr(ot) + 2 * oc, ldo, ptr(lse),
+                                         B, heads, Lq, Lk, dh, float(scale), float(p_drop), int(seed), int(ldp), int(bool(causal)),
+                                         _keep_ptr(keep, B, heads, Lq, Lk), stream()), "flash_attn_fwd")
 
 
-def flash_attn_bwd(q, k, v, o, do, lse, D, dq, dk, dv, B, heads, Lq, Lk, dh, scale, p_drop, seed, ldp, causal=False):
+def flash_attn_bwd(q, k, v, o, do, lse, D, dq, dk, dv, B, heads, Lq, Lk, dh, scale, p_drop, seed, ldp, causal=False, keep=None):
     (qt, qc, ldq), (kt, kc, ldk), (vt, vc, ldv), (ot, oc, ldo), (gt, gc, ldg) = q, k, v, o, do
     (dqt, dqc, lddq), (dkt, dkc, lddk), (dvt, dvc, lddv) = dq, dk, dv
-    check(lib().crog_flash_attn_bwd_masked(ptr(qt) + 2 * qc, ldq, ptr(kt) + 2 * kc, ldk, ptr(vt) + 2 * vc, ldv, ptr(ot) + 2 * oc, ldo,
-                                           ptr(gt) + 2 * gc, ldg, ptr(lse), ptr(D), ptr(dqt) + 2 * dqc, lddq, ptr(dkt) + 2 * dkc, lddk,
-                                           ptr(dvt) + 2 * dvc, lddv, B, heads, Lq, Lk, dh, float(scale), float(p_drop), int(seed), int(ldp),
-                                           int(bool(causal)), stream()), "flash_attn_bwd")
+    check(lib().crog_flash_attn_bwd_bits(ptr(qt) + 2 * qc, ldq, ptr(kt) + 2 * kc, ldk, ptr(vt) + 2 * vc, ldv, ptr(ot) + 2 * oc, ldo,
+                                         ptr(gt) + 2 * gc, ldg, ptr(lse), ptr(D), ptr(dqt) + 2 * dqc, lddq, ptr(dkt) + 2 * dkc, lddk,
+                                         ptr(dvt) + 2 * dvc, lddv, B, heads, Lq, Lk, dh, float(scale), float(p_drop), int(seed), int(ldp),
+                                         int(bool(causal)), _keep_ptr(keep, B, heads, Lq, Lk), stream()), "flash_attn_bwd")
 
 
 # --------------------------------------------------------------------------------------------

@@ -14,6 +14,11 @@ for B, heads, L, p in [(32, 8, 676, 0.1), (32, 8, 676, 0.0), (64, 12, 197, 0.0),
     sc = 1.0 / math.sqrt(64)
     fwd = lambda: K.flash_attn_fwd((q, 0, E), (k, 0, E), (v, 0, E), (o, 0, E), lse, B, heads, L, L, 64, sc, p, 1234, L)
     bwd = lambda: K.flash_attn_bwd((q, 0, E), (k, 0, E), (v, 0, E), (o, 0, E), (do, 0, E), lse, D, (dq, 0, E), (dk, 0, E), (dv, 0, E), B, heads, L, L, 64, sc, p, 1234, L)
+    if p > 0 and os.environ.get("CROG_FLASH_KEEP", "1") != "0":      # the forward's dropout decisions as a bit map for the backward kernels
+        keep = torch.empty(K.flash_keep_words(B, heads, L, L), device="cuda", dtype=torch.int32)
+        fwd_h, bwd_h = fwd, bwd
+        fwd = lambda: K.flash_attn_fwd((q, 0, E), (k, 0, E), (v, 0, E), (o, 0, E), lse, B, heads, L, L, 64, sc, p, 1234, L, keep=keep)
+        bwd = lambda: K.flash_attn_bwd((q, 0, E), (k, 0, E), (v, 0, E), (o, 0, E), (do, 0, E), lse, D, (dq, 0, E), (dk, 0, E), (dv, 0, E), B, heads, L, L, 64, sc, p, 1234, L, keep=keep)
     fwd(); bwd(); torch.cuda.synchronize()
     err = None
     if p == 0.0:
@@ -29,5 +34,7 @@ for B, heads, L, p in [(32, 8, 676, 0.1), (32, 8, 676, 0.0), (64, 12, 197, 0.0),
         e.record(); torch.cuda.synchronize()
         return s.elapsed_time(e) / n * 1e3
     tf, tb = t(fwd), t(bwd)
+    if p > 0 and os.environ.get("CROG_FLASH_KEEP", "1") != "0":
+        print(f"   (hashing in all three kernels: fwd {t(fwd_h):7.1f} us  bwd {t(bwd_h):7.1f} us)", flush=True)
     fl = 4.0 * B * heads * L * L * 64
     print(f"B={B} heads={heads} L={L} p={p}: fwd {tf:7.1f} us ({fl/tf/1e6:6.1f} TF/s)  bwd {tb:7.1f} us ({2.5*fl/tb/1e6:6.1f} TF/s)" + (f"  fwd max err {err:.2e}" if err is not None else ""), flush=True)

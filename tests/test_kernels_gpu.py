@@ -1228,6 +1228,52 @@ def test_flash_attention_matches_torch(K, B, H, Lq, Lk, causal):
     close(sl(dv, Lk), Vf.grad, dt, scale=2)
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,causal", [(2, 3, 197, 197, False), (1, 2, 300, 676, False), (1, 4, 33, 129, False), (2, 2, 77, 77, True),
+                                               (1, 1, 676, 676, False)])
+def test_flash_attention_keep_bits_reproduce_the_hash(K, B, H, Lq, Lk, causal):
+    """crog_flash_attn_fwd_bits / bwd_bits: the forward's dropout decisions kept as a bit map.  (1) the map says what the hash says:
+    decoded with the layout include/crog_hip.h documents it equals the elements crog_softmax_fwd (the unfused path, same seed and
+    index) keeps; (2) outputs and all three gradients are the SAME BITS whether the backward kernels read the map or hash again."""
+    dh, E, dt, p, seed = 64, 64 * H, torch.bfloat16, 0.1, 4242
+    qbuf = rnd(B * Lq, E, dt=dt, seed=7) * 0.7
+    kvbuf = rnd(B * Lk, 2 * E, dt=dt, seed=8) * 0.7
+    dO = rnd(B * Lq, E, dt=dt, seed=3)
+    qs, ks, vs = (qbuf, 0, E), (kvbuf, 0, 2 * E), (kvbuf, E, 2 * E)
+    scale, Lkp = dh ** -0.5, (Lk + 7) // 8 * 8
+    nkt = (Lk + 31) // 32
+    res = []
+    for use_bits in (False, True):
+        keep = torch.full((K.flash_keep_words(B, H, Lq, Lk),), -1, device="cuda", dtype=torch.int32) if use_bits else None
+        O = torch.empty(B * Lq, E, device="cuda", dtype=dt)
+        lse = torch.empty(B * H * Lq, device="cuda")
+        D = torch.empty_like(lse)
+        K.flash_attn_fwd(qs, ks, vs, (O, 0, E), lse, B, H, Lq, Lk, dh, scale, p, seed, Lkp, causal=causal, keep=keep)
+        dqb, dkvb = torch.zeros_like(qbuf), torch.zeros_like(kvbuf)
+        K.flash_attn_bwd(qs, ks, vs, (O, 0, E), (dO, 0, E), lse, D, (dqb, 0, E), (dkvb, 0, 2 * E), (dkvb, E, 2 * E), B, H, Lq, Lk, dh, scale,
+                         p, seed, Lkp, causal=causal, keep=keep)
+        torch.cuda.synchronize()
+        res.append((O, lse, dqb, dkvb, keep))
+    for a, b, name in zip(res[0][:4], res[1][:4], ("O", "lse", "dQ", "dK | dV")):
+        assert torch.equal(a, b), f"{name}: differs between hashed and bit-map backward"
+    assert res[0][2].float().abs().max() > 0 and res[0][3].float().abs().max() > 0
+    # decode the map: word ((b*H + h)*nkt + t)*Lq + q, bit 16*half + r <-> key 32*t + (r & 3) + 8*(r >> 2) + 4*half
+    words = res[1][4].view(B * H, nkt, Lq).to(torch.int64) & 0xffffffff
+    bit = torch.arange(32, device="cuda")
+    half, r = bit >> 4, bit & 15
+    key_of_bit = (r & 3) + 8 * (r >> 2) + 4 * half                                      # [32] within the tile
+    kept = ((words[..., None] >> bit) & 1).bool()                                        # [BH, nkt, Lq, 32 bits]
+    dec = torch.zeros(B * H, nkt, Lq, 32, dtype=torch.bool, device="cuda")
+    dec[..., key_of_bit] = kept
+    dec = dec.permute(0, 2, 1, 3).reshape(B * H, Lq, nkt * 32)[..., :Lk]               # [BH, Lq, Lk]
+    S = torch.zeros(B * H, Lq, Lkp, device="cuda", dtype=dt)
+    Pd = torch.empty_like(S)
+    K.softmax_fwd(S, B * H * Lq, Lq, Lk, Lkp, H, False, None, Pd, p, seed)
+    ref = Pd[..., :Lk] != 0
+    assert torch.equal(dec, ref), f"{int((dec != ref).sum())} keep bits differ from the unfused path's decisions"
+    rate = 1.0 - dec.float().mean().item()
+    assert abs(rate - p) < 0.01, rate
+
+
 def test_flash_attention_equals_unfused_path_with_dropout():
     """Same seed -> the fused kernels drop exactly the elements the unfused softmax kernel drops: the two MHA paths agree to bf16
     rounding in outputs and every gradient (decoder self-attention shape, p = 0.1)."""
