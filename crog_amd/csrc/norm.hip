@@ -418,6 +418,8 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
     for (int e = 0; e < VEC; e++) s1[e] = s2[e] = rsc[e] = rsh[e] = 0.f;
     ld_pairs<VEC>(mean_invstd + 2 * c, mu, is);
     if (relu_ss) ld_pairs<VEC>(relu_ss + 2 * c, rsc, rsh);
+    // (not unrolled: two / four rows in flight per thread cost a wave of occupancy - 135 / 205 VGPRs - and run the launch at 2.8-3.3 instead
+    // of 3.7-5.1 TB/s; LAB_NOTES section 10)
     for (long r = r0 + ty; r < r1; r += nty) {
       Vec16<T> g = ldg16(dy + (poolW ? pooled_row(r, poolH, poolW) : r) * lddy + c);
       Vec16<T> zz = ldg16(z + r * ldz + c);
