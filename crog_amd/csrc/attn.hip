@@ -32,6 +32,7 @@ struct AttnArgs {
   long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int Lq, Lk, heads, ldp;
   int causal;              // key k contributes to query q only if k <= q (CLIP text transformer, clip.py:446-452 build_attention_mask)
+  const uint8_t* kpm;      // key padding mask [B][Lk], non-zero = the key is padding and reaches no query (layers.py:332, crog.py:55); null = none
   float scale, p_drop;
   uint64_t seed;
   const uint64_t* epoch;   // crog_set_seed_epoch: per-step seed offset in device memory (null = none)
@@ -63,6 +64,18 @@ __device__ inline f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c)
 
 // row (0..31) of accumulator register r for the lane's half h
 __device__ inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// bit r: key kb + acc_row(r, h) of batch element b exists and is not padding (only called for ragged or padded key tiles)
+__device__ inline unsigned key_bits16(const AttnArgs& a, int b, int kb, int h) {
+  unsigned m = 0u;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int kk = kb + acc_row(r, h);
+    const bool ok = kk < a.Lk && !(a.kpm && a.kpm[(long)b * a.Lk + kk]);
+    m |= (ok ? 1u : 0u) << r;
+  }
+  return m;
+}
 
 __device__ inline bf16x8 pack8(const f32x16& v, int t) {
   bf16x8 o;
@@ -126,14 +139,15 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
     for (int ks = 0; ks < 4; ks++) s = mfma(kc_frag(sK[buf], ln, 2 * ks + h), qf[ks], s);
     const int kb = kt * TT;
     float mt = -INFINITY;
-    if (kb + TT <= a.Lk && !a.causal) {
+    if (kb + TT <= a.Lk && !a.causal && !a.kpm) {
 #pragma unroll
       for (int r = 0; r < 16; r++) { s[r] *= c2; mt = fmaxf(mt, s[r]); }
     } else {
+      const unsigned kv = key_bits16(a, b, kb, h);
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int kk = kb + acc_row(r, h);
-        s[r] = (kk < a.Lk && (!a.causal || kk <= q)) ? s[r] * c2 : -INFINITY;
+        s[r] = (((kv >> r) & 1u) && (!a.causal || kk <= q)) ? s[r] * c2 : -INFINITY;
         mt = fmaxf(mt, s[r]);
       }
     }
@@ -265,10 +279,11 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
       dp = mfma(kc_frag(sVc[buf], ln, 2 * ks + h), dof[ks], dp);
     }
     const int kb = kt * TT;
+    const unsigned kv = (kb + TT <= a.Lk && !a.kpm) ? 0xffffu : key_bits16(a, b, kb, h);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int kk = kb + acc_row(r, h);
-      const float p = (kk < a.Lk && (!a.causal || kk <= q)) ? ex2(s[r] * c2 - Lr) : 0.f;
+      const float p = (((kv >> r) & 1u) && (!a.causal || kk <= q)) ? ex2(s[r] * c2 - Lr) : 0.f;
       s[r] = p;
     }
     if (a.p_drop > 0.f) {
@@ -328,6 +343,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
   const int k0 = blockIdx.x * 128 + wave * 32;
   const int key = k0 + ln;
   const int kc = min(key, a.Lk - 1);
+  const bool kvalid = key < a.Lk && !(a.kpm && a.kpm[(long)b * a.Lk + key]);      // a padded key takes no probability: dK = dV = 0
   bf16x8 kf[4], vf[4];
   {
     const bf16* kp = a.K + ((long)b * a.Lk + kc) * a.ldk + hd * DH + h * 8;
@@ -386,6 +402,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
       else if (tid < 2 * TT) rs = dg[min((qt + 1) * TT + tid - TT, a.Lq - 1)];
       if (mstage) rm = mg[min((qt + 1) * TT + (tid & 31), a.Lq - 1)];
     }
+    if (k0 < a.Lk) {      // (a wave whose 32 keys all lie beyond Lk - three of four at the cross-attention's 20 keys - only helps with the loads)
     f32x16 s, dp;
 #pragma unroll
     for (int e = 0; e < 16; e++) s[e] = dp[e] = 0.f;
@@ -425,7 +442,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int qr = acc_row(r, h);
-      const float p = (qb + qr < a.Lq && (!a.causal || key <= qb + qr)) ? ex2(s[r] * c2 - sL[buf][qr]) : 0.f;
+      const float p = (kvalid && qb + qr < a.Lq && (!a.causal || key <= qb + qr)) ? ex2(s[r] * c2 - sL[buf][qr]) : 0.f;
       const bool keep = (keepbits >> r) & 1u;
       const float g = keep ? dp[r] * sc : 0.f;
       pd[r] = keep ? p * sc : 0.f;
@@ -439,6 +456,7 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
         dv[nt] = mfma(ap, tr_frag(sOt[buf], nt * 32, 16 * t + 4 * h, 16 * t + 8 + 4 * h, lane), dv[nt]);
         dk[nt] = mfma(as, tr_frag(sQt[buf], nt * 32, 16 * t + 4 * h, 16 * t + 8 + 4 * h, lane), dk[nt]);
       }
+    }
     }
     if (qt + 1 < nqt) {
       *reinterpret_cast<bf16x8*>(&sQc[buf ^ 1][kc_off(lrow, lch)]) = rq;
@@ -470,7 +488,7 @@ bool aligned8(long ld, const void* p) { return ld % 8 == 0 && ((uintptr_t)p % 16
 
 extern "C" int crog_flash_attn_fwd_bits(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
                                         float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed,
-                                        int ldp, int causal, void* keep_bits, crog_stream_t stream) {
+                                        int ldp, int causal, const void* key_padding_mask, void* keep_bits, crog_stream_t stream) {
   CROG_CHECK_ARG(head_dim == DH, "flash_attn: head_dim must be %d (got %d)", DH, head_dim);
   CROG_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && ldp >= Lk && p_drop >= 0.f && p_drop < 1.f, "flash_attn_fwd: bad sizes");
   CROG_CHECK_ARG(aligned8(ldq, Q) && aligned8(ldk, K) && aligned8(ldv, V) && ldo % 4 == 0 && ((uintptr_t)O % 8) == 0 && lse,
@@ -484,6 +502,8 @@ extern "C" int crog_flash_attn_fwd_bits(const void* Q, int64_t ldq, const void* 
   CROG_CHECK_ARG(!causal || Lq == Lk, "flash_attn: the causal mask is defined for self-attention (Lq == Lk)");
   CROG_CHECK_ARG(((uintptr_t)keep_bits % 4) == 0, "flash_attn_fwd: keep_bits must be 4-byte aligned");
   a.keep = p_drop > 0.f ? (uint16_t*)keep_bits : nullptr;
+  a.kpm = (const uint8_t*)key_padding_mask;
+  CROG_CHECK_ARG(!(causal && key_padding_mask), "flash_attn: causal and key_padding_mask together are not built");
   hipLaunchKernelGGL(flash_fwd_kernel, dim3(cdiv(Lq, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
@@ -491,7 +511,7 @@ extern "C" int crog_flash_attn_fwd_bits(const void* Q, int64_t ldq, const void* 
 extern "C" int crog_flash_attn_fwd_masked(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
                                           float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed,
                                           int ldp, int causal, crog_stream_t stream) {
-  return crog_flash_attn_fwd_bits(Q, ldq, K, ldk, V, ldv, O, ldo, lse, B, heads, Lq, Lk, head_dim, scale, p_drop, seed, ldp, causal, nullptr, stream);
+  return crog_flash_attn_fwd_bits(Q, ldq, K, ldk, V, ldv, O, ldo, lse, B, heads, Lq, Lk, head_dim, scale, p_drop, seed, ldp, causal, nullptr, nullptr, stream);
 }
 extern "C" int crog_flash_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
                                    float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed, int ldp,
@@ -502,7 +522,7 @@ extern "C" int crog_flash_attn_fwd(const void* Q, int64_t ldq, const void* K, in
 extern "C" int crog_flash_attn_bwd_bits(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo,
                                         const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq, void* dK, int64_t lddk,
                                         void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop,
-                                        uint64_t seed, int ldp, int causal, const void* keep_bits, crog_stream_t stream) {
+                                        uint64_t seed, int ldp, int causal, const void* key_padding_mask, const void* keep_bits, crog_stream_t stream) {
   CROG_CHECK_ARG(head_dim == DH, "flash_attn: head_dim must be %d (got %d)", DH, head_dim);
   CROG_CHECK_ARG(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && ldp >= Lk && p_drop >= 0.f && p_drop < 1.f, "flash_attn_bwd: bad sizes");
   CROG_CHECK_ARG(aligned8(ldq, Q) && aligned8(ldk, K) && aligned8(ldv, V) && aligned8(ldo, O) && aligned8(lddo, dO) && lse && D && dQ && dK && dV,
@@ -517,6 +537,8 @@ extern "C" int crog_flash_attn_bwd_bits(const void* Q, int64_t ldq, const void* 
   CROG_CHECK_ARG(!causal || Lq == Lk, "flash_attn: the causal mask is defined for self-attention (Lq == Lk)");
   CROG_CHECK_ARG(((uintptr_t)keep_bits % 4) == 0, "flash_attn_bwd: keep_bits must be 4-byte aligned");
   a.keep = p_drop > 0.f ? (uint16_t*)const_cast<void*>(keep_bits) : nullptr;
+  a.kpm = (const uint8_t*)key_padding_mask;
+  CROG_CHECK_ARG(!(causal && key_padding_mask), "flash_attn: causal and key_padding_mask together are not built");
   hipLaunchKernelGGL(flash_bwd_dq_kernel, dim3(cdiv(Lq, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
   hipLaunchKernelGGL(flash_bwd_dkdv_kernel, dim3(cdiv(Lk, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
@@ -528,7 +550,7 @@ extern "C" int crog_flash_attn_bwd_masked(const void* Q, int64_t ldq, const void
                                           void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim, float scale, float p_drop,
                                           uint64_t seed, int ldp, int causal, crog_stream_t stream) {
   return crog_flash_attn_bwd_bits(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, lse, D, dQ, lddq, dK, lddk, dV, lddv, B, heads, Lq, Lk, head_dim, scale,
-                                  p_drop, seed, ldp, causal, nullptr, stream);
+                                  p_drop, seed, ldp, causal, nullptr, nullptr, stream);
 }
 extern "C" int crog_flash_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O, int64_t ldo,
                                    const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq, void* dK, int64_t lddk,

@@ -50,6 +50,9 @@ FUSED_REDUCE_MAX_PARTS = 1 << 30
 FLASH_ATTN = True                # fused attention kernels (csrc/attn.hip) where they apply; tests compare with the unfused path
 FLASH_MIN_KEYS = 64
 FLASH_CAUSAL = os.environ.get("CROG_FLASH_CAUSAL", "1") != "0"      # causal self-attention (the CLIP text tower) through the fused kernels too
+FLASH_CROSS = os.environ.get("CROG_FLASH_CROSS", "1") != "0"        # the decoder's vision-to-text cross-attention (20 keys, key padding mask) through the fused kernels:
+#                                                                     one launch forward and two backward instead of three and five
+FLASH_CROSS_MIN_QUERIES = 128
 FLASH_KEEP = os.environ.get("CROG_FLASH_KEEP", "1") != "0"          # the fused forward leaves its dropout decisions as a bit map for the two backward kernels
 FWD_STAT_SYNC = os.environ.get("CROG_SYNCBN_FUSE_FWD", "1") != "0"      # SyncBatchNorm forward exchanges in / behind the statistics GEMM (round 5)
 BN_ATOMIC_STATS = True           # BN statistics: atomic replicas in the GEMM epilogue + in-kernel finalize (bf16)
@@ -999,14 +1002,18 @@ class MhaFn(Function):
         # ---- fused attention: no score matrix in HBM (unmasked bf16, head_dim 64, long key rows) ----
         # (... and - FLASH_CAUSAL - the text tower's causal 20-token blocks: one launch instead of three, two instead of five backward, on a
         # stream whose ~150 backward launches are latency-bound)
-        if FLASH_ATTN and dtype == torch.bfloat16 and dh == 64 and kpm is None and (
-                (not causal and Lk >= FLASH_MIN_KEYS) or (causal and FLASH_CAUSAL and Lq == Lk)):
+        cross = FLASH_CROSS and not causal and Lq >= FLASH_CROSS_MIN_QUERIES and (kpm is not None or Lk < FLASH_MIN_KEYS)
+        if FLASH_ATTN and dtype == torch.bfloat16 and dh == 64 and (cross or (kpm is None and (
+                (not causal and Lk >= FLASH_MIN_KEYS) or (causal and FLASH_CAUSAL and Lq == Lk)))):
             seed = RT.next_seed() if p_drop > 0 else 0
             O = torch.empty(B * Lq, E, device=dev, dtype=dtype)
             lse = torch.empty(B * heads * Lq, device=dev, dtype=torch.float32)
             keep = torch.empty(K.flash_keep_words(B, heads, Lq, Lk), device=dev, dtype=torch.int32) if (p_drop > 0 and FLASH_KEEP) else None
-            K.flash_attn_fwd(qb, kb, vb, (O, 0, E), lse, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp, causal=causal, keep=keep)
+            if kpm is not None and kpm.dtype not in (torch.bool, torch.uint8):
+                raise TypeError("key_padding_mask must be a bool / uint8 tensor")
+            K.flash_attn_fwd(qb, kb, vb, (O, 0, E), lse, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp, causal=causal, keep=keep, kpm=kpm)
             ctx.causal = bool(causal)
+            ctx.kpm = kpm
             out = torch.empty(B * Lq, wo.rows, device=dev, dtype=dtype)
             lin_fwd(O, wo, out, bias=bo, res=res)
             ctx.cfg = (merged, qb, kb, vb, wo, bo, B, heads, Lq, Lk, Lkp, E, dh, scale, p_drop, seed, res is not None, same_qk, same_kv)
@@ -1066,7 +1073,7 @@ class MhaFn(Function):
             lse = S
             D = torch.empty_like(lse)
             K.flash_attn_bwd(qb, kb, vb, (O, 0, E), (dO, 0, E), lse, D, dqb, dkb, dvb, B, heads, Lq, Lk, dh, scale, p_drop, seed, Lkp,
-                             causal=ctx.causal, keep=Pd)      # (Pd: the forward's keep-bit map in the fused case)
+                             causal=ctx.causal, keep=Pd, kpm=ctx.kpm)      # (Pd: the forward's keep-bit map in the fused case)
             return MhaFn._proj_backward(ctx, merged, qb, dqb, dkb, xq, xk, xv, dout, has_res, same_qk, same_kv, dev, dtype)
         Pm = Pd if Pd is not None else S
         bh = B * heads

@@ -413,22 +413,30 @@ def _keep_ptr(keep, B, heads, Lq, Lk):
     return ptr(keep)
 
 
-def flash_attn_fwd(q, k, v, o, lse, B, heads, Lq, Lk, dh, scale, p_drop, seed, ldp, causal=False, keep=None):
+def _kpm_ptr(kpm, B, Lk):
+    if kpm is None:
+        return None
+    assert kpm.dtype in (torch.bool, torch.uint8) and kpm.is_contiguous() and kpm.numel() == B * Lk, "flash_attn: key padding mask must be [B, Lk] bytes"
+    return ptr(kpm)
+
+
+def flash_attn_fwd(q, k, v, o, lse, B, heads, Lq, Lk, dh, scale, p_drop, seed, ldp, causal=False, keep=None, kpm=None):
     """q/k/v/o: (tensor, column offset, row stride) triples addressing [B*L, heads*dh] column slices (bf16).  keep: int32 buffer of
-    flash_keep_words() words that receives the dropout decisions (p_drop > 0) for flash_attn_bwd."""
+    flash_keep_words() words that receives the dropout decisions (p_drop > 0) for flash_attn_bwd.  kpm: [B, Lk] bool / uint8, non-zero =
+    padding key."""
     (qt, qc, ldq), (kt, kc, ldk), (vt, vc, ldv), (ot, oc, ldo) = q, k, v, o
     check(lib().crog_flash_attn_fwd_bits(ptr(qt) + 2 * qc, ldq, ptr(kt) + 2 * kc, ldk, ptr(vt) + 2 * vc, ldv, ptr(ot) + 2 * oc, ldo, ptr(lse),
                                          B, heads, Lq, Lk, dh, float(scale), float(p_drop), int(seed), int(ldp), int(bool(causal)),
-                                         _keep_ptr(keep, B, heads, Lq, Lk), stream()), "flash_attn_fwd")
+                                         _kpm_ptr(kpm, B, Lk), _keep_ptr(keep, B, heads, Lq, Lk), stream()), "flash_attn_fwd")
 
 
-def flash_attn_bwd(q, k, v, o, do, lse, D, dq, dk, dv, B, heads, Lq, Lk, dh, scale, p_drop, seed, ldp, causal=False, keep=None):
+def flash_attn_bwd(q, k, v, o, do, lse, D, dq, dk, dv, B, heads, Lq, Lk, dh, scale, p_drop, seed, ldp, causal=False, keep=None, kpm=None):
     (qt, qc, ldq), (kt, kc, ldk), (vt, vc, ldv), (ot, oc, ldo), (gt, gc, ldg) = q, k, v, o, do
     (dqt, dqc, lddq), (dkt, dkc, lddk), (dvt, dvc, lddv) = dq, dk, dv
     check(lib().crog_flash_attn_bwd_bits(ptr(qt) + 2 * qc, ldq, ptr(kt) + 2 * kc, ldk, ptr(vt) + 2 * vc, ldv, ptr(ot) + 2 * oc, ldo,
                                          ptr(gt) + 2 * gc, ldg, ptr(lse), ptr(D), ptr(dqt) + 2 * dqc, lddq, ptr(dkt) + 2 * dkc, lddk,
                                          ptr(dvt) + 2 * dvc, lddv, B, heads, Lq, Lk, dh, float(scale), float(p_drop), int(seed), int(ldp),
-                                         int(bool(causal)), _keep_ptr(keep, B, heads, Lq, Lk), stream()), "flash_attn_bwd")
+                                         int(bool(causal)), _kpm_ptr(kpm, B, Lk), _keep_ptr(keep, B, heads, Lq, Lk), stream()), "flash_attn_bwd")
 
 
 # --------------------------------------------------------------------------------------------

@@ -411,18 +411,21 @@ int crog_flash_attn_bwd_masked(const void* Q, int64_t ldq, const void* K, int64_
                                int64_t ldo, const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq,
                                void* dK, int64_t lddk, void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim,
                                float scale, float p_drop, uint64_t seed, int ldp, int causal, crog_stream_t stream);
-/* The same again with the forward's dropout decisions kept as a bit map: keep_bits (NULL = as above) is a caller-owned buffer of
+/* The same again with (a) a key padding mask - key_padding_mask (NULL = none): B*Lk bytes, non-zero = key (b, k) is padding and reaches no
+ * query: the decoder's vision-to-text cross-attention layers.py:292-296,329-332 with crog.py:55's pad_mask (not together with causal) - and
+ * (b) the forward's dropout decisions kept as a bit map: keep_bits (NULL = as above) is a caller-owned buffer of
  * B*heads*ceil(Lk/32)*Lq 32-bit words (4-byte aligned) that crog_flash_attn_fwd_bits fills when p_drop > 0 and crog_flash_attn_bwd_bits
  * reads instead of hashing (seed, index) again - same decisions, bit-identical gradients (layers.py:291-296: nn.MultiheadAttention(dropout=)
  * keeps its mask for the backward as well).  Word ((b*heads + head)*ceil(Lk/32) + t)*Lq + q: bit 16*h + r <-> key 32*t + (r&3) + 8*(r>>2) + 4*h. */
 int crog_flash_attn_fwd_bits(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O,
                              int64_t ldo, float* lse, int B, int heads, int Lq, int Lk, int head_dim, float scale,
-                             float p_drop, uint64_t seed, int ldp, int causal, void* keep_bits, crog_stream_t stream);
+                             float p_drop, uint64_t seed, int ldp, int causal, const void* key_padding_mask, void* keep_bits,
+                             crog_stream_t stream);
 int crog_flash_attn_bwd_bits(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, const void* O,
                              int64_t ldo, const void* dO, int64_t lddo, const float* lse, float* D, void* dQ, int64_t lddq,
                              void* dK, int64_t lddk, void* dV, int64_t lddv, int B, int heads, int Lq, int Lk, int head_dim,
-                             float scale, float p_drop, uint64_t seed, int ldp, int causal, const void* keep_bits,
-                             crog_stream_t stream);
+                             float scale, float p_drop, uint64_t seed, int ldp, int causal, const void* key_padding_mask,
+                             const void* keep_bits, crog_stream_t stream);
 /* QuickGELU x*sigmoid(1.702x): clip.py:234-236 */
 int crog_quickgelu_fwd(int dtype, const void* u, int64_t ldu, void* out, int64_t ldo, int64_t M, int C,
                        crog_stream_t stream);

@@ -1274,19 +1274,62 @@ def test_flash_attention_keep_bits_reproduce_the_hash(K, B, H, Lq, Lk, causal):
     assert abs(rate - p) < 0.01, rate
 
 
-def test_flash_attention_equals_unfused_path_with_dropout():
+@pytest.mark.parametrize("B,H,Lq,Lk", [(3, 2, 300, 20), (2, 3, 130, 70), (2, 1, 676, 17)])
+def test_flash_attention_with_key_padding_mask_matches_torch(K, B, H, Lq, Lk):
+    """crog_flash_attn_fwd_bits / bwd_bits with a key padding mask (the decoder's vision-to-text cross-attention: 20 word keys, crog.py:55
+    pad_mask, layers.py:329-332) against fp32 softmax attention with the padded keys at -inf; padded keys get exactly zero dK / dV."""
+    dh, E, dt = 64, 64 * H, torch.bfloat16
+    qbuf = rnd(B * Lq, E, dt=dt, seed=7) * 0.7
+    kvbuf = rnd(B * Lk, 2 * E, dt=dt, seed=8) * 0.7
+    dO = rnd(B * Lq, E, dt=dt, seed=3)
+    g = torch.Generator().manual_seed(5)
+    nvalid = torch.randint(1, Lk + 1, (B,), generator=g)
+    nvalid[0] = Lk
+    kpm = (torch.arange(Lk)[None, :] >= nvalid[:, None]).cuda().contiguous()             # True = padding (trailing, as word == 0 is)
+    kpm[-1, 1] = Lk > 2                                                                   # ... and one hole in the middle
+    qs, ks, vs = (qbuf, 0, E), (kvbuf, 0, 2 * E), (kvbuf, E, 2 * E)
+    Qf = qbuf.float().view(B, Lq, H, dh).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    Kf = kvbuf[:, :E].float().view(B, Lk, H, dh).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    Vf = kvbuf[:, E:].float().view(B, Lk, H, dh).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    scale, Lkp = dh ** -0.5, (Lk + 7) // 8 * 8
+    S = (scale * Qf @ Kf.transpose(-1, -2)).masked_fill(kpm[:, None, None, :], float("-inf"))
+    ref = torch.softmax(S, -1) @ Vf
+    ref.backward(dO.float().view(B, Lq, H, dh).permute(0, 2, 1, 3))
+    O = torch.empty(B * Lq, E, device="cuda", dtype=dt)
+    lse = torch.empty(B * H * Lq, device="cuda")
+    D = torch.empty_like(lse)
+    K.flash_attn_fwd(qs, ks, vs, (O, 0, E), lse, B, H, Lq, Lk, dh, scale, 0.0, 0, Lkp, kpm=kpm)
+    close(O.view(B, Lq, H, dh).permute(0, 2, 1, 3), ref, dt)
+    close(lse.view(B, H, Lq), torch.logsumexp(S, -1), torch.float32, scale=50)
+    dqb, dkvb = torch.zeros_like(qbuf), torch.full_like(kvbuf, 7.0)
+    K.flash_attn_bwd(qs, ks, vs, (O, 0, E), (dO, 0, E), lse, D, (dqb, 0, E), (dkvb, 0, 2 * E), (dkvb, E, 2 * E), B, H, Lq, Lk, dh, scale,
+                     0.0, 0, Lkp, kpm=kpm)
+    sl = lambda t, c, L: t[:, c:c + E].float().view(B, L, H, dh).permute(0, 2, 1, 3)
+    close(sl(dqb, 0, Lq), Qf.grad, dt, scale=2)
+    close(sl(dkvb, 0, Lk), Kf.grad, dt, scale=2)
+    close(sl(dkvb, E, Lk), Vf.grad, dt, scale=2)
+    assert float(dkvb.view(B, Lk, 2 * E)[kpm].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_flash_attention_equals_unfused_path_with_dropout(cross):
     """Same seed -> the fused kernels drop exactly the elements the unfused softmax kernel drops: the two MHA paths agree to bf16
-    rounding in outputs and every gradient (decoder self-attention shape, p = 0.1)."""
+    rounding in outputs and every gradient (decoder self-attention shape, p = 0.1; cross: the decoder's cross-attention - queries,
+    keys and values from three tensors, 20 keys behind a key padding mask)."""
     import importlib
     from crog_amd import functional as Fn
     from crog_amd.model.blocks import MultiheadAttention, bind_all
     from crog_amd.runtime import RT, ParamStore
     torch.manual_seed(0)
     B, L, E, H = 2, 200, 256, 4
+    Lk = 20 if cross else L
     mha = MultiheadAttention(E, H, dropout=0.1)
     store = ParamStore(mha, torch.device("cuda"))
     bind_all(mha, store)
     x0 = (torch.randn(B * L, E, device="cuda") * 0.5).to(torch.bfloat16)
+    k0 = (torch.randn(B * Lk, E, device="cuda") * 0.5).to(torch.bfloat16)
+    v0 = (torch.randn(B * Lk, E, device="cuda") * 0.5).to(torch.bfloat16)
+    kpm = (torch.arange(Lk, device="cuda")[None, :] >= torch.tensor([Lk, 7], device="cuda")[:, None]).contiguous() if cross else None
     res = {}
     for flash in (True, False):
         Fn.FLASH_ATTN = flash
@@ -1294,13 +1337,17 @@ def test_flash_attention_equals_unfused_path_with_dropout():
         store.zero_grad()
         store.invalidate_shadow()
         x = x0.clone().requires_grad_(True)
-        y = mha(x, x, x, B=B, training=True)
+        if cross:
+            xk, xv = k0.clone().requires_grad_(True), v0.clone().requires_grad_(True)
+            y = mha(x, xk, xv, B=B, kpm=kpm, training=True)
+        else:
+            y = mha(x, x, x, B=B, training=True)
         (y.float() * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
         RT.join_streams()
         torch.cuda.synchronize()
-        res[flash] = (y.detach().float(), x.grad.float(), store.G.clone())
+        res[flash] = (y.detach().float(), x.grad.float(), store.G.clone()) + ((xk.grad.float(), xv.grad.float()) if cross else ())
     Fn.FLASH_ATTN = True
-    for a, b, name in zip(res[True], res[False], ("out", "dx", "param grads")):
+    for a, b, name in zip(res[True], res[False], ("out", "dx", "param grads", "dxk", "dxv")):
         err = (a - b).abs().max().item()
         ref = b.abs().max().item()
         assert err <= 3e-2 * ref + 1e-3, f"{name}: {err} vs scale {ref}"
