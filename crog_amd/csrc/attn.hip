@@ -220,6 +220,9 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
   const long qrow = (long)b * a.Lq + qc;
   bf16x8 qf[4], dof[4];
   float Dq = 0.f;
+  // One key tile (the cross-attention's 20 words, the text tower's 20-token blocks): D = rowsum(dO * O) = sum_k dropout(P)_k (dO V^T)_k is
+  // taken from the tile itself below and O (a quarter of this kernel's bytes there) is not read.
+  const bool one_tile = a.Lk <= TT;
   {
     const bf16* qp = a.Q + qrow * a.ldq + hd * DH + h * 8;
     const bf16* dp = a.dO + qrow * a.lddo + hd * DH + h * 8;
@@ -228,14 +231,16 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
     for (int ks = 0; ks < 4; ks++) {
       qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
       dof[ks] = *reinterpret_cast<const bf16x8*>(dp + ks * 16);
-      const bf16x8 of = *reinterpret_cast<const bf16x8*>(op + ks * 16);
+      if (!one_tile) {
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(op + ks * 16);
 #pragma unroll
-      for (int j = 0; j < 8; j++) Dq += (float)dof[ks][j] * (float)of[j];
+        for (int j = 0; j < 8; j++) Dq += (float)dof[ks][j] * (float)of[j];
+      }
     }
-    Dq = xor32_sum(Dq);
+    if (!one_tile) Dq = xor32_sum(Dq);
   }
   const float Lr = a.lse[(long)bh * a.Lq + qc] * LOG2E, c2 = a.scale * LOG2E;      // (log2 units, as in the forward)
-  if (h == 0 && q < a.Lq) a.D[(long)bh * a.Lq + q] = Dq;
+  if (!one_tile && h == 0 && q < a.Lq) a.D[(long)bh * a.Lq + q] = Dq;
   f32x16 dq[2];
 #pragma unroll
   for (int e = 0; e < 16; e++) dq[0][e] = dq[1][e] = 0.f;
@@ -299,6 +304,13 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
           dp[r + 1] = attn_keep_hi(hh, thr) ? dp[r + 1] * sc : 0.f;
         }
       }
+    }
+    if (one_tile) {
+      float d = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) d += s[r] * dp[r];
+      Dq = xor32_sum(d);
+      if (h == 0 && q < a.Lq) a.D[(long)bh * a.Lq + q] = Dq;
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) s[r] = s[r] * (dp[r] - Dq) * a.scale;
@@ -482,6 +494,171 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
     }
 }
 
+// =====================================================================================================================
+// backward 2 for ONE key tile (Lk <= 32: the decoder's vision-to-text cross-attention, 20 word keys).  In flash_bwd_dkdv_kernel a wave
+// owns 32 keys, so three of the four waves of its single block per (batch, head) would idle while the fourth walks all 22 query tiles
+// (54 us in situ at B = 32).  Here the four waves own the SAME 32 keys and take every fourth query tile each, with wave-private tiles and no
+// block barrier in the loop: the Q / dO rows go from global memory straight into the MFMA A operand (lane = query row, 16 bytes per k-step:
+// what kc_frag reads from the row image elsewhere) and the same registers are stored as the transposed-read image for dV += P^T dO,
+// dK += dS^T Q; the next tile's loads are in flight during the products.  dK / dV are summed across the waves through LDS at the end.
+// grid (1, B * heads).
+// =====================================================================================================================
+__global__ void __launch_bounds__(NTHR, 1) flash_bwd_dkdv_short_kernel(const AttnArgs a) {
+  const uint64_t seed = a.seed + (a.epoch ? *a.epoch : 0ull);
+  __shared__ __attribute__((aligned(16))) bf16 sQt[4][TILE];
+  __shared__ __attribute__((aligned(16))) bf16 sOt[4][TILE];
+  __shared__ __attribute__((aligned(16))) float sL[4][TT];
+  __shared__ __attribute__((aligned(16))) float sD[4][TT];
+  __shared__ __attribute__((aligned(16))) uint32_t sM[4][TT];
+  __shared__ __attribute__((aligned(16))) float red[3][32][64];      // dK, then dV, of waves 1 .. 3 on their way to wave 0
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ln = lane & 31;
+  const int bh = blockIdx.y, b = bh / a.heads, hd = bh % a.heads;
+  const int key = ln;
+  const int kc = min(key, a.Lk - 1);
+  const bool kvalid = key < a.Lk && !(a.kpm && a.kpm[(long)b * a.Lk + key]);
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16* kp = a.K + ((long)b * a.Lk + kc) * a.ldk + hd * DH + h * 8;
+    const bf16* vp = a.V + ((long)b * a.Lk + kc) * a.ldv + hd * DH + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(kp + ks * 16);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(vp + ks * 16);
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int e = 0; e < 16; e++) dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f;
+
+  const bf16* qg = a.Q + (long)b * a.Lq * a.ldq + hd * DH + h * 8;
+  const bf16* og = a.dO + (long)b * a.Lq * a.lddo + hd * DH + h * 8;
+  const float* lg = a.lse + (long)bh * a.Lq;
+  const float* dg = a.D + (long)bh * a.Lq;
+  const uint32_t* mg = a.keep ? reinterpret_cast<const uint32_t*>(a.keep) + (long)bh * a.Lq : nullptr;      // one key tile: word (bh, q)
+  const int mbit = 16 * ((ln >> 2) & 1) + (ln & 3) + 4 * (ln >> 3);      // (see flash_bwd_dkdv_kernel)
+  const int nqt = (a.Lq + TT - 1) / TT;
+  const uint32_t thr = attn_thr16(a.p_drop);
+  const float sc = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const float c2 = a.scale * LOG2E;
+
+  bf16x8 nq[4], no[4];      // the NEXT tile: row qb + ln, k-steps 16 ks + 8 h
+  float rs = 0.f;
+  uint32_t rm = 0u;
+  auto fetch = [&](int qt) {
+    const int qq = min(qt * TT + ln, a.Lq - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      nq[ks] = *reinterpret_cast<const bf16x8*>(qg + (long)qq * a.ldq + ks * 16);
+      no[ks] = *reinterpret_cast<const bf16x8*>(og + (long)qq * a.lddo + ks * 16);
+    }
+    rs = h == 0 ? lg[qq] * LOG2E : dg[qq];      // (log2 units, as in the forward)
+    if (mg && h == 0) rm = mg[qq];
+  };
+  if (wave < nqt) fetch(wave);
+  for (int qt = wave; qt < nqt; qt += 4) {
+    bf16x8 cq[4], co[4];
+    // this wave's earlier reads of its tiles are done (one wave: LDS instructions complete in order); the fences keep the compiler from
+    // moving LDS accesses across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      cq[ks] = nq[ks];
+      co[ks] = no[ks];
+      *reinterpret_cast<bf16x8*>(&sQt[wave][tr_off(ln, 2 * ks + h)]) = cq[ks];
+      *reinterpret_cast<bf16x8*>(&sOt[wave][tr_off(ln, 2 * ks + h)]) = co[ks];
+    }
+    if (h == 0) { sL[wave][ln] = rs; if (mg) sM[wave][ln] = rm; }
+    else sD[wave][ln] = rs;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (qt + 4 < nqt) fetch(qt + 4);
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      s = mfma(cq[ks], kf[ks], s);      // S[query][key]
+      dp = mfma(co[ks], vf[ks], dp);    // (dO V^T)[query][key]
+    }
+    const int qb = qt * TT;
+    unsigned keepbits = 0xffffu;
+    if (mg) {
+      keepbits = 0u;
+      const uint4* mrow = reinterpret_cast<const uint4*>(&sM[wave][0]);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const uint4 w = mrow[2 * g + h];
+        keepbits |= (((w.x >> mbit) & 1u) | (((w.y >> mbit) & 1u) << 1) | (((w.z >> mbit) & 1u) << 2) | (((w.w >> mbit) & 1u) << 3)) << (4 * g);
+      }
+    } else if (a.p_drop > 0.f) {      // (the pair hash of flash_bwd_dkdv_kernel)
+      const bool odd = lane & 1;
+      keepbits = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int qmine = qb + acc_row(r, h) + (odd ? 1 : 0);
+        const uint32_t hm = attn_hash(seed, ((uint64_t)bh * a.Lq + qmine) * (uint64_t)((a.ldp + 1) >> 1) + (uint64_t)(key >> 1));
+        const uint32_t ho = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm, 0xB1, 0xF, 0xF, false);      // lane ^ 1
+        const uint32_t h0 = odd ? ho : hm, h1 = odd ? hm : ho;
+        const bool k0 = odd ? attn_keep_hi(h0, thr) : attn_keep_lo(h0, thr);
+        const bool k1 = odd ? attn_keep_hi(h1, thr) : attn_keep_lo(h1, thr);
+        keepbits |= (k0 ? 1u : 0u) << r;
+        keepbits |= (k1 ? 1u : 0u) << (r + 1);
+      }
+    }
+    f32x16 pd;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int qr = acc_row(r, h);
+      const float p = (kvalid && qb + qr < a.Lq) ? ex2(s[r] * c2 - sL[wave][qr]) : 0.f;
+      const bool keep = (keepbits >> r) & 1u;
+      const float g = keep ? dp[r] * sc : 0.f;
+      pd[r] = keep ? p * sc : 0.f;
+      s[r] = p * (g - sD[wave][qr]) * a.scale;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const bf16x8 ap = pack8(pd, t), as = pack8(s, t);
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        dv[nt] = mfma(ap, tr_frag(sOt[wave], nt * 32, 16 * t + 4 * h, 16 * t + 8 + 4 * h, lane), dv[nt]);
+        dk[nt] = mfma(as, tr_frag(sQt[wave], nt * 32, 16 * t + 4 * h, 16 * t + 8 + 4 * h, lane), dk[nt]);
+      }
+    }
+  }
+  // sums over the four waves: dK, then dV, through `red` (row = nt * 16 + r, lane-major)
+#pragma unroll
+  for (int which = 0; which < 2; which++) {
+    f32x16* acc = which == 0 ? dk : dv;
+    if (wave > 0) {
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[wave - 1][nt * 16 + r][lane] = acc[nt][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[nt][r] += red[0][nt * 16 + r][lane] + red[1][nt * 16 + r][lane] + red[2][nt * 16 + r][lane];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int kk = acc_row(r, h);
+        if (kk < a.Lk) {
+          a.dK[((long)b * a.Lk + kk) * a.lddk + hd * DH + nt * 32 + ln] = (bf16)dk[nt][r];
+          a.dV[((long)b * a.Lk + kk) * a.lddv + hd * DH + nt * 32 + ln] = (bf16)dv[nt][r];
+        }
+      }
+  }
+}
+
 bool aligned8(long ld, const void* p) { return ld % 8 == 0 && ((uintptr_t)p % 16) == 0; }
 
 }  // namespace
@@ -541,7 +718,11 @@ extern "C" int crog_flash_attn_bwd_bits(const void* Q, int64_t ldq, const void* 
   CROG_CHECK_ARG(!(causal && key_padding_mask), "flash_attn: causal and key_padding_mask together are not built");
   hipLaunchKernelGGL(flash_bwd_dq_kernel, dim3(cdiv(Lq, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(flash_bwd_dkdv_kernel, dim3(cdiv(Lk, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
+  static const bool short_keys = [] { const char* e = getenv("CROG_FLASH_SHORT"); return !e || atoi(e) != 0; }();
+  if (Lk <= TT && !causal && Lq >= 4 * TT && short_keys)      // one key tile, many query tiles: the four waves share the keys and split the queries
+    hipLaunchKernelGGL(flash_bwd_dkdv_short_kernel, dim3(1, B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(flash_bwd_dkdv_kernel, dim3(cdiv(Lk, 128), B * heads), dim3(NTHR), 0, (hipStream_t)stream, a);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }

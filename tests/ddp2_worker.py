@@ -15,6 +15,9 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    if os.environ.get("CROG_WORKER_DUMP_AFTER"):      # debugging aid (scripts/many_rank_probe.py): where is a rank that does not finish?
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CROG_WORKER_DUMP_AFTER"]), exit=True)
     rank, world, port, out_dir, dtype_name, gain = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], float(sys.argv[6])
     size, B, tag = int(sys.argv[7]), int(sys.argv[8]), sys.argv[9]
     from crog_amd.model import build_crog
@@ -33,6 +36,9 @@ def main():
     model = model.cuda()
     model.compute_dtype = dtype
     model.prepare()
+    if os.environ.get("CROG_WORKER_SINGLE_STREAM") == "1":      # (probe: no weight-gradient / text-tower side streams)
+        RT.overlap_wgrad = False
+        model.overlap_text = False
     net = model
     if world > 1:
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
@@ -73,6 +79,9 @@ def main():
     if world > 1:
         res["syncbn_launches"] = np.int64(RT.comm.calls)
         res["syncbn_in_kernel"] = np.int64(getattr(RT.comm, "fused", 0))
+    if world > 1 and os.environ.get("CROG_WORKER_DUMP_AFTER"):
+        print(f"rank {rank}: exchanges from Python {RT.comm.calls}, in kernels {getattr(RT.comm, 'fused', 0)}, timed out "
+              f"{RT.comm.direct.timed_out() if RT.comm.direct is not None else None}, loss {res['loss']}", flush=True)
     if world > 1 and RT.comm.direct is not None:
         assert RT.comm.direct.timed_out() == 0
     np.savez(os.path.join(out_dir, f"{tag}_rank{rank}_of{world}.npz"), **res)

@@ -1229,7 +1229,7 @@ def test_flash_attention_matches_torch(K, B, H, Lq, Lk, causal):
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", [(2, 3, 197, 197, False), (1, 2, 300, 676, False), (1, 4, 33, 129, False), (2, 2, 77, 77, True),
-                                               (1, 1, 676, 676, False)])
+                                               (1, 1, 676, 676, False), (2, 2, 300, 20, False)])
 def test_flash_attention_keep_bits_reproduce_the_hash(K, B, H, Lq, Lk, causal):
     """crog_flash_attn_fwd_bits / bwd_bits: the forward's dropout decisions kept as a bit map.  (1) the map says what the hash says:
     decoded with the layout include/crog_hip.h documents it equals the elements crog_softmax_fwd (the unfused path, same seed and
