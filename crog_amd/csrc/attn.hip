@@ -68,11 +68,17 @@ __device__ inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 
 // bit r: key kb + acc_row(r, h) of batch element b exists and is not padding (only called for ragged or padded key tiles)
 __device__ inline unsigned key_bits16(const AttnArgs& a, int b, int kb, int h) {
   unsigned m = 0u;
+  if (a.kpm) {      // (uniform branch; the 16 byte loads are unconditional - clamped - so that they are in flight together)
+    const uint8_t* row = a.kpm + (long)b * a.Lk;
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int kk = kb + acc_row(r, h);
-    const bool ok = kk < a.Lk && !(a.kpm && a.kpm[(long)b * a.Lk + kk]);
-    m |= (ok ? 1u : 0u) << r;
+    for (int r = 0; r < 16; r++) {
+      const int kk = kb + acc_row(r, h);
+      const unsigned pad = row[min(kk, a.Lk - 1)];
+      m |= ((kk < a.Lk && pad == 0u) ? 1u : 0u) << r;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; r++) m |= ((kb + acc_row(r, h) < a.Lk) ? 1u : 0u) << r;
   }
   return m;
 }
@@ -147,7 +153,8 @@ __global__ void __launch_bounds__(NTHR, 3) flash_fwd_kernel(const AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int kk = kb + acc_row(r, h);
-        s[r] = (((kv >> r) & 1u) && (!a.causal || kk <= q)) ? s[r] * c2 : -INFINITY;
+        const bool ok = (((kv >> r) & 1u) != 0u) & ((a.causal == 0) | (kk <= q));
+        s[r] = ok ? s[r] * c2 : -INFINITY;
         mt = fmaxf(mt, s[r]);
       }
     }
@@ -284,12 +291,20 @@ __global__ void __launch_bounds__(NTHR, 3) flash_bwd_dq_kernel(const AttnArgs a)
       dp = mfma(kc_frag(sVc[buf], ln, 2 * ks + h), dof[ks], dp);
     }
     const int kb = kt * TT;
-    const unsigned kv = (kb + TT <= a.Lk && !a.kpm) ? 0xffffu : key_bits16(a, b, kb, h);
+    if (kb + TT <= a.Lk && !a.kpm && !a.causal) {      // a whole, unmasked tile (uniform): no per-score conditions
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int kk = kb + acc_row(r, h);
-      const float p = (((kv >> r) & 1u) && (!a.causal || kk <= q)) ? ex2(s[r] * c2 - Lr) : 0.f;
-      s[r] = p;
+      for (int r = 0; r < 16; r++) s[r] = ex2(s[r] * c2 - Lr);
+    } else {
+      const unsigned kv = key_bits16(a, b, kb, h);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int kk = kb + acc_row(r, h);
+        // the exponential of a SELECTED ARGUMENT (v_exp_f32(-inf) = 0), not a selected exponential: hipcc compiles `cond ? ex2(x) : 0.f` into
+        // an exec-mask branch per score (16 per tile, each with its own waits)
+        const bool ok = (((kv >> r) & 1u) != 0u) & ((a.causal == 0) | (kk <= q));      // (bitwise: no short-circuit control flow)
+        const float x = s[r] * c2 - Lr;
+        s[r] = ex2(ok ? x : -INFINITY);
+      }
     }
     if (a.p_drop > 0.f) {
       if (kw) {
@@ -451,14 +466,26 @@ __global__ void __launch_bounds__(NTHR, 2) flash_bwd_dkdv_kernel(const AttnArgs 
         keepbits |= (k1 ? 1u : 0u) << (r + 1);
       }
     }
+    // lse / D of the lane's 16 query rows (8 g + 4 h + {0 .. 3}) as four 16-byte reads each, and the exponential of a SELECTED ARGUMENT
+    // (v_exp_f32(-inf) = 0): `cond ? ex2(s - sL[qr]) : 0.f` became an exec-mask branch per score with its own ds_read_b32 + wait inside
+    float lq[16], dq_[16];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const float4 l4 = *reinterpret_cast<const float4*>(&sL[buf][8 * g + 4 * h]), d4 = *reinterpret_cast<const float4*>(&sD[buf][8 * g + 4 * h]);
+      lq[4 * g] = l4.x; lq[4 * g + 1] = l4.y; lq[4 * g + 2] = l4.z; lq[4 * g + 3] = l4.w;
+      dq_[4 * g] = d4.x; dq_[4 * g + 1] = d4.y; dq_[4 * g + 2] = d4.z; dq_[4 * g + 3] = d4.w;
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int qr = acc_row(r, h);
-      const float p = (kvalid && qb + qr < a.Lq && (!a.causal || key <= qb + qr)) ? ex2(s[r] * c2 - sL[buf][qr]) : 0.f;
+      // (bitwise: no short-circuit control flow.  A uniform `whole tile` shortcut of these conditions measured SLOWER here: 177 -> 201 us)
+      const bool ok = kvalid & (qb + qr < a.Lq) & ((a.causal == 0) | (key <= qb + qr));
+      const float x = s[r] * c2 - lq[r];
+      const float p = ex2(ok ? x : -INFINITY);
       const bool keep = (keepbits >> r) & 1u;
       const float g = keep ? dp[r] * sc : 0.f;
       pd[r] = keep ? p * sc : 0.f;
-      s[r] = p * (g - sD[buf][qr]) * a.scale;
+      s[r] = p * (g - dq_[r]) * a.scale;
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -607,14 +634,23 @@ __global__ void __launch_bounds__(NTHR, 1) flash_bwd_dkdv_short_kernel(const Att
       }
     }
     f32x16 pd;
+    float lq[16], dq_[16];      // (as in flash_bwd_dkdv_kernel)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const float4 l4 = *reinterpret_cast<const float4*>(&sL[wave][8 * g + 4 * h]), d4 = *reinterpret_cast<const float4*>(&sD[wave][8 * g + 4 * h]);
+      lq[4 * g] = l4.x; lq[4 * g + 1] = l4.y; lq[4 * g + 2] = l4.z; lq[4 * g + 3] = l4.w;
+      dq_[4 * g] = d4.x; dq_[4 * g + 1] = d4.y; dq_[4 * g + 2] = d4.z; dq_[4 * g + 3] = d4.w;
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int qr = acc_row(r, h);
-      const float p = (kvalid && qb + qr < a.Lq) ? ex2(s[r] * c2 - sL[wave][qr]) : 0.f;
+      const bool ok = kvalid & (qb + qr < a.Lq);
+      const float x = s[r] * c2 - lq[r];
+      const float p = ex2(ok ? x : -INFINITY);
       const bool keep = (keepbits >> r) & 1u;
       const float g = keep ? dp[r] * sc : 0.f;
       pd[r] = keep ? p * sc : 0.f;
-      s[r] = p * (g - sD[wave][qr]) * a.scale;
+      s[r] = p * (g - dq_[r]) * a.scale;
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
