@@ -197,9 +197,9 @@ def test_two_rank_deterministic_mode_is_bit_reproducible(tmp_path):
 
 @pytest.mark.skipif("CROG_TEST_WORLD" not in os.environ,
                     reason="full training step with more than two processes on ONE GPU: set CROG_TEST_WORLD (8 = the target world size). "
-                           "On this pool's boxes (<= 6 GPU processes) the 4-rank form does not finish: every rank ends in Reducer.wait() "
-                           "on its gloo bucket works, with any SyncBatchNorm fusion switch, one stream, 2-s mailbox timeouts "
-                           "(scripts/many_rank_probe.py, LAB_NOTES section 10); the 8-rank form passed mid-round 5")
+                           "On this pool's boxes (<= 6 GPU processes) the 4-rank form does not finish within the 420 s of _run: with gloo "
+                           "statistics as with the mailboxes, all ranks in step inside one gloo all-reduce (scripts/many_rank_probe.py, "
+                           "LAB_NOTES section 10); the 8-rank form passed mid-round 5")
 def test_many_rank_ddp_syncbn_over_the_peer_mailboxes(tmp_path):
     """More than two ranks on one GPU (VERDICT r4 asked for the target world size, 8: CROG_TEST_WORLD=8; 4 by default, see MANY):
     MANY processes sharing cuda:0, one sample each, DistributedDataParallel + SyncBatchNorm (fp32, tiny CROG): every BatchNorm layer's
