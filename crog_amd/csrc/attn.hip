@@ -1,6 +1,6 @@
-// Fused multi-head attention for the unmasked, head_dim = 64, bf16 case: the decoder's 676-token self-attention
-// (layers.py:291-296,324) and the ViT tower's 197-token blocks (clip.py:246-260) — the "MFMA attention path" of BASELINE
-// config 4.  Scores are never written to HBM: the unfused path moves ~1 GB per decoder layer forward (S, P, dropout(P)) and
+// Fused multi-head attention for the head_dim = 64, bf16 case: the decoder's 676-token self-attention (layers.py:291-296,324) and - with a
+// key padding mask - its vision-to-text cross-attention over 20 word keys (layers.py:329-332), the ViT tower's 197-token blocks
+// (clip.py:246-260) — the "MFMA attention path" of BASELINE config 4 — and, causal, the text tower's 20-token blocks (clip.py:446-452).  Scores are never written to HBM: the unfused path moves ~1 GB per decoder layer forward (S, P, dropout(P)) and
 // ~2 GB backward at B = 32; this one reads Q, K, V (+ O, dO) once per 128-row block.
 //
 // Layout trick (all three kernels): the 32x32x16 MFMA returns C with lane = column, 16 rows in registers.  Computing the
