@@ -171,3 +171,37 @@ def test_device_code_is_built_without_packed_fp32_instructions(tmp_path):
     text = out.read_text()
     assert "upsample2_bwd_quad_kernel" in text
     assert not re.search(r"\bv_pk_(fma|mul|add)_f32\b", text)
+
+
+def test_attention_backward_loops_hold_no_per_score_branches(tmp_path):
+    """Round 5 (LAB_NOTES section 10): hipcc had compiled the backward attention kernels' `cond ? exp2(x) : 0` per score into an exec-mask
+    branch per score - in dK/dV 16 per tile, each with a ds_read_b32 and its own wait inside (44 s_and_saveexec in the loop, 231 us per decoder
+    layer).  Written as the exponential of a selected argument over bitwise conditions the loop is straight-line code (17 / 5 / 1 branches left:
+    prefetch guards and uniform paths; 180 us).  Compiles attn.hip to ISA with the library's flags and counts inside each kernel's main loop."""
+    out = tmp_path / "attn.s"
+    flags = [f for f in _lib.HIPCC_FLAGS if f != "-fPIC"] + _lib.EXTRA_FLAGS.get("attn.hip", [])
+    subprocess.check_call(["hipcc"] + flags + ["-S", "--cuda-device-only", os.path.join(_lib.CSRC, "attn.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    kernels, cur = {}, None
+    for line in out.read_text().splitlines():
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+        elif cur:
+            kernels[cur].append(line)
+    limits = {"flash_fwd_kernel": 6, "flash_bwd_dq_kernel": 12, "flash_bwd_dkdv_kernel": 24, "flash_bwd_dkdv_short_kernel": 14}
+    seen = set()
+    for name, lines in kernels.items():
+        key = next((k for k in limits if re.search(rf"\d+{k}E", name)), None)
+        if key is None:
+            continue
+        seen.add(key)
+        hdr = [i for i, l in enumerate(lines) if "Loop Header" in l]
+        end = max(i for i, l in enumerate(lines) if "in Loop: Header" in l or "Loop Header" in l)
+        body = lines[hdr[0]:end + 40]
+        n = sum("s_and_saveexec" in l for l in body)
+        assert sum("v_mfma" in l for l in body) >= 8, name
+        assert n <= limits[key], f"{key}: {n} exec-mask branches inside the main loop (limit {limits[key]})"
+        assert not any("ds_read_b32 " in l for l in body if key == "flash_bwd_dkdv_kernel"), "lse / D must be read as 16-byte vectors"
+    assert seen == set(limits), seen
