@@ -31,7 +31,7 @@ SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_ppt.hip", "conv_sw.hip", 
 # the feature and says so ("not a recognized feature for this target (ignoring feature)"): harmless.  scripts/count_pk.py counts them;
 # tests/test_abi_host.py checks that a rebuilt source holds none.
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"] + NO_PACKED_F32
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"] + NO_PACKED_F32 + ["-DCROG_NO_PACKED_F32=1"]      # (the macro is what crog_build_flags() reports)
 # norm.hip (BatchNorm / LayerNorm / softmax) is compiled WITHOUT fused-multiply-add contraction: its kernels are HBM-bound, and its fp32
 # arithmetic then has the reference's structure - every product rounded, as torch's kernels form them.  y = z * scale + (beta - mean * scale)
 # relies on fl(z * scale) and fl(mean * scale) rounding alike when z is close to the channel's mean (two samples per channel in config 1's
@@ -150,8 +150,20 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
             raise RuntimeError(f"libcrog_hip.so does not export {name} declared in crog_hip.h") from e
         fn.restype = restype
         fn.argtypes = argtypes
+    if not packed_f32_off(lib):
+        # a library supplied through CROG_LIB, or built by other means: its fp32 element-wise kernels may hold v_pk_*_f32, whose
+        # results were found wrong beside another stream's MFMA kernel (NO_PACKED_F32 above).  runtime.set_deterministic refuses such a library.
+        import warnings
+        warnings.warn(f"{path} was built with packed-fp32 VALU instructions ({lib.crog_build_flags().decode()}): results beside a second "
+                      "stream's GEMM are not trustworthy on gfx950 and deterministic mode is unavailable; rebuild with crog_amd._lib.build()")
     _lib = lib
     return lib
+
+
+def packed_f32_off(lib=None) -> bool:
+    """Was the loaded library compiled without the packed-fp32 VALU instructions (crog_build_flags)?"""
+    lib = lib if lib is not None else load()
+    return b"packed-fp32-ops=off" in lib.crog_build_flags()
 
 
 def source_digest() -> str:

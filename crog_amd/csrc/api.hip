@@ -14,6 +14,12 @@ void crog_set_error(const char* fmt, ...) {
 
 extern "C" int crog_hip_version(void) { return 100; }
 extern "C" const char* crog_last_error(void) { return g_err; }
+// How the device code of THIS library was compiled (crog_amd/_lib.py passes -DCROG_NO_PACKED_F32=1 together with the target-feature switch
+// that removes v_pk_*_f32; a library built by other means says "packed-fp32-ops=on" and the loader warns / deterministic mode refuses).
+#ifndef CROG_NO_PACKED_F32
+#define CROG_NO_PACKED_F32 0
+#endif
+extern "C" const char* crog_build_flags(void) { return CROG_NO_PACKED_F32 ? "arch=gfx950 packed-fp32-ops=off" : "arch=gfx950 packed-fp32-ops=on"; }
 
 // ---- peak probes (bench.py `measured_peaks`, SURVEY.md §8d: confirm the vendor peaks on the box before quoting fractions) ----
 // bf16 MFMA issue rate: every wave runs `iters` x 8 independent v_mfma_f32_32x32x16_bf16 on register operands (non-zero,

@@ -124,7 +124,9 @@ class WRef:
         """The kernels that write this parameter's gradient are enqueued (or parked: Runtime.defer_wgrad - then the announcement waits
         for the flush that really enqueues them, so a DDP bucket can never be launched ahead of its last gradient)."""
         if RT._pending_wgrad:
-            RT._pending_done.append(self._done_now)
+            # (re-evaluated by flush_wgrad once the deferred closure has run: if that closure PARKED the gradient for a grouped launch the
+            # announcement moves on to the group - ADVICE r5: _done_now here let FusedAdam / a DDP bucket go ahead of the grouped GEMM)
+            RT._pending_done.append(self.done)
             return
         if RT._groups:      # parked for a grouped launch (Runtime.park_wgrad): announced when that launch is enqueued
             lo = self.store.G.data_ptr() + 4 * self.off

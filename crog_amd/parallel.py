@@ -84,8 +84,8 @@ class SyncBNComm:
         CROG_SYNCBN_FUSE=0).  Counted in `fused` (bench.py reports both counts)."""
         if self.direct is None or not self.direct.has_peer or n > self._slot() or _os.environ.get("CROG_SYNCBN_FUSE", "1") == "0":
             return None
-        if not getattr(self.direct, "tail_ok", False) and getattr(self.direct, "selftested", False):
-            return None      # the tail form failed its start-up self-test on some rank: exchanges stay launches of their own
+        if not getattr(self.direct, "tail_ok", False):
+            return None      # the tail form has not passed its start-up self-test on every rank (failed, or a communicator built without one): launches of their own
         self.fused = getattr(self, "fused", 0) + 1
         return self.direct.sync_block()
 
@@ -292,6 +292,13 @@ class Reducer:
         """Flush buckets holding unused parameters, wait for all collectives, finish the mean."""
         if self._done:
             return
+        # Everything the runtime still holds back goes FIRST (ADVICE r5): this callback is queued by the first gradient announcement of the
+        # pass (the head's, before any weight gradient has armed Runtime._end_of_backward), so it runs ahead of the runtime's own
+        # end-of-backward flush.  A weight gradient still parked for a grouped launch (or deferred behind a data gradient) would be
+        # all-reduced before its GEMM is enqueued, and its late announcement would hit the reset reducer and start a second round of
+        # all-reduces.  The flush enqueues those launches and lets their announcements through (which may launch buckets from here).
+        RT.flush_wgrad()
+        RT.flush_group()
         for b in self.buckets:
             self._launch(b)
         for b in self.buckets:

@@ -178,18 +178,24 @@ class DirectComm:
     def _selftest_tail(self, dev) -> bool:
         """The first BatchNorm-backward pass with the exchange in its tail, eight times back to back (both slot parities, no host
         synchronisation in between): rank r's gradient is r + 1 everywhere and x-hat is 1, so every channel's two totals must come back as
-        M W (W + 1) / 2 - exact in fp32."""
+        M W (W + 1) / 2 - exact in fp32.  Round 6: then a many-block stress - 1024 blocks per launch (four waves of blocks
+        on the 256 CUs, so the last-arriver ticket is taken while other blocks' atomic adds are still in flight on every XCD) at 64, 256
+        and 1024 channels, twice each.  The hand-off inside crog_stat_sync_tail rests on gfx950 performing agent-scope fp32 atomics at the
+        memory side (comm_dev.h): this is where a part that does not would show."""
         try:
-            W, C, M, R = self.world_size, 64, 4096, 2
-            dy = torch.full((M, C), float(self.rank + 1), device=dev, dtype=torch.bfloat16)
-            z = torch.ones(M, C, device=dev, dtype=torch.bfloat16)
-            mi = torch.tensor([0.0, 1.0], device=dev).repeat(C).view(C, 2).contiguous()
-            rpb = K.bn_rows_per_block(M)
-            bufs = [torch.zeros(R * 2 * C + 2 * C + 8, device=dev) for _ in range(8)]
-            for buf in bufs:
-                K.bn_bwd_partial(dy, None, z, mi, rpb, buf, None, replicas=R, stat_sync=self.sync_block(), tail=True)
-            want = float(M * W * (W + 1) // 2)
-            ok = all(bool((buf[R * 2 * C:(R + 1) * 2 * C] == want).all()) for buf in bufs)
+            W, R = self.world_size, 2
+            cases = [(64, 4096)] * 8 + [(64, 32768), (256, 32768), (1024, 32768)] * 2
+            ops, bufs = {}, []
+            for C, M in cases:
+                if (C, M) not in ops:
+                    ops[(C, M)] = (torch.full((M, C), float(self.rank + 1), device=dev, dtype=torch.bfloat16),
+                                   torch.ones(M, C, device=dev, dtype=torch.bfloat16),
+                                   torch.tensor([0.0, 1.0], device=dev).repeat(C).view(C, 2).contiguous())
+                dy, z, mi = ops[(C, M)]
+                buf = torch.zeros(R * 2 * C + 2 * C + 8, device=dev)
+                K.bn_bwd_partial(dy, None, z, mi, K.bn_rows_per_block(M), buf, None, replicas=R, stat_sync=self.sync_block(), tail=True)
+                bufs.append((C, M, buf))
+            ok = all(bool((buf[R * 2 * C:(R + 1) * 2 * C] == float(M * W * (W + 1) // 2)).all()) for C, M, buf in bufs)
             return ok and self.timed_out() == 0
         except Exception:
             return False

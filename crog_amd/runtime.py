@@ -447,6 +447,11 @@ def set_deterministic(on: bool = True):
     pair behind each shuffle; with packed fp32 off the shuffle build is clean too.  The DPP / v_readlane reductions that replaced the
     shuffles stay: they are what the library uses.)
     Call it before the first step and outside a capture (it allocates the library's scratch once)."""
+    if on:
+        from ._lib import packed_f32_off
+        if not packed_f32_off(K.lib()):
+            raise RuntimeError("crog_amd: deterministic mode needs a library built without packed-fp32 VALU instructions "
+                               f"(crog_build_flags: {K.lib().crog_build_flags().decode()}); rebuild with crog_amd._lib.build()")
     K.check(K.lib().crog_set_deterministic(1 if on else 0), "set_deterministic")
     RT.deterministic = bool(on)
 

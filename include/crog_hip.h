@@ -33,6 +33,10 @@ enum crog_status { CROG_OK = 0, CROG_ERR_ARG = -1, CROG_ERR_LAUNCH = -2 };
 
 int crog_hip_version(void);
 const char* crog_last_error(void);
+/* Compile-time facts of the device code, as "key=value" words: "arch=gfx950 packed-fp32-ops=off|on".  The bit-reproducibility guarantee of
+ * crog_set_deterministic (and the default mode's correctness beside a second stream's MFMA kernel) holds only for a library built WITHOUT
+ * the packed-fp32 VALU instructions (crog_amd/_lib.py NO_PACKED_F32); a binding checks this word before it relies on either. */
+const char* crog_build_flags(void);
 /* Peak probes for the measurement harness (bench.py `measured_peaks`; SURVEY.md §8d asks for the box's own stream-copy and
  * MFMA rates beside the vendor figures).  crog_probe_mfma_bf16: `blocks` x 4 waves each issue iters x 8 independent
  * v_mfma_f32_32x32x16_bf16 on register operands (FLOP = blocks * 4 * iters * 8 * 32768); `sink` needs blocks * 256 floats and is

@@ -14,10 +14,46 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _install_trace(path):
+    """Debugging aid (scripts/many_rank_probe.py, CROG_WORKER_TRACE=1): one line per collective this rank issues - time, sequence number,
+    kind (stat = a BatchNorm statistics exchange launched from Python, fuse = one handed to its producing kernel, bucket = a gradient
+    bucket's all-reduce with its index, wait = Reducer.wait) - flushed as written, so that the ranks' sequences can be diffed and a
+    rank that stops can be told from one that is slow."""
+    import time
+    from crog_amd import parallel as PP
+    f, t0, seq = open(path, "w"), time.time(), [0]
+
+    def log(kind, detail=""):
+        seq[0] += 1
+        f.write(f"{time.time() - t0:9.3f} {seq[0]:5d} {kind} {detail}\n")
+        f.flush()
+
+    def wrap(cls, name, kind, detail):
+        orig = getattr(cls, name)
+
+        def w(self, *a, **k):
+            log(kind + "<", detail(self, *a, **k))
+            r = orig(self, *a, **k)
+            log(kind + ">", "" if r is None or kind != "fuse" else "in-kernel")
+            return r
+        setattr(cls, name, w)
+    wrap(PP.SyncBNComm, "all_reduce_sum", "stat", lambda self, t: f"n={t.numel()}")
+    wrap(PP.SyncBNComm, "fuse_ptr", "fuse", lambda self, n: f"n={n}")
+    wrap(PP.Reducer, "_launch", "bucket", lambda self, b: f"i={self.buckets.index(b)} launched={b['launched']} pending={b['pending']}")
+    wrap(PP.Reducer, "wait", "wait", lambda self: f"done={self._done} unlaunched={sum(not b['launched'] for b in self.buckets)}")
+    return log
+
+
 def main():
     if os.environ.get("CROG_WORKER_DUMP_AFTER"):      # debugging aid (scripts/many_rank_probe.py): where is a rank that does not finish?
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["CROG_WORKER_DUMP_AFTER"]), exit=True)
+        every = os.environ.get("CROG_WORKER_DUMP_EVERY")
+        if every:      # a dump every N seconds (a rank that moves between dumps is slow, not stuck), the process ends with the last one
+            faulthandler.dump_traceback_later(int(every), repeat=True)
+            import threading
+            threading.Timer(int(os.environ["CROG_WORKER_DUMP_AFTER"]), lambda: os._exit(1)).start()
+        else:
+            faulthandler.dump_traceback_later(int(os.environ["CROG_WORKER_DUMP_AFTER"]), exit=True)
     rank, world, port, out_dir, dtype_name, gain = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], float(sys.argv[6])
     size, B, tag = int(sys.argv[7]), int(sys.argv[8]), sys.argv[9]
     from crog_amd.model import build_crog
@@ -54,13 +90,18 @@ def main():
     b = {k: v[rank * per:(rank + 1) * per].cuda() for k, v in full.items()}
     net.train()
     res = {}
+    log = _install_trace(os.path.join(out_dir, f"{tag}_trace{rank}.txt")) if os.environ.get("CROG_WORKER_TRACE") == "1" else (lambda *a: None)
     names = meta["param_names"]
     for step in range(2):
         RT.manual_seed(11)
+        log("step", str(step))
         preds, tgts, loss, _ = net(b["img"], b["word"], b["mask"], b["qua"], b["sin"], b["cos"], b["wid"])
         opt.zero_grad()
+        log("backward<")
         loss.backward()
+        log("backward>")
         torch.cuda.synchronize()
+        log("synchronized")
         if step == 0:
             params = dict(model.named_parameters())
             res["preds"] = torch.cat([p.float() for p in preds], 1).cpu().numpy()
