@@ -171,9 +171,31 @@ class DirectComm:
                     self.all_reduce_bucket(y, average=avg)
                     ref = want(n, avg)
                     ok_rccl = ok_rccl and bool(torch.allclose(y, ref, rtol=1e-6, atol=0.0))
+                ok_rccl = ok_rccl and self._selftest_beside_mfma(dev)
         except Exception:
             ok_rccl = False
         return ok_peer, ok_rccl
+
+    def _selftest_beside_mfma(self, dev) -> bool:
+        """The gradient buckets are all-reduced BESIDE backward's MFMA kernels by design (parallel.Reducer: carrier stream), and round 5
+        found fp32 element-wise results of this library's own kernels going wrong in exactly that situation when they used packed-fp32 VALU
+        instructions (crog_amd/_lib.py NO_PACKED_F32).  RCCL's kernels are not rebuilt by this package (the gfx950 all-reduce kernels of the
+        resident librccl.so hold no such instruction: scripts/count_pk_foreign.py), so the hazard is bounded where it would show: the same
+        4 M-float bucket of non-trivial values all-reduced ALONE and again while an MFMA kernel (crog_probe_mfma_bf16, ~2 ms on every CU)
+        runs on a second stream must come back as the same bits.  Collective verdict like every other self-test."""
+        from .runtime import RT
+        n = 1 << 22
+        base = (torch.arange(n, device=dev, dtype=torch.float32) % 8191) * (0.37 + 0.01 * self.rank) - 1000.0
+        a, b = base.clone(), base.clone()
+        self.all_reduce_bucket(a, average=True)
+        cur = torch.cuda.current_stream()
+        side = RT.wgrad_stream() or torch.cuda.Stream()
+        sink = torch.empty(512 * 256, device=dev, dtype=torch.float32)
+        side.wait_stream(cur)
+        K.check(self._lib.crog_probe_mfma_bf16(sink.data_ptr(), 512, 8000, side.cuda_stream), "probe_mfma")
+        self.all_reduce_bucket(b, average=True)          # on the caller's stream, while the probe holds the matrix cores
+        cur.wait_stream(side)
+        return bool(torch.equal(a, b))
 
     def _selftest_tail(self, dev) -> bool:
         """The first BatchNorm-backward pass with the exchange in its tail, eight times back to back (both slot parities, no host

@@ -76,6 +76,32 @@ def seeded_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Ten
     return (gain / math.sqrt(fan_in)) * torch.randn(shape, generator=g)
 
 
+def grad_probe(name: str, numel: int, seed: int = 0) -> torch.Tensor:
+    """A fixed unit-normal vector per parameter name: <gradient, probe> is a direction-sensitive scalar of a gradient too large to commit
+    (|<e, probe>| ~ ||e|| for an error vector e).  Both the golden generator and the GPU tests flatten the gradient in the reference's
+    logical element order ([Cout, Cin, kh, kw] for convolutions)."""
+    return torch.randn(numel, generator=_gen("probe::" + name, seed))
+
+
+def seeded_cotangent(name: str, shape: Tuple[int, ...], seed: int = 0, scale: float = 1e-2, relu: bool = False) -> torch.Tensor:
+    """Synthetic stage inputs / upstream gradients of the stage-isolated backward tests (oracle/make_golden.py `stages`), in the reference's
+    NCHW element order; relu=True for stand-ins of post-ReLU feature maps."""
+    t = torch.randn(shape, generator=_gen("cot::" + name, seed)) * scale
+    return t.clamp_min(0) if relu else t
+
+
+STAGE_OF = (("image", lambda n: n.startswith("backbone.visual.")),
+            ("text", lambda n: n.startswith("backbone.") and not n.startswith("backbone.visual.") and n != "backbone.logit_scale"),
+            ("neck", lambda n: n.startswith("neck.")), ("decoder", lambda n: n.startswith("decoder.")), ("proj", lambda n: n.startswith("proj.")))
+
+
+def stage_of(name: str) -> str:
+    for st, pred in STAGE_OF:
+        if pred(name):
+            return st
+    return ""
+
+
 def seeded_state(shapes: Dict[str, Iterable[int]], seed: int = 0, residual_gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """`residual_gain` < 1 scales the last norm of every residual branch (bn3 of each Bottleneck), which is how
     trained / zero-init-residual networks look (clip.py:402-408 zero-inits bn3).  With gain 1 the random R50 trunk

@@ -19,8 +19,8 @@ REF = os.environ.get("CROG_REFERENCE", "/root/reference")
 import numpy as np
 import torch
 
-from crog_amd.testing import (SSG_OUTPUTS, make_cfg, seeded_state, ssg_surrogate_loss, ssg_tiny_cfg, synthetic_batch,
-                              synthetic_ssg_batch, synthetic_ssg_targets, tiny_cfg)
+from crog_amd.testing import (SSG_OUTPUTS, grad_probe, make_cfg, seeded_cotangent, seeded_state, ssg_surrogate_loss, ssg_tiny_cfg, stage_of,
+                              synthetic_batch, synthetic_ssg_batch, synthetic_ssg_targets, tiny_cfg)
 
 GOLD = os.path.join(REPO, "tests", "golden")
 
@@ -161,6 +161,164 @@ def run_case_bf16(name, cfg, B, seed, ref_model, ref_clip, residual_gain=1.0):
             out["grad::" + n] = p.grad.float()
     np.savez_compressed(os.path.join(GOLD, name + "_bf16ref.npz"), **{k: v.detach().numpy() for k, v in out.items()})
     print(name + "_bf16ref", "loss", float(loss.detach()), "pred dtype", preds[0].dtype, flush=True)
+
+
+def stage_fixture(name, cfg, B, seed, ref_model, ref_clip, residual_gain, maps, bf16=True):
+    """Stage-isolated backward pins.  The reference's full training step is run once with `retain_grad` on the stage
+    boundaries - (word_feat, state) out of the text tower (clip.py:439-456), (x2, x3, x4) out of the image tower (clip.py:207-223), fq out of
+    the neck (layers.py:371-398), fq_dec out of the decoder (layers.py:243-277) - and each stage is then run ALONE on the recorded boundary
+    values with the recorded upstream gradients injected: in fp32 (must reproduce the full step's parameter gradients: asserted here) and
+    under bf16 autocast (what a correct bf16 stage costs with its upstream gradient held fixed - the yardstick of the GPU test, free of
+    whatever the stages above amplify).  Stored as `name`_stages.npz: per parameter ||g|| and <g, probe(name)> of the fp32 step and of the
+    bf16 stage runs; the boundary values and gradients themselves for the text tower (always: 45 K floats) and, with `maps` (the tiny model),
+    for every boundary.  Full depth (`maps` False): image tower / neck / decoder boundaries are 23 M floats - instead those stages are pinned on
+    SEEDED inputs and cotangents (crog_amd.testing.seeded_cotangent, re-derived on the GPU side), fp32 and bf16 alike."""
+    import contextlib
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    model, _ = build_reference(cfg, ref_model, ref_clip)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    state0 = seeded_state(shapes, seed=seed, residual_gain=residual_gain)
+    model.load_state_dict(state0)
+    batch = synthetic_batch(B, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + seed)
+    names = [n for n, _ in model.named_parameters()]
+    params = dict(model.named_parameters())
+    probes = {n: grad_probe(n, params[n].numel(), seed) for n in names}
+    model.train()
+    kept = {}
+    bb = model.backbone
+    enc_i, enc_t = bb.encode_image, bb.encode_text
+
+    # (x3 is computed from x2, x4 from x3, state from word_feat: a boundary's OWN retained gradient would include what flows back through the
+    # later outputs of the same stage.  The stage hands out identity copies; their gradients are what the downstream stages send back.)
+    def wrap_i(img):
+        vis = tuple(v.clone() for v in enc_i(img))
+        for k, v in zip(("x2", "x3", "x4"), vis):
+            v.retain_grad()
+            kept[k] = v
+        return vis
+
+    def wrap_t(w):
+        wf, st = (t.clone() for t in enc_t(w))
+        wf.retain_grad(), st.retain_grad()
+        kept["word_feat"], kept["state"] = wf, st
+        return wf, st
+
+    def keep(key):
+        def f(_m, _i, o):
+            o.retain_grad()
+            kept[key] = o
+        return f
+    bb.encode_image, bb.encode_text = wrap_i, wrap_t
+    hooks = [model.neck.register_forward_hook(keep("fq")), model.decoder.register_forward_hook(keep("fq_dec"))]
+    model.zero_grad()
+    _, _, loss, _ = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
+    loss.backward()
+    del bb.encode_image, bb.encode_text
+    for h in hooks:
+        h.remove()
+    vals = {k: v.detach().clone() for k, v in kept.items()}
+    grads = {k: v.grad.detach().clone() for k, v in kept.items()}
+    pad_mask = torch.zeros_like(batch["word"]).masked_fill_(batch["word"] == 0, 1).bool()      # crog.py:55
+
+    def measure():
+        gn = torch.full((len(names),), -1.0, dtype=torch.float64)
+        gd = torch.zeros(len(names), dtype=torch.float64)
+        for i, n in enumerate(names):
+            g = params[n].grad
+            if g is not None:
+                gn[i], gd[i] = float(g.double().norm()), float(g.double().flatten() @ probes[n].double())
+        return gn, gd
+    full_gn, full_gd = measure()
+    out = {"full::gnorm": full_gn, "full::gdot": full_gd}
+
+    def run_stage(stage, ins, cots, autocast, f64=False):
+        """-> (parameter gradient norms, probes, input gradients) of `stage` alone: outputs contracted with `cots`.  f64: the same in
+        float64 (the exact answer the two fp32 implementations are measured against)."""
+        if f64:
+            model.double()
+        model.load_state_dict(state0)
+        model.zero_grad()
+        leaves = {k: (v.double() if (f64 and v.is_floating_point()) else v.clone()).requires_grad_(v.is_floating_point()) for k, v in ins.items()}
+        with (torch.autocast("cpu", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()):
+            if stage == "text":
+                outs = list(bb.encode_text(leaves["word"]))
+            elif stage == "image":
+                outs = list(bb.encode_image(leaves["img"]))
+            elif stage == "neck":
+                outs = [model.neck((leaves["x2"], leaves["x3"], leaves["x4"]), leaves["state"])]
+            else:
+                outs = [model.decoder(leaves["fq"], leaves["word_feat"], pad_mask)]
+        torch.autograd.backward(outs, [c.to(o.dtype) for c, o in zip(cots, outs)])
+        gn, gd = measure()
+        res = gn, gd, {k: v.grad.float() for k, v in leaves.items() if v.grad is not None}, [o.detach().float() for o in outs]
+        if f64:
+            model.float()
+            model.load_state_dict(state0)
+        return res
+
+    real = {"text": (dict(word=batch["word"]), [grads["word_feat"], grads["state"]]),
+            "image": (dict(img=batch["img"]), [grads["x2"], grads["x3"], grads["x4"]]),
+            "neck": ({k: vals[k] for k in ("x2", "x3", "x4", "state")}, [grads["fq"]]),
+            "decoder": (dict(fq=vals["fq"], word_feat=vals["word_feat"]), [grads["fq_dec"]])}
+    meta_shapes = {k: list(v.shape) for k, v in vals.items()}
+    for k in ("word_feat", "state"):
+        out["val::" + k], out["grad::" + k] = vals[k], grads[k]
+    if maps:
+        for k in vals:
+            out["val::" + k], out["grad::" + k] = vals[k], grads[k]
+    stages = ["text", "image", "neck", "decoder"] if maps else ["text"]
+    for st in stages:
+        ins, cots = real[st]
+        gn, gd, din, _ = run_stage(st, ins, cots, False)
+        sel = [i for i, n in enumerate(names) if stage_of(n) == st and full_gn[i] > 0]
+        # the isolation itself: the stage alone, fed the recorded upstream gradient, IS the full step's backward through that stage
+        rel = max(abs(float(gn[i]) - float(full_gn[i])) / (float(full_gn[i]) + 1e-12) for i in sel)
+        reld = max(abs(float(gd[i]) - float(full_gd[i])) / (float(full_gn[i]) + 1e-12) for i in sel)
+        print(f"{name} stage {st}: fp32 stage-alone vs full step, worst relative norm difference {rel:.2e}, probe {reld:.2e} over {len(sel)} tensors", flush=True)
+        assert rel < 1e-4 and reld < 1e-4, (st, rel, reld)
+        if st == "neck":
+            for k in ("x2", "x3", "x4"):
+                assert float((din[k] - grads[k]).abs().max()) <= 1e-5 * float(grads[k].abs().max()) + 1e-9
+        if st == "decoder":
+            for k in ("fq", "word_feat"):
+                assert float((din[k] - grads[k]).abs().max()) <= 1e-4 * float(grads[k].abs().max()) + 1e-9
+        if bf16:
+            gnb, gdb, _, _ = run_stage(st, ins, cots, True)
+            out[f"bf16::{st}::gnorm"], out[f"bf16::{st}::gdot"] = gnb, gdb
+    if not maps:
+        # full depth: image tower / neck / decoder on seeded inputs and cotangents (NCHW element order), nothing large to commit
+        sh = meta_shapes
+        syn = {"image": (dict(img=batch["img"]), [seeded_cotangent("d_" + k, tuple(sh[k]), seed) for k in ("x2", "x3", "x4")]),
+               "neck": ({**{k: seeded_cotangent(k, tuple(sh[k]), seed, scale=1.0, relu=True) for k in ("x2", "x3", "x4")},
+                         "state": seeded_cotangent("state", tuple(sh["state"]), seed, scale=1.0)}, [seeded_cotangent("d_fq", tuple(sh["fq"]), seed)]),
+               "decoder": (dict(fq=seeded_cotangent("fq", tuple(sh["fq"]), seed, scale=1.0), word_feat=seeded_cotangent("word_feat", tuple(sh["word_feat"]), seed, scale=1.0)),
+                           [seeded_cotangent("d_fq_dec", tuple(sh["fq_dec"]), seed)])}
+        for st, (ins, cots) in syn.items():
+            gn, gd, din, outs = run_stage(st, ins, cots, False)
+            out[f"syn::{st}::gnorm"], out[f"syn::{st}::gdot"] = gn, gd
+            for j, o in enumerate(outs):      # forward pins of the seeded stage: sums and a strided sample
+                f = o.flatten()
+                out[f"syn::{st}::out{j}::sums"] = torch.stack([f.double().sum(), f.double().abs().sum()])
+                out[f"syn::{st}::out{j}::sample"] = f[::997].clone()
+            for k, g in din.items():
+                if k != "img":
+                    out[f"syn::{st}::din::{k}::norm"] = g.norm()
+                    out[f"syn::{st}::din::{k}::sample"] = g.flatten()[::997].clone()
+            # the exact gradients (float64): the seeded inputs put many ReLU pre-activations within fp32 rounding of zero, and a gate that opens on
+            # one side only moves the gradients downstream of it - the reference's OWN fp32 distance to float64 is the yardstick of the GPU test
+            gn64, gd64, _, _ = run_stage(st, ins, cots, False, f64=True)
+            out[f"syn64::{st}::gnorm"], out[f"syn64::{st}::gdot"] = gn64, gd64
+            sel = [i for i, n in enumerate(names) if stage_of(n) == st and gn64[i] > 0]
+            e = [abs(float(gd[i]) - float(gd64[i])) / float(gn64[i]) for i in sel]
+            print(f"{name} seeded stage {st}: fp32 vs float64 probe distance median {np.median(e):.2e} p90 {np.quantile(e, 0.9):.2e} max {max(e):.2e}", flush=True)
+            if bf16:
+                gnb, gdb, _, _ = run_stage(st, ins, cots, True)
+                out[f"synbf16::{st}::gnorm"], out[f"synbf16::{st}::gdot"] = gnb, gdb
+                print(f"{name} seeded stage {st}: bf16 autocast done", flush=True)
+    np.savez_compressed(os.path.join(GOLD, name + "_stages.npz"), **{k: v.detach().numpy() for k, v in out.items()})
+    json.dump(dict(param_names=names, boundary_shapes=meta_shapes, seed=seed, B=B, residual_gain=residual_gain, maps=bool(maps)),
+              open(os.path.join(GOLD, name + "_stages.json"), "w"))
 
 
 def op_fixtures(ref_clip, ref_layers):
@@ -526,6 +684,10 @@ def main():
         # (not in the default list: ~10 minutes of emulated bf16 on the build container's CPU)
         run_case_bf16("tiny_crog", tiny_cfg(), B=4, seed=3, ref_model=ref_model, ref_clip=ref_clip)
         run_case_bf16("crog_r50_b4_damped", make_cfg(dropout=0.0), B=4, seed=10, ref_model=ref_model, ref_clip=ref_clip, residual_gain=0.25)
+    if "stages" in which:
+        # (not in the default list: the full-depth bf16-autocast stage runs take ~15 minutes of emulated bf16 on the build container's CPU)
+        stage_fixture("tiny_crog", tiny_cfg(), B=4, seed=3, ref_model=ref_model, ref_clip=ref_clip, residual_gain=1.0, maps=True)
+        stage_fixture("crog_r50_b4_damped", make_cfg(dropout=0.0), B=4, seed=10, ref_model=ref_model, ref_clip=ref_clip, residual_gain=0.25, maps=False)
     if "shapes" in which:
         shapes_only(ref_clip)
     if "full" in which:

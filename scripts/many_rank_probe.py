@@ -20,4 +20,7 @@ for p in procs:
         rcs.append(p.wait(timeout=max(1, float(os.environ.get('PROBE_LIMIT', '100')) - (time.time() - t0))))
     except subprocess.TimeoutExpired:
         p.kill(); rcs.append("killed")
+import glob
+for f in glob.glob(os.path.join(out, f"{tag}_rank*_of{world}.npz")):      # (66.6 M-float gradient / parameter dumps: gpurun copies back 64 MiB at most)
+    os.remove(f)
 print(f"{tag} {extra}: return codes {rcs} in {time.time() - t0:.0f} s", flush=True)

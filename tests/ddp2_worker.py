@@ -83,7 +83,9 @@ def main():
         assert RT.comm is not None and RT.comm.world_size == world
         if os.environ.get("CROG_SYNCBN_DIRECT") == "peer":      # the statistics really travel through the hipIpc mailboxes
             assert RT.comm.direct is not None and RT.comm.direct.has_peer and RT.comm.kind == "crog_comm:peer", RT.comm.kind
-        net = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True, bucket_cap_mb=0.25)
+        # 0.25 MiB buckets: ~1000 gradient collectives in flight per step of the tiny model (66.6 M parameters), which is what the two-rank tests want
+        # to exercise; the many-rank tests pass a larger cap (CROG_WORKER_BUCKET_MB) - see tests/test_ddp2_gpu.py on what gloo costs per collective
+        net = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True, bucket_cap_mb=float(os.environ.get("CROG_WORKER_BUCKET_MB", "0.25")))
     opt = FusedAdam(groups, lr=1e-4, store=model.store)
     full = synthetic_batch(B, cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + meta["seed"])
     per = B // world
@@ -118,6 +120,7 @@ def main():
     sd = model.state_dict()
     res["bn_final"] = np.concatenate([sd[k].float().cpu().numpy().ravel() for k in meta["bn_keys"]])
     if world > 1:
+        res["bucket_launches"] = np.int64(net.reducer.launches)      # over both steps: every bucket exactly once per step
         res["syncbn_launches"] = np.int64(RT.comm.calls)
         res["syncbn_in_kernel"] = np.int64(getattr(RT.comm, "fused", 0))
     if world > 1 and os.environ.get("CROG_WORKER_DUMP_AFTER"):

@@ -103,6 +103,74 @@ def test_reducer_matches_single_process(tmp_path):
     assert torch.allclose(r0["pairs"], ref, atol=1e-4)
 
 
+def _order_worker(rank, world, port, tmp):
+    """Four ranks: every rank must issue the SAME gradient-bucket collectives in the SAME order (gloo, like RCCL, matches collectives of a
+    communicator by issue order), each bucket exactly once per step - also when a weight gradient is still held back by the runtime at the
+    end of backward (a deferred / parked launch: Runtime._pending_wgrad + the announcement waiting in _pending_done), which Reducer.wait must
+    flush BEFORE it launches the remaining buckets (it ran ahead of the runtime's own end-of-backward flush, all-reduced the
+    bucket without that gradient and was re-armed by the late announcement)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from crog_amd import parallel as PP
+    from crog_amd.runtime import RT
+    torch.manual_seed(100)
+    net = Net().prepare("cpu")
+    net.explicit_grad_ready = True            # this test announces the gradients itself (as the crog_amd models do through WRef.done)
+    ddp = DistributedDataParallel = PP.DistributedDataParallel(net, bucket_cap_mb=0.0005)
+    order = []
+    orig = PP.Reducer._launch
+
+    def logged(self, b):
+        if not b["launched"]:
+            order.append(self.buckets.index(b))
+        return orig(self, b)
+    PP.Reducer._launch = logged
+    parked = net.a.weight                      # its "GEMM" is enqueued late: the gradient arrives when the runtime flushes
+    late = []
+
+    def hook(p):
+        if p is parked:
+            g = p.grad.clone()
+            p.grad.zero_()                     # not written yet ...
+            RT._pending_wgrad.append((lambda: p.grad.add_(g), ()))      # ... the deferred launch writes it
+            RT._pending_done.append(lambda: (late.append(len(order)), RT.reducer.mark_ready(p)))
+        else:
+            RT.reducer.mark_ready(p)
+    for q in net.parameters():
+        q.register_post_accumulate_grad_hook(hook)
+    g = torch.Generator().manual_seed(7)
+    X, I = torch.randn(4 * world, 12, generator=g), torch.randn(4 * world, 2, 6, 6, generator=g)
+    xs, im = X[rank * 4:(rank + 1) * 4], I[rank * 4:(rank + 1) * 4]
+    for step in range(2):
+        net.store.zero_grad()
+        ddp(xs, im).backward()
+        assert not RT._pending_wgrad and not RT._pending_done
+    nb = len(ddp.reducer.buckets)
+    assert nb > 3 and ddp.reducer.launches == 2 * nb, (nb, ddp.reducer.launches)       # every bucket once per step: no second round
+    assert sorted(order[:nb]) == list(range(nb)) and order[:nb] == order[nb:]
+    assert late and all(0 < n for n in late)      # the parked announcement arrived after other buckets had gone, from inside Reducer.wait
+    gathered = [None] * world
+    dist.all_gather_object(gathered, order)
+    assert all(o == gathered[0] for o in gathered), gathered
+    torch.save(dict(G=net.store.G.clone(), order=order), os.path.join(tmp, f"o{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_bucket_launch_order_is_identical_on_four_ranks_with_a_parked_gradient(tmp_path):
+    world, port = 4, 33000 + os.getpid() % 2000
+    mp.start_processes(_order_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    rs = [torch.load(tmp_path / f"o{r}.pt") for r in range(world)]
+    assert all(r["order"] == rs[0]["order"] for r in rs) and all(torch.equal(r["G"], rs[0]["G"]) for r in rs)
+    from crog_amd.runtime import ParamStore
+    torch.manual_seed(100)
+    net = Net()
+    st = ParamStore(net, torch.device("cpu"))
+    g = torch.Generator().manual_seed(7)
+    X, I = torch.randn(16, 12, generator=g), torch.randn(16, 2, 6, 6, generator=g)
+    (sum(net(X[4 * r:4 * r + 4], I[4 * r:4 * r + 4]) for r in range(4)) / 4).backward()
+    assert torch.allclose(st.G, rs[0]["G"], atol=1e-6, rtol=1e-5)        # the parked gradient made it into its bucket
+
+
 class _FakeLib:
     """Stands in for the C ABI (crog_comm_*) in the set-up protocol test: every call succeeds unless told to fail on this rank."""
 

@@ -1,0 +1,288 @@
+"""Stage-isolated backward parity: each stage of the hot path ALONE on the MI355X, fed the reference's own upstream
+gradient, against the reference's parameter gradients of that stage (tests/golden/*_stages.npz, written by oracle/make_golden.py `stages`
+from the imported reference: the full training step with retain_grad on the stage boundaries, then every stage alone - which reproduces the
+full step's gradients exactly, asserted there).
+
+What this isolates: the whole-model tests see the text tower only BEHIND neck.txt_proj's BatchNorm1d over 2-4 samples, whose backward turns
+last-bit differences of the statistics into per-cent changes of one common upstream factor; with the upstream gradient held fixed a stage's
+own arithmetic is all that is left, so the bounds here are the plain ones - fp32: 1e-3 relative on every parameter gradient (norm, and a
+random projection of the whole tensor), bf16: no further from the fp32 gradients than 1.5x what the REFERENCE's bf16-autocast run of the same
+stage costs.
+
+  tiny model (B = 4, 96 x 96): text tower, image tower, neck, decoder on the recorded boundary values and gradients of the real loss
+  CROG-R50 full depth (B = 4, 416 x 416, config 1's model on reference-conditioned weights):
+      text tower (clip.py:439-456) on the recorded (d word_feat, d state) of the real loss;
+      image tower (clip.py:207-223), neck (layers.py:371-398), decoder (layers.py:243-277) on SEEDED inputs / cotangents
+      (crog_amd.testing.seeded_cotangent: their real boundaries are 23 M floats - not committed)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from crog_amd.testing import grad_probe, make_cfg, seeded_cotangent, seeded_state, stage_of, synthetic_batch, tiny_cfg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+REPORT = os.environ.get("CROG_PARITY_REPORT")      # append the measured numbers to this file (profiles/r06_parity.txt is written this way)
+
+
+def say(line):
+    print(line)
+    if REPORT:
+        with open(REPORT, "a") as f:
+            f.write(line + "\n")
+
+
+def load(case):
+    d = np.load(os.path.join(GOLD, case + "_stages.npz"))
+    meta = json.load(open(os.path.join(GOLD, case + "_stages.json")))
+    base = json.load(open(os.path.join(GOLD, case + ".json")))
+    return {k: torch.from_numpy(d[k]) for k in d.files}, meta, base
+
+
+def build(case, cfg, dtype):
+    from crog_amd.model import build_crog
+    fx, meta, base = load(case)
+    model, _ = build_crog(cfg)
+    model.load_state_dict(seeded_state({k: tuple(v) for k, v in base["shapes"].items()}, seed=meta["seed"], residual_gain=meta["residual_gain"]))
+    model = model.cuda()
+    model.compute_dtype = dtype
+    model.prepare().train()
+    assert [n for n, _ in model.named_parameters()] == meta["param_names"]
+    batch = {k: v.cuda() for k, v in synthetic_batch(meta["B"], cfg.input_size, cfg.word_len, cfg.clip_arch["vocab_size"], seed=1234 + meta["seed"]).items()}
+    return model, fx, meta, batch
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def run_stage(model, stage, dtype, ins, cots):
+    """One stage of crog_amd.model.CROG alone (the calls CROG.forward makes, crog.py:60-74), its outputs contracted with `cots`
+    (reference layout: NCHW maps, [B, L, D] tokens) -> ({name: gradient} of the stage's parameters, input gradients, outputs)."""
+    from crog_amd.runtime import RT
+    store, dev = model.store, torch.device("cuda")
+    store.forward_begins()
+    RT.join_streams()
+    RT.begin_step(dev)
+    store.g_clean = False
+    store.zero_grad()
+    store.weights(dtype)
+    RT.streams = [torch.cuda.current_stream()]
+    leaves = {}
+    for k, v in ins.items():
+        v = v.cuda()
+        if v.is_floating_point() and k != "img":
+            v = (nhwc(v) if v.dim() == 4 else v.contiguous()).to(dtype).requires_grad_(True)
+        leaves[k] = v
+    with torch.autocast("cuda", enabled=False):
+        if stage == "text":
+            outs = list(model.backbone.text_features(leaves["word"], dtype))
+        elif stage == "image":
+            outs = list(model.backbone.image_features(leaves["img"], dtype))
+            model.backbone.visual.fan = None
+        elif stage == "neck":
+            outs = [model.neck((leaves["x2"], leaves["x3"], leaves["x4"]), leaves["state"])]
+        else:
+            B, C, H, W = ins["fq"].shape
+            outs = [model.decoder(leaves["fq"], leaves["word_feat"], (leaves["word"] == 0).contiguous())]
+    total = 0
+    for o, c in zip(outs, cots):
+        c = c.cuda()
+        if c.dim() == 3 and o.dim() == 4:          # the reference's decoder returns [B, C, HW]
+            c = c.view(c.shape[0], c.shape[1], o.shape[1], o.shape[2])
+        c = nhwc(c) if c.dim() == 4 else c
+        assert tuple(c.shape) == tuple(o.shape), (stage, c.shape, o.shape)
+        total = total + (o * c.to(o.dtype)).sum(dtype=torch.float32)
+    total.backward()
+    RT.join_streams()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().float().reshape(-1) for n, p in model.named_parameters() if stage_of(n) == stage and p.grad is not None}
+    din = {k: v.grad.detach().float() for k, v in leaves.items() if v.is_floating_point() and v.grad is not None}
+    return grads, din, [o.detach().float() for o in outs]
+
+
+def measure(grads, names, seed):
+    """-> (norms, probes) aligned with `names` (-1 / 0 where the stage holds no gradient)."""
+    gn, gd = torch.full((len(names),), -1.0, dtype=torch.float64), torch.zeros(len(names), dtype=torch.float64)
+    for i, n in enumerate(names):
+        if n in grads:
+            # in float64: a 2.4 M-element fp32 dot product carries ~1e-3 |g| of summation error of its own (the terms' absolute sum is ~1000 |g|),
+            # which is the size of what is being measured - the generator sums in float64 as well
+            g = grads[n].double().cpu()
+            gn[i], gd[i] = float(g.norm()), float(g @ grad_probe(n, g.numel(), seed).double())
+    return gn, gd
+
+
+def check_fp32(tag, stage, gn, gd, ref_n, ref_d, names, tol=1e-3):
+    sel = [i for i, n in enumerate(names) if stage_of(n) == stage and ref_n[i] > 0]
+    assert sel and all(gn[i] >= 0 for i in sel), (stage, [names[i] for i in sel if gn[i] < 0][:5])
+    top = float(max(ref_n[i] for i in sel))
+    rel_n = [abs(float(gn[i]) - float(ref_n[i])) / float(ref_n[i]) for i in sel]
+    rel_d = [abs(float(gd[i]) - float(ref_d[i])) / float(ref_n[i]) for i in sel]
+    zero = [j for j, i in enumerate(sel) if names[i].endswith("k_proj.bias")]
+    for j in zero:
+        rel_n[j] = rel_d[j] = 0.0
+    wn, wd = int(np.argmax(rel_n)), int(np.argmax(rel_d))
+    say(f"{tag} fp32 stage `{stage}` alone, {len(sel)} parameter gradients vs the reference: worst |norm / ref - 1| {rel_n[wn]:.2e} ({names[sel[wn]]}), "
+        f"worst |<g - g_ref, probe>| / |g_ref| {rel_d[wd]:.2e} ({names[sel[wd]]})")
+    for j, i in enumerate(sel):
+        if names[i].endswith("k_proj.bias"):
+            # mathematically zero (a key bias shifts every score of a row alike, clip.py:119-139): rounding noise on both sides
+            assert float(gn[i]) < 1e-4 * top and float(ref_n[i]) < 1e-4 * top, (names[i], float(gn[i]), float(ref_n[i]), top)
+            continue
+        assert rel_n[j] < tol and rel_d[j] < tol, (names[i], rel_n[j], rel_d[j], float(ref_n[i]))
+
+
+def check_fp32_against_float64(tag, stage, gn, gd, ref_n, ref_d, n64, d64, names, spread):
+    """The seeded full-depth stages.  Seeded normal inputs put ReLU pre-activations within fp32 rounding of zero, and ONE gate that opens in one
+    fp32 evaluation only changes a weight gradient of the layer behind it by ~1 / sqrt(elements of the map) ~ 1e-3 of its norm, and everything
+    downstream with it: the REFERENCE's fp32 gradients sit 1e-4 ... 6e-3 (probe / norm) from its own float64 gradients on these inputs
+    (oracle/make_golden.py prints it), and how many gates flip is a draw.  So: both fp32 results are measured against the float64 one - per
+    tensor |<g - g64, probe>| / |g64| and |norm / norm64 - 1| -, and the size of a draw is measured HERE (`spread`: the HIP stage again with its
+    inputs moved in their last bit, distance to the unperturbed HIP gradients).  The HIP stage's median / 90th percentile / maximum over the
+    stage's tensors stay within 1.5x the reference's + twice the spread's (+ 1e-4); whether the spread term was needed is printed."""
+    sel = [i for i, n in enumerate(names) if stage_of(n) == stage and n64[i] > 0 and not n.endswith("k_proj.bias")]
+    assert sel and all(gn[i] >= 0 for i in sel)
+
+    def dist(n_, d_, n0=n64, d0=d64):
+        return (np.array([abs(float(n_[i]) / float(n0[i]) - 1.0) for i in sel]), np.array([abs(float(d_[i]) - float(d0[i])) / float(n64[i]) for i in sel]))
+    hn, hd = dist(gn, gd)
+    rn, rd = dist(ref_n, ref_d)
+    sp = [dist(pn, pd, gn, gd) for pn, pd in spread]
+    sn, sd = np.maximum.reduce([a for a, _ in sp]), np.maximum.reduce([b for _, b in sp])
+    q = lambda a: (float(np.median(a)), float(np.quantile(a, 0.9)), float(a.max()))
+    fmt = lambda t: " / ".join(f"{x:.2e}" for x in t)
+    say(f"{tag} fp32 seeded stage `{stage}` alone, {len(sel)} parameter gradients, distance to the float64 gradients (median / p90 / max over tensors) - "
+        f"probe: HIP {fmt(q(hd))}, reference fp32 {fmt(q(rd))}, a last-bit input perturbation moves the HIP gradients by {fmt(q(sd))}; "
+        f"norm: HIP {fmt(q(hn))}, reference fp32 {fmt(q(rn))}, perturbation {fmt(q(sn))}")
+    if os.environ.get("CROG_STAGE_TABLE") == "1":
+        for j, i in enumerate(sel):
+            say(f"    {names[i]:48s} |g64| {float(n64[i]):.3e}  probe HIP {hd[j]:.2e} ref {rd[j]:.2e} spread {sd[j]:.2e}   norm HIP {hn[j]:.2e} ref {rn[j]:.2e}")
+    plain = all(q(h)[j] <= 1.5 * q(r)[j] + 1e-4 for h, r in ((hd, rd), (hn, rn)) for j in range(3))
+    say(f"    ... within 1.5x the reference's distance without the spread term: {plain}")
+    for h, r, s_, what in ((hd, rd, sd, "probe"), (hn, rn, sn, "norm")):
+        for j, which in enumerate(("median", "p90", "max")):
+            assert q(h)[j] <= 1.5 * q(r)[j] + 2.0 * q(s_)[j] + 1e-4, (stage, what, which, q(h), q(r), q(s_))
+
+
+def bf16_table(stage, names, gn, gd, n32, d32):
+    sel = [i for i, n in enumerate(names) if stage_of(n) == stage and n32[i] > 1e-9 and gn[i] >= 0]
+    dn = np.array([abs(float(gn[i]) / float(n32[i]) - 1.0) for i in sel])
+    dd = np.array([abs(float(gd[i]) - float(d32[i])) / float(n32[i]) for i in sel])
+    return dict(norm_med=float(np.median(dn)), norm_p90=float(np.quantile(dn, 0.9)), dir_med=float(np.median(dd)), dir_p90=float(np.quantile(dd, 0.9))), len(sel)
+
+
+def check_bf16(tag, stage, hip, ref, n):
+    """hip / ref: bf16_table of the HIP bf16 stage and of the reference's bf16-autocast stage, both against the reference's fp32 gradients."""
+    say(f"{tag} bf16 stage `{stage}` alone ({n} tensors), distance to the reference's fp32 gradients - HIP bf16 / reference bf16 autocast: " +
+        ", ".join(f"{k} {hip[k]:.2e} / {ref[k]:.2e}" for k in hip))
+    for k in hip:
+        # floor: half a bf16 ulp of relative error on a whole tensor is what neither side resolves
+        assert hip[k] <= 1.5 * ref[k] + 2e-3, (stage, k, hip[k], ref[k])
+
+
+@pytest.mark.parametrize("stage", ["text", "image", "neck", "decoder"])
+def test_tiny_stage_backward_on_the_reference_upstream_gradient(stage):
+    """Tiny CROG, fp32 and bf16: the stage alone on the boundary values and the upstream gradient the reference's real loss produced."""
+    for dtype in (torch.float32, torch.bfloat16):
+        model, fx, meta, batch = build("tiny_crog", tiny_cfg(), dtype)
+        names = meta["param_names"]
+        v, g = (lambda k: fx["val::" + k]), (lambda k: fx["grad::" + k])
+        ins, cots = {"text": (dict(word=batch["word"]), [g("word_feat"), g("state")]),
+                     "image": (dict(img=batch["img"]), [g("x2"), g("x3"), g("x4")]),
+                     "neck": (dict(x2=v("x2"), x3=v("x3"), x4=v("x4"), state=v("state")), [g("fq")]),
+                     "decoder": (dict(fq=v("fq"), word_feat=v("word_feat"), word=batch["word"]), [g("fq_dec")])}[stage]
+        grads, din, outs = run_stage(model, stage, dtype, ins, cots)
+        gn, gd = measure(grads, names, meta["seed"])
+        if dtype == torch.float32:
+            check_fp32("tiny", stage, gn, gd, fx["full::gnorm"], fx["full::gdot"], names)
+            # the stage's outputs are the next boundary's recorded values, its input gradients the previous boundary's recorded gradients
+            want = {"text": ["word_feat", "state"], "image": ["x2", "x3", "x4"], "neck": ["fq"], "decoder": ["fq_dec"]}[stage]
+            for o, k in zip(outs, want):
+                r = v(k)
+                r = r.view(r.shape[0], r.shape[1], o.shape[1], o.shape[2]) if (r.dim() == 3 and o.dim() == 4) else r
+                r = nhwc(r) if r.dim() == 4 else r
+                e = float((o.cpu() - r).abs().max())
+                assert e < 1e-3, (stage, k, e)
+            for k in {"neck": ["x2", "x3", "x4"], "decoder": ["fq", "word_feat"]}.get(stage, []):
+                r = g(k)
+                r = nhwc(r) if r.dim() == 4 else r
+                e = float((din[k].cpu() - r).norm() / r.norm())
+                say(f"tiny fp32 stage `{stage}`: input gradient d{k} vs the reference's, relative L2 {e:.2e}")
+                assert e < 1e-3, (stage, k, e)
+        else:
+            hip, n = bf16_table(stage, names, gn, gd, fx["full::gnorm"], fx["full::gdot"])
+            ref, _ = bf16_table(stage, names, fx[f"bf16::{stage}::gnorm"], fx[f"bf16::{stage}::gdot"], fx["full::gnorm"], fx["full::gdot"])
+            check_bf16("tiny", stage, hip, ref, n)
+        del model
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("stage", ["text", "image", "neck", "decoder"])
+def test_full_depth_stage_backward(stage):
+    """CROG-R50 at full depth (B = 4, 416 x 416, 20 tokens).  Text tower: the twelve blocks alone on the (d word_feat, d state) the reference's
+    real loss sends back - the check the whole-model tests cannot make behind neck.txt_proj's BatchNorm1d.  Image tower / neck / decoder: on
+    seeded inputs and cotangents, forward pinned by sums and strided samples of the reference's outputs."""
+    case = "crog_r50_b4_damped"
+    for dtype in (torch.float32, torch.bfloat16):
+        model, fx, meta, batch = build(case, make_cfg(dropout=0.0), dtype)
+        names, seed, sh = meta["param_names"], meta["seed"], meta["boundary_shapes"]
+        cot = lambda k, **kw: seeded_cotangent(k, tuple(sh[k[2:]] if k.startswith("d_") else sh[k]), seed, **kw)
+        if stage == "text":
+            ins, cots = dict(word=batch["word"]), [fx["grad::word_feat"], fx["grad::state"]]
+            ref_n, ref_d, bkey = fx["full::gnorm"], fx["full::gdot"], "bf16::text"
+        else:
+            ins, cots = {"image": (dict(img=batch["img"]), [cot("d_x2"), cot("d_x3"), cot("d_x4")]),
+                         "neck": (dict(x2=cot("x2", scale=1.0, relu=True), x3=cot("x3", scale=1.0, relu=True), x4=cot("x4", scale=1.0, relu=True),
+                                       state=cot("state", scale=1.0)), [cot("d_fq")]),
+                         "decoder": (dict(fq=cot("fq", scale=1.0), word_feat=cot("word_feat", scale=1.0), word=batch["word"]), [cot("d_fq_dec")])}[stage]
+            ref_n, ref_d, bkey = fx[f"syn::{stage}::gnorm"], fx[f"syn::{stage}::gdot"], f"synbf16::{stage}"
+        grads, din, outs = run_stage(model, stage, dtype, ins, cots)
+        gn, gd = measure(grads, names, seed)
+        if dtype == torch.float32:
+            if stage == "text":
+                for o, k in zip(outs, ("word_feat", "state")):
+                    e = float((o.cpu() - fx["val::" + k]).abs().max())
+                    assert e < 1e-3, (k, e)
+            else:
+                for j, o in enumerate(outs):
+                    f = (o.permute(0, 3, 1, 2) if o.dim() == 4 else o).reshape(-1).cpu()      # the reference's element order
+                    e = float((f[::997] - fx[f"syn::{stage}::out{j}::sample"]).abs().max())
+                    sums = torch.stack([f.double().sum(), f.double().abs().sum()])
+                    rs = float(((sums - fx[f"syn::{stage}::out{j}::sums"]).abs() / (fx[f"syn::{stage}::out{j}::sums"].abs() + 1.0)).max())
+                    say(f"full-depth fp32 seeded stage `{stage}` output {j}: sample max err {e:.2e}, sums rel err {rs:.2e}")
+                    assert e < 1e-3 and rs < 1e-3, (stage, j, e, rs)
+                for k, gin in din.items():
+                    key = f"syn::{stage}::din::{k}::norm"
+                    if key in fx:
+                        f = (gin.permute(0, 3, 1, 2) if gin.dim() == 4 else gin).reshape(-1).cpu()
+                        rn = float(fx[key])
+                        es = float((f[::997] - fx[f"syn::{stage}::din::{k}::sample"]).abs().max()) / (float(fx[f"syn::{stage}::din::{k}::sample"].abs().max()) + 1e-30)
+                        say(f"full-depth fp32 seeded stage `{stage}`: input gradient d{k} norm {float(f.norm()):.6e} vs {rn:.6e}, sample err / scale {es:.2e}")
+                        # (the norm to 1e-3; SINGLE elements to 5e-2 of the sample's scale: a ReLU input within fp32 rounding of zero opens its gate
+                        # on one side only - seeded normal inputs put many pre-activations there - and moves the elements downstream of it)
+                        assert abs(float(f.norm()) - rn) < 1e-3 * rn and es < 5e-2, (stage, k)
+            if stage == "text":
+                check_fp32("full-depth", stage, gn, gd, ref_n, ref_d, names)
+            else:
+                # the conditioning of THIS seeded input, measured here: the same stage with its floating-point inputs moved in their last bit
+                spread = []
+                for rep in range(2):
+                    gen = torch.Generator().manual_seed(991 + rep)
+                    ins_p = {k: (v * (1.0 + 6e-8 * torch.randn(v.shape, generator=gen).sign().to(v.device)) if v.is_floating_point() else v) for k, v in ins.items()}
+                    gp, _, _ = run_stage(model, stage, dtype, ins_p, cots)
+                    spread.append(measure(gp, names, seed))
+                check_fp32_against_float64("full-depth", stage, gn, gd, ref_n, ref_d, fx[f"syn64::{stage}::gnorm"], fx[f"syn64::{stage}::gdot"], names, spread)
+        else:
+            hip, n = bf16_table(stage, names, gn, gd, ref_n, ref_d)
+            ref, _ = bf16_table(stage, names, fx[bkey + "::gnorm"], fx[bkey + "::gdot"], ref_n, ref_d)
+            check_bf16("full-depth", stage, hip, ref, n)
+        del model
+        torch.cuda.empty_cache()
