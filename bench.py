@@ -429,6 +429,25 @@ def main():
                         kernel=K.GEMM_SYMBOL[k], launches_per_step=len(mine) // max(sampled, 1), timed_steps_bracketed=sampled,
                         avg_launch_us=round(avg_d * 1e6, 1), avg_gflop_per_launch=round(avg_f / 1e9, 2),
                         share_of_step=round(sum(durs) / max(sampled, 1) / (dt / args.steps), 4))
+        if recs and os.environ.get("CROG_BENCH_LAUNCH_TABLE"):
+            # per-shape table of the bracketed family: launches per step, average microseconds, algorithmic bytes, TB/s, TFLOP/s
+            esz = 2 if args.dtype == "bf16" else 4
+            by = {}
+            for d_, f_, m_ in recs:
+                if (m_[0], m_[1]) == key:
+                    by.setdefault(tuple(m_), []).append((d_, f_))
+            rows_ = []
+            for m_, L_ in by.items():
+                al, bl, M_, N_, K_, bt, sk = m_
+                alg_ = bt * (esz * (M_ * K_ / (9 if al == K.A_IM2COL else 1) + N_ * K_ / (9 if bl == K.B_NC_IM2COL else 1)) + M_ * N_ * (4 if al == K.A_MC else esz))
+                us_ = sum(d for d, _ in L_) / len(L_) * 1e6
+                rows_.append((us_ * len(L_) / max(sampled, 1), len(L_) / max(sampled, 1), M_, N_, K_, bt, sk, us_, alg_, alg_ / us_ / 1e6, L_[0][1] / us_ / 1e6))
+            with open(os.environ["CROG_BENCH_LAUNCH_TABLE"], "w") as tf:
+                tf.write(f"# {args.roofline_kernel} ({K.GEMM_SYMBOL[key]}) launches of one step, {'single stream' if os.environ.get('CROG_SINGLE_STREAM') == '1' else 'in situ'}; "
+                         f"bytes = each operand and the output once\n# us/step  launches  M  N  K  batch  splitk  us/launch  MB  TB/s  TFLOP/s\n")
+                for r_ in sorted(rows_, reverse=True):
+                    tf.write(f"{r_[0]:8.1f} {r_[1]:5.1f} {r_[2]:8d} {r_[3]:6d} {r_[4]:8d} {r_[5]:4d} {r_[6]:3d} {r_[7]:8.1f} {r_[8] / 1e6:8.1f} {r_[9]:6.2f} {r_[10]:7.1f}\n")
+                tf.write(f"# total {sum(r[0] for r in rows_):.1f} us per step in {sum(r[1] for r in rows_):.0f} launches, {sum(r[8] * r[1] for r in rows_) / 1e9:.2f} GB\n")
         if recs:
             roof = leg(args.roofline_kernel, key)
             if dom_key is not None:

@@ -1377,6 +1377,9 @@ __global__ void __launch_bounds__(NT) softmax_bwd_kernel(const T* __restrict__ P
 }
 
 inline int stream_grid(long work_items) {
+  // (round 6 A/B: caps of 4096 / 8192 / 16384 blocks - more blocks than are resident at once, so that the dispatcher deals rows to whichever CU is
+  // free of the side stream's GEMM blocks - made the step SLOWER: 27.8 / 28.0-28.9 / 29.0 ms against 27.5-27.6; every block re-derives its
+  // per-channel constants, and the kernels are not tail-bound)
   long g = (work_items + NT - 1) / NT;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;

@@ -30,6 +30,24 @@ _DBG_GROUP = os.environ.get("CROG_DBG_GROUP") == "1"      # print every grouped 
 DDP_PARK_ALL = os.environ.get("CROG_DDP_PARK_ALL", "1") == "1"
 
 
+def _xcd_masked_stream(xcds, dev):
+    """A/B aid (CROG_WGRAD_XCDS, VERDICT r5 item 4): a stream whose kernels may only use the CUs of the given XCDs (hipExtStreamCreateWithCUMask;
+    the driver deals mask bit i to XCD i mod 8, CU i div 8 of that XCD), wrapped for torch.  Round 3 measured low-N-bit masks (N / 8 CUs of
+    EVERY XCD) as the weight-gradient stream: 54-64 ms against 33.4 (LAB_NOTES section 4); this is the XCD-granular form of the same question."""
+    import ctypes
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    bits = 0
+    for i in range(256):
+        if (i % 8) in xcds:
+            bits |= 1 << i
+    words = (ctypes.c_uint32 * 8)(*[(bits >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+    h = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(8), words)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 class Runtime:
     def __init__(self):
         self.comm = None       # object with .world_size and .all_reduce_sum(tensor) for SyncBatchNorm
@@ -101,7 +119,8 @@ class Runtime:
                 # round-robin (1 % slower: the small atomic-bound launches contend with each other), stream priorities either way (no
                 # change), a CU-masked stream of 64 / 96 / 128 / 192 CUs (64.2 / 57.5 / 56.9 / 53.9 ms per step against 33.4: the weight
                 # gradients need half of the chip-time of a step and cannot finish on a slice of it).
-                self._wgrad_stream = [torch.cuda.Stream()]
+                nx = int(os.environ.get("CROG_WGRAD_XCDS", "0"))      # A/B only: the weight-gradient stream on the LAST nx XCDs
+                self._wgrad_stream = [_xcd_masked_stream(set(range(8 - nx, 8)), dev) if 0 < nx < 8 else torch.cuda.Stream()]
                 order += self._wgrad_stream
             import torch.distributed as dist
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1

@@ -28,6 +28,10 @@ if "rows" in sys.argv:      # tile heights at the default distance, on the mid-s
     variants = [("default", 0), ("pp256", 512), ("pp192", 1024), ("pp128", 524288)]
     shapes = [(32, 26, 256, 256, True), (32, 13, 512, 512, True), (32, 26, 512, 512, True), (32, 52, 128, 128, True), (32, 26, 1024, 256, False),
               (32, 26, 256, 1024, False), (32, 13, 2048, 512, False), (32, 13, 512, 2048, False), (32, 13, 1024, 2048, False), (32, 26, 512, 256, False)]
+if "lin" in sys.argv:       # round 6: the 1x1 / linear shapes of the step that run furthest from their HBM roof (profiles/r06_linfwd_table_serial.txt)
+    variants = [("default", 0), ("prev", 2048), ("pp256", 512), ("pp192", 1024), ("pp128", 524288)]
+    shapes = [(32, 26, 256, 1024, False), (32, 26, 1024, 256, False), (32, 52, 128, 512, False), (32, 104, 64, 256, False), (32, 26, 512, 512, False),
+              (32, 104, 128, 256, False), (32, 26, 512, 1024, False), (32, 52, 256, 512, False), (32, 26, 512, 2048, False), (32, 104, 256, 64, False)]
 if len(sys.argv) > 1 and sys.argv[1] == "stats":      # with BatchNorm statistics in the epilogue, as the training step launches them
     with_stats = True
 else:

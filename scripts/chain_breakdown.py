@@ -1,11 +1,14 @@
 """Per-queue kernel-time breakdown of the last full step in a rocprofv3 --kernel-trace CSV of a replayed run, split at the start of backward.
-usage: chain_breakdown.py <kernel_trace.csv>"""
+usage: chain_breakdown.py <kernel_trace.csv>   (STEP_BACK=n: the n-th step before the last full one; .csv.gz accepted)"""
 import csv, collections, re, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
+import gzip
+rows = list(csv.DictReader(gzip.open(sys.argv[1], "rt") if sys.argv[1].endswith(".gz") else open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in rows))
 # one full step = from one stem_im2col launch (the first kernel of the image forward, once per step) to the next; the last complete one
 starts = [i for i, e in enumerate(ev) if "stem_im2col" in e[3]]
-lo, hi = starts[-2], starts[-1]
+import os
+back = int(os.environ.get("STEP_BACK", "0"))
+lo, hi = starts[-2 - back], starts[-1 - back]
 seg = ev[lo:hi]
 t0 = seg[0][0]
 def short(n):

@@ -47,8 +47,9 @@ def test_config1_crog_r50_fp32_on_reference_conditioned_weights(case):
     * B = 2 (the configuration's own batch): neck.txt_proj is a BatchNorm1d over TWO samples (layers.py:14-16), which amplifies
       rounding ~60x on its own; the reference's fp32 logits sit 1.0-1.3e-3 (max) from the float64 value on this very input
       (tests/golden/crog_r50_b2_damped_fp64.npz, oracle/make_fp64.py), so two correct fp32 implementations differ by more than
-      1e-3 here in general.  Bound: the HIP path is no further from the exact result than 1.5x the reference's own distance plus twice what a
-      last-bit perturbation of the input moves the logits by (the conditioning of this input, measured in the test); loss within 1e-4."""
+      1e-3 here in general.  Bounds: the HIP path is no further from the exact result than 1.5x the reference's own distance (measured 0.7x), AND
+      within 1e-3 absolute of the reference's fp32 logits (measured 4-5e-4; what a last-bit perturbation of the input moves the logits by -
+      the conditioning of this input - is measured and printed beside it); loss within 1e-4."""
     from crog_amd.model import build_crog
     g, meta = load_case(case)
     assert meta["residual_gain"] == 0.25
@@ -91,13 +92,13 @@ def test_config1_crog_r50_fp32_on_reference_conditioned_weights(case):
             e_hip = float((preds[i].double().cpu() - truth).abs().max())
             e_ref = float((g["pred_" + nm].double() - truth).abs().max())
             print(f"  {nm}: distance to the float64 result: HIP {e_hip:.2e}, reference fp32 {e_ref:.2e}; a last-bit input perturbation moves the HIP logits by {spread[nm]:.2e}")
-            assert e_hip < 1.5 * e_ref + 2.0 * spread[nm], (nm, e_hip, e_ref, spread[nm])
-            # (rounds 3-4 also asserted |HIP - reference| < 1e-3 here - measured 4.9e-4 then.  That was one draw: two fp32 results that
-            # each sit ~1e-3 from the exact value can be 2e-3 apart, and round 5's build - the same sums in another association order,
-            # BatchNorm statistics differing in the last bit - measures 2.0e-3 on `ins` while staying inside the float64 bound above.
-            # What is asserted is the distance to the exact result; the distance between the two roundings is reported.)
+            # Round 6: the plain bounds again.  Round 5 had added "+ 2 x spread" here and replaced the absolute bound below while a rebuild (no packed
+            # fp32, BatchNorm scale / shift contracted) sat at 2.0x the reference's distance; the final build (norm.hip without FMA contraction)
+            # measures 0.69-0.72x of it (HIP 7.2-9.2e-4, reference 1.0-1.3e-3: profiles/r06_parity.txt) and needs neither.
+            assert e_hip < 1.5 * e_ref, (nm, e_hip, e_ref, spread[nm])
             print(f"  {nm}: |HIP - reference fp32| {errs[nm]:.2e} (each within {1.5 * e_ref:.2e} of float64)")
-            assert errs[nm] < 2.5 * e_ref + 2.0 * spread[nm] + 1e-6, (nm, errs[nm], e_ref, spread[nm])
+            # north_star's bound as written, at the configuration's own batch: measured 4.0-5.0e-4
+            assert errs[nm] < 1e-3, (nm, errs[nm], e_ref, spread[nm])
     for nm in NAMES:
         assert err(tgts[NAMES.index(nm)], g["tgt_" + nm]) == 0
     assert dl < 1e-4, dl
