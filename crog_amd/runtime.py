@@ -48,6 +48,23 @@ def _xcd_masked_stream(xcds, dev):
     return torch.cuda.ExternalStream(h.value, device=dev)
 
 
+def _low_priority_stream(dev):
+    """A/B aid (CROG_WGRAD_PRIO=low): a stream of the LEAST priority the device offers (torch.cuda.Stream clamps positive priorities to normal),
+    wrapped for torch: with short weight-gradient blocks the dispatcher would hand a freed CU to the main chain's waiting blocks first."""
+    import ctypes
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    least, greatest = ctypes.c_int(), ctypes.c_int()
+    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+        raise RuntimeError("hipDeviceGetStreamPriorityRange failed")
+    h = ctypes.c_void_p()
+    rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint32(1), ctypes.c_int(least.value))      # 1 = hipStreamNonBlocking
+    if rc != 0:
+        raise RuntimeError(f"hipStreamCreateWithPriority({least.value}) failed ({rc})")
+    if os.environ.get("CROG_DBG_GROUP") == "1":
+        print(f"[streams] weight-gradient stream at priority {least.value} (range least {least.value} .. greatest {greatest.value})", flush=True)
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 class Runtime:
     def __init__(self):
         self.comm = None       # object with .world_size and .all_reduce_sum(tensor) for SyncBatchNorm
@@ -120,7 +137,12 @@ class Runtime:
                 # change), a CU-masked stream of 64 / 96 / 128 / 192 CUs (64.2 / 57.5 / 56.9 / 53.9 ms per step against 33.4: the weight
                 # gradients need half of the chip-time of a step and cannot finish on a slice of it).
                 nx = int(os.environ.get("CROG_WGRAD_XCDS", "0"))      # A/B only: the weight-gradient stream on the LAST nx XCDs
-                self._wgrad_stream = [_xcd_masked_stream(set(range(8 - nx, 8)), dev) if 0 < nx < 8 else torch.cuda.Stream()]
+                if 0 < nx < 8:
+                    self._wgrad_stream = [_xcd_masked_stream(set(range(8 - nx, 8)), dev)]
+                elif os.environ.get("CROG_WGRAD_PRIO") == "low":      # A/B only
+                    self._wgrad_stream = [_low_priority_stream(dev)]
+                else:
+                    self._wgrad_stream = [torch.cuda.Stream()]
                 order += self._wgrad_stream
             import torch.distributed as dist
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
