@@ -486,6 +486,9 @@ def main():
                                            "gradient_buckets": gb,
                                            "syncbn_transport": RT.comm.kind if RT.comm is not None else None,
                                            "bucket_transport": "crog_comm:rccl" if getattr(net, "bucket_comm", None) is not None else "torch.distributed",
+                                           # one ncclAllReduce per bucket or reduce-scatter + all-gather, timed at start-up on this node (rccl.tune_bucket_algo)
+                                           "bucket_schedule": getattr(net, "bucket_algo", None),
+                                           "bucket_schedule_ms_64MiB": getattr(getattr(net, "bucket_comm", None), "bucket_times_ms", None),
                                            "replay_verified": getattr(graphed, "verified", None),
                                            "note": "BatchNorm statistics on a communicator of their own (crog_amd/parallel.py); metric all-reduce not counted"}
         if world == 1:

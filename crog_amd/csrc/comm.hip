@@ -47,6 +47,8 @@ struct Rccl {
   int (*GetUniqueId)(NcclUid*) = nullptr;
   int (*CommInitRank)(void**, int, NcclUid, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;      // optional (crog_comm_set_bucket_algo)
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
@@ -77,6 +79,8 @@ bool rccl_bind() {
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(so, "ncclCommInitRank");
   r.AllReduce = (decltype(r.AllReduce))dlsym(so, "ncclAllReduce");
   r.Broadcast = (decltype(r.Broadcast))dlsym(so, "ncclBroadcast");
+  r.ReduceScatter = (decltype(r.ReduceScatter))dlsym(so, "ncclReduceScatter");
+  r.AllGather = (decltype(r.AllGather))dlsym(so, "ncclAllGather");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(so, "ncclCommDestroy");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(so, "ncclGetErrorString");
   if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.GetErrorString) {
@@ -113,6 +117,7 @@ struct Comm {
   PeerPtrs peers{};
   std::vector<void*> opened;     // hipIpcOpenMemHandle mappings to close
   CrogSyncBlock* sync_dev = nullptr;      // device copy of what a kernel-tail exchange needs (crog_comm_sync_block)
+  int bucket_algo = 0;           // crog_allreduce_bucket: 0 = ncclAllReduce, 1 = ncclReduceScatter + ncclAllGather (crog_comm_set_bucket_algo)
 };
 
 // How long a rank waits for its peers inside one exchange before it gives up and raises the mailbox's error word.  Ranks of one job
@@ -253,12 +258,36 @@ extern "C" int crog_syncbn_stats(void* comm, float* ptr, int64_t count, crog_str
   return CROG_OK;
 }
 
+// How crog_allreduce_bucket moves a gradient bucket (588 MB of gradients per step; a single ring is bound by ONE xGMI
+// link).  0: one ncclAllReduce - the schedule is RCCL's choice.  1: ncclReduceScatter + ncclAllGather on the same stream, in place (rank r reduces
+// chunk r of the bucket, then every rank gathers the chunks): the two-phase form whose traffic is spread over all peers by construction; the
+// count's remainder modulo the world size goes through a small ncclAllReduce.  Which one is faster is a property of the node: the Python side
+// times both on a full-size bucket at start-up and sets the faster one on every rank (rccl.DirectComm.tune_bucket_algo: collective verdict).
+extern "C" int crog_comm_set_bucket_algo(void* comm, int algo) {
+  CROG_CHECK_ARG(comm && (algo == 0 || algo == 1), "comm_set_bucket_algo: algo is 0 (all-reduce) or 1 (reduce-scatter + all-gather)");
+  auto* c = (Comm*)comm;
+  CROG_CHECK_ARG(algo == 0 || (c->nccl && g_rccl.ReduceScatter && g_rccl.AllGather), "comm_set_bucket_algo: no RCCL communicator, or librccl without ncclReduceScatter / ncclAllGather");
+  c->bucket_algo = algo;
+  return CROG_OK;
+}
+
 extern "C" int crog_allreduce_bucket(void* comm, void* ptr, int64_t count, int dtype, int average, crog_stream_t stream) {
   CROG_CHECK_ARG(comm && ptr && count > 0 && (dtype == CROG_F32 || dtype == CROG_BF16), "allreduce_bucket: bad argument");
   auto* c = (Comm*)comm;
   CROG_CHECK_ARG(c->nccl != nullptr, "allreduce_bucket: the communicator was created without RCCL (peer-only)");
-  CM_NCCL(g_rccl.AllReduce(ptr, ptr, (size_t)count, dtype == CROG_BF16 ? NCCL_BFLOAT16 : NCCL_FLOAT32, average ? NCCL_AVG : NCCL_SUM, c->nccl,
-                           (hipStream_t)stream), "ncclAllReduce");
+  const int nt = dtype == CROG_BF16 ? NCCL_BFLOAT16 : NCCL_FLOAT32, op = average ? NCCL_AVG : NCCL_SUM;
+  const size_t esz = dtype == CROG_BF16 ? 2 : 4;
+  const int64_t chunk = (count / c->world) & ~(int64_t)63;      // per-rank chunk, whole 256-byte runs
+  if (c->bucket_algo == 1 && chunk > 0) {
+    char* base = (char*)ptr;
+    CM_NCCL(g_rccl.ReduceScatter(base, base + (size_t)c->rank * chunk * esz, (size_t)chunk, nt, op, c->nccl, (hipStream_t)stream), "ncclReduceScatter");
+    CM_NCCL(g_rccl.AllGather(base + (size_t)c->rank * chunk * esz, base, (size_t)chunk, nt, c->nccl, (hipStream_t)stream), "ncclAllGather");
+    const int64_t done = chunk * c->world;
+    if (done < count)
+      CM_NCCL(g_rccl.AllReduce(base + (size_t)done * esz, base + (size_t)done * esz, (size_t)(count - done), nt, op, c->nccl, (hipStream_t)stream), "ncclAllReduce");
+    return CROG_OK;
+  }
+  CM_NCCL(g_rccl.AllReduce(ptr, ptr, (size_t)count, nt, op, c->nccl, (hipStream_t)stream), "ncclAllReduce");
   return CROG_OK;
 }
 

@@ -361,6 +361,9 @@ class DistributedDataParallel(torch.nn.Module):
         if self.bucket_comm is None:
             import warnings
             warnings.warn(f"crog_amd: direct gradient-bucket communicator unavailable ({err!r}); buckets use torch.distributed on every rank")
+        else:
+            # one ncclAllReduce per bucket, or reduce-scatter + all-gather: timed on this node at start-up, the same choice on every rank
+            self.bucket_algo = self.bucket_comm.tune_bucket_algo(torch.device("cuda", torch.cuda.current_device()))
 
     def _sync_initial_state(self):
         """DDP broadcasts rank 0's parameters and buffers at construction."""

@@ -548,6 +548,10 @@ int crog_comm_sync_block(void* comm, void** dev_block);
 int crog_comm_status(void* comm, int* timed_out_seq);
 int crog_syncbn_stats(void* comm, float* ptr, int64_t count, crog_stream_t stream);
 int crog_allreduce_bucket(void* comm, void* ptr, int64_t count, int dtype, int average, crog_stream_t stream);
+/* Schedule of crog_allreduce_bucket: 0 = one ncclAllReduce (default), 1 = ncclReduceScatter + ncclAllGather in place (the remainder of count
+ * modulo the world size through a small ncclAllReduce).  Set the same value on every rank (crog_amd/rccl.py times both at start-up and
+ * agrees on the faster one: SURVEY.md section 2c C1 asks for the two-phase form where a ring would be bound by one xGMI link). */
+int crog_comm_set_bucket_algo(void* comm, int algo);
 int crog_comm_destroy(void* comm);
 
 /* ------------------------------------------------------------------------------------------

@@ -200,3 +200,29 @@ def test_ddp_buckets_are_stepped_on_their_carrier_stream(rccl_world1, monkeypatc
     assert s0 == s1 == 3
     assert not bad, (len(bad), bad[:8])      # (a parameter stepped while a data gradient still read it changes everything downstream)
     assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+
+
+def test_bucket_schedules_all_reduce_and_reduce_scatter_gather_agree(rccl_world1, monkeypatch):
+    """crog_comm_set_bucket_algo (round 6): the gradient-bucket all-reduce as ONE ncclAllReduce or as ncclReduceScatter +
+    ncclAllGather in place.  On the one-rank RCCL communicator of this box both must leave the bucket unchanged (mean over one rank) for a count
+    that is not a multiple of anything, the start-up tuner pins what CROG_BUCKET_ALGO asks for, and `auto` keeps ncclAllReduce at world size 1.
+    (With N > 1 ranks the tuner times both on a 64-MiB bucket and every rank takes the faster one: collective verdict, rccl.DirectComm.)"""
+    from crog_amd.rccl import DirectComm
+    comm, err = DirectComm.create(None, rccl=True, peer=False, selftest=True)
+    assert comm is not None, err
+    dev = torch.device("cuda")
+    x = torch.randn(1000003, device=dev)
+    for algo in (0, 1):
+        comm.set_bucket_algo(algo)
+        y = x.clone()
+        comm.all_reduce_bucket(y, average=True)
+        z = x.to(torch.bfloat16)
+        z0 = z.clone()
+        comm.all_reduce_bucket(z, average=False)
+        torch.cuda.synchronize()
+        assert torch.equal(y, x) and torch.equal(z, z0), algo
+    monkeypatch.setenv("CROG_BUCKET_ALGO", "rsag")
+    assert comm.tune_bucket_algo(dev) == "rsag" and comm.bucket_algo == 1
+    monkeypatch.setenv("CROG_BUCKET_ALGO", "auto")
+    assert comm.tune_bucket_algo(dev) == "allreduce" and comm.bucket_algo == 0
+    comm.close()
