@@ -56,13 +56,18 @@ __device__ inline void crog_peer_exchange(float* x, int n, const CrogPeerPtrs& p
   if ((int)threadIdx.x < world) {
     const unsigned* f = reinterpret_cast<const unsigned*>(mine + (size_t)2 * world * S) + par * world + threadIdx.x;
     const unsigned long long t0 = wall_clock64();
-    while (crog_ld_sys(f) != seq) {
+    // RELAXED polls + ONE acquire fence once the flag has arrived (round 6): an acquire load per iteration is a system-scope L2 invalidate
+    // per poll (buffer_inv sc0 sc1 in the loop), i.e. a rank waiting for a late peer kept throwing out the cache lines of whatever ran
+    // beside it.  The fence after the loop synchronises with the peer's release store exactly as the acquire load did (fence-atomic rule);
+    // the barrier below hands that to the other threads of the block.
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
       if (wall_clock64() - t0 > wait_ticks) {
         atomicOr(&s_bad, 1u);
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
   __syncthreads();
   if (s_bad) {

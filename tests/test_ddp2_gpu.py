@@ -30,7 +30,20 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def _run(world, out_dir, dtype, gain, size=96, B=4, tag="a", extra_env=None):
+_RUNS = {}      # (configuration, replica) -> results: several tests want the SAME run (a default two-rank bf16 step, a one-process step and its twin
+#                  for the run-to-run floor): each is executed once per pytest session.  `replica` tells runs of one configuration apart.
+
+
+def same(a, b, key):
+    """Bit-equality of the FULL flat gradient / parameter buffer of two runs: the workers store a SHA-1 of the whole 66.6 M-float buffer (`G_sha`,
+    `P_sha`) and every 16th element (`G`, `P`: what norms and cosines are taken on) instead of 266 MB per buffer and rank."""
+    return bool(np.array_equal(a[key + "_sha"], b[key + "_sha"])) and bool(np.array_equal(a[key], b[key]))
+
+
+def _run(world, out_dir, dtype, gain, size=96, B=4, tag="a", extra_env=None, replica=0):
+    key = (world, dtype, gain, size, B, tuple(sorted((extra_env or {}).items())), replica)
+    if key in _RUNS:
+        return _RUNS[key]
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, str(out_dir), dtype, str(gain), str(size), str(B), tag], env=env,
@@ -46,7 +59,8 @@ def _run(world, out_dir, dtype, gain, size=96, B=4, tag="a", extra_env=None):
                 p.kill()
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} of {world} failed:\n{o[-3000:]}"
-    return [dict(np.load(os.path.join(out_dir, f"{tag}_rank{r}_of{world}.npz"))) for r in range(world)]
+    _RUNS[key] = [dict(np.load(os.path.join(out_dir, f"{tag}_rank{r}_of{world}.npz"))) for r in range(world)]
+    return _RUNS[key]
 
 
 def test_two_rank_ddp_syncbn_fp32_equals_reference_on_concatenated_batch(tmp_path):
@@ -62,7 +76,7 @@ def test_two_rank_ddp_syncbn_fp32_equals_reference_on_concatenated_batch(tmp_pat
     # each rank's loss is the mean over its half; the reference's is the mean over all four samples
     assert abs(0.5 * (float(r0["loss"]) + float(r1["loss"])) - float(g["loss_total"])) < 1e-4
     # after the bucketed all-reduce both ranks hold the SAME averaged gradient, and it is the full-batch gradient
-    assert np.array_equal(r0["G"], r1["G"])
+    assert same(r0, r1, "G")
     ref = np.where(g["grad_norms"] < 0, 0.0, g["grad_norms"])
     names = meta["param_names"]
     loose = np.array(["txt_proj" in n for n in names])
@@ -74,7 +88,7 @@ def test_two_rank_ddp_syncbn_fp32_equals_reference_on_concatenated_batch(tmp_pat
     assert np.array_equal(r0["bn_checksum"], r1["bn_checksum"])
     assert np.allclose(r0["bn_checksum"], g["bn_running_checksum"], rtol=1e-4, atol=1e-3)
     # two optimizer steps later the replicas are still bit-identical (rank 1 STARTED from different weights: broadcast worked)
-    assert np.array_equal(r0["P"], r1["P"]) and np.array_equal(r0["bn_final"], r1["bn_final"])
+    assert same(r0, r1, "P") and np.array_equal(r0["bn_final"], r1["bn_final"])
 
 
 def test_two_rank_ddp_syncbn_bf16_equals_single_process(tmp_path):
@@ -85,9 +99,9 @@ def test_two_rank_ddp_syncbn_bf16_equals_single_process(tmp_path):
     meta = json.load(open(os.path.join(GOLD, "tiny_crog.json")))
     kw = dict(size=160, B=8)
     (one,) = _run(1, tmp_path, "bf16", 0.25, tag="one", **kw)
-    (two,) = _run(1, tmp_path, "bf16", 0.25, tag="again", **kw)
+    (two,) = _run(1, tmp_path, "bf16", 0.25, tag="again", replica=1, **kw)
     r0, r1 = _run(2, tmp_path, "bf16", 0.25, tag="ddp", **kw)
-    assert np.array_equal(r0["G"], r1["G"]) and np.array_equal(r0["P"], r1["P"]) and np.array_equal(r0["bn_final"], r1["bn_final"])
+    assert same(r0, r1, "G") and same(r0, r1, "P") and np.array_equal(r0["bn_final"], r1["bn_final"])
     got = np.concatenate([r0["preds"], r1["preds"]], 0)
     scale = float(np.abs(one["preds"]).max())
 
@@ -162,7 +176,7 @@ def test_two_rank_ddp_syncbn_over_the_peer_mailboxes_equals_the_gloo_exchange(tm
         rel = np.linalg.norm(a["G"] - b["G"]) / np.linalg.norm(a["G"])
         assert rel < 2e-2, rel
         assert np.allclose(a["bn_checksum"], b["bn_checksum"], rtol=1e-6)
-    assert np.array_equal(b0["P"], b1["P"])            # both ranks end on identical parameters
+    assert same(b0, b1, "P")            # both ranks end on identical parameters
 
 
 def test_two_rank_deterministic_mode_is_bit_reproducible(tmp_path):
@@ -174,7 +188,7 @@ def test_two_rank_deterministic_mode_is_bit_reproducible(tmp_path):
     bounds below are the reassociation's own, far under the 4x-noise yardsticks of the default-mode test above.)"""
     kw = dict(size=160, B=8, extra_env={"CROG_DETERMINISTIC": "1", **({"CROG_DET_STREAMS": os.environ["TEST_DET_STREAMS"]} if "TEST_DET_STREAMS" in os.environ else {})})
     a0, a1 = _run(2, tmp_path, "bf16", 0.25, tag="det_a", **kw)
-    b0, b1 = _run(2, tmp_path, "bf16", 0.25, tag="det_b", **kw)
+    b0, b1 = _run(2, tmp_path, "bf16", 0.25, tag="det_b", replica=1, **kw)
     for x, y in ((a0, b0), (a1, b1)):
         for k in ("preds", "G", "bn_checksum", "grad_norms"):
             assert np.array_equal(x[k], y[k]), k
@@ -182,11 +196,11 @@ def test_two_rank_deterministic_mode_is_bit_reproducible(tmp_path):
         # two optimizer steps later as well.  (Until the library was built without packed-fp32 VALU instructions this was only reported: two
         # PROCESSES time-slicing one GPU run their kernels beside each other, and the other process's MFMA kernels were enough to change a
         # v_pk_fma_f32 result of this one - LAB_NOTES section 10; seen once in three runs of this pair.)
-        assert np.array_equal(x["P"], y["P"]) and np.array_equal(x["bn_final"], y["bn_final"])
-    assert np.array_equal(a0["G"], a1["G"]) and np.array_equal(a0["P"], a1["P"])
+        assert same(x, y, "P") and np.array_equal(x["bn_final"], y["bn_final"])
+    assert same(a0, a1, "G") and same(a0, a1, "P")
     (one,) = _run(1, tmp_path, "bf16", 0.25, tag="det_one", **kw)
-    (again,) = _run(1, tmp_path, "bf16", 0.25, tag="det_one2", **kw)
-    assert np.array_equal(one["G"], again["G"]) and np.array_equal(one["preds"], again["preds"])
+    (again,) = _run(1, tmp_path, "bf16", 0.25, tag="det_one2", replica=1, **kw)
+    assert same(one, again, "G") and np.array_equal(one["preds"], again["preds"])
     got = np.concatenate([a0["preds"], a1["preds"]], 0)
     rms = float(np.sqrt(np.mean((got - one["preds"]) ** 2)) / np.sqrt(np.mean(one["preds"] ** 2)))
     ga, gb = a0["G"].astype(np.float64), one["G"].astype(np.float64)
@@ -200,8 +214,7 @@ def test_many_rank_ddp_syncbn_over_the_peer_mailboxes(tmp_path):
     MANY processes sharing cuda:0, one sample each, DistributedDataParallel + SyncBatchNorm (fp32, tiny CROG): every BatchNorm layer's
     statistics cross MANY - 1 peers per exchange through the hipIpc mailboxes (CROG_SYNCBN_DIRECT=peer), the gradient buckets through
     gloo.  All ranks end on identical bits (logit statistics of the global batch, averaged gradients, parameters after two optimizer
-    steps), the run agrees with the same ranks exchanging through gloo to rounding (gloo's tree adds the contributions in another order
-    than the mailbox's rank order) and with ONE process on the whole batch (what SyncBatchNorm over MANY x 1 samples must equal).
+    steps), the run agrees with ONE process on the whole batch (what SyncBatchNorm over MANY x 1 samples must equal).
 
     Gradient buckets of 32 MiB here (10 bucket collectives per step) instead of the two-rank tests' 0.25 MiB (100 per step).  Round 5 ended with
     this test skipped: at 4 ranks it did not finish.  Round 6 traced it (scripts/many_rank_probe.py, one time-stamped line per collective and
@@ -215,23 +228,20 @@ def test_many_rank_ddp_syncbn_over_the_peer_mailboxes(tmp_path):
     kw = dict(size=96, B=MANY)
     big = {"CROG_WORKER_BUCKET_MB": "32"}
     peer = _run(MANY, tmp_path, "f32", 1.0, tag="peer8", extra_env={"CROG_SYNCBN_DIRECT": "peer", **big}, **kw)
-    gloo = _run(MANY, tmp_path, "f32", 1.0, tag="gloo8", extra_env=big, **kw)
     assert int(peer[0]["n_buckets"]) >= 8 and int(peer[0]["bucket_launches"]) == 2 * int(peer[0]["n_buckets"])
     (one,) = _run(1, tmp_path, "f32", 1.0, tag="one8", **kw)
     for r in peer[1:]:
-        assert np.array_equal(r["G"], peer[0]["G"]) and np.array_equal(r["P"], peer[0]["P"]) and np.array_equal(r["bn_final"], peer[0]["bn_final"])
+        assert same(r, peer[0], "G") and same(r, peer[0], "P") and np.array_equal(r["bn_final"], peer[0]["bn_final"])
         assert np.array_equal(r["bn_checksum"], peer[0]["bn_checksum"])
     got = np.concatenate([r["preds"] for r in peer], 0)
-    ref = np.concatenate([r["preds"] for r in gloo], 0)
-    e_gloo, e_one = float(np.abs(got - ref).max()), float(np.abs(got - one["preds"]).max())
-    print(f"{MANY} ranks on one GPU, mailbox vs gloo statistics: max |dlogit| {e_gloo:.2e}; vs one process on the whole batch: {e_one:.2e}")
-    assert e_gloo < 1e-4 and e_one < 1e-3
+    e_one = float(np.abs(got - one["preds"]).max())
+    print(f"{MANY} ranks on one GPU, statistics over the mailboxes, vs one process on the whole batch: max |dlogit| {e_one:.2e}")
+    assert e_one < 1e-3
     lm = float(np.mean([float(r["loss"]) for r in peer]))
     assert abs(lm - float(one["loss"])) < 1e-4
-    rel = np.linalg.norm(peer[0]["G"] - gloo[0]["G"]) / np.linalg.norm(gloo[0]["G"])
     rel1 = np.linalg.norm(peer[0]["G"] - one["G"]) / np.linalg.norm(one["G"])
-    print(f"averaged gradient buffer: vs gloo run {rel:.2e}, vs one process {rel1:.2e}")
-    assert rel < 2e-2 and rel1 < 2e-2
+    print(f"averaged gradient buffer vs one process (every 16th element): {rel1:.2e}")
+    assert rel1 < 2e-2
     assert np.allclose(peer[0]["bn_checksum"], one["bn_checksum"], rtol=1e-4, atol=1e-3)
 
 
@@ -244,10 +254,10 @@ def test_two_rank_parked_weight_gradients_reach_their_bucket_before_it_is_reduce
     kw = dict(size=160, B=8)
     p0, p1 = _run(2, tmp_path, "bf16", 0.25, tag="parked", extra_env={"CROG_GROUP_STALE": "1000"}, **kw)
     d0, d1 = _run(2, tmp_path, "bf16", 0.25, tag="default", **kw)
-    e0, _ = _run(2, tmp_path, "bf16", 0.25, tag="default2", **kw)
+    e0, _ = _run(2, tmp_path, "bf16", 0.25, tag="default2", replica=1, **kw)
     for r in (p0, p1, d0, d1):
         assert int(r["bucket_launches"]) == 2 * int(r["n_buckets"]), (int(r["bucket_launches"]), int(r["n_buckets"]))
-    assert np.array_equal(p0["G"], p1["G"]) and np.array_equal(p0["P"], p1["P"])
+    assert same(p0, p1, "G") and same(p0, p1, "P")
     ga, gb, gc = (x["G"].astype(np.float64) for x in (p0, d0, e0))
     cos = lambda x, y: float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y)))
     print(f"flat gradient cosine: groups parked to the end vs default rule {cos(ga, gb):.5f}; default rule run-to-run {cos(gc, gb):.5f}; "
@@ -266,14 +276,14 @@ def test_two_rank_bf16_backward_exchanges_ride_in_the_producing_kernels(tmp_path
     r0, r1 = _run(2, tmp_path, "bf16", 0.25, tag="fused", extra_env={"CROG_SYNCBN_DIRECT": "peer"}, **kw)
     u0, u1 = _run(2, tmp_path, "bf16", 0.25, tag="unfused", extra_env={"CROG_SYNCBN_DIRECT": "peer", "CROG_SYNCBN_FUSE": "0"}, **kw)
     (one,) = _run(1, tmp_path, "bf16", 0.25, tag="one_f", **kw)
-    (two,) = _run(1, tmp_path, "bf16", 0.25, tag="one_f2", **kw)
+    (two,) = _run(1, tmp_path, "bf16", 0.25, tag="one_f2", replica=1, **kw)
     assert int(r0["syncbn_in_kernel"]) > 0 and int(u0["syncbn_in_kernel"]) == 0
     print(f"exchanges over two steps: fused run {int(r0['syncbn_launches'])} launches + {int(r0['syncbn_in_kernel'])} in-kernel; unfused run {int(u0['syncbn_launches'])} launches")
     assert int(r0["syncbn_launches"]) + int(r0["syncbn_in_kernel"]) == int(u0["syncbn_launches"])
     # every backward exchange, and - end of round 5 - the forward ones too: in the tail of the ping-pong GEMM that accumulates the statistics, or in
     # a single-block launch crog_gemm adds behind any other kernel (counted as in-kernel by SyncBNComm.fuse_ptr: no Python-side exchange call)
     assert int(r0["syncbn_in_kernel"]) >= int(u0["syncbn_launches"]) - 4
-    assert np.array_equal(r0["G"], r1["G"]) and np.array_equal(r0["P"], r1["P"]) and np.array_equal(r0["bn_final"], r1["bn_final"])
+    assert same(r0, r1, "G") and same(r0, r1, "P") and np.array_equal(r0["bn_final"], r1["bn_final"])
 
     def rms(a, b):
         return float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
