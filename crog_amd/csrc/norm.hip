@@ -3,6 +3,14 @@
 #include "comm_dev.h"
 #include <algorithm>
 
+// A/B (round 6, scripts/build_variant.py bnprio -DCROG_CHAIN_PRIO=3): the streaming kernels of the main chain raise their wave priority, so that on
+// a CU they share with a weight-gradient GEMM block of the side stream (which runs its MFMA phases at s_setprio 1) their loads issue first.
+#ifdef CROG_CHAIN_PRIO
+#define CHAIN_PRIO() __builtin_amdgcn_s_setprio(CROG_CHAIN_PRIO)
+#else
+#define CHAIN_PRIO()
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -238,6 +246,7 @@ template <typename T>
 __global__ void __launch_bounds__(NT) bn_apply_kernel(const T* __restrict__ z, long ldz, const float* __restrict__ scale_shift,
                                                       const T* __restrict__ res, long ldr, int relu, T* __restrict__ y,
                                                       long ldy, long M, int C, unsigned char* __restrict__ relu_mask) {
+  CHAIN_PRIO();
   constexpr int VEC = Elem<T>::VEC;
   const int cvec = C / VEC;
   const long total = M * cvec;
@@ -283,6 +292,7 @@ __global__ void __launch_bounds__(NT) bn_apply_stats_kernel(const T* __restrict_
                                                             float eps, float* __restrict__ scale_shift, float* __restrict__ mean_invstd,
                                                             const T* __restrict__ res, long ldr, int relu, T* __restrict__ y, long ldy, long M,
                                                             int C, unsigned char* __restrict__ relu_mask, int poolH, int poolW) {
+  CHAIN_PRIO();
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) float ss[];   // [C][2]
   const bool tiny = M <= 64 && count == (float)M && !poolW;      // local statistics (not SyncBatchNorm totals) over a handful of rows
@@ -403,6 +413,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_partial_kernel(const T* __restrict_
                                                             const float* __restrict__ relu_ss, long M, int C, int rows_per_block,
                                                             float* __restrict__ partial, int replicas, const unsigned char* __restrict__ relu_mask,
                                                             int poolH, int poolW, const CrogSyncBlock* __restrict__ sync, int tail) {
+  CHAIN_PRIO();
   // poolW != 0: dy is the gradient of the 2 x 2-average-POOLED output ([B][poolH/2][poolW/2][C]); pixel r takes a quarter of its cell's
   constexpr int VEC = Elem<T>::VEC;
   __shared__ float red[NT][2 * VEC + 1];
@@ -510,6 +521,7 @@ __global__ void __launch_bounds__(NT) bn_bwd_apply_kernel(const T* __restrict__ 
                                                           long lddres, long M, int C, int sum_rows, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, const unsigned char* __restrict__ relu_mask, float pgrad_scale,
                                                           int poolH, int poolW) {
+  CHAIN_PRIO();
   constexpr int VEC = Elem<T>::VEC;
   const float gscale = poolW ? 0.25f : 1.f;      // pooled dy (see bn_bwd_partial_kernel): each pixel takes a quarter of its cell's gradient
   // sum_rows > 0: `sums` is [sum_rows][C][2] (atomic replicas of bn_bwd_partial, or the all-reduced totals): every block adds the
@@ -660,6 +672,7 @@ __global__ void __launch_bounds__(NT) ln_fwd_kernel(const T* __restrict__ x, lon
                                                     T* __restrict__ out2, long ldo2, const T* __restrict__ pos, int pos_rows, long ldp,
                                                     float p_in, uint64_t seed_in, float p_out, uint64_t seed_out,
                                                     const uint64_t* __restrict__ epoch) {
+  CHAIN_PRIO();
   constexpr int VEC = Elem<T>::VEC;
   if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }     // crog_set_seed_epoch: per-step offset from device memory
   const int lane = threadIdx.x & 63;
@@ -783,6 +796,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_kernel(const T* __restrict__ dout, 
                                                     float* __restrict__ partial, int rows_per_block, float p_in, uint64_t seed_in,
                                                     float p_out, uint64_t seed_out, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                     const uint64_t* __restrict__ epoch, const T* __restrict__ dxadd, long lddxa, int relu_in) {
+  CHAIN_PRIO();
   constexpr int VEC = Elem<T>::VEC;
   if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -964,6 +978,7 @@ __global__ void __launch_bounds__(NT) ln_fwd_row_kernel(const T* __restrict__ x,
                                                         T* __restrict__ out2, long ldo2, const T* __restrict__ pos, int pos_rows, long ldp,
                                                         float p_in, uint64_t seed_in, float p_out, uint64_t seed_out,
                                                         const uint64_t* __restrict__ epoch) {
+  CHAIN_PRIO();
   constexpr int VEC = Elem<T>::VEC, NW = NT / 64;
   if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1083,6 +1098,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_row_kernel(const T* __restrict__ do
                                                         float* __restrict__ partial, int rows_per_block, float p_in, uint64_t seed_in,
                                                         float p_out, uint64_t seed_out, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                         const uint64_t* __restrict__ epoch, const T* __restrict__ dxadd, long lddxa, int relu_in) {
+  CHAIN_PRIO();
   constexpr int VEC = Elem<T>::VEC, NW = NT / 64;
   if (epoch) { const uint64_t e = *epoch; seed_in += e; seed_out += e; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
