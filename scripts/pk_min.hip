@@ -132,6 +132,48 @@ __global__ void __launch_bounds__(256) victim_ld(const float* __restrict__ in, i
   *reinterpret_cast<f32x4*>(out + (size_t)t * 4) = o;
 }
 
+// Round 6: what of the weight-gradient kernel makes it an aggressor?  scripts/pk_probe.py found the library's bilinear
+// backward (built WITH packed fp32) wrong beside gemm_ppt (atomic or slab epilogue: 998 / 997 of 1000 launches) and clean beside gemm_pp (the
+// forward ping-pong kernel: LDS-DMA + ds_read_b128 + MFMA), the MFMA probe, a copy and nothing.  gemm_ppt differs from gemm_pp by its
+// TRANSPOSED LDS reads (ds_read_b64_tr_b16) and its per-lane im2col addressing.  Synthetic aggressors of those ingredients:
+//   4 = ds_read_b64_tr_b16 in a loop (no MFMA), 5 = ds_read_b64_tr_b16 feeding v_mfma_f32_16x16x32_bf16, 6 = ds_read_b128 feeding the same MFMA
+__global__ void __launch_bounds__(512) aggressor_tr(int kind, int loops, float* sink) {
+  __shared__ __attribute__((aligned(16))) char smem[65536];
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 65536 / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = 0x3f803f80u + (unsigned)(i & 7);      // bf16 values near 1
+  __syncthreads();
+  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  bf16x8 fb;
+  for (int e = 0; e < 8; e++) fb[e] = (__bf16)1.f;
+  unsigned mix = 0;
+  for (int it = 0; it < loops; it++) {
+    const char* base = smem + wave * 8192 + ((it & 3) * 2048);
+    if (kind == 6) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const bf16x8 ra = *reinterpret_cast<const bf16x8*>(base + ((lane * 16 + i * 1024) & 8191 & ~15));
+        acc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra, fb, acc[i & 3], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + ((lane * 8 + i * 512) & 4095)));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + 4096 + ((lane * 8 + i * 512) & 4095)));
+        const bf16x8 ra = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (kind == 5) acc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra, fb, acc[i & 3], 0, 0, 0);
+        else mix ^= __builtin_bit_cast(unsigned, (float)ra[0]) + __builtin_bit_cast(unsigned, (float)ra[7]);
+      }
+    }
+  }
+  if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + (float)mix == 12345.678f) sink[0] = 1.f;
+}
+extern "C" int pk_aggressor_launch(int kind, int blocks, int loops, float* sink, void* stream) {
+  hipLaunchKernelGGL(aggressor_tr, dim3(blocks), dim3(512), 0, (hipStream_t)stream, kind, loops, sink);
+  return (int)hipGetLastError();
+}
+
 // the same victim / comparison as C entry points (hipcc -shared -fPIC -DPK_MIN_LIB -o scripts/pk_min.so): scripts/pk_probe.py runs them beside the
 // LIBRARY's weight-gradient GEMM, the neighbour that does trigger the effect
 extern "C" int pk_victim_launch(int fl, int blocks, int iters, const float* in, int n, float* out, void* stream) {

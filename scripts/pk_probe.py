@@ -1,7 +1,10 @@
 """Stand-alone reproducer of round 5's second run-to-run difference (LAB_NOTES section 10): the bilinear x2 BACKWARD kernel
 (upsample2_bwd_quad_kernel, pure register arithmetic: 36 loads, packed-fp32 FMAs the compiler's SLP vectoriser makes of the scalar code,
 4 stores; no LDS, no cross-lane operation) beside a 3x3 weight-gradient GEMM on another stream.  The same launch on the same input is repeated
-and compared with its serial result.  usage: pk_probe.py [iterations=3000] [aggressor=wgrad|none]
+and compared with its serial result.  usage: pk_probe.py [iterations=3000] [aggressor=wgrad|wgrad_slab|wgrad_lin|conv_fwd|mfma|copy|tr|tr_mfma|b128_mfma|none]
+Round 6: the AGGRESSOR swapped - wgrad = the ping-pong 3x3 weight gradient with atomic adds (LDS-DMA + transposed LDS reads
++ MFMA + fp32 atomics), wgrad_slab = the same with plain slab stores, conv_fwd = the forward ping-pong 3x3 GEMM (LDS-DMA + ds_read_b128 + MFMA,
+bf16 stores), mfma = crog_probe_mfma_bf16 (MFMA from registers only: no LDS, no memory), copy = crog_probe_copy (global loads / stores only).
 CROG_LIB=crog_amd/variants/libcrog_noslp_elt.so (scripts/build_variant.py, eltwise.hip with -fno-slp-vectorize) selects the build without
 v_pk_*_f32 in the victim."""
 import os
@@ -26,12 +29,43 @@ sk = K.pick_splitk(C, 9 * C, rows, 64, conv=True)
 side = torch.cuda.Stream()
 
 
+ws = torch.empty(sk * C * 9 * C, device="cuda", dtype=torch.float32) if AGG == "wgrad_slab" else None
+yf = torch.empty(rows, C, device="cuda", dtype=torch.bfloat16)
+wf = (torch.randn(C, 9 * C, device="cuda") * 0.02).to(torch.bfloat16)
+sink = torch.empty(512 * 256, device="cuda", dtype=torch.float32)
+cp_src, cp_dst = torch.empty(1 << 26, device="cuda", dtype=torch.uint8), torch.empty(1 << 26, device="cuda", dtype=torch.uint8)
+
+
+linA = (torch.randn(rows, 1024, device="cuda") * 0.1).to(torch.bfloat16) if AGG == "wgrad_lin" else None
+linB = (torch.randn(rows, 1024, device="cuda") * 0.1).to(torch.bfloat16) if AGG == "wgrad_lin" else None
+linG = torch.zeros(1024, 1024, device="cuda") if AGG == "wgrad_lin" else None
+PKLIB = None
+if AGG in ("tr", "tr_mfma", "b128_mfma"):
+    import ctypes
+    PKLIB = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pk_min.so"))
+    PKLIB.pk_aggressor_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+
+
 def aggressor():
     side.wait_stream(torch.cuda.current_stream())
     K.set_stream_override(side.cuda_stream)
     try:      # dW[512][9 x 512] += dy_slice^T x im2col(x): A = the SECOND channel slice of the concat gradient (row stride 3C, offset C)
-        K.gemm(K.BF16, K.A_MC, K.B_NC_IM2COL, cat, x, G, C, 9 * C, rows, 3 * C, C, 9 * C, a_off=C, conv=(2 * H, 2 * W, C), splitk=sk,
-               out_mode=K.OUT_F32_ATOMIC)
+        if AGG == "wgrad":
+            K.gemm(K.BF16, K.A_MC, K.B_NC_IM2COL, cat, x, G, C, 9 * C, rows, 3 * C, C, 9 * C, a_off=C, conv=(2 * H, 2 * W, C), splitk=sk,
+                   out_mode=K.OUT_F32_ATOMIC)
+        elif AGG == "wgrad_slab":
+            K.gemm(K.BF16, K.A_MC, K.B_NC_IM2COL, cat, x, ws, C, 9 * C, rows, 3 * C, C, 9 * C, a_off=C, conv=(2 * H, 2 * W, C), splitk=sk, out_mode=K.OUT_F32)
+        elif AGG == "conv_fwd":
+            for _ in range(2):
+                K.gemm(K.BF16, K.A_IM2COL, K.B_KC, x, wf, yf, rows, C, 9 * C, C, 9 * C, C, conv=(2 * H, 2 * W, C))
+        elif AGG == "mfma":
+            K.check(K.lib().crog_probe_mfma_bf16(sink.data_ptr(), 512, 1500, side.cuda_stream), "probe_mfma")
+        elif AGG in ("tr", "tr_mfma", "b128_mfma"):
+            assert PKLIB.pk_aggressor_launch({"tr": 4, "tr_mfma": 5, "b128_mfma": 6}[AGG], 256, 4000, sink.data_ptr(), side.cuda_stream) == 0
+        elif AGG == "wgrad_lin":      # the ping-pong weight-gradient kernel in its DENSE form (transposed LDS reads, no im2col addressing)
+            K.gemm(K.BF16, K.A_MC, K.B_NC, linA, linB, linG, 1024, 1024, rows, 1024, 1024, 1024, splitk=4, out_mode=K.OUT_F32_ATOMIC)
+        elif AGG == "copy":
+            K.check(K.lib().crog_probe_copy(cp_src.data_ptr(), cp_dst.data_ptr(), 1 << 26, 0, side.cuda_stream), "probe_copy")
     finally:
         K.set_stream_override(None)
 
@@ -64,7 +98,7 @@ print(f"[{os.environ.get('CROG_LIB', 'default build')}] aggressor {AGG} (splitk 
 # ---- the SYNTHETIC victim of scripts/pk_min.hip (one chain of v_pk_fma_f32 / v_pk_mul_f32 + v_pk_add_f32 per lane against the same chain in
 # scalar instructions, compared by a second kernel) beside the same GEMM: is a bare packed instruction enough, or does it take the real kernel?
 so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pk_min.so")
-if AGG != "none" and os.path.exists(so):
+if AGG == "wgrad" and os.path.exists(so) and os.environ.get("PK_SYNTHETIC", "1") == "1":
     import ctypes
     pk = ctypes.CDLL(so)
     pk.pk_victim_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
