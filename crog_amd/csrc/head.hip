@@ -226,7 +226,29 @@ __global__ void __launch_bounds__(NT) head_bias_grad_kernel(const float* __restr
   __shared__ float red[NT / 64];
   const long b = blockIdx.x;
   float s = 0.f;
-  for (long i = threadIdx.x; i < per_b; i += NT) s += dout[b * per_b + i];
+  const float* src = dout + b * per_b;
+  if ((per_b & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+    // 16-byte loads, four in flight per thread (round 6: one dependent 4-byte load per iteration made this 52 us for 54080 floats per
+    // sample - the first kernel of backward, on the critical chain)
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(src);
+    const long n4 = per_b >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long i = threadIdx.x;
+    for (; i + 3 * NT < n4; i += 4 * NT) {
+      const f32x4 a = p4[i], c = p4[i + NT], d = p4[i + 2 * NT], e = p4[i + 3 * NT];
+      s0 += (a[0] + a[1]) + (a[2] + a[3]);
+      s1 += (c[0] + c[1]) + (c[2] + c[3]);
+      s2 += (d[0] + d[1]) + (d[2] + d[3]);
+      s3 += (e[0] + e[1]) + (e[2] + e[3]);
+    }
+    for (; i < n4; i += NT) {
+      const f32x4 a = p4[i];
+      s0 += (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    s = (s0 + s1) + (s2 + s3);
+  } else {
+    for (long i = threadIdx.x; i < per_b; i += NT) s += src[i];
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();

@@ -308,13 +308,27 @@ __global__ void __launch_bounds__(NT) bn_apply_stats_kernel(const T* __restrict_
       // BatchNorm1d over the rows of a batch (linear_layer, layers.py:14-16: M = B = 2 in config 1): E[x^2] - mean^2 cancels to the last bits
       // when a channel's two values are close, and the normalisation then amplifies that rounding ~60x (tests/test_fulldepth_gpu.py, B = 2).
       // With at most 64 rows the channel is simply read twice: mean, then the sum of squared deviations - what torch's two-pass kernel does.
+      // (round 6: the rows are fetched eight at a time and then added in the SAME order - one dependent load per addition made this launch
+      // 209 us for a 32 x 1024 tensor, on the forward's critical chain: every block derives all C channels, four per thread, two passes)
       float m = 0.f;
-      for (long r = 0; r < M; r++) m += Elem<T>::to_f(z[r * ldz + c]);
+      for (long r0 = 0; r0 < M; r0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = r0 + j < M ? Elem<T>::to_f(z[(r0 + j) * ldz + c]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) m += t[j];
+      }
       m /= (float)M;
       float v = 0.f;
-      for (long r = 0; r < M; r++) {
-        const float d = Elem<T>::to_f(z[r * ldz + c]) - m;
-        v += d * d;
+      for (long r0 = 0; r0 < M; r0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = r0 + j < M ? Elem<T>::to_f(z[(r0 + j) * ldz + c]) : m;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float d = t[j] - m;
+          v += d * d;
+        }
       }
       mean = m;
       var = v / (float)M;
