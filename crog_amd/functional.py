@@ -1682,15 +1682,15 @@ class FusedHeadFn(Function):
     either direction.  The conv bias reaches the logits as per-sample constants cb[b][g][tap] (csrc/head.hip)."""
 
     @staticmethod
-    def forward(ctx, x4, state, _p1, _p2, _p3, _p4, w5: WRef, b5: WRef, tw: WRef, tb: WRef, C, groups):
+    def forward(ctx, x4, word, _p1, _p2, w5: WRef, b5: WRef, C, groups, tail_stream=None):
+        """word: fp32 [B, pad8(9 C + 1)] = txt(state), layers.py:90-91 - HeadWordFn (its own node since round 6: it depends on the text tower
+        alone, so CROG.forward runs it on the text stream, and its backward - a 32-row weight gradient, a bias sum and a 16-block data
+        gradient, 0.08 ms of latency-bound launches - leaves the main chain with it)."""
         B, H, W, Cx = x4.shape
         dev, dtype = x4.device, x4.dtype
         dt = K.dcode(dtype)
         P, g = H * W, groups
-        nout = C * 9 + 1
-        ldw = _pad(nout, 8)
-        word = torch.empty(B, ldw, device=dev, dtype=torch.float32)
-        lin_fwd(state, tw, word, bias=tb, out_mode=K.OUT_F32, ldc=ldw)
+        ldw = word.shape[1]
         wpad = torch.empty(B, C, 16, device=dev, dtype=dtype)
         K.head_pack_weights(word, wpad, B, C)
         # Wf[b][g][tap][k] = sum_c wpad[b][c][tap] * W5[g*C + c][k]
@@ -1705,14 +1705,15 @@ class FusedHeadFn(Function):
                sC=(P * g * 16, 0), out_mode=K.OUT_F32)
         out = torch.empty(B, g, H, W, device=dev, dtype=torch.float32)
         K.head_stencil_fwd(t, word, C * 9, out, B, g, H, W, tbias=cb)
-        ctx.cfg = (w5, b5, tw, tb, C, g, ldw)
-        ctx.save_for_backward(x4, state, wpad, Wf)
+        ctx.cfg = (w5, b5, C, g, ldw)
+        ctx.tail_stream = tail_stream      # the stream `word` was produced on (None: this one)
+        ctx.save_for_backward(x4, wpad, Wf)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        w5, b5, tw, tb, C, g, ldw = ctx.cfg
-        x4, state, wpad, Wf = ctx.saved_tensors
+        w5, b5, C, g, ldw = ctx.cfg
+        x4, wpad, Wf = ctx.saved_tensors
         B, H, W, _ = x4.shape
         dev, dtype = x4.device, x4.dtype
         dt = K.dcode(dtype)
@@ -1727,53 +1728,103 @@ class FusedHeadFn(Function):
         # dx4[b][p][k] = sum_(g,tap) dt[b][p][(g,tap)] * Wf[b][(g,tap)][k]
         dx4 = torch.empty(B, H, W, C, device=dev, dtype=dtype)
         K.gemm(dt, K.A_KC, K.B_NC, dtb, Wf, dx4, P, C, g * 16, g * 16, C, C, batch=B, sA=(P * g * 16, 0), sB=(g * 16 * C, 0), sC=(P * C, 0))
-        # dWf[b][(g,tap)][k] = sum_p dt[b][p][(g,tap)] * x4[b][p][k]
+        # Everything below feeds the gradient of `word` and two parameter gradients - nothing the main chain waits for.  When `word` came from
+        # another stream (CROG.forward computes txt(state) on the text stream, `tail_stream`), the whole tail is enqueued THERE: its only consumer,
+        # HeadWordFn.backward, runs on that stream too (autograd replays a node on its forward stream), so stream order carries the dependency and
+        # the main chain goes on with dx4 at once (0.15 ms of launches at the very start of backward).  torch's fills run on the current stream:
+        # they are issued first, then the tail stream waits for this one.
         dWf = torch.zeros(B, g * 16, C, device=dev, dtype=torch.float32)
-        sk = 1 if RT.deterministic else max(1, min(24, P // 1024))
-        K.gemm(dt, K.A_MC, K.B_NC, dtb, x4, dWf, g * 16, C, P, g * 16, ldx, C, batch=B, sA=(P * g * 16, 0), sB=(P * ldx, 0), sC=(g * 16 * C, 0),
-               splitk=sk, out_mode=K.OUT_F32 if RT.deterministic else K.OUT_F32_ATOMIC)
-        if dtype == torch.float32:
-            dWf_c = dWf
-        else:
-            dWf_c = torch.empty(B, g * 16, C, device=dev, dtype=dtype)
-            K.cast_pad2d(dWf, C, C, dWf_c, C, C, B * g * 16)
-        # dW5[g*C + c][k] += sum_b sum_tap wpad[b][c][tap] * dWf[b][g][tap][k]
-        if RT.deterministic:
-            # the B samples add into the same rows of dW5: one launch per sample (its g groups write disjoint rows), in stream order
-            for bi in range(B):
-                K.gemm(dt, K.A_KC, K.B_NC, wpad, dWf_c, w5.G, C, C, 16, 16, C, w5.cols, batch=g, batch_inner=g, sA=(0, 0),
-                       sB=(0, 16 * C), sC=(0, C * w5.cols), a_off=bi * C * 16, b_off=bi * g * 16 * C, c_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
-        else:
-            K.gemm(dt, K.A_KC, K.B_NC, wpad, dWf_c, w5.G, C, C, 16, 16, C, w5.cols, batch=B * g, batch_inner=g, sA=(C * 16, 0),
-                   sB=(g * 16 * C, 16 * C), sC=(0, C * w5.cols), c_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
-        # dwpad[b][c][tap] = sum_g sum_k W5[g*C + c][k] * dWf[b][g][tap][k]   (+ the cb share below)
         dwpad = torch.zeros(B, C, 16, device=dev, dtype=torch.float32)
-        if RT.deterministic:
-            # the g groups add into the same dwpad[b]: one launch per group (its B samples write disjoint blocks), in stream order
-            for gi in range(g):
-                K.gemm(dt, K.A_KC, K.B_KC, w5.w(dtype), dWf_c, dwpad, C, 16, C, w5.cols, C, 16, batch=B, batch_inner=1, sA=(0, 0),
-                       sB=(g * 16 * C, 0), sC=(C * 16, 0), a_off=w5.off + gi * C * w5.cols, b_off=gi * 16 * C, out_mode=K.OUT_F32_ATOMIC)
+        dWf_c = dWf if dtype == torch.float32 else torch.empty(B, g * 16, C, device=dev, dtype=dtype)
+        dword = torch.empty(B, ldw, device=dev, dtype=torch.float32)      # (the unpack kernel writes the padding columns too)
+        side = ctx.tail_stream if (ctx.tail_stream is not None and not RT.deterministic and K._STREAM_OVERRIDE is None) else None
+        cur = torch.cuda.current_stream()
+        if side is not None and side != cur:
+            side.wait_stream(cur)
+            K.set_stream_override(side.cuda_stream)
         else:
-            K.gemm(dt, K.A_KC, K.B_KC, w5.w(dtype), dWf_c, dwpad, C, 16, C, w5.cols, C, 16, batch=B * g, batch_inner=g, sA=(0, C * w5.cols),
-                   sB=(g * 16 * C, 16 * C), sC=(C * 16, 0), a_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
-        K.head_cb_bwd(b5.P, b5.off, wpad, dcb, b5.G, b5.off, dwpad, B, g, C)
-        dword = torch.empty(B, ldw, device=dev, dtype=dtype)
-        K.head_unpack_wgrad(dwpad, dbias, dword, B, C)
+            side = None
+        try:
+            # dWf[b][(g,tap)][k] = sum_p dt[b][p][(g,tap)] * x4[b][p][k]
+            sk = 1 if RT.deterministic else max(1, min(24, P // 1024))
+            K.gemm(dt, K.A_MC, K.B_NC, dtb, x4, dWf, g * 16, C, P, g * 16, ldx, C, batch=B, sA=(P * g * 16, 0), sB=(P * ldx, 0), sC=(g * 16 * C, 0),
+                   splitk=sk, out_mode=K.OUT_F32 if RT.deterministic else K.OUT_F32_ATOMIC)
+            if dtype != torch.float32:
+                K.cast_pad2d(dWf, C, C, dWf_c, C, C, B * g * 16)
+            # dW5[g*C + c][k] += sum_b sum_tap wpad[b][c][tap] * dWf[b][g][tap][k]
+            if RT.deterministic:
+                # the B samples add into the same rows of dW5: one launch per sample (its g groups write disjoint rows), in stream order
+                for bi in range(B):
+                    K.gemm(dt, K.A_KC, K.B_NC, wpad, dWf_c, w5.G, C, C, 16, 16, C, w5.cols, batch=g, batch_inner=g, sA=(0, 0),
+                           sB=(0, 16 * C), sC=(0, C * w5.cols), a_off=bi * C * 16, b_off=bi * g * 16 * C, c_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
+            else:
+                def dw5():
+                    K.gemm(dt, K.A_KC, K.B_NC, wpad, dWf_c, w5.G, C, C, 16, 16, C, w5.cols, batch=B * g, batch_inner=g, sA=(C * 16, 0),
+                           sB=(g * 16 * C, 16 * C), sC=(0, C * w5.cols), c_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
+                if side is not None:
+                    dw5()          # (already off the main chain)
+                else:
+                    RT.on_wgrad_stream(dw5, wpad, dWf_c, tag="linear")      # a parameter gradient only: the weight-gradient stream
+            # dwpad[b][c][tap] = sum_g sum_k W5[g*C + c][k] * dWf[b][g][tap][k]   (+ the cb share below)
+            if RT.deterministic:
+                # the g groups add into the same dwpad[b]: one launch per group (its B samples write disjoint blocks), in stream order
+                for gi in range(g):
+                    K.gemm(dt, K.A_KC, K.B_KC, w5.w(dtype), dWf_c, dwpad, C, 16, C, w5.cols, C, 16, batch=B, batch_inner=1, sA=(0, 0),
+                           sB=(g * 16 * C, 0), sC=(C * 16, 0), a_off=w5.off + gi * C * w5.cols, b_off=gi * 16 * C, out_mode=K.OUT_F32_ATOMIC)
+            else:
+                K.gemm(dt, K.A_KC, K.B_KC, w5.w(dtype), dWf_c, dwpad, C, 16, C, w5.cols, C, 16, batch=B * g, batch_inner=g, sA=(0, C * w5.cols),
+                       sB=(g * 16 * C, 16 * C), sC=(C * 16, 0), a_off=w5.off, out_mode=K.OUT_F32_ATOMIC)
+            K.head_cb_bwd(b5.P, b5.off, wpad, dcb, b5.G, b5.off, dwpad, B, g, C)
+            # the gradient of `word` (fp32, as the forward's word is): HeadWordFn rounds it to the compute dtype exactly as this kernel did when
+            # it wrote the compute dtype itself
+            K.head_unpack_wgrad(dwpad, dbias, dword, B, C)
+        finally:
+            if side is not None:
+                K.set_stream_override(None)
+        if side is not None:
+            for t in (dtb, x4, dWf, dWf_c, dwpad, dword, dcb, dbias, wpad):
+                t.record_stream(side)
+        # (announced after the last kernel that reads them is enqueued: see LinearFn.backward)
+        w5.done()
+        b5.done()
+        return (dx4, dword) + (None,) * 7
+
+
+class HeadWordFn(Function):
+    """word = txt(state) (layers.py:90-91: Linear word_dim -> 9 C + 1) as fp32 rows padded to 8 columns: the per-sample 3x3 kernel and bias of
+    the dynamic head.  A node of its own so that forward AND backward run on the stream of the text tower (CROG.forward)."""
+
+    @staticmethod
+    def forward(ctx, state, _p1, _p2, tw: WRef, tb: WRef, C):
+        B = state.shape[0]
         nout = C * 9 + 1
+        ldw = _pad(nout, 8)
+        word = torch.empty(B, ldw, device=state.device, dtype=torch.float32)
+        lin_fwd(state, tw, word, bias=tb, out_mode=K.OUT_F32, ldc=ldw)
+        ctx.cfg = (tw, tb, nout)
+        ctx.save_for_backward(state)
+        return word
+
+    @staticmethod
+    def backward(ctx, dword32):
+        tw, tb, nout = ctx.cfg
+        (state,) = ctx.saved_tensors
+        dword = dword32.contiguous() if state.dtype == torch.float32 else dword32.to(state.dtype)
         lin_wgrad(dword, state, tw, N=nout)
         bias_grad(dword[:, :nout], tb)
         dstate = torch.empty_like(state)
         lin_dgrad(dword, tw, dstate, N=nout)
-        # (all four announced after the last kernel that reads them is enqueued: see LinearFn.backward)
-        w5.done()
-        b5.done()
         tw.done()
         tb.done()
-        return (dx4, dstate) + (None,) * 10
+        return dstate, None, None, None, None, None
 
 
-def fused_head(x4, state, w5: WRef, b5: WRef, tw: WRef, tb: WRef, C, groups):
-    return FusedHeadFn.apply(x4, state, w5.param, b5.param, tw.param, tb.param, w5, b5, tw, tb, C, groups)
+def head_word(state, tw: WRef, tb: WRef, C):
+    return HeadWordFn.apply(state, tw.param, tb.param, tw, tb, C)
+
+
+def fused_head(x4, word, w5: WRef, b5: WRef, C, groups, tail_stream=None):
+    return FusedHeadFn.apply(x4, word, w5.param, b5.param, w5, b5, C, groups, tail_stream)
 
 
 class BackwardBeginFn(Function):

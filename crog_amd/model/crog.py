@@ -23,6 +23,7 @@ from .layers import FPN, MultiTaskProjector, Projector, TransformerDecoder
 # path stays the default until the host becomes the limiter.
 TEXT_GRAPH = os.environ.get("CROG_TEXT_GRAPH", "0") == "1"
 TEXT_AFTER = os.environ.get("CROG_TEXT_AFTER", "0") == "1"
+GATE_ON_TEXT = os.environ.get("CROG_GATE_ON_TEXT", "1") != "0"      # the neck's sentence gate runs on the text stream (single-GPU step)
 DGW_LATE = os.environ.get("CROG_DGW_LATE", "1") != "0"      # the data-gradient weight copies are refreshed beside the neck, not beside the stem
 
 RN50_ARCH = dict(embed_dim=1024, image_resolution=224, vision_layers=(3, 4, 6, 3), vision_width=64, vision_patch_size=None,
@@ -197,7 +198,7 @@ class CROG(nn.Module):
             # (deterministic mode keeps the side streams since round 5: the run-to-run differences of rounds 3-4 were packed-fp32 VALU results
             # going wrong beside another stream's MFMA kernel - runtime.set_deterministic, LAB_NOTES section 10; RT.det_streams = "0" restores one stream)
             overlap_text = self.overlap_text and (not RT.deterministic or RT.det_streams in ("all", "text"))
-            graphed = None
+            graphed = gate = hword = None
             if overlap_text:
                 if self._side is None:
                     RT.ensure_streams(dev)      # creation ORDER of the side streams decides which hardware queues they share
@@ -227,9 +228,23 @@ class CROG(nn.Module):
                 while not txt:          # whatever the image tower's hooks did not get to
                     issue_text()
                 wfeat, state = txt
+                # the neck's sentence gate (layers.py:376) on the text stream, behind the tower: it needs nothing of the image side.  Not
+                # under SyncBatchNorm: its BatchNorm1d would exchange statistics on a second stream, and the mailbox exchanges of one
+                # communicator are sequenced on ONE stream (csrc/comm.hip).
+                if GATE_ON_TEXT and RT.comm is None and hasattr(self.neck, "text_gate"):
+                    with torch.cuda.stream(self._side):
+                        gate = self.neck.text_gate(state)
+                # ... and the dynamic head's per-sample kernel txt(state) (layers.py:90-91; a plain linear: also under SyncBatchNorm)
+                if GATE_ON_TEXT and hasattr(self.proj, "text_word"):
+                    with torch.cuda.stream(self._side):
+                        hword = self.proj.text_word(state)
                 main.wait_stream(self._side)
                 wfeat.record_stream(main)
                 state.record_stream(main)
+                if gate is not None:
+                    gate.record_stream(main)
+                if hword is not None:
+                    hword.record_stream(main)
             else:
                 vis = self.backbone.image_features(img, dtype)
                 wfeat, state = self.backbone.text_features(word, dtype)
@@ -244,14 +259,14 @@ class CROG(nn.Module):
                                  "ModifiedResNet tower; with a ViT tower use backbone.encode_image / encode_text")
             fan = getattr(self.backbone.visual, "fan", None)
             self.backbone.visual.fan = None
-            fq = self.neck(vis, state, fan=fan)
+            fq = self.neck(vis, state, fan=fan, gate=gate)
             if self.use_contrastive:
                 fq = self.decoder(fq, wfeat, pad_mask)
                 if isinstance(fq, list):
                     # cfg.intermediate=True: the reference's decoder returns a list and crog.py:69 then calls .reshape on it
                     raise AttributeError("'list' object has no attribute 'reshape' (TransformerDecoder(return_intermediate=True) "
                                          "returns per-layer outputs; CROG.forward consumes a single map, as in the reference)")
-            pred = self.proj(fq, state)                      # fp32 logits [b, groups, H, W]
+            pred = self.proj(fq, state, word=hword, word_stream=self._side if hword is not None else None)      # fp32 logits [b, groups, H, W]
             if t_side is not None:
                 main.wait_stream(t_side)
             if self.training and self._bns:

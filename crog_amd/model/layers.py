@@ -56,14 +56,21 @@ class FPN(Bound):
         self.coordconv = nn.Sequential(CoordConv(o[1], o[1], 3), conv_layer(o[1], o[1], 3))
         self.o = tuple(o)
 
-    def forward(self, imgs, state, fan=None):
-        """fan: (slot for v3's gradient, slot for v4's) - ModifiedResNet.fan; the tower's own backward adds them (clip.py Bottleneck)."""
+    def text_gate(self, state):
+        """layers.py:376: the sentence gate relu(bn(linear(state))) [B, o2] - a function of the text tower's output alone.  CROG.forward
+        computes it on the TEXT stream, right behind the tower (round 6): a 32-row linear + a BatchNorm1d over 32 rows are ~0.1 ms of
+        latency-bound launches that the main chain otherwise runs between the image tower and the neck, and again in backward."""
+        return self.txt_proj.run(state, ksize=1)
+
+    def forward(self, imgs, state, fan=None, gate=None):
+        """fan: (slot for v3's gradient, slot for v4's) - ModifiedResNet.fan; the tower's own backward adds them (clip.py Bottleneck).
+        gate: text_gate(state) when the caller has already computed it (on another stream)."""
         v3, v4, v5 = imgs                      # [B,52,52,512] [B,26,26,1024] [B,13,13,1024] channels-last
         fan3, fan4 = fan if fan is not None else (None, None)
         o0, o1, o2 = self.o
         dev, dt = v4.device, v4.dtype
         B, H4, W4, _ = v4.shape
-        s = self.txt_proj.run(state, ksize=1)                                  # Linear + BN1d + ReLU -> [B, o2]
+        s = gate if gate is not None else self.text_gate(state)                # Linear + BN1d + ReLU -> [B, o2]
         f5 = self.f1_v_proj.run(v5)
         f5 = self.norm_layer.run(Fn.mul_bcast(f5, s), ksize=0)                 # relu(bn(f5 * state))
         # fusion 2: cat([f2_v_proj(v4), up(f5)])
@@ -199,12 +206,20 @@ class _ProjectorBase(Bound):
                                   "4": Conv2d(in_dim, in_dim * groups, 1, bias=True)})
         self.txt = Linear(word_dim, in_dim * 9 + 1)
 
-    def forward(self, x, state):
-        """x: [B, h, w, 2*in_dim] channels-last, state: [B, word_dim] -> fp32 logits [B, groups, 4h, 4w]."""
+    def text_word(self, state):
+        """layers.py:90-91: the per-sample dynamic kernel + bias txt(state), fp32 [B, pad8(9 in_dim + 1)] - a function of the text tower's output
+        alone (CROG.forward computes it on the text stream); None when the unfused head is selected."""
+        return Fn.head_word(state, self.txt.w, self.txt.b, self.in_dim) if Fn.FUSED_HEAD else None
+
+    def forward(self, x, state, word=None, word_stream=None):
+        """x: [B, h, w, 2*in_dim] channels-last, state: [B, word_dim] -> fp32 logits [B, groups, 4h, 4w].  word: text_word(state) when the
+        caller has already computed it, word_stream: the stream it was computed on (the backward of the head's weight side follows it there)."""
         x = self.vis["1"].run(Fn.upsample2(x))
         x = self.vis["3"].run(Fn.upsample2(x))
         if Fn.FUSED_HEAD:
-            return Fn.fused_head(x, state, self.vis["4"].w, self.vis["4"].b, self.txt.w, self.txt.b, self.in_dim, self.groups)
+            if word is None:
+                word = self.text_word(state)
+            return Fn.fused_head(x, word, self.vis["4"].w, self.vis["4"].b, self.in_dim, self.groups, tail_stream=word_stream)
         x5 = Fn.linear(x, self.vis["4"].w, self.vis["4"].b)
         return Fn.dyn_head(x5, state, self.txt.w, self.txt.b, self.in_dim)
 
