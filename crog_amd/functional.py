@@ -120,19 +120,21 @@ class WRef:
     def grad(self) -> torch.Tensor:
         return self.store.G[self.off:self.off + self.rows * self.cols]
 
-    def done(self):
+    def done(self, then=None):
         """The kernels that write this parameter's gradient are enqueued (or parked: Runtime.defer_wgrad - then the announcement waits
-        for the flush that really enqueues them, so a DDP bucket can never be launched ahead of its last gradient)."""
+        for the flush that really enqueues them, so a DDP bucket can never be launched ahead of its last gradient).
+        then: what to call instead of the announcement itself (done_joint: one of several row blocks of a packed parameter)."""
+        fn = then if then is not None else self._done_now
         if RT._pending_wgrad:
             # (re-evaluated by flush_wgrad once the deferred closure has run: if that closure PARKED the gradient for a grouped launch the
             # announcement moves on to the group - ADVICE r5: _done_now here let FusedAdam / a DDP bucket go ahead of the grouped GEMM)
-            RT._pending_done.append(self.done)
+            RT._pending_done.append(self.done if then is None else (lambda: self.done(then)))
             return
         if RT._groups:      # parked for a grouped launch (Runtime.park_wgrad): announced when that launch is enqueued
             lo = self.store.G.data_ptr() + 4 * self.off
-            if RT.defer_done(lo, lo + 4 * self.rows * self.cols, self._done_now):
+            if RT.defer_done(lo, lo + 4 * self.rows * self.cols, fn):
                 return
-        self._done_now()
+        fn()
 
     def _done_now(self):
         st, p = self.store, self.param
@@ -145,6 +147,30 @@ class WRef:
             RT.reducer.mark_ready(p)
         if RT.early_adam is not None:
             RT.early_adam.mark_ready(p)
+
+
+def done_joint(refs):
+    """Announce parameters whose gradient is written by SEVERAL launches - the q / k / v row blocks of a packed in_proj_weight / in_proj_bias
+    (clip.py:246, layers.py:291-296) - exactly once each, after the LAST of those launches is really enqueued.  Round 6: the blocks were
+    announced one by one, and any one of them marks the whole parameter ready; with the blocks parked in different grouped launches (the
+    decoder's cross-attention: q reduces over 21632 pixel rows, k and v over 640 token rows - two groups) the first group to go out announced
+    the parameter while another block's GEMM was still parked, i.e. a DDP bucket could be reduced (or an Adam chunk stepped) ahead of it."""
+    by_param = {}
+    for r in refs:
+        if r is not None:
+            by_param.setdefault(id(r.param), []).append(r)
+    for rs in by_param.values():
+        if len(rs) == 1:
+            rs[0].done()
+            continue
+        left = [len(rs)]
+
+        def arrive(left=left, first=rs[0]):
+            left[0] -= 1
+            if left[0] == 0:
+                first._done_now()
+        for r in rs:
+            r.done(arrive)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -958,6 +984,68 @@ def layernorm(x, gamma: WRef, beta: WRef, *, eps=1e-5, res=None, pos=None, p_in=
 # ------------------------------------------------------------------------------------------------
 # Multi-head attention (projections + scores + masked softmax + PV + out-proj [+ residual])
 # ------------------------------------------------------------------------------------------------
+class JointDone:
+    """done_joint across autograd nodes: a packed parameter whose row blocks are written by DIFFERENT backward nodes (q in MhaFn, k / v in
+    KvProjFn) is announced by whichever node's last block arrives, once `n` blocks have."""
+
+    def __init__(self, n: int):
+        self.left, self.first = n, None
+
+    def add(self, ref):
+        if ref is None:
+            return
+        if self.first is None:
+            self.first = ref
+        ref.done(self._arrive)
+
+    def _arrive(self):
+        self.left -= 1
+        if self.left == 0:
+            self.first._done_now()
+
+
+class KvProjFn(Function):
+    """The key / value projections of a cross-attention (layers.py:329-332: nn.MultiheadAttention's packed in_proj rows E..3E) as a node of their
+    own: they depend on the text side alone, so CROG.forward runs them on the text stream behind the tower, and autograd replays their backward
+    (two 80-block data gradients per decoder layer, latency-bound) there instead of on the main chain.  -> [B*Lk, 2E]: K | V."""
+
+    @staticmethod
+    def forward(ctx, xk, xv, _p1, _p2, wk: WRef, wv: WRef, bk, bv, jw, jb):
+        E = wk.rows
+        kv = torch.empty(xk.shape[0], 2 * E, device=xk.device, dtype=xk.dtype)
+        lin_fwd(xk, wk, kv, bias=bk, c_off=0, ldc=2 * E)
+        lin_fwd(xv, wv, kv, bias=bv, c_off=E, ldc=2 * E)
+        ctx.cfg = (wk, wv, bk, bv, jw, jb, E)
+        ctx.save_for_backward(xk, xv)
+        return kv
+
+    @staticmethod
+    def backward(ctx, dkv):
+        wk, wv, bk, bv, jw, jb, E = ctx.cfg
+        xk, xv = ctx.saved_tensors
+        dkv = dkv.contiguous()
+        out = []
+        for x_, w_, b_, col in ((xk, wk, bk, 0), (xv, wv, bv, E)):
+            def wgrad_proj(x_=x_, w_=w_, b_=b_, col=col):
+                lin_wgrad(dkv, x_, w_, a_off=col, lda=2 * E, N=E, bias=b_)
+            RT.on_wgrad_stream(wgrad_proj, dkv, x_, tag="mha")
+            dx = torch.empty(x_.shape, device=x_.device, dtype=x_.dtype)
+            lin_dgrad(dkv, w_, dx, a_off=col, lda=2 * E, N=E)
+            out.append(dx)
+        for r in (wk, wv):
+            jw.add(r)
+        for r in (bk, bv):
+            jb.add(r)
+        return out[0], out[1], None, None, None, None, None, None, None, None
+
+
+def kv_proj(xk, xv, wk: WRef, wv: WRef, bk, bv):
+    """-> (K | V buffer, (joint announcement of the packed weight, of the packed bias)) for mha(..., kv=)."""
+    jw, jb = JointDone(3), JointDone(3)
+    kv = KvProjFn.apply(xk, xv, wk.param, bk.param if bk is not None else None, wk, wv, bk, bv, jw, jb)
+    return kv, (jw, jb)
+
+
 class MhaFn(Function):
     """F.multi_head_attention_forward restated on row matrices (clip.py:119-139,246-260; layers.py:291-296,324,329-332).
     xq: [B*Lq, E]; xk, xv: [B*Lk, E].  Weight rows come as WRefs so packed in_proj slices and separate q/k/v
@@ -965,9 +1053,12 @@ class MhaFn(Function):
     padded to a multiple of 8 so that P feeds the P.V MFMA GEMM directly."""
 
     @staticmethod
-    def forward(ctx, xq, xk, xv, res, *args):
-        (wq, wk, wv, bq, bk, bv, wo, bo, B, heads, causal, kpm, p_drop, res_slot) = args[-14:]
+    def forward(ctx, xq, xk, xv, res, kv, *args):
+        """kv: the K | V projections [B*Lk, 2E] when the caller has computed them already (KvProjFn, with `joint` = its JointDone pair):
+        this node then projects the queries only and hands dK | dV back as kv's gradient."""
+        (wq, wk, wv, bq, bk, bv, wo, bo, B, heads, causal, kpm, p_drop, res_slot, joint) = args[-15:]
         ctx.res_slot = res_slot
+        ctx.joint = joint if kv is not None else None
         dev, dtype = xq.device, xq.dtype
         dt = K.dcode(dtype)
         E = wq.rows
@@ -981,9 +1072,11 @@ class MhaFn(Function):
             qb, kb, vb = (qkv, 0, 3 * E), (qkv, E, 3 * E), (qkv, 2 * E, 3 * E)
         else:
             qbuf = torch.empty(B * Lq, E, device=dev, dtype=dtype)
-            kvbuf = torch.empty(B * Lk, 2 * E, device=dev, dtype=dtype)
+            kvbuf = kv if kv is not None else torch.empty(B * Lk, 2 * E, device=dev, dtype=dtype)
             qb, kb, vb = (qbuf, 0, E), (kvbuf, 0, 2 * E), (kvbuf, E, 2 * E)
-        jobs = [[xq, wq, bq, qb], [xk, wk, bk, kb], [xv, wv, bv, vb]]
+        if kv is not None and Lq == Lk:
+            raise ValueError("mha(kv=): precomputed key / value projections are for cross-attention (Lq != Lk)")
+        jobs = [[xq, wq, bq, qb]] if kv is not None else [[xq, wq, bq, qb], [xk, wk, bk, kb], [xv, wv, bv, vb]]
         merged = []
         for j in jobs:
             if merged:
@@ -1109,19 +1202,26 @@ class MhaFn(Function):
             grads[id(x_)] = dx
         # a packed in_proj parameter is written by up to three row-block GEMMs: it is ready (DDP bucket bookkeeping) only once
         # ALL of them are enqueued, so the marks come after the loop, one per parameter
-        for _, w_, b_, _ in merged:
-            w_.done()
-            if b_ is not None:
-                b_.done()
+        dkv = None
+        if ctx.joint is not None:
+            # the key / value projections belong to KvProjFn: dK | dV goes back as the gradient of its output, and the packed parameters are
+            # announced by whichever of the two nodes enqueues its last block
+            jw, jb = ctx.joint
+            for _, w_, b_, _ in merged:
+                jw.add(w_)
+                jb.add(b_)
+            dkv = dkb[0]
+        else:
+            done_joint([w_ for _, w_, _, _ in merged] + [b_ for _, _, b_, _ in merged])
         dxq = grads.get(id(xq))
-        dxk = None if same_qk else grads.get(id(xk))
-        dxv = None if (same_kv or xv is xq) else grads.get(id(xv))
+        dxk = None if (same_qk or dkv is not None) else grads.get(id(xk))
+        dxv = None if (same_kv or xv is xq or dkv is not None) else grads.get(id(xv))
         dres = dout if has_res else None
         if ctx.res_slot is not None and dres is not None:      # (LinearFn: the LayerNorm backward of the same tensor adds it)
             ctx.res_slot.put(dres)
             dres = None
-        n_extra = 14 + 8
-        return (dxq, dxk, dxv, dres) + (None,) * n_extra
+        n_extra = 15 + 8
+        return (dxq, dxk, dxv, dres, dkv) + (None,) * n_extra
 
 
 def _merge_w(a: WRef, b: WRef) -> WRef:
@@ -1132,10 +1232,12 @@ def _merge_w(a: WRef, b: WRef) -> WRef:
 
 
 def mha(xq, xk, xv, wq: WRef, wk: WRef, wv: WRef, bq, bk, bv, wo: WRef, bo, *, B, heads, causal=False, kpm=None, p_drop=0.0, res=None,
-        res_slot=None):
+        res_slot=None, kv=None):
+    """kv: (K | V buffer, joint) from kv_proj(xk, xv, ...) when the key / value projections were computed elsewhere (another stream)."""
     params = [r.param for r in (wq, wk, wv, bq, bk, bv, wo, bo) if r is not None]
     params = params + [None] * (8 - len(params))
-    return MhaFn.apply(xq, xk, xv, res, *params, wq, wk, wv, bq, bk, bv, wo, bo, B, heads, causal, kpm, float(p_drop), res_slot)
+    kvbuf, joint = kv if kv is not None else (None, None)
+    return MhaFn.apply(xq, xk, xv, res, kvbuf, *params, wq, wk, wv, bq, bk, bv, wo, bo, B, heads, causal, kpm, float(p_drop), res_slot, joint)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -111,10 +111,14 @@ class MultiheadAttention(Bound):
         self.wq, self.wk, self.wv = (WRef(store, self.in_proj_weight, i * E, E) for i in range(3))
         self.bq, self.bk, self.bv = (WRef(store, self.in_proj_bias, i * E, E, cols=1) for i in range(3))
 
-    def __call__(self, xq, xk, xv, *, B, causal=False, kpm=None, res=None, training=True, res_slot=None):
+    def project_kv(self, xk, xv):
+        """The key / value projections alone (for a caller that computes them on another stream): -> what `kv=` of __call__ takes."""
+        return Fn.kv_proj(xk, xv, self.wk, self.wv, self.bk, self.bv)
+
+    def __call__(self, xq, xk, xv, *, B, causal=False, kpm=None, res=None, training=True, res_slot=None, kv=None):
         p = self.dropout if training else 0.0
         return Fn.mha(xq, xk, xv, self.wq, self.wk, self.wv, self.bq, self.bk, self.bv, self.out_proj.w, self.out_proj.b, B=B,
-                      heads=self.num_heads, causal=causal, kpm=kpm, p_drop=p, res=res, res_slot=res_slot)
+                      heads=self.num_heads, causal=causal, kpm=kpm, p_drop=p, res=res, res_slot=res_slot, kv=kv)
 
 
 class ConvBN(Bound):

@@ -198,7 +198,7 @@ class CROG(nn.Module):
             # (deterministic mode keeps the side streams since round 5: the run-to-run differences of rounds 3-4 were packed-fp32 VALU results
             # going wrong beside another stream's MFMA kernel - runtime.set_deterministic, LAB_NOTES section 10; RT.det_streams = "0" restores one stream)
             overlap_text = self.overlap_text and (not RT.deterministic or RT.det_streams in ("all", "text"))
-            graphed = gate = hword = None
+            graphed = gate = hword = dtext = None
             if overlap_text:
                 if self._side is None:
                     RT.ensure_streams(dev)      # creation ORDER of the side streams decides which hardware queues they share
@@ -238,6 +238,10 @@ class CROG(nn.Module):
                 if GATE_ON_TEXT and hasattr(self.proj, "text_word"):
                     with torch.cuda.stream(self._side):
                         hword = self.proj.text_word(state)
+                # ... and the decoder's text side: word features + positions, every layer's cross-attention key / value projections
+                if GATE_ON_TEXT and self.use_contrastive and self.training and torch.is_grad_enabled() and hasattr(self.decoder, "text_kv"):
+                    with torch.cuda.stream(self._side):
+                        dtext = self.decoder.text_kv(wfeat)
                 main.wait_stream(self._side)
                 wfeat.record_stream(main)
                 state.record_stream(main)
@@ -245,6 +249,9 @@ class CROG(nn.Module):
                     gate.record_stream(main)
                 if hword is not None:
                     hword.record_stream(main)
+                if dtext is not None:
+                    for t_ in (dtext[0], dtext[1]) + tuple(kv[0] for kv in dtext[2]):
+                        t_.record_stream(main)
             else:
                 vis = self.backbone.image_features(img, dtype)
                 wfeat, state = self.backbone.text_features(word, dtype)
@@ -261,7 +268,7 @@ class CROG(nn.Module):
             self.backbone.visual.fan = None
             fq = self.neck(vis, state, fan=fan, gate=gate)
             if self.use_contrastive:
-                fq = self.decoder(fq, wfeat, pad_mask)
+                fq = self.decoder(fq, wfeat, pad_mask, text=dtext)
                 if isinstance(fq, list):
                     # cfg.intermediate=True: the reference's decoder returns a list and crog.py:69 then calls .reshape on it
                     raise AttributeError("'list' object has no attribute 'reshape' (TransformerDecoder(return_intermediate=True) "

@@ -143,7 +143,7 @@ class TransformerDecoderLayer(Bound):
         self.norm1, self.norm2, self.norm3 = LayerNorm(d_model), LayerNorm(d_model), LayerNorm(d_model)
         self.p = dropout
 
-    def forward(self, vis, txt, txt_k, vis_pos, pad_mask, B):
+    def forward(self, vis, txt, txt_k, vis_pos, pad_mask, B, kv=None):
         p = self.p if self.training else 0.0
         tr = self.training
         # each `vis` below has two consumers, a norm and the residual add after the sub-layer: the residual's gradient travels in a
@@ -154,7 +154,7 @@ class TransformerDecoderLayer(Bound):
         a = self.self_attn(qk, qk, v2, B=B, training=tr)
         vis = self.self_attn_norm(a, res=vis, p_out=p, res_slot=s1)
         _, q = self.norm2(vis, pos=vis_pos, want_out2=True, add_slot=s2)
-        a = self.multihead_attn(q, txt_k, txt, B=B, kpm=pad_mask, training=tr)
+        a = self.multihead_attn(q, txt_k, txt, B=B, kpm=pad_mask, training=tr, kv=kv)
         vis = self.cross_attn_norm(a, res=vis, p_out=p, res_slot=s2)
         v2 = self.norm3(vis, add_slot=s3 if p > 0 else None)
         # (the ReLU's backward rides in the LayerNorm's, which holds the ReLU output in registers anyway: no activation-backward pass
@@ -177,18 +177,30 @@ class TransformerDecoder(Bound):
         self.norm = LayerNorm(d_model)
         self.return_intermediate = return_intermediate
 
-    def forward(self, vis, txt, pad_mask):
-        """vis: [B, H, W, C] channels-last; txt: [B, L, D]; pad_mask: [B, L] bool -> [B, H, W, C]."""
-        B, H, W, C = vis.shape
-        _, L, D = txt.shape
-        vis_pos = pos2d(C, H, W, vis.device, vis.dtype)
-        txt_pos = pos1d(D, L, vis.device, vis.dtype)
-        x = vis.reshape(B * H * W, C)
+    def text_kv(self, txt):
+        """Everything of the decoder that depends on the text side alone (layers.py:252-253, 329-332): the word features with their 1-D positions
+        and every layer's key / value projections of the cross-attention.  CROG.forward calls it on the text stream (round 6) and hands the result to
+        forward(text=): six 80-block GEMMs forward and six backward leave the main chain."""
+        B, L, D = txt.shape
         t = txt.reshape(B * L, D)
-        t_k = Fn.add_rows(t, txt_pos)
+        t_k = Fn.add_rows(t, pos1d(D, L, txt.device, txt.dtype))
+        return t, t_k, [layer.multihead_attn.project_kv(t_k, t) for layer in self.layers]
+
+    def forward(self, vis, txt, pad_mask, text=None):
+        """vis: [B, H, W, C] channels-last; txt: [B, L, D]; pad_mask: [B, L] bool -> [B, H, W, C].  text: text_kv(txt) when already computed."""
+        B, H, W, C = vis.shape
+        vis_pos = pos2d(C, H, W, vis.device, vis.dtype)
+        x = vis.reshape(B * H * W, C)
+        if text is not None:
+            t, t_k, kvs = text
+        else:
+            _, L, D = txt.shape
+            t = txt.reshape(B * L, D)
+            t_k = Fn.add_rows(t, pos1d(D, L, vis.device, vis.dtype))
+            kvs = [None] * len(self.layers)
         intermediate = []
-        for layer in self.layers:
-            x = layer(x, t, t_k, vis_pos, pad_mask, B)
+        for layer, kv in zip(self.layers, kvs):
+            x = layer(x, t, t_k, vis_pos, pad_mask, B, kv=kv)
             if self.return_intermediate:            # layers.py:262-274: the shared final norm applied to every layer's output
                 intermediate.append(self.norm(x).view(B, H, W, C))
         if self.return_intermediate:
