@@ -52,7 +52,7 @@ def train_step(model, optimizer, scaler, batch, args=None, autocast_dtype=torch.
         pred, target, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
     # (crog_engine.py:84 computes the batch metric after the optimizer step; it reads the forward's outputs only, so it is enqueued HERE,
     # beside the start of backward, instead of behind the last weight gradient at the very end of the step: 65 us of the step's tail)
-    m = Fn.train_metric(pred[0], target[0], 0.35, 0.5)
+    m = Fn.train_metric_beside(pred[0], target[0], 0.35, 0.5)
     optimizer.zero_grad()
     max_norm = getattr(args, "max_norm", 0.0) if args is not None else 0.0
     if scaler is not None and scaler.is_enabled():

@@ -14,6 +14,7 @@ Conventions
 from __future__ import annotations
 
 import math
+import contextlib
 import os
 from typing import List, Optional, Tuple
 
@@ -1793,14 +1794,24 @@ class FusedHeadFn(Function):
         dt = K.dcode(dtype)
         P, g = H * W, groups
         ldw = word.shape[1]
-        wpad = torch.empty(B, C, 16, device=dev, dtype=dtype)
-        K.head_pack_weights(word, wpad, B, C)
-        # Wf[b][g][tap][k] = sum_c wpad[b][c][tap] * W5[g*C + c][k]
-        Wf = torch.empty(B, g * 16, C, device=dev, dtype=dtype)
-        K.gemm(dt, K.A_MC, K.B_NC, wpad, w5.w(dtype), Wf, 16, C, C, 16, w5.cols, C, batch=B * g, batch_inner=g,
-               sA=(C * 16, 0), sB=(0, C * w5.cols), sC=(g * 16 * C, 16 * C), b_off=w5.off)
-        cb = torch.empty(B, g, 16, device=dev, dtype=torch.float32)
-        K.head_cb_fwd(b5.P, b5.off, wpad, cb, B, g, C)
+        # the "compose" half depends on word and the weights alone: with the word on another stream (tail_stream) it is enqueued there - the
+        # host reaches this point long before the main chain's GPU work does, so it runs beside the projector's convolutions.  Its buffers are
+        # allocated IN that stream's context (a block just freed on this stream may still be in use by queued work here).
+        cur = torch.cuda.current_stream()
+        side = tail_stream if (tail_stream is not None and tail_stream != cur and K._STREAM_OVERRIDE is None) else None
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            wpad = torch.empty(B, C, 16, device=dev, dtype=dtype)
+            Wf = torch.empty(B, g * 16, C, device=dev, dtype=dtype)
+            cb = torch.empty(B, g, 16, device=dev, dtype=torch.float32)
+            K.head_pack_weights(word, wpad, B, C)
+            # Wf[b][g][tap][k] = sum_c wpad[b][c][tap] * W5[g*C + c][k]
+            K.gemm(dt, K.A_MC, K.B_NC, wpad, w5.w(dtype), Wf, 16, C, C, 16, w5.cols, C, batch=B * g, batch_inner=g,
+                   sA=(C * 16, 0), sB=(0, C * w5.cols), sC=(g * 16 * C, 16 * C), b_off=w5.off)
+            K.head_cb_fwd(b5.P, b5.off, wpad, cb, B, g, C)
+        if side is not None:
+            cur.wait_stream(side)
+            for t_ in (wpad, Wf, cb):
+                t_.record_stream(cur)
         ldx = K.mat(x4)[2]
         t = torch.empty(B * P * g, 16, device=dev, dtype=torch.float32)
         K.gemm(dt, K.A_KC, K.B_KC, x4, Wf, t, P, g * 16, C, ldx, C, g * 16, batch=B, sA=(P * ldx, 0), sB=(g * 16 * C, 0),
@@ -1974,6 +1985,22 @@ class LossFn(Function):
 
 def head_loss(pred, targets, weighted):
     return LossFn.apply(pred, targets, weighted)
+
+
+def train_metric_beside(pred_ins, target, threshold=0.35, pr_iou=0.5):
+    """train_metric on the text stream when the step has one (round 6): the two launches (27 us) leave the main chain, which goes straight
+    into backward; the result is read after the end-of-backward join of the side streams (engine.train_step, graphs.GraphedTrainStep)."""
+    side = RT.text_stream
+    cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
+    if side is None or cur is None or side not in RT.streams or side == cur or not pred_ins.is_cuda:
+        return train_metric(pred_ins, target, threshold, pr_iou)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        out = train_metric(pred_ins, target, threshold, pr_iou)
+    pred_ins.record_stream(side)
+    target.record_stream(side)
+    out.record_stream(cur)
+    return out
 
 
 def train_metric(pred_ins, target, threshold=0.35, pr_iou=0.5):

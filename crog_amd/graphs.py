@@ -166,7 +166,7 @@ class GraphedTrainStep:
             opt._store.request_zero()      # (engine.train_step: the gradient memset may run on the forward's side stream)
         with torch.autocast("cuda", dtype=adt or torch.bfloat16, enabled=adt is not None):
             pred, target, loss, loss_dict = model(batch["img"], batch["word"], batch["mask"], batch["qua"], batch["sin"], batch["cos"], batch["wid"])
-        m = Fn.train_metric(pred[0], target[0], 0.35, 0.5)      # (beside the start of backward, not behind the last Adam launch: engine.train_step)
+        m = Fn.train_metric_beside(pred[0], target[0], 0.35, 0.5)      # (beside the start of backward, not behind the last Adam launch: engine.train_step)
         opt.zero_grad()
         max_norm = getattr(self.args, "max_norm", 0.0) if self.args is not None else 0.0
         from .engine import ADAM_OVERLAP
