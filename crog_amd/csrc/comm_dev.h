@@ -45,12 +45,19 @@ __device__ inline void crog_peer_exchange(float* x, int n, const CrogPeerPtrs& p
     float* dst = peers.box[r] + ((size_t)par * world + rank) * S;
     for (int i = threadIdx.x; i < n; i += blockDim.x) __builtin_nontemporal_store(x[i], dst + i);
   }
-  __threadfence_system();
+  // Round 6: ONE system-scope write-back per exchange instead of three (and by one wave instead of four).  Before: every thread ran
+  // __threadfence_system() (buffer_wbl2 + buffer_inv per wave), the flag store was a release store of its own (another write-back) and a third
+  // fence followed the wait - each write-back flushes whatever the XCD's L2 holds dirty, and an exchange in a GEMM's tail runs right behind
+  // that GEMM's output stores (forced DDP at world size 1: 29.15 -> see LAB_NOTES section 11).  Now: the block meets (a workgroup barrier
+  // completes every wave's stores: s_waitcnt vmcnt(0) + s_barrier), THEN the publishing lanes - one wave - execute a system-scope RELEASE
+  // fence, which covers every store that happens-before it, the other waves' included (the barrier orders them), and store the flags
+  // RELAXED behind it (fence-atomic synchronisation with the peer's acquire fence below).
   __syncthreads();
   // 2. publish: flag [par][rank] of every mailbox = seq
   if ((int)threadIdx.x < world) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     unsigned* f = reinterpret_cast<unsigned*>(peers.box[threadIdx.x] + (size_t)2 * world * S) + par * world + rank;
-    crog_st_sys(f, seq);
+    __hip_atomic_store(f, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // 3. wait for every rank's flag in MY mailbox (bounded)
   if ((int)threadIdx.x < world) {
@@ -79,7 +86,7 @@ __device__ inline void crog_peer_exchange(float* x, int n, const CrogPeerPtrs& p
     __syncthreads();
     return;
   }
-  __threadfence_system();
+  // (the polling lanes' acquire fence above + the barrier order the loads below behind the peers' stores: no further fence)
   // 4. sum in rank order (identical on every rank)
   const float* slots = mine + (size_t)par * world * S;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {

@@ -1203,6 +1203,14 @@ using ShapeMidBwd = Shape<2, 2, 2, 2, true, 0, true>;   // 128 x 128 data gradie
 
 // ASUM: the launch also accumulates a_sum[m] += sum_k A(m, k) (bias gradient inside a weight-gradient GEMM); a template flag so
 // that the main loop of every other launch is one basic block
+// The FORWARD statistics' exchange in the tail of the kernel that accumulated them (SyncBatchNorm: crog_gemm_desc.stat_sync with col_stats in
+// replica rows, no bwd_z), called by every block after its last store - no accumulator is live any more.  Round 6: the LDS-DMA tiles carry it
+// like the ping-pong tile, so crog_gemm adds no single-block finish launch behind them (27 of the 33 that were left per CROG-R50 step).
+__device__ __attribute__((always_inline)) inline void fwd_stat_sync_tail(const crog_gemm_desc& p) {
+  if (p.stat_sync && p.col_stats && p.stat_replicas > 0 && !p.bwd_z && p.splitk <= 1 && p.batch == 1)
+    crog_stat_sync_tail(reinterpret_cast<const CrogSyncBlock*>(p.stat_sync), p.col_stats, p.stat_replicas, 2 * p.N, gridDim.x * gridDim.y * gridDim.z);
+}
+
 template <typename T, int AL, int BL, typename S, int ASUM>
 __global__ void __launch_bounds__(S::NT, (sizeof(T) == 4 && dma_blocks_per_cu<S>() > 2 ? dma_blocks_per_cu<S>() - 1 : dma_blocks_per_cu<S>()))
 gemm_dma_kernel(const crog_gemm_desc p) {   // (fp32 carries a second accumulator set, KBLOCK_F32: one block per CU less)
@@ -1408,6 +1416,7 @@ gemm_dma_kernel(const crog_gemm_desc p) {   // (fp32 carries a second accumulato
   if (do_asum) flush_a_sum<WM>(asum, p.a_sum, m0 + wr * WM * 32, p.M, lane);
   __syncthreads();
   gemm_epilogue<T, S>(acc, p, smem, m0, n0, zs, coff);
+  if constexpr (!S::BWD && !S::ATOM && sizeof(T) == 2) fwd_stat_sync_tail(p);
 }
 
 
@@ -1593,6 +1602,7 @@ __global__ void __launch_bounds__(S::NT, S::NT == 512 ? 1 : 3) gemm_dma16_kernel
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  fwd_stat_sync_tail(p);
 }
 
 #ifdef CROG_GEMM_PROBE
@@ -1604,6 +1614,11 @@ template __global__ void gemm_dma16_kernel<CROG_A_IM2COL, ShapeDma8>(const crog_
 template __global__ void gemm_dma16_kernel<CROG_A_KC, ShapeMid>(const crog_gemm_desc);
 }  // namespace
 #else
+// forward statistics + stat_sync: did the launched kernel carry the exchange in its own tail (the ping-pong tile; round 6: the LDS-DMA tiles too),
+// or does crog_gemm add the single-block finish launch behind it?
+static thread_local bool g_fwd_tail = false;
+inline bool wants_fwd_tail(const crog_gemm_desc& d) { return d.stat_sync && d.col_stats && d.stat_replicas > 0 && !d.bwd_z && d.splitk <= 1 && d.batch == 1; }
+
 template <typename T, int AL, int BL, typename S>
 int launch_dma(const crog_gemm_desc& d, hipStream_t s) {
   constexpr int ring = dma_nstage<S>() * (S::BM + S::BN) * 64, epi = lds_bytes<T, S>();   // the epilogue reuses the ring
@@ -1630,6 +1645,7 @@ int launch_dma(const crog_gemm_desc& d, hipStream_t s) {
   if (splitk_by_xcd(d)) grid = dim3(grid.x * d.splitk, 1, 1);
   hipLaunchKernelGGL(d.a_sum ? kern_asum : kern, grid, dim3(S::NT), LDS, s, d);
   CROG_LAUNCH_CHECK();
+  if (!S::BWD && !S::ATOM && sizeof(T) == 2 && wants_fwd_tail(d)) g_fwd_tail = true;
   return CROG_OK;
 }
 
@@ -1652,6 +1668,7 @@ int launch_dma16(const crog_gemm_desc& d, hipStream_t s) {
   dim3 grid(cdiv(d.M, S::BM) * cdiv(d.N, S::BN), d.batch, 1);
   hipLaunchKernelGGL(kern, grid, dim3(S::NT), LDS, s, d);
   CROG_LAUNCH_CHECK();
+  if (wants_fwd_tail(d)) g_fwd_tail = true;
   return CROG_OK;
 }
 
@@ -1831,9 +1848,6 @@ inline int pp_rows(const crog_gemm_desc& d) {
   return (c192 * 11 < c256 * 10 && crog_gemm_pp_eligible(d, 192)) ? 192 : 256;      // (a 192-row tile runs ~10 % below the 256-row tile's rate per row)
 }
 
-// forward statistics + stat_sync: did the launched kernel carry the exchange in its own tail (the ping-pong tile), or does crog_gemm add the
-// single-block finish launch behind it?
-static thread_local bool g_fwd_tail = false;
 __global__ void __launch_bounds__(256) stat_sync_finish_kernel(const CrogSyncBlock* sb, float* sums, int R, int n2) {
   crog_stat_sync_tail(sb, sums, R, n2, 1u);
 }
