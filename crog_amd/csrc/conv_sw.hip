@@ -17,6 +17,7 @@
 // Lean launches only (alpha 1, no bias / activation / residual, statistics in replica mode or none); everything else stays with
 // crog_gemm's implicit-GEMM kernels.  Dispatch: crog_gemm -> crog_conv_sw_eligible (below).
 #include "gemm_dma.h"
+#include "comm_dev.h"
 #include <algorithm>
 
 namespace {
@@ -58,7 +59,11 @@ __global__ void __launch_bounds__(SW_NT, 1) conv_sw_kernel(const crog_gemm_desc 
   char* zrow = smem + NS * RS;                             // the all-zero row
 
   const int r0 = blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, total_rows);
-  if (r0 >= r1) return;
+  if (r0 >= r1) {      // (a workgroup without rows - the launcher creates none - still takes its ticket in the statistics' exchange)
+    if (p.stat_sync && p.col_stats && p.stat_replicas > 0 && !p.bwd_z)
+      crog_stat_sync_tail(reinterpret_cast<const CrogSyncBlock*>(p.stat_sync), p.col_stats, p.stat_replicas, 2 * p.N, gridDim.x * gridDim.y * gridDim.z);
+    return;
+  }
 
   // zero the border pixels of the ring rows and the whole zero row (once)
   for (unsigned i = tid * 16u; i < (unsigned)(NS + 1) * RS; i += SW_NT * 16u) {
@@ -202,6 +207,9 @@ __global__ void __launch_bounds__(SW_NT, 1) conv_sw_kernel(const crog_gemm_desc 
       atomicAdd(p.col_stats + (int64_t)(blockIdx.x % p.stat_replicas) * p.N * 2 + tid, v);
     }
   }
+  // SyncBatchNorm forward statistics: the last block exchanges the totals (crog_gemm_desc.stat_sync, comm_dev.h; round 6: no finish launch)
+  if (p.stat_sync && stats && p.stat_replicas > 0 && !p.bwd_z)
+    crog_stat_sync_tail(reinterpret_cast<const CrogSyncBlock*>(p.stat_sync), p.col_stats, p.stat_replicas, 2 * p.N, gridDim.x * gridDim.y * gridDim.z);
 }
 
 template <int CI, int CO, int G>

@@ -1877,14 +1877,19 @@ int dispatch_shape(const crog_gemm_desc& d, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     // the stem's first convolution on its im2col rows (N = K = 32, 1.38 M rows): streamed, no LDS stage.  CROG_SKINNY=0: the tiled kernel
     static const bool skinny = [] { const char* e = getenv("CROG_SKINNY"); return !e || atoi(e) != 0; }();
-    if (skinny && d.M >= 16384 && crog_gemm_skinny_eligible(d)) return crog_gemm_skinny_launch(d, s);
+    if (skinny && d.M >= 16384 && crog_gemm_skinny_eligible(d)) {
+      if (wants_fwd_tail(d)) g_fwd_tail = true;      // (its last block runs the exchange)
+      return crog_gemm_skinny_launch(d, s);
+    }
   }
   if constexpr (sizeof(T) == 2) {
     // small-channel 3x3 convolutions (stem, layer1: N = 32 / 64, K = 288 / 576) with at least 64 K pixels: the sliding-window kernel
     // fetches every input row once instead of nine times through L2 -> LDS.  CROG_CONV_SW=0 / debug bit 20: the implicit GEMM
     static const bool conv_sw = [] { const char* e = getenv("CROG_CONV_SW"); return !e || atoi(e) != 0; }();
-    if (conv_sw && !(d.debug & 1048576) && d.a_layout == CROG_A_IM2COL && (d.M >= 65536 || (d.debug & 2097152)) && crog_conv_sw_eligible(d))
+    if (conv_sw && !(d.debug & 1048576) && d.a_layout == CROG_A_IM2COL && (d.M >= 65536 || (d.debug & 2097152)) && crog_conv_sw_eligible(d)) {
+      if (wants_fwd_tail(d)) g_fwd_tail = true;      // (its last block runs the exchange)
       return crog_conv_sw_launch(d, s);
+    }
   }
   if constexpr (sizeof(T) == 2) {
     // ... and their weight gradients (the tail of the step): CROG_WGRAD_SW=0 / debug bit 22: the implicit GEMM; bit 23 lifts the size threshold

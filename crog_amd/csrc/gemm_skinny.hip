@@ -11,6 +11,7 @@
 // Lean launches only (alpha 1, no bias / activation / residual; statistics in replica mode or none).  Dispatch: crog_gemm ->
 // crog_gemm_skinny_eligible.
 #include "gemm_dma.h"
+#include "comm_dev.h"
 #include <algorithm>
 
 namespace {
@@ -79,6 +80,9 @@ __global__ void __launch_bounds__(SK_NT) gemm_skinny32_kernel(const crog_gemm_de
       for (int mm = 0; mm < 32; mm++) v += red[w][32 * hh + mm][16 * k + e];
     atomicAdd(p.col_stats + ((int64_t)(blockIdx.x % p.stat_replicas) * 32 + c) * 2 + k, v);
   }
+  // SyncBatchNorm forward statistics: the last block exchanges the totals (crog_gemm_desc.stat_sync, comm_dev.h; round 6: no finish launch)
+  if (p.stat_sync && stats && p.stat_replicas > 0 && !p.bwd_z)
+    crog_stat_sync_tail(reinterpret_cast<const CrogSyncBlock*>(p.stat_sync), p.col_stats, p.stat_replicas, 2 * 32, gridDim.x * gridDim.y * gridDim.z);
 }
 
 }  // namespace
