@@ -11,9 +11,10 @@
 //    the critical path (a BatchNorm layer cannot normalise before the global sums exist), where a ring collective costs 20-40 us of
 //    latency per call.  Every rank owns a mailbox in uncached device memory, opened by its peers through hipIpc.  An exchange is ONE
 //    single-block kernel per rank: write my n floats into slot [parity][my rank] of every rank's mailbox (peer stores over xGMI),
-//    system-scope fence, publish the sequence number in every mailbox's flag word, wait until all `world` flags of my own mailbox
-//    carry this sequence number, then add the slots up in rank order - the same order on every rank, so all ranks hold bit-identical
-//    sums.  One hop, no ring; the latency is a peer write + a flag poll.
+//    workgroup barrier, ONE system-scope release fence by the publishing lanes, the sequence number stored (relaxed) in every mailbox's
+//    flag word, relaxed polls until all `world` flags of my own mailbox carry this sequence number, one acquire fence, then the slots
+//    added up in rank order - the same order on every rank, so all ranks hold bit-identical sums (comm_dev.h: crog_peer_exchange).
+//    One hop, no ring; the latency is a peer write + a flag poll.
 //    Two slot sets (sequence parity): a rank can only run ahead of a peer by one exchange - it needs that peer's contribution to finish
 //    the next one - so exchange e + 2 can never overwrite data a slower peer is still reading from exchange e.
 //    The sequence number lives in device memory and is advanced by the kernel, so the launch carries no per-step scalar and can be

@@ -13,9 +13,6 @@ struct CrogSyncBlock {
   unsigned long long wait_ticks;      // bound of a wait for the peers, in ticks of the 100 MHz wall clock
 };
 
-__device__ inline unsigned crog_ld_sys(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ inline void crog_st_sys(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-
 // One exchange by ONE workgroup (all its threads call): x[0 .. n) (global or LDS, fp32) becomes the sum over the ranks, added in rank
 // order (bit-identical on every rank).  Mailbox layout and protocol: csrc/comm.hip.  A rank whose earlier exchange timed out, or whose
 // peers do not show up within wait_ticks, gets NaN (and the mailbox's error word set).  n <= S.
