@@ -54,7 +54,11 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if defined(CROG_PPT_WAVE_MAP) && CROG_PPT_WAVE_MAP == 1     // (A/B: neighbouring waves in different groups, for a wave w on SIMD w >> 1)
+  const int wr = wave & 1, wc = wave >> 1;
+#else
   const int wr = wave >> 2, wc = wave & 3;
+#endif
   const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
   const int nwg = tilesM * tilesN;
   int id = blk, z = 0;
@@ -198,12 +202,37 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
   _Pragma("unroll") for (int r_ = 0; r_ < RBQ; r_++)                                                                   \
     _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++)                                                                   \
       _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) mma32(fa[r_][ks_], FB[c_][ks_], acc[(I0) + r_][(J0) + c_])
+// CROG_PPT_PROBE (scripts/build_variant.py pptN -DCROG_PPT_PROBE=N, TIMING ONLY - the results are wrong): what does a phase spend its time on?
+//   1: no second barrier per phase   2: no LDS-DMA requests after the prologue   3: no fragment reads (the MFMAs run on stale registers)
+//   4: no MFMAs
+#ifndef CROG_PPT_PROBE
+#define CROG_PPT_PROBE 0
+#endif
+// CROG_PPT_ILV = 1: the fragment reads of the NEXT phase ride between this phase's MFMAs of the same wave instead of opening the next phase
+// (B-h1 during phase 0; A-h1 row block r after the last phase-1 MFMA that reads A-h0's block r; the next k-tile's A-h0 likewise in phase 3;
+// only B-h0 is still read ahead of its phase).  Deadlines are unchanged: a read in the MFMA part of phase ph touches half-tile <= ph + 2, which
+// that phase's vmcnt wait + barrier cover, and a slot is last read >= 2 phases before the request that refills it.
+#ifndef CROG_PPT_ILV
+#define CROG_PPT_ILV 0
+#endif
+#define PT_MFMA_ROW(FB, I0, J0, R)                                                                                     \
+  _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++)                                                                     \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) mma32(fa[R][ks_], FB[c_][ks_], acc[(I0) + (R)][(J0) + c_])
+#define PT_READ_A_ROW(SLOTIDX, R)                                                                                      \
+  _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++)                                                                  \
+    fa[R][ks_] = tr_frag(smem + (SLOTIDX) * SLOT + ks_ * 8192 + aad[0][R], smem + (SLOTIDX) * SLOT + ks_ * 8192 + aad[1][R])
 #define PT_PHASE(P, BUF, T)                                                                                            \
   do {                                                                                                                 \
+    if constexpr (CROG_PPT_PROBE != 3) {                                                                               \
+    if constexpr (CROG_PPT_ILV) {                                                                                      \
+      if constexpr ((P) == 0) { PT_READ_B(fb0, (BUF) * 4 + 1); }                                                       \
+    } else {                                                                                                           \
     if constexpr ((P) == 0) { PT_READ_A((BUF) * 4 + 0); PT_READ_B(fb0, (BUF) * 4 + 1); }                               \
     if constexpr ((P) == 1) { PT_READ_B(fb1, (BUF) * 4 + 2); }                                                         \
     if constexpr ((P) == 2) { PT_READ_A((BUF) * 4 + 3); }                                                              \
-    {                                                                                                                  \
+    }                                                                                                                  \
+    }                                                                                                                  \
+    if constexpr (CROG_PPT_PROBE != 2) {                                                                               \
       constexpr int m_ = (P) + D, j_ = m_ & 3, dt_ = m_ >> 2, buf_ = ((BUF) + dt_) & 1;                                 \
       PT_ISSUE(j_, buf_, (T) + dt_);                                                                                   \
     }                                                                                                                  \
@@ -213,22 +242,59 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
     __builtin_amdgcn_s_barrier();                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                     \
+    if constexpr (CROG_PPT_PROBE != 4) {                                                                               \
+    if constexpr (CROG_PPT_ILV) {                                                                                      \
+      if constexpr ((P) == 0) {                                                                                        \
+        PT_MFMA(fb0, 0, 0);                                                                                            \
+        PT_READ_B(fb1, (BUF) * 4 + 2);                                                                                 \
+        _Pragma("unroll") for (int g_ = 0; g_ < 8; g_++) {                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                           \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                           \
+        }                                                                                                              \
+      }                                                                                                                \
+      if constexpr ((P) == 1) {                                                                                        \
+        PT_MFMA_ROW(fb1, 0, 2, 0); PT_READ_A_ROW((BUF) * 4 + 3, 0);                                                    \
+        PT_MFMA_ROW(fb1, 0, 2, 1); PT_READ_A_ROW((BUF) * 4 + 3, 1);                                                    \
+        PT_MFMA_ROW(fb1, 0, 2, 2); PT_READ_A_ROW((BUF) * 4 + 3, 2);                                                    \
+        PT_MFMA_ROW(fb1, 0, 2, 3); PT_READ_A_ROW((BUF) * 4 + 3, 3);                                                    \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; g_++) {                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                           \
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                           \
+        }                                                                                                              \
+      }                                                                                                                \
+      if constexpr ((P) == 2) { PT_MFMA(fb1, RBQ, 2); }                                                                \
+      if constexpr ((P) == 3) {                                                                                        \
+        PT_MFMA_ROW(fb0, RBQ, 0, 0); PT_READ_A_ROW(((BUF) ^ 1) * 4 + 0, 0);                                            \
+        PT_MFMA_ROW(fb0, RBQ, 0, 1); PT_READ_A_ROW(((BUF) ^ 1) * 4 + 0, 1);                                            \
+        PT_MFMA_ROW(fb0, RBQ, 0, 2); PT_READ_A_ROW(((BUF) ^ 1) * 4 + 0, 2);                                            \
+        PT_MFMA_ROW(fb0, RBQ, 0, 3); PT_READ_A_ROW(((BUF) ^ 1) * 4 + 0, 3);                                            \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; g_++) {                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                           \
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                           \
+        }                                                                                                              \
+      }                                                                                                                \
+    } else {                                                                                                           \
     if constexpr ((P) == 0) { PT_MFMA(fb0, 0, 0); }                                                                    \
     if constexpr ((P) == 1) { PT_MFMA(fb1, 0, 2); }                                                                    \
     if constexpr ((P) == 2) { PT_MFMA(fb1, RBQ, 2); }                                                                  \
     if constexpr ((P) == 3) { PT_MFMA(fb0, RBQ, 0); }                                                                  \
+    }                                                                                                                  \
+    }                                                                                                                  \
     __builtin_amdgcn_s_setprio(0);                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    __builtin_amdgcn_s_barrier();                                                                                      \
+    if constexpr (CROG_PPT_PROBE != 1) __builtin_amdgcn_s_barrier();                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
   } while (0)
 
+  if constexpr (CROG_PPT_ILV) { PT_READ_A(0); }      // (half-tile 0 landed with the prologue's wait + barrier)
   for (int t = 0; t < nt2; t += 2) {
     PT_PHASE(0, 0, t); PT_PHASE(1, 0, t); PT_PHASE(2, 0, t); PT_PHASE(3, 0, t);
     PT_PHASE(0, 1, t + 1); PT_PHASE(1, 1, t + 1); PT_PHASE(2, 1, t + 1); PT_PHASE(3, 1, t + 1);
   }
 #undef PT_PHASE
 #undef PT_MFMA
+#undef PT_MFMA_ROW
+#undef PT_READ_A_ROW
 #undef PT_READ_A
 #undef PT_READ_B
 #undef PT_ISSUE
