@@ -1196,7 +1196,10 @@ using ShapeDma8A = Shape<4, 2, 2, 4, true, 0, false, true>;   // the same tile w
 #define CROG_TALL_NSTAGE 0             // (A/B builds: depth of the 256 x 64 tile's LDS-DMA ring; 0 = the default of its size)
 #endif
 using ShapeTall = Shape<2, 2, 4, 1, false, CROG_TALL_NSTAGE>;   // 256 x  64, 4 waves: layers with <= 64 output columns (N = 32 / 64)
-using ShapeDma64 = Shape<1, 1, 2, 2>;  //  64 x  64, 4 waves: small GEMMs (text tower, attention pooling), no BN statistics
+#ifndef CROG_DMA64_NSTAGE
+#define CROG_DMA64_NSTAGE 0            // (A/B builds: depth of the 64 x 64 tile's LDS-DMA ring; 0 = the default of its size, 3)
+#endif
+using ShapeDma64 = Shape<1, 1, 2, 2, false, CROG_DMA64_NSTAGE>;  //  64 x  64, 4 waves: small GEMMs (text tower, attention pooling), no BN statistics
 using ShapeMidBwd = Shape<2, 2, 2, 2, true, 0, true>;   // 128 x 128 data gradient that does the consumer BatchNorm's first backward pass
 // (8-deep rings for launches of <= 1-2 blocks per CU were tried: no gain standalone -- those launches are not bound by request
 // latency -- and 3 % slower in the step, where a 128 KiB block keeps the other streams' blocks off the CU.)
