@@ -23,6 +23,7 @@ from .layers import FPN, MultiTaskProjector, Projector, TransformerDecoder
 # path stays the default until the host becomes the limiter.
 TEXT_GRAPH = os.environ.get("CROG_TEXT_GRAPH", "0") == "1"
 TEXT_AFTER = os.environ.get("CROG_TEXT_AFTER", "0") == "1"
+TEXT_FREE = os.environ.get("CROG_PROBE_TEXT_FREE") == "1"      # TIMING PROBE, wrong training: the text tower runs once, its outputs are reused as constants
 GATE_ON_TEXT = os.environ.get("CROG_GATE_ON_TEXT", "1") != "0"      # the neck's sentence gate runs on the text stream (single-GPU step)
 DGW_LATE = os.environ.get("CROG_DGW_LATE", "1") != "0"      # the data-gradient weight copies are refreshed beside the neck, not beside the stem
 
@@ -224,10 +225,15 @@ class CROG(nn.Module):
                             txt.extend(r)
                 # (CROG_TEXT_AFTER=1, A/B: the whole text tower issued AFTER the image tower - its autograd nodes then run, host-side, before
                 # the image tower's backward, so its Adam chunks ripen early in the weight-gradient / aux stream's queue)
-                vis = self.backbone.image_features(img, dtype, None if TEXT_AFTER else issue_text)
+                frozen = getattr(self, "_probe_text", None) if TEXT_FREE else None
+                vis = self.backbone.image_features(img, dtype, None if (TEXT_AFTER or frozen is not None) else issue_text)
+                if frozen is not None:
+                    txt = list(frozen)
                 while not txt:          # whatever the image tower's hooks did not get to
                     issue_text()
                 wfeat, state = txt
+                if TEXT_FREE and frozen is None:
+                    self._probe_text = (wfeat.detach().clone(), state.detach().clone())
                 # the neck's sentence gate (layers.py:376) on the text stream, behind the tower: it needs nothing of the image side.  Not
                 # under SyncBatchNorm: its BatchNorm1d would exchange statistics on a second stream, and the mailbox exchanges of one
                 # communicator are sequenced on ONE stream (csrc/comm.hip).
