@@ -184,6 +184,12 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
   _Pragma("unroll") for (int r_ = 0; r_ < RBQ; r_++)                                                                   \
     _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++)                                                                   \
       _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) mma32(fa[r_][ks_], FB[c_][ks_], acc[(I0) + r_][(J0) + c_])
+  // CROG_PP_LGKM_LATE = 1 (A/B): the wait for the phase's own fragment reads sits AFTER the phase's first barrier, so the reads' latency
+  // overlaps the barrier wait.  The WAR argument above then needs the refill >= 2 phases behind the last read: D <= 6.
+#ifndef CROG_PP_LGKM_LATE
+#define CROG_PP_LGKM_LATE 0
+#endif
+  constexpr bool LGKM_LATE = CROG_PP_LGKM_LATE != 0 && D <= 6;
   // one phase: P = 0 .. 3, BUF = buffer of k-tile T (compile-time), T = k-tile index
 #define PP_PHASE(P, BUF, T)                                                                                            \
   do {                                                                                                                 \
@@ -195,9 +201,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
       PP_ISSUE(j_, buf_, (T) + dt_);                                                                                   \
     }                                                                                                                  \
     wait_vmcnt<2 * (D - 2)>();                                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+    if constexpr (!LGKM_LATE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_barrier();                                                                                      \
+    if constexpr (LGKM_LATE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                     \
     if constexpr ((P) == 0) { PP_MFMA(fb0, 0, 0); }                                                                    \

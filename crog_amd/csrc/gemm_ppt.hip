@@ -212,6 +212,11 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
 // (B-h1 during phase 0; A-h1 row block r after the last phase-1 MFMA that reads A-h0's block r; the next k-tile's A-h0 likewise in phase 3;
 // only B-h0 is still read ahead of its phase).  Deadlines are unchanged: a read in the MFMA part of phase ph touches half-tile <= ph + 2, which
 // that phase's vmcnt wait + barrier cover, and a slot is last read >= 2 phases before the request that refills it.
+// CROG_PPT_LGKM_LATE = 1 (A/B): the wait for the phase's own fragment reads sits AFTER the phase's first barrier (the reads' latency then overlaps
+// the barrier wait).  WAR is unchanged: the request that refills a slot is issued >= 2 phases after the slot's last read (D <= 6).
+#ifndef CROG_PPT_LGKM_LATE
+#define CROG_PPT_LGKM_LATE 0
+#endif
 #ifndef CROG_PPT_ILV
 #define CROG_PPT_ILV 0
 #endif
@@ -237,9 +242,10 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
       PT_ISSUE(j_, buf_, (T) + dt_);                                                                                   \
     }                                                                                                                  \
     wait_vmcnt<2 * (D - 2)>();                                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+    if constexpr (!(CROG_PPT_LGKM_LATE && D <= 6)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_barrier();                                                                                      \
+    if constexpr (CROG_PPT_LGKM_LATE && D <= 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                     \
     if constexpr (CROG_PPT_PROBE != 4) {                                                                               \
