@@ -413,18 +413,23 @@ def main():
             # HBM bytes per launch of this kernel: NOT measured in this run (PMC counters need rocprofv3 around the process) but read from
             # the committed PMC passes of the same workload, and labelled as such - it goes stale when the kernels change and the
             # round's profile is not re-taken
-            traffic = traffic_source = None
+            traffic = traffic_source = traffic_stale = None
             try:
                 pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
                 if args.dtype == "bf16" and args.batch == 32:
                     traffic = pm[name]["bytes_per_launch"]
                     traffic_source = "committed profile, not this run: profiles/pmc_traffic.json (" + pm[name].get("source", "?") + ")"
+                    from crog_amd import _lib
+                    took = pm[name].get("source_digest")
+                    traffic_stale = None if took is None else (took != _lib.source_digest())
+                    if traffic_stale:
+                        traffic_source += f"; STALE: counters taken on kernel sources {took}, this run's are {_lib.source_digest()}"
             except (OSError, KeyError, ValueError):
                 pass
             mf, hf = avg_f / avg_d / 1e12 / PEAK_MFMA_TF, alg / avg_d / 1e9 / PEAK_HBM_GBS
             return dict(bound="mfma" if mf >= hf else "hbm", achieved=round(avg_f / avg_d / 1e12, 2), peak=PEAK_MFMA_TF, unit="TFLOP/s",
                         frac=round(mf, 4), hbm_frac=round(hf, 4), hbm_achieved_GBps=round(alg / avg_d / 1e9, 1),
-                        traffic=traffic, traffic_source=traffic_source,
+                        traffic=traffic, traffic_source=traffic_source, traffic_stale=traffic_stale,
                         traffic_algorithmic=round(alg), traffic_ratio=(round(traffic / alg, 3) if traffic else None),
                         kernel=K.GEMM_SYMBOL[k], launches_per_step=len(mine) // max(sampled, 1), timed_steps_bracketed=sampled,
                         avg_launch_us=round(avg_d * 1e6, 1), avg_gflop_per_launch=round(avg_f / 1e9, 2),

@@ -77,6 +77,12 @@ for k in f:   # one roofline key can cover several tile-shape instantiations of 
         e["_bytes"] += (2 * f[k][1] + (w[k][1] if k in w else 0)) * 1024
 for e in pm.values():
     e["bytes_per_launch"] = round(e.pop("_bytes") / e["launches"])
+    try:      # which kernel sources these counters were taken on: bench.py marks the figure stale when the library's sources differ
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from crog_amd import _lib
+        e["source_digest"] = _lib.source_digest()
+    except Exception:
+        pass
 if pm: json.dump(pm, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 if tb and not os.environ.get("PROFILE_ENV"):
     # where the step's HBM bytes go: every kernel's PMC bytes per step, largest first (profiles/<tag>_traffic.md; the text around the table is
