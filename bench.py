@@ -524,6 +524,10 @@ def main():
     if rank == 0:
         if world > 1:
             time.sleep(0.5)      # the other ranks' last flush (above) may still be on its way to the shared stdout
+        probes = [k for k in ("CROG_PROBE_TEXT_FREE",) if os.environ.get(k) == "1"]
+        if probes:      # timing probes skip work inside the step: the line is labelled so that it cannot pass for a measurement of the training step
+            out["valid"] = False
+            out["invalid_because"] = "timing probe(s) in the environment: " + ", ".join(probes)
         print(json.dumps(out), flush=True)
 
 
