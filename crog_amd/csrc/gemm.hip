@@ -1753,7 +1753,8 @@ int dispatch_layout(const crog_gemm_desc& d, hipStream_t s) {
 // 1 = 64 x 64 tiles (latency-bound small problems without BatchNorm statistics), 2 = 128 x 128
 int pick_shape(const crog_gemm_desc& d) {
   const long mid = (long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.batch * d.splitk;
-  return (mid < 192 && !d.col_stats) ? 1 : 2;
+  static const long small_max = [] { const char* e = getenv("CROG_SMALL_TILE_MAX"); return e ? atol(e) : 192L; }();      // (A/B: below this many 128 x 128 tiles, 64 x 64)
+  return (mid < small_max && !d.col_stats) ? 1 : 2;
 }
 
 // Small-output weight gradients are bound by L2 -> LDS bytes and by the fp32-atomic epilogue, not by MFMA (scripts/ablate_wgrad.py,
