@@ -204,7 +204,8 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
       _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) mma32(fa[r_][ks_], FB[c_][ks_], acc[(I0) + r_][(J0) + c_])
 // CROG_PPT_PROBE (scripts/build_variant.py pptN -DCROG_PPT_PROBE=N, TIMING ONLY - the results are wrong): what does a phase spend its time on?
 //   1: no second barrier per phase   2: no LDS-DMA requests after the prologue   3: no fragment reads (the MFMAs run on stale registers)
-//   4: no MFMAs
+//   4: no MFMAs (the compiler then drops the fragment reads too: LDS-DMA requests + barriers only; 5 is the same build)
+//   6: barriers only   7: MFMAs only (no requests, no reads)
 #ifndef CROG_PPT_PROBE
 #define CROG_PPT_PROBE 0
 #endif
@@ -228,7 +229,7 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
     fa[R][ks_] = tr_frag(smem + (SLOTIDX) * SLOT + ks_ * 8192 + aad[0][R], smem + (SLOTIDX) * SLOT + ks_ * 8192 + aad[1][R])
 #define PT_PHASE(P, BUF, T)                                                                                            \
   do {                                                                                                                 \
-    if constexpr (CROG_PPT_PROBE != 3) {                                                                               \
+    if constexpr (CROG_PPT_PROBE != 3 && CROG_PPT_PROBE != 5 && CROG_PPT_PROBE != 7) {                                                        \
     if constexpr (CROG_PPT_ILV) {                                                                                      \
       if constexpr ((P) == 0) { PT_READ_B(fb0, (BUF) * 4 + 1); }                                                       \
     } else {                                                                                                           \
@@ -237,7 +238,7 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
     if constexpr ((P) == 2) { PT_READ_A((BUF) * 4 + 3); }                                                              \
     }                                                                                                                  \
     }                                                                                                                  \
-    if constexpr (CROG_PPT_PROBE != 2) {                                                                               \
+    if constexpr (CROG_PPT_PROBE != 2 && CROG_PPT_PROBE != 6 && CROG_PPT_PROBE != 7) {                                                        \
       constexpr int m_ = (P) + D, j_ = m_ & 3, dt_ = m_ >> 2, buf_ = ((BUF) + dt_) & 1;                                 \
       PT_ISSUE(j_, buf_, (T) + dt_);                                                                                   \
     }                                                                                                                  \
@@ -248,7 +249,7 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
     if constexpr (CROG_PPT_LGKM_LATE && D <= 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                     \
-    if constexpr (CROG_PPT_PROBE != 4) {                                                                               \
+    if constexpr (CROG_PPT_PROBE != 4 && CROG_PPT_PROBE != 5 && CROG_PPT_PROBE != 6) {                                 \
     if constexpr (CROG_PPT_ILV) {                                                                                      \
       if constexpr ((P) == 0) {                                                                                        \
         PT_MFMA(fb0, 0, 0);                                                                                            \
