@@ -21,6 +21,10 @@
 
 namespace {
 
+#if defined(CROG_PPT_STAMP) && CROG_PPT_STAMP
+__device__ unsigned g_ppt_stamp[64];      // [wave][reads, requests, vmcnt, lgkmcnt, barrier 1, MFMAs, barrier 2, phases] of block 0 (see PT_CLK)
+#endif
+
 __device__ __attribute__((always_inline)) inline bf16x8 tr_frag(const char* lo, const char* hi) {
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
   const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)lo);
@@ -221,14 +225,49 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
 #ifndef CROG_PPT_ILV
 #define CROG_PPT_ILV 0
 #endif
+// CROG_PPT_DMA_MFMA = 1: the two LDS-DMA requests of a phase are issued by the wave that is in its MFMA half (between its 8th and 9th MFMA)
+// instead of opening the load half behind the fragment reads.  Stamps (scripts/ppt_stamps.py) show why: a load half is ~430 cycles of ISSUE -
+// the reads, then the requests queued behind the CU's fill path (8 KiB per group and phase at 32 B/clk = 256 cycles) - against 256 cycles of MFMAs
+// on the partner wave, and the fill path idles while the reads are issued.  Hazards: the requests of phase ph now follow that phase's first
+// barrier, so the wait in the load half covers one half-tile less - vmcnt(2 (D - 3)) for the same guarantee (half-tiles <= ph + 2 landed) -
+// and the refill of a slot moves later, never earlier (legal up to D = 7).
+#ifndef CROG_PPT_DMA_MFMA
+#define CROG_PPT_DMA_MFMA 0
+#endif
 #define PT_MFMA_ROW(FB, I0, J0, R)                                                                                     \
   _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++)                                                                     \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) mma32(fa[R][ks_], FB[c_][ks_], acc[(I0) + (R)][(J0) + c_])
 #define PT_READ_A_ROW(SLOTIDX, R)                                                                                      \
   _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++)                                                                  \
     fa[R][ks_] = tr_frag(smem + (SLOTIDX) * SLOT + ks_ * 8192 + aad[0][R], smem + (SLOTIDX) * SLOT + ks_ * 8192 + aad[1][R])
+// CROG_PPT_STAMP = 1 (scripts/build_variant.py pptstamp -DCROG_PPT_STAMP=1, scripts/ppt_stamps.py): every wave of block 0 adds up, over its
+// phases, the s_memtime distances between the points of a phase - reads + requests issued, vmcnt wait, lgkmcnt wait, first barrier, MFMAs
+// issued, second barrier.  A stamp is read one phase later, behind that phase's own lgkmcnt(0), so that no wait is added for it.
+#ifndef CROG_PPT_STAMP
+#define CROG_PPT_STAMP 0
+#endif
+#if CROG_PPT_STAMP
+#define PT_CLK(V) do { __builtin_amdgcn_sched_barrier(0); V = (unsigned)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  unsigned s_a, s_i = 0, s_v = 0, s_b, s_c, s_d, p_v, p_b, p_c, p_d;
+  unsigned a_is = 0, a_vm = 0, a_lg = 0, a_b1 = 0, a_mf = 0, a_b2 = 0, a_n = 0;
+  PT_CLK(s_a);
+  s_b = s_c = s_d = p_v = p_b = p_c = p_d = s_a;      // (the first phase's "previous phase" terms are a few cycles of nothing)
+#define PT_FLUSH()                                                                                                     \
+  do {                                                                                                                 \
+    a_lg += p_b - p_v; a_b1 += p_c - p_b; a_mf += p_d - p_c; a_b2 += s_a - p_d;                                         \
+    a_is += s_i - s_a; a_vm += s_v - s_i; a_n++;                                                                       \
+  } while (0)
+#define PT_CARRY_V() do { p_v = s_v; } while (0)
+#define PT_CARRY_E() do { p_b = s_b; p_c = s_c; p_d = s_d; } while (0)
+#else
+#define PT_CLK(V) do {} while (0)
+#define PT_FLUSH() do {} while (0)
+#define PT_CARRY_V() do {} while (0)
+#define PT_CARRY_E() do {} while (0)
+#endif
 #define PT_PHASE(P, BUF, T)                                                                                            \
   do {                                                                                                                 \
+    PT_CLK(s_a);                                                                                                       \
     if constexpr (CROG_PPT_PROBE != 3 && CROG_PPT_PROBE != 5 && CROG_PPT_PROBE != 7) {                                                        \
     if constexpr (CROG_PPT_ILV) {                                                                                      \
       if constexpr ((P) == 0) { PT_READ_B(fb0, (BUF) * 4 + 1); }                                                       \
@@ -238,15 +277,21 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
     if constexpr ((P) == 2) { PT_READ_A((BUF) * 4 + 3); }                                                              \
     }                                                                                                                  \
     }                                                                                                                  \
-    if constexpr (CROG_PPT_PROBE != 2 && CROG_PPT_PROBE != 6 && CROG_PPT_PROBE != 7) {                                                        \
+    if constexpr (CROG_PPT_PROBE != 2 && CROG_PPT_PROBE != 6 && CROG_PPT_PROBE != 7 && !CROG_PPT_DMA_MFMA) {                                                        \
       constexpr int m_ = (P) + D, j_ = m_ & 3, dt_ = m_ >> 2, buf_ = ((BUF) + dt_) & 1;                                 \
       PT_ISSUE(j_, buf_, (T) + dt_);                                                                                   \
     }                                                                                                                  \
-    wait_vmcnt<2 * (D - 2)>();                                                                                         \
+    PT_CLK(s_i);                                                                                                       \
+    wait_vmcnt<2 * (D - 2 - (CROG_PPT_DMA_MFMA ? 1 : 0))>();                                                          \
+    PT_CLK(s_v);                                                                                                       \
     if constexpr (!(CROG_PPT_LGKM_LATE && D <= 6)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              \
+    PT_FLUSH();                                                                                                        \
+    PT_CARRY_V();                                                                                                      \
+    PT_CLK(s_b);                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_barrier();                                                                                      \
     if constexpr (CROG_PPT_LGKM_LATE && D <= 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
+    PT_CLK(s_c);                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                     \
     if constexpr (CROG_PPT_PROBE != 4 && CROG_PPT_PROBE != 5 && CROG_PPT_PROBE != 6) {                                 \
@@ -280,6 +325,21 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
           __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                           \
         }                                                                                                              \
       }                                                                                                                \
+    } else if constexpr (CROG_PPT_DMA_MFMA) {                                                                          \
+      if constexpr ((P) == 0) { PT_MFMA_ROW(fb0, 0, 0, 0); PT_MFMA_ROW(fb0, 0, 0, 1); }                                \
+      if constexpr ((P) == 1) { PT_MFMA_ROW(fb1, 0, 2, 0); PT_MFMA_ROW(fb1, 0, 2, 1); }                                \
+      if constexpr ((P) == 2) { PT_MFMA_ROW(fb1, RBQ, 2, 0); PT_MFMA_ROW(fb1, RBQ, 2, 1); }                            \
+      if constexpr ((P) == 3) { PT_MFMA_ROW(fb0, RBQ, 0, 0); PT_MFMA_ROW(fb0, RBQ, 0, 1); }                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      {                                                                                                                \
+        constexpr int m_ = (P) + D, j_ = m_ & 3, dt_ = m_ >> 2, buf_ = ((BUF) + dt_) & 1;                               \
+        PT_ISSUE(j_, buf_, (T) + dt_);                                                                                 \
+      }                                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if constexpr ((P) == 0) { PT_MFMA_ROW(fb0, 0, 0, 2); PT_MFMA_ROW(fb0, 0, 0, 3); }                                \
+      if constexpr ((P) == 1) { PT_MFMA_ROW(fb1, 0, 2, 2); PT_MFMA_ROW(fb1, 0, 2, 3); }                                \
+      if constexpr ((P) == 2) { PT_MFMA_ROW(fb1, RBQ, 2, 2); PT_MFMA_ROW(fb1, RBQ, 2, 3); }                            \
+      if constexpr ((P) == 3) { PT_MFMA_ROW(fb0, RBQ, 0, 2); PT_MFMA_ROW(fb0, RBQ, 0, 3); }                            \
     } else {                                                                                                           \
     if constexpr ((P) == 0) { PT_MFMA(fb0, 0, 0); }                                                                    \
     if constexpr ((P) == 1) { PT_MFMA(fb1, 0, 2); }                                                                    \
@@ -288,9 +348,11 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
     }                                                                                                                  \
     }                                                                                                                  \
     __builtin_amdgcn_s_setprio(0);                                                                                     \
+    PT_CLK(s_d);                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     if constexpr (CROG_PPT_PROBE != 1) __builtin_amdgcn_s_barrier();                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    PT_CARRY_E();                                                                                                      \
   } while (0)
 
   if constexpr (CROG_PPT_ILV) { PT_READ_A(0); }      // (half-tile 0 landed with the prologue's wait + barrier)
@@ -299,6 +361,12 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
     PT_PHASE(0, 1, t + 1); PT_PHASE(1, 1, t + 1); PT_PHASE(2, 1, t + 1); PT_PHASE(3, 1, t + 1);
   }
 #undef PT_PHASE
+#if CROG_PPT_STAMP
+  if (blk == 0 && lane == 0) {
+    unsigned* o = g_ppt_stamp + wave * 8;
+    o[0] = 0; o[1] = a_is; o[2] = a_vm; o[3] = a_lg; o[4] = a_b1; o[5] = a_mf; o[6] = a_b2; o[7] = a_n;
+  }
+#endif
 #undef PT_MFMA
 #undef PT_MFMA_ROW
 #undef PT_READ_A_ROW
@@ -525,6 +593,12 @@ int crog_gemm_ppt_launch(const crog_gemm_desc& d, int dist, hipStream_t s) {
   crog_set_error("crog_gemm: no ping-pong weight-gradient instantiation for dist=%d", dist);
   return CROG_ERR_ARG;
 }
+
+#if defined(CROG_PPT_STAMP) && CROG_PPT_STAMP
+extern "C" int crog_probe_ppt_stamps(unsigned* out64) {      // (probe builds only: not part of include/crog_hip.h)
+  return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ppt_stamp), sizeof(unsigned) * 64);
+}
+#endif
 
 extern "C" int crog_gemm_group(const crog_gemm_desc* descs, int n, crog_stream_t stream) {
   CROG_CHECK_ARG(descs && n >= 1 && n <= PPT_GROUP_MAX, "crog_gemm_group: 1 .. %d descriptors", PPT_GROUP_MAX);

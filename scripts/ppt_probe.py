@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from crog_amd import kernels as K
 dt = torch.bfloat16
+K.DEBUG_FLAGS = int(os.environ.get('PROBE_D', '0')) << 12      # DMA distance 3 .. 7 (0 = the default, 5)
 for B, HW, Cin, Cout in ((32, 104, 512, 256), (32, 52, 512, 512), (32, 26, 1024, 512)):
     Mpix, N = B * HW * HW, 9 * Cin
     sk = K.lib().crog_gemm_splitk_hint(K.BF16, K.A_MC, K.B_NC_IM2COL, Cout, N, Mpix)
@@ -26,4 +27,4 @@ for B, HW, Cin, Cout in ((32, 104, 512, 256), (32, 52, 512, 512), (32, 26, 1024,
     t = sorted(ts)[2]
     tiles = (Cout // 256) * (N // 256)
     ktb = (Mpix // 64 + sk - 1) // sk
-    print(f"[{os.environ.get('CROG_LIB', 'default')}] dW[{Cout} x {N}] over {Mpix} pixels, {tiles * sk} blocks x {ktb} k-tiles: {t * 1e3:8.1f} us  = {t * 1e6 / ktb:6.1f} ns per k-tile  ({2.0 * Mpix * Cout * N / t / 1e9:6.0f} TFLOP/s)", flush=True)
+    print(f"[{os.environ.get('CROG_LIB', 'default')} D={os.environ.get('PROBE_D', '-')}] dW[{Cout} x {N}] over {Mpix} pixels, {tiles * sk} blocks x {ktb} k-tiles: {t * 1e3:8.1f} us  = {t * 1e6 / ktb:6.1f} ns per k-tile  ({2.0 * Mpix * Cout * N / t / 1e9:6.0f} TFLOP/s)", flush=True)
