@@ -234,6 +234,13 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
 #ifndef CROG_PPT_DMA_MFMA
 #define CROG_PPT_DMA_MFMA 0
 #endif
+// CROG_PPT_STAGGER = 1: in the load half, two of a group's four waves issue their fill requests BEFORE their fragment reads and two after, so
+// that the CU's fill path has work from the first cycle of the half and no wave's reads queue behind all four waves' requests
+// (2: by wave pairs instead of alternating waves).  No hazard changes: the requests and the reads of one load half touch different slots.
+#ifndef CROG_PPT_STAGGER
+#define CROG_PPT_STAGGER 0
+#endif
+  const bool fills_first = CROG_PPT_STAGGER == 2 ? ((wc >> 1) & 1) != 0 : (wc & 1) != 0;
 #define PT_MFMA_ROW(FB, I0, J0, R)                                                                                     \
   _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++)                                                                     \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) mma32(fa[R][ks_], FB[c_][ks_], acc[(I0) + (R)][(J0) + c_])
@@ -265,21 +272,45 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
 #define PT_CARRY_V() do {} while (0)
 #define PT_CARRY_E() do {} while (0)
 #endif
+#define PT_LOAD_READS(P, BUF)                                                                                          \
+  do {                                                                                                                 \
+    if constexpr (CROG_PPT_PROBE != 3 && CROG_PPT_PROBE != 5 && CROG_PPT_PROBE != 7) {                                 \
+      if constexpr (CROG_PPT_ILV) {                                                                                    \
+        if constexpr ((P) == 0) { PT_READ_B(fb0, (BUF) * 4 + 1); }                                                     \
+      } else {                                                                                                         \
+        if constexpr ((P) == 0) { PT_READ_A((BUF) * 4 + 0); PT_READ_B(fb0, (BUF) * 4 + 1); }                           \
+        if constexpr ((P) == 1) { PT_READ_B(fb1, (BUF) * 4 + 2); }                                                     \
+        if constexpr ((P) == 2) { PT_READ_A((BUF) * 4 + 3); }                                                          \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+#define PT_LOAD_FILLS(P, BUF, T)                                                                                       \
+  do {                                                                                                                 \
+    if constexpr (CROG_PPT_PROBE != 2 && CROG_PPT_PROBE != 6 && CROG_PPT_PROBE != 7 && !CROG_PPT_DMA_MFMA) {           \
+      constexpr int m_ = (P) + D, j_ = m_ & 3, dt_ = m_ >> 2, buf_ = ((BUF) + dt_) & 1;                                 \
+      PT_ISSUE(j_, buf_, (T) + dt_);                                                                                   \
+    }                                                                                                                  \
+  } while (0)
 #define PT_PHASE(P, BUF, T)                                                                                            \
   do {                                                                                                                 \
     PT_CLK(s_a);                                                                                                       \
-    if constexpr (CROG_PPT_PROBE != 3 && CROG_PPT_PROBE != 5 && CROG_PPT_PROBE != 7) {                                                        \
-    if constexpr (CROG_PPT_ILV) {                                                                                      \
-      if constexpr ((P) == 0) { PT_READ_B(fb0, (BUF) * 4 + 1); }                                                       \
+    if constexpr (CROG_PPT_STAGGER == 3) {      /* (every wave: requests first - no control flow) */                   \
+      PT_LOAD_FILLS(P, BUF, T);                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      PT_LOAD_READS(P, BUF);                                                                                           \
+    } else if constexpr (CROG_PPT_STAGGER != 0) {                                                                      \
+      if (fills_first) {                                                                                               \
+        PT_LOAD_FILLS(P, BUF, T);                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        PT_LOAD_READS(P, BUF);                                                                                         \
+      } else {                                                                                                         \
+        PT_LOAD_READS(P, BUF);                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        PT_LOAD_FILLS(P, BUF, T);                                                                                      \
+      }                                                                                                                \
     } else {                                                                                                           \
-    if constexpr ((P) == 0) { PT_READ_A((BUF) * 4 + 0); PT_READ_B(fb0, (BUF) * 4 + 1); }                               \
-    if constexpr ((P) == 1) { PT_READ_B(fb1, (BUF) * 4 + 2); }                                                         \
-    if constexpr ((P) == 2) { PT_READ_A((BUF) * 4 + 3); }                                                              \
-    }                                                                                                                  \
-    }                                                                                                                  \
-    if constexpr (CROG_PPT_PROBE != 2 && CROG_PPT_PROBE != 6 && CROG_PPT_PROBE != 7 && !CROG_PPT_DMA_MFMA) {                                                        \
-      constexpr int m_ = (P) + D, j_ = m_ & 3, dt_ = m_ >> 2, buf_ = ((BUF) + dt_) & 1;                                 \
-      PT_ISSUE(j_, buf_, (T) + dt_);                                                                                   \
+      PT_LOAD_READS(P, BUF);                                                                                           \
+      PT_LOAD_FILLS(P, BUF, T);                                                                                        \
     }                                                                                                                  \
     PT_CLK(s_i);                                                                                                       \
     wait_vmcnt<2 * (D - 2 - (CROG_PPT_DMA_MFMA ? 1 : 0))>();                                                          \
@@ -361,6 +392,8 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
     PT_PHASE(0, 1, t + 1); PT_PHASE(1, 1, t + 1); PT_PHASE(2, 1, t + 1); PT_PHASE(3, 1, t + 1);
   }
 #undef PT_PHASE
+#undef PT_LOAD_READS
+#undef PT_LOAD_FILLS
 #if CROG_PPT_STAMP
   if (blk == 0 && lane == 0) {
     unsigned* o = g_ppt_stamp + wave * 8;
@@ -580,8 +613,17 @@ bool crog_gemm_ppt_eligible(const crog_gemm_desc& d) {
   return true;
 }
 
+// Default DMA distance.  Round 4 measured 5 as 4-7 % ahead of 3 / 4 / 6 - with the compiler's vmcnt(0) in front of every phase's transposed reads
+// (gemm_dma.h), i.e. with a ring that never held more than one phase of requests.  Without it depth pays stand-alone as designed: 1820 / 1647 /
+// 1599 / 1575 / 1543 ns per k-tile at distance 3 / 4 / 5 / 6 / 7 (profiles/r06_ppt_probe.txt); in the step, beside the main chain, 7 is no better
+// than 5 (26.74 / 26.69 / 26.61 against 26.55 / 26.67 / 26.49 ms, three interleaved pairs), so 5 stays.  CROG_PPT_DIST=7 overrides (A/B).
+static int ppt_default_dist() {
+  static const int v = [] { const char* e = getenv("CROG_PPT_DIST"); const int x = e ? atoi(e) : 5; return (x == 5 || x == 7) ? x : 5; }();
+  return v;
+}
+
 int crog_gemm_ppt_launch(const crog_gemm_desc& d, int dist, hipStream_t s) {
-  if (dist == 0) dist = 5;      // scripts/ab_ppt.py: 5 is 4-7 % ahead of 3 / 4 / 6 on the large 3x3 forms, equal on the linear ones
+  if (dist == 0) dist = ppt_default_dist();
   const bool conv = d.b_layout == CROG_B_NC_IM2COL, slab = d.out_mode == CROG_OUT_F32;
 #define PT_CASE(DD)                                                                                                    \
   if (dist == (DD)) {                                                                                                  \
@@ -595,7 +637,7 @@ int crog_gemm_ppt_launch(const crog_gemm_desc& d, int dist, hipStream_t s) {
 }
 
 #if defined(CROG_PPT_STAMP) && CROG_PPT_STAMP
-extern "C" int crog_probe_ppt_stamps(unsigned* out64) {      // (probe builds only: not part of include/crog_hip.h)
+extern "C" int ppt_probe_stamps(unsigned* out64) {      // (probe builds only: not part of include/crog_hip.h)
   return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ppt_stamp), sizeof(unsigned) * 64);
 }
 #endif
@@ -638,8 +680,10 @@ extern "C" int crog_gemm_group(const crog_gemm_desc* descs, int n, crog_stream_t
 #else
   constexpr int LDS = 8 * 16384;
 #endif
-  static bool attr_set = false;
-  auto kern = gemm_ppt_group_kernel<5>;
+  static bool attr_set5 = false, attr_set7 = false;
+  const bool d7 = ppt_default_dist() == 7;
+  auto kern = d7 ? gemm_ppt_group_kernel<7> : gemm_ppt_group_kernel<5>;
+  bool& attr_set = d7 ? attr_set7 : attr_set5;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {

@@ -28,7 +28,7 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record(); run(); e.record(); torch.cuda.synchronize()
 tiles = (Cout // 256) * (N // 256); ktb = (Mpix // 64 + sk - 1) // sk
 print(f"{'dense' if dense else '3x3'} dW[{Cout} x {N}] over {Mpix}: {tiles * sk} blocks x {ktb} k-tiles, {s.elapsed_time(e) * 1e3:.1f} us = {s.elapsed_time(e) * 1e6 / ktb:.0f} ns per k-tile")
-fn = getattr(K.lib(), "crog_probe_ppt_stamps", None)
+fn = getattr(K.lib(), "ppt_probe_stamps", None)
 if fn is None:
     sys.exit("this library has no stamps (build with -DCROG_PPT_STAMP=1)")
 out = (ctypes.c_uint * 64)()
