@@ -1773,7 +1773,7 @@ inline bool small_wgrad(int a_layout, int b_layout, int out_mode, long M, long N
 
 // Large weight gradients (both output sides multiples of 256, a reduction of >= 8192) on the 256 x 256 tile with the atomic-only
 // epilogue (round 3): half the L2 -> LDS bytes and half the LDS fragment reads per MFMA of the 128 x 128 tile, which is what bounds a
-// weight gradient (both operands are read transposed out of LDS).  One 8-wave block owns a CU, so a launch is kept to ~144 blocks (112 since round 6, below): the
+// weight gradient (both operands are read transposed out of LDS).  One 8-wave block owns a CU, so a launch is kept to ~144 blocks: the
 // side stream works a little over half of the chip at the better per-CU rate and leaves the rest to the main stream.  Measured in the
 // step (interleaved runs of 60 steps, finite losses checked): 3x3 forms from 512 K outputs 32.55-33.03 ms against 33.2-33.6 on
 // 128 x 128 tiles, and the roofline kernel next to them 573-580 instead of 528-537 TFLOP/s; adding the 1x1 / linear forms from 1 M
@@ -1781,9 +1781,12 @@ inline bool small_wgrad(int a_layout, int b_layout, int out_mode, long M, long N
 // whose four tiles need 21 splits).  Block targets of 80 / 96 / 112 help the neighbour more (617-629 TFLOP/s) and the step less,
 // 176-208 lose: 144.  (A first measurement of 31.8-32.2 ms for the 256 K variant was of a step whose text tower had gone NaN - an
 // unordered workspace, fixed - and NaN operands let the chip hold a higher clock: bench.py now refuses non-finite statistics.)
-// Round 6, after the LDS-DMA requests became inline assembly (gemm_dma.h: the kernel is 18 % faster per block): 112 blocks - 26.43-26.67 ms per
-// step against 26.55-27.13 with 144 in eleven interleaved pairs on three boxes (profiles/r06_ab_wgrad_blocks.txt); 80 / 96 / 128 / 176 do not beat 144.
-static const long WGRAD256_BLOCKS = [] { const char* e = getenv("CROG_WGRAD_BLOCKS"); return e ? atol(e) : 112L; }();      // (the environment override is for scripts/ A-B runs)
+// Round 6, after the LDS-DMA requests became inline assembly (gemm_dma.h: a block is 18 % faster): 112 blocks are 0.1-0.4 ms ahead of 144 in the
+// step (26.45-26.56 against 26.52-26.71 ms, six interleaved pairs; profiles/r06_ab_wgrad_blocks.txt) but read the operands TWICE: 18 tiles x 6
+// slices are 13.5 blocks per XCD, every reduction slice lands in two or three L2s (PMC: 1149 MB fetched per launch for 531 MB of operands; with
+// 8 slices = one per XCD: 1.0 x).  Whole slices on 6 of the 8 XCDs (CROG_PPT_XCDS=1, gemm_ppt.hip) fetch 1.00 x and LOSE 0.5 ms - the main
+// chain's blocks on the six busy XCDs become the stragglers.  144 stays: one slice per XCD, and 0.4 % is inside the spread between boxes.
+static const long WGRAD256_BLOCKS = [] { const char* e = getenv("CROG_WGRAD_BLOCKS"); return e ? atol(e) : 144L; }();      // (the environment override is for scripts/ A-B runs)
 inline bool big_wgrad(int dtype, int a_layout, int b_layout, int out_mode, long M, long N, long K) {
   if (dtype != CROG_BF16 || out_mode != CROG_OUT_F32_ATOMIC || a_layout != CROG_A_MC) return false;
   if (M % 256 != 0 || N % 256 != 0 || K < 8192) return false;

@@ -66,7 +66,29 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
   const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
   const int nwg = tilesM * tilesN;
   int id = blk, z = 0;
-  xcd_map(nwg, p.splitk, id, z);          // (reduction slice, tile) runs per XCD: an operand slice lands in one L2
+  bool whole = false;
+  if constexpr (std::is_same<P, crog_gemm_desc>::value) {
+    // WHOLE reduction slices per XCD (launch_ppt sets bit 30 and sizes the grid to 8 x blocks-per-XCD): with S <= 8 slices, 8 / S XCDs share one slice
+    // and S * (8 / S) XCDs work - the others' blocks leave at once, i.e. those XCDs and their L2s stay with the main chain; with S > 8, ceil(S / 8)
+    // slices per XCD.  An operand slice is then fetched into 8 / S L2s (one for S >= 5) instead of the two or three that a cut of the slice-major
+    // work list into eight equal runs touches when S is not a multiple of 8 (xcd_map below: 6 slices x 18 tiles = 13.5 blocks per XCD).
+    if (p.debug & (1 << 30)) {
+      const int S = p.splitk, xcd = blk & 7, loc = blk >> 3;
+      if (S <= 8) {
+        const int c = 8 / S, per = (nwg + c - 1) / c;
+        z = xcd / c;
+        id = (xcd - z * c) * per + loc;
+        if (xcd >= S * c || id >= nwg) return;
+      } else {
+        const int spx = (S + 7) >> 3;
+        z = xcd * spx + loc / nwg;
+        id = loc % nwg;
+        if (z >= S) return;
+      }
+      whole = true;
+    }
+  }
+  if (!whole) xcd_map(nwg, p.splitk, id, z);          // (reduction slice, tile) runs per XCD: an operand slice lands in one L2
   const int tm = id / tilesN, tn = id - tm * tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
   const bf16* A = reinterpret_cast<const bf16*>(p.A);
@@ -525,8 +547,17 @@ int launch_ppt(const crog_gemm_desc& d, hipStream_t s) {
     }
     attr_set = true;
   }
-  dim3 grid(cdiv(d.M, 256) * cdiv(d.N, 256) * d.splitk, 1, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(512), LDS, s, d);
+  const int nwg = cdiv(d.M, 256) * cdiv(d.N, 256);
+  dim3 grid(nwg * d.splitk, 1, 1);
+  // CROG_PPT_XCDS=1: whole reduction slices per XCD (ppt_body); 0: the slice-major list cut into eight equal runs
+  static const bool whole = [] { const char* e = getenv("CROG_PPT_XCDS"); return e && atoi(e) != 0; }();
+  crog_gemm_desc dd = d;
+  if (whole && d.splitk > 1) {
+    dd.debug |= 1 << 30;
+    const int S = d.splitk;
+    grid.x = S <= 8 ? 8 * cdiv(nwg, 8 / S) : 8 * cdiv(S, 8) * nwg;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), LDS, s, dd);
   CROG_LAUNCH_CHECK();
   return CROG_OK;
 }
