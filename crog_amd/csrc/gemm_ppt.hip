@@ -21,10 +21,6 @@
 
 namespace {
 
-#if defined(CROG_PPT_STAMP) && CROG_PPT_STAMP
-__device__ unsigned g_ppt_stamp[64];      // [wave][reads, requests, vmcnt, lgkmcnt, barrier 1, MFMAs, barrier 2, phases] of block 0 (see PT_CLK)
-#endif
-
 __device__ __attribute__((always_inline)) inline bf16x8 tr_frag(const char* lo, const char* hi) {
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
   const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)lo);
@@ -58,11 +54,7 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#if defined(CROG_PPT_WAVE_MAP) && CROG_PPT_WAVE_MAP == 1     // (A/B: neighbouring waves in different groups, for a wave w on SIMD w >> 1)
-  const int wr = wave & 1, wc = wave >> 1;
-#else
-  const int wr = wave >> 2, wc = wave & 3;
-#endif
+  const int wr = wave >> 2, wc = wave & 3;      // (waves w and w + 4 share a SIMD: scripts/simd_map.hip)
   const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
   const int nwg = tilesM * tilesN;
   int id = blk, z = 0;
@@ -256,44 +248,12 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
 #ifndef CROG_PPT_DMA_MFMA
 #define CROG_PPT_DMA_MFMA 0
 #endif
-// CROG_PPT_STAGGER = 1: in the load half, two of a group's four waves issue their fill requests BEFORE their fragment reads and two after, so
-// that the CU's fill path has work from the first cycle of the half and no wave's reads queue behind all four waves' requests
-// (2: by wave pairs instead of alternating waves).  No hazard changes: the requests and the reads of one load half touch different slots.
-#ifndef CROG_PPT_STAGGER
-#define CROG_PPT_STAGGER 0
-#endif
-  const bool fills_first = CROG_PPT_STAGGER == 2 ? ((wc >> 1) & 1) != 0 : (wc & 1) != 0;
 #define PT_MFMA_ROW(FB, I0, J0, R)                                                                                     \
   _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++)                                                                     \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) mma32(fa[R][ks_], FB[c_][ks_], acc[(I0) + (R)][(J0) + c_])
 #define PT_READ_A_ROW(SLOTIDX, R)                                                                                      \
   _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++)                                                                  \
     fa[R][ks_] = tr_frag(smem + (SLOTIDX) * SLOT + ks_ * 8192 + aad[0][R], smem + (SLOTIDX) * SLOT + ks_ * 8192 + aad[1][R])
-// CROG_PPT_STAMP = 1 (scripts/build_variant.py pptstamp -DCROG_PPT_STAMP=1, scripts/ppt_stamps.py): every wave of block 0 adds up, over its
-// phases, the s_memtime distances between the points of a phase - reads + requests issued, vmcnt wait, lgkmcnt wait, first barrier, MFMAs
-// issued, second barrier.  A stamp is read one phase later, behind that phase's own lgkmcnt(0), so that no wait is added for it.
-#ifndef CROG_PPT_STAMP
-#define CROG_PPT_STAMP 0
-#endif
-#if CROG_PPT_STAMP
-#define PT_CLK(V) do { __builtin_amdgcn_sched_barrier(0); V = (unsigned)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
-  unsigned s_a, s_i = 0, s_v = 0, s_b, s_c, s_d, p_v, p_b, p_c, p_d;
-  unsigned a_is = 0, a_vm = 0, a_lg = 0, a_b1 = 0, a_mf = 0, a_b2 = 0, a_n = 0;
-  PT_CLK(s_a);
-  s_b = s_c = s_d = p_v = p_b = p_c = p_d = s_a;      // (the first phase's "previous phase" terms are a few cycles of nothing)
-#define PT_FLUSH()                                                                                                     \
-  do {                                                                                                                 \
-    a_lg += p_b - p_v; a_b1 += p_c - p_b; a_mf += p_d - p_c; a_b2 += s_a - p_d;                                         \
-    a_is += s_i - s_a; a_vm += s_v - s_i; a_n++;                                                                       \
-  } while (0)
-#define PT_CARRY_V() do { p_v = s_v; } while (0)
-#define PT_CARRY_E() do { p_b = s_b; p_c = s_c; p_d = s_d; } while (0)
-#else
-#define PT_CLK(V) do {} while (0)
-#define PT_FLUSH() do {} while (0)
-#define PT_CARRY_V() do {} while (0)
-#define PT_CARRY_E() do {} while (0)
-#endif
 #define PT_LOAD_READS(P, BUF)                                                                                          \
   do {                                                                                                                 \
     if constexpr (CROG_PPT_PROBE != 3 && CROG_PPT_PROBE != 5 && CROG_PPT_PROBE != 7) {                                 \
@@ -315,36 +275,13 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
   } while (0)
 #define PT_PHASE(P, BUF, T)                                                                                            \
   do {                                                                                                                 \
-    PT_CLK(s_a);                                                                                                       \
-    if constexpr (CROG_PPT_STAGGER == 3) {      /* (every wave: requests first - no control flow) */                   \
-      PT_LOAD_FILLS(P, BUF, T);                                                                                        \
-      __builtin_amdgcn_sched_barrier(0);                                                                               \
-      PT_LOAD_READS(P, BUF);                                                                                           \
-    } else if constexpr (CROG_PPT_STAGGER != 0) {                                                                      \
-      if (fills_first) {                                                                                               \
-        PT_LOAD_FILLS(P, BUF, T);                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        PT_LOAD_READS(P, BUF);                                                                                         \
-      } else {                                                                                                         \
-        PT_LOAD_READS(P, BUF);                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        PT_LOAD_FILLS(P, BUF, T);                                                                                      \
-      }                                                                                                                \
-    } else {                                                                                                           \
-      PT_LOAD_READS(P, BUF);                                                                                           \
-      PT_LOAD_FILLS(P, BUF, T);                                                                                        \
-    }                                                                                                                  \
-    PT_CLK(s_i);                                                                                                       \
+    PT_LOAD_READS(P, BUF);                                                                                             \
+    PT_LOAD_FILLS(P, BUF, T);                                                                                          \
     wait_vmcnt<2 * (D - 2 - (CROG_PPT_DMA_MFMA ? 1 : 0))>();                                                          \
-    PT_CLK(s_v);                                                                                                       \
     if constexpr (!(CROG_PPT_LGKM_LATE && D <= 6)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              \
-    PT_FLUSH();                                                                                                        \
-    PT_CARRY_V();                                                                                                      \
-    PT_CLK(s_b);                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_barrier();                                                                                      \
     if constexpr (CROG_PPT_LGKM_LATE && D <= 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
-    PT_CLK(s_c);                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                     \
     if constexpr (CROG_PPT_PROBE != 4 && CROG_PPT_PROBE != 5 && CROG_PPT_PROBE != 6) {                                 \
@@ -401,11 +338,9 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
     }                                                                                                                  \
     }                                                                                                                  \
     __builtin_amdgcn_s_setprio(0);                                                                                     \
-    PT_CLK(s_d);                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     if constexpr (CROG_PPT_PROBE != 1) __builtin_amdgcn_s_barrier();                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    PT_CARRY_E();                                                                                                      \
   } while (0)
 
   if constexpr (CROG_PPT_ILV) { PT_READ_A(0); }      // (half-tile 0 landed with the prologue's wait + barrier)
@@ -416,12 +351,6 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
 #undef PT_PHASE
 #undef PT_LOAD_READS
 #undef PT_LOAD_FILLS
-#if CROG_PPT_STAMP
-  if (blk == 0 && lane == 0) {
-    unsigned* o = g_ppt_stamp + wave * 8;
-    o[0] = 0; o[1] = a_is; o[2] = a_vm; o[3] = a_lg; o[4] = a_b1; o[5] = a_mf; o[6] = a_b2; o[7] = a_n;
-  }
-#endif
 #undef PT_MFMA
 #undef PT_MFMA_ROW
 #undef PT_READ_A_ROW
@@ -666,12 +595,6 @@ int crog_gemm_ppt_launch(const crog_gemm_desc& d, int dist, hipStream_t s) {
   crog_set_error("crog_gemm: no ping-pong weight-gradient instantiation for dist=%d", dist);
   return CROG_ERR_ARG;
 }
-
-#if defined(CROG_PPT_STAMP) && CROG_PPT_STAMP
-extern "C" int ppt_probe_stamps(unsigned* out64) {      // (probe builds only: not part of include/crog_hip.h)
-  return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ppt_stamp), sizeof(unsigned) * 64);
-}
-#endif
 
 extern "C" int crog_gemm_group(const crog_gemm_desc* descs, int n, crog_stream_t stream) {
   CROG_CHECK_ARG(descs && n >= 1 && n <= PPT_GROUP_MAX, "crog_gemm_group: 1 .. %d descriptors", PPT_GROUP_MAX);
