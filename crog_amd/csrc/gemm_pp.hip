@@ -138,7 +138,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
   };
   // the two requests of half-tile type J of k-tile TI into buffer BUF (J, BUF compile-time).  `live` enters as a mask, not as a
   // branch (a block-uniform branch around a request splits the loop body)
-#define PP_ISSUE(J, BUF, TI)                                                                                           \
+#define PP_ISSUE(J, BUF, TI) PP_ISSUE_RANGE(J, BUF, TI, 0, 2)
+#define PP_ISSUE_RANGE(J, BUF, TI, I0, I1)                                                                             \
   do {                                                                                                                 \
     const int ti_ = (TI);                                                                                              \
     const bool lv_ = ti_ < nt;                                                                                         \
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
     char* dst_ = smem + ((BUF) * 4 + (J)) * SLOT + wave * 2048;                                                        \
     if constexpr ((J) == 0 || (J) == 3) {                                                                              \
       constexpr int h_ = (J) == 3 ? 1 : 0;                                                                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                                               \
+      _Pragma("unroll") for (int i_ = (I0); i_ < (I1); i_++) {                                                         \
         bool ok_;                                                                                                      \
         if constexpr (AL == CROG_A_IM2COL) ok_ = ((amask[i_][h_] & (lv_ ? ~0u : 0u)) >> tap_) & 1u;                     \
         else ok_ = lv_;                                                                                                \
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
       }                                                                                                                \
     } else {                                                                                                           \
       constexpr int h_ = (J) == 2 ? 1 : 0;                                                                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++)                                                                 \
+      _Pragma("unroll") for (int i_ = (I0); i_ < (I1); i_++)                                                           \
         dma_piece(B, exb, dst_ + i_ * 1024, lv_ ? bbase[i_] + (h_ ? b_h1 : 0u) + kb_ : DMA_OOB);                        \
     }                                                                                                                  \
   } while (0)
@@ -190,6 +191,17 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
 #define CROG_PP_LGKM_LATE 0
 #endif
   constexpr bool LGKM_LATE = CROG_PP_LGKM_LATE != 0 && D <= 6;
+  // CROG_PP_SPLIT_DMA = 1: the second of a phase's two requests is issued by the wave in its MFMA half (after half of its MFMAs) instead of in the
+  // load half - the CU's fill path then has a request from each group in every barrier-to-barrier segment, and a load half queues behind 4 KiB of its
+  // group's requests instead of 8 (gemm_ppt.hip: + 7 % there).  The wait in the load half then covers one request less: vmcnt(2 (D - 2) - 1).
+#ifndef CROG_PP_SPLIT_DMA
+#define CROG_PP_SPLIT_DMA 0
+#endif
+  constexpr bool SPLIT_DMA = CROG_PP_SPLIT_DMA != 0;
+#define PP_MFMA_ROWS(FB, I0, J0, R0, R1)                                                                               \
+  _Pragma("unroll") for (int r_ = (R0); r_ < (R1); r_++)                                                               \
+    _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++)                                                                   \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ks_++) mma32(fa[r_][ks_], FB[c_][ks_], acc[(I0) + r_][(J0) + c_])
   // one phase: P = 0 .. 3, BUF = buffer of k-tile T (compile-time), T = k-tile index
 #define PP_PHASE(P, BUF, T)                                                                                            \
   do {                                                                                                                 \
@@ -198,19 +210,36 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
     if constexpr ((P) == 2) { PP_READ_A((BUF) * 4 + 3); }                                                              \
     {                                                                                                                  \
       constexpr int m_ = (P) + D, j_ = m_ & 3, dt_ = m_ >> 2, buf_ = ((BUF) + dt_) & 1;                                 \
-      PP_ISSUE(j_, buf_, (T) + dt_);                                                                                   \
+      PP_ISSUE_RANGE(j_, buf_, (T) + dt_, 0, SPLIT_DMA ? 1 : 2);                                                       \
     }                                                                                                                  \
-    wait_vmcnt<2 * (D - 2)>();                                                                                         \
+    wait_vmcnt<2 * (D - 2) - (SPLIT_DMA ? 1 : 0)>();                                                                   \
     if constexpr (!LGKM_LATE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_barrier();                                                                                      \
     if constexpr (LGKM_LATE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                     \
+    if constexpr (SPLIT_DMA) {                                                                                         \
+      if constexpr ((P) == 0) { PP_MFMA_ROWS(fb0, 0, 0, 0, RBQ / 2); }                                                 \
+      if constexpr ((P) == 1) { PP_MFMA_ROWS(fb1, 0, 2, 0, RBQ / 2); }                                                 \
+      if constexpr ((P) == 2) { PP_MFMA_ROWS(fb1, RBQ, 2, 0, RBQ / 2); }                                               \
+      if constexpr ((P) == 3) { PP_MFMA_ROWS(fb0, RBQ, 0, 0, RBQ / 2); }                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      {                                                                                                                \
+        constexpr int m_ = (P) + D, j_ = m_ & 3, dt_ = m_ >> 2, buf_ = ((BUF) + dt_) & 1;                               \
+        PP_ISSUE_RANGE(j_, buf_, (T) + dt_, 1, 2);                                                                     \
+      }                                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+      if constexpr ((P) == 0) { PP_MFMA_ROWS(fb0, 0, 0, RBQ / 2, RBQ); }                                               \
+      if constexpr ((P) == 1) { PP_MFMA_ROWS(fb1, 0, 2, RBQ / 2, RBQ); }                                               \
+      if constexpr ((P) == 2) { PP_MFMA_ROWS(fb1, RBQ, 2, RBQ / 2, RBQ); }                                             \
+      if constexpr ((P) == 3) { PP_MFMA_ROWS(fb0, RBQ, 0, RBQ / 2, RBQ); }                                             \
+    } else {                                                                                                           \
     if constexpr ((P) == 0) { PP_MFMA(fb0, 0, 0); }                                                                    \
     if constexpr ((P) == 1) { PP_MFMA(fb1, 0, 2); }                                                                    \
     if constexpr ((P) == 2) { PP_MFMA(fb1, RBQ, 2); }                                                                  \
     if constexpr ((P) == 3) { PP_MFMA(fb0, RBQ, 0); }                                                                  \
+    }                                                                                                                  \
     __builtin_amdgcn_s_setprio(0);                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_barrier();                                                                                      \
@@ -226,6 +255,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const crog_gemm_desc p)
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_ISSUE
+#undef PP_ISSUE_RANGE
+#undef PP_MFMA_ROWS
   if (wr == 0) __builtin_amdgcn_s_barrier();      // the leading group waits for the lagging one (equal barrier counts)
   // the trailing out-of-range requests write zeros into the ring and the epilogue reuses it: every wave's requests must have landed
   wait_vmcnt<0>();

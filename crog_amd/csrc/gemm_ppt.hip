@@ -155,7 +155,8 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
 
   // the two requests of half-tile type J (0: A-h0, 1: B-h0, 2: B-h1, 3: A-h1) of k-tile TI into buffer BUF.  k-tiles are requested
   // strictly in order, so the 3x3 form advances its image coordinates after the B-h1 request of every k-tile.
-#define PT_ISSUE(J, BUF, TI)                                                                                           \
+#define PT_ISSUE(J, BUF, TI) PT_ISSUE_RANGE(J, BUF, TI, 0, 2)
+#define PT_ISSUE_RANGE(J, BUF, TI, I0, I1)                                                                             \
   do {                                                                                                                 \
     const int ti_ = (TI);                                                                                              \
     const bool lv_ = ti_ < nt;                                                                                         \
@@ -163,14 +164,14 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
     if constexpr ((J) == 0 || (J) == 3) {                                                                              \
       constexpr int h_ = (J) == 3 ? 1 : 0;                                                                             \
       const unsigned kk_ = (unsigned)(ti_ * BK) * ldab + (h_ ? 256u : 0u);                                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                                               \
+      _Pragma("unroll") for (int i_ = (I0); i_ < (I1); i_++) {                                                         \
         const bool ok_ = lv_ & (((avalid >> (2 * i_ + h_)) & 1u) != 0);                                                \
         dma_piece(A, exa, dst_ + i_ * 1024, ok_ ? abase[i_] + kk_ : DMA_OOB);                                          \
       }                                                                                                                \
     } else {                                                                                                           \
       constexpr int h_ = (J) == 2 ? 1 : 0;                                                                             \
       const unsigned kk_ = (unsigned)(ti_ * BK) * ldbb;                                                                \
-      _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                                               \
+      _Pragma("unroll") for (int i_ = (I0); i_ < (I1); i_++) {                                                         \
         bool ok_ = lv_ & (((bvalid >> (2 * i_ + h_)) & 1u) != 0);                                                      \
         unsigned off_;                                                                                                 \
         if constexpr (BL == CROG_B_NC_IM2COL) {                                                                        \
@@ -184,7 +185,7 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
         }                                                                                                              \
         dma_piece(B, exb, dst_ + i_ * 1024, ok_ ? off_ : DMA_OOB);                                                     \
       }                                                                                                                \
-      if constexpr (BL == CROG_B_NC_IM2COL && (J) == 2) {                                                              \
+      if constexpr (BL == CROG_B_NC_IM2COL && (J) == 2 && (I1) == 2) {                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                                             \
           int x_ = px[i_] + stepx, y_ = py[i_] + stepy;                                                                \
           const bool wrap_ = x_ >= W;                                                                                  \
@@ -239,14 +240,17 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
 #ifndef CROG_PPT_ILV
 #define CROG_PPT_ILV 0
 #endif
-// CROG_PPT_DMA_MFMA = 1: the two LDS-DMA requests of a phase are issued by the wave that is in its MFMA half (between its 8th and 9th MFMA)
-// instead of opening the load half behind the fragment reads.  Stamps (scripts/ppt_stamps.py) show why: a load half is ~430 cycles of ISSUE -
-// the reads, then the requests queued behind the CU's fill path (8 KiB per group and phase at 32 B/clk = 256 cycles) - against 256 cycles of MFMAs
-// on the partner wave, and the fill path idles while the reads are issued.  Hazards: the requests of phase ph now follow that phase's first
-// barrier, so the wait in the load half covers one half-tile less - vmcnt(2 (D - 3)) for the same guarantee (half-tiles <= ph + 2 landed) -
-// and the refill of a slot moves later, never earlier (legal up to D = 7).
+// CROG_PPT_DMA_MFMA: where a phase's two LDS-DMA requests are issued.  0: both in the load half, behind the fragment reads (rounds 4-5, and the
+// forward kernel's order).  1: both by the wave in its MFMA half (between its 8th and 9th MFMA).  **2 (default, round 6)**: one in the load half, the
+// other in the MFMA half.  A load half is in-order ISSUE on one wave - 12 transposed reads on average, then requests that queue behind its group's
+// 8 KiB on the CU's fill path (32 B/clk = 256 cycles) - against 256 cycles of MFMAs on the partner wave; with one request per half the fill path has
+// work from both groups in every barrier-to-barrier segment and a load half queues behind 4 KiB: 1601 / 1633 / 1744 -> 1492 / 1527 / 1632 ns per
+// k-tile (754 -> 810 TFLOP/s on 144 CUs; 1: 1603 - no gain; the forward kernel, whose load half has a third of the reads, LOSES 2-3 % with the same
+// split: gemm_pp.hip CROG_PP_SPLIT_DMA).  Hazards: a request issued in the MFMA half of phase ph follows that phase's first barrier, so the wait in
+// the load half covers one request less per moved request - vmcnt(2 (D - 2) - 1) for 2, vmcnt(2 (D - 3)) for 1, for the same guarantee
+// (half-tiles <= ph + 2 landed) - and the refill of a slot moves later, never earlier (legal up to D = 7).
 #ifndef CROG_PPT_DMA_MFMA
-#define CROG_PPT_DMA_MFMA 0
+#define CROG_PPT_DMA_MFMA 2
 #endif
 #define PT_MFMA_ROW(FB, I0, J0, R)                                                                                     \
   _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++)                                                                     \
@@ -268,16 +272,16 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
   } while (0)
 #define PT_LOAD_FILLS(P, BUF, T)                                                                                       \
   do {                                                                                                                 \
-    if constexpr (CROG_PPT_PROBE != 2 && CROG_PPT_PROBE != 6 && CROG_PPT_PROBE != 7 && !CROG_PPT_DMA_MFMA) {           \
+    if constexpr (CROG_PPT_PROBE != 2 && CROG_PPT_PROBE != 6 && CROG_PPT_PROBE != 7 && CROG_PPT_DMA_MFMA != 1) {       \
       constexpr int m_ = (P) + D, j_ = m_ & 3, dt_ = m_ >> 2, buf_ = ((BUF) + dt_) & 1;                                 \
-      PT_ISSUE(j_, buf_, (T) + dt_);                                                                                   \
+      PT_ISSUE_RANGE(j_, buf_, (T) + dt_, 0, CROG_PPT_DMA_MFMA == 2 ? 1 : 2);                                          \
     }                                                                                                                  \
   } while (0)
 #define PT_PHASE(P, BUF, T)                                                                                            \
   do {                                                                                                                 \
     PT_LOAD_READS(P, BUF);                                                                                             \
     PT_LOAD_FILLS(P, BUF, T);                                                                                          \
-    wait_vmcnt<2 * (D - 2 - (CROG_PPT_DMA_MFMA ? 1 : 0))>();                                                          \
+    wait_vmcnt<2 * (D - 2 - (CROG_PPT_DMA_MFMA ? 1 : 0)) + (CROG_PPT_DMA_MFMA == 2 ? 1 : 0)>();                                                          \
     if constexpr (!(CROG_PPT_LGKM_LATE && D <= 6)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     __builtin_amdgcn_s_barrier();                                                                                      \
@@ -323,7 +327,7 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
       __builtin_amdgcn_sched_barrier(0);                                                                               \
       {                                                                                                                \
         constexpr int m_ = (P) + D, j_ = m_ & 3, dt_ = m_ >> 2, buf_ = ((BUF) + dt_) & 1;                               \
-        PT_ISSUE(j_, buf_, (T) + dt_);                                                                                 \
+        PT_ISSUE_RANGE(j_, buf_, (T) + dt_, CROG_PPT_DMA_MFMA == 2 ? 1 : 0, 2);                                        \
       }                                                                                                                \
       __builtin_amdgcn_sched_barrier(0);                                                                               \
       if constexpr ((P) == 0) { PT_MFMA_ROW(fb0, 0, 0, 2); PT_MFMA_ROW(fb0, 0, 0, 3); }                                \
@@ -357,6 +361,7 @@ __device__ __attribute__((always_inline)) inline void ppt_body(const P& p, const
 #undef PT_READ_A
 #undef PT_READ_B
 #undef PT_ISSUE
+#undef PT_ISSUE_RANGE
   if (wr == 0) __builtin_amdgcn_s_barrier();      // equal barrier counts for both groups
   wait_vmcnt<0>();
 
