@@ -348,7 +348,7 @@ BN_BWD_FUSED = True   # BnLink fusion on (bf16, atomic statistics path); tests c
 # adds 5-7 us to a 21632- / 86528-row data gradient and saves a 16-23 us first pass; on the 346112-row layers of layer1 it costs what it
 # saves (+17 us vs 19-21 us: bn_bwd_partial streams at 4.2 TB/s, the epilogue gathers z in 4-byte pieces and its atomics collide on 64
 # columns), and on the 1.38 M-row stem it LOSES 13-19 us.
-BN_BWD_FUSED_MAX_ROWS = 131072
+BN_BWD_FUSED_MAX_ROWS = int(os.environ.get("CROG_BN_BWD_FUSED_MAX_ROWS", "131072"))
 # The same between two Bottlenecks (a BnLink as `res_out` of block b-1's conv3 / bn3 layer and `res_in` of block b's conv1): the gradient
 # of out_{b-1} = relu(bn3(z) + identity) is conv1's data gradient plus block b's identity gradient, both already joined in that GEMM
 # (R) - its epilogue also gates the sum with the forward's bit mask and accumulates (sum g, sum g*z): block b-1 skips bn3's first
