@@ -481,6 +481,47 @@ def test_ping_pong_weight_gradient_kernel(K, monkeypatch, case):
     monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
 
 
+@pytest.mark.parametrize("kind", ["ppt_conv3", "ppt_dense", "tile128"])
+def test_transposed_operand_kernels_keep_their_bits_beside_a_bandwidth_hungry_neighbour(K, monkeypatch, kind):
+    """The LDS-DMA request is inline assembly (csrc/gemm_dma.h): the compiler no longer drains the ring in front of the transposed LDS reads, so the
+    counted vmcnt / barrier pairs of the schedules are the ONLY thing between a fill and the read of its slot.  A missing wait shows when fills
+    land late: split-K slabs (plain stores, one deterministic result) of production-size weight gradients, alone and 12 times beside a second
+    stream that streams 1 GiB copies through HBM, must be the same bits every time."""
+    dt = torch.bfloat16
+    if kind == "ppt_conv3":
+        (B, H, W), Cin, Cout, conv3, flag = (8, 52, 52), 256, 256, True, 32768
+    elif kind == "ppt_dense":
+        (B, H, W), Cin, Cout, conv3, flag = (8, 52, 52), 1024, 512, False, 32768
+    else:      # the 128 x 128 tile of gemm_dma_kernel<A_MC, B_NC>: the ping-pong kernel switched off (debug bit 16)
+        (B, H, W), Cin, Cout, conv3, flag = (8, 52, 52), 256, 128, False, 65536
+    Mpix = B * H * W
+    N = 9 * Cin if conv3 else Cin
+    x = rnd(Mpix, Cin, dt=dt)
+    dy = (rnd(Mpix, Cout, dt=dt, seed=1) * 0.1).to(dt)
+    sk = 8
+    monkeypatch.setattr(K, "DEBUG_FLAGS", flag)
+
+    def run():
+        ws = torch.full((sk, Cout, N), float("nan"), device="cuda")
+        K.gemm(1, K.A_MC, K.B_NC_IM2COL if conv3 else K.B_NC, dy, x, ws, Cout, N, Mpix, Cout, Cin, N, splitk=sk, out_mode=K.OUT_F32,
+               conv=(H, W, Cin) if conv3 else (0, 0, 0))
+        return ws
+
+    ref = run()
+    torch.cuda.synchronize()
+    assert not torch.isnan(ref).any()
+    side = torch.cuda.Stream()
+    a, b = torch.empty(1 << 28, device="cuda"), torch.empty(1 << 28, device="cuda")
+    for i in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                b.copy_(a)
+        got = run()
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), f"{kind}: run {i} beside the copies differs from the run alone"
+    monkeypatch.setattr(K, "DEBUG_FLAGS", 0)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("shape", [(2, 13, 64, 72, 3, 64, True), (3, 10, 32, 40, 1, 32, True), (2, 9, 27, 64, 3, 32, False), (2, 12, 64, 64, 1, 64, False)])
 def test_eval_batchnorm_folded_into_the_convolution(K, dt, shape):
